@@ -1,0 +1,20 @@
+"""darsia_amd -- MI355X-native implementation of DarSIA's dense image hot path.
+
+Flat namespace like ``darsia`` itself: ``darsia_amd.TVD``, ``tvd``,
+``split_bregman_tvd``, ``Jacobi``, ``Solver``, ``H1_regularization``,
+``backward_diff`` ... with the reference's names, arguments and error
+behaviour.  All arithmetic runs in ``libdarsia_hip.so`` (hand-written HIP for
+gfx950); there is no CPU fallback.
+"""
+from ._lib import HipError, device_count  # noqa: F401
+from .image import Image  # noqa: F401
+from .utils.array_slice import array_slice, array_slice_argument  # noqa: F401
+from .utils.dtype import convert_dtype  # noqa: F401
+from .utils.derivatives import backward_diff, forward_diff, laplace  # noqa: F401
+from .utils.linear_solvers.solver import Solver  # noqa: F401
+from .utils.linear_solvers.jacobi import Jacobi  # noqa: F401
+from .restoration.split_bregman_tvd import DeviceTVD, split_bregman_tvd  # noqa: F401
+from .restoration.h1_regularization import H1_regularization  # noqa: F401
+from .restoration.tvd import TVD, tvd  # noqa: F401
+
+__version__ = "0.1.0"

@@ -1,0 +1,145 @@
+"""ctypes binding of ``libdarsia_hip.so`` (C ABI: ``include/darsia_hip.h``).
+
+There is NO CPU fallback: if the library is missing, or no MI355X is visible,
+every operator raises.  The library is built in-tree by
+``darsia_amd/csrc/build.sh`` (or ``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdarsia_hip.so")
+
+DXH_F32, DXH_F64 = 0, 1
+NSUM_ALL_AXES, NSUM_SPATIAL = 0, 1
+FLAG_ISOTROPIC, FLAG_NO_FUSED, FLAG_NO_DPP = 1, 2, 4
+
+# every symbol include/darsia_hip.h declares (tests check that the library exports them all)
+EXPORTS = (
+    "dxh_last_error", "dxh_version", "dxh_device_count",
+    "dxh_tvd_create", "dxh_tvd_destroy", "dxh_tvd_set_coeffs", "dxh_tvd_upload", "dxh_tvd_run",
+    "dxh_tvd_download", "dxh_tvd_halo_bytes", "dxh_tvd_pack_rows", "dxh_tvd_unpack_rows",
+    "dxh_tvd_partial_norms", "dxh_tvd_sync", "dxh_jacobi_solve", "dxh_diff",
+)
+
+
+class HipError(RuntimeError):
+    """An error reported by libdarsia_hip (HIP runtime failure, allocation failure, bad state)."""
+
+
+class TvdDesc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("device", C.c_int32), ("dtype", C.c_int32), ("ndim", C.c_int32),
+        ("dim", C.c_int32), ("nsum", C.c_int32),
+        ("n0", C.c_int64), ("n1", C.c_int64), ("n2", C.c_int64),
+        ("top_is_boundary", C.c_int32), ("bottom_is_boundary", C.c_int32),
+        ("stream", C.c_void_p),
+    ]
+
+
+class TvdResult(C.Structure):
+    _fields_ = [
+        ("iters_done", C.c_int32), ("converged", C.c_int32), ("rel_increment", C.c_double),
+        ("loop_ms", C.c_double), ("launches", C.c_int64),
+    ]
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def _declare(lib):
+    vp, i, i64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_double
+    lib.dxh_last_error.restype = C.c_char_p
+    lib.dxh_last_error.argtypes = []
+    lib.dxh_version.restype = i
+    lib.dxh_device_count.argtypes = [C.POINTER(i)]
+    lib.dxh_tvd_create.argtypes = [C.POINTER(vp), C.POINTER(TvdDesc)]
+    lib.dxh_tvd_destroy.argtypes = [vp]
+    lib.dxh_tvd_set_coeffs.argtypes = [vp, dbl, vp, dbl, vp, i, dbl, vp]
+    lib.dxh_tvd_upload.argtypes = [vp, vp, vp, vp, vp]
+    lib.dxh_tvd_run.argtypes = [vp, i, i, dbl, dbl, dbl, C.c_uint32, C.POINTER(TvdResult)]
+    lib.dxh_tvd_download.argtypes = [vp, vp, vp, vp]
+    lib.dxh_tvd_halo_bytes.argtypes = [vp, i64, C.POINTER(C.c_size_t)]
+    lib.dxh_tvd_pack_rows.argtypes = [vp, i64, i64, vp]
+    lib.dxh_tvd_unpack_rows.argtypes = [vp, i64, i64, vp]
+    lib.dxh_tvd_partial_norms.argtypes = [vp, i64, i64, C.POINTER(dbl), C.POINTER(dbl)]
+    lib.dxh_tvd_sync.argtypes = [vp]
+    lib.dxh_jacobi_solve.argtypes = [i, i, i, i, i, i64, i64, i64, vp, vp, vp, dbl, vp, dbl, vp, dbl, i, dbl,
+                                     C.POINTER(i)]
+    lib.dxh_diff.argtypes = [i, i, i64, i64, i64, i, i, dbl, vp, vp]
+    for name in EXPORTS:
+        if name != "dxh_last_error":
+            getattr(lib, name).restype = i
+
+
+def load():
+    """Load the shared library (once).  Raises ImportError when it has not been built."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise ImportError(
+                    f"{LIB_PATH} not found: build it with darsia_amd/csrc/build.sh "
+                    "(darsia_amd has no CPU fallback)")
+            lib = C.CDLL(LIB_PATH)
+            _declare(lib)
+            _lib = lib
+    return _lib
+
+
+def check(rc: int):
+    if rc == 0:
+        return
+    msg = load().dxh_last_error().decode("utf-8", "replace")
+    if rc == -1:
+        raise ValueError(msg)
+    raise HipError(f"libdarsia_hip error {rc}: {msg}")
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    check(load().dxh_device_count(C.byref(n)))
+    return n.value
+
+
+def default_device() -> int:
+    return int(os.environ.get("DARSIA_HIP_DEVICE", "0"))
+
+
+def require_gpu():
+    if device_count() < 1:
+        raise HipError("no HIP device visible: darsia_amd runs on MI355X only (no CPU fallback)")
+
+
+def dtype_code(dt) -> int:
+    dt = np.dtype(dt)
+    if dt == np.float32:
+        return DXH_F32
+    if dt == np.float64:
+        return DXH_F64
+    raise TypeError(f"dtype {dt} not supported: float32/float64 only (SURVEY.md quirk Q5)")
+
+
+def ptr(a):
+    """Pointer to a C-contiguous ndarray (or None)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def shape3(shape, dim):
+    """(ndim, n0, n1, n2) of an image shape; 2 or 3 axes supported."""
+    nd = len(shape)
+    if nd not in (2, 3):
+        raise ValueError(f"arrays with {nd} axes are not supported (2 or 3 axes)")
+    if dim not in (2, 3) or dim > nd:
+        raise ValueError(f"dim={dim} not supported for an array with {nd} axes")
+    n2 = shape[2] if nd == 3 else 1
+    return nd, int(shape[0]), int(shape[1]), int(n2)

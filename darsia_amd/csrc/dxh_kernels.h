@@ -1,0 +1,566 @@
+// Device kernels of the split-Bregman TV path.  All arithmetic is IEEE add/sub/mul/div/sqrt in
+// the image dtype, one rounding per operation and in the reference's operation order (compile with
+// -ffp-contract=off), so that results equal a NumPy evaluation in that dtype bit for bit.
+//
+// Storage: an array of shape (n0, n1, n2) is kept as n0 rows of L = n1*n2 elements with a row
+// pitch (in elements) that is a multiple of 32.  Colour images stay INTERLEAVED (H, W*C): the
+// column neighbour is C elements away, the channel neighbour 1 element.
+//
+// State: instead of the reference's split variables d_j, b_j (2*dim planes) only
+// q_j = b_j_old + D_j(u)   ("dub", split_bregman_tvd.py:144) is stored; d_j and b_j are recomputed
+// from q_j where needed (dxh_common.h: split_vars).  u and q_j are double buffered.
+#pragma once
+
+#include "dxh_common.h"
+
+namespace dxh {
+
+template <typename T>
+struct Coef {       // scalar coefficients, already rounded to T like NumPy's weak scalars
+    T ell;          // Bregman regularisation / diffusion coefficient
+    T diag;         // omega + ell*2*dim/h^2                               jacobi.py:72
+    T dsc;          // diag / (ell/h^2)                                    jacobi.py:104-106
+    T kq;           // mu / ell (shrinkage threshold)                      split_bregman_tvd.py:140,145
+};
+
+template <typename T>
+struct CoefPlanes {  // heterogeneous coefficients (nullptr = scalar)
+    const T* ell;
+    const T* diag;
+    const T* dsc;
+    const T* kq;
+};
+
+struct Geom {
+    int64_t n0, n1, n2;  // array shape
+    int64_t L;           // n1 * n2
+    int64_t pitch;       // row pitch in elements
+    int ndim, dim, nsum_axes;
+};
+
+// ============================================================================================
+// Generic three-kernel path: any dim (2,3), any channel count, any number of Jacobi sweeps.
+// One thread per element; neighbour values come through the caches.
+// ============================================================================================
+
+struct ElemIdx {
+    int64_t row, x, i1, i2;
+    int64_t off;
+};
+
+__device__ __forceinline__ bool elem_index(const Geom& g, ElemIdx& e) {
+    const int64_t bpr = (g.L + blockDim.x - 1) / blockDim.x;
+    const int64_t bid = blockIdx.x;
+    e.row = bid / bpr;
+    e.x = (bid - e.row * bpr) * blockDim.x + threadIdx.x;
+    if (e.row >= g.n0 || e.x >= g.L) return false;
+    e.i1 = e.x / g.n2;
+    e.i2 = e.x - e.i1 * g.n2;
+    e.off = e.row * g.pitch + e.x;
+    return true;
+}
+
+// offset of the lower (-1) / upper (+1) neighbour along `axis`, clamped at the array ends
+__device__ __forceinline__ int64_t nb_off(const Geom& g, const ElemIdx& e, int axis, int dir) {
+    if (axis == 0) {
+        if (dir < 0) return e.row > 0 ? e.off - g.pitch : e.off;
+        return e.row < g.n0 - 1 ? e.off + g.pitch : e.off;
+    } else if (axis == 1) {
+        if (dir < 0) return e.i1 > 0 ? e.off - g.n2 : e.off;
+        return e.i1 < g.n1 - 1 ? e.off + g.n2 : e.off;
+    } else {
+        if (dir < 0) return e.i2 > 0 ? e.off - 1 : e.off;
+        return e.i2 < g.n2 - 1 ? e.off + 1 : e.off;
+    }
+}
+
+template <typename T, int DIM>
+struct QPlanes {
+    const T* in[DIM];
+    T* out[DIM];
+};
+
+// t_j(p) = ell * (b_j - d_j) at offset `off`, from the stored state (or from explicit d, b planes)
+template <typename T, int DIM, bool ISO, bool FROM_DB>
+__device__ __forceinline__ void t_at(const QPlanes<T, DIM>& q, const T* const* dpl, const T* const* bpl,
+                                     int64_t off, T ell, T kq, T (&t)[DIM]) {
+    T d[DIM], b[DIM];
+    if constexpr (FROM_DB) {
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) {
+            d[j] = dpl[j][off];
+            b[j] = bpl[j][off];
+        }
+    } else {
+        T qq[DIM];
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) qq[j] = q.in[j][off];
+        split_vars<T, DIM, ISO>(qq, kq, d, b);
+    }
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) t[j] = ell * (b[j] - d[j]);
+}
+
+template <typename T>
+struct DBPlanes {
+    const T* d[3];
+    const T* b[3];
+};
+
+// rs = (omega*img + sum_j forward_diff(ell*(b_j - d_j), j)) / diag
+// split_bregman_tvd.py:84-89, jacobi.py:107
+template <typename T, int DIM, bool ISO, bool FROM_DB>
+__global__ void __launch_bounds__(256) k_rhs(Geom g, const T* __restrict__ of, QPlanes<T, DIM> q, DBPlanes<T> db,
+                                              Coef<T> c, CoefPlanes<T> cp, T* __restrict__ rs) {
+    ElemIdx e;
+    if (!elem_index(g, e)) return;
+    const T ell_c = cp.ell ? cp.ell[e.off] : c.ell;
+    const T kq_c = cp.kq ? cp.kq[e.off] : c.kq;
+    T tc[DIM];
+    t_at<T, DIM, ISO, FROM_DB>(q, db.d, db.b, e.off, ell_c, kq_c, tc);
+    T r = of[e.off];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+        const int64_t o = nb_off(g, e, j, -1);
+        const T ell_n = cp.ell ? cp.ell[o] : c.ell;
+        const T kq_n = cp.kq ? cp.kq[o] : c.kq;
+        T tn[DIM];
+        t_at<T, DIM, ISO, FROM_DB>(q, db.d, db.b, o, ell_n, kq_n, tn);
+        r = r + (tc[j] - tn[j]);
+    }
+    const T diag = cp.diag ? cp.diag[e.off] : c.diag;
+    rs[e.off] = r / diag;
+}
+
+// one Jacobi sweep  x_out = rs + N(x_in) / dsc,  N = neighbour sum with replicate ghosts over the
+// first nsum_axes array axes (jacobi.py:25-55,110-114)
+template <typename T>
+__global__ void __launch_bounds__(256) k_jacobi(Geom g, const T* __restrict__ rs, const T* __restrict__ xin,
+                                                 Coef<T> c, CoefPlanes<T> cp, T* __restrict__ xout) {
+    ElemIdx e;
+    if (!elem_index(g, e)) return;
+    T acc = T(0);
+    for (int ax = 0; ax < g.nsum_axes; ++ax) {
+        acc = acc + xin[nb_off(g, e, ax, -1)];
+        acc = acc + xin[nb_off(g, e, ax, +1)];
+    }
+    const T dsc = cp.dsc ? cp.dsc[e.off] : c.dsc;
+    xout[e.off] = rs[e.off] + acc / dsc;
+}
+
+// q_j <- backward_diff(u_new, j) + b_j       split_bregman_tvd.py:136-146 (both branches)
+template <typename T, int DIM, bool ISO, bool FROM_DB>
+__global__ void __launch_bounds__(256) k_shrink(Geom g, const T* __restrict__ unew, QPlanes<T, DIM> q, DBPlanes<T> db,
+                                                 Coef<T> c, CoefPlanes<T> cp) {
+    ElemIdx e;
+    if (!elem_index(g, e)) return;
+    T d[DIM], b[DIM];
+    if constexpr (FROM_DB) {
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) b[j] = db.b[j][e.off];
+    } else {
+        const T kq = cp.kq ? cp.kq[e.off] : c.kq;
+        T qq[DIM];
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) qq[j] = q.in[j][e.off];
+        split_vars<T, DIM, ISO>(qq, kq, d, b);
+    }
+    const T uc = unew[e.off];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+        const T g_j = unew[nb_off(g, e, j, +1)] - uc;
+        q.out[j][e.off] = g_j + b[j];
+    }
+}
+
+// expand the state into the reference's split variables, layout (*shape, dim) (download / x0 round trip)
+template <typename T, int DIM, bool ISO>
+__global__ void __launch_bounds__(256) k_expand(Geom g, QPlanes<T, DIM> q, Coef<T> c, CoefPlanes<T> cp,
+                                                 T* __restrict__ dout, T* __restrict__ bout) {
+    ElemIdx e;
+    if (!elem_index(g, e)) return;
+    const T kq = cp.kq ? cp.kq[e.off] : c.kq;
+    T qq[DIM], d[DIM], b[DIM];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) qq[j] = q.in[j][e.off];
+    split_vars<T, DIM, ISO>(qq, kq, d, b);
+    const int64_t o = (e.row * g.L + e.x) * DIM;  // dense (no pitch)
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+        if (dout) dout[o + j] = d[j];
+        if (bout) bout[o + j] = b[j];
+    }
+}
+
+// de-interleave a dense (*shape, dim) array into pitched planes
+template <typename T, int DIM>
+__global__ void __launch_bounds__(256) k_deinterleave(Geom g, const T* __restrict__ src, T* p0, T* p1, T* p2) {
+    ElemIdx e;
+    if (!elem_index(g, e)) return;
+    const int64_t o = (e.row * g.L + e.x) * DIM;
+    T* pl[3] = {p0, p1, p2};
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) pl[j][e.off] = src[o + j];
+}
+
+// out = a * s  (s scalar or plane)  -- omega * img, split_bregman_tvd.py:85
+template <typename T>
+__global__ void __launch_bounds__(256) k_scale(Geom g, const T* __restrict__ a, T s, const T* __restrict__ splane,
+                                                T* __restrict__ out) {
+    ElemIdx e;
+    if (!elem_index(g, e)) return;
+    out[e.off] = (splane ? splane[e.off] : s) * a[e.off];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_divide(Geom g, const T* __restrict__ a, T s, const T* __restrict__ splane,
+                                                 T* __restrict__ out) {
+    ElemIdx e;
+    if (!elem_index(g, e)) return;
+    out[e.off] = a[e.off] / (splane ? splane[e.off] : s);
+}
+
+// coefficient planes from mu / omega / ell given as scalars or planes, with NumPy's evaluation order:
+//   ell  = 2*mu                       (when not given)            split_bregman_tvd.py:62-63
+//   diag = omega + ell*2*dim/h**2                                 jacobi.py:72
+//   dsc  = diag / (ell/h**2)                                      jacobi.py:104-106
+//   kq   = mu / ell                                               split_bregman_tvd.py:140,145
+// scalar-only sub-expressions are folded in double on the host and arrive here rounded to T.
+template <typename T>
+struct CoefIn {
+    const T* mu;
+    const T* omega;
+    const T* ell;
+    T mu_s, omega_s, ell_s;  // scalars rounded to T
+    T two_dim_over_h2_ell_s; // T(ell*2*dim/h^2) when ell is scalar
+    T ell_over_h2_s;         // T(ell/h^2) when ell is scalar
+    T h2;                    // T(h^2)
+    T two_dim;               // unused helper
+    int dim;
+    int has_ell;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_coef_planes(Geom g, CoefIn<T> in, T* __restrict__ ell_o, T* __restrict__ diag_o,
+                                                      T* __restrict__ dsc_o, T* __restrict__ kq_o) {
+    ElemIdx e;
+    if (!elem_index(g, e)) return;
+    const bool ell_is_arr = in.ell != nullptr || (!in.has_ell && in.mu != nullptr);
+    T ell, lap, ell_h2;
+    if (ell_is_arr) {
+        ell = in.ell ? in.ell[e.off] : T(2) * in.mu[e.off];
+        lap = ((ell * T(2)) * T(in.dim)) / in.h2;
+        ell_h2 = ell / in.h2;
+    } else {
+        ell = in.ell_s;
+        lap = in.two_dim_over_h2_ell_s;
+        ell_h2 = in.ell_over_h2_s;
+    }
+    const T omega = in.omega ? in.omega[e.off] : in.omega_s;
+    const T diag = omega + lap;
+    const T mu = in.mu ? in.mu[e.off] : in.mu_s;
+    ell_o[e.off] = ell;
+    diag_o[e.off] = diag;
+    dsc_o[e.off] = diag / ell_h2;
+    if (kq_o) kq_o[e.off] = mu / ell;
+}
+
+// finite differences, utils/derivatives.py:16-59
+template <typename T>
+__global__ void __launch_bounds__(256) k_diff(Geom g, const T* __restrict__ in, int axis, int mode, T h, int use_h,
+                                               T* __restrict__ out) {
+    ElemIdx e;
+    if (!elem_index(g, e)) return;
+    T r;
+    if (mode == 0)
+        r = in[nb_off(g, e, axis, +1)] - in[e.off];
+    else
+        r = in[e.off] - in[nb_off(g, e, axis, -1)];
+    out[e.off] = use_h ? r / h : r;
+}
+
+// ---- reductions: sum (a - b)^2 (b may be null) over rows [row0, row0 + nrows) -----------------
+// deterministic two-stage tree in double (per-block partials, then one block)
+template <typename T>
+__global__ void __launch_bounds__(256) k_sqdiff_partial(Geom g, const T* __restrict__ a, const T* __restrict__ b,
+                                                         int64_t row0, int64_t nrows, double* __restrict__ partial) {
+    __shared__ double sm[256 / kWave];
+    double acc = 0.0;
+    const int64_t total = nrows * g.L;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / g.L;
+        const int64_t x = i - r * g.L;
+        const int64_t off = (row0 + r) * g.pitch + x;
+        const double v = b ? (double)a[off] - (double)b[off] : (double)a[off];
+        acc += v * v;
+    }
+#pragma unroll
+    for (int s = kWave / 2; s > 0; s >>= 1) acc += __shfl_down(acc, s, kWave);
+    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+    if (lane == 0) sm[wid] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < 256 / kWave; ++w) s += sm[w];
+        partial[blockIdx.x] = s;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_sum_partials(const double* __restrict__ partial, int n, double* __restrict__ out) {
+    __shared__ double sm[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = sm[0];
+}
+
+// ============================================================================================
+// Fused sweep (dim = 2, one Jacobi sweep): rhs + Jacobi + shrink of one outer iteration in a single
+// pass.  Algorithmic traffic per element: read of, u, q0, q1; write u, q0, q1  = 7 values.
+//
+// Decomposition: one WAVE owns a column strip of 64 lanes x N elements (16 B per lane) and a chunk of
+// rows, and marches down the rows keeping a rolling window in registers:
+//     um, uc, up   u at rows r-1, r, r+1            t0m   ell*(b0-d0) at row r-1
+//     upm          u_new at row r-1                  b0m   b0 at row r-1
+// Row neighbours are registers; column (+-C) and channel (+-1) neighbours come from adjacent lanes by
+// DPP wave shifts.  Strips overlap by LH lanes on the left and RH lanes on the right so that no wave
+// ever needs another wave's data: no LDS, no barriers.  The chunk's last step computes u_new of the
+// first row of the next chunk (not stored) to finish q0 of the chunk's last row.
+//
+// Image borders are handled by clamping: row indices are clamped in the address, column / channel
+// neighbours by selecting the element itself (loop-invariant lane masks).  This reproduces the
+// reference's replicate ghosts (jacobi.py:43,52) and zero one-sided differences
+// (derivatives.py:33,57) with the same arithmetic (x - x = 0).
+// ============================================================================================
+
+template <typename T>
+struct FusedArgs {
+    const T* of;
+    const T* u_in;
+    T* u_out;
+    const T* q0_in;
+    const T* q1_in;
+    T* q0_out;
+    T* q1_out;
+    int64_t n0, L, pitch;
+    int64_t rows_per_chunk;
+    int nstrips;       // strips per row
+    int nchunks;
+    Coef<T> c;
+    CoefPlanes<T> cp;
+};
+
+template <typename T, int C>
+struct StripGeom {
+    static constexpr int N = VecOf<T>::N;
+    static constexpr int LH = (C + N - 1) / N;          // left halo lanes
+    static constexpr int RH = (2 * C + N - 1) / N;      // right halo lanes
+    static constexpr int VALID = kWave - LH - RH;       // lanes that store
+    static constexpr int STRIDE = VALID * N;            // elements advanced per strip
+};
+
+template <typename T, int C, bool COUPLED, bool ISO, bool HET, bool DPP>
+__global__ void __launch_bounds__(256) k_fused(FusedArgs<T> a) {
+    constexpr int N = VecOf<T>::N;
+    using SG = StripGeom<T, C>;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    constexpr int WPB = 4;
+    const int nbx = (a.nstrips + WPB - 1) / WPB;
+    const int bx = blockIdx.x % nbx;
+    const int chunk = blockIdx.x / nbx;
+    const int strip = bx * WPB + wave;
+    if (strip >= a.nstrips || chunk >= a.nchunks) return;  // wave-uniform
+
+    const int64_t R0 = (int64_t)chunk * a.rows_per_chunk;
+    const int64_t R1 = (R0 + a.rows_per_chunk < a.n0) ? R0 + a.rows_per_chunk : a.n0;
+    if (R0 >= a.n0) return;
+
+    // element range of this lane: [x0, x0 + N)
+    const int64_t x0 = (int64_t)strip * SG::STRIDE + (int64_t)(lane - SG::LH) * N;
+    // lanes outside the padded row read a clamped address (their values are never used for stores)
+    int64_t xl = x0;
+    if (xl < 0) xl = 0;
+    if (xl > a.pitch - N) xl = a.pitch - N;
+    const bool store_lane = lane >= SG::LH && lane < kWave - SG::RH && x0 < a.L;
+
+    // loop-invariant per-element border predicates
+    bool edgeL[N], edgeR[N], ch0[N], chLast[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int64_t x = x0 + j;
+        edgeL[j] = x < C;
+        edgeR[j] = x >= a.L - C;
+        const int cc = (int)(((x % C) + C) % C);
+        ch0[j] = cc == 0;
+        chLast[j] = cc == C - 1;
+    }
+
+    const T* of = a.of + xl;
+    const T* u_in = a.u_in + xl;
+    const T* q0_in = a.q0_in + xl;
+    const T* q1_in = a.q1_in + xl;
+    T* u_out = a.u_out + xl;
+    T* q0_out = a.q0_out + xl;
+    T* q1_out = a.q1_out + xl;
+    const T* p_ell = HET ? a.cp.ell + xl : nullptr;
+    const T* p_diag = HET ? a.cp.diag + xl : nullptr;
+    const T* p_dsc = HET ? a.cp.dsc + xl : nullptr;
+    const T* p_kq = HET ? a.cp.kq + xl : nullptr;
+
+    const int64_t P = a.pitch;
+    auto clampr = [&](int64_t r) -> int64_t { return r < 0 ? 0 : (r > a.n0 - 1 ? a.n0 - 1 : r); };
+
+    T ell[N], diag[N], dsc[N], kq[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        ell[j] = a.c.ell;
+        diag[j] = a.c.diag;
+        dsc[j] = a.c.dsc;
+        kq[j] = a.c.kq;
+    }
+
+    // ---- prologue: rows R0-1 and R0 ---------------------------------------------------------
+    T um[N], uc[N], up[N], t0m[N], upm[N], b0m[N];
+    load_vec(u_in + clampr(R0 - 1) * P, um);
+    load_vec(u_in + R0 * P, uc);
+    {
+        const int64_t rm = clampr(R0 - 1);
+        T q0v[N], q1v[N], ellm[N], kqm[N];
+        load_vec(q0_in + rm * P, q0v);
+        load_vec(q1_in + rm * P, q1v);
+        if constexpr (HET) {
+            load_vec(p_ell + rm * P, ellm);
+            load_vec(p_kq + rm * P, kqm);
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            T qq[2] = {q0v[j], q1v[j]}, d[2], b[2];
+            split_vars<T, 2, ISO>(qq, HET ? kqm[j] : kq[j], d, b);
+            t0m[j] = (HET ? ellm[j] : ell[j]) * (b[0] - d[0]);
+            upm[j] = T(0);
+            b0m[j] = T(0);
+        }
+    }
+
+    // software prefetch of the first step's operands
+    T fr[N], q0r[N], q1r[N];
+    load_vec(u_in + clampr(R0 + 1) * P, up);
+    load_vec(of + R0 * P, fr);
+    load_vec(q0_in + R0 * P, q0r);
+    load_vec(q1_in + R0 * P, q1r);
+    if constexpr (HET) {
+        load_vec(p_ell + R0 * P, ell);
+        load_vec(p_diag + R0 * P, diag);
+        load_vec(p_dsc + R0 * P, dsc);
+        load_vec(p_kq + R0 * P, kq);
+    }
+
+    for (int64_t r = R0; r <= R1; ++r) {
+        // issue next step's loads early (clamped rows keep the addresses valid on the last steps)
+        T upn[N], frn[N], q0n[N], q1n[N], elln[N], diagn[N], dscn[N], kqn[N];
+        {
+            const int64_t rn = clampr(r + 1);
+            load_vec(u_in + clampr(r + 2) * P, upn);
+            load_vec(of + rn * P, frn);
+            load_vec(q0_in + rn * P, q0n);
+            load_vec(q1_in + rn * P, q1n);
+            if constexpr (HET) {
+                load_vec(p_ell + rn * P, elln);
+                load_vec(p_diag + rn * P, diagn);
+                load_vec(p_dsc + rn * P, dscn);
+                load_vec(p_kq + rn * P, kqn);
+            }
+        }
+
+        T un[N], b0c[N], t0c[N];
+        if (r < a.n0) {
+            // split variables and t = ell*(b - d) of row r
+            T b1c[N], t1c[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                T qq[2] = {q0r[j], q1r[j]}, d[2], b[2];
+                split_vars<T, 2, ISO>(qq, kq[j], d, b);
+                b0c[j] = b[0];
+                b1c[j] = b[1];
+                t0c[j] = ell[j] * (b[0] - d[0]);
+                t1c[j] = ell[j] * (b[1] - d[1]);
+            }
+            T t1l[N], ul[N], ur[N];
+            shifted<-C, DPP>(t1c, t1l);
+            shifted<-C, DPP>(uc, ul);
+            shifted<+C, DPP>(uc, ur);
+            T ucl[N], ucr[N];
+            if constexpr (COUPLED) {
+                shifted<-1, DPP>(uc, ucl);
+                shifted<+1, DPP>(uc, ucr);
+            }
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                // rhs = omega*img + fd_0 + fd_1 ; rs = rhs / diag
+                T rhs = fr[j] + (t0c[j] - t0m[j]);
+                rhs = rhs + (t1c[j] - (edgeL[j] ? t1c[j] : t1l[j]));
+                const T rs = rhs / diag[j];
+                // neighbour sum in the reference's order: axis 0 (rows), axis 1 (columns), axis 2 (channels)
+                T acc = um[j] + up[j];
+                acc = acc + (edgeL[j] ? uc[j] : ul[j]);
+                acc = acc + (edgeR[j] ? uc[j] : ur[j]);
+                if constexpr (COUPLED) {
+                    acc = acc + (ch0[j] ? uc[j] : ucl[j]);
+                    acc = acc + (chLast[j] ? uc[j] : ucr[j]);
+                }
+                un[j] = rs + acc / dsc[j];
+            }
+            // q1 of row r:  (u_new[x+C] - u_new[x]) + b1
+            T unr[N], q1o[N];
+            shifted<+C, DPP>(un, unr);
+#pragma unroll
+            for (int j = 0; j < N; ++j) q1o[j] = ((edgeR[j] ? un[j] : unr[j]) - un[j]) + b1c[j];
+            if (store_lane && r < R1) {
+                store_vec(q1_out + r * P, q1o);
+                store_vec(u_out + r * P, un);
+            }
+        } else {
+            // r == n0: below the last row, replicate u_new so that the row difference is 0
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                un[j] = upm[j];
+                b0c[j] = T(0);
+                t0c[j] = T(0);
+            }
+        }
+        // q0 of row r-1:  (u_new[r] - u_new[r-1]) + b0[r-1]
+        if (r > R0) {
+            T q0o[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) q0o[j] = (un[j] - upm[j]) + b0m[j];
+            if (store_lane) store_vec(q0_out + (r - 1) * P, q0o);
+        }
+        // rotate the window
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            um[j] = uc[j];
+            uc[j] = up[j];
+            up[j] = upn[j];
+            t0m[j] = t0c[j];
+            upm[j] = un[j];
+            b0m[j] = b0c[j];
+            fr[j] = frn[j];
+            q0r[j] = q0n[j];
+            q1r[j] = q1n[j];
+            if constexpr (HET) {
+                ell[j] = elln[j];
+                diag[j] = diagn[j];
+                dsc[j] = dscn[j];
+                kq[j] = kqn[j];
+            }
+        }
+    }
+}
+
+}  // namespace dxh

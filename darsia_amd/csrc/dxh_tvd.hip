@@ -1,0 +1,803 @@
+// libdarsia_hip.so -- host side of the C ABI declared in include/darsia_hip.h.
+// Written for gfx950 (MI355X) only.
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "dxh_kernels.h"
+
+namespace dxh {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+struct Ctx {
+    dxh_tvd_desc desc{};
+    Geom g{};
+    size_t esz = 4;
+    size_t plane_bytes = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cu = 256;
+
+    void* of = nullptr;            // omega * img
+    void* u[2] = {nullptr, nullptr};
+    void* q[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+    void* rs = nullptr;            // rhs / diag (three-kernel path)
+    void* dpl[3] = {nullptr, nullptr, nullptr};  // explicit d, b planes of a warm start (first iteration only)
+    void* bpl[3] = {nullptr, nullptr, nullptr};
+    void* cp_ell = nullptr;        // heterogeneous coefficient planes
+    void* cp_diag = nullptr;
+    void* cp_dsc = nullptr;
+    void* cp_kq = nullptr;
+    void* om_plane = nullptr;      // omega as a plane (array-valued omega only)
+    void* stage = nullptr;         // dense staging buffer (dim * plane) for (*shape, dim) transfers
+    double* partial = nullptr;
+    double* red_out = nullptr;     // 2 doubles
+    int npartial = 1024;
+
+    int cur = 0;                   // index of the current u / q buffers
+    bool have_coefs = false, het = false, uploaded = false, from_db = false;
+    bool last_iso = false;
+    double mu_s = 0, omega_s = 1, ell_s = 0;  // scalar views (valid when !het)
+    double c_ell = 0, c_diag = 0, c_dsc = 0, c_kq = 0;
+    double sq_img = -1.0;          // sum img^2 over this slab
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+static int alloc_plane(Ctx* c, void** p) {
+    if (*p) return DXH_OK;
+    DXH_HIP(hipMalloc(p, c->plane_bytes));
+    DXH_HIP(hipMemsetAsync(*p, 0, c->plane_bytes, c->stream));
+    return DXH_OK;
+}
+
+static dim3 elem_grid(const Geom& g) {
+    const int64_t bpr = (g.L + 255) / 256;
+    return dim3((unsigned)(bpr * g.n0));
+}
+
+template <typename T>
+static Coef<T> make_coef(const Ctx* c) {
+    Coef<T> k;
+    k.ell = (T)c->c_ell;
+    k.diag = (T)c->c_diag;
+    k.dsc = (T)c->c_dsc;
+    k.kq = (T)c->c_kq;
+    return k;
+}
+template <typename T>
+static CoefPlanes<T> make_planes(const Ctx* c) {
+    CoefPlanes<T> p;
+    p.ell = (const T*)c->cp_ell;
+    p.diag = (const T*)c->cp_diag;
+    p.dsc = (const T*)c->cp_dsc;
+    p.kq = (const T*)c->cp_kq;
+    return p;
+}
+
+static int set_device(const Ctx* c) {
+    DXH_HIP(hipSetDevice(c->desc.device));
+    return DXH_OK;
+}
+
+// dense host array (n0, L) <-> pitched device plane
+static int h2d_plane(Ctx* c, void* dst, const void* src) {
+    DXH_HIP(hipMemcpy2DAsync(dst, c->g.pitch * c->esz, src, c->g.L * c->esz, c->g.L * c->esz, c->g.n0,
+                             hipMemcpyHostToDevice, c->stream));
+    return DXH_OK;
+}
+static int d2h_plane(Ctx* c, void* dst, const void* src) {
+    DXH_HIP(hipMemcpy2DAsync(dst, c->g.L * c->esz, src, c->g.pitch * c->esz, c->g.L * c->esz, c->g.n0,
+                             hipMemcpyDeviceToHost, c->stream));
+    return DXH_OK;
+}
+
+// ---- reductions ---------------------------------------------------------------------------------
+template <typename T>
+static int sq_diff(Ctx* c, const void* a, const void* b, int64_t row0, int64_t nrows, double* out_host, int slot) {
+    const int nb = c->npartial;
+    hipLaunchKernelGGL((k_sqdiff_partial<T>), dim3(nb), dim3(256), 0, c->stream, c->g, (const T*)a, (const T*)b, row0,
+                       nrows, c->partial);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->partial, nb, c->red_out + slot);
+    DXH_HIP(hipGetLastError());
+    if (out_host) {
+        DXH_HIP(hipMemcpyAsync(out_host, c->red_out + slot, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        DXH_HIP(hipStreamSynchronize(c->stream));
+    }
+    return DXH_OK;
+}
+
+// ---- the fused sweep launch ---------------------------------------------------------------------
+template <typename T, int C, bool COUPLED, bool ISO, bool HET, bool DPP>
+static void launch_fused_t(Ctx* c, int in, int out) {
+    using SG = StripGeom<T, C>;
+    FusedArgs<T> a;
+    a.of = (const T*)c->of;
+    a.u_in = (const T*)c->u[in];
+    a.u_out = (T*)c->u[out];
+    a.q0_in = (const T*)c->q[0][in];
+    a.q1_in = (const T*)c->q[1][in];
+    a.q0_out = (T*)c->q[0][out];
+    a.q1_out = (T*)c->q[1][out];
+    a.n0 = c->g.n0;
+    a.L = c->g.L;
+    a.pitch = c->g.pitch;
+    a.nstrips = (int)((c->g.L + SG::STRIDE - 1) / SG::STRIDE);
+    const int nbx = (a.nstrips + 3) / 4;
+    // size the grid to the machine: about 16 waves per CU, every wave the same number of rows
+    const int64_t target_blocks = (int64_t)c->num_cu * 4;
+    int64_t nchunks = std::max<int64_t>(1, target_blocks / nbx);
+    int64_t rpc = std::max<int64_t>(8, (c->g.n0 + nchunks - 1) / nchunks);
+    nchunks = (c->g.n0 + rpc - 1) / rpc;
+    a.rows_per_chunk = rpc;
+    a.nchunks = (int)nchunks;
+    a.c = make_coef<T>(c);
+    a.cp = make_planes<T>(c);
+    hipLaunchKernelGGL((k_fused<T, C, COUPLED, ISO, HET, DPP>), dim3((unsigned)(nbx * nchunks)), dim3(256), 0, c->stream,
+                       a);
+}
+
+template <typename T, int C, bool COUPLED>
+static void launch_fused_c(Ctx* c, int in, int out, bool iso, bool dpp) {
+    const bool het = c->het;
+#define DXH_F(ISO_, HET_, DPP_) launch_fused_t<T, C, COUPLED, ISO_, HET_, DPP_>(c, in, out)
+    if (iso) {
+        if (het) { if (dpp) DXH_F(true, true, true); else DXH_F(true, true, false); }
+        else     { if (dpp) DXH_F(true, false, true); else DXH_F(true, false, false); }
+    } else {
+        if (het) { if (dpp) DXH_F(false, true, true); else DXH_F(false, true, false); }
+        else     { if (dpp) DXH_F(false, false, true); else DXH_F(false, false, false); }
+    }
+#undef DXH_F
+}
+
+// channel count / coupling the fused kernel is instantiated for
+static bool fused_supported(const Ctx* c) {
+    if (c->desc.dim != 2) return false;
+    const int64_t C = c->g.n2;
+    if (C < 1 || C > 4) return false;
+    return true;
+}
+
+template <typename T>
+static void launch_fused(Ctx* c, int in, int out, bool iso, bool dpp) {
+    const int C = (int)c->g.n2;
+    // channel neighbours take part in the Jacobi sum only when the array has a third axis AND the
+    // reference semantics (all axes) are requested
+    const bool coupled = c->desc.ndim == 3 && c->desc.nsum == DXH_NSUM_ALL_AXES;
+    switch (C) {
+        case 1: coupled ? launch_fused_c<T, 1, true>(c, in, out, iso, dpp) : launch_fused_c<T, 1, false>(c, in, out, iso, dpp); break;
+        case 2: coupled ? launch_fused_c<T, 2, true>(c, in, out, iso, dpp) : launch_fused_c<T, 2, false>(c, in, out, iso, dpp); break;
+        case 3: coupled ? launch_fused_c<T, 3, true>(c, in, out, iso, dpp) : launch_fused_c<T, 3, false>(c, in, out, iso, dpp); break;
+        case 4: coupled ? launch_fused_c<T, 4, true>(c, in, out, iso, dpp) : launch_fused_c<T, 4, false>(c, in, out, iso, dpp); break;
+    }
+}
+
+// ---- the three-kernel path ----------------------------------------------------------------------
+template <typename T, int DIM>
+static QPlanes<T, DIM> make_q(Ctx* c, int in, int out) {
+    QPlanes<T, DIM> q;
+    for (int j = 0; j < DIM; ++j) {
+        q.in[j] = (const T*)c->q[j][in];
+        q.out[j] = (T*)c->q[j][out];
+    }
+    return q;
+}
+template <typename T>
+static DBPlanes<T> make_db(Ctx* c) {
+    DBPlanes<T> db;
+    for (int j = 0; j < 3; ++j) {
+        db.d[j] = (const T*)c->dpl[j];
+        db.b[j] = (const T*)c->bpl[j];
+    }
+    return db;
+}
+
+template <typename T, int DIM>
+static void launch_rhs(Ctx* c, bool iso, bool from_db) {
+    const dim3 grid = elem_grid(c->g), blk(256);
+    auto q = make_q<T, DIM>(c, c->cur, c->cur);
+    auto db = make_db<T>(c);
+    auto co = make_coef<T>(c);
+    auto cp = make_planes<T>(c);
+    if (from_db)
+        hipLaunchKernelGGL((k_rhs<T, DIM, false, true>), grid, blk, 0, c->stream, c->g, (const T*)c->of, q, db, co, cp, (T*)c->rs);
+    else if (iso)
+        hipLaunchKernelGGL((k_rhs<T, DIM, true, false>), grid, blk, 0, c->stream, c->g, (const T*)c->of, q, db, co, cp, (T*)c->rs);
+    else
+        hipLaunchKernelGGL((k_rhs<T, DIM, false, false>), grid, blk, 0, c->stream, c->g, (const T*)c->of, q, db, co, cp, (T*)c->rs);
+}
+
+template <typename T, int DIM>
+static void launch_shrink(Ctx* c, const void* unew, bool iso, bool from_db) {
+    const dim3 grid = elem_grid(c->g), blk(256);
+    auto q = make_q<T, DIM>(c, c->cur, c->cur);  // in place: each thread touches only its own element
+    auto db = make_db<T>(c);
+    auto co = make_coef<T>(c);
+    auto cp = make_planes<T>(c);
+    if (from_db)
+        hipLaunchKernelGGL((k_shrink<T, DIM, false, true>), grid, blk, 0, c->stream, c->g, (const T*)unew, q, db, co, cp);
+    else if (iso)
+        hipLaunchKernelGGL((k_shrink<T, DIM, true, false>), grid, blk, 0, c->stream, c->g, (const T*)unew, q, db, co, cp);
+    else
+        hipLaunchKernelGGL((k_shrink<T, DIM, false, false>), grid, blk, 0, c->stream, c->g, (const T*)unew, q, db, co, cp);
+}
+
+template <typename T>
+static void launch_jacobi(Ctx* c, const void* xin, void* xout) {
+    hipLaunchKernelGGL((k_jacobi<T>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const T*)c->rs, (const T*)xin,
+                       make_coef<T>(c), make_planes<T>(c), (T*)xout);
+}
+
+// Jacobi.__call__ on device buffers: x0 in u[cur], rs ready; leaves the result in u[cur ^ 1]... or, when
+// the reference returns x0 itself (tol met on the first sweep, or maxiter == 0), copies it there.
+// Needs a third buffer for sweeps > 1: `tmp`.
+template <typename T>
+static int jacobi_sweeps(Ctx* c, int maxiter, double tol, void* tmp, int64_t* launches, int* sweeps_done) {
+    const int in = c->cur, out = c->cur ^ 1;
+    const bool use_tol = tol >= 0.0 && !std::isnan(tol);
+    double nrm0 = 0.0;
+    if (use_tol) {
+        int rc = sq_diff<T>(c, c->u[in], nullptr, 0, c->g.n0, &nrm0, 0);
+        if (rc) return rc;
+        nrm0 = std::sqrt(nrm0);
+    }
+    // x lives alternately in `out` and `tmp`; the first sweep reads u[in]
+    const void* x = c->u[in];
+    void* bufs[2] = {c->u[out], tmp};
+    int w = 0, done = 0;
+    for (int s = 0; s < maxiter; ++s) {
+        void* xn = bufs[w];
+        launch_jacobi<T>(c, x, xn);
+        ++*launches;
+        if (use_tol) {
+            double inc = 0.0;
+            int rc = sq_diff<T>(c, xn, x, 0, c->g.n0, &inc, 0);
+            if (rc) return rc;
+            if (std::sqrt(inc) / nrm0 < tol) break;  // reference keeps the PREVIOUS iterate (jacobi.py:123-126)
+        }
+        x = xn;
+        w ^= 1;
+        ++done;
+    }
+    if (x != c->u[out]) DXH_HIP(hipMemcpyAsync(c->u[out], x, c->plane_bytes, hipMemcpyDeviceToDevice, c->stream));
+    if (sweeps_done) *sweeps_done = done;
+    return DXH_OK;
+}
+
+template <typename T>
+static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, double eps, double norm_scale,
+                 uint32_t flags, dxh_tvd_result* res) {
+    const bool iso = flags & DXH_FLAG_ISOTROPIC;
+    const bool use_eps = eps >= 0.0 && !std::isnan(eps);
+    const bool use_tol = jacobi_tol >= 0.0 && !std::isnan(jacobi_tol);
+    const bool dpp = !(flags & DXH_FLAG_NO_DPP);
+    bool fused_ok = fused_supported(c) && jacobi_maxiter == 1 && !use_tol && !(flags & DXH_FLAG_NO_FUSED);
+    const int dim = c->desc.dim;
+    c->last_iso = iso;
+
+    void* tmp = nullptr;
+    const bool need_generic = !fused_ok || c->from_db;
+    if (need_generic) {
+        int rc = alloc_plane(c, &c->rs);
+        if (rc) return rc;
+        if (jacobi_maxiter > 1) {
+            DXH_HIP(hipMalloc(&tmp, c->plane_bytes));
+        }
+    }
+    double nrm_img = 0.0;
+    if (use_eps) {
+        if (norm_scale > 0.0)
+            nrm_img = norm_scale;
+        else
+            nrm_img = std::sqrt(c->sq_img);
+    }
+
+    int64_t launches = 0;
+    int done = 0, converged = 0;
+    double rel = std::numeric_limits<double>::quiet_NaN();
+    DXH_HIP(hipEventRecord(c->ev0, c->stream));
+    for (int it = 0; it < n_iter; ++it) {
+        const int in = c->cur, out = c->cur ^ 1;
+        if (fused_ok && !c->from_db) {
+            launch_fused<T>(c, in, out, iso, dpp);
+            ++launches;
+            c->cur = out;
+        } else {
+            const bool fdb = c->from_db;
+            if (dim == 2) launch_rhs<T, 2>(c, iso, fdb); else launch_rhs<T, 3>(c, iso, fdb);
+            ++launches;
+            int rc = jacobi_sweeps<T>(c, jacobi_maxiter, jacobi_tol, tmp, &launches, nullptr);
+            if (rc) { if (tmp) (void)hipFree(tmp); return rc; }
+            if (dim == 2) launch_shrink<T, 2>(c, c->u[out], iso, fdb); else launch_shrink<T, 3>(c, c->u[out], iso, fdb);
+            ++launches;
+            // the q planes were updated in place in buffer `cur`; move them along with u
+            for (int j = 0; j < dim; ++j) std::swap(c->q[j][in], c->q[j][out]);
+            c->cur = out;
+            c->from_db = false;
+        }
+        done = it + 1;
+        if (use_eps) {
+            double inc = 0.0;
+            int rc = sq_diff<T>(c, c->u[c->cur], c->u[c->cur ^ 1], 0, c->g.n0, &inc, 0);
+            if (rc) { if (tmp) (void)hipFree(tmp); return rc; }
+            rel = std::sqrt(inc) / nrm_img;
+            if (rel < eps) { converged = 1; break; }
+        }
+    }
+    DXH_HIP(hipGetLastError());
+    DXH_HIP(hipEventRecord(c->ev1, c->stream));
+    DXH_HIP(hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    DXH_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    if (tmp) DXH_HIP(hipFree(tmp));
+    if (res) {
+        res->iters_done = done;
+        res->converged = converged;
+        res->rel_increment = rel;
+        res->loop_ms = ms;
+        res->launches = launches;
+    }
+    return DXH_OK;
+}
+
+template <typename T>
+static int set_coeffs_t(Ctx* c, double mu, const void* mu_arr, double omega, const void* omega_arr, int has_ell,
+                        double ell, const void* ell_arr, double h, bool want_kq) {
+    const int dim = c->desc.dim;
+    const double h2 = h * h;
+    c->het = mu_arr || omega_arr || ell_arr;
+    c->mu_s = mu;
+    c->omega_s = omega;
+    if (!c->het) {
+        // all-scalar: fold in double like Python floats, round once where the value meets an array
+        const double ell_d = has_ell ? ell : 2.0 * mu;
+        c->ell_s = ell_d;
+        c->c_ell = ell_d;
+        c->c_diag = omega + ell_d * 2 * dim / h2;
+        c->c_dsc = c->c_diag / (ell_d / h2);
+        c->c_kq = mu / ell_d;
+        for (void** p : {&c->cp_ell, &c->cp_diag, &c->cp_dsc, &c->cp_kq}) {
+            if (*p) { DXH_HIP(hipFree(*p)); *p = nullptr; }
+        }
+        return DXH_OK;
+    }
+    // heterogeneous: build the four planes on the device with NumPy's evaluation order
+    void *d_mu = nullptr, *d_om = nullptr, *d_ell = nullptr;
+    auto up = [&](const void* src, void** dst) -> int {
+        if (!src) return DXH_OK;
+        DXH_HIP(hipMalloc(dst, c->plane_bytes));
+        return h2d_plane(c, *dst, src);
+    };
+    int rc;
+    if ((rc = up(mu_arr, &d_mu)) || (rc = up(omega_arr, &d_om)) || (rc = up(ell_arr, &d_ell))) return rc;
+    if ((rc = alloc_plane(c, &c->cp_ell)) || (rc = alloc_plane(c, &c->cp_diag)) || (rc = alloc_plane(c, &c->cp_dsc)) ||
+        (rc = alloc_plane(c, &c->cp_kq)))
+        return rc;
+    CoefIn<T> in;
+    in.mu = (const T*)d_mu;
+    in.omega = (const T*)d_om;
+    in.ell = (const T*)d_ell;
+    in.mu_s = (T)mu;
+    in.omega_s = (T)omega;
+    const double ell_d = has_ell ? ell : 2.0 * mu;  // only meaningful when ell is scalar
+    in.ell_s = (T)ell_d;
+    in.two_dim_over_h2_ell_s = (T)(ell_d * 2 * dim / h2);
+    in.ell_over_h2_s = (T)(ell_d / h2);
+    in.h2 = (T)h2;
+    in.two_dim = (T)(2 * dim);
+    in.dim = dim;
+    in.has_ell = has_ell;
+    hipLaunchKernelGGL((k_coef_planes<T>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, in, (T*)c->cp_ell,
+                       (T*)c->cp_diag, (T*)c->cp_dsc, want_kq ? (T*)c->cp_kq : nullptr);
+    DXH_HIP(hipGetLastError());
+    DXH_HIP(hipStreamSynchronize(c->stream));
+    for (void* p : {d_mu, d_om, d_ell})
+        if (p) DXH_HIP(hipFree(p));
+    return DXH_OK;
+}
+
+}  // namespace dxh
+
+using namespace dxh;
+
+extern "C" {
+
+const char* dxh_last_error(void) { return g_err.c_str(); }
+int dxh_version(void) { return 100; }
+
+int dxh_device_count(int* count) {
+    if (!count) return DXH_EINVAL;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return DXH_OK;
+}
+
+int dxh_tvd_create(dxh_tvd_t* out, const dxh_tvd_desc* d) {
+    DXH_REQUIRE(out && d, "null argument");
+    DXH_REQUIRE(d->struct_size == (int32_t)sizeof(dxh_tvd_desc), "dxh_tvd_desc size mismatch (%d vs %zu)", d->struct_size,
+                sizeof(dxh_tvd_desc));
+    DXH_REQUIRE(d->dtype == DXH_F32 || d->dtype == DXH_F64, "dtype must be float32 or float64");
+    DXH_REQUIRE(d->ndim == 2 || d->ndim == 3, "ndim must be 2 or 3 (got %d)", d->ndim);
+    DXH_REQUIRE(d->dim == 2 || d->dim == 3, "dim must be 2 or 3 (got %d)", d->dim);
+    DXH_REQUIRE(d->dim <= d->ndim, "dim (%d) exceeds ndim (%d)", d->dim, d->ndim);
+    DXH_REQUIRE(d->n0 >= 1 && d->n1 >= 1 && d->n2 >= 1, "empty image");
+    DXH_REQUIRE(d->ndim == 3 || d->n2 == 1, "n2 must be 1 for a 2-D array");
+    DXH_REQUIRE(d->nsum == DXH_NSUM_ALL_AXES || d->nsum == DXH_NSUM_SPATIAL, "bad nsum");
+    int ndev = 0;
+    DXH_HIP(hipGetDeviceCount(&ndev));
+    DXH_REQUIRE(d->device >= 0 && d->device < ndev, "device %d not available (%d devices)", d->device, ndev);
+    Ctx* c = new (std::nothrow) Ctx();
+    if (!c) { set_error("out of host memory"); return DXH_ENOMEM; }
+    c->desc = *d;
+    c->esz = d->dtype == DXH_F32 ? 4 : 8;
+    c->g.n0 = d->n0;
+    c->g.n1 = d->n1;
+    c->g.n2 = d->n2;
+    c->g.L = d->n1 * d->n2;
+    c->g.pitch = round_up(c->g.L, 32);
+    c->g.ndim = d->ndim;
+    c->g.dim = d->dim;
+    c->g.nsum_axes = d->nsum == DXH_NSUM_ALL_AXES ? d->ndim : d->dim;
+    c->plane_bytes = (size_t)c->g.pitch * (size_t)c->g.n0 * c->esz;
+    auto fail = [&](int rc) { dxh_tvd_destroy(reinterpret_cast<dxh_tvd_t>(c)); return rc; };
+    if (hipSetDevice(d->device) != hipSuccess) { set_error("hipSetDevice(%d) failed", d->device); return fail(DXH_EHIP); }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, d->device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+    if (d->stream) {
+        c->stream = (hipStream_t)d->stream;
+    } else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(DXH_EHIP); }
+        c->own_stream = true;
+    }
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { set_error("hipEventCreate failed"); return fail(DXH_EHIP); }
+    int rc;
+    if ((rc = alloc_plane(c, &c->of))) return fail(rc);
+    for (int k = 0; k < 2; ++k) {
+        if ((rc = alloc_plane(c, &c->u[k]))) return fail(rc);
+        for (int j = 0; j < d->dim; ++j)
+            if ((rc = alloc_plane(c, &c->q[j][k]))) return fail(rc);
+    }
+    if (hipMalloc((void**)&c->partial, sizeof(double) * c->npartial) != hipSuccess ||
+        hipMalloc((void**)&c->red_out, sizeof(double) * 2) != hipSuccess) {
+        set_error("hipMalloc failed");
+        return fail(DXH_ENOMEM);
+    }
+    *out = reinterpret_cast<dxh_tvd_t>(c);
+    return DXH_OK;
+}
+
+int dxh_tvd_destroy(dxh_tvd_t h) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    if (!c) return DXH_OK;
+    (void)hipSetDevice(c->desc.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    auto fr = [](void* p) { if (p) (void)hipFree(p); };
+    fr(c->of); fr(c->u[0]); fr(c->u[1]); fr(c->rs);
+    for (int j = 0; j < 3; ++j) { fr(c->q[j][0]); fr(c->q[j][1]); fr(c->dpl[j]); fr(c->bpl[j]); }
+    fr(c->cp_ell); fr(c->cp_diag); fr(c->cp_dsc); fr(c->cp_kq); fr(c->om_plane); fr(c->stage); fr(c->partial); fr(c->red_out);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return DXH_OK;
+}
+
+int dxh_tvd_set_coeffs(dxh_tvd_t h, double mu, const void* mu_arr, double omega, const void* omega_arr, int has_ell,
+                       double ell, const void* ell_arr) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    DXH_REQUIRE(c, "null context");
+    int rc = set_device(c);
+    if (rc) return rc;
+    if (!ell_arr && has_ell) DXH_REQUIRE(ell != 0.0, "ell must be non-zero");
+    rc = c->desc.dtype == DXH_F32 ? set_coeffs_t<float>(c, mu, mu_arr, omega, omega_arr, has_ell, ell, ell_arr, 1.0, true)
+                                  : set_coeffs_t<double>(c, mu, mu_arr, omega, omega_arr, has_ell, ell, ell_arr, 1.0, true);
+    if (rc) return rc;
+    // omega array: kept as a plane, upload multiplies it into the image
+    if (omega_arr) {
+        if ((rc = alloc_plane(c, &c->om_plane))) return rc;
+        if ((rc = h2d_plane(c, c->om_plane, omega_arr))) return rc;
+        DXH_HIP(hipStreamSynchronize(c->stream));
+    } else if (c->om_plane) {
+        DXH_HIP(hipFree(c->om_plane));
+        c->om_plane = nullptr;
+    }
+    c->have_coefs = true;
+    c->uploaded = false;  // omega*img must be rebuilt
+    c->omega_s = omega_arr ? std::numeric_limits<double>::quiet_NaN() : omega;
+    return DXH_OK;
+}
+
+int dxh_tvd_upload(dxh_tvd_t h, const void* img, const void* u0, const void* d0, const void* b0) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    DXH_REQUIRE(c && img, "null argument");
+    if (!c->have_coefs) { set_error("dxh_tvd_set_coeffs must be called before dxh_tvd_upload"); return DXH_ESTATE; }
+    DXH_REQUIRE((d0 == nullptr) == (b0 == nullptr), "d0 and b0 must be given together");
+    int rc = set_device(c);
+    if (rc) return rc;
+    const bool f32 = c->desc.dtype == DXH_F32;
+    const int dim = c->desc.dim;
+    c->cur = 0;
+    // img -> u[0]; norm; of = omega * img
+    if ((rc = h2d_plane(c, c->u[0], img))) return rc;
+    rc = f32 ? sq_diff<float>(c, c->u[0], nullptr, 0, c->g.n0, &c->sq_img, 1)
+             : sq_diff<double>(c, c->u[0], nullptr, 0, c->g.n0, &c->sq_img, 1);
+    if (rc) return rc;
+    const bool om_arr = std::isnan(c->omega_s);
+    if (f32)
+        hipLaunchKernelGGL((k_scale<float>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const float*)c->u[0],
+                           (float)c->omega_s, om_arr ? (const float*)c->om_plane : nullptr, (float*)c->of);
+    else
+        hipLaunchKernelGGL((k_scale<double>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const double*)c->u[0],
+                           c->omega_s, om_arr ? (const double*)c->om_plane : nullptr, (double*)c->of);
+    DXH_HIP(hipGetLastError());
+    if (u0 && (rc = h2d_plane(c, c->u[0], u0))) return rc;
+    for (int j = 0; j < dim; ++j) {
+        DXH_HIP(hipMemsetAsync(c->q[j][0], 0, c->plane_bytes, c->stream));
+        DXH_HIP(hipMemsetAsync(c->q[j][1], 0, c->plane_bytes, c->stream));
+    }
+    DXH_HIP(hipMemsetAsync(c->u[1], 0, c->plane_bytes, c->stream));
+    c->from_db = false;
+    if (d0) {
+        // explicit split variables: keep them as planes for the first iteration
+        const size_t dense = (size_t)c->g.n0 * c->g.L * dim * c->esz;
+        if (!c->stage) DXH_HIP(hipMalloc(&c->stage, dense));
+        for (int pass = 0; pass < 2; ++pass) {
+            void** pl = pass == 0 ? c->dpl : c->bpl;
+            for (int j = 0; j < dim; ++j)
+                if ((rc = alloc_plane(c, &pl[j]))) return rc;
+            DXH_HIP(hipMemcpyAsync(c->stage, pass == 0 ? d0 : b0, dense, hipMemcpyHostToDevice, c->stream));
+            if (f32) {
+                if (dim == 2) hipLaunchKernelGGL((k_deinterleave<float, 2>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const float*)c->stage, (float*)pl[0], (float*)pl[1], (float*)pl[2]);
+                else hipLaunchKernelGGL((k_deinterleave<float, 3>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const float*)c->stage, (float*)pl[0], (float*)pl[1], (float*)pl[2]);
+            } else {
+                if (dim == 2) hipLaunchKernelGGL((k_deinterleave<double, 2>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const double*)c->stage, (double*)pl[0], (double*)pl[1], (double*)pl[2]);
+                else hipLaunchKernelGGL((k_deinterleave<double, 3>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const double*)c->stage, (double*)pl[0], (double*)pl[1], (double*)pl[2]);
+            }
+            DXH_HIP(hipGetLastError());
+            DXH_HIP(hipStreamSynchronize(c->stream));
+        }
+        c->from_db = true;
+    }
+    DXH_HIP(hipStreamSynchronize(c->stream));
+    c->uploaded = true;
+    return DXH_OK;
+}
+
+int dxh_tvd_run(dxh_tvd_t h, int n_iter, int jacobi_maxiter, double jacobi_tol, double eps, double norm_scale,
+                uint32_t flags, dxh_tvd_result* result) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    DXH_REQUIRE(c, "null context");
+    if (!c->uploaded) { set_error("dxh_tvd_upload must be called before dxh_tvd_run"); return DXH_ESTATE; }
+    DXH_REQUIRE(n_iter >= 0, "n_iter must be >= 0");
+    DXH_REQUIRE(jacobi_maxiter >= 0, "jacobi_maxiter must be >= 0");
+    int rc = set_device(c);
+    if (rc) return rc;
+    return c->desc.dtype == DXH_F32 ? run_t<float>(c, n_iter, jacobi_maxiter, jacobi_tol, eps, norm_scale, flags, result)
+                                    : run_t<double>(c, n_iter, jacobi_maxiter, jacobi_tol, eps, norm_scale, flags, result);
+}
+
+int dxh_tvd_download(dxh_tvd_t h, void* u, void* d, void* b) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    DXH_REQUIRE(c, "null context");
+    if (!c->uploaded) { set_error("nothing to download"); return DXH_ESTATE; }
+    int rc = set_device(c);
+    if (rc) return rc;
+    if (u && (rc = d2h_plane(c, u, c->u[c->cur]))) return rc;
+    if (d || b) {
+        const int dim = c->desc.dim;
+        const size_t dense = (size_t)c->g.n0 * c->g.L * dim * c->esz;
+        if (c->from_db) {
+            // nothing ran since the warm start was uploaded: hand the explicit planes back
+            set_error("download of split variables before any iteration is not supported");
+            return DXH_ESTATE;
+        }
+        void *dd = nullptr, *bb = nullptr;
+        if (d) DXH_HIP(hipMalloc(&dd, dense));
+        if (b) DXH_HIP(hipMalloc(&bb, dense));
+        const bool iso = c->last_iso;
+        const dim3 grid = elem_grid(c->g), blk(256);
+#define DXH_EXPAND(T, DIM, ISO) \
+    hipLaunchKernelGGL((k_expand<T, DIM, ISO>), grid, blk, 0, c->stream, c->g, make_q<T, DIM>(c, c->cur, c->cur), \
+                       make_coef<T>(c), make_planes<T>(c), (T*)dd, (T*)bb)
+        if (c->desc.dtype == DXH_F32) {
+            if (dim == 2) { if (iso) DXH_EXPAND(float, 2, true); else DXH_EXPAND(float, 2, false); }
+            else          { if (iso) DXH_EXPAND(float, 3, true); else DXH_EXPAND(float, 3, false); }
+        } else {
+            if (dim == 2) { if (iso) DXH_EXPAND(double, 2, true); else DXH_EXPAND(double, 2, false); }
+            else          { if (iso) DXH_EXPAND(double, 3, true); else DXH_EXPAND(double, 3, false); }
+        }
+#undef DXH_EXPAND
+        DXH_HIP(hipGetLastError());
+        if (d) DXH_HIP(hipMemcpyAsync(d, dd, dense, hipMemcpyDeviceToHost, c->stream));
+        if (b) DXH_HIP(hipMemcpyAsync(b, bb, dense, hipMemcpyDeviceToHost, c->stream));
+        DXH_HIP(hipStreamSynchronize(c->stream));
+        if (dd) DXH_HIP(hipFree(dd));
+        if (bb) DXH_HIP(hipFree(bb));
+    }
+    DXH_HIP(hipStreamSynchronize(c->stream));
+    return DXH_OK;
+}
+
+// ---- halo plumbing -------------------------------------------------------------------------------
+int dxh_tvd_halo_bytes(dxh_tvd_t h, int64_t nrows, size_t* bytes) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    DXH_REQUIRE(c && bytes && nrows >= 0, "bad argument");
+    *bytes = (size_t)(1 + c->desc.dim) * (size_t)nrows * (size_t)c->g.pitch * c->esz;
+    return DXH_OK;
+}
+
+static int halo_copy(Ctx* c, int64_t row0, int64_t nrows, void* buf, bool pack) {
+    DXH_REQUIRE(row0 >= 0 && nrows >= 0 && row0 + nrows <= c->g.n0, "row range [%lld, %lld) outside the slab",
+                (long long)row0, (long long)(row0 + nrows));
+    if (c->from_db) { set_error("halo exchange before the first iteration of a warm start is not supported"); return DXH_ESTATE; }
+    int rc = set_device(c);
+    if (rc) return rc;
+    const size_t row_bytes = (size_t)c->g.pitch * c->esz;
+    const size_t blk = (size_t)nrows * row_bytes;
+    if (blk == 0) return DXH_OK;
+    char* p = static_cast<char*>(buf);
+    void* fields[4] = {c->u[c->cur], c->q[0][c->cur], c->q[1][c->cur], c->q[2][c->cur]};
+    for (int f = 0; f < 1 + c->desc.dim; ++f) {
+        char* fld = static_cast<char*>(fields[f]) + (size_t)row0 * row_bytes;
+        if (pack)
+            DXH_HIP(hipMemcpyAsync(p + f * blk, fld, blk, hipMemcpyDeviceToDevice, c->stream));
+        else
+            DXH_HIP(hipMemcpyAsync(fld, p + f * blk, blk, hipMemcpyDeviceToDevice, c->stream));
+    }
+    return DXH_OK;
+}
+
+int dxh_tvd_pack_rows(dxh_tvd_t h, int64_t row0, int64_t nrows, void* dst) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    DXH_REQUIRE(c && dst, "null argument");
+    return halo_copy(c, row0, nrows, dst, true);
+}
+int dxh_tvd_unpack_rows(dxh_tvd_t h, int64_t row0, int64_t nrows, const void* src) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    DXH_REQUIRE(c && src, "null argument");
+    return halo_copy(c, row0, nrows, const_cast<void*>(src), false);
+}
+
+int dxh_tvd_partial_norms(dxh_tvd_t h, int64_t row0, int64_t nrows, double* sq_inc, double* sq_img) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    DXH_REQUIRE(c, "null context");
+    DXH_REQUIRE(row0 >= 0 && nrows >= 0 && row0 + nrows <= c->g.n0, "row range outside the slab");
+    if (!c->uploaded) { set_error("nothing uploaded"); return DXH_ESTATE; }
+    int rc = set_device(c);
+    if (rc) return rc;
+    const bool f32 = c->desc.dtype == DXH_F32;
+    if (sq_inc) {
+        rc = f32 ? sq_diff<float>(c, c->u[c->cur], c->u[c->cur ^ 1], row0, nrows, sq_inc, 0)
+                 : sq_diff<double>(c, c->u[c->cur], c->u[c->cur ^ 1], row0, nrows, sq_inc, 0);
+        if (rc) return rc;
+    }
+    if (sq_img) {
+        // img = of / omega is not kept; the slab norm over a row range is recomputed from `of` only for
+        // scalar omega (exact up to the rounding of omega*img); callers with array omega pass row0=0,nrows=n0.
+        if (row0 == 0 && nrows == c->g.n0) {
+            *sq_img = c->sq_img;
+        } else {
+            DXH_REQUIRE(!std::isnan(c->omega_s) && c->omega_s != 0.0, "partial image norm needs a scalar, non-zero omega");
+            double s = 0.0;
+            rc = f32 ? sq_diff<float>(c, c->of, nullptr, row0, nrows, &s, 1) : sq_diff<double>(c, c->of, nullptr, row0, nrows, &s, 1);
+            if (rc) return rc;
+            *sq_img = s / (c->omega_s * c->omega_s);
+        }
+    }
+    return DXH_OK;
+}
+
+int dxh_tvd_sync(dxh_tvd_t h) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    DXH_REQUIRE(c, "null context");
+    DXH_HIP(hipStreamSynchronize(c->stream));
+    return DXH_OK;
+}
+
+// ---- one-shot helpers ----------------------------------------------------------------------------
+int dxh_jacobi_solve(int device, int dtype, int ndim, int dim, int nsum, int64_t n0, int64_t n1, int64_t n2,
+                     const void* x0, const void* rhs, void* out, double mass, const void* mass_arr, double diffusion,
+                     const void* diffusion_arr, double h, int maxiter, double tol, int* sweeps_done) {
+    DXH_REQUIRE(x0 && rhs && out, "null argument");
+    DXH_REQUIRE(maxiter >= 0, "maxiter must be >= 0");
+    DXH_REQUIRE(h > 0.0, "h must be positive");
+    dxh_tvd_desc d{};
+    d.struct_size = sizeof d;
+    d.device = device;
+    d.dtype = dtype;
+    d.ndim = ndim;
+    d.dim = dim;
+    d.nsum = nsum;
+    d.n0 = n0; d.n1 = n1; d.n2 = n2;
+    d.top_is_boundary = d.bottom_is_boundary = 1;
+    dxh_tvd_t hctx = nullptr;
+    int rc = dxh_tvd_create(&hctx, &d);
+    if (rc) return rc;
+    Ctx* c = reinterpret_cast<Ctx*>(hctx);
+    auto body = [&]() -> int {
+        int r;
+        // mass plays omega, diffusion plays ell; mu is unused (kq not needed)
+        r = dtype == DXH_F32 ? set_coeffs_t<float>(c, 0.0, nullptr, mass, mass_arr, 1, diffusion, diffusion_arr, h, false)
+                             : set_coeffs_t<double>(c, 0.0, nullptr, mass, mass_arr, 1, diffusion, diffusion_arr, h, false);
+        if (r) return r;
+        if ((r = alloc_plane(c, &c->rs))) return r;
+        if ((r = h2d_plane(c, c->u[0], x0))) return r;
+        if ((r = h2d_plane(c, c->u[1], rhs))) return r;
+        // rs = rhs / diag
+        if (dtype == DXH_F32)
+            hipLaunchKernelGGL((k_divide<float>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const float*)c->u[1],
+                               (float)c->c_diag, (const float*)c->cp_diag, (float*)c->rs);
+        else
+            hipLaunchKernelGGL((k_divide<double>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const double*)c->u[1],
+                               c->c_diag, (const double*)c->cp_diag, (double*)c->rs);
+        DXH_HIP(hipGetLastError());
+        void* tmp = nullptr;
+        if (maxiter > 1) DXH_HIP(hipMalloc(&tmp, c->plane_bytes));
+        c->cur = 0;
+        int64_t launches = 0;
+        r = dtype == DXH_F32 ? jacobi_sweeps<float>(c, maxiter, tol, tmp, &launches, sweeps_done)
+                             : jacobi_sweeps<double>(c, maxiter, tol, tmp, &launches, sweeps_done);
+        if (!r) r = d2h_plane(c, out, c->u[1]);
+        if (!r && hipStreamSynchronize(c->stream) != hipSuccess) { set_error("stream sync failed"); r = DXH_EHIP; }
+        if (tmp) (void)hipFree(tmp);
+        return r;
+    };
+    rc = body();
+    dxh_tvd_destroy(hctx);
+    return rc;
+}
+
+int dxh_diff(int device, int dtype, int64_t n0, int64_t n1, int64_t n2, int axis, int mode, double h, const void* in,
+             void* out) {
+    DXH_REQUIRE(in && out, "null argument");
+    DXH_REQUIRE(axis >= 0 && axis < 3, "axis must be 0, 1 or 2");
+    DXH_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (backward) or 1 (forward)");
+    dxh_tvd_desc d{};
+    d.struct_size = sizeof d;
+    d.device = device;
+    d.dtype = dtype;
+    d.ndim = 3;
+    d.dim = 2;
+    d.nsum = DXH_NSUM_ALL_AXES;
+    d.n0 = n0; d.n1 = n1; d.n2 = n2;
+    d.top_is_boundary = d.bottom_is_boundary = 1;
+    dxh_tvd_t hctx = nullptr;
+    int rc = dxh_tvd_create(&hctx, &d);
+    if (rc) return rc;
+    Ctx* c = reinterpret_cast<Ctx*>(hctx);
+    auto body = [&]() -> int {
+        int r;
+        if ((r = h2d_plane(c, c->u[0], in))) return r;
+        if (dtype == DXH_F32)
+            hipLaunchKernelGGL((k_diff<float>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const float*)c->u[0], axis,
+                               mode, (float)h, h > 0.0 ? 1 : 0, (float*)c->u[1]);
+        else
+            hipLaunchKernelGGL((k_diff<double>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const double*)c->u[0],
+                               axis, mode, h, h > 0.0 ? 1 : 0, (double*)c->u[1]);
+        DXH_HIP(hipGetLastError());
+        if ((r = d2h_plane(c, out, c->u[1]))) return r;
+        DXH_HIP(hipStreamSynchronize(c->stream));
+        return DXH_OK;
+    };
+    rc = body();
+    dxh_tvd_destroy(hctx);
+    return rc;
+}
+
+}  // extern "C"

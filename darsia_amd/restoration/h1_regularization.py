@@ -1,0 +1,55 @@
+"""H1 regularisation (reference: restoration/h1_regularization.py:15-146): one
+Jacobi solve of ``omega*u - mu*laplace(u) = omega*img``; arrays with more axes
+than ``dim`` are treated channel by channel (no channel coupling here, unlike
+the TV path -- h1_regularization.py:54-67)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from .. import _lib
+from ..utils.linear_solvers.jacobi import Jacobi
+from ..utils.linear_solvers.solver import Solver
+
+
+def _h1_array(img: np.ndarray, mu: float, omega: float, dim: int, solver: Solver) -> np.ndarray:
+    if img.dtype.kind != "f":
+        raise TypeError("H1_regularization needs a float32/float64 image")
+    if not isinstance(solver, Jacobi):
+        raise NotImplementedError("only darsia_amd.Jacobi is available on the device path")
+    solver.update_params(mass_coeff=omega, diffusion_coeff=mu, dim=dim)
+    code = _lib.dtype_code(img.dtype)
+    _lib.require_gpu()
+    src = np.ascontiguousarray(img)
+    if img.ndim == dim + 1 and dim == 2:
+        # all channels in one launch: neighbour sum restricted to the spatial axes
+        ndim, n0, n1, n2 = _lib.shape3(img.shape, dim)
+        nsum = _lib.NSUM_SPATIAL
+    elif img.ndim == dim:
+        ndim, n0, n1, n2 = _lib.shape3(img.shape, dim)
+        nsum = _lib.NSUM_ALL_AXES
+    else:
+        raise ValueError(f"image with {img.ndim} axes and dim={dim} not supported")
+    rhs = np.ascontiguousarray(omega * src, dtype=img.dtype)
+    out = np.empty_like(src)
+    done = C.c_int(0)
+    _lib.check(_lib.load().dxh_jacobi_solve(
+        _lib.default_device(), code, ndim, dim, nsum, n0, n1, n2, _lib.ptr(src), _lib.ptr(rhs), _lib.ptr(out),
+        float(omega), None, float(mu), None, 1.0, int(solver.maxiter), -1.0 if solver.tol is None else float(solver.tol),
+        C.byref(done)))
+    return out
+
+
+def H1_regularization(img, mu: float, omega: float = 1.0, dim: int = 2, solver: Optional[Solver] = None):
+    """Inline application of H1 regularisation to an array or an Image-like object."""
+    if solver is None:
+        solver = Jacobi()
+    if isinstance(img, np.ndarray):
+        return _h1_array(img, mu, omega, dim, solver)
+    if hasattr(img, "img") and hasattr(img, "copy"):
+        out = img.copy()
+        out.img = _h1_array(img.img, mu, omega, dim, solver)
+        return out
+    raise TypeError(f"Type {type(img)} not supported.")

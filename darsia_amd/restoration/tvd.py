@@ -1,0 +1,74 @@
+"""``TVD`` / ``tvd``: DarSIA's TV-denoising operator interface (reference:
+restoration/tvd.py:15-163) in front of the MI355X split-Bregman implementation.
+
+The constructor reproduces the reference's kwarg handling: ``key``-prefixed
+``method`` / ``weight`` / ``max_num_iter`` / ``eps``, un-prefixed ``omega`` and
+``regularization`` for the heterogeneous method, leftovers forwarded.
+
+Divergence: the reference only *reads* ``regularization``
+(tvd.py:37) and then forwards it a second time through ``**kwargs``, which
+raises ``TypeError`` inside ``split_bregman_tvd``.  Here it is popped, so
+``TVD(method="heterogeneous bregman", regularization=...)`` works.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .split_bregman_tvd import split_bregman_tvd
+
+_SKIMAGE_METHODS = ("chambolle", "anisotropic bregman", "isotropic bregman")
+
+
+def _is_image(obj) -> bool:
+    """darsia.Image duck type: carries ``.img`` and can ``copy()`` itself."""
+    return hasattr(obj, "img") and hasattr(obj, "copy") and not isinstance(obj, np.ndarray)
+
+
+class TVD:
+    """Total variation denoising interface (tvd.py:15-129)."""
+
+    def __init__(self, key: str = "", **kwargs) -> None:
+        self.method = kwargs.pop(key + "method", "chambolle").lower()
+        if self.method == "heterogeneous bregman":
+            self.omega = kwargs.pop("omega", 1)
+            self.regularization = kwargs.pop("regularization", 1.0)
+        self.weight = kwargs.pop(key + "weight", 0.1)
+        self.max_num_iter = kwargs.pop(key + "max_num_iter", 200)
+        self.eps = kwargs.pop(key + "eps", 2e-4)
+        self.kwargs = kwargs
+
+    def __call__(self, img):
+        if isinstance(img, np.ndarray):
+            return self._tvd_array(img)
+        elif _is_image(img):
+            return self._tvd_image(img)
+        else:
+            raise TypeError(f"Input type {type(img)} not supported.")
+
+    def _tvd_array(self, img: np.ndarray) -> np.ndarray:
+        if self.method == "heterogeneous bregman":
+            return split_bregman_tvd(
+                img,
+                mu=self.weight,
+                omega=self.omega,
+                ell=self.regularization,
+                max_num_iter=self.max_num_iter,
+                eps=self.eps,
+                **self.kwargs,
+            )
+        elif self.method in _SKIMAGE_METHODS:
+            raise NotImplementedError(
+                f"method '{self.method}' is scikit-image arithmetic (tvd.py:77-101), not part of the MI355X "
+                "hot path yet; use method='heterogeneous bregman'")
+        else:
+            raise ValueError(f"Method {self.method} not supported.")
+
+    def _tvd_image(self, img):
+        img_copy = img.copy()
+        img_copy.img = self._tvd_array(img.img)
+        return img_copy
+
+
+def tvd(img, method: str = "chambolle", weight=1.0, max_num_iter: int = 200, eps: float = 2e-4, **kwargs):
+    """Inline application of TVD (tvd.py:132-163)."""
+    return TVD(method=method, weight=weight, max_num_iter=max_num_iter, eps=eps, **kwargs)(img)

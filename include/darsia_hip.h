@@ -1,0 +1,157 @@
+/*
+ * darsia_hip.h -- C ABI of libdarsia_hip.so: MI355X (gfx950) kernels for DarSIA's
+ * dense image hot path (split-Bregman TV denoising, Jacobi/H1 smoothing,
+ * derivatives, affine colour apply).
+ *
+ * The reference (pmgbergen/DarSIA) is pure Python and has no FFI layer; its
+ * boundary for this path is Python duck typing.  Every entry point below names
+ * the reference function whose arithmetic it replaces (file:line relative to
+ * /root/reference/src/darsia).  INTEGRATION.md shows the ctypes stub a DarSIA
+ * maintainer would add to bind them.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative DXH_E* code otherwise;
+ *     dxh_last_error() gives the message for the calling thread.  Never aborts.
+ *   - host arrays are caller-owned, C-contiguous, never retained.
+ *   - a context owns its device buffers and (unless given one) its stream; one
+ *     context per host thread at a time, not re-entrant.
+ *   - dtype: 0 = float32, 1 = float64.
+ *   - an image/volume is described as an array of up to 3 axes (n0, n1, n2)
+ *     stored row-major; a 2-D image has ndim = 2 and n2 = 1.  `dim` is the
+ *     number of leading SPATIAL axes (reference `dim`), so an (H, W, 3) colour
+ *     image is ndim = 3, dim = 2.
+ */
+#ifndef DARSIA_HIP_H
+#define DARSIA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DXH_OK 0
+#define DXH_EINVAL -1   /* bad argument (maps to Python ValueError/TypeError) */
+#define DXH_EHIP -2     /* HIP runtime error */
+#define DXH_ENOMEM -3   /* device allocation failed */
+#define DXH_ESTATE -4   /* call order violated (e.g. run before upload) */
+
+#define DXH_F32 0
+#define DXH_F64 1
+
+/* which Jacobi neighbour sum to use */
+#define DXH_NSUM_ALL_AXES 0 /* reference behaviour inside split_bregman_tvd: every array axis
+                               (utils/linear_solvers/jacobi.py:41), i.e. colour channels are coupled */
+#define DXH_NSUM_SPATIAL 1  /* only the `dim` spatial axes (what H1_regularization's per-channel loop
+                               computes, restoration/h1_regularization.py:54-67) */
+
+/* run flags */
+#define DXH_FLAG_ISOTROPIC 1u /* split_bregman_tvd(isotropic=True), split_bregman_tvd.py:136-140 */
+#define DXH_FLAG_NO_FUSED 2u  /* force the three-kernel path (rhs / Jacobi sweep / shrink) */
+#define DXH_FLAG_NO_DPP 4u    /* fused kernel: use ds_bpermute lane exchange instead of DPP */
+
+const char* dxh_last_error(void);
+int dxh_version(void);
+
+/* number of visible HIP devices (0 when there is none; never an error) */
+int dxh_device_count(int* count);
+
+typedef struct dxh_tvd_ctx* dxh_tvd_t;
+
+typedef struct dxh_tvd_desc {
+    int32_t struct_size; /* = sizeof(dxh_tvd_desc) */
+    int32_t device;      /* HIP device ordinal */
+    int32_t dtype;       /* DXH_F32 / DXH_F64 */
+    int32_t ndim;        /* 2 or 3 array axes */
+    int32_t dim;         /* 2 or 3 spatial axes, dim <= ndim */
+    int32_t nsum;        /* DXH_NSUM_* */
+    int64_t n0, n1, n2;  /* array shape; n2 = 1 when ndim == 2.  n0 = rows of THIS slab, halo rows included */
+    int32_t top_is_boundary;    /* 1: row 0 is the image boundary (replicate ghosts); 0: halo, rows decay */
+    int32_t bottom_is_boundary; /* 1: row n0-1 is the image boundary */
+    void* stream;        /* optional hipStream_t to run on (e.g. the current torch stream); NULL = own */
+} dxh_tvd_desc;
+
+/*
+ * Device-resident state of one split-Bregman problem (or of one row slab of it).
+ * Replaces the arrays set up in restoration/split_bregman_tvd.py:93-101.
+ */
+int dxh_tvd_create(dxh_tvd_t* ctx, const dxh_tvd_desc* desc);
+int dxh_tvd_destroy(dxh_tvd_t ctx);
+
+/*
+ * Coefficients mu (TV weight), omega (mass weight), ell (Bregman regularisation);
+ * split_bregman_tvd.py:18-20,62-68 and jacobi.py:57-72.  Each may be a scalar or a
+ * host array with the image's shape and dtype (pointer non-NULL).  has_ell = 0
+ * means ell = 2 * mu (split_bregman_tvd.py:62-63).  Scalars are doubles; all
+ * derived constants (diag, diag/ell, mu/ell) are formed in double and rounded to
+ * the image dtype once, like NumPy's weak Python scalars.
+ */
+int dxh_tvd_set_coeffs(dxh_tvd_t ctx, double mu, const void* mu_arr, double omega, const void* omega_arr,
+                       int has_ell, double ell, const void* ell_arr);
+
+/*
+ * Upload the image (split_bregman_tvd.py:99) and, optionally, a warm start
+ * x0 = (u0, d0, b0) (split_bregman_tvd.py:93-97).  d0/b0 use the reference's
+ * layout: shape (*img.shape, dim), split index last.  u0 = NULL starts from img,
+ * d0 = b0 = NULL from zeros.  Coefficients must have been set before.
+ */
+int dxh_tvd_upload(dxh_tvd_t ctx, const void* img, const void* u0, const void* d0, const void* b0);
+
+typedef struct dxh_tvd_result {
+    int32_t iters_done;   /* outer iterations executed */
+    int32_t converged;    /* 1 if the eps criterion stopped the loop */
+    double rel_increment; /* last ||u_new - u|| / ||img||  (NaN when eps was not requested) */
+    double loop_ms;       /* device time of the iteration loop (hipEvents on the context stream) */
+    int64_t launches;     /* kernels launched inside the timed loop */
+} dxh_tvd_result;
+
+/*
+ * The iteration loop, split_bregman_tvd.py:129-175 with Jacobi.__call__
+ * (jacobi.py:74-133) as inner solver.  eps < 0 or NaN: no convergence test.
+ * jacobi_tol < 0 or NaN: fixed number of sweeps.  norm_scale: the caller may
+ * pass ||img||_2 of the WHOLE image when this context holds only a slab
+ * (<= 0: computed from this context's image).
+ */
+int dxh_tvd_run(dxh_tvd_t ctx, int n_iter, int jacobi_maxiter, double jacobi_tol, double eps, double norm_scale,
+                uint32_t flags, dxh_tvd_result* result);
+
+/* download u and (optionally) the split variables d, b in the reference layout (*img.shape, dim). */
+int dxh_tvd_download(dxh_tvd_t ctx, void* u, void* d, void* b);
+
+/*
+ * Row-slab halo plumbing for multi-GPU runs (no reference counterpart: the
+ * reference is single-process).  Rows [row0, row0 + nrows) of the three evolving
+ * fields u, dub_0.. are copied to / from a caller-provided DEVICE buffer of
+ * dxh_tvd_halo_bytes() bytes on the context stream.
+ */
+int dxh_tvd_halo_bytes(dxh_tvd_t ctx, int64_t nrows, size_t* bytes);
+int dxh_tvd_pack_rows(dxh_tvd_t ctx, int64_t row0, int64_t nrows, void* dst_device);
+int dxh_tvd_unpack_rows(dxh_tvd_t ctx, int64_t row0, int64_t nrows, const void* src_device);
+/* sum over rows [row0, row0+nrows) of (u - u_prev)^2 of the last iteration and of img^2 (for a global eps test) */
+int dxh_tvd_partial_norms(dxh_tvd_t ctx, int64_t row0, int64_t nrows, double* sq_increment, double* sq_img);
+int dxh_tvd_sync(dxh_tvd_t ctx);
+
+/*
+ * One-shot Jacobi solve  mass * x - diffusion * laplace(x) = rhs  (jacobi.py:74-133),
+ * used by Jacobi.__call__ and H1_regularization (h1_regularization.py:54-70).
+ * x0, rhs, out: host arrays of shape (n0, n1, n2).  Returns the iterate count in
+ * *sweeps_done (with tol the reference returns the iterate BEFORE the one that
+ * met the tolerance; kept).
+ */
+int dxh_jacobi_solve(int device, int dtype, int ndim, int dim, int nsum, int64_t n0, int64_t n1, int64_t n2,
+                     const void* x0, const void* rhs, void* out, double mass, const void* mass_arr,
+                     double diffusion, const void* diffusion_arr, double h, int maxiter, double tol,
+                     int* sweeps_done);
+
+/*
+ * Finite differences (utils/derivatives.py:16-59): mode 0 = backward_diff
+ * (x[i+1]-x[i], last 0), 1 = forward_diff (x[i]-x[i-1], first 0); h <= 0: no scaling.
+ */
+int dxh_diff(int device, int dtype, int64_t n0, int64_t n1, int64_t n2, int axis, int mode, double h,
+             const void* in, void* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DARSIA_HIP_H */

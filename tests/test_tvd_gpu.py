@@ -1,0 +1,229 @@
+"""Parity of the HIP path (through the C ABI) with the oracle and the golden
+vectors.  Needs a real MI355X: ``pytest -m gpu``.
+
+Bars (north star: rtol 1e-4 vs the CPU path):
+* vs the oracle's same-dtype flow ("strict"): BIT-EXACT -- the kernels perform
+  the same IEEE operations in the same order (-ffp-contract=off);
+* vs the golden vectors from the imported reference: float64 bit-exact;
+  float32 within rtol 1e-4 / atol 1e-6 (the reference promotes the float32
+  Jacobi iterate to float64 under NumPy >= 2, the kernels stay in float32).
+"""
+import numpy as np
+import pytest
+
+import darsia_amd as da
+from darsia_amd import _lib
+from oracle import tvd_numpy as O
+from conftest import split_last_axis
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-4, 1e-6
+
+VARIANTS = {"fused_dpp": 0, "fused_bpermute": _lib.FLAG_NO_DPP, "three_kernel": _lib.FLAG_NO_FUSED}
+
+
+def run_device(img, mu=1.0, omega=1.0, ell=None, dim=2, n_iter=10, eps=None, isotropic=False, jm=1, jtol=None,
+               flags=0, x0=None, want_split=False):
+    with da.DeviceTVD(img.shape, img.dtype, dim=dim) as st:
+        st.set_coeffs(mu, omega, ell, img)
+        if x0 is None:
+            st.upload(img)
+        else:
+            st.upload(img, *x0)
+        res = st.run(n_iter, jm, jtol, eps=eps, isotropic=isotropic, flags=flags)
+        out = st.download(want_split=want_split)
+    return out, res
+
+
+def assert_bits(a, b):
+    assert a.dtype == b.dtype and a.shape == b.shape
+    if not np.array_equal(a, b):
+        diff = np.abs(a.astype(np.float64) - b.astype(np.float64))
+        raise AssertionError(f"not bit-exact: {np.count_nonzero(diff)} of {diff.size} differ, max abs {diff.max():.3e}")
+
+
+CASES = [
+    ("g1_aniso2d_f64", dict(mu=0.1), 20),
+    ("g2_aniso2d_f32", dict(mu=0.1), 20),
+    ("g3_aniso_rgb_f32", dict(mu=0.1), 10),
+    ("g3_aniso_rgb_f64", dict(mu=0.1), 10),
+    ("g3_aniso_rgb_odd_f32", dict(mu=0.15, omega=0.7), 7),
+    ("g3_aniso_2ch_odd_f32", dict(mu=0.1), 6),
+    ("g2_aniso2d_odd_f32", dict(mu=0.2, ell=0.3), 9),
+    ("g2_tiny_f32", dict(mu=0.1), 4),
+    ("g2_tiny_col_f32", dict(mu=0.1), 4),
+    ("g2_single_px_f32", dict(mu=0.1), 3),
+]
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+@pytest.mark.parametrize("name,kw,n", CASES, ids=[c[0] for c in CASES])
+def test_anisotropic_scalar(golden, name, kw, n, variant):
+    img = golden[name + "/img"]
+    out, res = run_device(img, n_iter=n, flags=VARIANTS[variant], **kw)
+    assert res.iters_done == n
+    assert_bits(out, O.split_bregman_tvd(img, max_num_iter=n, promotion="strict", **kw))
+    ref = golden[name + "/out"]
+    if img.dtype == np.float64:
+        assert_bits(out, ref)
+    else:
+        np.testing.assert_allclose(out, ref, rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_isotropic(golden, variant):
+    img = golden["g4_iso2d_f64/img"]
+    out, _ = run_device(img, mu=0.1, n_iter=10, isotropic=True, flags=VARIANTS[variant])
+    assert_bits(out, O.split_bregman_tvd(img, mu=0.1, max_num_iter=10, isotropic=True, promotion="strict"))
+    np.testing.assert_allclose(out, golden["g4_iso2d_f64/out"], rtol=1e-13, atol=0)
+    # extension beyond the reference: float32 and colour
+    rgb = golden["g3_aniso_rgb_f32/img"]
+    out, _ = run_device(rgb, mu=0.1, n_iter=6, isotropic=True, flags=VARIANTS[variant])
+    assert_bits(out, O.split_bregman_tvd(rgb, mu=0.1, max_num_iter=6, isotropic=True, promotion="strict"))
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_heterogeneous_coefficients(golden, variant):
+    g, fl = golden, VARIANTS[variant]
+    for name, kw, n in (
+        ("g5_het_mu_f64", dict(mu=g["g5_het_mu_f64/mu"], omega=0.1), 12),
+        ("g5_het_mu_f32", dict(mu=g["g5_het_mu_f32/mu"], omega=0.1), 12),
+        ("g5_het_omega_f64", dict(mu=0.1, omega=g["g5_het_omega_f64/omega"], ell=0.25), 8),
+        ("g5_het_mu_rgb_f32", dict(mu=g["g5_het_mu_rgb_f32/mu"]), 6),
+    ):
+        img = g[name + "/img"]
+        out, _ = run_device(img, n_iter=n, flags=fl, **kw)
+        assert_bits(out, O.split_bregman_tvd(img, max_num_iter=n, promotion="strict", **kw))
+        if img.dtype == np.float64:
+            assert_bits(out, g[name + "/out"])
+        else:
+            np.testing.assert_allclose(out, g[name + "/out"], rtol=RTOL, atol=ATOL)
+
+
+def test_inner_solver_variants(golden):
+    g = golden
+    out, _ = run_device(g["g6_jacobi3_f64/img"], mu=0.1, n_iter=8, jm=3)
+    assert_bits(out, g["g6_jacobi3_f64/out"])
+    out, _ = run_device(g["g6_jacobi3_rgb_f32/img"], mu=0.1, n_iter=5, jm=3)
+    assert_bits(out, O.split_bregman_tvd(g["g6_jacobi3_rgb_f32/img"], mu=0.1, max_num_iter=5, jacobi_maxiter=3,
+                                         promotion="strict"))
+    np.testing.assert_allclose(out, g["g6_jacobi3_rgb_f32/out"], rtol=RTOL, atol=ATOL)
+    out, _ = run_device(g["g6_jacobi_tol_f64/img"], mu=0.1, n_iter=6, jm=20, jtol=1e-3)
+    assert_bits(out, g["g6_jacobi_tol_f64/out"])
+
+
+@pytest.mark.parametrize("name,eps", [("g7_eps_f64", 1e-3), ("g7_eps_f32", 1e-3), ("g7_eps_rgb_f32", 2e-3)])
+def test_early_stop(golden, name, eps):
+    img = golden[name + "/img"]
+    out, res = run_device(img, mu=0.1, n_iter=100, eps=eps)
+    assert res.converged == 1
+    assert res.iters_done == int(golden[name + "/iters"])
+    np.testing.assert_allclose(out, golden[name + "/out"], rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_warm_start_in_reference_layout(golden, tag):
+    """x0 = (img0, d0, b0) with (*shape, dim) split variables, updated in place (split_bregman_tvd.py:93-97)."""
+    g = golden
+    img = g[f"g8_warm_{tag}/img"]
+    d = np.zeros(img.shape + (2,), img.dtype)
+    b = np.zeros(img.shape + (2,), img.dtype)
+    first = da.split_bregman_tvd(img, mu=0.1, max_num_iter=5, x0=(img.copy(), d, b))
+    tol = dict(rtol=0, atol=0) if tag == "f64" else dict(rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(first, g[f"g8_warm_{tag}/first"], **tol)
+    np.testing.assert_allclose(d, g[f"g8_warm_{tag}/d5"], **tol)
+    np.testing.assert_allclose(b, g[f"g8_warm_{tag}/b5"], **tol)
+    second = da.split_bregman_tvd(img, mu=0.1, max_num_iter=5, x0=(first, d, b))
+    np.testing.assert_allclose(second, g[f"g8_warm_{tag}/second"], **tol)
+    np.testing.assert_allclose(d, g[f"g8_warm_{tag}/d10"], **tol)
+    np.testing.assert_allclose(b, g[f"g8_warm_{tag}/b10"], **tol)
+    # and 5 + 5 warm-started iterations equal 10 straight ones bit for bit
+    straight = da.split_bregman_tvd(img, mu=0.1, max_num_iter=10)
+    assert_bits(second, straight)
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_volume_dim3(golden, tag):
+    img = golden[f"g9_vol3d_{tag}/img"]
+    out = da.split_bregman_tvd(img, mu=0.1, dim=3, max_num_iter=6)
+    assert_bits(out, O.split_bregman_tvd(img, mu=0.1, dim=3, max_num_iter=6, promotion="strict"))
+    if tag == "f64":
+        assert_bits(out, golden[f"g9_vol3d_{tag}/out"])
+    else:
+        np.testing.assert_allclose(out, golden[f"g9_vol3d_{tag}/out"], rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("tag", ["2d_f64", "2d_f32", "rgb_f32"])
+def test_h1_regularization(golden, tag):
+    img = golden[f"g10_h1_{tag}/img"]
+    out = da.H1_regularization(img, mu=0.4, omega=1.3, dim=2, solver=da.Jacobi(maxiter=4))
+    assert_bits(out, O.h1_regularization(img, mu=0.4, omega=1.3, dim=2, jacobi_maxiter=4, promotion="strict"))
+    if img.dtype == np.float64:
+        assert_bits(out, golden[f"g10_h1_{tag}/out"])
+    else:
+        np.testing.assert_allclose(out, golden[f"g10_h1_{tag}/out"], rtol=RTOL, atol=ATOL)
+
+
+def test_jacobi_operator(golden):
+    img = golden["g1_aniso2d_f64/img"]
+    s = da.Jacobi(maxiter=5, mass_coeff=1.0, diffusion_coeff=0.7, dim=2)
+    assert_bits(s(img, 1.0 * img), O.jacobi(img, 1.0 * img, 1.0, 0.7, dim=2, maxiter=5))
+    s = da.Jacobi(maxiter=30, tol=1e-2, mass_coeff=1.0, diffusion_coeff=0.7, dim=2)
+    assert_bits(s(img, 1.0 * img), O.jacobi(img, 1.0 * img, 1.0, 0.7, dim=2, maxiter=30, tol=1e-2))
+
+
+def test_derivatives(golden):
+    g = golden
+    a2, a3 = g["g11_diff/a2"], g["g11_diff/a3"]
+    for ax in range(2):
+        assert_bits(da.backward_diff(a2, ax), g[f"g11_diff/a2_bwd{ax}"])
+        assert_bits(da.forward_diff(a2, ax), g[f"g11_diff/a2_fwd{ax}"])
+        assert_bits(da.backward_diff(a2, ax, h=0.5), g[f"g11_diff/a2_bwd{ax}_h"])
+        assert_bits(da.backward_diff(a3, ax), g[f"g11_diff/a3_bwd{ax}"])
+        assert_bits(da.forward_diff(a3, ax), g[f"g11_diff/a3_fwd{ax}"])
+    assert_bits(da.backward_diff(a3, 2, dim=3), g["g11_diff/a3_bwd2"])
+    assert_bits(da.forward_diff(a3, 2, dim=3), g["g11_diff/a3_fwd2"])
+    assert_bits(da.laplace(a2), g["g11_diff/a2_lap"])
+    assert_bits(da.laplace(a2, h=0.5, diffusion_coeff=2.0), g["g11_diff/a2_lap_h"])
+    assert_bits(da.laplace(a3, dim=3), g["g11_diff/a3_lap3"])
+    assert_bits(da.laplace(a2, axis=1), g["g11_diff/a2_lap_ax1"])
+
+
+def test_tvd_operator_on_array_and_image(golden):
+    img = golden["g13_tvd_call/img"]
+    op = da.TVD(method="heterogeneous bregman", weight=0.1, max_num_iter=6, eps=None)
+    out = op(img)
+    np.testing.assert_allclose(out, golden["g13_tvd_call/out"], rtol=RTOL, atol=ATOL)
+    im = da.Image(img.copy(), tag="frame")
+    res = op(im)
+    assert isinstance(res, da.Image) and res is not im and res.metadata() == {"tag": "frame"}
+    assert_bits(res.img, out)
+    assert_bits(im.img, img)  # input untouched
+    assert_bits(da.tvd(img, method="heterogeneous bregman", weight=0.1, max_num_iter=6, eps=None), out)
+
+
+def test_config1_512_through_public_api(golden):
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden import noisy_blocks
+    g = golden
+    big = noisy_blocks((512, 512), int(g["g12_512/seed"]), np.float64)
+    res = da.split_bregman_tvd(big, mu=0.1, max_num_iter=20)
+    assert_bits(res[:16, :16], g["g12_512/crop_tl"])
+    assert_bits(res[-16:, -16:], g["g12_512/crop_br"])
+    assert_bits(res[248:264, 248:264], g["g12_512/crop_mid"])
+    assert res.sum() == float(g["g12_512/sum"])
+    res32 = da.split_bregman_tvd(big.astype(np.float32), mu=0.1, max_num_iter=20)
+    np.testing.assert_allclose(res32[248:264, 248:264], g["g12_512/crop_mid_f32"], rtol=RTOL, atol=ATOL)
+
+
+def test_wide_image_many_strips_and_chunks():
+    """Sizes that exercise several column strips, row chunks and ragged edges of the fused sweep."""
+    rng = np.random.default_rng(5)
+    for shape in ((70, 523, 3), (301, 260), (9, 1031, 4), (64, 249, 3), (130, 245, 3)):
+        img = rng.random(shape).astype(np.float32)
+        ref = O.split_bregman_tvd(img, mu=0.1, max_num_iter=4, promotion="strict")
+        for fl in VARIANTS.values():
+            out, _ = run_device(img, mu=0.1, n_iter=4, flags=fl)
+            assert_bits(out, ref)
