@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libdarsia_hip.so")
 
 DXH_F32, DXH_F64 = 0, 1
 NSUM_ALL_AXES, NSUM_SPATIAL = 0, 1
-FLAG_ISOTROPIC, FLAG_NO_FUSED, FLAG_NO_DPP = 1, 2, 4
+FLAG_ISOTROPIC, FLAG_NO_FUSED, FLAG_NO_DPP, FLAG_ASYNC = 1, 2, 4, 8
 
 # every symbol include/darsia_hip.h declares (tests check that the library exports them all)
 EXPORTS = (

@@ -310,7 +310,8 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
     int64_t launches = 0;
     int done = 0, converged = 0;
     double rel = std::numeric_limits<double>::quiet_NaN();
-    DXH_HIP(hipEventRecord(c->ev0, c->stream));
+    const bool async = (flags & DXH_FLAG_ASYNC) && !use_eps && !use_tol;
+    if (!async) DXH_HIP(hipEventRecord(c->ev0, c->stream));
     for (int it = 0; it < n_iter; ++it) {
         const int in = c->cur, out = c->cur ^ 1;
         if (fused_ok && !c->from_db) {
@@ -340,11 +341,16 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
         }
     }
     DXH_HIP(hipGetLastError());
-    DXH_HIP(hipEventRecord(c->ev1, c->stream));
-    DXH_HIP(hipStreamSynchronize(c->stream));
-    float ms = 0.f;
-    DXH_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    if (tmp) DXH_HIP(hipFree(tmp));
+    float ms = std::numeric_limits<float>::quiet_NaN();
+    if (!async) {
+        DXH_HIP(hipEventRecord(c->ev1, c->stream));
+        DXH_HIP(hipStreamSynchronize(c->stream));
+        DXH_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    }
+    if (tmp) {
+        if (async) DXH_HIP(hipStreamSynchronize(c->stream));
+        DXH_HIP(hipFree(tmp));
+    }
     if (res) {
         res->iters_done = done;
         res->converged = converged;

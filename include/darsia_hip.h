@@ -50,6 +50,8 @@ extern "C" {
 #define DXH_FLAG_ISOTROPIC 1u /* split_bregman_tvd(isotropic=True), split_bregman_tvd.py:136-140 */
 #define DXH_FLAG_NO_FUSED 2u  /* force the three-kernel path (rhs / Jacobi sweep / shrink) */
 #define DXH_FLAG_NO_DPP 4u    /* fused kernel: use ds_bpermute lane exchange instead of DPP */
+#define DXH_FLAG_ASYNC 8u     /* enqueue only: no event timing, no stream synchronisation (loop_ms = NaN);
+                                 ignored when eps or jacobi_tol need host-side tests */
 
 const char* dxh_last_error(void);
 int dxh_version(void);
