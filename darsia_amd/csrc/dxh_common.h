@@ -68,6 +68,16 @@ __device__ __forceinline__ void store_vec(T* p, const T (&v)[VecOf<T>::N]) {
     *reinterpret_cast<V*>(p) = t;
 }
 
+// streaming (non-temporal) 16-byte store: the written lines are not read again by this launch
+template <typename T>
+__device__ __forceinline__ void store_vec_nt(T* p, const T (&v)[VecOf<T>::N]) {
+    typedef T EV __attribute__((ext_vector_type(VecOf<T>::N)));
+    EV t;
+#pragma unroll
+    for (int j = 0; j < VecOf<T>::N; ++j) t[j] = v[j];
+    __builtin_nontemporal_store(t, reinterpret_cast<EV*>(p));
+}
+
 // ---- cross-lane moves -----------------------------------------------------------------------
 // lane_from<K>(x): value of x held by lane (lane + K), K in {-3..3}; lanes whose source is outside
 // the wave get an unspecified value (callers never use it for a stored result).

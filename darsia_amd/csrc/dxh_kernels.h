@@ -351,29 +351,50 @@ struct FusedArgs {
     int64_t rows_per_chunk;
     int nstrips;       // strips per row
     int nchunks;
+    int remap;         // XCD-aware block -> tile mapping (block_to_tile)
     Coef<T> c;
     CoefPlanes<T> cp;
 };
 
-template <typename T, int C>
+// ALIGN: the lanes that store cover whole 128-byte lines (strip stride rounded down to a multiple of
+// 128 B; row pitch is a multiple of 128 B), so no line is ever written by two waves.  Measured on
+// MI355X with the 4-read/3-write marching stream (tools/membench.hip): +11..14 % over the tight
+// packing (61 of 64 lanes storing), although 5 more lanes per wave only load.
+template <typename T, int C, bool ALIGN = true>
 struct StripGeom {
     static constexpr int N = VecOf<T>::N;
+    static constexpr int LINE = 128 / (int)sizeof(T);   // elements per 128-byte line
     static constexpr int LH = (C + N - 1) / N;          // left halo lanes
-    static constexpr int RH = (2 * C + N - 1) / N;      // right halo lanes
-    static constexpr int VALID = kWave - LH - RH;       // lanes that store
-    static constexpr int STRIDE = VALID * N;            // elements advanced per strip
+    static constexpr int RH = (2 * C + N - 1) / N;      // right halo lanes (minimum)
+    static constexpr int TIGHT = (kWave - LH - RH) * N;
+    static constexpr int STRIDE = ALIGN ? (TIGHT / LINE) * LINE : TIGHT;  // elements advanced per strip
+    static constexpr int VALID = STRIDE / N;            // lanes that store: [LH, LH + VALID)
 };
 
-template <typename T, int C, bool COUPLED, bool ISO, bool HET, bool DPP>
+// blockIdx -> (column block bx, row chunk).  Blocks are dealt round-robin over the 8 XCDs
+// (MI355X_MICROARCH.md, workgroup dispatch), so with nchunks a multiple of 8 the mapping
+// chunk = id % nchunks puts a whole chunk row -- all column strips that share halo columns -- on one
+// XCD's L2.  Placement only affects speed, never results.
+__device__ __forceinline__ void block_to_tile(int bid, int nbx, int nchunks, int& bx, int& chunk) {
+    chunk = bid % nchunks;
+    bx = bid / nchunks;
+}
+
+template <typename T, int C, bool COUPLED, bool ISO, bool HET, bool DPP, bool ALIGN = true, bool NTS = true>
 __global__ void __launch_bounds__(256) k_fused(FusedArgs<T> a) {
     constexpr int N = VecOf<T>::N;
-    using SG = StripGeom<T, C>;
+    using SG = StripGeom<T, C, ALIGN>;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
     constexpr int WPB = 4;
     const int nbx = (a.nstrips + WPB - 1) / WPB;
-    const int bx = blockIdx.x % nbx;
-    const int chunk = blockIdx.x / nbx;
+    int bx, chunk;
+    if (a.remap) {
+        block_to_tile((int)blockIdx.x, nbx, a.nchunks, bx, chunk);
+    } else {
+        bx = blockIdx.x % nbx;
+        chunk = blockIdx.x / nbx;
+    }
     const int strip = bx * WPB + wave;
     if (strip >= a.nstrips || chunk >= a.nchunks) return;  // wave-uniform
 
@@ -387,7 +408,7 @@ __global__ void __launch_bounds__(256) k_fused(FusedArgs<T> a) {
     int64_t xl = x0;
     if (xl < 0) xl = 0;
     if (xl > a.pitch - N) xl = a.pitch - N;
-    const bool store_lane = lane >= SG::LH && lane < kWave - SG::RH && x0 < a.L;
+    const bool store_lane = lane >= SG::LH && lane < SG::LH + SG::VALID && x0 < a.L;
 
     // loop-invariant per-element border predicates
     bool edgeL[N], edgeR[N], ch0[N], chLast[N];
@@ -522,8 +543,13 @@ __global__ void __launch_bounds__(256) k_fused(FusedArgs<T> a) {
 #pragma unroll
             for (int j = 0; j < N; ++j) q1o[j] = ((edgeR[j] ? un[j] : unr[j]) - un[j]) + b1c[j];
             if (store_lane && r < R1) {
-                store_vec(q1_out + r * P, q1o);
-                store_vec(u_out + r * P, un);
+                if constexpr (NTS) {
+                    store_vec_nt(q1_out + r * P, q1o);
+                    store_vec_nt(u_out + r * P, un);
+                } else {
+                    store_vec(q1_out + r * P, q1o);
+                    store_vec(u_out + r * P, un);
+                }
             }
         } else {
             // r == n0: below the last row, replicate u_new so that the row difference is 0
@@ -539,7 +565,12 @@ __global__ void __launch_bounds__(256) k_fused(FusedArgs<T> a) {
             T q0o[N];
 #pragma unroll
             for (int j = 0; j < N; ++j) q0o[j] = (un[j] - upm[j]) + b0m[j];
-            if (store_lane) store_vec(q0_out + (r - 1) * P, q0o);
+            if (store_lane) {
+                if constexpr (NTS)
+                    store_vec_nt(q0_out + (r - 1) * P, q0o);
+                else
+                    store_vec(q0_out + (r - 1) * P, q0o);
+            }
         }
         // rotate the window
 #pragma unroll

@@ -2,9 +2,11 @@
 // Written for gfx950 (MI355X) only.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "dxh_kernels.h"
@@ -32,6 +34,8 @@ struct Ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int num_cu = 256;
+    int tune = 0;                  // developer A/B bits (DXH_FUSED_TUNE)
+    int waves_per_cu = 8;          // fused sweep: resident waves per CU the grid is sized for
 
     void* of = nullptr;            // omega * img
     void* u[2] = {nullptr, nullptr};
@@ -122,9 +126,9 @@ static int sq_diff(Ctx* c, const void* a, const void* b, int64_t row0, int64_t n
 }
 
 // ---- the fused sweep launch ---------------------------------------------------------------------
-template <typename T, int C, bool COUPLED, bool ISO, bool HET, bool DPP>
-static void launch_fused_t(Ctx* c, int in, int out) {
-    using SG = StripGeom<T, C>;
+template <typename T, int C, bool COUPLED, bool ISO, bool HET, bool DPP, bool ALIGN, bool NTS>
+static void launch_fused_v(Ctx* c, int in, int out) {
+    using SG = StripGeom<T, C, ALIGN>;
     FusedArgs<T> a;
     a.of = (const T*)c->of;
     a.u_in = (const T*)c->u[in];
@@ -138,17 +142,36 @@ static void launch_fused_t(Ctx* c, int in, int out) {
     a.pitch = c->g.pitch;
     a.nstrips = (int)((c->g.L + SG::STRIDE - 1) / SG::STRIDE);
     const int nbx = (a.nstrips + 3) / 4;
-    // size the grid to the machine: about 16 waves per CU, every wave the same number of rows
-    const int64_t target_blocks = (int64_t)c->num_cu * 4;
+    // size the grid to the machine: c->waves_per_cu waves per CU, every wave the same number of rows,
+    // the number of row chunks a multiple of 8 (one chunk row per XCD, block_to_tile)
+    const int64_t target_blocks = (int64_t)c->num_cu * c->waves_per_cu / 4;
     int64_t nchunks = std::max<int64_t>(1, target_blocks / nbx);
+    const bool remap = !(c->tune & 4);
+    if (remap && nchunks >= 8) nchunks = nchunks / 8 * 8;
     int64_t rpc = std::max<int64_t>(8, (c->g.n0 + nchunks - 1) / nchunks);
     nchunks = (c->g.n0 + rpc - 1) / rpc;
     a.rows_per_chunk = rpc;
     a.nchunks = (int)nchunks;
+    a.remap = remap ? 1 : 0;
     a.c = make_coef<T>(c);
     a.cp = make_planes<T>(c);
-    hipLaunchKernelGGL((k_fused<T, C, COUPLED, ISO, HET, DPP>), dim3((unsigned)(nbx * nchunks)), dim3(256), 0, c->stream,
-                       a);
+    hipLaunchKernelGGL((k_fused<T, C, COUPLED, ISO, HET, DPP, ALIGN, NTS>), dim3((unsigned)(nbx * nchunks)), dim3(256), 0,
+                       c->stream, a);
+}
+
+template <typename T, int C, bool COUPLED, bool ISO, bool HET, bool DPP>
+static void launch_fused_t(Ctx* c, int in, int out) {
+    // developer A/B switches (DXH_FUSED_TUNE: 1 = tight strips, 2 = plain stores, 4 = no XCD remap) exist
+    // for the headline instantiation only
+    if constexpr (std::is_same<T, float>::value && C == 3 && COUPLED && !ISO && !HET && DPP) {
+        switch (c->tune & 3) {
+            case 1: return launch_fused_v<T, C, COUPLED, ISO, HET, DPP, false, true>(c, in, out);
+            case 2: return launch_fused_v<T, C, COUPLED, ISO, HET, DPP, true, false>(c, in, out);
+            case 3: return launch_fused_v<T, C, COUPLED, ISO, HET, DPP, false, false>(c, in, out);
+            default: break;
+        }
+    }
+    launch_fused_v<T, C, COUPLED, ISO, HET, DPP, true, true>(c, in, out);
 }
 
 template <typename T, int C, bool COUPLED>
@@ -465,6 +488,11 @@ int dxh_tvd_create(dxh_tvd_t* out, const dxh_tvd_desc* d) {
     if (hipSetDevice(d->device) != hipSuccess) { set_error("hipSetDevice(%d) failed", d->device); return fail(DXH_EHIP); }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, d->device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+    if (const char* e = getenv("DXH_FUSED_TUNE")) c->tune = atoi(e);
+    if (const char* e = getenv("DXH_WAVES_PER_CU")) {  // developer knob
+        const int v = atoi(e);
+        if (v >= 1 && v <= 32) c->waves_per_cu = v;
+    }
     if (d->stream) {
         c->stream = (hipStream_t)d->stream;
     } else {
