@@ -85,15 +85,15 @@ __device__ __forceinline__ void store_vec_nt(T* p, const T (&v)[VecOf<T>::N]) {
 // lower one; one v_mov_b32_dpp per 32-bit word and step, no LDS crossbar involved.
 template <bool DPP>
 __device__ __forceinline__ int lane_step_up(int x) {  // result(lane) = x(lane - 1)
-    if constexpr (DPP)
-        return __builtin_amdgcn_update_dpp(x, x, 0x138, 0xf, 0xf, false);
+    if constexpr (DPP)  // old = 0 with bound_ctrl: lane 0 reads 0, no copy of x is needed before the move
+        return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, true);
     else
         return __shfl_up(x, 1, kWave);
 }
 template <bool DPP>
 __device__ __forceinline__ int lane_step_down(int x) {  // result(lane) = x(lane + 1)
     if constexpr (DPP)
-        return __builtin_amdgcn_update_dpp(x, x, 0x130, 0xf, 0xf, false);
+        return __builtin_amdgcn_update_dpp(0, x, 0x130, 0xf, 0xf, true);
     else
         return __shfl_down(x, 1, kWave);
 }
@@ -158,13 +158,18 @@ __device__ __forceinline__ T t_max0(T x) {  // np.maximum(x, 0) for non-NaN x
 }
 __device__ __forceinline__ float t_abs(float x) { return fabsf(x); }
 __device__ __forceinline__ double t_abs(double x) { return fabs(x); }
+__device__ __forceinline__ float t_copysign(float m, float s) { return copysignf(m, s); }
+__device__ __forceinline__ double t_copysign(double m, double s) { return copysign(m, s); }
 __device__ __forceinline__ float t_sqrt(float x) { return sqrtf(x); }  // correctly rounded (no fast-math)
 __device__ __forceinline__ double t_sqrt(double x) { return sqrt(x); }
 
 // (d, b) of one pixel from its stored state q = b_old + D(u) ("dub" in the reference):
 //   anisotropic  d = shrink(q, k), b = q - d                    split_bregman_tvd.py:80-81,143-146
 //   isotropic    s = |q|_2, f = max(s-k,0)/(s+1e-18), d = q f, b = q (1-f)       :107-126
-template <typename T, int DIM, bool ISO>
+// FASTSIGN (callers guarantee k >= 0): max(|q| - k, 0) * sign(q) only transfers q's sign -- for q == 0
+// the magnitude is max(-k, 0) = 0 as well -- so copysign gives the same value with 3 instructions
+// instead of 8.  For k < 0 or NaN the forms differ at q == 0, hence the flag.
+template <typename T, int DIM, bool ISO, bool FASTSIGN = false>
 __device__ __forceinline__ void split_vars(const T (&q)[DIM], T k, T (&d)[DIM], T (&b)[DIM]) {
     if constexpr (ISO) {
         T s = T(0);
@@ -180,7 +185,10 @@ __device__ __forceinline__ void split_vars(const T (&q)[DIM], T k, T (&d)[DIM], 
     } else {
 #pragma unroll
         for (int j = 0; j < DIM; ++j) {
-            d[j] = t_max0(t_abs(q[j]) - k) * sgn(q[j]);
+            if constexpr (FASTSIGN)
+                d[j] = t_copysign(t_max0(t_abs(q[j]) - k), q[j]);
+            else
+                d[j] = t_max0(t_abs(q[j]) - k) * sgn(q[j]);
             b[j] = q[j] - d[j];
         }
     }

@@ -462,7 +462,7 @@ __global__ void __launch_bounds__(256) k_fused(FusedArgs<T> a) {
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             T qq[2] = {q0v[j], q1v[j]}, d[2], b[2];
-            split_vars<T, 2, ISO>(qq, HET ? kqm[j] : kq[j], d, b);
+            split_vars<T, 2, ISO, !HET>(qq, HET ? kqm[j] : kq[j], d, b);
             t0m[j] = (HET ? ellm[j] : ell[j]) * (b[0] - d[0]);
             upm[j] = T(0);
             b0m[j] = T(0);
@@ -506,7 +506,7 @@ __global__ void __launch_bounds__(256) k_fused(FusedArgs<T> a) {
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 T qq[2] = {q0r[j], q1r[j]}, d[2], b[2];
-                split_vars<T, 2, ISO>(qq, kq[j], d, b);
+                split_vars<T, 2, ISO, !HET>(qq, kq[j], d, b);
                 b0c[j] = b[0];
                 b1c[j] = b[1];
                 t0c[j] = ell[j] * (b[0] - d[0]);
@@ -592,6 +592,299 @@ __global__ void __launch_bounds__(256) k_fused(FusedArgs<T> a) {
             }
         }
     }
+}
+
+
+// ============================================================================================
+// K outer iterations in ONE pass (temporal blocking of the fused sweep; scalar coefficients).
+//
+// The wave still marches down its column strip, but now runs a K-stage pipeline per step: stage s
+// applies iteration n+s+1 to row r-s, taking its operands (level-s rows of u, q0, q1) from stage
+// s-1's outputs of this and the previous step, which live in registers.  Only level 0 is read from
+// memory and only level K is written: 7 values per element per K iterations.
+//
+//   stage s at row p = r - s needs          comes from
+//     U_s[p-1], U_s[p]                      rolling registers um[s], uc[s]
+//     U_s[p+1]                              stage s-1, this step (s = 0: loaded)
+//     Q0_s[p]                               stage s-1, this step (it emits q0 one row behind)
+//     Q1_s[p]                               stage s-1, previous step (held in q1h[s])
+//     t0_s[p-1], b0_s[p-1]                  rolling registers
+//     of[p]                                 s-deep delay line of the loaded rows
+//
+// Each stage loses C elements of validity on the left and 2C on the right, so a wave stores lanes
+// [LH, LH + VALID) with LH = ceil(K C / N), RH = ceil(2 K C / N); for float32 RGB the 128-byte aligned
+// stride stays 224 elements up to K = 3.  A chunk starts K-1 rows early and ends K-1 rows late so that
+// every stage reaches its first stored row with valid carried state (the leading rows are computed
+// and discarded).  Image borders: rows above 0 / below n0-1 are replicated per stage (p == 0: the
+// carried row-above state is replaced by the current row; p == n0: the new iterate is replicated),
+// which is the same arithmetic as clamped addressing in the single-iteration kernel.
+// ============================================================================================
+
+template <typename T, int C, int K, bool ALIGN = true>
+struct StripGeomK {
+    static constexpr int N = VecOf<T>::N;
+    static constexpr int LINE = 128 / (int)sizeof(T);
+    static constexpr int LH = (K * C + N - 1) / N;
+    static constexpr int RH = (2 * K * C + N - 1) / N;
+    static constexpr int TIGHT = (kWave - LH - RH) * N;
+    static constexpr int STRIDE = ALIGN ? (TIGHT / LINE) * LINE : TIGHT;
+    static constexpr int VALID = STRIDE / N;
+    static_assert(STRIDE > 0, "too many fused iterations for this channel count");
+};
+
+// EDGE: this strip contains elements within C of the left or right image border (column replicate
+// selects needed); interior strips -- all but the first and the last one or two -- skip them.
+template <typename T, int C, bool COUPLED, bool ISO, int K, bool NTS, bool EDGE>
+__device__ __forceinline__ void fused_multi_body(const FusedArgs<T>& a, const int strip, const int chunk, const int lane) {
+    constexpr int N = VecOf<T>::N;
+    constexpr bool DPP = true;
+    using SG = StripGeomK<T, C, K>;
+
+    const int64_t R0 = (int64_t)chunk * a.rows_per_chunk;
+    const int64_t R1 = (R0 + a.rows_per_chunk < a.n0) ? R0 + a.rows_per_chunk : a.n0;
+    if (R0 >= a.n0) return;
+
+    const int64_t x0 = (int64_t)strip * SG::STRIDE + (int64_t)(lane - SG::LH) * N;
+    int64_t xl = x0;
+    if (xl < 0) xl = 0;
+    if (xl > a.pitch - N) xl = a.pitch - N;
+    const bool store_lane = lane >= SG::LH && lane < SG::LH + SG::VALID && x0 < a.L;
+
+    bool edgeL[N], edgeR[N], ch0[N], chLast[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int64_t x = x0 + j;
+        edgeL[j] = x < C;
+        edgeR[j] = x >= a.L - C;
+        const int cc = (int)(((x % C) + C) % C);
+        ch0[j] = cc == 0;
+        chLast[j] = cc == C - 1;
+    }
+
+    const T* of = a.of + xl;
+    const T* u_in = a.u_in + xl;
+    const T* q0_in = a.q0_in + xl;
+    const T* q1_in = a.q1_in + xl;
+    T* u_out = a.u_out + xl;
+    T* q0_out = a.q0_out + xl;
+    T* q1_out = a.q1_out + xl;
+    const int64_t P = a.pitch;
+    const int64_t nrow = a.n0;
+    auto clampr = [&](int64_t r) -> int64_t { return r < 0 ? 0 : (r > nrow - 1 ? nrow - 1 : r); };
+    const T ell = a.c.ell, diag = a.c.diag, dsc = a.c.dsc, kq = a.c.kq;
+
+    // per-stage rolling state
+    T um[K][N], uc[K + 1][N], t0m[K][N], b0m[K][N], q1h[K][N], ofd[K][N], ulast[N];  // uc[K] is never read
+#pragma unroll
+    for (int s = 0; s < K; ++s)
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            um[s][j] = uc[s][j] = t0m[s][j] = b0m[s][j] = q1h[s][j] = ofd[s][j] = T(0);
+        }
+#pragma unroll
+    for (int j = 0; j < N; ++j) uc[K][j] = T(0);
+#pragma unroll
+    for (int j = 0; j < N; ++j) ulast[j] = T(0);
+
+    const int64_t rs = R0 - (K - 1);  // first row of stage 0 (may be negative: clamped loads)
+    load_vec(u_in + clampr(rs - 1) * P, um[0]);
+    load_vec(u_in + clampr(rs) * P, uc[0]);
+    {
+        const int64_t rm = clampr(rs - 1);
+        T q0v[N], q1v[N];
+        load_vec(q0_in + rm * P, q0v);
+        load_vec(q1_in + rm * P, q1v);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            T qq[2] = {q0v[j], q1v[j]}, d[2], b[2];
+            split_vars<T, 2, ISO>(qq, kq, d, b);
+            t0m[0][j] = ell * (b[0] - d[0]);
+            b0m[0][j] = b[0];
+        }
+    }
+    T up0[N], q0r[N], q1r[N];
+    load_vec(u_in + clampr(rs + 1) * P, up0);
+    load_vec(of + clampr(rs) * P, ofd[0]);
+    load_vec(q0_in + clampr(rs) * P, q0r);
+    load_vec(q1_in + clampr(rs) * P, q1r);
+
+    const int64_t r_end = R1 + (K - 1);
+    for (int64_t r = rs; r <= r_end; ++r) {
+        T upn[N], frn[N], q0n[N], q1n[N];
+        {
+            const int64_t rn = clampr(r + 1);
+            load_vec(u_in + clampr(r + 2) * P, upn);
+            load_vec(of + rn * P, frn);
+            load_vec(q0_in + rn * P, q0n);
+            load_vec(q1_in + rn * P, q1n);
+        }
+
+        T up_s[N], q0c_s[N];      // operands handed from stage s-1 to stage s within this step
+        T q1new[K][N];            // Q1 outputs, committed to q1h at the end of the step
+        T upsave[K][N], t0save[K][N], b0save[K][N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            up_s[j] = up0[j];
+            q0c_s[j] = q0r[j];
+        }
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            const int64_t p = r - s;  // this stage's row (wave-uniform)
+            T q1c[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                q1c[j] = (s == 0) ? q1r[j] : q1h[s][j];
+                upsave[s][j] = up_s[j];
+            }
+            T un[N], q1o[N], q0o[N], b0c[N], t0c[N];
+            // U_{s+1}[p-1]: the next stage's current row, or the last level's previous row
+            T unm[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) unm[j] = (s < K - 1) ? uc[s + 1][j] : ulast[j];
+            {
+                // rows outside [0, n0) are computed like any other (finite garbage, never stored); the two
+                // image borders are rare wave-uniform fix-ups of the carried state
+                T b1c[N], t1c[N];
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    T qq[2] = {q0c_s[j], q1c[j]}, d[2], b[2];
+                    split_vars<T, 2, ISO, true>(qq, kq, d, b);
+                    b0c[j] = b[0];
+                    b1c[j] = b[1];
+                    t0c[j] = ell * (b[0] - d[0]);
+                    t1c[j] = ell * (b[1] - d[1]);
+                }
+                if (p == 0) {  // replicate the row above the image: N uses u[0] twice, forward_diff is 0
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {
+                        um[s][j] = uc[s][j];
+                        t0m[s][j] = t0c[j];
+                    }
+                }
+                T t1l[N], ul[N], ur[N], ucl[N], ucr[N];
+                shifted<-C, DPP>(t1c, t1l);
+                shifted<-C, DPP>(uc[s], ul);
+                shifted<+C, DPP>(uc[s], ur);
+                if constexpr (COUPLED) {
+                    shifted<-1, DPP>(uc[s], ucl);
+                    shifted<+1, DPP>(uc[s], ucr);
+                }
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    T rhs = ofd[s][j] + (t0c[j] - t0m[s][j]);
+                    if constexpr (EDGE)
+                        rhs = rhs + (t1c[j] - (edgeL[j] ? t1c[j] : t1l[j]));
+                    else
+                        rhs = rhs + (t1c[j] - t1l[j]);
+                    const T rsc = rhs / diag;
+                    T acc = um[s][j] + up_s[j];
+                    if constexpr (EDGE) {
+                        acc = acc + (edgeL[j] ? uc[s][j] : ul[j]);
+                        acc = acc + (edgeR[j] ? uc[s][j] : ur[j]);
+                    } else {
+                        acc = acc + ul[j];
+                        acc = acc + ur[j];
+                    }
+                    if constexpr (COUPLED) {
+                        acc = acc + (ch0[j] ? uc[s][j] : ucl[j]);
+                        acc = acc + (chLast[j] ? uc[s][j] : ucr[j]);
+                    }
+                    un[j] = rsc + acc / dsc;
+                }
+                if (p >= nrow) {  // below the image: replicate the new iterate (row difference 0)
+#pragma unroll
+                    for (int j = 0; j < N; ++j) un[j] = unm[j];
+                }
+                T unr[N];
+                shifted<+C, DPP>(un, unr);
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    if constexpr (EDGE)
+                        q1o[j] = ((edgeR[j] ? un[j] : unr[j]) - un[j]) + b1c[j];
+                    else
+                        q1o[j] = (unr[j] - un[j]) + b1c[j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                q0o[j] = (un[j] - unm[j]) + b0m[s][j];
+                t0save[s][j] = t0c[j];
+                b0save[s][j] = b0c[j];
+                q1new[s][j] = q1o[j];
+            }
+            if (s == K - 1) {
+                if (store_lane) {
+                    if (p >= R0 && p < R1) {
+                        if constexpr (NTS) {
+                            store_vec_nt(q1_out + p * P, q1o);
+                            store_vec_nt(u_out + p * P, un);
+                        } else {
+                            store_vec(q1_out + p * P, q1o);
+                            store_vec(u_out + p * P, un);
+                        }
+                    }
+                    if (p - 1 >= R0 && p - 1 < R1) {
+                        if constexpr (NTS)
+                            store_vec_nt(q0_out + (p - 1) * P, q0o);
+                        else
+                            store_vec(q0_out + (p - 1) * P, q0o);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < N; ++j) ulast[j] = un[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    up_s[j] = un[j];    // U_{s+1}[p] = row above-next of stage s+1 (its p+1)
+                    q0c_s[j] = q0o[j];  // Q0_{s+1}[p-1] = stage s+1's current row
+                }
+            }
+        }
+        // rotate all stages
+#pragma unroll
+        for (int s = 0; s < K; ++s)
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                um[s][j] = uc[s][j];
+                uc[s][j] = upsave[s][j];
+                t0m[s][j] = t0save[s][j];
+                b0m[s][j] = b0save[s][j];
+            }
+#pragma unroll
+        for (int s = K - 1; s >= 1; --s)
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                q1h[s][j] = q1new[s - 1][j];
+                ofd[s][j] = ofd[s - 1][j];
+            }
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            ofd[0][j] = frn[j];
+            up0[j] = upn[j];
+            q0r[j] = q0n[j];
+            q1r[j] = q1n[j];
+        }
+    }
+}
+
+template <typename T, int C, bool COUPLED, bool ISO, int K, bool NTS = true>
+__global__ void __launch_bounds__(256) k_fused_multi(FusedArgs<T> a) {
+    constexpr int N = VecOf<T>::N;
+    using SG = StripGeomK<T, C, K>;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    constexpr int WPB = 4;
+    const int nbx = (a.nstrips + WPB - 1) / WPB;
+    int bx, chunk;
+    block_to_tile((int)blockIdx.x, nbx, a.nchunks, bx, chunk);
+    const int strip = bx * WPB + wave;
+    if (strip >= a.nstrips || chunk >= a.nchunks) return;  // wave-uniform
+    const int64_t w0 = (int64_t)strip * SG::STRIDE - SG::LH * N;  // first element of the wave's window
+    const bool edge = (w0 < C) || (w0 + kWave * N > a.L - C);     // wave-uniform
+    if (edge)
+        fused_multi_body<T, C, COUPLED, ISO, K, NTS, true>(a, strip, chunk, lane);
+    else
+        fused_multi_body<T, C, COUPLED, ISO, K, NTS, false>(a, strip, chunk, lane);
 }
 
 }  // namespace dxh

@@ -35,6 +35,7 @@ struct Ctx {
     bool own_stream = false;
     int num_cu = 256;
     int tune = 0;                  // developer A/B bits (DXH_FUSED_TUNE)
+    int fuse_k = 2;                // outer iterations fused per launch (1..4)
     int waves_per_cu = 8;          // fused sweep: resident waves per CU the grid is sized for
 
     void* of = nullptr;            // omega * img
@@ -172,6 +173,61 @@ static void launch_fused_t(Ctx* c, int in, int out) {
         }
     }
     launch_fused_v<T, C, COUPLED, ISO, HET, DPP, true, true>(c, in, out);
+}
+
+// K iterations per launch (scalar coefficients only)
+template <typename T, int C, bool COUPLED, bool ISO, int K>
+static void launch_fused_multi_t(Ctx* c, int in, int out) {
+    using SG = StripGeomK<T, C, K>;
+    FusedArgs<T> a;
+    a.of = (const T*)c->of;
+    a.u_in = (const T*)c->u[in];
+    a.u_out = (T*)c->u[out];
+    a.q0_in = (const T*)c->q[0][in];
+    a.q1_in = (const T*)c->q[1][in];
+    a.q0_out = (T*)c->q[0][out];
+    a.q1_out = (T*)c->q[1][out];
+    a.n0 = c->g.n0;
+    a.L = c->g.L;
+    a.pitch = c->g.pitch;
+    a.nstrips = (int)((c->g.L + SG::STRIDE - 1) / SG::STRIDE);
+    const int nbx = (a.nstrips + 3) / 4;
+    const int64_t target_blocks = (int64_t)c->num_cu * c->waves_per_cu / 4;
+    int64_t nchunks = std::max<int64_t>(1, target_blocks / nbx);
+    if (nchunks >= 8) nchunks = nchunks / 8 * 8;
+    int64_t rpc = std::max<int64_t>(8 * K, (c->g.n0 + nchunks - 1) / nchunks);
+    nchunks = (c->g.n0 + rpc - 1) / rpc;
+    a.rows_per_chunk = rpc;
+    a.nchunks = (int)nchunks;
+    a.remap = 1;
+    a.c = make_coef<T>(c);
+    a.cp = make_planes<T>(c);
+    hipLaunchKernelGGL((k_fused_multi<T, C, COUPLED, ISO, K>), dim3((unsigned)(nbx * nchunks)), dim3(256), 0, c->stream, a);
+}
+
+// channel counts the multi-iteration kernel is instantiated for
+static bool multi_supported(const Ctx* c) {
+    return c->desc.dim == 2 && !c->het && (c->g.n2 == 1 || c->g.n2 == 3);
+}
+
+template <typename T, int C>
+static void launch_fused_multi_c(Ctx* c, int in, int out, bool iso, int K) {
+    const bool coupled = c->desc.ndim == 3 && c->desc.nsum == DXH_NSUM_ALL_AXES;
+#define DXH_M(CP_, ISO_)                                                              \
+    switch (K) {                                                                      \
+        case 2: launch_fused_multi_t<T, C, CP_, ISO_, 2>(c, in, out); break;          \
+        case 3: launch_fused_multi_t<T, C, CP_, ISO_, 3>(c, in, out); break;          \
+        default: launch_fused_multi_t<T, C, CP_, ISO_, 4>(c, in, out); break;         \
+    }
+    if (coupled) { if (iso) { DXH_M(true, true) } else { DXH_M(true, false) } }
+    else         { if (iso) { DXH_M(false, true) } else { DXH_M(false, false) } }
+#undef DXH_M
+}
+
+template <typename T>
+static void launch_fused_multi(Ctx* c, int in, int out, bool iso, int K) {
+    if (c->g.n2 == 1) launch_fused_multi_c<T, 1>(c, in, out, iso, K);
+    else launch_fused_multi_c<T, 3>(c, in, out, iso, K);
 }
 
 template <typename T, int C, bool COUPLED>
@@ -338,7 +394,15 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
     for (int it = 0; it < n_iter; ++it) {
         const int in = c->cur, out = c->cur ^ 1;
         if (fused_ok && !c->from_db) {
-            launch_fused<T>(c, in, out, iso, dpp);
+            // temporal blocking: fuse_k iterations per launch while enough iterations remain and no
+            // per-iteration host test is requested
+            const int K = (!use_eps && dpp && multi_supported(c)) ? std::min(c->fuse_k, n_iter - it) : 1;
+            if (K >= 2) {
+                launch_fused_multi<T>(c, in, out, iso, K);
+                it += K - 1;
+            } else {
+                launch_fused<T>(c, in, out, iso, dpp);
+            }
             ++launches;
             c->cur = out;
         } else {
@@ -489,6 +553,10 @@ int dxh_tvd_create(dxh_tvd_t* out, const dxh_tvd_desc* d) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, d->device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
     if (const char* e = getenv("DXH_FUSED_TUNE")) c->tune = atoi(e);
+    if (const char* e = getenv("DXH_FUSE_K")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 4) c->fuse_k = v;
+    }
     if (const char* e = getenv("DXH_WAVES_PER_CU")) {  // developer knob
         const int v = atoi(e);
         if (v >= 1 && v <= 32) c->waves_per_cu = v;

@@ -227,3 +227,24 @@ def test_wide_image_many_strips_and_chunks():
         for fl in VARIANTS.values():
             out, _ = run_device(img, mu=0.1, n_iter=4, flags=fl)
             assert_bits(out, ref)
+
+
+@pytest.mark.parametrize("fuse_k", [1, 2, 3, 4])
+def test_temporal_blocking_is_bit_exact(monkeypatch, fuse_k):
+    """K outer iterations per launch (k_fused_multi) must equal K single launches / the oracle bit for bit,
+    for iteration counts that are and are not multiples of K, tall images (several row chunks, first/last
+    chunk at the image border), tiny images (fewer rows than pipeline stages) and both dtypes."""
+    monkeypatch.setenv("DXH_FUSE_K", str(fuse_k))
+    rng = np.random.default_rng(17)
+    cases = [((70, 523, 3), np.float32, 7), ((1500, 230, 3), np.float32, 6), ((3, 40, 3), np.float32, 5),
+             ((1, 17), np.float32, 4), ((2, 300), np.float32, 9), ((257, 300), np.float64, 5),
+             ((90, 130, 3), np.float64, 8), ((640, 700), np.float32, 12)]
+    for shape, dt, n in cases:
+        img = rng.random(shape).astype(dt)
+        ref = O.split_bregman_tvd(img, mu=0.1, max_num_iter=n, promotion="strict")
+        out, res = run_device(img, mu=0.1, n_iter=n)
+        assert res.iters_done == n
+        assert_bits(out, ref)
+    img = rng.random((120, 260, 3)).astype(np.float32)
+    out, _ = run_device(img, mu=0.1, n_iter=6, isotropic=True)
+    assert_bits(out, O.split_bregman_tvd(img, mu=0.1, max_num_iter=6, isotropic=True, promotion="strict"))

@@ -1,4 +1,5 @@
-"""Developer A/B of the fused sweep's tuning knobs inside ONE process (interleaved rounds)."""
+"""Developer A/B of the fused sweep's tuning knobs inside ONE process (interleaved rounds).
+usage: tune_bench.py "NAME:ENV=V,ENV=V" ...   (default set below)"""
 import os, sys
 import numpy as np
 sys.path.insert(0, ".")
@@ -6,24 +7,24 @@ import darsia_amd as da
 from darsia_amd.synthetic import synthetic_image
 
 H, W, C = 4000, 8000, 3
-iters = 50
+iters = 48
 img = synthetic_image(H, W, C)
-configs = [("base tight/plain/noremap w16", dict(DXH_FUSED_TUNE="7", DXH_WAVES_PER_CU="16")),
-           ("align+nts+remap w8", dict(DXH_FUSED_TUNE="0", DXH_WAVES_PER_CU="8")),
-           ("align+nts+remap w4", dict(DXH_FUSED_TUNE="0", DXH_WAVES_PER_CU="4")),
-           ("align+nts+remap w12", dict(DXH_FUSED_TUNE="0", DXH_WAVES_PER_CU="12")),
-           ("align+nts+remap w16", dict(DXH_FUSED_TUNE="0", DXH_WAVES_PER_CU="16")),
-           ("align+plain+remap w8", dict(DXH_FUSED_TUNE="2", DXH_WAVES_PER_CU="8")),
-           ("align+nts+noremap w8", dict(DXH_FUSED_TUNE="4", DXH_WAVES_PER_CU="8")),
-           ("tight+nts+remap w8", dict(DXH_FUSED_TUNE="1", DXH_WAVES_PER_CU="8")),
-           ]
+default = ["k1w8:DXH_FUSE_K=1,DXH_WAVES_PER_CU=8", "k2w8:DXH_FUSE_K=2,DXH_WAVES_PER_CU=8",
+           "k3w8:DXH_FUSE_K=3,DXH_WAVES_PER_CU=8", "k4w8:DXH_FUSE_K=4,DXH_WAVES_PER_CU=8",
+           "k2w6:DXH_FUSE_K=2,DXH_WAVES_PER_CU=6", "k2w12:DXH_FUSE_K=2,DXH_WAVES_PER_CU=12",
+           "k3w6:DXH_FUSE_K=3,DXH_WAVES_PER_CU=6", "k3w12:DXH_FUSE_K=3,DXH_WAVES_PER_CU=12",
+           "k4w6:DXH_FUSE_K=4,DXH_WAVES_PER_CU=6", "k4w5:DXH_FUSE_K=4,DXH_WAVES_PER_CU=5"]
+specs = sys.argv[1:] or default
 ctxs = []
-for name, env in configs:
-    os.environ.update(env)
+for spec in specs:
+    name, envs = spec.split(":")
+    for kv in envs.split(","):
+        k, v = kv.split("=")
+        os.environ[k] = v
     st = da.DeviceTVD(img.shape, img.dtype, dim=2)
     st.set_coeffs(0.1, 1.0, None, img)
     st.upload(img)
-    st.run(3)
+    st.run(12)
     ctxs.append((name, st, []))
 for rnd in range(5):
     for name, st, ts in ctxs:
@@ -32,4 +33,4 @@ for rnd in range(5):
 npc = H * W * C
 for name, st, ts in ctxs:
     med, mn = float(np.median(ts)), min(ts)
-    print(f"{name:32s} median {med:.4f} ms  min {mn:.4f} ms   {H*W/med/1e3:.0f} MPix/s   {28*npc/med/1e6:.0f} GB/s (28B)", flush=True)
+    print(f"{name:12s} median {med:.4f} ms/iter  min {mn:.4f}   {H*W/med/1e3:.0f} MPix/s", flush=True)
