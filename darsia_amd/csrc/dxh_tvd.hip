@@ -35,8 +35,8 @@ struct Ctx {
     bool own_stream = false;
     int num_cu = 256;
     int tune = 0;                  // developer A/B bits (DXH_FUSED_TUNE)
-    int fuse_k = 2;                // outer iterations fused per launch (1..4)
-    int waves_per_cu = 8;          // fused sweep: resident waves per CU the grid is sized for
+    int fuse_k = 4;                // outer iterations fused per launch (1..4)
+    int waves_per_cu = 0;          // fused sweep: waves per CU the grid is sized for (0 = 8 for K = 1, 12 for K > 1)
 
     void* of = nullptr;            // omega * img
     void* u[2] = {nullptr, nullptr};
@@ -145,7 +145,7 @@ static void launch_fused_v(Ctx* c, int in, int out) {
     const int nbx = (a.nstrips + 3) / 4;
     // size the grid to the machine: c->waves_per_cu waves per CU, every wave the same number of rows,
     // the number of row chunks a multiple of 8 (one chunk row per XCD, block_to_tile)
-    const int64_t target_blocks = (int64_t)c->num_cu * c->waves_per_cu / 4;
+    const int64_t target_blocks = (int64_t)c->num_cu * (c->waves_per_cu ? c->waves_per_cu : 8) / 4;
     int64_t nchunks = std::max<int64_t>(1, target_blocks / nbx);
     const bool remap = !(c->tune & 4);
     if (remap && nchunks >= 8) nchunks = nchunks / 8 * 8;
@@ -192,7 +192,7 @@ static void launch_fused_multi_t(Ctx* c, int in, int out) {
     a.pitch = c->g.pitch;
     a.nstrips = (int)((c->g.L + SG::STRIDE - 1) / SG::STRIDE);
     const int nbx = (a.nstrips + 3) / 4;
-    const int64_t target_blocks = (int64_t)c->num_cu * c->waves_per_cu / 4;
+    const int64_t target_blocks = (int64_t)c->num_cu * (c->waves_per_cu ? c->waves_per_cu : 12) / 4;
     int64_t nchunks = std::max<int64_t>(1, target_blocks / nbx);
     if (nchunks >= 8) nchunks = nchunks / 8 * 8;
     int64_t rpc = std::max<int64_t>(8 * K, (c->g.n0 + nchunks - 1) / nchunks);

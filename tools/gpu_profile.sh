@@ -4,7 +4,7 @@ set -uo pipefail
 TAG="${1:-r01}"
 REPO="${GRAFT_REPO_ROOT:-$(pwd)}"
 OUT="${REPO}/gpurun_out/prof_${TAG}"
-mkdir -p "${OUT}"
+rm -rf "${OUT}"; mkdir -p "${OUT}"
 export TMPDIR=/tmp
 cd "${REPO}"
 echo "== kernel trace" 
