@@ -101,6 +101,16 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
         a.gpus = world
 
+    rehearsal = os.environ.get("DXH_BENCH_REHEARSAL", "")
+    if world > 1:
+        # torch's bundled HIP runtime must initialise before libdarsia_hip.so pulls in the system one
+        import torch
+
+        if rehearsal:
+            local_rank = local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local_rank)
+        torch.zeros(1, device="cuda")
+
     from darsia_amd import _lib
     from darsia_amd.synthetic import synthetic_image
 
@@ -135,8 +145,12 @@ def main():
 
         from darsia_amd.parallel import SlabTVD, make_plan
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # DXH_BENCH_REHEARSAL=gloo: rehearse the N-rank path on a box with fewer GPUs than ranks (all ranks on
+        # the visible devices round-robin, halo exchange staged through the host).  Never used by the driver.
+        if rehearsal:
+            dist.init_process_group(rehearsal)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         total_rows = H * world if a.scaling == "weak" else H
         plan = make_plan(total_rows, world, rank, a.halo_iters)
         slab = synthetic_image(plan.rows, W, C, row0=plan.slab0)
@@ -160,7 +174,7 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         elapsed = time.perf_counter() - t0
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         kernel_ms, launches = None, None
@@ -181,7 +195,8 @@ def main():
             "scaling": a.scaling,
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not os.environ.get("DXH_BENCH_REHEARSAL") else "synthetic (REHEARSAL: ranks share GPUs, "
+                    "host-staged exchange; not a valid multi-GPU number)",
             "config": {
                 "workload": f"anisotropic split-Bregman TVD, {total_rows}x{W}x{C} float32 (H x W x C), "
                             f"{a.iters} iterations per step, mu=0.1 omega=1 ell=2mu Jacobi(maxiter=1) eps=off, "

@@ -13,7 +13,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdarsia_hip.so")
+LIB_PATH = os.environ.get("DARSIA_HIP_LIB") or os.path.join(_HERE, "libdarsia_hip.so")  # env: developer A/B of builds
 
 DXH_F32, DXH_F64 = 0, 1
 NSUM_ALL_AXES, NSUM_SPATIAL = 0, 1

@@ -11,7 +11,13 @@
 // from q_j where needed (dxh_common.h: split_vars).  u and q_j are double buffered.
 #pragma once
 
+#include <type_traits>
+
 #include "dxh_common.h"
+
+#ifndef DXH_LB4
+#define DXH_LB4 2  // minimum waves per SIMD requested for the K = 4 pipeline (register cap 256 / 168)
+#endif
 
 namespace dxh {
 
@@ -21,6 +27,7 @@ struct Coef {       // scalar coefficients, already rounded to T like NumPy's we
     T diag;         // omega + ell*2*dim/h^2                               jacobi.py:72
     T dsc;          // diag / (ell/h^2)                                    jacobi.py:104-106
     T kq;           // mu / ell (shrinkage threshold)                      split_bregman_tvd.py:140,145
+    T rdiag, rdsc;  // RN(1/diag), RN(1/dsc) for div_by_const; 0 = use the IEEE division
 };
 
 template <typename T>
@@ -632,187 +639,169 @@ struct StripGeomK {
     static_assert(STRIDE > 0, "too many fused iterations for this channel count");
 };
 
-// EDGE: this strip contains elements within C of the left or right image border (column replicate
-// selects needed); interior strips -- all but the first and the last one or two -- skip them.
+// --------------------------------------------------------------------------------------------------
+// Implementation: every carried value lives in a small ring whose slot index is a compile-time
+// function of the step's phase (step number mod 4), and the row loop is unrolled by 4 (one
+// instantiation of Pipe::step per phase), so the pipeline advances by register renaming instead of
+// register-to-register copies.  EDGE: the strip contains elements within C of the left or right image
+// border (column replicate selects needed); interior strips skip them.  Rings:
+//   U[l][4]   rows of level l (l = 0: loaded, l = s+1: written by stage s), slot = (row - rs) & 3;
+//             a stage reads slots c-1, c, c+1 and the producer overwrites the dead slot c-3 = c+1
+//   U[K][2]   the last level only needs its previous row
+//   t0, b0, q1, q0l [..][2]   one-step carries, alternate by phase parity
+//   of[4]     omega*f rows r .. r-3 (the prefetched row r+1 is moved in at the end of the step)
+// (A first version with rolling variables spent ~20 % of its VALU instructions on v_mov rotation.)
+// --------------------------------------------------------------------------------------------------
+template <int V>
+using IC = std::integral_constant<int, V>;
+
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(IC<B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+template <typename T, int K>
+struct PipeState {
+    static constexpr int N = VecOf<T>::N;
+    T U[K + 1][4][N];
+    T t0[K][2][N];
+    T b0[K][2][N];
+    T q1[K][2][N];
+    T q0l[2][N];
+    T of[4][N];
+};
+
 template <typename T, int C, bool COUPLED, bool ISO, int K, bool NTS, bool EDGE>
-__device__ __forceinline__ void fused_multi_body(const FusedArgs<T>& a, const int strip, const int chunk, const int lane) {
-    constexpr int N = VecOf<T>::N;
-    constexpr bool DPP = true;
-    using SG = StripGeomK<T, C, K>;
-
-    const int64_t R0 = (int64_t)chunk * a.rows_per_chunk;
-    const int64_t R1 = (R0 + a.rows_per_chunk < a.n0) ? R0 + a.rows_per_chunk : a.n0;
-    if (R0 >= a.n0) return;
-
-    const int64_t x0 = (int64_t)strip * SG::STRIDE + (int64_t)(lane - SG::LH) * N;
-    int64_t xl = x0;
-    if (xl < 0) xl = 0;
-    if (xl > a.pitch - N) xl = a.pitch - N;
-    const bool store_lane = lane >= SG::LH && lane < SG::LH + SG::VALID && x0 < a.L;
-
+struct Pipe {
+    static constexpr int N = VecOf<T>::N;
+    static constexpr bool DPP = true;
+    const T* of_p;
+    const T* u_in;
+    const T* q0_in;
+    const T* q1_in;
+    T* u_out;
+    T* q0_out;
+    T* q1_out;
+    int64_t P, nrow, R0, R1;
+    T ell, diag, dsc, kq, rdiag, rdsc;
+    bool store_lane;
     bool edgeL[N], edgeR[N], ch0[N], chLast[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-        const int64_t x = x0 + j;
-        edgeL[j] = x < C;
-        edgeR[j] = x >= a.L - C;
-        const int cc = (int)(((x % C) + C) % C);
-        ch0[j] = cc == 0;
-        chLast[j] = cc == C - 1;
-    }
 
-    const T* of = a.of + xl;
-    const T* u_in = a.u_in + xl;
-    const T* q0_in = a.q0_in + xl;
-    const T* q1_in = a.q1_in + xl;
-    T* u_out = a.u_out + xl;
-    T* q0_out = a.q0_out + xl;
-    T* q1_out = a.q1_out + xl;
-    const int64_t P = a.pitch;
-    const int64_t nrow = a.n0;
-    auto clampr = [&](int64_t r) -> int64_t { return r < 0 ? 0 : (r > nrow - 1 ? nrow - 1 : r); };
-    const T ell = a.c.ell, diag = a.c.diag, dsc = a.c.dsc, kq = a.c.kq;
+    __device__ __forceinline__ int64_t clampr(int64_t r) const { return r < 0 ? 0 : (r > nrow - 1 ? nrow - 1 : r); }
 
-    // per-stage rolling state
-    T um[K][N], uc[K + 1][N], t0m[K][N], b0m[K][N], q1h[K][N], ofd[K][N], ulast[N];  // uc[K] is never read
-#pragma unroll
-    for (int s = 0; s < K; ++s)
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            um[s][j] = uc[s][j] = t0m[s][j] = b0m[s][j] = q1h[s][j] = ofd[s][j] = T(0);
-        }
-#pragma unroll
-    for (int j = 0; j < N; ++j) uc[K][j] = T(0);
-#pragma unroll
-    for (int j = 0; j < N; ++j) ulast[j] = T(0);
-
-    const int64_t rs = R0 - (K - 1);  // first row of stage 0 (may be negative: clamped loads)
-    load_vec(u_in + clampr(rs - 1) * P, um[0]);
-    load_vec(u_in + clampr(rs) * P, uc[0]);
-    {
-        const int64_t rm = clampr(rs - 1);
-        T q0v[N], q1v[N];
-        load_vec(q0_in + rm * P, q0v);
-        load_vec(q1_in + rm * P, q1v);
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            T qq[2] = {q0v[j], q1v[j]}, d[2], b[2];
-            split_vars<T, 2, ISO>(qq, kq, d, b);
-            t0m[0][j] = ell * (b[0] - d[0]);
-            b0m[0][j] = b[0];
-        }
-    }
-    T up0[N], q0r[N], q1r[N];
-    load_vec(u_in + clampr(rs + 1) * P, up0);
-    load_vec(of + clampr(rs) * P, ofd[0]);
-    load_vec(q0_in + clampr(rs) * P, q0r);
-    load_vec(q1_in + clampr(rs) * P, q1r);
-
-    const int64_t r_end = R1 + (K - 1);
-    for (int64_t r = rs; r <= r_end; ++r) {
-        T upn[N], frn[N], q0n[N], q1n[N];
+    template <int PH>
+    __device__ __forceinline__ void step(PipeState<T, K>& st, const int64_t r) const {
+        // prefetch next step's level-0 rows straight into their ring slots
+        T frn[N];
         {
             const int64_t rn = clampr(r + 1);
-            load_vec(u_in + clampr(r + 2) * P, upn);
-            load_vec(of + rn * P, frn);
-            load_vec(q0_in + rn * P, q0n);
-            load_vec(q1_in + rn * P, q1n);
+            load_vec(u_in + clampr(r + 2) * P, st.U[0][(PH + 2) & 3]);
+            load_vec(of_p + rn * P, frn);
+            load_vec(q0_in + rn * P, st.q0l[(PH + 1) & 1]);
+            load_vec(q1_in + rn * P, st.q1[0][(PH + 1) & 1]);
         }
+        T q0h[N];  // Q0 of the next level at the next stage's row, handed from stage to stage
+        static_for<0, K>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            constexpr int c = (PH - s) & 3;          // ring slot of this stage's row
+            constexpr int cm = (c + 3) & 3, cp = (c + 1) & 3;
+            constexpr int cur = PH & 1, prv = cur ^ 1;
+            const int64_t p = r - s;
+            T(&um)[N] = st.U[s][cm];
+            T(&uc)[N] = st.U[s][c];
+            T(&up)[N] = st.U[s][cp];
+            T(&t0m)[N] = st.t0[s][prv];
+            T(&t0c)[N] = st.t0[s][cur];
+            T(&b0m)[N] = st.b0[s][prv];
+            T(&b0c)[N] = st.b0[s][cur];
+            const T(&q1c)[N] = st.q1[s][cur];
+            const T(&ofv)[N] = st.of[c];
+            // destination of the new iterate (level s+1, row p) and that level's previous row
+            constexpr bool last = (s == K - 1);
+            T(&un)[N] = last ? st.U[K][cur] : st.U[s + 1][c];
+            const T(&unm)[N] = last ? st.U[K][prv] : st.U[s + 1][cm];
 
-        T up_s[N], q0c_s[N];      // operands handed from stage s-1 to stage s within this step
-        T q1new[K][N];            // Q1 outputs, committed to q1h at the end of the step
-        T upsave[K][N], t0save[K][N], b0save[K][N];
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            up_s[j] = up0[j];
-            q0c_s[j] = q0r[j];
-        }
-#pragma unroll
-        for (int s = 0; s < K; ++s) {
-            const int64_t p = r - s;  // this stage's row (wave-uniform)
-            T q1c[N];
+            T b1c[N], t1c[N];
 #pragma unroll
             for (int j = 0; j < N; ++j) {
-                q1c[j] = (s == 0) ? q1r[j] : q1h[s][j];
-                upsave[s][j] = up_s[j];
+                T qq[2] = {(s == 0) ? st.q0l[cur][j] : q0h[j], q1c[j]}, d[2], b[2];
+                split_vars<T, 2, ISO, true>(qq, kq, d, b);
+                b0c[j] = b[0];
+                b1c[j] = b[1];
+                t0c[j] = ell * (b[0] - d[0]);
+                t1c[j] = ell * (b[1] - d[1]);
             }
-            T un[N], q1o[N], q0o[N], b0c[N], t0c[N];
-            // U_{s+1}[p-1]: the next stage's current row, or the last level's previous row
-            T unm[N];
-#pragma unroll
-            for (int j = 0; j < N; ++j) unm[j] = (s < K - 1) ? uc[s + 1][j] : ulast[j];
-            {
-                // rows outside [0, n0) are computed like any other (finite garbage, never stored); the two
-                // image borders are rare wave-uniform fix-ups of the carried state
-                T b1c[N], t1c[N];
+            if (p == 0) {  // replicate the row above the image
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
-                    T qq[2] = {q0c_s[j], q1c[j]}, d[2], b[2];
-                    split_vars<T, 2, ISO, true>(qq, kq, d, b);
-                    b0c[j] = b[0];
-                    b1c[j] = b[1];
-                    t0c[j] = ell * (b[0] - d[0]);
-                    t1c[j] = ell * (b[1] - d[1]);
+                    um[j] = uc[j];
+                    t0m[j] = t0c[j];
                 }
-                if (p == 0) {  // replicate the row above the image: N uses u[0] twice, forward_diff is 0
+            }
+            T t1l[N], ul[N], ur[N], ucl[N], ucr[N];
+            shifted<-C, DPP>(t1c, t1l);
+            shifted<-C, DPP>(uc, ul);
+            shifted<+C, DPP>(uc, ur);
+            if constexpr (COUPLED) {
+                shifted<-1, DPP>(uc, ucl);
+                shifted<+1, DPP>(uc, ucr);
+            }
+            T rhs[N], acc[N];
 #pragma unroll
-                    for (int j = 0; j < N; ++j) {
-                        um[s][j] = uc[s][j];
-                        t0m[s][j] = t0c[j];
-                    }
+            for (int j = 0; j < N; ++j) {
+                rhs[j] = ofv[j] + (t0c[j] - t0m[j]);
+                if constexpr (EDGE)
+                    rhs[j] = rhs[j] + (t1c[j] - (edgeL[j] ? t1c[j] : t1l[j]));
+                else
+                    rhs[j] = rhs[j] + (t1c[j] - t1l[j]);
+                acc[j] = um[j] + up[j];
+                if constexpr (EDGE) {
+                    acc[j] = acc[j] + (edgeL[j] ? uc[j] : ul[j]);
+                    acc[j] = acc[j] + (edgeR[j] ? uc[j] : ur[j]);
+                } else {
+                    acc[j] = acc[j] + ul[j];
+                    acc[j] = acc[j] + ur[j];
                 }
-                T t1l[N], ul[N], ur[N], ucl[N], ucr[N];
-                shifted<-C, DPP>(t1c, t1l);
-                shifted<-C, DPP>(uc[s], ul);
-                shifted<+C, DPP>(uc[s], ur);
                 if constexpr (COUPLED) {
-                    shifted<-1, DPP>(uc[s], ucl);
-                    shifted<+1, DPP>(uc[s], ucr);
-                }
-#pragma unroll
-                for (int j = 0; j < N; ++j) {
-                    T rhs = ofd[s][j] + (t0c[j] - t0m[s][j]);
-                    if constexpr (EDGE)
-                        rhs = rhs + (t1c[j] - (edgeL[j] ? t1c[j] : t1l[j]));
-                    else
-                        rhs = rhs + (t1c[j] - t1l[j]);
-                    const T rsc = rhs / diag;
-                    T acc = um[s][j] + up_s[j];
-                    if constexpr (EDGE) {
-                        acc = acc + (edgeL[j] ? uc[s][j] : ul[j]);
-                        acc = acc + (edgeR[j] ? uc[s][j] : ur[j]);
-                    } else {
-                        acc = acc + ul[j];
-                        acc = acc + ur[j];
-                    }
-                    if constexpr (COUPLED) {
-                        acc = acc + (ch0[j] ? uc[s][j] : ucl[j]);
-                        acc = acc + (chLast[j] ? uc[s][j] : ucr[j]);
-                    }
-                    un[j] = rsc + acc / dsc;
-                }
-                if (p >= nrow) {  // below the image: replicate the new iterate (row difference 0)
-#pragma unroll
-                    for (int j = 0; j < N; ++j) un[j] = unm[j];
-                }
-                T unr[N];
-                shifted<+C, DPP>(un, unr);
-#pragma unroll
-                for (int j = 0; j < N; ++j) {
-                    if constexpr (EDGE)
-                        q1o[j] = ((edgeR[j] ? un[j] : unr[j]) - un[j]) + b1c[j];
-                    else
-                        q1o[j] = (unr[j] - un[j]) + b1c[j];
+                    acc[j] = acc[j] + (ch0[j] ? uc[j] : ucl[j]);
+                    acc[j] = acc[j] + (chLast[j] ? uc[j] : ucr[j]);
                 }
             }
+            {
+                T lo = t_min(t_abs(rhs[0]), t_abs(acc[0]));
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    un[j] = div_by_const(rhs[j], diag, rdiag) + div_by_const(acc[j], dsc, rdsc);
+                    if (j > 0) lo = t_min(lo, t_min(t_abs(rhs[j]), t_abs(acc[j])));
+                }
+                if (__builtin_expect(__any(lo < DivSafe<T>::tiny), 0)) {
+                    bool unsafe = false;
+#pragma unroll
+                    for (int j = 0; j < N; ++j) unsafe = unsafe || div_unsafe(rhs[j]) || div_unsafe(acc[j]);
+                    if (__any(unsafe)) {
+#pragma unroll
+                        for (int j = 0; j < N; ++j) un[j] = rhs[j] / diag + acc[j] / dsc;
+                    }
+                }
+            }
+            if (p >= nrow) {  // below the image: replicate the new iterate
+#pragma unroll
+                for (int j = 0; j < N; ++j) un[j] = unm[j];
+            }
+            T unr[N], q1o[N], q0o[N];
+            shifted<+C, DPP>(un, unr);
 #pragma unroll
             for (int j = 0; j < N; ++j) {
-                q0o[j] = (un[j] - unm[j]) + b0m[s][j];
-                t0save[s][j] = t0c[j];
-                b0save[s][j] = b0c[j];
-                q1new[s][j] = q1o[j];
+                if constexpr (EDGE)
+                    q1o[j] = ((edgeR[j] ? un[j] : unr[j]) - un[j]) + b1c[j];
+                else
+                    q1o[j] = (unr[j] - un[j]) + b1c[j];
+                q0o[j] = (un[j] - unm[j]) + b0m[j];
             }
-            if (s == K - 1) {
+            if constexpr (last) {
                 if (store_lane) {
                     if (p >= R0 && p < R1) {
                         if constexpr (NTS) {
@@ -830,45 +819,110 @@ __device__ __forceinline__ void fused_multi_body(const FusedArgs<T>& a, const in
                             store_vec(q0_out + (p - 1) * P, q0o);
                     }
                 }
-#pragma unroll
-                for (int j = 0; j < N; ++j) ulast[j] = un[j];
             } else {
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
-                    up_s[j] = un[j];    // U_{s+1}[p] = row above-next of stage s+1 (its p+1)
-                    q0c_s[j] = q0o[j];  // Q0_{s+1}[p-1] = stage s+1's current row
+                    st.q1[s + 1][prv][j] = q1o[j];  // read by stage s+1 at the next step (its parity "cur")
+                    q0h[j] = q0o[j];
                 }
             }
-        }
-        // rotate all stages
+        });
 #pragma unroll
-        for (int s = 0; s < K; ++s)
+        for (int j = 0; j < N; ++j) st.of[(PH + 1) & 3][j] = frn[j];
+    }
+};
+
+template <typename T, int C, bool COUPLED, bool ISO, int K, bool NTS, bool EDGE>
+__device__ __forceinline__ void fused_pipe_body(const FusedArgs<T>& a, const int strip, const int chunk, const int lane) {
+    constexpr int N = VecOf<T>::N;
+    using SG = StripGeomK<T, C, K>;
+    Pipe<T, C, COUPLED, ISO, K, NTS, EDGE> pp;
+    pp.R0 = (int64_t)chunk * a.rows_per_chunk;
+    pp.R1 = (pp.R0 + a.rows_per_chunk < a.n0) ? pp.R0 + a.rows_per_chunk : a.n0;
+    if (pp.R0 >= a.n0) return;
+    const int64_t x0 = (int64_t)strip * SG::STRIDE + (int64_t)(lane - SG::LH) * N;
+    int64_t xl = x0;
+    if (xl < 0) xl = 0;
+    if (xl > a.pitch - N) xl = a.pitch - N;
+    pp.store_lane = lane >= SG::LH && lane < SG::LH + SG::VALID && x0 < a.L;
 #pragma unroll
-            for (int j = 0; j < N; ++j) {
-                um[s][j] = uc[s][j];
-                uc[s][j] = upsave[s][j];
-                t0m[s][j] = t0save[s][j];
-                b0m[s][j] = b0save[s][j];
-            }
+    for (int j = 0; j < N; ++j) {
+        const int64_t x = x0 + j;
+        pp.edgeL[j] = x < C;
+        pp.edgeR[j] = x >= a.L - C;
+        const int cc = (int)(((x % C) + C) % C);
+        pp.ch0[j] = cc == 0;
+        pp.chLast[j] = cc == C - 1;
+    }
+    pp.of_p = a.of + xl;
+    pp.u_in = a.u_in + xl;
+    pp.q0_in = a.q0_in + xl;
+    pp.q1_in = a.q1_in + xl;
+    pp.u_out = a.u_out + xl;
+    pp.q0_out = a.q0_out + xl;
+    pp.q1_out = a.q1_out + xl;
+    pp.P = a.pitch;
+    pp.nrow = a.n0;
+    pp.ell = a.c.ell;
+    pp.diag = a.c.diag;
+    pp.dsc = a.c.dsc;
+    pp.kq = a.c.kq;
+    pp.rdiag = a.c.rdiag;
+    pp.rdsc = a.c.rdsc;
+
+    PipeState<T, K> st;
 #pragma unroll
-        for (int s = K - 1; s >= 1; --s)
+    for (int l = 0; l <= K; ++l)
 #pragma unroll
-            for (int j = 0; j < N; ++j) {
-                q1h[s][j] = q1new[s - 1][j];
-                ofd[s][j] = ofd[s - 1][j];
-            }
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) st.U[l][i][j] = T(0);
+#pragma unroll
+    for (int l = 0; l < K; ++l)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) st.t0[l][i][j] = st.b0[l][i][j] = st.q1[l][i][j] = T(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) st.of[i][j] = T(0);
+
+    // prologue: phase 0 at row rs = R0 - (K-1): rows rs-1, rs, rs+1 of u in slots 3, 0, 1
+    const int64_t rs = pp.R0 - (K - 1);
+    const int64_t P = pp.P;
+    load_vec(pp.u_in + pp.clampr(rs - 1) * P, st.U[0][3]);
+    load_vec(pp.u_in + pp.clampr(rs) * P, st.U[0][0]);
+    load_vec(pp.u_in + pp.clampr(rs + 1) * P, st.U[0][1]);
+    load_vec(pp.of_p + pp.clampr(rs) * P, st.of[0]);
+    load_vec(pp.q0_in + pp.clampr(rs) * P, st.q0l[0]);
+    load_vec(pp.q1_in + pp.clampr(rs) * P, st.q1[0][0]);
+    {
+        const int64_t rm = pp.clampr(rs - 1);
+        T q0v[N], q1v[N];
+        load_vec(pp.q0_in + rm * P, q0v);
+        load_vec(pp.q1_in + rm * P, q1v);
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-            ofd[0][j] = frn[j];
-            up0[j] = upn[j];
-            q0r[j] = q0n[j];
-            q1r[j] = q1n[j];
+            T qq[2] = {q0v[j], q1v[j]}, d[2], b[2];
+            split_vars<T, 2, ISO, true>(qq, pp.kq, d, b);
+            st.t0[0][1][j] = pp.ell * (b[0] - d[0]);  // parity "prv" of phase 0
+            st.b0[0][1][j] = b[0];
         }
+    }
+    // the last stage must reach row R1: steps rs .. R1 + K - 1, rounded up to whole groups of 4
+    // (extra steps touch clamped rows only and store nothing)
+    const int64_t r_end = pp.R1 + (K - 1);
+    for (int64_t r = rs; r <= r_end; r += 4) {
+        pp.template step<0>(st, r);
+        pp.template step<1>(st, r + 1);
+        pp.template step<2>(st, r + 2);
+        pp.template step<3>(st, r + 3);
     }
 }
 
 template <typename T, int C, bool COUPLED, bool ISO, int K, bool NTS = true>
-__global__ void __launch_bounds__(256) k_fused_multi(FusedArgs<T> a) {
+__global__ void __launch_bounds__(256, (K >= 4 ? DXH_LB4 : 3)) k_fused_multi(FusedArgs<T> a) {
     constexpr int N = VecOf<T>::N;
     using SG = StripGeomK<T, C, K>;
     const int lane = threadIdx.x & (kWave - 1);
@@ -882,9 +936,9 @@ __global__ void __launch_bounds__(256) k_fused_multi(FusedArgs<T> a) {
     const int64_t w0 = (int64_t)strip * SG::STRIDE - SG::LH * N;  // first element of the wave's window
     const bool edge = (w0 < C) || (w0 + kWave * N > a.L - C);     // wave-uniform
     if (edge)
-        fused_multi_body<T, C, COUPLED, ISO, K, NTS, true>(a, strip, chunk, lane);
+        fused_pipe_body<T, C, COUPLED, ISO, K, NTS, true>(a, strip, chunk, lane);
     else
-        fused_multi_body<T, C, COUPLED, ISO, K, NTS, false>(a, strip, chunk, lane);
+        fused_pipe_body<T, C, COUPLED, ISO, K, NTS, false>(a, strip, chunk, lane);
 }
 
 }  // namespace dxh

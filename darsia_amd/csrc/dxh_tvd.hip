@@ -36,7 +36,7 @@ struct Ctx {
     int num_cu = 256;
     int tune = 0;                  // developer A/B bits (DXH_FUSED_TUNE)
     int fuse_k = 4;                // outer iterations fused per launch (1..4)
-    int waves_per_cu = 0;          // fused sweep: waves per CU the grid is sized for (0 = 8 for K = 1, 12 for K > 1)
+    int waves_per_cu = 0;          // fused sweep: waves per CU the grid is sized for (0 = 8 for K = 1, 16 for K > 1)
 
     void* of = nullptr;            // omega * img
     void* u[2] = {nullptr, nullptr};
@@ -82,6 +82,13 @@ static Coef<T> make_coef(const Ctx* c) {
     k.diag = (T)c->c_diag;
     k.dsc = (T)c->c_dsc;
     k.kq = (T)c->c_kq;
+    // reciprocals for div_by_const: only for divisors in a comfortable range, rounded in T by IEEE division
+    k.rdiag = k.rdsc = T(0);
+    auto ok = [](T d) { return std::isfinite((double)d) && std::fabs((double)d) >= 0x1p-20 && std::fabs((double)d) <= 0x1p+20; };
+    if (!c->het && ok(k.diag) && ok(k.dsc)) {
+        k.rdiag = T(1) / k.diag;
+        k.rdsc = T(1) / k.dsc;
+    }
     return k;
 }
 template <typename T>
@@ -192,7 +199,7 @@ static void launch_fused_multi_t(Ctx* c, int in, int out) {
     a.pitch = c->g.pitch;
     a.nstrips = (int)((c->g.L + SG::STRIDE - 1) / SG::STRIDE);
     const int nbx = (a.nstrips + 3) / 4;
-    const int64_t target_blocks = (int64_t)c->num_cu * (c->waves_per_cu ? c->waves_per_cu : 12) / 4;
+    const int64_t target_blocks = (int64_t)c->num_cu * (c->waves_per_cu ? c->waves_per_cu : 16) / 4;
     int64_t nchunks = std::max<int64_t>(1, target_blocks / nbx);
     if (nchunks >= 8) nchunks = nchunks / 8 * 8;
     int64_t rpc = std::max<int64_t>(8 * K, (c->g.n0 + nchunks - 1) / nchunks);
@@ -207,7 +214,10 @@ static void launch_fused_multi_t(Ctx* c, int in, int out) {
 
 // channel counts the multi-iteration kernel is instantiated for
 static bool multi_supported(const Ctx* c) {
-    return c->desc.dim == 2 && !c->het && (c->g.n2 == 1 || c->g.n2 == 3);
+    if (!(c->desc.dim == 2 && !c->het && (c->g.n2 == 1 || c->g.n2 == 3))) return false;
+    // k_fused_multi divides through precomputed reciprocals: the divisors must be in a comfortable range
+    auto ok = [](double d) { return std::isfinite(d) && std::fabs(d) >= 0x1p-20 && std::fabs(d) <= 0x1p+20; };
+    return ok(c->c_diag) && ok(c->c_dsc) && !(c->tune & 8);
 }
 
 template <typename T, int C>
