@@ -15,6 +15,7 @@ from .utils.linear_solvers.solver import Solver  # noqa: F401
 from .utils.linear_solvers.jacobi import Jacobi  # noqa: F401
 from .restoration.split_bregman_tvd import DeviceTVD, split_bregman_tvd  # noqa: F401
 from .restoration.h1_regularization import H1_regularization  # noqa: F401
+from .restoration.chambolle import denoise_tv_chambolle  # noqa: F401
 from .restoration.tvd import TVD, tvd  # noqa: F401
 
 __version__ = "0.1.0"

@@ -24,7 +24,7 @@ EXPORTS = (
     "dxh_last_error", "dxh_version", "dxh_device_count",
     "dxh_tvd_create", "dxh_tvd_destroy", "dxh_tvd_set_coeffs", "dxh_tvd_upload", "dxh_tvd_run",
     "dxh_tvd_download", "dxh_tvd_halo_bytes", "dxh_tvd_pack_rows", "dxh_tvd_unpack_rows",
-    "dxh_tvd_partial_norms", "dxh_tvd_sync", "dxh_jacobi_solve", "dxh_diff",
+    "dxh_tvd_partial_norms", "dxh_tvd_sync", "dxh_jacobi_solve", "dxh_diff", "dxh_chambolle",
 )
 
 
@@ -73,6 +73,7 @@ def _declare(lib):
     lib.dxh_jacobi_solve.argtypes = [i, i, i, i, i, i64, i64, i64, vp, vp, vp, dbl, vp, dbl, vp, dbl, i, dbl,
                                      C.POINTER(i)]
     lib.dxh_diff.argtypes = [i, i, i64, i64, i64, i, i, dbl, vp, vp]
+    lib.dxh_chambolle.argtypes = [i, i, i, i64, i64, i64, vp, vp, dbl, dbl, i, C.POINTER(i)]
     for name in EXPORTS:
         if name != "dxh_last_error":
             getattr(lib, name).restype = i

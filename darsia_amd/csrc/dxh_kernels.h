@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(256) k_sqdiff_partial(Geom g, const T* __restr
     }
 }
 
-__global__ void __launch_bounds__(256) k_sum_partials(const double* __restrict__ partial, int n, double* __restrict__ out) {
+static __global__ void __launch_bounds__(256) k_sum_partials(const double* __restrict__ partial, int n, double* __restrict__ out) {
     __shared__ double sm[256];
     double acc = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];

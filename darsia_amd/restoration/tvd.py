@@ -14,9 +14,10 @@ from __future__ import annotations
 
 import numpy as np
 
+from .chambolle import denoise_tv_chambolle
 from .split_bregman_tvd import split_bregman_tvd
 
-_SKIMAGE_METHODS = ("chambolle", "anisotropic bregman", "isotropic bregman")
+_SKIMAGE_BREGMAN = ("anisotropic bregman", "isotropic bregman")
 
 
 def _is_image(obj) -> bool:
@@ -56,10 +57,14 @@ class TVD:
                 eps=self.eps,
                 **self.kwargs,
             )
-        elif self.method in _SKIMAGE_METHODS:
+        elif self.method == "chambolle":
+            # tvd.py:77-83: no channel axis -> colour images are denoised as 3-D volumes
+            return denoise_tv_chambolle(img, weight=self.weight, max_num_iter=self.max_num_iter, eps=self.eps)
+        elif self.method in _SKIMAGE_BREGMAN:
             raise NotImplementedError(
-                f"method '{self.method}' is scikit-image arithmetic (tvd.py:77-101), not part of the MI355X "
-                "hot path yet; use method='heterogeneous bregman'")
+                f"method '{self.method}' is scikit-image's Gauss-Seidel split Bregman (tvd.py:85-101), a "
+                "sequential raster sweep that is not part of the MI355X hot path; use 'chambolle' or "
+                "'heterogeneous bregman'")
         else:
             raise ValueError(f"Method {self.method} not supported.")
 

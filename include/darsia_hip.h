@@ -153,6 +153,15 @@ int dxh_jacobi_solve(int device, int dtype, int ndim, int dim, int nsum, int64_t
 int dxh_diff(int device, int dtype, int64_t n0, int64_t n1, int64_t n2, int axis, int mode, double h,
              const void* in, void* out);
 
+/*
+ * Chambolle's TV projection algorithm: the arithmetic of DarSIA's default TVD() method, which the
+ * reference obtains from skimage.restoration.denoise_tv_chambolle(img, weight, max_num_iter, eps)
+ * (restoration/tvd.py:77-83; no channel axis, so an (H, W, 3) image is a 3-D volume, ndim = 3).
+ * Stops when |E_prev - E| < eps * E_0; *iters_done = iterations completed before the stop.
+ */
+int dxh_chambolle(int device, int dtype, int ndim, int64_t n0, int64_t n1, int64_t n2, const void* img, void* out,
+                  double weight, double eps, int max_num_iter, int* iters_done);
+
 #ifdef __cplusplus
 }
 #endif

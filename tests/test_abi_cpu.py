@@ -75,7 +75,7 @@ def test_error_types_match_reference(golden):
     with pytest.raises(TypeError):
         da.split_bregman_tvd(np.zeros((4, 4), np.uint8))
     with pytest.raises(NotImplementedError):
-        da.TVD()(np.zeros((4, 4), np.float32))  # skimage 'chambolle' is not on the device path yet
+        da.TVD(method="isotropic bregman")(np.zeros((4, 4), np.float32))  # skimage's Gauss-Seidel sweep
 
 
 def test_operator_call_signature_is_plain_method():

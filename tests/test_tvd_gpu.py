@@ -248,3 +248,36 @@ def test_temporal_blocking_is_bit_exact(monkeypatch, fuse_k):
     img = rng.random((120, 260, 3)).astype(np.float32)
     out, _ = run_device(img, mu=0.1, n_iter=6, isotropic=True)
     assert_bits(out, O.split_bregman_tvd(img, mu=0.1, max_num_iter=6, isotropic=True, promotion="strict"))
+
+
+# ---- Chambolle (default TVD() method) --------------------------------------------------------------
+import os as _os
+
+from oracle import chambolle_numpy as OC
+
+
+@pytest.fixture(scope="module")
+def sk():
+    root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    return np.load(_os.path.join(root, "tests", "golden", "skimage_0_18_3_golden.npz"))
+
+
+@pytest.mark.parametrize("name", ["c2d_f64", "c2d_f32", "c2d_fixed_f64", "c2d_fixed_f32", "crgb_f32",
+                                  "crgb_fixed_f64", "c2d_one_iter", "c2d_tiny"])
+def test_chambolle_vs_skimage_golden(sk, name):
+    """Bit-exact per iteration; the stop iteration may differ only if the energy test is within rounding
+    (energies are reduced in double here, in the image dtype with pairwise sums in NumPy)."""
+    img = sk[name + "/img"]
+    w, eps, n = (float(v) for v in sk[name + "/kw"])
+    out, iters = da.denoise_tv_chambolle(img, weight=w, eps=eps, max_num_iter=int(n), return_iters=True)
+    ref, ref_iters = OC.denoise_tv_chambolle(img, weight=w, eps=eps, max_num_iter=int(n), return_iters=True)
+    assert iters == ref_iters
+    assert_bits(out, ref)
+    assert_bits(out, sk[name + "/out"])
+
+
+def test_default_tvd_is_chambolle(sk):
+    img = sk["crgb_f32/img"]
+    out = da.TVD()(img)  # method "chambolle", weight 0.1, max_num_iter 200, eps 2e-4 (tvd.py:31-43)
+    assert_bits(out, sk["crgb_f32/out"])
+    assert_bits(da.tvd(img, weight=0.1), out)
