@@ -18,4 +18,8 @@ from .restoration.h1_regularization import H1_regularization  # noqa: F401
 from .restoration.chambolle import denoise_tv_chambolle  # noqa: F401
 from .restoration.tvd import TVD, tvd  # noqa: F401
 
+from .color import AffineBalance, BaseBalance, apply_affine_balance  # noqa: F401
+from .registration import (Patches, PiecewisePerspectiveTransform, evaluate_rbf, evaluate_rbf_on_grid,  # noqa: F401
+                           get_perspective_transform)
+
 __version__ = "0.1.0"

@@ -25,6 +25,7 @@ EXPORTS = (
     "dxh_tvd_create", "dxh_tvd_destroy", "dxh_tvd_set_coeffs", "dxh_tvd_upload", "dxh_tvd_run",
     "dxh_tvd_download", "dxh_tvd_halo_bytes", "dxh_tvd_pack_rows", "dxh_tvd_unpack_rows",
     "dxh_tvd_partial_norms", "dxh_tvd_sync", "dxh_jacobi_solve", "dxh_diff", "dxh_chambolle",
+    "dxh_warp_patches", "dxh_tps_eval", "dxh_affine_color",
 )
 
 
@@ -39,6 +40,15 @@ class TvdDesc(C.Structure):
         ("n0", C.c_int64), ("n1", C.c_int64), ("n2", C.c_int64),
         ("top_is_boundary", C.c_int32), ("bottom_is_boundary", C.c_int32),
         ("stream", C.c_void_p),
+    ]
+
+
+class WarpPatch(C.Structure):
+    """dxh_warp_patch (include/darsia_hip.h)."""
+    _fields_ = [
+        ("minv", C.c_double * 9), ("sr0", C.c_int32), ("sc0", C.c_int32), ("sh", C.c_int32), ("sw", C.c_int32),
+        ("ox", C.c_int32), ("oy", C.c_int32), ("w_eff", C.c_int32), ("h_eff", C.c_int32),
+        ("nx", C.c_int32), ("ny", C.c_int32), ("bw0", C.c_int32), ("pad", C.c_int32),
     ]
 
 
@@ -74,6 +84,9 @@ def _declare(lib):
                                      C.POINTER(i)]
     lib.dxh_diff.argtypes = [i, i, i64, i64, i64, i, i, dbl, vp, vp]
     lib.dxh_chambolle.argtypes = [i, i, i, i64, i64, i64, vp, vp, dbl, dbl, i, C.POINTER(i)]
+    lib.dxh_warp_patches.argtypes = [i, i, i, i, vp, vp, i, vp]
+    lib.dxh_tps_eval.argtypes = [i, i, i, vp, vp, vp, vp, vp, i64, vp, i, dbl, dbl, dbl, dbl, vp]
+    lib.dxh_affine_color.argtypes = [i, i, i64, vp, vp, vp, i, vp]
     for name in EXPORTS:
         if name != "dxh_last_error":
             getattr(lib, name).restype = i

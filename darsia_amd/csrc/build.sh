@@ -7,5 +7,5 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 # -ffp-contract=off: every operation rounds once, as in the NumPy evaluation the results are compared with
 "${HIPCC}" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off \
     -Wall -Wno-unused-function \
-    "${HERE}/dxh_tvd.hip" "${HERE}/dxh_chambolle.hip" -o "${OUT}" "$@"
+    "${HERE}/dxh_tvd.hip" "${HERE}/dxh_chambolle.hip" "${HERE}/dxh_dense.hip" -o "${OUT}" "$@"
 echo "built ${OUT}"

@@ -1,0 +1,297 @@
+// Dense per-pixel kernels around the TV path: piecewise perspective warp (registration), thin-plate
+// spline displacement field, affine colour balance.  gfx950 only.
+#include <cmath>
+#include <vector>
+
+#include "dxh_common.h"
+
+namespace dxh {
+
+// ---- piecewise perspective warp -------------------------------------------------------------------
+// One thread per canvas pixel (all channels).  It visits the patch table in the reference's loop order
+// (piecewiseperspective.py:71-133) and, for every patch whose effective destination rectangle covers
+// the pixel, evaluates OpenCV's float32 bilinear perspective sample (see oracle/warp_numpy.py for the
+// restated algorithm) and adds it to the pixel in float32 -- the same order of additions as the
+// reference's  canvas[roi] += tmp , hence deterministic and free of atomics.
+struct WarpPatch {
+    double minv[9];              // inverse homography: destination (patch-local) -> source (patch-local)
+    int sr0, sc0, sh, sw;        // source patch: origin in the base image and size
+    int ox, oy;                  // origin of the warped tile in the canvas (x = column, y = row)
+    int w_eff, h_eff;            // size of the warped tile (cv2 dsize)
+    int nx, ny;                  // part of the tile added to the canvas: canvas[oy:oy+ny, ox:ox+nx]
+    int bw0;                     // OpenCV's block width for this tile size
+    int pad;
+};
+
+__device__ __forceinline__ long long round_half_even_clamped(double v) {
+    const double lo = -2147483648.0, hi = 2147483647.0;
+    v = v < lo ? lo : (v > hi ? hi : v);  // max(INT_MIN, min(INT_MAX, v)); NaN falls through to lo below
+    if (!(v == v)) v = lo;
+    return (long long)rint(v);            // round half to even, like cvRound / lrint
+}
+
+template <int C>
+__global__ void __launch_bounds__(256) k_warp(const float* __restrict__ base, int H, int W, const WarpPatch* __restrict__ pt,
+                                               int npatch, float* __restrict__ canvas) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= W || y >= H) return;
+    float acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = 0.f;
+    for (int k = 0; k < npatch; ++k) {
+        const WarpPatch& p = pt[k];
+        const int tx = x - p.ox, ty = y - p.oy;
+        if (tx < 0 || ty < 0 || tx >= p.nx || ty >= p.ny) continue;
+        const int bx = (tx / p.bw0) * p.bw0;
+        const double x1 = (double)(tx - bx), fbx = (double)bx, fy_ = (double)ty;
+        const double X0 = p.minv[0] * fbx + p.minv[1] * fy_ + p.minv[2];
+        const double Y0 = p.minv[3] * fbx + p.minv[4] * fy_ + p.minv[5];
+        const double W0 = p.minv[6] * fbx + p.minv[7] * fy_ + p.minv[8];
+        double Wd = W0 + p.minv[6] * x1;
+        Wd = Wd != 0.0 ? 32.0 / Wd : 0.0;
+        const long long X = round_half_even_clamped((X0 + p.minv[0] * x1) * Wd);
+        const long long Y = round_half_even_clamped((Y0 + p.minv[3] * x1) * Wd);
+        long long sx = X >> 5, sy = Y >> 5;
+        sx = sx < -32768 ? -32768 : (sx > 32767 ? 32767 : sx);
+        sy = sy < -32768 ? -32768 : (sy > 32767 ? 32767 : sy);
+        const float fx = (float)(X & 31) * (1.0f / 32.0f), fy = (float)(Y & 31) * (1.0f / 32.0f);
+        const float wx[2] = {1.0f - fx, fx}, wy[2] = {1.0f - fy, fy};
+        float v[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) v[c] = 0.f;
+        bool first = true;
+#pragma unroll
+        for (int ky = 0; ky < 2; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 2; ++kx) {
+                const long long yy = sy + ky, xx = sx + kx;
+                const bool ok = yy >= 0 && yy < p.sh && xx >= 0 && xx < p.sw;
+                const float wgt = wy[ky] * wx[kx];
+                const float* s = base + ((size_t)(p.sr0 + (ok ? yy : 0)) * W + (p.sc0 + (ok ? xx : 0))) * C;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float term = (ok ? s[c] : 0.f) * wgt;
+                    v[c] = first ? term : v[c] + term;
+                }
+                first = false;
+            }
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = acc[c] + v[c];
+    }
+    float* o = canvas + ((size_t)y * W + x) * C;
+#pragma unroll
+    for (int c = 0; c < C; ++c) o[c] = acc[c];
+}
+
+// ---- thin-plate-spline field ------------------------------------------------------------------------
+// out[n][d] = sum_i coef[i][d] * r^2 log r  +  polynomial(xhat) with r = |x_n - y_i|, SciPy's
+// RBFInterpolator evaluation for kernel 'thin_plate_spline', epsilon = 1 (translationanalysis.py:285-301,
+// imageregistration.py:265-306).  Points are either given explicitly or are the pixel grid
+// (x = column + 0 , y = row) scaled by an affine map, so that the dense field needs no point upload.
+struct TpsArgs {
+    const double* centers;  // (p, 2)
+    const double* coeffs;   // (p + 3, dout)
+    const double* points;   // (n, 2) or null for the grid
+    double shift[2], scale[2];
+    int powers[3][2];
+    int p, dout;
+    long long n;
+    int grid_w;             // grid mode: point n = (gx0 + gsx * (n % grid_w), gy0 + gsy * (n / grid_w))
+    double gx0, gy0, gsx, gsy;
+    double* out;            // (n, dout)
+};
+
+__global__ void __launch_bounds__(256) k_tps(TpsArgs a) {
+    extern __shared__ double sm[];  // centers (2p) then coeffs ((p+3) * dout)
+    const int nc = 2 * a.p, nk = (a.p + 3) * a.dout;
+    for (int i = threadIdx.x; i < nc; i += blockDim.x) sm[i] = a.centers[i];
+    for (int i = threadIdx.x; i < nk; i += blockDim.x) sm[nc + i] = a.coeffs[i];
+    __syncthreads();
+    const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= a.n) return;
+    double x, y;
+    if (a.points) {
+        x = a.points[2 * n];
+        y = a.points[2 * n + 1];
+    } else {
+        x = a.gx0 + a.gsx * (double)(n % a.grid_w);
+        y = a.gy0 + a.gsy * (double)(n / a.grid_w);
+    }
+    double acc0 = 0.0, acc1 = 0.0;
+    const double* cf = sm + nc;
+    for (int i = 0; i < a.p; ++i) {
+        const double dx = x - sm[2 * i], dy = y - sm[2 * i + 1];
+        const double r = sqrt(dx * dx + dy * dy);
+        const double phi = r == 0.0 ? 0.0 : (r * r) * log(r);
+        acc0 += phi * cf[i * a.dout];
+        if (a.dout > 1) acc1 += phi * cf[i * a.dout + 1];
+    }
+    const double xh = (x - a.shift[0]) / a.scale[0], yh = (y - a.shift[1]) / a.scale[1];
+    for (int j = 0; j < 3; ++j) {
+        const double mono = pow(xh, (double)a.powers[j][0]) * pow(yh, (double)a.powers[j][1]);
+        acc0 += mono * cf[(a.p + j) * a.dout];
+        if (a.dout > 1) acc1 += mono * cf[(a.p + j) * a.dout + 1];
+    }
+    a.out[n * a.dout] = acc0;
+    if (a.dout > 1) a.out[n * a.dout + 1] = acc1;
+}
+
+// ---- affine colour balance -----------------------------------------------------------------------------
+// out = img_as_float(img) @ A + b, optional clip to [0, 1], float32 result
+// (corrections/color/colorbalance.py:186-196, colorcorrection.py:388-394); arithmetic in double.
+template <typename TIN>
+__global__ void __launch_bounds__(256) k_affine_color(const TIN* __restrict__ in, long long npix, double in_scale,
+                                                       const double* __restrict__ ab, int clip, float* __restrict__ out) {
+    const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= npix) return;
+    double x[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) x[k] = (double)in[3 * n + k] / in_scale;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double v = x[0] * ab[0 * 3 + c];
+        v = v + x[1] * ab[1 * 3 + c];
+        v = v + x[2] * ab[2 * 3 + c];
+        v = v + ab[9 + c];
+        if (clip) v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+        out[3 * n + c] = (float)v;
+    }
+}
+
+struct Dev {
+    std::vector<void*> bufs;
+    hipStream_t st = nullptr;
+    ~Dev() {
+        for (void* b : bufs) if (b) (void)hipFree(b);
+        if (st) (void)hipStreamDestroy(st);
+    }
+    int alloc(void** p, size_t n) {
+        DXH_HIP(hipMalloc(p, n ? n : 1));
+        bufs.push_back(*p);
+        return DXH_OK;
+    }
+};
+
+static int check_device(int device) {
+    int ndev = 0;
+    DXH_HIP(hipGetDeviceCount(&ndev));
+    DXH_REQUIRE(device >= 0 && device < ndev, "device %d not available (%d devices)", device, ndev);
+    DXH_HIP(hipSetDevice(device));
+    return DXH_OK;
+}
+
+}  // namespace dxh
+
+using namespace dxh;
+
+extern "C" {
+
+int dxh_warp_patches(int device, int H, int W, int C, const float* base, const dxh_warp_patch* patches, int npatch,
+                     float* canvas) {
+    DXH_REQUIRE(base && canvas && (patches || npatch == 0), "null argument");
+    DXH_REQUIRE(H >= 1 && W >= 1 && (C == 1 || C == 3), "shape (%d, %d, %d) not supported (C must be 1 or 3)", H, W, C);
+    static_assert(sizeof(dxh_warp_patch) == sizeof(WarpPatch), "patch struct mismatch");
+    int rc = check_device(device);
+    if (rc) return rc;
+    for (int k = 0; k < npatch; ++k) {
+        const dxh_warp_patch& p = patches[k];
+        DXH_REQUIRE(p.sr0 >= 0 && p.sc0 >= 0 && p.sh >= 1 && p.sw >= 1 && p.sr0 + p.sh <= H && p.sc0 + p.sw <= W,
+                    "patch %d: source rectangle outside the image", k);
+        DXH_REQUIRE(p.ox >= 0 && p.oy >= 0 && p.nx >= 0 && p.ny >= 0 && p.ox + p.nx <= W && p.oy + p.ny <= H,
+                    "patch %d: destination rectangle outside the canvas", k);
+        DXH_REQUIRE(p.bw0 >= 1, "patch %d: bad block width", k);
+    }
+    Dev d;
+    DXH_HIP(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking));
+    const size_t bytes = (size_t)H * W * C * sizeof(float);
+    void *dbase = nullptr, *dcanvas = nullptr, *dpt = nullptr;
+    if ((rc = d.alloc(&dbase, bytes)) || (rc = d.alloc(&dcanvas, bytes)) || (rc = d.alloc(&dpt, sizeof(WarpPatch) * (size_t)npatch)))
+        return rc;
+    DXH_HIP(hipMemcpyAsync(dbase, base, bytes, hipMemcpyHostToDevice, d.st));
+    if (npatch) DXH_HIP(hipMemcpyAsync(dpt, patches, sizeof(WarpPatch) * (size_t)npatch, hipMemcpyHostToDevice, d.st));
+    const dim3 grid((W + 255) / 256, H), blk(256);
+    if (C == 1)
+        hipLaunchKernelGGL((k_warp<1>), grid, blk, 0, d.st, (const float*)dbase, H, W, (const WarpPatch*)dpt, npatch, (float*)dcanvas);
+    else
+        hipLaunchKernelGGL((k_warp<3>), grid, blk, 0, d.st, (const float*)dbase, H, W, (const WarpPatch*)dpt, npatch, (float*)dcanvas);
+    DXH_HIP(hipGetLastError());
+    DXH_HIP(hipMemcpyAsync(canvas, dcanvas, bytes, hipMemcpyDeviceToHost, d.st));
+    DXH_HIP(hipStreamSynchronize(d.st));
+    return DXH_OK;
+}
+
+int dxh_tps_eval(int device, int p, int dout, const double* centers, const double* coeffs, const double* shift,
+                 const double* scale, const int* powers, int64_t n, const double* points, int grid_w, double gx0,
+                 double gy0, double gsx, double gsy, double* out) {
+    DXH_REQUIRE(centers && coeffs && shift && scale && powers && out, "null argument");
+    DXH_REQUIRE(p >= 1 && (dout == 1 || dout == 2), "p >= 1 and dout in {1, 2} required");
+    DXH_REQUIRE(n >= 0 && (points || grid_w >= 1), "bad point set");
+    const size_t smem = sizeof(double) * (2 * (size_t)p + (size_t)(p + 3) * dout);
+    DXH_REQUIRE(smem <= 64 * 1024, "too many centres (%d) for the LDS-resident table", p);
+    int rc = check_device(device);
+    if (rc) return rc;
+    if (n == 0) return DXH_OK;
+    Dev d;
+    DXH_HIP(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking));
+    void *dc = nullptr, *dk = nullptr, *dp = nullptr, *dout_ = nullptr;
+    if ((rc = d.alloc(&dc, sizeof(double) * 2 * p)) || (rc = d.alloc(&dk, sizeof(double) * (p + 3) * dout)) ||
+        (rc = d.alloc(&dout_, sizeof(double) * (size_t)n * dout)))
+        return rc;
+    DXH_HIP(hipMemcpyAsync(dc, centers, sizeof(double) * 2 * p, hipMemcpyHostToDevice, d.st));
+    DXH_HIP(hipMemcpyAsync(dk, coeffs, sizeof(double) * (p + 3) * dout, hipMemcpyHostToDevice, d.st));
+    if (points) {
+        if ((rc = d.alloc(&dp, sizeof(double) * 2 * (size_t)n))) return rc;
+        DXH_HIP(hipMemcpyAsync(dp, points, sizeof(double) * 2 * (size_t)n, hipMemcpyHostToDevice, d.st));
+    }
+    TpsArgs a;
+    a.centers = (const double*)dc;
+    a.coeffs = (const double*)dk;
+    a.points = (const double*)dp;
+    for (int i = 0; i < 2; ++i) { a.shift[i] = shift[i]; a.scale[i] = scale[i]; }
+    for (int j = 0; j < 3; ++j) for (int i = 0; i < 2; ++i) a.powers[j][i] = powers[2 * j + i];
+    a.p = p; a.dout = dout; a.n = n;
+    a.grid_w = grid_w > 0 ? grid_w : 1;
+    a.gx0 = gx0; a.gy0 = gy0; a.gsx = gsx; a.gsy = gsy;
+    a.out = (double*)dout_;
+    hipLaunchKernelGGL(k_tps, dim3((unsigned)((n + 255) / 256)), dim3(256), smem, d.st, a);
+    DXH_HIP(hipGetLastError());
+    DXH_HIP(hipMemcpyAsync(out, dout_, sizeof(double) * (size_t)n * dout, hipMemcpyDeviceToHost, d.st));
+    DXH_HIP(hipStreamSynchronize(d.st));
+    return DXH_OK;
+}
+
+int dxh_affine_color(int device, int in_dtype, int64_t npix, const void* img, const double* A, const double* b,
+                     int clip, float* out) {
+    DXH_REQUIRE(img && A && b && out, "null argument");
+    DXH_REQUIRE(npix >= 0, "npix must be >= 0");
+    DXH_REQUIRE(in_dtype >= 0 && in_dtype <= 3, "in_dtype: 0 float32, 1 float64, 2 uint8, 3 uint16");
+    int rc = check_device(device);
+    if (rc) return rc;
+    if (npix == 0) return DXH_OK;
+    const size_t esz = in_dtype == 0 ? 4 : in_dtype == 1 ? 8 : in_dtype == 2 ? 1 : 2;
+    Dev d;
+    DXH_HIP(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking));
+    void *din = nullptr, *dab = nullptr, *dout_ = nullptr;
+    if ((rc = d.alloc(&din, esz * 3 * (size_t)npix)) || (rc = d.alloc(&dab, sizeof(double) * 12)) ||
+        (rc = d.alloc(&dout_, sizeof(float) * 3 * (size_t)npix)))
+        return rc;
+    double ab[12];
+    for (int i = 0; i < 9; ++i) ab[i] = A[i];
+    for (int i = 0; i < 3; ++i) ab[9 + i] = b[i];
+    DXH_HIP(hipMemcpyAsync(din, img, esz * 3 * (size_t)npix, hipMemcpyHostToDevice, d.st));
+    DXH_HIP(hipMemcpyAsync(dab, ab, sizeof ab, hipMemcpyHostToDevice, d.st));
+    const dim3 grid((unsigned)((npix + 255) / 256)), blk(256);
+    switch (in_dtype) {
+        case 0: hipLaunchKernelGGL((k_affine_color<float>), grid, blk, 0, d.st, (const float*)din, (long long)npix, 1.0, (const double*)dab, clip, (float*)dout_); break;
+        case 1: hipLaunchKernelGGL((k_affine_color<double>), grid, blk, 0, d.st, (const double*)din, (long long)npix, 1.0, (const double*)dab, clip, (float*)dout_); break;
+        case 2: hipLaunchKernelGGL((k_affine_color<unsigned char>), grid, blk, 0, d.st, (const unsigned char*)din, (long long)npix, 255.0, (const double*)dab, clip, (float*)dout_); break;
+        default: hipLaunchKernelGGL((k_affine_color<unsigned short>), grid, blk, 0, d.st, (const unsigned short*)din, (long long)npix, 65535.0, (const double*)dab, clip, (float*)dout_); break;
+    }
+    DXH_HIP(hipGetLastError());
+    DXH_HIP(hipMemcpyAsync(out, dout_, sizeof(float) * 3 * (size_t)npix, hipMemcpyDeviceToHost, d.st));
+    DXH_HIP(hipStreamSynchronize(d.st));
+    return DXH_OK;
+}
+
+}  // extern "C"

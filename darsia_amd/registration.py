@@ -1,0 +1,191 @@
+"""Dense parts of DarSIA's image registration on the GPU: the piecewise
+perspective warp (corrections/shape/piecewiseperspective.py:35-145) and the
+thin-plate-spline displacement field (multi_image_analysis/
+translationanalysis.py:285-301, imageregistration.py:265-306).
+
+The sparse, OpenCV-internal feature matching that produces the per-patch
+translations (corrections/shape/translation.py, utils/features.py) is out of
+scope and stays an injectable host callback.
+
+Parity for this path is UNPINNED: the reference delegates the arithmetic to
+opencv-python (absent here, unpinned upstream); the kernels follow OpenCV's
+published float32 bilinear perspective-warp algorithm as restated in
+``oracle/warp_numpy.py`` and SciPy's RBFInterpolator evaluation.
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+from math import ceil
+from typing import Callable
+
+import numpy as np
+
+from . import _lib
+from .image import Image
+
+
+def get_perspective_transform(src: np.ndarray, dst: np.ndarray) -> np.ndarray:
+    """``cv2.getPerspectiveTransform`` for four point pairs ((4, 2), x/y order; float32 input precision)."""
+    src = np.asarray(src, dtype=np.float32).astype(np.float64)
+    dst = np.asarray(dst, dtype=np.float32).astype(np.float64)
+    if src.shape != (4, 2) or dst.shape != (4, 2):
+        raise ValueError("four (x, y) points are needed on both sides")
+    a = np.zeros((8, 8))
+    b = np.zeros(8)
+    for i in range(4):
+        x, y = src[i]
+        X, Y = dst[i]
+        a[i] = [x, y, 1, 0, 0, 0, -x * X, -y * X]
+        a[i + 4] = [0, 0, 0, x, y, 1, -x * Y, -y * Y]
+        b[i], b[i + 4] = X, Y
+    return np.append(np.linalg.solve(a, b), 1.0).reshape(3, 3)
+
+
+def _opencv_block_width(w: int, h: int) -> int:
+    bh0 = min(16, h)
+    bw0 = min(1024 // bh0, w)
+    return bw0
+
+
+class Patches:
+    """Regular grid of (possibly overlapping) rectangular patches of a 2-D image: the subset of
+    ``darsia.Patches`` (image/patches.py:28-304) the warp needs -- ROIs, corner voxels in patch-local and
+    global coordinates, patch access.  Patch sizes are ``ceil(extent / num_patches)`` voxels like the
+    reference's ``num_voxels`` (coordinatesystem.py:126-147)."""
+
+    def __init__(self, img, num_patches, rel_overlap: float = 0.0) -> None:
+        self.base = img if hasattr(img, "img") else Image(np.asarray(img))
+        arr = self.base.img
+        self.num_patches = [int(n) for n in num_patches]
+        self.num_active_spatial_axes = 2
+        nv = arr.shape[:2]
+        pv = [ceil(nv[k] / self.num_patches[k]) for k in range(2)]
+        ov = [ceil(rel_overlap * nv[k] / self.num_patches[k]) for k in range(2)]
+        self.rois = [[(slice(max(i * pv[0] - ov[0], 0), min((i + 1) * pv[0] + ov[0], nv[0])),
+                       slice(max(j * pv[1] - ov[1], 0), min((j + 1) * pv[1] + ov[1], nv[1])))
+                      for j in range(self.num_patches[1])] for i in range(self.num_patches[0])]
+        ni, nj = self.num_patches
+        self.global_corners_voxels = np.empty((ni, nj, 4, 2), dtype=int)
+        self.local_corners_voxels = np.empty((ni, nj, 4, 2), dtype=int)
+        for i in range(ni):
+            for j in range(nj):
+                r, c = self.rois[i][j]
+                # corner order: top left, bottom left, bottom right, top right (voxel = (row, col))
+                g = np.array([[r.start, c.start], [r.stop, c.start], [r.stop, c.stop], [r.start, c.stop]])
+                self.global_corners_voxels[i, j] = g
+                self.local_corners_voxels[i, j] = g - np.array([r.start, c.start])
+
+    def __call__(self, i: int, j: int) -> Image:
+        return Image(self.base.img[self.rois[i][j]])
+
+
+class PiecewisePerspectiveTransform:
+    """Globally continuous, patch-wise defined perspective transform (piecewiseperspective.py:13-145)."""
+
+    def __init__(self, **kwargs) -> None:
+        self.have_transform = False
+        self.verbosity = kwargs.get("verbosity", 0)
+
+    def find_and_warp(self, patches, displacement: Callable, reverse: bool = False):
+        """Warp ``patches.base`` by the continuous ``displacement`` map.  ``patches`` is a
+        ``darsia_amd.Patches`` or any object with the same attributes (``darsia.Patches`` included);
+        ``displacement(points_xy)`` returns a (2, n) array like the reference's interpolator pair."""
+        if patches.num_active_spatial_axes != 2:
+            raise NotImplementedError
+        base = patches.base.img
+        if base.ndim not in (2, 3) or (base.ndim == 3 and base.shape[2] != 3):
+            raise NotImplementedError("2-D scalar or RGB images only")
+        h, w = base.shape[:2]
+        chans = 1 if base.ndim == 2 else 3
+        records = []
+        for i in range(patches.num_patches[0]):
+            for j in range(patches.num_patches[1]):
+                gc = np.fliplr(np.asarray(patches.global_corners_voxels[i, j], dtype=np.float64))
+                lc = np.fliplr(np.asarray(patches.local_corners_voxels[i, j], dtype=np.float64))
+                pts_dst = gc + (-1.0 if reverse else 1.0) * np.asarray(displacement(gc)).T
+                origin = np.array([max(0, np.min(pts_dst[:, 0])), max(0, np.min(pts_dst[:, 1]))]).astype(np.int32)
+                pts_dst_eff = pts_dst - origin
+                w_eff = ceil(min(w, np.max(pts_dst[:, 0])) - max(0, origin[0]))
+                h_eff = ceil(min(h, np.max(pts_dst[:, 1])) - max(0, origin[1]))
+                if min(h_eff, w_eff) <= 1:
+                    continue
+                ox, oy = int(origin[0]), int(origin[1])
+                nx, ny = min(w, ox + w_eff) - ox, min(h, oy + h_eff) - oy
+                if nx <= 0 or ny <= 0:
+                    continue
+                p_eff = get_perspective_transform(lc.astype(np.float32), pts_dst_eff.astype(np.float32))
+                rec = _lib.WarpPatch()
+                rec.minv[:] = list(np.linalg.inv(p_eff).ravel())
+                roi = patches.rois[i][j] if hasattr(patches, "rois") else None
+                if roi is None:
+                    raise NotImplementedError("patches must expose .rois")
+                r0, r1 = roi[0].start, min(roi[0].stop, h)
+                c0, c1 = roi[1].start, min(roi[1].stop, w)
+                rec.sr0, rec.sc0, rec.sh, rec.sw = r0, c0, r1 - r0, c1 - c0
+                rec.ox, rec.oy, rec.w_eff, rec.h_eff = ox, oy, int(w_eff), int(h_eff)
+                rec.nx, rec.ny = int(nx), int(ny)
+                rec.bw0 = _opencv_block_width(int(w_eff), int(h_eff))
+                records.append(rec)
+        _lib.require_gpu()
+        src = np.ascontiguousarray(base, dtype=np.float32)
+        canvas = np.empty_like(src)
+        table = (_lib.WarpPatch * max(1, len(records)))(*records)
+        _lib.check(_lib.load().dxh_warp_patches(_lib.default_device(), h, w, chans, _lib.ptr(src),
+                                                 C.cast(table, C.c_void_p), len(records), _lib.ptr(canvas)))
+        out = canvas.astype(base.dtype)
+        result = copy.copy(patches.base)
+        result = patches.base.copy() if hasattr(patches.base, "copy") else result
+        result.img = out
+        return result
+
+
+def evaluate_rbf(rbf, points: np.ndarray) -> np.ndarray:
+    """Evaluate a fitted ``scipy.interpolate.RBFInterpolator`` (thin-plate spline, degree 1, 2-D) at
+    ``points`` (n, 2) on the GPU.  Returns what ``rbf(points)`` returns."""
+    y, coeffs, shift, scale, powers, dout, squeeze = _rbf_params(rbf)
+    pts = np.ascontiguousarray(points, dtype=np.float64)
+    if pts.ndim != 2 or pts.shape[1] != 2:
+        raise ValueError("points must have shape (n, 2)")
+    _lib.require_gpu()
+    out = np.empty((pts.shape[0], dout))
+    _lib.check(_lib.load().dxh_tps_eval(_lib.default_device(), y.shape[0], dout, _lib.ptr(y), _lib.ptr(coeffs),
+                                         _lib.ptr(shift), _lib.ptr(scale), _lib.ptr(powers), pts.shape[0],
+                                         _lib.ptr(pts), 0, 0.0, 0.0, 0.0, 0.0, _lib.ptr(out)))
+    return out[:, 0] if squeeze else out
+
+
+def evaluate_rbf_on_grid(rbf, shape, x0=0.0, y0=0.0, dx=1.0, dy=1.0) -> np.ndarray:
+    """``rbf`` at every pixel of an (H, W) grid, point (col, row) -> (x0 + dx*col, y0 + dy*row) -- the dense
+    field of ``DiffeomorphicImageRegistration.displacement`` without materialising the H*W point list."""
+    y, coeffs, shift, scale, powers, dout, squeeze = _rbf_params(rbf)
+    h, w = int(shape[0]), int(shape[1])
+    _lib.require_gpu()
+    out = np.empty((h * w, dout))
+    _lib.check(_lib.load().dxh_tps_eval(_lib.default_device(), y.shape[0], dout, _lib.ptr(y), _lib.ptr(coeffs),
+                                         _lib.ptr(shift), _lib.ptr(scale), _lib.ptr(powers), h * w, None, w,
+                                         float(x0), float(y0), float(dx), float(dy), _lib.ptr(out)))
+    out = out.reshape(h, w, dout)
+    return out[..., 0] if squeeze else out
+
+
+def _rbf_params(rbf):
+    if getattr(rbf, "kernel", None) != "thin_plate_spline":
+        raise NotImplementedError("only kernel='thin_plate_spline' (SciPy's and the reference's default)")
+    if getattr(rbf, "neighbors", None) is not None:
+        raise NotImplementedError("RBFInterpolator(neighbors=...) is not supported")
+    y = np.ascontiguousarray(rbf.y, dtype=np.float64)
+    if y.shape[1] != 2:
+        raise NotImplementedError("2-D interpolators only")
+    if float(rbf.epsilon) != 1.0:
+        raise NotImplementedError("epsilon must be 1")
+    coeffs = np.asarray(rbf._coeffs, dtype=np.float64)
+    powers = np.ascontiguousarray(rbf.powers, dtype=np.int32)
+    if powers.shape != (3, 2):
+        raise NotImplementedError("degree-1 polynomial tail expected")
+    squeeze = tuple(getattr(rbf, "d_shape", (coeffs.shape[1],))) == ()
+    dout = coeffs.shape[1]
+    if dout not in (1, 2):
+        raise NotImplementedError("1 or 2 output components")
+    return (y, np.ascontiguousarray(coeffs), np.ascontiguousarray(rbf._shift, dtype=np.float64),
+            np.ascontiguousarray(rbf._scale, dtype=np.float64), powers, dout, squeeze)

@@ -162,6 +162,44 @@ int dxh_diff(int device, int dtype, int64_t n0, int64_t n1, int64_t n2, int axis
 int dxh_chambolle(int device, int dtype, int ndim, int64_t n0, int64_t n1, int64_t n2, const void* img, void* out,
                   double weight, double eps, int max_num_iter, int* iters_done);
 
+/*
+ * Piecewise perspective warp: the per-patch  cv2.warpPerspective(patch.astype(float32), P, (w_eff, h_eff),
+ * INTER_LINEAR)  +  canvas[roi] += tmp[...]  loop of PiecewisePerspectiveTransform.find_and_warp
+ * (corrections/shape/piecewiseperspective.py:71-133) in one launch.  The caller prepares one record per
+ * patch (homography already inverted, in double); patches are applied in table order.
+ */
+typedef struct dxh_warp_patch {
+    double minv[9];       /* inverse of P: tile pixel (x, y, 1) -> source patch pixel, row-major */
+    int32_t sr0, sc0;     /* source patch origin (row, col) in the base image */
+    int32_t sh, sw;       /* source patch size */
+    int32_t ox, oy;       /* tile origin in the canvas (col, row) = origin_eff */
+    int32_t w_eff, h_eff; /* tile size passed to warpPerspective */
+    int32_t nx, ny;       /* tile part added: canvas[oy:oy+ny, ox:ox+nx] += tile[:ny, :nx] */
+    int32_t bw0;          /* OpenCV's internal block width for (w_eff, h_eff) */
+    int32_t pad;
+} dxh_warp_patch;
+
+int dxh_warp_patches(int device, int H, int W, int C, const float* base, const dxh_warp_patch* patches, int npatch,
+                     float* canvas);
+
+/*
+ * Thin-plate-spline evaluation of a fitted scipy.interpolate.RBFInterpolator (kernel 'thin_plate_spline',
+ * degree 1, epsilon 1) at n points -- TranslationAnalysis.translation / DiffeomorphicImageRegistration.
+ * displacement (translationanalysis.py:285-301, imageregistration.py:265-306).  centers (p, 2), coeffs
+ * (p + 3, dout), powers (3, 2).  points (n, 2) or, if NULL, the grid  (gx0 + gsx*(i % grid_w), gy0 + gsy*(i / grid_w)).
+ */
+int dxh_tps_eval(int device, int p, int dout, const double* centers, const double* coeffs, const double* shift,
+                 const double* scale, const int* powers, int64_t n, const double* points, int grid_w, double gx0,
+                 double gy0, double gsx, double gsy, double* out);
+
+/*
+ * out = img_as_float(img) @ A + b, optional clip to [0, 1], float32 -- AffineBalance.apply_balance and the
+ * tail of ColorCorrection.correct_array (corrections/color/colorbalance.py:186-196, colorcorrection.py:388-394).
+ * in_dtype: 0 float32, 1 float64, 2 uint8 (/255), 3 uint16 (/65535); img (npix, 3); A row-major (3, 3).
+ */
+int dxh_affine_color(int device, int in_dtype, int64_t npix, const void* img, const double* A, const double* b,
+                     int clip, float* out);
+
 #ifdef __cplusplus
 }
 #endif

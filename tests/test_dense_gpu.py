@@ -1,0 +1,86 @@
+"""GPU parity of the dense registration / colour kernels with their oracles (`pytest -m gpu`)."""
+import numpy as np
+import pytest
+from scipy.interpolate import RBFInterpolator
+
+import darsia_amd as da
+from oracle import warp_numpy as W
+
+pytestmark = pytest.mark.gpu
+
+
+def _smooth_displacement(h, w, ax=3.0, ay=2.0):
+    def disp(pts_xy):
+        x, y = pts_xy[:, 0], pts_xy[:, 1]
+        return np.array([ax * np.sin(np.pi * y / h) * np.sin(np.pi * x / w), ay * np.sin(np.pi * x / w) * np.sin(np.pi * y / h)])
+    return disp
+
+
+@pytest.mark.parametrize("shape,npatch,overlap,dtype", [
+    ((64, 96), [3, 4], 0.0, np.float32),
+    ((61, 97, 3), [4, 5], 0.0, np.float32),
+    ((80, 120), [4, 6], 0.1, np.float64),
+    ((50, 70, 3), [2, 3], 0.05, np.uint8),
+])
+@pytest.mark.parametrize("reverse", [False, True])
+def test_piecewise_perspective_warp_equals_oracle(shape, npatch, overlap, dtype, reverse):
+    rng = np.random.default_rng(5)
+    img = rng.random(shape)
+    img = (img * 255).astype(np.uint8) if dtype == np.uint8 else img.astype(dtype)
+    patches = da.Patches(img, npatch, rel_overlap=overlap)
+    disp = _smooth_displacement(shape[0], shape[1])
+    out = da.PiecewisePerspectiveTransform().find_and_warp(patches, disp, reverse=reverse)
+    ref = W.find_and_warp(img, patches.rois, patches.local_corners_voxels, patches.global_corners_voxels, disp, reverse)
+    assert out.img.dtype == img.dtype and out.img.shape == img.shape
+    assert np.array_equal(out.img, ref), f"max abs {np.abs(out.img.astype(float) - ref).max():.3e}"
+    assert np.array_equal(patches.base.img, img)  # input untouched
+
+
+def test_zero_displacement_is_identity_in_the_interior():
+    rng = np.random.default_rng(6)
+    img = rng.random((48, 64)).astype(np.float32)
+    patches = da.Patches(img, [3, 4])
+    out = da.PiecewisePerspectiveTransform().find_and_warp(patches, lambda p: np.zeros((2, len(p))))
+    ref = W.find_and_warp(img, patches.rois, patches.local_corners_voxels, patches.global_corners_voxels,
+                          lambda p: np.zeros((2, len(p))))
+    assert np.array_equal(out.img, ref)
+    # interior of every patch reproduces the image exactly; seam rows/columns are summed twice (quirk Q8)
+    assert np.array_equal(out.img[1:15, 1:15], img[1:15, 1:15])
+
+
+def test_thin_plate_spline_field_matches_scipy():
+    rng = np.random.default_rng(7)
+    c = rng.random((60, 2)) * np.array([800, 400])
+    rx = RBFInterpolator(c, rng.normal(size=60))
+    rxy = RBFInterpolator(c, rng.normal(size=(60, 2)))
+    pts = rng.random((5000, 2)) * np.array([800, 400])
+    np.testing.assert_allclose(da.evaluate_rbf(rx, pts), rx(pts), rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(da.evaluate_rbf(rxy, pts), rxy(pts), rtol=1e-10, atol=1e-10)
+    h, w = 37, 53
+    yy, xx = np.mgrid[0:h, 0:w]
+    grid_pts = np.c_[xx.ravel() * 2.0 + 1.0, yy.ravel() * 3.0 - 2.0]
+    dense = da.evaluate_rbf_on_grid(rxy, (h, w), x0=1.0, y0=-2.0, dx=2.0, dy=3.0)
+    np.testing.assert_allclose(dense.reshape(-1, 2), rxy(grid_pts), rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32, np.float64])
+def test_affine_colour_balance(dtype):
+    rng = np.random.default_rng(8)
+    a = np.eye(3) + 0.05 * rng.normal(size=(3, 3))
+    b = 0.01 * rng.normal(size=3)
+    raw = rng.random((33, 47, 3))
+    if dtype == np.uint8:
+        img, f = (raw * 255).astype(np.uint8), lambda v: v / 255.0
+    elif dtype == np.uint16:
+        img, f = (raw * 65535).astype(np.uint16), lambda v: v / 65535.0
+    else:
+        img, f = raw.astype(dtype), lambda v: v
+    ref = (f(img.astype(np.float64)) @ a + b)
+    out = da.apply_affine_balance(img, a, b)
+    assert out.dtype == np.float32
+    np.testing.assert_allclose(out, ref.astype(np.float32), rtol=2e-7, atol=1e-7)
+    np.testing.assert_allclose(da.apply_affine_balance(img, a, b, clip=True), np.clip(ref, 0, 1).astype(np.float32),
+                               rtol=2e-7, atol=1e-7)
+    bal = da.AffineBalance()
+    bal.balance_scaling, bal.balance_translation = a, b
+    assert np.array_equal(bal.apply_balance(img), out)
