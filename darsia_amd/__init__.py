@@ -7,7 +7,10 @@ behaviour.  All arithmetic runs in ``libdarsia_hip.so`` (hand-written HIP for
 gfx950); there is no CPU fallback.
 """
 from ._lib import HipError, device_count  # noqa: F401
-from .image import Image  # noqa: F401
+from .image import Image, OpticalImage, ScalarImage  # noqa: F401
+from .geometry import (Coordinate, CoordinateArray, CoordinateSystem, Voxel, VoxelArray, full_like,  # noqa: F401
+                       interpret_indexing, make_coordinate, make_voxel, ones_like, roi_to_mask,
+                       to_cartesian_indexing, to_matrix_indexing, zeros_like)
 from .utils.array_slice import array_slice, array_slice_argument  # noqa: F401
 from .utils.dtype import convert_dtype  # noqa: F401
 from .utils.derivatives import backward_diff, forward_diff, laplace  # noqa: F401

@@ -93,7 +93,9 @@ def test_solver_update_params_semantics():
 
 
 def test_image_container_copy_is_deep():
-    im = da.Image(np.arange(6.0).reshape(2, 3), name="x")
+    im = da.Image(np.arange(6.0).reshape(2, 3), name="x", tag="frame 7")
     cp = im.copy()
     cp.img[0, 0] = 99
-    assert im.img[0, 0] == 0 and cp.metadata() == {"name": "x"}
+    assert im.img[0, 0] == 0 and cp.metadata()["name"] == "x" and cp.metadata()["tag"] == "frame 7"
+    again = da.Image(cp.img, **cp.metadata())
+    assert again.dimensions == im.dimensions and np.array_equal(again.origin, im.origin)

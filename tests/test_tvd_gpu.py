@@ -197,7 +197,7 @@ def test_tvd_operator_on_array_and_image(golden):
     np.testing.assert_allclose(out, golden["g13_tvd_call/out"], rtol=RTOL, atol=ATOL)
     im = da.Image(img.copy(), tag="frame")
     res = op(im)
-    assert isinstance(res, da.Image) and res is not im and res.metadata() == {"tag": "frame"}
+    assert isinstance(res, da.Image) and res is not im and res.metadata()["tag"] == "frame"
     assert_bits(res.img, out)
     assert_bits(im.img, img)  # input untouched
     assert_bits(da.tvd(img, method="heterogeneous bregman", weight=0.1, max_num_iter=6, eps=None), out)
