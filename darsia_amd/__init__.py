@@ -24,5 +24,7 @@ from .restoration.tvd import TVD, tvd  # noqa: F401
 from .color import AffineBalance, BaseBalance, apply_affine_balance  # noqa: F401
 from .registration import (Patches, PiecewisePerspectiveTransform, evaluate_rbf, evaluate_rbf_on_grid,  # noqa: F401
                            get_perspective_transform)
+from .imageregistration import (DiffeomorphicImageRegistration, ImageRegistration,  # noqa: F401
+                                PhaseCorrelationEstimator, TranslationAnalysis)
 
 __version__ = "0.1.0"

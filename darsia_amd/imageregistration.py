@@ -1,0 +1,305 @@
+"""Image registration façade on top of the GPU warp and thin-plate-spline kernels
+(reference: multi_image_analysis/translationanalysis.py:20-833,
+multi_image_analysis/imageregistration.py:17-306, 490-659).
+
+What runs where:
+
+* per-patch translation estimation -- HOST, injectable.  The reference uses ORB features + RANSAC
+  homographies from OpenCV (corrections/shape/translation.py:36-107), which is sparse, OpenCV-internal
+  work and out of scope.  Any object with the reference estimator's
+  ``find_effective_translation(img_src, img_dst, roi_src, roi_dst, mask_src=, mask_dst=, plot_matches=)``
+  method can be plugged in (``darsia.TranslationEstimator`` included).  The default here is a small
+  phase-correlation estimator so that the pipeline runs without OpenCV; it is NOT the reference's
+  estimator and produces different translations.
+* thin-plate-spline fit on ~N_patches + boundary points -- HOST, SciPy, as in the reference.
+* dense evaluation of the displacement field and the piecewise perspective warp -- GPU
+  (``darsia_amd.registration``).
+
+Only the single-level registration is mirrored; the multilevel driver
+(imageregistration.py:309-484) composes single levels with ``add``/``deduct`` and can be built on top.
+"""
+from __future__ import annotations
+
+import logging
+from typing import Optional, Union
+
+import numpy as np
+from scipy.interpolate import RBFInterpolator
+
+from .image import Image
+from .registration import Patches, PiecewisePerspectiveTransform, evaluate_rbf
+
+logger = logging.getLogger(__name__)
+
+_GPU_EVAL_THRESHOLD = 4096  # below this many points SciPy on the host is faster than a launch
+
+
+class PhaseCorrelationEstimator:
+    """Whole-patch translation by FFT phase correlation with a parabolic sub-pixel fit (host, NumPy).
+    Stand-in for ``darsia.TranslationEstimator`` (ORB + RANSAC), same call signature."""
+
+    def __init__(self, max_shift_fraction: float = 0.25) -> None:
+        self.max_shift_fraction = max_shift_fraction
+
+    def find_effective_translation(self, img_src, img_dst, roi_src=None, roi_dst=None, mask_src=None, mask_dst=None,
+                                   plot_matches: bool = False):
+        a = np.asarray(img_src, dtype=np.float64)
+        b = np.asarray(img_dst, dtype=np.float64)
+        if a.ndim == 3:
+            a, b = a.mean(axis=2), b.mean(axis=2)
+        if a.shape != b.shape or min(a.shape) < 8:
+            return None, False
+        if mask_src is not None and mask_dst is not None and not (np.any(mask_src) and np.any(mask_dst)):
+            return None, False
+        wy, wx = np.hanning(a.shape[0])[:, None], np.hanning(a.shape[1])[None, :]
+        fa = np.fft.rfft2((a - a.mean()) * wy * wx)
+        fb = np.fft.rfft2((b - b.mean()) * wy * wx)
+        cross = fb * np.conj(fa)
+        cross /= np.maximum(np.abs(cross), 1e-12)
+        corr = np.fft.irfft2(cross, s=a.shape)
+        py, px = np.unravel_index(np.argmax(corr), corr.shape)
+
+        def refine(c_m, c_0, c_p):
+            den = c_m - 2 * c_0 + c_p
+            return 0.0 if den == 0 else 0.5 * (c_m - c_p) / den
+
+        h, w = corr.shape
+        dy = py + refine(corr[(py - 1) % h, px], corr[py, px], corr[(py + 1) % h, px])
+        dx = px + refine(corr[py, (px - 1) % w], corr[py, px], corr[py, (px + 1) % w])
+        if dy > h / 2:
+            dy -= h
+        if dx > w / 2:
+            dx -= w
+        if abs(dy) > self.max_shift_fraction * h or abs(dx) > self.max_shift_fraction * w:
+            return None, False
+        return np.array([[1.0, 0.0, dx], [0.0, 1.0, dy]]), True
+
+
+class TranslationAnalysis:
+    """Patch-wise translation between a test image and a baseline image, interpolated to a continuous
+    displacement map and applied as a piecewise perspective warp (translationanalysis.py:20-833)."""
+
+    def __init__(self, base, N_patches, rel_overlap: float, translation_estimator, mask=None) -> None:
+        self.N_patches = list(N_patches)
+        self.rel_overlap = rel_overlap
+        self.update_base(base)
+        self.translation_estimator = translation_estimator
+        self.translation = lambda arg: np.zeros((2, np.atleast_2d(arg).shape[0]))
+        self.have_translation = np.zeros(tuple(self.N_patches), dtype=bool)
+        self.mask_base = (Image(np.ones(base.img.shape[:2], dtype=bool), dimensions=base.dimensions)
+                          if mask is None else mask.copy())
+        self.interpolator_translation_x = None
+        self.interpolator_translation_y = None
+
+    # ---- set-up ----------------------------------------------------------------------------------
+    def update_params(self, N_patches=None, rel_overlap=None) -> None:
+        changed = False
+        if N_patches is not None and list(N_patches) != self.N_patches:
+            self.N_patches, changed = list(N_patches), True
+        if rel_overlap is not None and rel_overlap != self.rel_overlap:
+            self.rel_overlap, changed = rel_overlap, True
+        if changed:
+            self.update_base_patches()
+
+    def update_base(self, base) -> None:
+        self.base = base
+        self.update_base_patches()
+
+    def update_base_patches(self) -> None:
+        self.patches_base = Patches(self.base, self.N_patches, rel_overlap=self.rel_overlap)
+
+    def load_image(self, img, mask=None) -> None:
+        self.img = img
+        self.mask_img = (Image(np.ones(img.img.shape[:2], dtype=bool), dimensions=img.dimensions)
+                         if mask is None else mask.copy())
+
+    # ---- boundary conditions (translationanalysis.py:310-404, pixel units) ----------------------------
+    def bc_x(self, units=("pixel", "pixel")):
+        assert units[0] == "pixel", "metric units are not mirrored"
+        ys = np.linspace(0, self.base.num_voxels[0], self.N_patches[0] + 1)
+        pts = [np.array([0, y]) for y in ys] + [np.array([self.base.num_voxels[1], y]) for y in ys]
+        return pts, len(pts) * [0.0]
+
+    def bc_y(self, units=("pixel", "pixel")):
+        assert units[0] == "pixel", "metric units are not mirrored"
+        # NOTE: the reference places the bottom boundary at y = num_voxels[1] (the image WIDTH),
+        # translationanalysis.py:394-398; kept.
+        pts = [np.array([x, self.base.num_voxels[1]]) for x in np.linspace(0, self.base.num_voxels[1], self.N_patches[1] + 1)]
+        return pts, len(pts) * [0.0]
+
+    def _patch_centers_pixel(self):
+        """Patch centres as (x, y) pixels: metric centre -> voxel (floor) -> flipped, as the reference does."""
+        cs = self.base.coordinatesystem
+        centers = np.empty((self.N_patches[0], self.N_patches[1], 2))
+        for i in range(self.N_patches[0]):
+            for j in range(self.N_patches[1]):
+                voxel_center = np.mean(self.patches_base.global_corners_voxels[i, j], axis=0)
+                centers[i, j] = np.flip(cs.voxel(cs.coordinate(voxel_center)))
+        return centers
+
+    def _set_interpolators(self, coords, tx, ty) -> None:
+        ex, etx = self.bc_x()
+        ey, ety = self.bc_y()
+        self.interpolator_translation_x = RBFInterpolator(coords + ex, tx + etx)
+        self.interpolator_translation_y = RBFInterpolator(coords + ey, ty + ety)
+
+        def translation_callable(arg):
+            arg = np.atleast_2d(np.asarray(arg, dtype=np.float64))
+            if arg.shape[0] >= _GPU_EVAL_THRESHOLD:
+                return np.array([evaluate_rbf(self.interpolator_translation_x, arg),
+                                 evaluate_rbf(self.interpolator_translation_y, arg)])
+            return np.array([self.interpolator_translation_x(arg), self.interpolator_translation_y(arg)])
+
+        self.translation = translation_callable
+
+    # ---- analysis -----------------------------------------------------------------------------------
+    def find_translation(self, units=("pixel", "pixel")):
+        """translationanalysis.py:149-308 (pixel units)."""
+        assert list(units) == ["pixel", "pixel"], "metric units are not mirrored"
+        patches_img = Patches(self.img, self.N_patches, rel_overlap=self.rel_overlap)
+        patches_mask_base = Patches(self.mask_base, self.N_patches, rel_overlap=self.rel_overlap)
+        patches_mask_img = Patches(self.mask_img, self.N_patches, rel_overlap=self.rel_overlap)
+        have = np.zeros(tuple(self.N_patches), dtype=bool)
+        centers = self._patch_centers_pixel()
+        coords, tx, ty = [], [], []
+        for i in range(self.N_patches[0]):
+            for j in range(self.N_patches[1]):
+                translation, intact = self.translation_estimator.find_effective_translation(
+                    patches_img(i, j).img, self.patches_base(i, j).img, None, None,
+                    mask_src=patches_mask_img(i, j).img, mask_dst=patches_mask_base(i, j).img, plot_matches=False)
+                if intact:
+                    have[i, j] = True
+                    disp = np.asarray(translation)[:, -1]
+                    coords.append(centers[i, j])
+                    tx.append(float(disp[0]))
+                    ty.append(float(disp[1]))
+        self._set_interpolators(coords, tx, ty)
+        self.have_translation = have.copy()
+        return self.translation, bool(have.any())
+
+    def translate_image(self, reverse: bool = True):
+        """translationanalysis.py:616-646: piecewise perspective warp of the loaded image (GPU)."""
+        patches = Patches(self.img, self.N_patches, rel_overlap=0.0)
+        return PiecewisePerspectiveTransform().find_and_warp(patches, self.translation, reverse)
+
+    def __call__(self, img, reverse: bool = False, mask=None):
+        self.load_image(img, mask)
+        self.find_translation()
+        return self.translate_image(reverse)
+
+    def return_patch_translation(self, reverse: bool = True) -> np.ndarray:
+        """Displacement (x, y) in pixels at the patch centres, shape (*N_patches, 2)."""
+        centers = self._patch_centers_pixel().reshape(-1, 2)
+        t = self.translation(centers)
+        out = np.stack([t[0], t[1]], axis=-1).reshape(self.N_patches[0], self.N_patches[1], 2)
+        return -out if reverse else out
+
+    # ---- composition (translationanalysis.py:676-833) ----------------------------------------------
+    def deduct_translation_analysis(self, other) -> None:
+        centers = self._patch_centers_pixel().reshape(-1, 2)
+        d = other.translation(centers)
+        self._set_interpolators([c for c in centers], [float(v) for v in d[0]], [float(v) for v in d[1]])
+
+    def add_translation_analysis(self, other) -> None:
+        centers = self._patch_centers_pixel().reshape(-1, 2)
+        d0 = self.translation(centers)
+        displaced = centers + np.stack([d0[0], d0[1]], axis=-1)
+        d1 = other.translation(displaced)
+        total = d0 + d1
+        self._set_interpolators([c for c in centers], [float(v) for v in total[0]], [float(v) for v in total[1]])
+
+
+class DiffeomorphicImageRegistration:
+    """Single-level registration (imageregistration.py:17-306)."""
+
+    def __init__(self, img_dst, **kwargs) -> None:
+        self.translation_estimator = kwargs.get("translation_estimator") or PhaseCorrelationEstimator()
+        self.N_patches = kwargs.get("N_patches", [1, 1])
+        self.rel_overlap = kwargs.get("rel_overlap", 0.0)
+        self.dst = img_dst
+        self.translation_analysis = TranslationAnalysis(
+            img_dst, N_patches=self.N_patches, rel_overlap=self.rel_overlap,
+            translation_estimator=self.translation_estimator, mask=kwargs.get("mask_dst", None))
+
+    def update_dst(self, img_dst) -> None:
+        self.dst = img_dst
+        self.translation_analysis.update_base(img_dst)
+
+    def deduct(self, other: "DiffeomorphicImageRegistration") -> None:
+        self.translation_analysis.deduct_translation_analysis(other.translation_analysis)
+
+    def add(self, other: "DiffeomorphicImageRegistration") -> None:
+        self.translation_analysis.add_translation_analysis(other.translation_analysis)
+
+    def __call__(self, img, mask=None, return_transformed_dst: bool = False):
+        transformed = self.translation_analysis(img, mask=mask)
+        if return_transformed_dst:
+            return transformed, self.apply(self.dst, reverse=True)
+        return transformed
+
+    def evaluate(self, coords: Union[np.ndarray, Patches], reverse: bool = False, units: str = "metric") -> np.ndarray:
+        """Deformation vectors at arbitrary points (imageregistration.py:166-217)."""
+        base = self.translation_analysis.base
+        if isinstance(coords, Patches):
+            cs = base.coordinatesystem
+            coords = np.array([[cs.coordinate(np.mean(coords.global_corners_voxels[i, j], axis=0))
+                                for j in range(coords.num_patches[1])] for i in range(coords.num_patches[0])])
+        assert coords.shape[-1] == 2
+        shape = coords.shape
+        coords = coords.reshape(-1, 2)
+        if units == "metric":
+            pixel_coords = np.fliplr(np.asarray(base.coordinatesystem.voxel(coords)))
+        elif units == "pixel":
+            pixel_coords = coords
+        else:
+            raise ValueError
+        translation = self.translation_analysis.translation(pixel_coords)
+        if reverse:
+            translation = -1.0 * translation
+        displacement = np.transpose(np.vstack((translation[1], translation[0])))
+        if units == "metric":
+            displacement = base.coordinatesystem.coordinate_vector(displacement)
+        return displacement.reshape(shape)
+
+    def apply(self, img, reverse: bool = False):
+        self.translation_analysis.load_image(img)
+        return self.translation_analysis.translate_image(reverse)
+
+    def displacement(self) -> np.ndarray:
+        """Displacement in metric units on all pixels, shape (H*W, 2) (imageregistration.py:265-306).
+        The two thin-plate splines are evaluated on the GPU over the pixel grid."""
+        from .registration import evaluate_rbf_on_grid
+
+        ta = self.translation_analysis
+        if ta.interpolator_translation_x is None:
+            raise RuntimeError("no translation has been determined yet")
+        ny, nx = ta.base.img.shape[:2]
+        tx = evaluate_rbf_on_grid(ta.interpolator_translation_x, (ny, nx)).reshape(-1)
+        ty = evaluate_rbf_on_grid(ta.interpolator_translation_y, (ny, nx)).reshape(-1)
+        displacement = np.transpose(np.vstack((ty, tx)))  # (row, col) order, as in the reference
+        return ta.base.coordinatesystem.coordinate_vector(displacement)
+
+
+class ImageRegistration:
+    """Façade (imageregistration.py:490-659), single level."""
+
+    def __init__(self, img_dst, method: Optional[str] = None, **kwargs) -> None:
+        assert method in (None, "multilevel", "onelevel")
+        n_patches = kwargs.get("N_patches", [1, 1])
+        nested = isinstance(n_patches, list) and all(isinstance(n, list) for n in n_patches)
+        if method == "multilevel" or (method is None and nested):
+            raise NotImplementedError("multilevel registration is not mirrored; compose single levels with add()/deduct()")
+        self.method = "onelevel"
+        self.registration = DiffeomorphicImageRegistration(img_dst, **kwargs)
+
+    def __call__(self, img, mask=None, return_transformed_dst: bool = False):
+        return self.registration(img, mask=mask, return_transformed_dst=return_transformed_dst)
+
+    def apply(self, img, reverse: bool = False):
+        return self.registration.apply(img, reverse)
+
+    def evaluate(self, coords, reverse: bool = False, units: str = "metric"):
+        return self.registration.evaluate(coords, reverse, units)
+
+    def displacement(self):
+        return self.registration.displacement()

@@ -84,3 +84,41 @@ def test_affine_colour_balance(dtype):
     bal = da.AffineBalance()
     bal.balance_scaling, bal.balance_translation = a, b
     assert np.array_equal(bal.apply_balance(img), out)
+
+
+def _textured(h, w, seed):
+    rng = np.random.default_rng(seed)
+    coarse = rng.random((h // 8 + 2, w // 8 + 2))
+    from scipy.ndimage import zoom, gaussian_filter
+    img = zoom(coarse, 8, order=3)[:h, :w]
+    return gaussian_filter(img + 0.3 * rng.random((h, w)), 1.0).astype(np.float32)
+
+
+def test_registration_end_to_end_recovers_a_known_warp():
+    """Functional test of the façade (estimator on the host, TPS + warp on the GPU): a frame displaced by a
+    smooth known field is pulled back onto the reference frame."""
+    from scipy.ndimage import map_coordinates
+
+    h, w = 192, 256
+    dst = _textured(h, w, 11)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    dx = 2.5 * np.sin(np.pi * yy / h) * np.sin(np.pi * xx / w)
+    dy = -1.5 * np.sin(np.pi * yy / h) * np.sin(np.pi * xx / w)
+    src = map_coordinates(dst, [yy + dy, xx + dx], order=1, mode="nearest").astype(np.float32)
+    reg = da.ImageRegistration(da.Image(dst), N_patches=[4, 4])
+    out = reg(da.Image(src))
+    inner = (slice(24, h - 24), slice(24, w - 24))
+    before = np.abs(src - dst)[inner].mean()
+    after = np.abs(out.img - dst)[inner].mean()
+    assert after < 0.6 * before, (before, after)
+    # evaluate() and displacement() describe the same field
+    pts = np.array([[64.0, 48.0], [128.0, 96.0], [200.0, 150.0]])
+    ev = reg.evaluate(pts, units="pixel")
+    dense = reg.displacement().reshape(h, w, 2)
+    vs = np.array(da.Image(dst).voxel_size)
+    for (x, y), d in zip(pts, ev):
+        # evaluate(pixel) gives (d_row, d_col); displacement() gives metric (x, y) = (d_col * vs_x, -d_row * vs_y)
+        np.testing.assert_allclose([d[1] * vs[1], -d[0] * vs[0]], dense[int(y), int(x)], rtol=1e-8, atol=1e-10)
+    # apply() warps any other image with the same map
+    again = reg.apply(da.Image(src))
+    assert np.array_equal(again.img, out.img)
