@@ -98,12 +98,13 @@ static int chambolle_t(int device, int ndim, int64_t n0, int64_t n1, int64_t n2,
     const unsigned nblocks = (unsigned)(bpr * n0);
     hipStream_t st = nullptr;
     void* bufs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // f, out, p0..p2
-    double *partial = nullptr, *red = nullptr;
+    double *partial = nullptr, *red = nullptr, *stage2 = nullptr;
     int rc = DXH_OK;
     auto cleanup = [&]() {
         for (void* b : bufs) if (b) (void)hipFree(b);
         if (partial) (void)hipFree(partial);
         if (red) (void)hipFree(red);
+        if (stage2) (void)hipFree(stage2);
         if (st) (void)hipStreamDestroy(st);
     };
     auto body = [&]() -> int {
@@ -114,6 +115,7 @@ static int chambolle_t(int device, int ndim, int64_t n0, int64_t n1, int64_t n2,
         }
         DXH_HIP(hipMalloc((void**)&partial, sizeof(double) * nblocks));
         DXH_HIP(hipMalloc((void**)&red, sizeof(double)));
+        DXH_HIP(hipMalloc((void**)&stage2, sizeof(double) * 256));
         DXH_HIP(hipMemcpy2DAsync(bufs[0], g.pitch * sizeof(T), img, g.L * sizeof(T), g.L * sizeof(T), n0,
                                  hipMemcpyHostToDevice, st));
         DXH_HIP(hipMemcpyAsync(bufs[1], bufs[0], plane, hipMemcpyDeviceToDevice, st));  // out = image (iteration 0)
@@ -127,7 +129,9 @@ static int chambolle_t(int device, int ndim, int64_t n0, int64_t n1, int64_t n2,
         a.tau_over_w = (T)(tau / weight);
         a.partial = partial;
         auto reduce = [&](double* host) -> int {
-            hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, partial, (int)nblocks, red);
+            // two-level deterministic tree: 256 slices, then one block
+            hipLaunchKernelGGL(k_sum_partials, dim3(256), dim3(256), 0, st, partial, (int)nblocks, stage2);
+            hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, stage2, 256, red);
             DXH_HIP(hipGetLastError());
             DXH_HIP(hipMemcpyAsync(host, red, sizeof(double), hipMemcpyDeviceToHost, st));
             DXH_HIP(hipStreamSynchronize(st));

@@ -16,7 +16,7 @@
 #include "dxh_common.h"
 
 #ifndef DXH_LB4
-#define DXH_LB4 2  // minimum waves per SIMD requested for the K = 4 pipeline (register cap 256 / 168)
+#define DXH_LB4 2  // minimum waves per SIMD requested for the K >= 3 pipelines (register cap 256; 3 would spill)
 #endif
 
 namespace dxh {
@@ -314,16 +314,20 @@ __global__ void __launch_bounds__(256) k_sqdiff_partial(Geom g, const T* __restr
 }
 
 static __global__ void __launch_bounds__(256) k_sum_partials(const double* __restrict__ partial, int n, double* __restrict__ out) {
+    // block b sums the slice [b*chunk, (b+1)*chunk) of `partial` into out[b]; a fixed tree, so the result does
+    // not depend on timing.  Long lists are reduced in two launches (many blocks, then one).
     __shared__ double sm[256];
+    const int chunk = (n + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * chunk, hi = min(n, lo + chunk);
     double acc = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+    for (int i = lo + threadIdx.x; i < hi; i += 256) acc += partial[i];
     sm[threadIdx.x] = acc;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *out = sm[0];
+    if (threadIdx.x == 0) out[blockIdx.x] = sm[0];
 }
 
 // ============================================================================================
@@ -361,6 +365,11 @@ struct FusedArgs {
     int remap;         // XCD-aware block -> tile mapping (block_to_tile)
     Coef<T> c;
     CoefPlanes<T> cp;
+    // optional (k_fused_multi): per-wave partial sums of (u_{n+s+1} - u_{n+s})^2 for each fused iteration s,
+    // layout [K][nwaves_total]; nullptr = off.  Lets the eps test of split_bregman_tvd.py:161-175 run on
+    // K-iteration launches without any extra pass over the data.
+    double* inc_partial;
+    int nwaves_total;
 };
 
 // ALIGN: the lanes that store cover whole 128-byte lines (strip stride rounded down to a multiple of
@@ -689,11 +698,13 @@ struct Pipe {
     T ell, diag, dsc, kq, rdiag, rdsc;
     bool store_lane;
     bool edgeL[N], edgeR[N], ch0[N], chLast[N];
+    bool want_inc;      // accumulate squared increments (wave-uniform)
+    bool inL[N];        // element inside the row (x < L)
 
     __device__ __forceinline__ int64_t clampr(int64_t r) const { return r < 0 ? 0 : (r > nrow - 1 ? nrow - 1 : r); }
 
     template <int PH>
-    __device__ __forceinline__ void step(PipeState<T, K>& st, const int64_t r) const {
+    __device__ __forceinline__ void step(PipeState<T, K>& st, float (&inc)[K][N], const int64_t r) const {
         // prefetch next step's level-0 rows straight into their ring slots
         T frn[N];
         {
@@ -791,6 +802,13 @@ struct Pipe {
 #pragma unroll
                 for (int j = 0; j < N; ++j) un[j] = unm[j];
             }
+            if (want_inc && p >= R0 && p < R1) {  // wave-uniform; rows of this chunk only (each element once)
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const float dlt = (float)(un[j] - uc[j]);
+                    inc[s][j] += (store_lane && inL[j]) ? dlt * dlt : 0.f;
+                }
+            }
             T unr[N], q1o[N], q0o[N];
             shifted<+C, DPP>(un, unr);
 #pragma unroll
@@ -853,7 +871,9 @@ __device__ __forceinline__ void fused_pipe_body(const FusedArgs<T>& a, const int
         const int cc = (int)(((x % C) + C) % C);
         pp.ch0[j] = cc == 0;
         pp.chLast[j] = cc == C - 1;
+        pp.inL[j] = x >= 0 && x < a.L;
     }
+    pp.want_inc = a.inc_partial != nullptr;
     pp.of_p = a.of + xl;
     pp.u_in = a.u_in + xl;
     pp.q0_in = a.q0_in + xl;
@@ -913,16 +933,33 @@ __device__ __forceinline__ void fused_pipe_body(const FusedArgs<T>& a, const int
     // the last stage must reach row R1: steps rs .. R1 + K - 1, rounded up to whole groups of 4
     // (extra steps touch clamped rows only and store nothing)
     const int64_t r_end = pp.R1 + (K - 1);
+    float inc[K][N];
+#pragma unroll
+    for (int s = 0; s < K; ++s)
+#pragma unroll
+        for (int j = 0; j < N; ++j) inc[s][j] = 0.f;
     for (int64_t r = rs; r <= r_end; r += 4) {
-        pp.template step<0>(st, r);
-        pp.template step<1>(st, r + 1);
-        pp.template step<2>(st, r + 2);
-        pp.template step<3>(st, r + 3);
+        pp.template step<0>(st, inc, r);
+        pp.template step<1>(st, inc, r + 1);
+        pp.template step<2>(st, inc, r + 2);
+        pp.template step<3>(st, inc, r + 3);
+    }
+    if (pp.want_inc) {
+        const int wave_id = chunk * a.nstrips + strip;  // < nchunks * nstrips <= nwaves_total
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            double v = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) v += (double)inc[s][j];
+#pragma unroll
+            for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+            if (lane == 0) a.inc_partial[(size_t)s * a.nwaves_total + wave_id] = v;
+        }
     }
 }
 
 template <typename T, int C, bool COUPLED, bool ISO, int K, bool NTS = true>
-__global__ void __launch_bounds__(256, (K >= 4 ? DXH_LB4 : 3)) k_fused_multi(FusedArgs<T> a) {
+__global__ void __launch_bounds__(256, (K >= 3 ? DXH_LB4 : 3)) k_fused_multi(FusedArgs<T> a) {
     constexpr int N = VecOf<T>::N;
     using SG = StripGeomK<T, C, K>;
     const int lane = threadIdx.x & (kWave - 1);

@@ -51,7 +51,10 @@ struct Ctx {
     void* om_plane = nullptr;      // omega as a plane (array-valued omega only)
     void* stage = nullptr;         // dense staging buffer (dim * plane) for (*shape, dim) transfers
     double* partial = nullptr;
-    double* red_out = nullptr;     // 2 doubles
+    double* red_out = nullptr;     // 8 doubles
+    double* inc_partial = nullptr; // per-wave squared increments of the fused iterations
+    size_t inc_bytes = 0;
+    int inc_nwaves = 0;
     int npartial = 1024;
 
     int cur = 0;                   // index of the current u / q buffers
@@ -161,6 +164,8 @@ static void launch_fused_v(Ctx* c, int in, int out) {
     a.rows_per_chunk = rpc;
     a.nchunks = (int)nchunks;
     a.remap = remap ? 1 : 0;
+    a.inc_partial = nullptr;
+    a.nwaves_total = 0;
     a.c = make_coef<T>(c);
     a.cp = make_planes<T>(c);
     hipLaunchKernelGGL((k_fused<T, C, COUPLED, ISO, HET, DPP, ALIGN, NTS>), dim3((unsigned)(nbx * nchunks)), dim3(256), 0,
@@ -184,7 +189,7 @@ static void launch_fused_t(Ctx* c, int in, int out) {
 
 // K iterations per launch (scalar coefficients only)
 template <typename T, int C, bool COUPLED, bool ISO, int K>
-static void launch_fused_multi_t(Ctx* c, int in, int out) {
+static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
     using SG = StripGeomK<T, C, K>;
     FusedArgs<T> a;
     a.of = (const T*)c->of;
@@ -207,6 +212,20 @@ static void launch_fused_multi_t(Ctx* c, int in, int out) {
     a.rows_per_chunk = rpc;
     a.nchunks = (int)nchunks;
     a.remap = 1;
+    a.inc_partial = nullptr;
+    a.nwaves_total = (int)(nchunks * a.nstrips);
+    if (want_inc) {
+        // [K][nwaves] doubles; (re)allocated on demand, zero-filled so that unused slots do not matter
+        const size_t need = sizeof(double) * (size_t)K * a.nwaves_total;
+        if (c->inc_bytes < need) {
+            if (c->inc_partial) (void)hipFree(c->inc_partial);
+            c->inc_partial = nullptr;
+            c->inc_bytes = 0;
+            if (hipMalloc((void**)&c->inc_partial, need) == hipSuccess) c->inc_bytes = need;
+        }
+        a.inc_partial = c->inc_partial;
+        c->inc_nwaves = a.nwaves_total;
+    }
     a.c = make_coef<T>(c);
     a.cp = make_planes<T>(c);
     hipLaunchKernelGGL((k_fused_multi<T, C, COUPLED, ISO, K>), dim3((unsigned)(nbx * nchunks)), dim3(256), 0, c->stream, a);
@@ -221,13 +240,13 @@ static bool multi_supported(const Ctx* c) {
 }
 
 template <typename T, int C>
-static void launch_fused_multi_c(Ctx* c, int in, int out, bool iso, int K) {
+static void launch_fused_multi_c(Ctx* c, int in, int out, bool iso, int K, bool want_inc) {
     const bool coupled = c->desc.ndim == 3 && c->desc.nsum == DXH_NSUM_ALL_AXES;
 #define DXH_M(CP_, ISO_)                                                              \
     switch (K) {                                                                      \
-        case 2: launch_fused_multi_t<T, C, CP_, ISO_, 2>(c, in, out); break;          \
-        case 3: launch_fused_multi_t<T, C, CP_, ISO_, 3>(c, in, out); break;          \
-        default: launch_fused_multi_t<T, C, CP_, ISO_, 4>(c, in, out); break;         \
+        case 2: launch_fused_multi_t<T, C, CP_, ISO_, 2>(c, in, out, want_inc); break;          \
+        case 3: launch_fused_multi_t<T, C, CP_, ISO_, 3>(c, in, out, want_inc); break;          \
+        default: launch_fused_multi_t<T, C, CP_, ISO_, 4>(c, in, out, want_inc); break;         \
     }
     if (coupled) { if (iso) { DXH_M(true, true) } else { DXH_M(true, false) } }
     else         { if (iso) { DXH_M(false, true) } else { DXH_M(false, false) } }
@@ -235,9 +254,9 @@ static void launch_fused_multi_c(Ctx* c, int in, int out, bool iso, int K) {
 }
 
 template <typename T>
-static void launch_fused_multi(Ctx* c, int in, int out, bool iso, int K) {
-    if (c->g.n2 == 1) launch_fused_multi_c<T, 1>(c, in, out, iso, K);
-    else launch_fused_multi_c<T, 3>(c, in, out, iso, K);
+static void launch_fused_multi(Ctx* c, int in, int out, bool iso, int K, bool want_inc = false) {
+    if (c->g.n2 == 1) launch_fused_multi_c<T, 1>(c, in, out, iso, K, want_inc);
+    else launch_fused_multi_c<T, 3>(c, in, out, iso, K, want_inc);
 }
 
 template <typename T, int C, bool COUPLED>
@@ -403,7 +422,49 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
     if (!async) DXH_HIP(hipEventRecord(c->ev0, c->stream));
     for (int it = 0; it < n_iter; ++it) {
         const int in = c->cur, out = c->cur ^ 1;
-        if (fused_ok && !c->from_db) {
+        if (fused_ok && !c->from_db && use_eps && dpp && multi_supported(c) && c->fuse_k >= 2 && n_iter - it >= 2) {
+            // eps with temporal blocking: one launch does K iterations and also reduces every iteration's
+            // squared increment; if the test fires at an inner iteration j, the K-iteration result is
+            // discarded (the input buffers still hold iteration `it`) and exactly j+1 iterations are redone
+            const int K = std::min(c->fuse_k, n_iter - it);
+            launch_fused_multi<T>(c, in, out, iso, K, true);
+            ++launches;
+            if (!c->inc_partial) { set_error("out of device memory for the increment partials"); if (tmp) (void)hipFree(tmp); return DXH_ENOMEM; }
+            hipLaunchKernelGGL(k_sum_partials, dim3(K), dim3(256), 0, c->stream, c->inc_partial, K * c->inc_nwaves,
+                               c->red_out + 2);
+            double incs[4] = {0, 0, 0, 0};
+            DXH_HIP(hipMemcpyAsync(incs, c->red_out + 2, sizeof(double) * K, hipMemcpyDeviceToHost, c->stream));
+            DXH_HIP(hipStreamSynchronize(c->stream));
+            int hit = -1;
+            for (int j = 0; j < K; ++j) {
+                rel = std::sqrt(incs[j]) / nrm_img;
+                if (rel < eps) { hit = j; break; }
+            }
+            if (hit < 0) {
+                c->cur = out;
+                it += K - 1;
+                done = it + 1;
+                continue;
+            }
+            converged = 1;
+            done = it + hit + 1;
+            if (hit == K - 1) {
+                c->cur = out;
+            } else {
+                // redo exactly hit+1 iterations from the untouched input state
+                int left = hit + 1, a_in = in, a_out = out;
+                while (left > 0) {
+                    const int k2 = left >= 2 ? std::min(left, c->fuse_k) : 1;
+                    if (k2 >= 2) launch_fused_multi<T>(c, a_in, a_out, iso, k2, false);
+                    else launch_fused<T>(c, a_in, a_out, iso, dpp);
+                    ++launches;
+                    left -= k2;
+                    std::swap(a_in, a_out);
+                }
+                c->cur = a_in;  // the buffer written last
+            }
+            break;
+        } else if (fused_ok && !c->from_db) {
             // temporal blocking: fuse_k iterations per launch while enough iterations remain and no
             // per-iteration host test is requested
             const int K = (!use_eps && dpp && multi_supported(c)) ? std::min(c->fuse_k, n_iter - it) : 1;
@@ -586,7 +647,7 @@ int dxh_tvd_create(dxh_tvd_t* out, const dxh_tvd_desc* d) {
             if ((rc = alloc_plane(c, &c->q[j][k]))) return fail(rc);
     }
     if (hipMalloc((void**)&c->partial, sizeof(double) * c->npartial) != hipSuccess ||
-        hipMalloc((void**)&c->red_out, sizeof(double) * 2) != hipSuccess) {
+        hipMalloc((void**)&c->red_out, sizeof(double) * 8) != hipSuccess) {
         set_error("hipMalloc failed");
         return fail(DXH_ENOMEM);
     }
@@ -602,7 +663,7 @@ int dxh_tvd_destroy(dxh_tvd_t h) {
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
     fr(c->of); fr(c->u[0]); fr(c->u[1]); fr(c->rs);
     for (int j = 0; j < 3; ++j) { fr(c->q[j][0]); fr(c->q[j][1]); fr(c->dpl[j]); fr(c->bpl[j]); }
-    fr(c->cp_ell); fr(c->cp_diag); fr(c->cp_dsc); fr(c->cp_kq); fr(c->om_plane); fr(c->stage); fr(c->partial); fr(c->red_out);
+    fr(c->cp_ell); fr(c->cp_diag); fr(c->cp_dsc); fr(c->cp_kq); fr(c->om_plane); fr(c->stage); fr(c->partial); fr(c->red_out); fr(c->inc_partial);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);

@@ -281,3 +281,21 @@ def test_default_tvd_is_chambolle(sk):
     out = da.TVD()(img)  # method "chambolle", weight 0.1, max_num_iter 200, eps 2e-4 (tvd.py:31-43)
     assert_bits(out, sk["crgb_f32/out"])
     assert_bits(da.tvd(img, weight=0.1), out)
+
+
+@pytest.mark.parametrize("fuse_k", [1, 2, 3, 4])
+@pytest.mark.parametrize("name,eps", [("g7_eps_f64", 1e-3), ("g7_eps_f32", 1e-3), ("g7_eps_rgb_f32", 2e-3)])
+def test_early_stop_with_temporal_blocking(golden, monkeypatch, name, eps, fuse_k):
+    """The eps test runs on K-iteration launches (increments of every fused iteration are reduced inside the
+    kernel); a hit at an inner iteration is redone with exactly that many iterations.  Same stop iteration
+    and same result as the per-iteration path / the reference."""
+    monkeypatch.setenv("DXH_FUSE_K", str(fuse_k))
+    img = golden[name + "/img"]
+    out, res = run_device(img, mu=0.1, n_iter=100, eps=eps)
+    assert res.converged == 1 and res.iters_done == int(golden[name + "/iters"])
+    ref = O.split_bregman_tvd(img, mu=0.1, max_num_iter=res.iters_done, promotion="strict")
+    assert_bits(out, ref)
+    # eps never met: all iterations run
+    out2, res2 = run_device(img, mu=0.1, n_iter=7, eps=1e-12)
+    assert res2.converged == 0 and res2.iters_done == 7
+    assert_bits(out2, O.split_bregman_tvd(img, mu=0.1, max_num_iter=7, promotion="strict"))

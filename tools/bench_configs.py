@@ -1,0 +1,47 @@
+"""Timings of the BASELINE.json configs other than the headline one (wall time of whole calls; run under
+rocprofv3 --kernel-trace --stats for kernel-only durations)."""
+import sys, time
+import numpy as np
+sys.path.insert(0, ".")
+import darsia_amd as da
+from darsia_amd.synthetic import synthetic_image
+from scipy.interpolate import RBFInterpolator
+
+def t(label, f, n=1):
+    f(); t0 = time.perf_counter()
+    for _ in range(n): r = f()
+    dt = (time.perf_counter() - t0) / n
+    print(f"{label:70s} {dt*1e3:10.2f} ms", flush=True)
+    return r
+
+H, W = 4000, 8000
+rgb = synthetic_image(H, W, 3)
+gray = synthetic_image(H, W, 1)
+print("config 2 whole call (upload + 100 it + download), f32 RGB")
+t("split_bregman_tvd(rgb, mu=.1, 100 it)  [PCIe-inclusive]", lambda: da.split_bregman_tvd(rgb, mu=0.1, max_num_iter=100))
+st = da.DeviceTVD(rgb.shape, rgb.dtype); st.set_coeffs(0.1, 1.0, None, rgb); st.upload(rgb)
+for iso in (False, True):
+    st.run(8, isotropic=iso); r = st.run(100, isotropic=iso)
+    print(f"  device loop {'isotropic' if iso else 'anisotropic'}: {r.loop_ms/100:.4f} ms/iter  {H*W/(r.loop_ms/100)/1e3:.0f} MPix/s")
+st.close()
+g64 = gray.astype(np.float64)
+st = da.DeviceTVD(g64.shape, g64.dtype); st.set_coeffs(0.1, 1.0, None, g64); st.upload(g64); st.run(8); r = st.run(100)
+print(f"  device loop float64 gray: {r.loop_ms/100:.4f} ms/iter  {H*W/(r.loop_ms/100)/1e3:.0f} MPix/s"); st.close()
+st = da.DeviceTVD(gray.shape, gray.dtype); st.set_coeffs(0.1, 1.0, None, gray); st.upload(gray); st.run(8); r = st.run(100)
+print(f"  device loop float32 gray: {r.loop_ms/100:.4f} ms/iter  {H*W/(r.loop_ms/100)/1e3:.0f} MPix/s"); st.close()
+print("config 3: colour apply + isotropic TVD")
+A = np.eye(3) + 0.05 * np.random.default_rng(7).normal(size=(3, 3)); b = 0.01 * np.random.default_rng(7).normal(size=3)
+t("apply_affine_balance(rgb f32)  [PCIe-inclusive]", lambda: da.apply_affine_balance(rgb, A, b, clip=True))
+t("split_bregman_tvd(rgb, isotropic, 100 it) [PCIe-inclusive]", lambda: da.split_bregman_tvd(rgb, mu=0.1, max_num_iter=100, isotropic=True))
+print("default TVD(): chambolle on RGB-as-volume, eps 2e-4")
+out, iters = da.denoise_tv_chambolle(rgb, weight=0.1, return_iters=True)
+t0 = time.perf_counter(); out, iters = da.denoise_tv_chambolle(rgb, weight=0.1, return_iters=True); dt = time.perf_counter() - t0
+print(f"  chambolle: {iters} iterations, {dt*1e3:.1f} ms total, {dt/max(iters,1)*1e3:.2f} ms/iteration [PCIe-inclusive]")
+print("config 4: registration dense parts on two 4000 x 8000 gray frames, N_patches = [10, 20]")
+img = da.Image(gray)
+patches = da.Patches(img, [10, 20])
+disp = lambda p: np.array([6 * np.sin(np.pi * p[:, 0] / W), 4 * np.sin(np.pi * p[:, 1] / H)])
+t("PiecewisePerspectiveTransform.find_and_warp  [PCIe-inclusive]", lambda: da.PiecewisePerspectiveTransform().find_and_warp(patches, disp))
+rng = np.random.default_rng(3)
+c = rng.random((262, 2)) * np.array([W, H]); rbf = RBFInterpolator(c, rng.normal(size=262))
+t("evaluate_rbf_on_grid (262 centres, 32 M pixels)  [incl. 256 MB download]", lambda: da.evaluate_rbf_on_grid(rbf, (H, W)))

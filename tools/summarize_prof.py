@@ -11,7 +11,8 @@ import csv, glob, json, os, shutil, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
-stats = glob.glob(f"{src}/trace/*/*_kernel_stats.csv")
+newest = lambda pat: sorted(glob.glob(pat), key=os.path.getmtime)[-1:]  # noqa: E731
+stats = newest(f"{src}/trace/*/*_kernel_stats.csv")
 if stats:
     shutil.copy(stats[0], f"profiles/{tag}_kernel_stats.csv")
     rows = list(csv.DictReader(open(stats[0])))
@@ -30,8 +31,8 @@ def per_kernel(path, counter):
     return {k: (sum(v) / len(v), len(v)) for k, v in out.items()}
 
 
-f = glob.glob(f"{src}/pmc_fetch/*/*_counter_collection.csv")
-w = glob.glob(f"{src}/pmc_write/*/*_counter_collection.csv")
+f = newest(f"{src}/pmc_fetch/*/*_counter_collection.csv")
+w = newest(f"{src}/pmc_write/*/*_counter_collection.csv")
 if f and w:
     fe, wr = per_kernel(f[0], "FETCH_SIZE"), per_kernel(w[0], "WRITE_SIZE")
     with open(f"profiles/{tag}_pmc_summary.csv", "w") as o:
