@@ -51,7 +51,7 @@ def parse():
     p.add_argument("--height", type=int, default=4000)
     p.add_argument("--width", type=int, default=8000)
     p.add_argument("--channels", type=int, default=3)
-    p.add_argument("--halo-iters", type=int, default=4, help="iterations between halo exchanges (N > 1)")
+    p.add_argument("--halo-iters", type=int, default=8, help="iterations between halo exchanges (N > 1)")
     p.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", default="4000x8000", help="HxW of the CPU baseline sample")

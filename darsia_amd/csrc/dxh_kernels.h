@@ -15,6 +15,9 @@
 
 #include "dxh_common.h"
 
+#ifndef DXH_STRIP_ALIGN_BYTES
+#define DXH_STRIP_ALIGN_BYTES 128  // k_fused_multi: a wave's store range covers whole granules of this size
+#endif
 #ifndef DXH_LB4
 #define DXH_LB4 2  // minimum waves per SIMD requested for the K >= 3 pipelines (register cap 256; 3 would spill)
 #endif
@@ -639,7 +642,7 @@ __global__ void __launch_bounds__(256) k_fused(FusedArgs<T> a) {
 template <typename T, int C, int K, bool ALIGN = true>
 struct StripGeomK {
     static constexpr int N = VecOf<T>::N;
-    static constexpr int LINE = 128 / (int)sizeof(T);
+    static constexpr int LINE = DXH_STRIP_ALIGN_BYTES / (int)sizeof(T);  // store-range granule in elements
     static constexpr int LH = (K * C + N - 1) / N;
     static constexpr int RH = (2 * K * C + N - 1) / N;
     static constexpr int TIGHT = (kWave - LH - RH) * N;
