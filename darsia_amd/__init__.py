@@ -25,6 +25,7 @@ from .color import AffineBalance, BaseBalance, apply_affine_balance  # noqa: F40
 from .registration import (Patches, PiecewisePerspectiveTransform, evaluate_rbf, evaluate_rbf_on_grid,  # noqa: F401
                            get_perspective_transform)
 from .imageregistration import (DiffeomorphicImageRegistration, ImageRegistration,  # noqa: F401
-                                PhaseCorrelationEstimator, TranslationAnalysis)
+                                MultiscaleDiffeomorphicImageRegistration, PhaseCorrelationEstimator,
+                                TranslationAnalysis)
 
 __version__ = "0.1.0"

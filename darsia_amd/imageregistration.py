@@ -280,17 +280,83 @@ class DiffeomorphicImageRegistration:
         return ta.base.coordinatesystem.coordinate_vector(displacement)
 
 
+class MultiscaleDiffeomorphicImageRegistration:
+    """Multilevel registration for larger deformations (imageregistration.py:309-484): every level
+    registers the CURRENTLY warped image against the destination on its own patch grid; the levels are
+    composed into one translation map (level 0: deduct, later levels: add) and the ORIGINAL image is
+    re-warped with the combined map."""
+
+    def __init__(self, img_dst, config, mask_dst=None, total_config=None, **kwargs) -> None:
+        assert isinstance(config, list) and all(isinstance(c, dict) for c in config)
+        self.img_dst = img_dst
+        self.dst = img_dst
+        self.mask_dst = mask_dst
+        self.config = config
+        self.num_levels = len(config)
+        self.total_config = config[-1] if total_config is None else total_config
+        self.verbosity = kwargs.get("verbosity", 0)
+
+    def _single_level_iteration(self, img, mask, config):
+        registration = DiffeomorphicImageRegistration(self.img_dst, mask_dst=self.mask_dst, **config)
+        transformed = registration(img, mask=mask)
+        return transformed, registration
+
+    def __call__(self, img, mask=None, return_transformed_dst: bool = False):
+        transformed_img = img.copy()
+        transformed_mask = mask.copy() if mask is not None else None
+        self.combined_image_registration = DiffeomorphicImageRegistration(transformed_img, **self.total_config)
+        for level in range(self.num_levels):
+            _, registration = self._single_level_iteration(transformed_img, transformed_mask, self.config[level])
+            if level == 0:
+                self.combined_image_registration.deduct(registration)
+            else:
+                self.combined_image_registration.add(registration)
+            if transformed_mask is not None:
+                warped = registration.apply(Image(transformed_mask.img.astype(np.float32), **transformed_mask.metadata()))
+                transformed_mask = Image(warped.img > 0.5, **transformed_mask.metadata())
+            transformed_img = self.combined_image_registration.apply(img)
+        if return_transformed_dst:
+            return transformed_img, self.combined_image_registration.apply(self.dst, reverse=True)
+        return transformed_img
+
+    def apply(self, img, reverse: bool = False):
+        if not hasattr(self, "combined_image_registration"):
+            raise ValueError("Construct the deformation first.")
+        return self.combined_image_registration.apply(img, reverse)
+
+    def evaluate(self, coords, reverse: bool = False, units: str = "metric"):
+        return self.combined_image_registration.evaluate(coords, reverse, units)
+
+    def displacement(self):
+        return self.combined_image_registration.displacement()
+
+
 class ImageRegistration:
-    """Façade (imageregistration.py:490-659), single level."""
+    """Façade (imageregistration.py:490-659): one level for a flat ``N_patches``, multilevel for a list of
+    patch grids (per-level ``rel_overlap`` / estimator options may be lists of the same length)."""
 
     def __init__(self, img_dst, method: Optional[str] = None, **kwargs) -> None:
         assert method in (None, "multilevel", "onelevel")
         n_patches = kwargs.get("N_patches", [1, 1])
         nested = isinstance(n_patches, list) and all(isinstance(n, list) for n in n_patches)
-        if method == "multilevel" or (method is None and nested):
-            raise NotImplementedError("multilevel registration is not mirrored; compose single levels with add()/deduct()")
-        self.method = "onelevel"
-        self.registration = DiffeomorphicImageRegistration(img_dst, **kwargs)
+        if method is None:
+            method = "multilevel" if nested else "onelevel"
+        self.method = method
+        if method == "multilevel":
+            if not nested:
+                n_patches = [n_patches]
+            levels = len(n_patches)
+            rel_overlap = kwargs.get("rel_overlap", 0.0)
+            if not isinstance(rel_overlap, list):
+                rel_overlap = levels * [rel_overlap]
+            if len(rel_overlap) != levels:
+                raise ValueError("rel_overlap must be a scalar or have one entry per level")
+            config = [{"N_patches": n_patches[i], "rel_overlap": rel_overlap[i],
+                       "translation_estimator": kwargs.get("translation_estimator")} for i in range(levels)]
+            self.registration = MultiscaleDiffeomorphicImageRegistration(
+                img_dst, config, mask_dst=kwargs.get("mask_dst", None), verbosity=kwargs.get("verbosity", 0))
+        else:
+            self.registration = DiffeomorphicImageRegistration(img_dst, **kwargs)
 
     def __call__(self, img, mask=None, return_transformed_dst: bool = False):
         return self.registration(img, mask=mask, return_transformed_dst=return_transformed_dst)

@@ -122,3 +122,22 @@ def test_registration_end_to_end_recovers_a_known_warp():
     # apply() warps any other image with the same map
     again = reg.apply(da.Image(src))
     assert np.array_equal(again.img, out.img)
+
+
+def test_multilevel_registration_handles_a_larger_warp():
+    from scipy.ndimage import map_coordinates
+
+    h, w = 256, 320
+    dst = _textured(h, w, 13)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    dx = 7.0 * np.sin(np.pi * yy / h) * np.sin(np.pi * xx / w)
+    dy = -5.0 * np.sin(np.pi * yy / h) * np.sin(np.pi * xx / w)
+    src = map_coordinates(dst, [yy + dy, xx + dx], order=1, mode="nearest").astype(np.float32)
+    reg = da.ImageRegistration(da.Image(dst), N_patches=[[2, 2], [4, 5]])
+    assert reg.method == "multilevel"
+    out = reg(da.Image(src))
+    inner = (slice(32, h - 32), slice(32, w - 32))
+    before = np.abs(src - dst)[inner].mean()
+    after = np.abs(out.img - dst)[inner].mean()
+    assert after < 0.6 * before, (before, after)
+    assert np.array_equal(reg.apply(da.Image(src)).img, out.img)
