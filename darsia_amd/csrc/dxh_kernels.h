@@ -681,12 +681,21 @@ struct PipeState {
     T U[K + 1][4][N];
     T t0[K][2][N];
     T b0[K][2][N];
-    T q1[K][2][N];
-    T q0l[2][N];
-    T of[4][N];
+    T q1l[2][N];   // loaded level-0 q1 rows (prefetch target / current)
+    T q0l[2][N];   // loaded level-0 q0 rows
+    T of0[N];      // omega*f of stage 0's row
 };
 
-template <typename T, int C, bool COUPLED, bool ISO, int K, bool NTS, bool EDGE>
+// LDS rings of one wave (register relief, not communication: every lane reads back only what it wrote
+// itself, so no barrier is involved).  Layout per wave: [slot][lane] vectors of 16 bytes.
+//   slots 0..3            omega*f rows r .. r-3 (slot = (row - rs) & 3), written by stage 0, read by stages 1..K-1
+//   slots 4 + 2(s-1) + p  Q1 of level s handed from stage s-1 (written with parity p = next step's) to stage s
+template <int K>
+struct PipeLds {
+    static constexpr int SLOTS = 4 + 2 * (K - 1);
+};
+
+template <typename T, int C, bool COUPLED, bool ISO, int K, bool NTS, bool EDGE, bool NORM>
 struct Pipe {
     static constexpr int N = VecOf<T>::N;
     static constexpr bool DPP = true;
@@ -701,13 +710,16 @@ struct Pipe {
     T ell, diag, dsc, kq, rdiag, rdsc;
     bool store_lane;
     bool edgeL[N], edgeR[N], ch0[N], chLast[N];
-    bool want_inc;      // accumulate squared increments (wave-uniform)
     bool inL[N];        // element inside the row (x < L)
+    T* lds;             // this lane's vector in slot 0 of the wave's LDS rings; slot stride = kWave * N elements
+
+    __device__ __forceinline__ void lds_put(int slot, const T (&v)[N]) const { store_vec(lds + slot * (kWave * N), v); }
+    __device__ __forceinline__ void lds_get(int slot, T (&v)[N]) const { load_vec(lds + slot * (kWave * N), v); }
 
     __device__ __forceinline__ int64_t clampr(int64_t r) const { return r < 0 ? 0 : (r > nrow - 1 ? nrow - 1 : r); }
 
     template <int PH>
-    __device__ __forceinline__ void step(PipeState<T, K>& st, float (&inc)[K][N], const int64_t r) const {
+    __device__ __forceinline__ void step(PipeState<T, K>& st, float (&inc)[NORM ? K : 1][N], const int64_t r) const {
         // prefetch next step's level-0 rows straight into their ring slots
         T frn[N];
         {
@@ -715,8 +727,9 @@ struct Pipe {
             load_vec(u_in + clampr(r + 2) * P, st.U[0][(PH + 2) & 3]);
             load_vec(of_p + rn * P, frn);
             load_vec(q0_in + rn * P, st.q0l[(PH + 1) & 1]);
-            load_vec(q1_in + rn * P, st.q1[0][(PH + 1) & 1]);
+            load_vec(q1_in + rn * P, st.q1l[(PH + 1) & 1]);
         }
+        if constexpr (K > 1) lds_put(PH & 3, st.of0);  // omega*f of row r for the later stages
         T q0h[N];  // Q0 of the next level at the next stage's row, handed from stage to stage
         static_for<0, K>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
@@ -731,8 +744,17 @@ struct Pipe {
             T(&t0c)[N] = st.t0[s][cur];
             T(&b0m)[N] = st.b0[s][prv];
             T(&b0c)[N] = st.b0[s][cur];
-            const T(&q1c)[N] = st.q1[s][cur];
-            const T(&ofv)[N] = st.of[c];
+            T q1c[N], ofv[N];
+            if constexpr (s == 0) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    q1c[j] = st.q1l[cur][j];
+                    ofv[j] = st.of0[j];
+                }
+            } else {
+                lds_get(4 + 2 * (s - 1) + cur, q1c);
+                lds_get(c, ofv);
+            }
             // destination of the new iterate (level s+1, row p) and that level's previous row
             constexpr bool last = (s == K - 1);
             T(&un)[N] = last ? st.U[K][cur] : st.U[s + 1][c];
@@ -805,11 +827,11 @@ struct Pipe {
 #pragma unroll
                 for (int j = 0; j < N; ++j) un[j] = unm[j];
             }
-            if (want_inc && p >= R0 && p < R1) {  // wave-uniform; rows of this chunk only (each element once)
+            if (NORM && p >= R0 && p < R1) {  // wave-uniform; rows of this chunk only (each element once)
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
                     const float dlt = (float)(un[j] - uc[j]);
-                    inc[s][j] += (store_lane && inL[j]) ? dlt * dlt : 0.f;
+                    inc[NORM ? s : 0][j] += (store_lane && inL[j]) ? dlt * dlt : 0.f;
                 }
             }
             T unr[N], q1o[N], q0o[N];
@@ -841,23 +863,23 @@ struct Pipe {
                     }
                 }
             } else {
+                lds_put(4 + 2 * s + prv, q1o);  // read by stage s+1 at the next step (its parity "cur")
 #pragma unroll
-                for (int j = 0; j < N; ++j) {
-                    st.q1[s + 1][prv][j] = q1o[j];  // read by stage s+1 at the next step (its parity "cur")
-                    q0h[j] = q0o[j];
-                }
+                for (int j = 0; j < N; ++j) q0h[j] = q0o[j];
             }
         });
 #pragma unroll
-        for (int j = 0; j < N; ++j) st.of[(PH + 1) & 3][j] = frn[j];
+        for (int j = 0; j < N; ++j) st.of0[j] = frn[j];
     }
 };
 
-template <typename T, int C, bool COUPLED, bool ISO, int K, bool NTS, bool EDGE>
-__device__ __forceinline__ void fused_pipe_body(const FusedArgs<T>& a, const int strip, const int chunk, const int lane) {
+template <typename T, int C, bool COUPLED, bool ISO, int K, bool NTS, bool EDGE, bool NORM>
+__device__ __forceinline__ void fused_pipe_body(const FusedArgs<T>& a, const int strip, const int chunk, const int lane,
+                                                T* lds_lane) {
     constexpr int N = VecOf<T>::N;
     using SG = StripGeomK<T, C, K>;
-    Pipe<T, C, COUPLED, ISO, K, NTS, EDGE> pp;
+    Pipe<T, C, COUPLED, ISO, K, NTS, EDGE, NORM> pp;
+    pp.lds = lds_lane;
     pp.R0 = (int64_t)chunk * a.rows_per_chunk;
     pp.R1 = (pp.R0 + a.rows_per_chunk < a.n0) ? pp.R0 + a.rows_per_chunk : a.n0;
     if (pp.R0 >= a.n0) return;
@@ -876,7 +898,6 @@ __device__ __forceinline__ void fused_pipe_body(const FusedArgs<T>& a, const int
         pp.chLast[j] = cc == C - 1;
         pp.inL[j] = x >= 0 && x < a.L;
     }
-    pp.want_inc = a.inc_partial != nullptr;
     pp.of_p = a.of + xl;
     pp.u_in = a.u_in + xl;
     pp.q0_in = a.q0_in + xl;
@@ -905,11 +926,16 @@ __device__ __forceinline__ void fused_pipe_body(const FusedArgs<T>& a, const int
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < N; ++j) st.t0[l][i][j] = st.b0[l][i][j] = st.q1[l][i][j] = T(0);
+            for (int j = 0; j < N; ++j) st.t0[l][i][j] = st.b0[l][i][j] = T(0);
+    {
+        // LDS rings start zeroed: the leading (discarded) rows must not see NaN bit patterns that would
+        // trip the division screen for the whole wave
+        T z[N];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < N; ++j) z[j] = T(0);
 #pragma unroll
-        for (int j = 0; j < N; ++j) st.of[i][j] = T(0);
+        for (int i = 0; i < PipeLds<K>::SLOTS; ++i) pp.lds_put(i, z);
+    }
 
     // prologue: phase 0 at row rs = R0 - (K-1): rows rs-1, rs, rs+1 of u in slots 3, 0, 1
     const int64_t rs = pp.R0 - (K - 1);
@@ -917,9 +943,9 @@ __device__ __forceinline__ void fused_pipe_body(const FusedArgs<T>& a, const int
     load_vec(pp.u_in + pp.clampr(rs - 1) * P, st.U[0][3]);
     load_vec(pp.u_in + pp.clampr(rs) * P, st.U[0][0]);
     load_vec(pp.u_in + pp.clampr(rs + 1) * P, st.U[0][1]);
-    load_vec(pp.of_p + pp.clampr(rs) * P, st.of[0]);
+    load_vec(pp.of_p + pp.clampr(rs) * P, st.of0);
     load_vec(pp.q0_in + pp.clampr(rs) * P, st.q0l[0]);
-    load_vec(pp.q1_in + pp.clampr(rs) * P, st.q1[0][0]);
+    load_vec(pp.q1_in + pp.clampr(rs) * P, st.q1l[0]);
     {
         const int64_t rm = pp.clampr(rs - 1);
         T q0v[N], q1v[N];
@@ -936,9 +962,9 @@ __device__ __forceinline__ void fused_pipe_body(const FusedArgs<T>& a, const int
     // the last stage must reach row R1: steps rs .. R1 + K - 1, rounded up to whole groups of 4
     // (extra steps touch clamped rows only and store nothing)
     const int64_t r_end = pp.R1 + (K - 1);
-    float inc[K][N];
+    float inc[NORM ? K : 1][N];
 #pragma unroll
-    for (int s = 0; s < K; ++s)
+    for (int s = 0; s < (NORM ? K : 1); ++s)
 #pragma unroll
         for (int j = 0; j < N; ++j) inc[s][j] = 0.f;
     for (int64_t r = rs; r <= r_end; r += 4) {
@@ -947,7 +973,7 @@ __device__ __forceinline__ void fused_pipe_body(const FusedArgs<T>& a, const int
         pp.template step<2>(st, inc, r + 2);
         pp.template step<3>(st, inc, r + 3);
     }
-    if (pp.want_inc) {
+    if constexpr (NORM) {
         const int wave_id = chunk * a.nstrips + strip;  // < nchunks * nstrips <= nwaves_total
 #pragma unroll
         for (int s = 0; s < K; ++s) {
@@ -961,7 +987,7 @@ __device__ __forceinline__ void fused_pipe_body(const FusedArgs<T>& a, const int
     }
 }
 
-template <typename T, int C, bool COUPLED, bool ISO, int K, bool NTS = true>
+template <typename T, int C, bool COUPLED, bool ISO, int K, bool NORM = false, bool NTS = true>
 __global__ void __launch_bounds__(256, (K >= 3 ? DXH_LB4 : 3)) k_fused_multi(FusedArgs<T> a) {
     constexpr int N = VecOf<T>::N;
     using SG = StripGeomK<T, C, K>;
@@ -975,10 +1001,12 @@ __global__ void __launch_bounds__(256, (K >= 3 ? DXH_LB4 : 3)) k_fused_multi(Fus
     if (strip >= a.nstrips || chunk >= a.nchunks) return;  // wave-uniform
     const int64_t w0 = (int64_t)strip * SG::STRIDE - SG::LH * N;  // first element of the wave's window
     const bool edge = (w0 < C) || (w0 + kWave * N > a.L - C);     // wave-uniform
+    __shared__ typename VecOf<T>::type lds_rings[WPB * PipeLds<K>::SLOTS * kWave];
+    T* lds_lane = reinterpret_cast<T*>(lds_rings + (size_t)wave * PipeLds<K>::SLOTS * kWave + lane);
     if (edge)
-        fused_pipe_body<T, C, COUPLED, ISO, K, NTS, true>(a, strip, chunk, lane);
+        fused_pipe_body<T, C, COUPLED, ISO, K, NTS, true, NORM>(a, strip, chunk, lane, lds_lane);
     else
-        fused_pipe_body<T, C, COUPLED, ISO, K, NTS, false>(a, strip, chunk, lane);
+        fused_pipe_body<T, C, COUPLED, ISO, K, NTS, false, NORM>(a, strip, chunk, lane, lds_lane);
 }
 
 }  // namespace dxh

@@ -228,7 +228,10 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
     }
     a.c = make_coef<T>(c);
     a.cp = make_planes<T>(c);
-    hipLaunchKernelGGL((k_fused_multi<T, C, COUPLED, ISO, K>), dim3((unsigned)(nbx * nchunks)), dim3(256), 0, c->stream, a);
+    if (want_inc)
+        hipLaunchKernelGGL((k_fused_multi<T, C, COUPLED, ISO, K, true>), dim3((unsigned)(nbx * nchunks)), dim3(256), 0, c->stream, a);
+    else
+        hipLaunchKernelGGL((k_fused_multi<T, C, COUPLED, ISO, K, false>), dim3((unsigned)(nbx * nchunks)), dim3(256), 0, c->stream, a);
 }
 
 // channel counts the multi-iteration kernel is instantiated for
