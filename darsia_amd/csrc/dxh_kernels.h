@@ -711,12 +711,20 @@ struct Pipe {
     bool store_lane;
     bool edgeL[N], edgeR[N], ch0[N], chLast[N];
     bool inL[N];        // element inside the row (x < L)
+    uint32_t voff;      // this lane's byte offset inside a row: addresses are (uniform row base in SGPRs) + voff
     T* lds;             // this lane's vector in slot 0 of the wave's LDS rings; slot stride = kWave * N elements
 
     __device__ __forceinline__ void lds_put(int slot, const T (&v)[N]) const { store_vec(lds + slot * (kWave * N), v); }
     __device__ __forceinline__ void lds_get(int slot, T (&v)[N]) const { load_vec(lds + slot * (kWave * N), v); }
 
     __device__ __forceinline__ int64_t clampr(int64_t r) const { return r < 0 ? 0 : (r > nrow - 1 ? nrow - 1 : r); }
+    // row pointer (wave-uniform) + 32-bit lane offset -> global_load/store with an SGPR base
+    __device__ __forceinline__ const T* at(const T* plane, int64_t row) const {
+        return reinterpret_cast<const T*>(reinterpret_cast<const char*>(plane + row * P) + voff);
+    }
+    __device__ __forceinline__ T* at(T* plane, int64_t row) const {
+        return reinterpret_cast<T*>(reinterpret_cast<char*>(plane + row * P) + voff);
+    }
 
     template <int PH>
     __device__ __forceinline__ void step(PipeState<T, K>& st, float (&inc)[NORM ? K : 1][N], const int64_t r) const {
@@ -724,10 +732,10 @@ struct Pipe {
         T frn[N];
         {
             const int64_t rn = clampr(r + 1);
-            load_vec(u_in + clampr(r + 2) * P, st.U[0][(PH + 2) & 3]);
-            load_vec(of_p + rn * P, frn);
-            load_vec(q0_in + rn * P, st.q0l[(PH + 1) & 1]);
-            load_vec(q1_in + rn * P, st.q1l[(PH + 1) & 1]);
+            load_vec(at(u_in, clampr(r + 2)), st.U[0][(PH + 2) & 3]);
+            load_vec(at(of_p, rn), frn);
+            load_vec(at(q0_in, rn), st.q0l[(PH + 1) & 1]);
+            load_vec(at(q1_in, rn), st.q1l[(PH + 1) & 1]);
         }
         if constexpr (K > 1) lds_put(PH & 3, st.of0);  // omega*f of row r for the later stages
         T q0h[N];  // Q0 of the next level at the next stage's row, handed from stage to stage
@@ -848,18 +856,18 @@ struct Pipe {
                 if (store_lane) {
                     if (p >= R0 && p < R1) {
                         if constexpr (NTS) {
-                            store_vec_nt(q1_out + p * P, q1o);
-                            store_vec_nt(u_out + p * P, un);
+                            store_vec_nt(at(q1_out, p), q1o);
+                            store_vec_nt(at(u_out, p), un);
                         } else {
-                            store_vec(q1_out + p * P, q1o);
-                            store_vec(u_out + p * P, un);
+                            store_vec(at(q1_out, p), q1o);
+                            store_vec(at(u_out, p), un);
                         }
                     }
                     if (p - 1 >= R0 && p - 1 < R1) {
                         if constexpr (NTS)
-                            store_vec_nt(q0_out + (p - 1) * P, q0o);
+                            store_vec_nt(at(q0_out, p - 1), q0o);
                         else
-                            store_vec(q0_out + (p - 1) * P, q0o);
+                            store_vec(at(q0_out, p - 1), q0o);
                     }
                 }
             } else {
@@ -898,13 +906,14 @@ __device__ __forceinline__ void fused_pipe_body(const FusedArgs<T>& a, const int
         pp.chLast[j] = cc == C - 1;
         pp.inL[j] = x >= 0 && x < a.L;
     }
-    pp.of_p = a.of + xl;
-    pp.u_in = a.u_in + xl;
-    pp.q0_in = a.q0_in + xl;
-    pp.q1_in = a.q1_in + xl;
-    pp.u_out = a.u_out + xl;
-    pp.q0_out = a.q0_out + xl;
-    pp.q1_out = a.q1_out + xl;
+    pp.of_p = a.of;
+    pp.u_in = a.u_in;
+    pp.q0_in = a.q0_in;
+    pp.q1_in = a.q1_in;
+    pp.u_out = a.u_out;
+    pp.q0_out = a.q0_out;
+    pp.q1_out = a.q1_out;
+    pp.voff = (uint32_t)(xl * (int64_t)sizeof(T));
     pp.P = a.pitch;
     pp.nrow = a.n0;
     pp.ell = a.c.ell;
@@ -940,17 +949,17 @@ __device__ __forceinline__ void fused_pipe_body(const FusedArgs<T>& a, const int
     // prologue: phase 0 at row rs = R0 - (K-1): rows rs-1, rs, rs+1 of u in slots 3, 0, 1
     const int64_t rs = pp.R0 - (K - 1);
     const int64_t P = pp.P;
-    load_vec(pp.u_in + pp.clampr(rs - 1) * P, st.U[0][3]);
-    load_vec(pp.u_in + pp.clampr(rs) * P, st.U[0][0]);
-    load_vec(pp.u_in + pp.clampr(rs + 1) * P, st.U[0][1]);
-    load_vec(pp.of_p + pp.clampr(rs) * P, st.of0);
-    load_vec(pp.q0_in + pp.clampr(rs) * P, st.q0l[0]);
-    load_vec(pp.q1_in + pp.clampr(rs) * P, st.q1l[0]);
+    load_vec(pp.at(pp.u_in, pp.clampr(rs - 1)), st.U[0][3]);
+    load_vec(pp.at(pp.u_in, pp.clampr(rs)), st.U[0][0]);
+    load_vec(pp.at(pp.u_in, pp.clampr(rs + 1)), st.U[0][1]);
+    load_vec(pp.at(pp.of_p, pp.clampr(rs)), st.of0);
+    load_vec(pp.at(pp.q0_in, pp.clampr(rs)), st.q0l[0]);
+    load_vec(pp.at(pp.q1_in, pp.clampr(rs)), st.q1l[0]);
     {
         const int64_t rm = pp.clampr(rs - 1);
         T q0v[N], q1v[N];
-        load_vec(pp.q0_in + rm * P, q0v);
-        load_vec(pp.q1_in + rm * P, q1v);
+        load_vec(pp.at(pp.q0_in, rm), q0v);
+        load_vec(pp.at(pp.q1_in, rm), q1v);
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             T qq[2] = {q0v[j], q1v[j]}, d[2], b[2];
