@@ -27,5 +27,7 @@ from .registration import (Patches, PiecewisePerspectiveTransform, evaluate_rbf,
 from .imageregistration import (DiffeomorphicImageRegistration, ImageRegistration,  # noqa: F401
                                 MultiscaleDiffeomorphicImageRegistration, PhaseCorrelationEstimator,
                                 TranslationAnalysis)
+from .concentration import (ClipModel, CombinedModel, ConcentrationAnalysis, LinearModel,  # noqa: F401
+                            MonochromaticReduction, ScalingModel)
 
 __version__ = "0.1.0"

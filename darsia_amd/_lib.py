@@ -26,6 +26,7 @@ EXPORTS = (
     "dxh_tvd_download", "dxh_tvd_halo_bytes", "dxh_tvd_pack_rows", "dxh_tvd_unpack_rows",
     "dxh_tvd_partial_norms", "dxh_tvd_sync", "dxh_jacobi_solve", "dxh_diff", "dxh_chambolle",
     "dxh_warp_patches", "dxh_tps_eval", "dxh_affine_color",
+    "dxh_tvd_set_base", "dxh_tvd_set_cleaning_filter", "dxh_tvd_upload_signal", "dxh_tvd_download_model",
 )
 
 
@@ -50,6 +51,11 @@ class WarpPatch(C.Structure):
         ("ox", C.c_int32), ("oy", C.c_int32), ("w_eff", C.c_int32), ("h_eff", C.c_int32),
         ("nx", C.c_int32), ("ny", C.c_int32), ("bw0", C.c_int32), ("pad", C.c_int32),
     ]
+
+
+class ModelOp(C.Structure):
+    """dxh_model_op (include/darsia_hip.h)."""
+    _fields_ = [("kind", C.c_int32), ("flags", C.c_int32), ("a", C.c_double), ("b", C.c_double)]
 
 
 class TvdResult(C.Structure):
@@ -87,6 +93,10 @@ def _declare(lib):
     lib.dxh_warp_patches.argtypes = [i, i, i, i, vp, vp, i, vp]
     lib.dxh_tps_eval.argtypes = [i, i, i, vp, vp, vp, vp, vp, i64, vp, i, dbl, dbl, dbl, dbl, vp]
     lib.dxh_affine_color.argtypes = [i, i, i64, vp, vp, vp, i, vp]
+    lib.dxh_tvd_set_base.argtypes = [vp, vp, i]
+    lib.dxh_tvd_set_cleaning_filter.argtypes = [vp, vp]
+    lib.dxh_tvd_upload_signal.argtypes = [vp, vp, i, i, i, vp, i]
+    lib.dxh_tvd_download_model.argtypes = [vp, vp, vp, i]
     for name in EXPORTS:
         if name != "dxh_last_error":
             getattr(lib, name).restype = i

@@ -1,0 +1,348 @@
+"""``ConcentrationAnalysis`` with its elementwise stages fused around the device-resident TV
+restoration (reference: multi_image_analysis/concentrationanalysis.py:20-421,
+signals/reduction/monochromatic.py:12-95, signals/models/linearmodel.py:14-149,
+clipmodel.py:10-106, combinedmodel.py:13-52).
+
+A frame goes to the GPU once (colour), ``diff -> reduce -> clean -> [model] -> restoration -> [model]``
+run there, and the concentration comes back once (scalar).  The fused path needs stages it can
+express on the device:
+
+* difference: the four ``diff option`` values;
+* reduction: ``MonochromaticReduction`` with colour "red", "green", "blue", "red+green", "gray",
+  "negative-key" (or no reduction for scalar frames);
+* cleaning: threshold filter;  balancing: none;
+* restoration: ``darsia_amd.TVD(method="heterogeneous bregman")`` or none;
+* model: ``ScalingModel``, ``LinearModel``, ``ClipModel`` or a ``CombinedModel`` of them.
+
+Anything else (callables, other reductions, Chambolle restoration ...) is applied stage by stage through
+the objects' own ``__call__`` exactly as the reference does -- the device operators still do their part,
+only the array makes more trips.
+
+The small model / reduction classes are cheap per-pixel maps (out of scope as
+stand-alone kernels); their ``__call__`` is plain NumPy like the reference's.
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+from typing import Optional
+from warnings import warn
+
+import numpy as np
+
+from . import _lib
+from .image import Image, ScalarImage
+from .restoration.split_bregman_tvd import DeviceTVD
+from .restoration.tvd import TVD
+from .utils.linear_solvers.jacobi import Jacobi
+
+
+# ---- per-pixel maps (host semantics = reference) ---------------------------------------------------------
+class MonochromaticReduction:
+    """signals/reduction/monochromatic.py:12-95 (without the hsv branch, which needs skimage.color)."""
+
+    _CODES = {"red": 1, "green": 2, "blue": 3, "red+green": 4, "gray": 5, "negative-key": 6}
+
+    def __init__(self, **kwargs) -> None:
+        self.color = kwargs.get("color", "gray")
+        self.verbosity = kwargs.get("verbosity", 0)
+
+    def __call__(self, img: np.ndarray) -> np.ndarray:
+        c = self.color
+        if c == "gray":  # cv2.cvtColor(img.astype(float32), COLOR_RGB2GRAY)
+            f = img.astype(np.float32)
+            return f[:, :, 0] * np.float32(0.299) + f[:, :, 1] * np.float32(0.587) + f[:, :, 2] * np.float32(0.114)
+        if c == "red":
+            return img[:, :, 0]
+        if c == "green":
+            return img[:, :, 1]
+        if c == "blue":
+            return img[:, :, 2]
+        if c == "red+green":
+            return img[:, :, 0] + img[:, :, 1]
+        if c == "negative-key":
+            return 1 - np.min(1 - img, axis=2)
+        if callable(c):
+            return c(img)
+        if c == "":
+            return img
+        raise ValueError(f"Mono-colored space {c} not supported.")
+
+
+class ScalingModel:
+    def __init__(self, key: str = "", **kwargs) -> None:
+        self._scaling = kwargs.get(key + "scaling", 1.0)
+        self.num_parameters = 1
+
+    def update(self, scaling: Optional[float] = None) -> None:
+        if scaling is not None:
+            self._scaling = scaling
+
+    def __call__(self, img: np.ndarray) -> np.ndarray:
+        return img if np.isclose(self._scaling, 1.0) else self._scaling * img
+
+
+class LinearModel:
+    def __init__(self, key: str = "", **kwargs) -> None:
+        self._scaling = kwargs.get(key + "scaling", 1.0)
+        self._offset = kwargs.get(key + "offset", 0.0)
+        self.num_parameters = 2
+
+    def update(self, scaling: Optional[float] = None, offset: Optional[float] = None) -> None:
+        if scaling is not None:
+            self._scaling = scaling
+        if offset is not None:
+            self._offset = offset
+
+    def __call__(self, img: np.ndarray) -> np.ndarray:
+        return self._scaling * img + self._offset
+
+
+class ClipModel:
+    def __init__(self, min_value=None, max_value=None, key=None, **kwargs) -> None:
+        if key is None:
+            self._min_value, self._max_value = min_value, max_value
+        else:
+            self._min_value = kwargs.get(key + "_min_value", None)
+            self._max_value = kwargs.get(key + "_max_value", None)
+        if self._min_value is None and self._max_value is None:
+            raise ValueError("at least one of min_value or max_value must be provided")
+        self.num_parameters = 2
+
+    def update(self, min_value=None, max_value=None) -> None:
+        if min_value is not None:
+            self._min_value = min_value
+        if max_value is not None:
+            self._max_value = max_value
+
+    def __call__(self, img):
+        if isinstance(img, np.ndarray):
+            return np.clip(img, self._min_value, self._max_value)
+        if hasattr(img, "img") and hasattr(img, "copy"):
+            result = img.copy()
+            result.img = np.clip(result.img, self._min_value, self._max_value)
+            return result
+        raise ValueError("invalid input type")
+
+
+class CombinedModel:
+    """Chain of models; a model whose ``__call__`` takes more than (self, img) receives the extra
+    positional arguments (combinedmodel.py:29-52)."""
+
+    def __init__(self, models: list) -> None:
+        self.models = models
+        self.num_parameters = sum(getattr(m, "num_parameters", 0) for m in models)
+
+    def __call__(self, img: np.ndarray, *args) -> np.ndarray:
+        result = img.copy()
+        for model in self.models:
+            nargs = model.__call__.__code__.co_argcount
+            result = model(result) if nargs == 2 else model(result, *args[: nargs - 2])
+        return result
+
+    def __getitem__(self, pos: int):
+        return self.models[pos]
+
+
+def _model_ops(model):
+    """Model -> list of device ops, or None if it cannot be expressed."""
+    if model is None:
+        return []
+    if isinstance(model, CombinedModel):
+        ops = []
+        for m in model.models:
+            sub = _model_ops(m)
+            if sub is None:
+                return None
+            ops += sub
+        return ops if len(ops) <= 8 else None
+    if isinstance(model, LinearModel):
+        return [(0, 0, float(model._scaling), float(model._offset))]
+    if isinstance(model, ScalingModel):
+        return [] if np.isclose(model._scaling, 1.0) else [(1, 0, float(model._scaling), 0.0)]
+    if isinstance(model, ClipModel):
+        lo, hi = model._min_value, model._max_value
+        return [(2, (1 if lo is not None else 0) | (2 if hi is not None else 0), float(lo or 0.0), float(hi or 0.0))]
+    return None
+
+
+def _ops_array(ops):
+    arr = (_lib.ModelOp * max(1, len(ops)))()
+    for i, (kind, flags, a, b) in enumerate(ops):
+        arr[i].kind, arr[i].flags, arr[i].a, arr[i].b = kind, flags, a, b
+    return arr
+
+
+_DIFF = {"plain": 0, "positive": 1, "negative": 2, "absolute": 3}
+
+
+class ConcentrationAnalysis:
+    """Concentration/saturation profiles from image comparison (concentrationanalysis.py:20-421)."""
+
+    def __init__(self, base=None, signal_reduction=None, balancing=None, restoration=None, model=None, labels=None,
+                 **kwargs) -> None:
+        self.base = None
+        self._base_collection = []
+        if base is not None:
+            if not isinstance(base, list):
+                base = [base]
+            if any(img.img.dtype not in (np.float32, np.float64) for img in base):
+                raise TypeError("baseline images must be float32/float64 (convert before, e.g. img / 255.)")
+            self.base = base[0].copy()
+            self._base_collection = base
+            if getattr(self.base, "space_dim", 2) != 2:
+                raise NotImplementedError
+        self.signal_reduction = signal_reduction
+        self.balancing = balancing
+        self.model = model
+        self.restoration = restoration
+        self.labels = labels
+        self._diff_option = kwargs.get("diff option", "absolute")
+        self.first_restoration_then_model = kwargs.get("restoration -> model", False)
+        self.verbosity = kwargs.get("verbosity", 0)
+        self._ctx = None
+        self._ctx_key = None
+        self.find_cleaning_filter()
+        self.mask = None if self.base is None else np.ones(self.base.img.shape[:2], dtype=bool)
+
+    # ---- stages on host arrays (used for the cleaning filter and the non-fusable path) -------------------
+    def _subtract_background(self, img) -> np.ndarray:
+        opt = self._diff_option
+        if opt not in _DIFF:
+            raise ValueError(f"Diff option {opt} not supported")
+        a = img.img
+        if self.base is None:
+            return {"positive": lambda: np.clip(a, 0, None), "negative": lambda: np.clip(-a, 0, None),
+                    "absolute": lambda: np.absolute(a), "plain": lambda: a}[opt]()
+        b = self.base.img
+        return {"positive": lambda: np.clip(a - b, 0, None), "negative": lambda: np.clip(b - a, 0, None),
+                "absolute": lambda: np.abs(a - b), "plain": lambda: a - b}[opt]()
+
+    def _reduce_signal(self, img: np.ndarray) -> np.ndarray:
+        return img if self.signal_reduction is None else self.signal_reduction(img)
+
+    def _clean_signal(self, img: np.ndarray) -> np.ndarray:
+        return img if self.threshold_cleaning_filter is None else np.clip(img - self.threshold_cleaning_filter, 0, None)
+
+    def _balance_signal(self, img: np.ndarray) -> np.ndarray:
+        return img if self.balancing is None else self.balancing(img)
+
+    def _restore_signal(self, signal: np.ndarray) -> np.ndarray:
+        return signal if self.restoration is None else self.restoration(signal)
+
+    def _convert_signal(self, signal: np.ndarray, diff: np.ndarray) -> np.ndarray:
+        return signal if self.model is None else self.model(signal)
+
+    def find_cleaning_filter(self, baseline_images=None) -> None:
+        """Structural noise threshold from a series of baseline images (concentrationanalysis.py:167-200)."""
+        if baseline_images is None and self.base is not None:
+            baseline_images = self._base_collection[1:] or None
+        self.threshold_cleaning_filter = None
+        if baseline_images is not None:
+            self.threshold_cleaning_filter = np.zeros(self.base.img.shape[:2], dtype=float)
+            for img in baseline_images:
+                mono = self._reduce_signal(self._subtract_background(img.copy()))
+                self.threshold_cleaning_filter = np.maximum(self.threshold_cleaning_filter, mono)
+        self._ctx_key = None  # device copies are stale
+
+    def update(self, base=None, mask=None) -> None:
+        if base is not None:
+            self.base = base.copy()
+            self._ctx_key = None
+        if mask is not None:
+            self.mask = mask
+
+    # ---- fused device path ----------------------------------------------------------------------------------
+    def _fusable(self, probe: np.ndarray):
+        if self.balancing is not None or self._diff_option not in _DIFF:
+            return None
+        if probe.ndim == 3 and probe.shape[2] == 3:
+            red = self.signal_reduction
+            if not isinstance(red, MonochromaticReduction) or red.color not in MonochromaticReduction._CODES:
+                return None
+            reduction, channels = MonochromaticReduction._CODES[red.color], 3
+        elif probe.ndim == 2 and self.signal_reduction is None:
+            reduction, channels = 0, 1
+        else:
+            return None
+        rest = self.restoration
+        if rest is not None:
+            if not (isinstance(rest, TVD) and rest.method == "heterogeneous bregman"):
+                return None
+            kw = dict(rest.kwargs)
+            solver = kw.pop("solver", None)
+            bad = (kw.pop("dim", 2) != 2 or kw.pop("x0", None) is not None or kw.pop("adaptive", None) is not None
+                   or kw.pop("verbose", False) or (solver is not None and not isinstance(solver, Jacobi)))
+            if bad:
+                return None
+            iso = bool(kw.pop("isotropic", False))
+            if kw:
+                return None
+            for coef in (rest.weight, rest.omega, rest.regularization):
+                if isinstance(coef, np.ndarray) and coef.ndim > 0 and coef.shape != probe.shape[:2]:
+                    return None
+        else:
+            solver, iso = None, False
+        ops = _model_ops(self.model)
+        if ops is None:
+            return None
+        return reduction, channels, ops, solver, iso
+
+    def _device_call(self, probe: np.ndarray, plan) -> np.ndarray:
+        reduction, channels, ops, solver, iso = plan
+        # dtype as NumPy would promote: a (float64) cleaning filter promotes the signal; gray is float32 in cv2
+        dt = probe.dtype if self.threshold_cleaning_filter is None else np.result_type(probe.dtype, np.float64)
+        if reduction == 5 and self.threshold_cleaning_filter is None:
+            dt = np.dtype(np.float32)
+        h, w = probe.shape[:2]
+        key = (h, w, np.dtype(dt).str)
+        if self._ctx is None or self._ctx_key != key:
+            if self._ctx is not None:
+                self._ctx.close()
+            self._ctx = DeviceTVD((h, w), dt, dim=2)
+            lib, hd = self._ctx.lib, self._ctx._h
+            base = None if self.base is None else np.ascontiguousarray(self.base.img, dtype=dt)
+            _lib.check(lib.dxh_tvd_set_base(hd, _lib.ptr(base), channels))
+            filt = None if self.threshold_cleaning_filter is None else np.ascontiguousarray(self.threshold_cleaning_filter, dtype=dt)
+            _lib.check(lib.dxh_tvd_set_cleaning_filter(hd, _lib.ptr(filt)))
+            self._ctx_key = key
+        st = self._ctx
+        rest = self.restoration
+        like = np.empty((h, w), dt)
+        if rest is not None:
+            st.set_coeffs(rest.weight, rest.omega, rest.regularization, like)
+        else:
+            st.set_coeffs(1.0, 1.0, None, like)
+        pre, post = (ops, []) if not self.first_restoration_then_model else ([], ops)
+        src = np.ascontiguousarray(probe, dtype=dt)
+        _lib.check(st.lib.dxh_tvd_upload_signal(st._h, _lib.ptr(src), channels, _DIFF[self._diff_option], reduction,
+                                                 C.cast(_ops_array(pre), C.c_void_p), len(pre)))
+        if rest is not None:
+            maxiter, tol = (1, None) if solver is None else (solver.maxiter, solver.tol)
+            st.run(rest.max_num_iter, maxiter, tol, eps=rest.eps, isotropic=iso)
+        out = np.empty((h, w), dt)
+        _lib.check(st.lib.dxh_tvd_download_model(st._h, _lib.ptr(out), C.cast(_ops_array(post), C.c_void_p), len(post)))
+        return out
+
+    def __call__(self, img):
+        """Extract the concentration from a probing image (concentrationanalysis.py:230-310)."""
+        if img.img.dtype not in (np.float32, np.float64):
+            raise TypeError("the probing image must be float32/float64 (convert before, e.g. img / 255.)")
+        probe = img.img
+        plan = self._fusable(probe)
+        if plan is not None:
+            concentration = self._device_call(probe, plan)
+        else:
+            probe_img = copy.deepcopy(img)
+            diff = self._subtract_background(probe_img)
+            signal = self._balance_signal(self._clean_signal(self._reduce_signal(diff)))
+            if self.first_restoration_then_model:
+                concentration = self._convert_signal(self._restore_signal(signal), diff)
+            else:
+                concentration = self._restore_signal(self._convert_signal(signal, diff))
+        metadata = img.metadata() if hasattr(img, "metadata") else {}
+        if concentration.ndim == probe.ndim - 1 or concentration.ndim == 2:
+            return ScalarImage(concentration, **{k: v for k, v in metadata.items() if k != "scalar"})
+        if concentration.shape[-1] == 1:
+            return ScalarImage(concentration[..., 0], **{k: v for k, v in metadata.items() if k != "scalar"})
+        return type(img)(concentration, **metadata)

@@ -49,6 +49,11 @@ struct Ctx {
     void* cp_dsc = nullptr;
     void* cp_kq = nullptr;
     void* om_plane = nullptr;      // omega as a plane (array-valued omega only)
+    void* base_img = nullptr;      // ConcentrationAnalysis: dense baseline (H, W, base_channels)
+    int base_channels = 0;
+    void* clean_filter = nullptr;  // dense (H, W) threshold cleaning filter
+    void* probe_buf = nullptr;     // dense staging for the probe frame
+    size_t probe_bytes = 0;
     void* stage = nullptr;         // dense staging buffer (dim * plane) for (*shape, dim) transfers
     double* partial = nullptr;
     double* red_out = nullptr;     // 8 doubles
@@ -666,7 +671,7 @@ int dxh_tvd_destroy(dxh_tvd_t h) {
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
     fr(c->of); fr(c->u[0]); fr(c->u[1]); fr(c->rs);
     for (int j = 0; j < 3; ++j) { fr(c->q[j][0]); fr(c->q[j][1]); fr(c->dpl[j]); fr(c->bpl[j]); }
-    fr(c->cp_ell); fr(c->cp_diag); fr(c->cp_dsc); fr(c->cp_kq); fr(c->om_plane); fr(c->stage); fr(c->partial); fr(c->red_out); fr(c->inc_partial);
+    fr(c->cp_ell); fr(c->cp_diag); fr(c->cp_dsc); fr(c->cp_kq); fr(c->om_plane); fr(c->base_img); fr(c->clean_filter); fr(c->probe_buf); fr(c->stage); fr(c->partial); fr(c->red_out); fr(c->inc_partial);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -699,18 +704,12 @@ int dxh_tvd_set_coeffs(dxh_tvd_t h, double mu, const void* mu_arr, double omega,
     return DXH_OK;
 }
 
-int dxh_tvd_upload(dxh_tvd_t h, const void* img, const void* u0, const void* d0, const void* b0) {
-    Ctx* c = reinterpret_cast<Ctx*>(h);
-    DXH_REQUIRE(c && img, "null argument");
-    if (!c->have_coefs) { set_error("dxh_tvd_set_coeffs must be called before dxh_tvd_upload"); return DXH_ESTATE; }
-    DXH_REQUIRE((d0 == nullptr) == (b0 == nullptr), "d0 and b0 must be given together");
-    int rc = set_device(c);
-    if (rc) return rc;
+// common tail of the two upload paths: the image is in u[0]; builds ||img||^2, of = omega*img, zeroes the state
+static int finish_upload(Ctx* c, const void* u0, const void* d0, const void* b0) {
+    int rc;
     const bool f32 = c->desc.dtype == DXH_F32;
     const int dim = c->desc.dim;
     c->cur = 0;
-    // img -> u[0]; norm; of = omega * img
-    if ((rc = h2d_plane(c, c->u[0], img))) return rc;
     rc = f32 ? sq_diff<float>(c, c->u[0], nullptr, 0, c->g.n0, &c->sq_img, 1)
              : sq_diff<double>(c, c->u[0], nullptr, 0, c->g.n0, &c->sq_img, 1);
     if (rc) return rc;
@@ -752,6 +751,115 @@ int dxh_tvd_upload(dxh_tvd_t h, const void* img, const void* u0, const void* d0,
     }
     DXH_HIP(hipStreamSynchronize(c->stream));
     c->uploaded = true;
+    return DXH_OK;
+}
+
+int dxh_tvd_upload(dxh_tvd_t h, const void* img, const void* u0, const void* d0, const void* b0) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    DXH_REQUIRE(c && img, "null argument");
+    if (!c->have_coefs) { set_error("dxh_tvd_set_coeffs must be called before dxh_tvd_upload"); return DXH_ESTATE; }
+    DXH_REQUIRE((d0 == nullptr) == (b0 == nullptr), "d0 and b0 must be given together");
+    int rc = set_device(c);
+    if (rc) return rc;
+    if ((rc = h2d_plane(c, c->u[0], img))) return rc;
+    return finish_upload(c, u0, d0, b0);
+}
+
+static int to_ops(const dxh_model_op* ops, int n, ModelOps* out) {
+    DXH_REQUIRE(n >= 0 && n <= 8 && (ops || n == 0), "0..8 model operations supported");
+    out->n = n;
+    for (int i = 0; i < n; ++i) {
+        DXH_REQUIRE(ops[i].kind >= 0 && ops[i].kind <= 2, "unknown model operation %d", ops[i].kind);
+        out->kind[i] = ops[i].kind;
+        out->flags[i] = ops[i].flags;
+        out->a[i] = ops[i].a;
+        out->b[i] = ops[i].b;
+    }
+    return DXH_OK;
+}
+
+static int set_dense(Ctx* c, void** slot, const void* host, size_t bytes) {
+    if (*slot) { DXH_HIP(hipFree(*slot)); *slot = nullptr; }
+    if (!host) return DXH_OK;
+    DXH_HIP(hipMalloc(slot, bytes));
+    DXH_HIP(hipMemcpyAsync(*slot, host, bytes, hipMemcpyHostToDevice, c->stream));
+    DXH_HIP(hipStreamSynchronize(c->stream));
+    return DXH_OK;
+}
+
+int dxh_tvd_set_base(dxh_tvd_t h, const void* base, int channels) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    DXH_REQUIRE(c, "null context");
+    DXH_REQUIRE(c->desc.ndim == 2, "the signal pipeline needs a scalar (H, W) context");
+    DXH_REQUIRE(base == nullptr || channels == 1 || channels == 3, "channels must be 1 or 3");
+    int rc = set_device(c);
+    if (rc) return rc;
+    c->base_channels = base ? channels : 0;
+    return set_dense(c, &c->base_img, base, (size_t)c->g.n0 * c->g.L * (base ? channels : 0) * c->esz);
+}
+
+int dxh_tvd_set_cleaning_filter(dxh_tvd_t h, const void* filter) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    DXH_REQUIRE(c, "null context");
+    DXH_REQUIRE(c->desc.ndim == 2, "the signal pipeline needs a scalar (H, W) context");
+    int rc = set_device(c);
+    if (rc) return rc;
+    return set_dense(c, &c->clean_filter, filter, (size_t)c->g.n0 * c->g.L * c->esz);
+}
+
+int dxh_tvd_upload_signal(dxh_tvd_t h, const void* probe, int channels, int diff_option, int reduction,
+                          const dxh_model_op* pre_ops, int n_pre) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    DXH_REQUIRE(c && probe, "null argument");
+    if (!c->have_coefs) { set_error("dxh_tvd_set_coeffs must be called before dxh_tvd_upload_signal"); return DXH_ESTATE; }
+    DXH_REQUIRE(c->desc.ndim == 2, "the signal pipeline needs a scalar (H, W) context");
+    DXH_REQUIRE(channels == 1 || channels == 3, "channels must be 1 or 3");
+    DXH_REQUIRE(diff_option >= 0 && diff_option <= 3, "diff_option must be 0..3");
+    DXH_REQUIRE((channels == 1 && reduction == 0) || (channels == 3 && reduction >= 1 && reduction <= 6),
+                "reduction %d does not fit %d channel(s)", reduction, channels);
+    DXH_REQUIRE(c->base_img == nullptr || c->base_channels == channels, "baseline has %d channel(s), probe %d",
+                c->base_channels, channels);
+    ModelOps pre;
+    int rc = to_ops(pre_ops, n_pre, &pre);
+    if (rc) return rc;
+    if ((rc = set_device(c))) return rc;
+    const size_t bytes = (size_t)c->g.n0 * c->g.L * channels * c->esz;
+    if (c->probe_bytes < bytes) {
+        if (c->probe_buf) { DXH_HIP(hipFree(c->probe_buf)); c->probe_buf = nullptr; c->probe_bytes = 0; }
+        DXH_HIP(hipMalloc(&c->probe_buf, bytes));
+        c->probe_bytes = bytes;
+    }
+    DXH_HIP(hipMemcpyAsync(c->probe_buf, probe, bytes, hipMemcpyHostToDevice, c->stream));
+    const dim3 grid = elem_grid(c->g), blk(256);
+#define DXH_SIG(T, CH) hipLaunchKernelGGL((k_signal<T, CH>), grid, blk, 0, c->stream, c->g, (const T*)c->probe_buf, \
+                                          (const T*)c->base_img, (const T*)c->clean_filter, diff_option, reduction, pre, (T*)c->u[0])
+    if (c->desc.dtype == DXH_F32) { if (channels == 1) DXH_SIG(float, 1); else DXH_SIG(float, 3); }
+    else                          { if (channels == 1) DXH_SIG(double, 1); else DXH_SIG(double, 3); }
+#undef DXH_SIG
+    DXH_HIP(hipGetLastError());
+    return finish_upload(c, nullptr, nullptr, nullptr);
+}
+
+int dxh_tvd_download_model(dxh_tvd_t h, void* out, const dxh_model_op* post_ops, int n_post) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    DXH_REQUIRE(c && out, "null argument");
+    if (!c->uploaded) { set_error("nothing to download"); return DXH_ESTATE; }
+    ModelOps post;
+    int rc = to_ops(post_ops, n_post, &post);
+    if (rc) return rc;
+    if ((rc = set_device(c))) return rc;
+    const size_t dense = (size_t)c->g.n0 * c->g.L * c->esz;
+    if (!c->stage || dense > (size_t)c->g.n0 * c->g.L * c->desc.dim * c->esz) {
+        if (c->stage) { DXH_HIP(hipFree(c->stage)); c->stage = nullptr; }
+        DXH_HIP(hipMalloc(&c->stage, (size_t)c->g.n0 * c->g.L * c->desc.dim * c->esz));
+    }
+    if (c->desc.dtype == DXH_F32)
+        hipLaunchKernelGGL((k_model<float>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const float*)c->u[c->cur], post, (float*)c->stage);
+    else
+        hipLaunchKernelGGL((k_model<double>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const double*)c->u[c->cur], post, (double*)c->stage);
+    DXH_HIP(hipGetLastError());
+    DXH_HIP(hipMemcpyAsync(out, c->stage, dense, hipMemcpyDeviceToHost, c->stream));
+    DXH_HIP(hipStreamSynchronize(c->stream));
     return DXH_OK;
 }
 

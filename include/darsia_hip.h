@@ -122,6 +122,33 @@ int dxh_tvd_run(dxh_tvd_t ctx, int n_iter, int jacobi_maxiter, double jacobi_tol
 int dxh_tvd_download(dxh_tvd_t ctx, void* u, void* d, void* b);
 
 /*
+ * ConcentrationAnalysis fusion (multi_image_analysis/concentrationanalysis.py:230-310): the elementwise stages
+ * either side of the restoration run on the device, so that a frame goes up once (colour) and the
+ * concentration comes down once (scalar).  The context is the scalar (H, W) TVD problem.
+ *   set_base            baseline image (H, W, channels) in the context dtype, or NULL (concentrationanalysis.py:328-364)
+ *   set_cleaning_filter threshold filter (H, W) or NULL (:381-395)
+ *   upload_signal       signal = model_pre(clean(reduce(diff(probe, base)))) becomes the context's image
+ *                       (what dxh_tvd_upload does with a host image); coefficients must be set before
+ *   download_model      out = model_post(u)
+ * diff_option: 0 plain, 1 positive, 2 negative, 3 absolute.  reduction (signals/reduction/monochromatic.py:66-95):
+ * 0 none (channels == 1), 1 red, 2 green, 3 blue, 4 red+green, 5 gray (0.299, 0.587, 0.114 in float32, like
+ * cv2.COLOR_RGB2GRAY), 6 negative-key.  Model ops are applied in order: kind 0: a*x + b (LinearModel,
+ * signals/models/linearmodel.py:140-149), kind 1: a*x (ScalingModel :63), kind 2: clip to [a, b] with
+ * flags bit0 = has lower, bit1 = has upper bound (ClipModel, clipmodel.py:87-106).
+ */
+typedef struct dxh_model_op {
+    int32_t kind;
+    int32_t flags;
+    double a, b;
+} dxh_model_op;
+
+int dxh_tvd_set_base(dxh_tvd_t ctx, const void* base, int channels);
+int dxh_tvd_set_cleaning_filter(dxh_tvd_t ctx, const void* filter);
+int dxh_tvd_upload_signal(dxh_tvd_t ctx, const void* probe, int channels, int diff_option, int reduction,
+                          const dxh_model_op* pre_ops, int n_pre);
+int dxh_tvd_download_model(dxh_tvd_t ctx, void* out, const dxh_model_op* post_ops, int n_post);
+
+/*
  * Row-slab halo plumbing for multi-GPU runs (no reference counterpart: the
  * reference is single-process).  Rows [row0, row0 + nrows) of the three evolving
  * fields u, dub_0.. are copied to / from a caller-provided DEVICE buffer of

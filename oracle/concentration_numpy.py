@@ -1,0 +1,55 @@
+"""CPU restatement (NumPy) of the elementwise chain of DarSIA's ConcentrationAnalysis
+(multi_image_analysis/concentrationanalysis.py:230-421) around the TV restoration.
+
+TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  The reference class cannot be imported here (it needs
+darsia.Image -> cv2), so parity is pinned on the formulas of the cited lines: they are one-line NumPy
+expressions.  The only third-party arithmetic is ``cv2.cvtColor(.., COLOR_RGB2GRAY)`` for the "gray"
+reduction (float32 weights 0.299 / 0.587 / 0.114), which is UNPINNED (cv2 absent).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import tvd_numpy
+
+
+def diff(img, base, option):
+    # concentrationanalysis.py:328-364 (skimage.util.compare_images(method="diff") is |a - b| for floats)
+    if base is None:
+        return {"positive": np.clip(img, 0, None), "negative": np.clip(-img, 0, None), "absolute": np.absolute(img),
+                "plain": img}[option]
+    return {"positive": np.clip(img - base, 0, None), "negative": np.clip(base - img, 0, None),
+            "absolute": np.abs(img - base), "plain": img - base}[option]
+
+
+def reduce(img, color):
+    # signals/reduction/monochromatic.py:66-95
+    if color is None:
+        return img
+    if color == "gray":
+        f = img.astype(np.float32)
+        return f[:, :, 0] * np.float32(0.299) + f[:, :, 1] * np.float32(0.587) + f[:, :, 2] * np.float32(0.114)
+    if color in ("red", "green", "blue"):
+        return img[:, :, ("red", "green", "blue").index(color)]
+    if color == "red+green":
+        return img[:, :, 0] + img[:, :, 1]
+    if color == "negative-key":
+        return 1 - np.min(1 - img, axis=2)
+    raise ValueError(color)
+
+
+def concentration(img, base, option, color, cleaning_filter, model, tvd_kwargs, restoration_first):
+    """model: list of callables applied in order; tvd_kwargs: None or kwargs of tvd_numpy.split_bregman_tvd."""
+    signal = reduce(diff(img, base, option), color)
+    if cleaning_filter is not None:
+        signal = np.clip(signal - cleaning_filter, 0, None)
+
+    def apply_model(x):
+        for m in model:
+            x = m(x)
+        return x
+
+    def restore(x):
+        return x if tvd_kwargs is None else tvd_numpy.split_bregman_tvd(np.ascontiguousarray(x), promotion="strict", **tvd_kwargs)
+
+    return apply_model(restore(signal)) if restoration_first else restore(apply_model(signal))

@@ -45,3 +45,14 @@ t("PiecewisePerspectiveTransform.find_and_warp  [PCIe-inclusive]", lambda: da.Pi
 rng = np.random.default_rng(3)
 c = rng.random((262, 2)) * np.array([W, H]); rbf = RBFInterpolator(c, rng.normal(size=262))
 t("evaluate_rbf_on_grid (262 centres, 32 M pixels)  [incl. 256 MB download]", lambda: da.evaluate_rbf_on_grid(rbf, (H, W)))
+print("ConcentrationAnalysis (RGB frame -> concentration), fused on the device vs NumPy stage chain on the host")
+base_img = da.OpticalImage(rgb)
+probe_img = da.OpticalImage(np.clip(rgb + 0.1 * np.random.default_rng(1).random(rgb.shape).astype(np.float32), 0, 1))
+tvd_op = da.TVD(method="heterogeneous bregman", weight=0.1, max_num_iter=100, eps=None)
+model = da.CombinedModel([da.LinearModel(scaling=2.0, offset=0.0), da.ClipModel(min_value=0.0, max_value=1.0)])
+ca = da.ConcentrationAnalysis(base_img, da.MonochromaticReduction(color="red"), None, tvd_op, model, **{"diff option": "positive"})
+t("ConcentrationAnalysis.__call__ fused (upload RGB, 100 TVD it, download scalar)", lambda: ca(probe_img))
+def host_chain():
+    d = np.clip(probe_img.img - base_img.img, 0, None); s = d[:, :, 0]; m = np.clip(2.0 * s + 0.0, 0.0, 1.0)
+    return m
+t("  the same elementwise stages as NumPy passes on the host (no TVD)", host_chain)
