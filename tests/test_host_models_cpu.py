@@ -1,0 +1,45 @@
+"""Host-side mirrors: array slicing helpers and the per-pixel model / reduction classes
+(NumPy semantics of the reference; no device work)."""
+import numpy as np
+import pytest
+
+import darsia_amd as da
+from oracle import concentration_numpy as OC
+
+
+def test_array_slice_helpers():
+    a = np.arange(24).reshape(2, 3, 4)
+    assert np.array_equal(da.array_slice(a, 1, 0, 2), a[:, 0:2])
+    assert np.array_equal(da.array_slice(a, -1, 1, None, 2), a[:, :, 1::2])
+    assert da.array_slice_argument(a, 2, 0, 1) == (slice(None), slice(None), slice(0, 1, 1))
+    b = np.zeros_like(a)
+    b[da.array_slice_argument(a, 0, -1, None)] += 7
+    assert b[-1].min() == 7 and b[0].max() == 0
+
+
+def test_models_and_reduction_follow_numpy_semantics():
+    rng = np.random.default_rng(0)
+    x = rng.random((5, 7)).astype(np.float32)
+    assert da.ScalingModel(scaling=1.0)(x) is x
+    assert np.array_equal(da.ScalingModel(scaling=2.0)(x), 2.0 * x)
+    assert np.array_equal(da.LinearModel(scaling=3.0, offset=0.5)(x), 3.0 * x + 0.5)
+    assert np.array_equal(da.ClipModel(max_value=0.5)(x), np.clip(x, None, 0.5))
+    with pytest.raises(ValueError):
+        da.ClipModel()
+    cm = da.CombinedModel([da.LinearModel(scaling=2.0, offset=-0.2), da.ClipModel(min_value=0.0, max_value=1.0)])
+    assert np.array_equal(cm(x), np.clip(2.0 * x - 0.2, 0.0, 1.0))
+    assert cm.num_parameters == 4 and isinstance(cm[1], da.ClipModel)
+    rgb = rng.random((4, 6, 3)).astype(np.float32)
+    for color in ("red", "green", "blue", "red+green", "gray", "negative-key"):
+        assert np.array_equal(da.MonochromaticReduction(color=color)(rgb), OC.reduce(rgb, color))
+    with pytest.raises(ValueError):
+        da.MonochromaticReduction(color="purple")(rgb)
+
+
+def test_cleaning_filter_is_the_maximum_reduced_difference():
+    rng = np.random.default_rng(1)
+    frames = [da.OpticalImage(rng.random((6, 8, 3)).astype(np.float32)) for _ in range(3)]
+    ca = da.ConcentrationAnalysis(frames, da.MonochromaticReduction(color="green"), **{"diff option": "absolute"})
+    expect = np.maximum(np.abs(frames[1].img - frames[0].img)[:, :, 1], np.abs(frames[2].img - frames[0].img)[:, :, 1])
+    assert ca.threshold_cleaning_filter.dtype == np.float64
+    assert np.array_equal(ca.threshold_cleaning_filter, np.maximum(0.0, expect))
