@@ -1,0 +1,51 @@
+"""bench.py contract checks on a real GPU: one JSON line with the required fields at N = 1, and the
+N-rank code path in rehearsal mode (ranks share the GPU, gloo-staged exchange)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _last_json(stdout: str):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_has_contract_fields():
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--height", "512", "--width", "768",
+                        "--iters", "20", "--cpu-sample", "128x192"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1.5
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1
+    assert "workload" in d["config"]
+
+
+def test_two_rank_rehearsal_runs_the_slab_path():
+    env = dict(os.environ, DXH_BENCH_REHEARSAL="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--height", "256", "--width", "512", "--iters", "16"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["rows_per_gpu"] == 256
+    assert "REHEARSAL" in d["data"] and d["value"] > 0
