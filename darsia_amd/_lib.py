@@ -26,7 +26,7 @@ EXPORTS = (
     "dxh_tvd_download", "dxh_tvd_halo_bytes", "dxh_tvd_pack_rows", "dxh_tvd_unpack_rows",
     "dxh_tvd_partial_norms", "dxh_tvd_sync", "dxh_jacobi_solve", "dxh_diff", "dxh_chambolle",
     "dxh_warp_patches", "dxh_tps_eval", "dxh_affine_color",
-    "dxh_tvd_set_base", "dxh_tvd_set_cleaning_filter", "dxh_tvd_upload_signal", "dxh_tvd_download_model",
+    "dxh_tvd_energy", "dxh_tvd_set_base", "dxh_tvd_set_cleaning_filter", "dxh_tvd_upload_signal", "dxh_tvd_download_model",
 )
 
 
@@ -86,6 +86,7 @@ def _declare(lib):
     lib.dxh_tvd_unpack_rows.argtypes = [vp, i64, i64, vp]
     lib.dxh_tvd_partial_norms.argtypes = [vp, i64, i64, C.POINTER(dbl), C.POINTER(dbl)]
     lib.dxh_tvd_sync.argtypes = [vp]
+    lib.dxh_tvd_energy.argtypes = [vp, i, C.POINTER(dbl)]
     lib.dxh_jacobi_solve.argtypes = [i, i, i, i, i, i64, i64, i64, vp, vp, vp, dbl, vp, dbl, vp, dbl, i, dbl,
                                      C.POINTER(i)]
     lib.dxh_diff.argtypes = [i, i, i64, i64, i64, i, i, dbl, vp, vp]

@@ -367,6 +367,35 @@ __global__ void __launch_bounds__(256) k_model(Geom g, const T* __restrict__ in,
     out_dense[e.row * g.L + e.x] = apply_model_ops<T>(in[e.off], post);
 }
 
+// energy functional 0.5 ||omega (x - img)||^2 + sum_j sum |mu D+_j x|  (split_bregman_tvd.py:71-77, verbose only).
+// Diagnostic: evaluated in double from the stored planes (omega*img instead of img, mu = kq*ell).
+template <typename T, int DIM>
+__global__ void __launch_bounds__(256) k_energy(Geom g, const T* __restrict__ x, const T* __restrict__ of, double omega_s,
+                                                 const T* __restrict__ omega_p, Coef<T> c, CoefPlanes<T> cp,
+                                                 double* __restrict__ partial) {
+    __shared__ double sm[256 / kWave];
+    ElemIdx e;
+    double v = 0.0;
+    if (elem_index(g, e)) {
+        const double om = omega_p ? (double)omega_p[e.off] : omega_s;
+        const double fid = om * (double)x[e.off] - (double)of[e.off];
+        const double mu = (double)(cp.kq ? cp.kq[e.off] : c.kq) * (double)(cp.ell ? cp.ell[e.off] : c.ell);
+        v = 0.5 * fid * fid;
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) v += fabs(mu * ((double)x[nb_off(g, e, j, +1)] - (double)x[e.off]));
+    }
+#pragma unroll
+    for (int s = kWave / 2; s > 0; s >>= 1) v += __shfl_down(v, s, kWave);
+    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+    if (lane == 0) sm[wid] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < 256 / kWave; ++w) s += sm[w];
+        partial[blockIdx.x] = s;
+    }
+}
+
 // ---- reductions: sum (a - b)^2 (b may be null) over rows [row0, row0 + nrows) -----------------
 // deterministic two-stage tree in double (per-block partials, then one block)
 template <typename T>

@@ -987,6 +987,33 @@ int dxh_tvd_partial_norms(dxh_tvd_t h, int64_t row0, int64_t nrows, double* sq_i
     return DXH_OK;
 }
 
+int dxh_tvd_energy(dxh_tvd_t h, int which, double* value) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    DXH_REQUIRE(c && value, "null argument");
+    DXH_REQUIRE(which == 0 || which == 1, "which: 0 = current iterate, 1 = previous iterate");
+    if (!c->uploaded) { set_error("nothing uploaded"); return DXH_ESTATE; }
+    int rc = set_device(c);
+    if (rc) return rc;
+    const dim3 grid = elem_grid(c->g), blk(256);
+    const unsigned nb = grid.x;
+    double* part = nullptr;
+    DXH_HIP(hipMalloc((void**)&part, sizeof(double) * nb));
+    const void* x = c->u[which == 0 ? c->cur : c->cur ^ 1];
+    const double om = std::isnan(c->omega_s) ? 0.0 : c->omega_s;
+#define DXH_EN(T, DIM) hipLaunchKernelGGL((k_energy<T, DIM>), grid, blk, 0, c->stream, c->g, (const T*)x, (const T*)c->of, om, \
+                                          (const T*)c->om_plane, make_coef<T>(c), make_planes<T>(c), part)
+    if (c->desc.dtype == DXH_F32) { if (c->desc.dim == 2) DXH_EN(float, 2); else DXH_EN(float, 3); }
+    else                          { if (c->desc.dim == 2) DXH_EN(double, 2); else DXH_EN(double, 3); }
+#undef DXH_EN
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, part, (int)nb, c->red_out + 6);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(value, c->red_out + 6, sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(part);
+    if (e != hipSuccess) { set_error("energy evaluation failed: %s", hipGetErrorString(e)); return DXH_EHIP; }
+    return DXH_OK;
+}
+
 int dxh_tvd_sync(dxh_tvd_t h) {
     Ctx* c = reinterpret_cast<Ctx*>(h);
     DXH_REQUIRE(c, "null context");

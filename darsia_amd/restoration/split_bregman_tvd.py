@@ -103,6 +103,12 @@ class DeviceTVD:
                                         -1.0 if eps is None else float(eps), float(norm_scale), flags, C.byref(res)))
         return res
 
+    def energy(self, previous: bool = False) -> float:
+        """Energy functional of split_bregman_tvd.py:71-77 of the current (or previous) iterate."""
+        v = C.c_double(0.0)
+        _lib.check(self.lib.dxh_tvd_energy(self._h, 1 if previous else 0, C.byref(v)))
+        return v.value
+
     def download(self, want_split=False):
         u = np.empty(self.shape, self.dtype)
         if not want_split:
@@ -163,11 +169,14 @@ def split_bregman_tvd(
         st.upload(img, u0, d0, b0)
         show = (lambda it: verbose) if isinstance(verbose, bool) else (lambda it: verbose > 0 and it % verbose == 0)
         if (verbose if isinstance(verbose, bool) else verbose > 0):
-            # verbose: one iteration per call so that the increment can be printed (debug path)
+            # verbose: one iteration per call so that increment and energy can be printed (debug path,
+            # same messages as split_bregman_tvd.py:103-104,161-167)
+            print(f"The energy functional starts at {st.energy()}")
             for it in range(max_num_iter):
                 r = st.run(1, solver.maxiter, solver.tol, eps=0.0 if eps is None else eps, isotropic=isotropic)
                 if show(it):
-                    print(f"Split Bregman iteration {it} - relative increment: {r.rel_increment}")
+                    print(f"Split Bregman iteration {it} - relative increment: {r.rel_increment}, "
+                          f"energy functional: {st.energy(previous=True)}")
                 if eps is not None and r.converged:
                     break
         else:

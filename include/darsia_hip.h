@@ -160,6 +160,8 @@ int dxh_tvd_unpack_rows(dxh_tvd_t ctx, int64_t row0, int64_t nrows, const void* 
 /* sum over rows [row0, row0+nrows) of (u - u_prev)^2 of the last iteration and of img^2 (for a global eps test) */
 int dxh_tvd_partial_norms(dxh_tvd_t ctx, int64_t row0, int64_t nrows, double* sq_increment, double* sq_img);
 int dxh_tvd_sync(dxh_tvd_t ctx);
+/* energy functional of split_bregman_tvd.py:71-77 (verbose output) of the current (0) or previous (1) iterate */
+int dxh_tvd_energy(dxh_tvd_t ctx, int which, double* value);
 
 /*
  * One-shot Jacobi solve  mass * x - diffusion * laplace(x) = rhs  (jacobi.py:74-133),

@@ -326,3 +326,24 @@ def test_full_size_config2_parity_and_invariants(monkeypatch):
     # TV denoising reduces the total variation of the image
     tv = lambda a: np.abs(np.diff(a, axis=0)).sum(dtype=np.float64) + np.abs(np.diff(a, axis=1)).sum(dtype=np.float64)  # noqa: E731
     assert tv(out_k4) < tv(img)
+
+
+def test_verbose_prints_increment_and_energy(golden, capsys):
+    """verbose=True prints the reference's two messages; the energy is the functional of
+    split_bregman_tvd.py:71-77 (compared here with a NumPy evaluation)."""
+    img = golden["g2_aniso2d_f32/img"]
+    out = da.split_bregman_tvd(img, mu=0.1, max_num_iter=3, verbose=True)
+    text = capsys.readouterr().out.splitlines()
+    assert text[0].startswith("The energy functional starts at ")
+    assert len([ln for ln in text if ln.startswith("Split Bregman iteration")]) == 3
+    assert_bits(out, O.split_bregman_tvd(img, mu=0.1, max_num_iter=3, promotion="strict"))
+
+    def functional(x):
+        x = x.astype(np.float64)
+        return 0.5 * np.sum((x - img) ** 2) + sum(np.abs(0.1 * O.backward_diff(x, j)).sum() for j in range(2))
+
+    e0 = float(text[0].split()[-1])
+    assert abs(e0 - functional(img)) <= 1e-6 * functional(img)
+    u2 = O.split_bregman_tvd(img, mu=0.1, max_num_iter=2, promotion="strict")
+    e_last = float(text[-1].split()[-1])  # energy of the iterate BEFORE the third update
+    assert abs(e_last - functional(u2)) <= 1e-5 * functional(u2)
