@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("DARSIA_HIP_LIB") or os.path.join(_HERE, "libdarsia_hi
 
 DXH_F32, DXH_F64 = 0, 1
 NSUM_ALL_AXES, NSUM_SPATIAL = 0, 1
-FLAG_ISOTROPIC, FLAG_NO_FUSED, FLAG_NO_DPP, FLAG_ASYNC = 1, 2, 4, 8
+FLAG_ISOTROPIC, FLAG_NO_FUSED, FLAG_NO_DPP, FLAG_ASYNC, FLAG_EXPLICIT = 1, 2, 4, 8, 16
 
 # every symbol include/darsia_hip.h declares (tests check that the library exports them all)
 EXPORTS = (
@@ -26,7 +26,7 @@ EXPORTS = (
     "dxh_tvd_download", "dxh_tvd_halo_bytes", "dxh_tvd_pack_rows", "dxh_tvd_unpack_rows",
     "dxh_tvd_partial_norms", "dxh_tvd_sync", "dxh_jacobi_solve", "dxh_diff", "dxh_chambolle",
     "dxh_warp_patches", "dxh_tps_eval", "dxh_affine_color",
-    "dxh_tvd_energy", "dxh_tvd_set_base", "dxh_tvd_set_cleaning_filter", "dxh_tvd_upload_signal", "dxh_tvd_download_model",
+    "dxh_tvd_energy", "dxh_tvd_adapt_ell", "dxh_tvd_set_base", "dxh_tvd_set_cleaning_filter", "dxh_tvd_upload_signal", "dxh_tvd_download_model",
 )
 
 
@@ -87,6 +87,7 @@ def _declare(lib):
     lib.dxh_tvd_partial_norms.argtypes = [vp, i64, i64, C.POINTER(dbl), C.POINTER(dbl)]
     lib.dxh_tvd_sync.argtypes = [vp]
     lib.dxh_tvd_energy.argtypes = [vp, i, C.POINTER(dbl)]
+    lib.dxh_tvd_adapt_ell.argtypes = [vp]
     lib.dxh_jacobi_solve.argtypes = [i, i, i, i, i, i64, i64, i64, vp, vp, vp, dbl, vp, dbl, vp, dbl, i, dbl,
                                      C.POINTER(i)]
     lib.dxh_diff.argtypes = [i, i, i64, i64, i64, i, i, dbl, vp, vp]

@@ -183,6 +183,87 @@ __global__ void __launch_bounds__(256) k_shrink(Geom g, const T* __restrict__ un
     }
 }
 
+// explicit-(d, b) variant of the shrink step, used when the state cannot be kept compressed (adaptive ell:
+// the threshold changes between the iteration that produced d, b and the one that consumes them)
+template <typename T, int DIM, bool ISO>
+__global__ void __launch_bounds__(256) k_shrink_db(Geom g, const T* __restrict__ unew, T* d0, T* d1, T* d2, T* b0, T* b1,
+                                                    T* b2, Coef<T> c, CoefPlanes<T> cp) {
+    ElemIdx e;
+    if (!elem_index(g, e)) return;
+    T* dp[3] = {d0, d1, d2};
+    T* bp[3] = {b0, b1, b2};
+    const T kq = cp.kq ? cp.kq[e.off] : c.kq;
+    const T uc = unew[e.off];
+    T q[DIM], d[DIM], b[DIM];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) q[j] = (unew[nb_off(g, e, j, +1)] - uc) + bp[j][e.off];
+    split_vars<T, DIM, ISO>(q, kq, d, b);
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+        dp[j][e.off] = d[j];
+        bp[j][e.off] = b[j];
+    }
+}
+
+// state -> explicit planes (entering explicit mode)
+template <typename T, int DIM, bool ISO>
+__global__ void __launch_bounds__(256) k_expand_planes(Geom g, QPlanes<T, DIM> q, Coef<T> c, CoefPlanes<T> cp, T* d0, T* d1,
+                                                        T* d2, T* b0, T* b1, T* b2) {
+    ElemIdx e;
+    if (!elem_index(g, e)) return;
+    T* dp[3] = {d0, d1, d2};
+    T* bp[3] = {b0, b1, b2};
+    const T kq = cp.kq ? cp.kq[e.off] : c.kq;
+    T qq[DIM], d[DIM], b[DIM];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) qq[j] = q.in[j][e.off];
+    split_vars<T, DIM, ISO>(qq, kq, d, b);
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+        dp[j][e.off] = d[j];
+        bp[j][e.off] = b[j];
+    }
+}
+
+// explicit planes -> dense (*shape, dim) arrays
+template <typename T, int DIM>
+__global__ void __launch_bounds__(256) k_interleave(Geom g, const T* p0, const T* p1, const T* p2, T* __restrict__ dst) {
+    ElemIdx e;
+    if (!elem_index(g, e)) return;
+    const T* pl[3] = {p0, p1, p2};
+    const int64_t o = (e.row * g.L + e.x) * DIM;
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) dst[o + j] = pl[j][e.off];
+}
+
+// scalar coefficients -> planes with exactly the scalar path's values
+template <typename T>
+__global__ void __launch_bounds__(256) k_fill_coef(Geom g, Coef<T> c, T* ell_o, T* diag_o, T* dsc_o, T* kq_o) {
+    ElemIdx e;
+    if (!elem_index(g, e)) return;
+    ell_o[e.off] = c.ell;
+    diag_o[e.off] = c.diag;
+    dsc_o[e.off] = c.dsc;
+    kq_o[e.off] = c.kq;
+}
+
+// adaptive regularisation (split_bregman_tvd.py:149-158): ell = 1 / max(sum_j |D+_j u|, 1e-12), kq = mu / ell.
+// diag / dsc are NOT touched: the reference's Jacobi keeps its cached diagonal (quirk Q3).
+template <typename T, int DIM>
+__global__ void __launch_bounds__(256) k_adapt_ell(Geom g, const T* __restrict__ u, T mu_s, const T* __restrict__ mu_p,
+                                                    T* __restrict__ ell_o, T* __restrict__ kq_o) {
+    ElemIdx e;
+    if (!elem_index(g, e)) return;
+    const T uc = u[e.off];
+    T l1 = T(0);
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) l1 = l1 + t_abs(u[nb_off(g, e, j, +1)] - uc);
+    const T lo = T(1e-12);
+    const T ell = T(1) / (l1 > lo ? l1 : lo);
+    ell_o[e.off] = ell;
+    kq_o[e.off] = (mu_p ? mu_p[e.off] : mu_s) / ell;
+}
+
 // expand the state into the reference's split variables, layout (*shape, dim) (download / x0 round trip)
 template <typename T, int DIM, bool ISO>
 __global__ void __launch_bounds__(256) k_expand(Geom g, QPlanes<T, DIM> q, Coef<T> c, CoefPlanes<T> cp,

@@ -49,6 +49,8 @@ struct Ctx {
     void* cp_dsc = nullptr;
     void* cp_kq = nullptr;
     void* om_plane = nullptr;      // omega as a plane (array-valued omega only)
+    void* mu_plane = nullptr;      // mu as a plane (array-valued mu; needed by the adaptive update)
+    bool explicit_db = false;      // split variables live in dpl / bpl instead of the compressed q planes
     void* base_img = nullptr;      // ConcentrationAnalysis: dense baseline (H, W, base_channels)
     int base_channels = 0;
     void* clean_filter = nullptr;  // dense (H, W) threshold cleaning filter
@@ -64,7 +66,7 @@ struct Ctx {
 
     int cur = 0;                   // index of the current u / q buffers
     bool have_coefs = false, het = false, uploaded = false, from_db = false;
-    bool last_iso = false;
+    bool last_iso = false, last_iso_prev = false;
     double mu_s = 0, omega_s = 1, ell_s = 0;  // scalar views (valid when !het)
     double c_ell = 0, c_diag = 0, c_dsc = 0, c_kq = 0;
     double sq_img = -1.0;          // sum img^2 over this slab
@@ -404,6 +406,7 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
     const bool dpp = !(flags & DXH_FLAG_NO_DPP);
     bool fused_ok = fused_supported(c) && jacobi_maxiter == 1 && !use_tol && !(flags & DXH_FLAG_NO_FUSED);
     const int dim = c->desc.dim;
+    c->last_iso_prev = c->last_iso;
     c->last_iso = iso;
 
     void* tmp = nullptr;
@@ -413,6 +416,29 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
         if (rc) return rc;
         if (jacobi_maxiter > 1) {
             DXH_HIP(hipMalloc(&tmp, c->plane_bytes));
+        }
+    }
+    const bool explicit_mode = (flags & DXH_FLAG_EXPLICIT) || c->explicit_db;
+    if (explicit_mode) {
+        fused_ok = false;
+        int rc = alloc_plane(c, &c->rs);
+        if (rc) return rc;
+        if (jacobi_maxiter > 1 && !tmp) DXH_HIP(hipMalloc(&tmp, c->plane_bytes));
+        if (!c->explicit_db) {
+            if (!c->from_db) {
+                // expand the compressed state into explicit planes
+                for (int j = 0; j < dim; ++j)
+                    if ((rc = alloc_plane(c, &c->dpl[j])) || (rc = alloc_plane(c, &c->bpl[j]))) return rc;
+                const dim3 grid = elem_grid(c->g), blk(256);
+#define DXH_XP(DIM_, ISO_) hipLaunchKernelGGL((k_expand_planes<T, DIM_, ISO_>), grid, blk, 0, c->stream, c->g, make_q<T, DIM_>(c, c->cur, c->cur), \
+        make_coef<T>(c), make_planes<T>(c), (T*)c->dpl[0], (T*)c->dpl[1], (T*)c->dpl[2], (T*)c->bpl[0], (T*)c->bpl[1], (T*)c->bpl[2])
+                if (dim == 2) { if (c->last_iso_prev) DXH_XP(2, true); else DXH_XP(2, false); }
+                else          { if (c->last_iso_prev) DXH_XP(3, true); else DXH_XP(3, false); }
+#undef DXH_XP
+                DXH_HIP(hipGetLastError());
+            }
+            c->from_db = false;
+            c->explicit_db = true;
         }
     }
     double nrm_img = 0.0;
@@ -481,6 +507,24 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
                 it += K - 1;
             } else {
                 launch_fused<T>(c, in, out, iso, dpp);
+            }
+            ++launches;
+            c->cur = out;
+        } else if (explicit_mode) {
+            // rhs from explicit planes, Jacobi, shrink back into the planes
+            if (dim == 2) launch_rhs<T, 2>(c, iso, true); else launch_rhs<T, 3>(c, iso, true);
+            ++launches;
+            int rc = jacobi_sweeps<T>(c, jacobi_maxiter, jacobi_tol, tmp, &launches, nullptr);
+            if (rc) { if (tmp) (void)hipFree(tmp); return rc; }
+            {
+                const dim3 grid = elem_grid(c->g), blk(256);
+                auto co = make_coef<T>(c);
+                auto cp = make_planes<T>(c);
+#define DXH_SDB(DIM_, ISO_) hipLaunchKernelGGL((k_shrink_db<T, DIM_, ISO_>), grid, blk, 0, c->stream, c->g, (const T*)c->u[out], \
+        (T*)c->dpl[0], (T*)c->dpl[1], (T*)c->dpl[2], (T*)c->bpl[0], (T*)c->bpl[1], (T*)c->bpl[2], co, cp)
+                if (dim == 2) { if (iso) DXH_SDB(2, true); else DXH_SDB(2, false); }
+                else          { if (iso) DXH_SDB(3, true); else DXH_SDB(3, false); }
+#undef DXH_SDB
             }
             ++launches;
             c->cur = out;
@@ -671,7 +715,7 @@ int dxh_tvd_destroy(dxh_tvd_t h) {
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
     fr(c->of); fr(c->u[0]); fr(c->u[1]); fr(c->rs);
     for (int j = 0; j < 3; ++j) { fr(c->q[j][0]); fr(c->q[j][1]); fr(c->dpl[j]); fr(c->bpl[j]); }
-    fr(c->cp_ell); fr(c->cp_diag); fr(c->cp_dsc); fr(c->cp_kq); fr(c->om_plane); fr(c->base_img); fr(c->clean_filter); fr(c->probe_buf); fr(c->stage); fr(c->partial); fr(c->red_out); fr(c->inc_partial);
+    fr(c->cp_ell); fr(c->cp_diag); fr(c->cp_dsc); fr(c->cp_kq); fr(c->om_plane); fr(c->mu_plane); fr(c->base_img); fr(c->clean_filter); fr(c->probe_buf); fr(c->stage); fr(c->partial); fr(c->red_out); fr(c->inc_partial);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -698,6 +742,15 @@ int dxh_tvd_set_coeffs(dxh_tvd_t h, double mu, const void* mu_arr, double omega,
         DXH_HIP(hipFree(c->om_plane));
         c->om_plane = nullptr;
     }
+    if (mu_arr) {
+        if ((rc = alloc_plane(c, &c->mu_plane))) return rc;
+        if ((rc = h2d_plane(c, c->mu_plane, mu_arr))) return rc;
+        DXH_HIP(hipStreamSynchronize(c->stream));
+    } else if (c->mu_plane) {
+        DXH_HIP(hipFree(c->mu_plane));
+        c->mu_plane = nullptr;
+    }
+    c->explicit_db = false;
     c->have_coefs = true;
     c->uploaded = false;  // omega*img must be rebuilt
     c->omega_s = omega_arr ? std::numeric_limits<double>::quiet_NaN() : omega;
@@ -728,6 +781,7 @@ static int finish_upload(Ctx* c, const void* u0, const void* d0, const void* b0)
     }
     DXH_HIP(hipMemsetAsync(c->u[1], 0, c->plane_bytes, c->stream));
     c->from_db = false;
+    c->explicit_db = false;
     if (d0) {
         // explicit split variables: keep them as planes for the first iteration
         const size_t dense = (size_t)c->g.n0 * c->g.L * dim * c->esz;
@@ -886,10 +940,30 @@ int dxh_tvd_download(dxh_tvd_t h, void* u, void* d, void* b) {
     if (d || b) {
         const int dim = c->desc.dim;
         const size_t dense = (size_t)c->g.n0 * c->g.L * dim * c->esz;
-        if (c->from_db) {
-            // nothing ran since the warm start was uploaded: hand the explicit planes back
-            set_error("download of split variables before any iteration is not supported");
-            return DXH_ESTATE;
+        if (c->from_db || c->explicit_db) {
+            // explicit planes: interleave them into the reference layout
+            void* tmpd = nullptr;
+            DXH_HIP(hipMalloc(&tmpd, dense));
+            const dim3 grid2 = elem_grid(c->g), blk2(256);
+            for (int pass = 0; pass < 2; ++pass) {
+                void* host = pass == 0 ? d : b;
+                if (!host) continue;
+                void** pl = pass == 0 ? c->dpl : c->bpl;
+                if (c->desc.dtype == DXH_F32) {
+                    if (dim == 2) hipLaunchKernelGGL((k_interleave<float, 2>), grid2, blk2, 0, c->stream, c->g, (const float*)pl[0], (const float*)pl[1], (const float*)pl[2], (float*)tmpd);
+                    else hipLaunchKernelGGL((k_interleave<float, 3>), grid2, blk2, 0, c->stream, c->g, (const float*)pl[0], (const float*)pl[1], (const float*)pl[2], (float*)tmpd);
+                } else {
+                    if (dim == 2) hipLaunchKernelGGL((k_interleave<double, 2>), grid2, blk2, 0, c->stream, c->g, (const double*)pl[0], (const double*)pl[1], (const double*)pl[2], (double*)tmpd);
+                    else hipLaunchKernelGGL((k_interleave<double, 3>), grid2, blk2, 0, c->stream, c->g, (const double*)pl[0], (const double*)pl[1], (const double*)pl[2], (double*)tmpd);
+                }
+                hipError_t e = hipGetLastError();
+                if (e == hipSuccess) e = hipMemcpyAsync(host, tmpd, dense, hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+                if (e != hipSuccess) { (void)hipFree(tmpd); set_error("download failed: %s", hipGetErrorString(e)); return DXH_EHIP; }
+            }
+            DXH_HIP(hipFree(tmpd));
+            DXH_HIP(hipStreamSynchronize(c->stream));
+            return DXH_OK;
         }
         void *dd = nullptr, *bb = nullptr;
         if (d) DXH_HIP(hipMalloc(&dd, dense));
@@ -1011,6 +1085,34 @@ int dxh_tvd_energy(dxh_tvd_t h, int which, double* value) {
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(part);
     if (e != hipSuccess) { set_error("energy evaluation failed: %s", hipGetErrorString(e)); return DXH_EHIP; }
+    return DXH_OK;
+}
+
+int dxh_tvd_adapt_ell(dxh_tvd_t h) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    DXH_REQUIRE(c, "null context");
+    if (!c->uploaded || !c->explicit_db) { set_error("dxh_tvd_adapt_ell needs a context in explicit mode (run with DXH_FLAG_EXPLICIT first)"); return DXH_ESTATE; }
+    int rc = set_device(c);
+    if (rc) return rc;
+    const dim3 grid = elem_grid(c->g), blk(256);
+    const bool f32 = c->desc.dtype == DXH_F32;
+    if (!c->het) {
+        // materialise the four coefficient planes with exactly the scalar path's values
+        if ((rc = alloc_plane(c, &c->cp_ell)) || (rc = alloc_plane(c, &c->cp_diag)) || (rc = alloc_plane(c, &c->cp_dsc)) ||
+            (rc = alloc_plane(c, &c->cp_kq)))
+            return rc;
+        if (f32) hipLaunchKernelGGL((k_fill_coef<float>), grid, blk, 0, c->stream, c->g, make_coef<float>(c), (float*)c->cp_ell, (float*)c->cp_diag, (float*)c->cp_dsc, (float*)c->cp_kq);
+        else hipLaunchKernelGGL((k_fill_coef<double>), grid, blk, 0, c->stream, c->g, make_coef<double>(c), (double*)c->cp_ell, (double*)c->cp_diag, (double*)c->cp_dsc, (double*)c->cp_kq);
+        DXH_HIP(hipGetLastError());
+        c->het = true;
+    }
+    const void* u = c->u[c->cur];
+#define DXH_AD(T, DIM) hipLaunchKernelGGL((k_adapt_ell<T, DIM>), grid, blk, 0, c->stream, c->g, (const T*)u, (T)c->mu_s, \
+                                          (const T*)c->mu_plane, (T*)c->cp_ell, (T*)c->cp_kq)
+    if (f32) { if (c->desc.dim == 2) DXH_AD(float, 2); else DXH_AD(float, 3); }
+    else     { if (c->desc.dim == 2) DXH_AD(double, 2); else DXH_AD(double, 3); }
+#undef DXH_AD
+    DXH_HIP(hipGetLastError());
     return DXH_OK;
 }
 

@@ -103,6 +103,10 @@ class DeviceTVD:
                                         -1.0 if eps is None else float(eps), float(norm_scale), flags, C.byref(res)))
         return res
 
+    def adapt_ell(self) -> None:
+        """ell <- 1 / max(|grad u|_1, 1e-12) per element (split_bregman_tvd.py:149-158); explicit mode only."""
+        _lib.check(self.lib.dxh_tvd_adapt_ell(self._h))
+
     def energy(self, previous: bool = False) -> float:
         """Energy functional of split_bregman_tvd.py:71-77 of the current (or previous) iterate."""
         v = C.c_double(0.0)
@@ -148,8 +152,6 @@ def split_bregman_tvd(
     if img.dtype.kind != "f":
         raise TypeError("split_bregman_tvd needs a float32/float64 image (integer images break the "
                         "reference's split variables, SURVEY.md quirk Q5)")
-    if adaptive is not None:
-        raise NotImplementedError("adaptive regularisation schedules are not supported on the device path")
     if solver is None:
         solver = Jacobi()
     if not isinstance(solver, Jacobi):
@@ -168,7 +170,17 @@ def split_bregman_tvd(
         st.set_coeffs(mu, omega, ell, img)
         st.upload(img, u0, d0, b0)
         show = (lambda it: verbose) if isinstance(verbose, bool) else (lambda it: verbose > 0 and it % verbose == 0)
-        if (verbose if isinstance(verbose, bool) else verbose > 0):
+        if adaptive is not None:
+            # the schedule is a host callable: one iteration per call, split variables kept explicit because
+            # the shrinkage threshold changes between the iteration that writes d, b and the one that reads them
+            for it in range(max_num_iter):
+                r = st.run(1, solver.maxiter, solver.tol, eps=0.0 if eps is None else eps, isotropic=isotropic,
+                           flags=_lib.FLAG_EXPLICIT)
+                if adaptive(it):
+                    st.adapt_ell()
+                if eps is not None and r.converged:
+                    break
+        elif (verbose if isinstance(verbose, bool) else verbose > 0):
             # verbose: one iteration per call so that increment and energy can be printed (debug path,
             # same messages as split_bregman_tvd.py:103-104,161-167)
             print(f"The energy functional starts at {st.energy()}")

@@ -50,6 +50,8 @@ extern "C" {
 #define DXH_FLAG_ISOTROPIC 1u /* split_bregman_tvd(isotropic=True), split_bregman_tvd.py:136-140 */
 #define DXH_FLAG_NO_FUSED 2u  /* force the three-kernel path (rhs / Jacobi sweep / shrink) */
 #define DXH_FLAG_NO_DPP 4u    /* fused kernel: use ds_bpermute lane exchange instead of DPP */
+#define DXH_FLAG_EXPLICIT 16u /* keep the split variables d, b as explicit planes (needed by dxh_tvd_adapt_ell);
+                                 the context stays in this mode */
 #define DXH_FLAG_ASYNC 8u     /* enqueue only: no event timing, no stream synchronisation (loop_ms = NaN);
                                  ignored when eps or jacobi_tol need host-side tests */
 
@@ -159,6 +161,10 @@ int dxh_tvd_pack_rows(dxh_tvd_t ctx, int64_t row0, int64_t nrows, void* dst_devi
 int dxh_tvd_unpack_rows(dxh_tvd_t ctx, int64_t row0, int64_t nrows, const void* src_device);
 /* sum over rows [row0, row0+nrows) of (u - u_prev)^2 of the last iteration and of img^2 (for a global eps test) */
 int dxh_tvd_partial_norms(dxh_tvd_t ctx, int64_t row0, int64_t nrows, double* sq_increment, double* sq_img);
+/* adaptive regularisation, split_bregman_tvd.py:149-158: ell <- 1 / max(|grad u|_1, 1e-12) per element for the rhs
+ * and the shrinkage threshold (the Jacobi diagonal keeps its value, as the reference's cached one does).
+ * Requires the context to be in explicit mode (run with DXH_FLAG_EXPLICIT). */
+int dxh_tvd_adapt_ell(dxh_tvd_t ctx);
 int dxh_tvd_sync(dxh_tvd_t ctx);
 /* energy functional of split_bregman_tvd.py:71-77 (verbose output) of the current (0) or previous (1) iterate */
 int dxh_tvd_energy(dxh_tvd_t ctx, int which, double* value);

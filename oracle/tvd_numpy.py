@@ -127,14 +127,17 @@ def _coefficients(omega, ell, dim, h, promotion, dtype):
 
 
 def jacobi(x0, rhs, mass_coeff, diffusion_coeff, dim=2, maxiter=1, tol=None, h=1.0,
-           promotion="numpy2"):
+           promotion="numpy2", coefficients=None):
     """``maxiter`` Jacobi sweeps for ``mass*x - diffusion*laplace(x) = rhs``.
 
     jacobi.py:74-133.  With ``tol`` the reference returns the iterate BEFORE
     the one that met the tolerance (quirk Q7); kept.
     """
-    diag, diag_scaled = _coefficients(mass_coeff, diffusion_coeff, dim, h, promotion,
-                                      np.asarray(x0).dtype)
+    if coefficients is None:
+        diag, diag_scaled = _coefficients(mass_coeff, diffusion_coeff, dim, h, promotion,
+                                          np.asarray(x0).dtype)
+    else:  # the reference's cached diagonal (quirk Q3): fixed at the solver's first call
+        diag, diag_scaled = coefficients
     rhs_scaled = np.divide(rhs, diag)
     x = x0
     if tol is None:
@@ -164,8 +167,13 @@ def split_bregman_tvd(
     jacobi_tol=None,
     promotion: str = "numpy2",
     return_state: bool = False,
+    adaptive=None,
 ):
     """split_bregman_tvd.py:14-177 with a fresh Jacobi solver.
+
+    ``adaptive(iteration) -> bool`` (split_bregman_tvd.py:149-158): when true, ``ell`` becomes the per-pixel
+    ``1 / max(|grad u|_1, 1e-12)``.  As in the reference, the Jacobi solver keeps the diagonal it cached at
+    its first call (quirk Q3); only the right-hand side and the shrinkage threshold follow the new ``ell``.
 
     ``x0 = (u0, [d_0..d_{dim-1}], [b_0..b_{dim-1}])`` uses PLANAR split
     variables (one array per axis).  With ``return_state`` the result is
@@ -192,12 +200,13 @@ def split_bregman_tvd(
         b = [np.array(a, dtype=dt) for a in b]
 
     done = 0
+    jac_coef = _coefficients(omega, ell, dim, 1.0, promotion, dt)  # cached by the reference's solver
     for it in range(max_num_iter):
         rhs = np.multiply(omega, img)
         for j in range(dim):
             rhs = rhs + forward_diff(ell * (b[j] - d[j]), j)
         u_new = jacobi(u, rhs, omega, ell, dim=dim, maxiter=jacobi_maxiter, tol=jacobi_tol,
-                       promotion=promotion)
+                       promotion=promotion, coefficients=jac_coef)
         if promotion == "strict":
             u_new = u_new.astype(dt, copy=False)
         q = mu / ell
@@ -216,6 +225,11 @@ def split_bregman_tvd(
                 dub = backward_diff(u_new, j) + b[j]
                 d[j] = shrink(dub, q).astype(dt)
                 b[j] = (dub - d[j]).astype(dt)
+        if adaptive is not None and adaptive(it):
+            l1 = np.zeros(img.shape, dt)
+            for j in range(dim):
+                l1 = l1 + np.abs(backward_diff(u_new, j).astype(dt))
+            ell = 1.0 / np.maximum(l1, 1e-12)
         rel = np.linalg.norm(u_new - u) / img_nrm
         u = u_new
         done = it + 1

@@ -190,6 +190,12 @@ def main():
     run("g7_eps_f32", img32, mu=0.1, max_num_iter=100, eps=1e-3, capture_iters=True)
     run("g7_eps_rgb_f32", rgb32, mu=0.1, max_num_iter=100, eps=2e-3, capture_iters=True)
 
+    # G14 adaptive regularisation (split_bregman_tvd.py:149-158); the Jacobi diagonal stays at its first
+    # value (quirk Q3) while rhs and shrinkage follow the per-pixel ell
+    run("g14_adaptive_f64", img64, mu=0.1, max_num_iter=9, adaptive=lambda it: it % 3 == 1)
+    run("g14_adaptive_f32", img32, mu=0.1, max_num_iter=9, adaptive=lambda it: it % 3 == 1)
+    run("g14_adaptive_rgb_f32", rgb32, mu=0.1, omega=0.9, max_num_iter=6, adaptive=lambda it: it >= 2)
+
     # G8 warm start: 5 iterations, then 5 more from the returned state
     for tag, im in (("f64", img64), ("f32", img32)):
         d = np.zeros((*im.shape, 2), dtype=im.dtype)

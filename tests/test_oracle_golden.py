@@ -50,6 +50,15 @@ def test_isotropic(golden):
     np.testing.assert_allclose(out, golden["g4_iso2d_f64/out"], rtol=1e-14, atol=0)
 
 
+@pytest.mark.parametrize("name,kw,sched", [
+    ("g14_adaptive_f64", dict(mu=0.1, max_num_iter=9), lambda it: it % 3 == 1),
+    ("g14_adaptive_f32", dict(mu=0.1, max_num_iter=9), lambda it: it % 3 == 1),
+    ("g14_adaptive_rgb_f32", dict(mu=0.1, omega=0.9, max_num_iter=6), lambda it: it >= 2),
+])
+def test_adaptive_regularisation(golden, name, kw, sched):
+    _eq(O.split_bregman_tvd(golden[name + "/img"], adaptive=sched, **kw), golden[name + "/out"])
+
+
 def test_heterogeneous_coefficients(golden):
     g = golden
     _eq(O.split_bregman_tvd(g["g5_het_mu_f64/img"], mu=g["g5_het_mu_f64/mu"], omega=0.1, max_num_iter=12),

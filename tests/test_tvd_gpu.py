@@ -347,3 +347,26 @@ def test_verbose_prints_increment_and_energy(golden, capsys):
     u2 = O.split_bregman_tvd(img, mu=0.1, max_num_iter=2, promotion="strict")
     e_last = float(text[-1].split()[-1])  # energy of the iterate BEFORE the third update
     assert abs(e_last - functional(u2)) <= 1e-5 * functional(u2)
+
+
+@pytest.mark.parametrize("name,kw,sched", [
+    ("g14_adaptive_f64", dict(mu=0.1, max_num_iter=9), lambda it: it % 3 == 1),
+    ("g14_adaptive_f32", dict(mu=0.1, max_num_iter=9), lambda it: it % 3 == 1),
+    ("g14_adaptive_rgb_f32", dict(mu=0.1, omega=0.9, max_num_iter=6), lambda it: it >= 2),
+])
+def test_adaptive_regularisation(golden, name, kw, sched):
+    """adaptive ell (split_bregman_tvd.py:149-158) incl. the reference's quirk that the Jacobi diagonal keeps
+    its first value: explicit (d, b) planes on the device, schedule evaluated on the host."""
+    img = golden[name + "/img"]
+    out = da.split_bregman_tvd(img, adaptive=sched, **kw)
+    assert_bits(out, O.split_bregman_tvd(img, adaptive=sched, promotion="strict", **kw))
+    if img.dtype == np.float64:
+        assert_bits(out, golden[name + "/out"])
+    else:
+        # ell = 1/|grad u| makes the iteration expansive (values grow to 1e7 on a [0, 1] image after 9
+        # iterations), so the reference's float64 promotion of u and a pure float32 flow decorrelate in a few
+        # elements; bit-exactness against the same-dtype oracle above is the parity statement, here only a
+        # robust closeness check against the reference's mixed flow
+        ref = golden[name + "/out"].astype(np.float64)
+        rel = np.abs(out - ref) / (np.abs(ref) + 1.0)
+        assert np.median(rel) < 1e-4 and np.mean(rel < 1e-2) > 0.98
