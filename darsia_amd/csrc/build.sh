@@ -1,11 +1,46 @@
 #!/bin/bash
 # Build libdarsia_hip.so for gfx950 in-tree (the .so is git-ignored but travels to the GPU box).
+# Objects are compiled in parallel (JOBS, default 8): the multi-iteration pipelines are one object per
+# (element type, K).  Extra arguments are passed to every compile (e.g. -DDXH_DEV_FAST, -DDXH_ENABLE_PAIR).
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="${HERE}/../libdarsia_hip.so"
+OBJ="${HERE}/_build"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+JOBS="${JOBS:-8}"
+mkdir -p "${OBJ}"
+rm -f "${OBJ}"/*.o "${OBJ}"/*.log
 # -ffp-contract=off: every operation rounds once, as in the NumPy evaluation the results are compared with
-"${HIPCC}" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off \
-    -Wall -Wno-unused-function \
-    "${HERE}/dxh_tvd.hip" "${HERE}/dxh_chambolle.hip" "${HERE}/dxh_dense.hip" -o "${OUT}" "$@"
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function "$@")
+
+pids=()
+names=()
+run() {  # run NAME SRC [extra flags]
+    local name="$1" src="$2"
+    shift 2
+    while [ "$(jobs -rp | wc -l)" -ge "${JOBS}" ]; do sleep 0.2; done
+    ( "${HIPCC}" "${FLAGS[@]}" "$@" -c "${HERE}/${src}" -o "${OBJ}/${name}.o" > "${OBJ}/${name}.log" 2>&1 ) &
+    pids+=($!)
+    names+=("${name}")
+}
+# heaviest first
+for k in 4 3 2; do
+    run "multi_f32_k${k}" dxh_multi.hip -DDXH_MULTI_T=float -DDXH_MULTI_K=${k}
+    run "multi_f64_k${k}" dxh_multi.hip -DDXH_MULTI_T=double -DDXH_MULTI_K=${k}
+done
+run tvd dxh_tvd.hip
+run chambolle dxh_chambolle.hip
+run dense dxh_dense.hip
+fail=0
+for i in "${!pids[@]}"; do
+    if ! wait "${pids[$i]}"; then
+        echo "compile of ${names[$i]} failed:" >&2
+        cat "${OBJ}/${names[$i]}.log" >&2
+        fail=1
+    elif [ -s "${OBJ}/${names[$i]}.log" ]; then
+        cat "${OBJ}/${names[$i]}.log" >&2   # warnings
+    fi
+done
+[ "${fail}" -eq 0 ] || exit 1
+"${HIPCC}" --offload-arch=gfx950 -shared -fPIC "${OBJ}"/*.o -o "${OUT}"
 echo "built ${OUT}"

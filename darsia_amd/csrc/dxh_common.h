@@ -68,6 +68,23 @@ __device__ __forceinline__ void store_vec(T* p, const T (&v)[VecOf<T>::N]) {
     *reinterpret_cast<V*>(p) = t;
 }
 
+// opaque (volatile) 16-byte accesses: LDS traffic the optimiser must not forward into registers
+template <typename T>
+__device__ __forceinline__ void load_vec_opaque(const T* p, T (&v)[VecOf<T>::N]) {
+    typedef T EV __attribute__((ext_vector_type(VecOf<T>::N)));
+    EV t = *reinterpret_cast<const volatile EV*>(p);
+#pragma unroll
+    for (int j = 0; j < VecOf<T>::N; ++j) v[j] = t[j];
+}
+template <typename T>
+__device__ __forceinline__ void store_vec_opaque(T* p, const T (&v)[VecOf<T>::N]) {
+    typedef T EV __attribute__((ext_vector_type(VecOf<T>::N)));
+    EV t;
+#pragma unroll
+    for (int j = 0; j < VecOf<T>::N; ++j) t[j] = v[j];
+    *reinterpret_cast<volatile EV*>(p) = t;
+}
+
 // streaming (non-temporal) 16-byte store: the written lines are not read again by this launch
 template <typename T>
 __device__ __forceinline__ void store_vec_nt(T* p, const T (&v)[VecOf<T>::N]) {

@@ -873,6 +873,8 @@ struct PipeState {
     T q0l[2][N];   // loaded level-0 q0 rows
     T of0[N];      // omega*f of stage 0's row
     T pf[2][4][N]; // prefetch distance 2: rows in flight two steps ahead (u, omega*f, q0, q1), slot = phase parity
+    T ofr[K][N];   // pair roles: omega*f delay line in registers (ofr[s] = row of local stage s)
+    T q1r[K][2][N];// pair roles: inter-stage Q1 hand-off in registers
 };
 
 // LDS rings of one wave (register relief, not communication: every lane reads back only what it wrote
@@ -884,11 +886,16 @@ struct PipeLds {
     static constexpr int SLOTS = 4 + 2 * (K - 1);
 };
 
+// step<PH, ROLE>: ROLE 0 = SOLO (one wave runs all K stages: HBM in, HBM out), 1 = HEAD (first K stages of a
+// wave pair: HBM in, the pair's shared LDS rings out), 2 = TAIL (last K stages of a pair: shared LDS rings in,
+// HBM out).
 template <typename T, int C, bool COUPLED, bool ISO, int K, bool NTS, bool EDGE, bool NORM>
 struct Pipe {
     static constexpr int N = VecOf<T>::N;
     static constexpr bool DPP = true;
-    static constexpr int PFD = K >= 4 ? 2 : 1;  // prefetch distance in steps
+    T* xlds;            // pair roles: this lane's vector in slot 0 of the pair's shared rings (U, Q0, Q1, of: 4 slots each)
+    __device__ __forceinline__ void xput(int slot, const T (&v)[N]) const { store_vec(xlds + slot * (kWave * N), v); }
+    __device__ __forceinline__ void xget(int slot, T (&v)[N]) const { load_vec(xlds + slot * (kWave * N), v); }
     const T* of_p;
     const T* u_in;
     const T* q0_in;
@@ -904,8 +911,13 @@ struct Pipe {
     uint32_t voff;      // this lane's byte offset inside a row: addresses are (uniform row base in SGPRs) + voff
     T* lds;             // this lane's vector in slot 0 of the wave's LDS rings; slot stride = kWave * N elements
 
+#ifdef DXH_LDS_OPAQUE
+    __device__ __forceinline__ void lds_put(int slot, const T (&v)[N]) const { store_vec_opaque(lds + slot * (kWave * N), v); }
+    __device__ __forceinline__ void lds_get(int slot, T (&v)[N]) const { load_vec_opaque(lds + slot * (kWave * N), v); }
+#else
     __device__ __forceinline__ void lds_put(int slot, const T (&v)[N]) const { store_vec(lds + slot * (kWave * N), v); }
     __device__ __forceinline__ void lds_get(int slot, T (&v)[N]) const { load_vec(lds + slot * (kWave * N), v); }
+#endif
 
     __device__ __forceinline__ int64_t clampr(int64_t r) const { return r < 0 ? 0 : (r > nrow - 1 ? nrow - 1 : r); }
     // row pointer (wave-uniform) + 32-bit lane offset -> global_load/store with an SGPR base
@@ -916,13 +928,27 @@ struct Pipe {
         return reinterpret_cast<T*>(reinterpret_cast<char*>(plane + row * P) + voff);
     }
 
-    template <int PH>
+    template <int PH, int ROLE = 0>
     __device__ __forceinline__ void step(PipeState<T, K>& st, float (&inc)[NORM ? K : 1][N], const int64_t r) const {
+        constexpr int PFD = (K >= 4 && ROLE == 0) ? 2 : 1;  // prefetch distance in steps
+        constexpr bool INTRA_LDS = ROLE == 0;               // of / q1 hand-off between own stages through LDS
         // prefetch the level-0 rows of a later step: distance 1 straight into their ring slots, distance 2
         // (K >= 4: a step is long, the registers are there at 2 waves/SIMD; +2.6 % measured) into staging
         // registers that are moved into the rings at the end of the next step, when the loads are two steps old
         T frn[N];
-        if constexpr (PFD == 1) {
+        if constexpr (ROLE == 2) {
+            // level-0 rows of THIS step come from the pair's shared rings (written by the head wave at
+            // least one barrier ago): U[row+1], Q0[row], Q1[row], omega*f[row]
+            xget(0 + ((PH + 1) & 3), st.U[0][(PH + 1) & 3]);
+            xget(4 + (PH & 3), st.q0l[PH & 1]);
+            xget(8 + (PH & 3), st.q1l[PH & 1]);
+            xget(12 + (PH & 3), st.of0);
+        } else if constexpr (ROLE == 1) {
+            // head wave: only u is fetched a full step ahead; the q / omega*f rows of the next step are
+            // loaded into the SAME registers right after stage 0 has consumed the current ones (register
+            // budget of 128 for 4 waves per SIMD; the other waves of the SIMD cover the shorter distance)
+            load_vec(at(u_in, clampr(r + 2)), st.U[0][(PH + 2) & 3]);
+        } else if constexpr (PFD == 1) {
             const int64_t rn = clampr(r + 1);
             load_vec(at(u_in, clampr(r + 2)), st.U[0][(PH + 2) & 3]);
             load_vec(at(of_p, rn), frn);
@@ -935,13 +961,25 @@ struct Pipe {
             load_vec(at(q0_in, rn), st.pf[PH & 1][2]);
             load_vec(at(q1_in, rn), st.pf[PH & 1][3]);
         }
-        if constexpr (K > 1) lds_put(PH & 3, st.of0);  // omega*f of row r for the later stages
+        if constexpr (INTRA_LDS) {
+            if constexpr (K > 1) lds_put(PH & 3, st.of0);  // omega*f of row r for the later stages
+        } else if constexpr (ROLE == 2) {
+            // delay line in registers: ofr[s] must hold row r - s
+#pragma unroll
+            for (int s = K - 1; s >= 1; --s)
+#pragma unroll
+                for (int j = 0; j < N; ++j) st.ofr[s][j] = st.ofr[s - 1][j];
+#pragma unroll
+            for (int j = 0; j < N; ++j) st.ofr[0][j] = st.of0[j];
+        }
+        if constexpr (ROLE == 1) xput(12 + (PH & 3), st.of0);  // forward omega*f[row r] to the tail wave
         T q0h[N];  // Q0 of the next level at the next stage's row, handed from stage to stage
         static_for<0, K>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             constexpr int c = (PH - s) & 3;          // ring slot of this stage's row
             constexpr int cm = (c + 3) & 3, cp = (c + 1) & 3;
             constexpr int cur = PH & 1, prv = cur ^ 1;
+            constexpr int lcur = (ROLE == 1) ? 0 : cur;  // slot of the loaded q rows (head: single buffer)
             const int64_t p = r - s;
             T(&um)[N] = st.U[s][cm];
             T(&uc)[N] = st.U[s][c];
@@ -954,22 +992,34 @@ struct Pipe {
             if constexpr (s == 0) {
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
-                    q1c[j] = st.q1l[cur][j];
+                    q1c[j] = st.q1l[lcur][j];
                     ofv[j] = st.of0[j];
                 }
-            } else {
+            } else if constexpr (INTRA_LDS) {
                 lds_get(4 + 2 * (s - 1) + cur, q1c);
                 lds_get(c, ofv);
+            } else {
+#pragma unroll
+                for (int j = 0; j < N; ++j) q1c[j] = st.q1r[s][cur][j];
+                if constexpr (ROLE == 1) {
+                    xget(12 + c, ofv);  // the head's own forward of row r - s, written s steps ago
+                } else {
+#pragma unroll
+                    for (int j = 0; j < N; ++j) ofv[j] = st.ofr[s][j];
+                }
             }
             // destination of the new iterate (level s+1, row p) and that level's previous row
             constexpr bool last = (s == K - 1);
-            T(&un)[N] = last ? st.U[K][cur] : st.U[s + 1][c];
-            const T(&unm)[N] = last ? st.U[K][prv] : st.U[s + 1][cm];
+            constexpr bool ring_out = last && ROLE == 1;  // head: level K lives in the pair's shared U ring only
+            T un_tmp[N], unm_tmp[N];
+            T(&un)[N] = ring_out ? un_tmp : (last ? st.U[K][cur] : st.U[s + 1][c]);
+            const T(&unm)[N] = ring_out ? unm_tmp : (last ? st.U[K][prv] : st.U[s + 1][cm]);
+            if constexpr (ring_out) xget(0 + cm, unm_tmp);  // written by this wave one step ago
 
             T b1c[N], t1c[N];
 #pragma unroll
             for (int j = 0; j < N; ++j) {
-                T qq[2] = {(s == 0) ? st.q0l[cur][j] : q0h[j], q1c[j]}, d[2], b[2];
+                T qq[2] = {(s == 0) ? st.q0l[lcur][j] : q0h[j], q1c[j]}, d[2], b[2];
                 split_vars<T, 2, ISO, true>(qq, kq, d, b);
                 b0c[j] = b[0];
                 b1c[j] = b[1];
@@ -1012,6 +1062,12 @@ struct Pipe {
                     acc[j] = acc[j] + (chLast[j] ? uc[j] : ucr[j]);
                 }
             }
+            if constexpr (ROLE == 1 && s == 0) {
+                const int64_t rn = clampr(r + 1);
+                load_vec(at(of_p, rn), st.of0);
+                load_vec(at(q0_in, rn), st.q0l[0]);
+                load_vec(at(q1_in, rn), st.q1l[0]);
+            }
             {
                 T lo = t_min(t_abs(rhs[0]), t_abs(acc[0]));
 #pragma unroll
@@ -1050,7 +1106,12 @@ struct Pipe {
                     q1o[j] = (unr[j] - un[j]) + b1c[j];
                 q0o[j] = (un[j] - unm[j]) + b0m[j];
             }
-            if constexpr (last) {
+            if constexpr (last && ROLE == 1) {
+                // hand level K over to the tail wave: U and Q1 of row p, Q0 of row p-1
+                xput(0 + c, un);
+                xput(8 + c, q1o);
+                xput(4 + cm, q0o);
+            } else if constexpr (last) {
                 if (store_lane) {
                     if (p >= R0 && p < R1) {
                         if constexpr (NTS) {
@@ -1069,11 +1130,19 @@ struct Pipe {
                     }
                 }
             } else {
-                lds_put(4 + 2 * s + prv, q1o);  // read by stage s+1 at the next step (its parity "cur")
+                if constexpr (INTRA_LDS) {
+                    lds_put(4 + 2 * s + prv, q1o);  // read by stage s+1 at the next step (its parity "cur")
+                } else {
+#pragma unroll
+                    for (int j = 0; j < N; ++j) st.q1r[s + 1][prv][j] = q1o[j];
+                }
 #pragma unroll
                 for (int j = 0; j < N; ++j) q0h[j] = q0o[j];
             }
         });
+        if constexpr (ROLE != 0) {
+            return;  // tail: the next step reads its rows from the shared rings; head: loaded in place above
+        }
         if constexpr (PFD == 2) {
 #pragma unroll
             for (int j = 0; j < N; ++j) {
@@ -1088,16 +1157,15 @@ struct Pipe {
     }
 };
 
-template <typename T, int C, bool COUPLED, bool ISO, int K, bool NTS, bool EDGE, bool NORM>
-__device__ __forceinline__ void fused_pipe_body(const FusedArgs<T>& a, const int strip, const int chunk, const int lane,
-                                                T* lds_lane) {
+// Fill the strip / chunk geometry and the plane pointers of a pipeline object.  KG = number of fused
+// iterations the strip halo is sized for (the pipeline's own K for a solo wave, the pair's total for a wave pair).
+template <int KG, typename T, int C, typename PipeT>
+__device__ __forceinline__ bool pipe_setup(PipeT& pp, const FusedArgs<T>& a, const int strip, const int chunk, const int lane) {
     constexpr int N = VecOf<T>::N;
-    using SG = StripGeomK<T, C, K>;
-    Pipe<T, C, COUPLED, ISO, K, NTS, EDGE, NORM> pp;
-    pp.lds = lds_lane;
+    using SG = StripGeomK<T, C, KG>;
     pp.R0 = (int64_t)chunk * a.rows_per_chunk;
     pp.R1 = (pp.R0 + a.rows_per_chunk < a.n0) ? pp.R0 + a.rows_per_chunk : a.n0;
-    if (pp.R0 >= a.n0) return;
+    if (pp.R0 >= a.n0) return false;
     const int64_t x0 = (int64_t)strip * SG::STRIDE + (int64_t)(lane - SG::LH) * N;
     int64_t xl = x0;
     if (xl < 0) xl = 0;
@@ -1129,8 +1197,12 @@ __device__ __forceinline__ void fused_pipe_body(const FusedArgs<T>& a, const int
     pp.kq = a.c.kq;
     pp.rdiag = a.c.rdiag;
     pp.rdsc = a.c.rdsc;
+    return true;
+}
 
-    PipeState<T, K> st;
+template <typename T, int K>
+__device__ __forceinline__ void pipe_state_zero(PipeState<T, K>& st) {
+    constexpr int N = VecOf<T>::N;
 #pragma unroll
     for (int l = 0; l <= K; ++l)
 #pragma unroll
@@ -1142,7 +1214,75 @@ __device__ __forceinline__ void fused_pipe_body(const FusedArgs<T>& a, const int
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < N; ++j) st.t0[l][i][j] = st.b0[l][i][j] = T(0);
+            for (int j = 0; j < N; ++j) st.t0[l][i][j] = st.b0[l][i][j] = st.q1r[l][i][j] = T(0);
+#pragma unroll
+    for (int l = 0; l < K; ++l)
+#pragma unroll
+        for (int j = 0; j < N; ++j) st.ofr[l][j] = T(0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) st.q0l[i][j] = st.q1l[i][j] = T(0);
+#pragma unroll
+    for (int j = 0; j < N; ++j) st.of0[j] = T(0);
+}
+
+// Prologue of a wave that reads level 0 from HBM (solo / head): phase 0 at row rs, rows rs-1, rs, rs+1 of u in
+// ring slots 3, 0, 1, the carried (t0, b0) of row rs-1 recomputed from the stored q.
+template <int PFD, bool ISO, typename T, int K, typename PipeT>
+__device__ __forceinline__ void pipe_prologue(const PipeT& pp, PipeState<T, K>& st, const int64_t rs) {
+    constexpr int N = VecOf<T>::N;
+    load_vec(pp.at(pp.u_in, pp.clampr(rs - 1)), st.U[0][3]);
+    load_vec(pp.at(pp.u_in, pp.clampr(rs)), st.U[0][0]);
+    load_vec(pp.at(pp.u_in, pp.clampr(rs + 1)), st.U[0][1]);
+    load_vec(pp.at(pp.of_p, pp.clampr(rs)), st.of0);
+    load_vec(pp.at(pp.q0_in, pp.clampr(rs)), st.q0l[0]);
+    load_vec(pp.at(pp.q1_in, pp.clampr(rs)), st.q1l[0]);
+    if constexpr (PFD == 2) {  // prefetch distance 2: rows consumed at the end of the first step
+        load_vec(pp.at(pp.u_in, pp.clampr(rs + 2)), st.pf[1][0]);
+        load_vec(pp.at(pp.of_p, pp.clampr(rs + 1)), st.pf[1][1]);
+        load_vec(pp.at(pp.q0_in, pp.clampr(rs + 1)), st.pf[1][2]);
+        load_vec(pp.at(pp.q1_in, pp.clampr(rs + 1)), st.pf[1][3]);
+    }
+    const int64_t rm = pp.clampr(rs - 1);
+    T q0v[N], q1v[N];
+    load_vec(pp.at(pp.q0_in, rm), q0v);
+    load_vec(pp.at(pp.q1_in, rm), q1v);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        T qq[2] = {q0v[j], q1v[j]}, d[2], b[2];
+        split_vars<T, 2, ISO, true>(qq, pp.kq, d, b);
+        st.t0[0][1][j] = pp.ell * (b[0] - d[0]);  // parity "prv" of phase 0
+        st.b0[0][1][j] = b[0];
+    }
+}
+
+template <int KLOC, int G0, typename T>
+__device__ __forceinline__ void pipe_write_partials(const FusedArgs<T>& a, float (&inc)[KLOC][VecOf<T>::N], const int wave_id,
+                                                    const int lane) {
+    constexpr int N = VecOf<T>::N;
+#pragma unroll
+    for (int s = 0; s < KLOC; ++s) {
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) v += (double)inc[s][j];
+#pragma unroll
+        for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+        if (lane == 0) a.inc_partial[(size_t)(G0 + s) * a.nwaves_total + wave_id] = v;
+    }
+}
+
+template <typename T, int C, bool COUPLED, bool ISO, int K, bool NTS, bool EDGE, bool NORM>
+__device__ __forceinline__ void fused_pipe_body(const FusedArgs<T>& a, const int strip, const int chunk, const int lane,
+                                                T* lds_lane) {
+    constexpr int N = VecOf<T>::N;
+    Pipe<T, C, COUPLED, ISO, K, NTS, EDGE, NORM> pp;
+    pp.lds = lds_lane;
+    pp.xlds = lds_lane;
+    if (!pipe_setup<K, T, C>(pp, a, strip, chunk, lane)) return;
+
+    PipeState<T, K> st;
+    pipe_state_zero(st);
     {
         // LDS rings start zeroed: the leading (discarded) rows must not see NaN bit patterns that would
         // trip the division screen for the whole wave
@@ -1152,35 +1292,8 @@ __device__ __forceinline__ void fused_pipe_body(const FusedArgs<T>& a, const int
 #pragma unroll
         for (int i = 0; i < PipeLds<K>::SLOTS; ++i) pp.lds_put(i, z);
     }
-
-    // prologue: phase 0 at row rs = R0 - (K-1): rows rs-1, rs, rs+1 of u in slots 3, 0, 1
     const int64_t rs = pp.R0 - (K - 1);
-    const int64_t P = pp.P;
-    load_vec(pp.at(pp.u_in, pp.clampr(rs - 1)), st.U[0][3]);
-    load_vec(pp.at(pp.u_in, pp.clampr(rs)), st.U[0][0]);
-    load_vec(pp.at(pp.u_in, pp.clampr(rs + 1)), st.U[0][1]);
-    load_vec(pp.at(pp.of_p, pp.clampr(rs)), st.of0);
-    load_vec(pp.at(pp.q0_in, pp.clampr(rs)), st.q0l[0]);
-    load_vec(pp.at(pp.q1_in, pp.clampr(rs)), st.q1l[0]);
-    if constexpr ((K >= 4 ? 2 : 1) == 2) {  // prefetch distance 2: rows consumed at the end of the first step
-        load_vec(pp.at(pp.u_in, pp.clampr(rs + 2)), st.pf[1][0]);
-        load_vec(pp.at(pp.of_p, pp.clampr(rs + 1)), st.pf[1][1]);
-        load_vec(pp.at(pp.q0_in, pp.clampr(rs + 1)), st.pf[1][2]);
-        load_vec(pp.at(pp.q1_in, pp.clampr(rs + 1)), st.pf[1][3]);
-    }
-    {
-        const int64_t rm = pp.clampr(rs - 1);
-        T q0v[N], q1v[N];
-        load_vec(pp.at(pp.q0_in, rm), q0v);
-        load_vec(pp.at(pp.q1_in, rm), q1v);
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            T qq[2] = {q0v[j], q1v[j]}, d[2], b[2];
-            split_vars<T, 2, ISO, true>(qq, pp.kq, d, b);
-            st.t0[0][1][j] = pp.ell * (b[0] - d[0]);  // parity "prv" of phase 0
-            st.b0[0][1][j] = b[0];
-        }
-    }
+    pipe_prologue<(K >= 4 ? 2 : 1), ISO>(pp, st, rs);
     // the last stage must reach row R1: steps rs .. R1 + K - 1, rounded up to whole groups of 4
     // (extra steps touch clamped rows only and store nothing)
     const int64_t r_end = pp.R1 + (K - 1);
@@ -1195,19 +1308,117 @@ __device__ __forceinline__ void fused_pipe_body(const FusedArgs<T>& a, const int
         pp.template step<2>(st, inc, r + 2);
         pp.template step<3>(st, inc, r + 3);
     }
+    if constexpr (NORM) pipe_write_partials<K, 0>(a, inc, chunk * a.nstrips + strip, lane);
+}
+
+#ifdef DXH_ENABLE_PAIR
+// --------------------------------------------------------------------------------------------------
+// EXPERIMENT, compiled only with -DDXH_ENABLE_PAIR (bit-exact, not faster; measured notes in DESIGN.md).
+// Wave-pair variant of the K = 4 pipeline.  A solo wave that runs four stages needs ~200 VGPRs, i.e. two
+// waves per SIMD, and the kernel is bound by VALU issue at that occupancy.  Here a strip is owned by a PAIR of
+// waves: the head wave runs global stages 0-1 (HBM loads in, level-2 rows out to LDS), the tail wave runs stages
+// 2-3 (LDS in, HBM stores out) three row-steps behind the head.  The pair's shared rings (U, Q0, Q1, omega*f)
+// have 4 slots each, slot = (row - rs) & 3.  At iteration t the head writes U[t-1], Q1[t-1], Q0[t-2], of[t]
+// (rows relative to rs) and the tail reads U[t-2], Q0[t-3], Q1[t-3], of[t-3]: always different slots inside
+// one iteration, and every slot is read one to three barriers after it was written and overwritten at the
+// earliest one barrier after it was read.  One __syncthreads() per iteration, the same trip count for every
+// wave of the block (the count depends on the chunk only, and all waves of a block share the chunk).
+// --------------------------------------------------------------------------------------------------
+#ifndef DXH_PAIR_LB
+#define DXH_PAIR_LB 4
+#endif
+constexpr int kPairSlots = 16;  // U 0-3, Q0 4-7, Q1 8-11, omega*f 12-15
+constexpr int kPairLag = 3;
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for vmcnt(0), which would drain
+// the head wave's prefetched HBM loads and the tail wave's stores at every row step.  The rings live in LDS, so
+// lgkmcnt(0) before the barrier is all the hand-over needs.
+__device__ __forceinline__ void pair_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <typename T, int C, bool COUPLED, bool ISO, bool NTS, bool EDGE, bool NORM>
+__device__ __forceinline__ void fused_pair_body(const FusedArgs<T>& a, const int strip, const int chunk, const int lane,
+                                                const bool tail, const bool active, T* xlds_lane) {
+    constexpr int N = VecOf<T>::N;
+    constexpr int KH = 2, KT = 4;
+    Pipe<T, C, COUPLED, ISO, KH, NTS, EDGE, NORM> pp;
+    pp.lds = xlds_lane;
+    pp.xlds = xlds_lane;
+    // an inactive pair (strip past the end in the last block) runs the same barriers on a clamped strip and
+    // stores nothing
+    const bool ok = pipe_setup<KT, T, C>(pp, a, strip, chunk, lane);
+    if (!ok) return;  // chunk past the end: uniform over the block
+    if (!active) pp.store_lane = false;
+    PipeState<T, KH> st;
+    pipe_state_zero(st);
+    const int64_t rs = pp.R0 - (KT - 1);
+    if (!tail) {
+        T z[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) z[j] = T(0);
+#pragma unroll
+        for (int i = 0; i < kPairSlots; ++i) pp.xput(i, z);
+        pipe_prologue<1, ISO>(pp, st, rs);
+    }
+    __syncthreads();
+    float inc[NORM ? KH : 1][N];
+#pragma unroll
+    for (int s = 0; s < (NORM ? KH : 1); ++s)
+#pragma unroll
+        for (int j = 0; j < N; ++j) inc[s][j] = 0.f;
+    // head steps rs .. R1 + KT - 1, tail steps rs .. R1 + 1 at a lag of kPairLag iterations
+    const int64_t r_end = pp.R1 + (KT - KH - 1) + kPairLag;
+    for (int64_t r = rs; r <= r_end; r += 4) {
+        if (!tail) pp.template step<0, 1>(st, inc, r); else pp.template step<1, 2>(st, inc, r - kPairLag);
+        pair_barrier();
+        if (!tail) pp.template step<1, 1>(st, inc, r + 1); else pp.template step<2, 2>(st, inc, r + 1 - kPairLag);
+        pair_barrier();
+        if (!tail) pp.template step<2, 1>(st, inc, r + 2); else pp.template step<3, 2>(st, inc, r + 2 - kPairLag);
+        pair_barrier();
+        if (!tail) pp.template step<3, 1>(st, inc, r + 3); else pp.template step<0, 2>(st, inc, r + 3 - kPairLag);
+        pair_barrier();
+    }
     if constexpr (NORM) {
-        const int wave_id = chunk * a.nstrips + strip;  // < nchunks * nstrips <= nwaves_total
-#pragma unroll
-        for (int s = 0; s < K; ++s) {
-            double v = 0.0;
-#pragma unroll
-            for (int j = 0; j < N; ++j) v += (double)inc[s][j];
-#pragma unroll
-            for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
-            if (lane == 0) a.inc_partial[(size_t)s * a.nwaves_total + wave_id] = v;
+        if (active) {
+            const int wave_id = chunk * a.nstrips + strip;
+            if (!tail)
+                pipe_write_partials<KH, 0>(a, inc, wave_id, lane);
+            else
+                pipe_write_partials<KH, KH>(a, inc, wave_id, lane);
         }
     }
 }
+
+template <typename T, int C, bool COUPLED, bool ISO, bool NORM = false, bool NTS = true>
+__global__ void __launch_bounds__(256, DXH_PAIR_LB) k_fused_pair(FusedArgs<T> a) {
+    constexpr int N = VecOf<T>::N;
+    using SG = StripGeomK<T, C, 4>;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    constexpr int PPB = 2;  // pairs (strips) per block
+    const int pair = wave >> 1;
+    // waves land on SIMD (wave & 3): alternate the roles from block to block so that every SIMD hosts heads
+    // (HBM loads) and tails (HBM stores) alike
+    const bool tail = ((wave ^ (int)blockIdx.x) & 1) != 0;
+    const int nbx = (a.nstrips + PPB - 1) / PPB;
+    int bx, chunk;
+    block_to_tile((int)blockIdx.x, nbx, a.nchunks, bx, chunk);
+    if (chunk >= a.nchunks) return;  // block-uniform
+    int strip = bx * PPB + pair;
+    const bool active = strip < a.nstrips;
+    if (!active) strip = a.nstrips - 1;
+    // border handling is chosen per BLOCK so that every wave of the block meets the same barriers
+    const int64_t wlo = (int64_t)(bx * PPB) * SG::STRIDE - SG::LH * N;
+    const int last_strip = (bx * PPB + PPB - 1 < a.nstrips) ? bx * PPB + PPB - 1 : a.nstrips - 1;
+    const int64_t whi = (int64_t)last_strip * SG::STRIDE - SG::LH * N + kWave * N;
+    const bool edge = (wlo < C) || (whi > a.L - C);
+    __shared__ typename VecOf<T>::type pair_rings[PPB * kPairSlots * kWave];
+    T* xl = reinterpret_cast<T*>(pair_rings + (size_t)pair * kPairSlots * kWave + lane);
+    if (edge)
+        fused_pair_body<T, C, COUPLED, ISO, NTS, true, NORM>(a, strip, chunk, lane, tail, active, xl);
+    else
+        fused_pair_body<T, C, COUPLED, ISO, NTS, false, NORM>(a, strip, chunk, lane, tail, active, xl);
+}
+#endif  // DXH_ENABLE_PAIR
 
 template <typename T, int C, bool COUPLED, bool ISO, int K, bool NORM = false, bool NTS = true>
 __global__ void __launch_bounds__(256, (K >= 3 ? DXH_LB4 : 3)) k_fused_multi(FusedArgs<T> a) {

@@ -1,0 +1,24 @@
+// Launch entry of the K-iterations-per-launch pipelines (k_fused_multi).  The kernels are heavy to compile
+// (4 x unrolled, up to 4 stages), so each (element type, K) pair is instantiated in its own object file
+// (dxh_multi.hip, compiled with -DDXH_MULTI_T / -DDXH_MULTI_K by build.sh) and the objects build in parallel.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace dxh {
+
+template <typename T>
+struct FusedArgs;
+
+// C in {1, 3}; `pair` selects the experimental wave-pair kernel (only with -DDXH_ENABLE_PAIR, float, K = 4)
+template <typename T, int K>
+void launch_multi_kernel(int C, bool coupled, bool iso, bool want_inc, bool pair, const FusedArgs<T>& a, unsigned grid,
+                         hipStream_t stream);
+
+extern template void launch_multi_kernel<float, 2>(int, bool, bool, bool, bool, const FusedArgs<float>&, unsigned, hipStream_t);
+extern template void launch_multi_kernel<float, 3>(int, bool, bool, bool, bool, const FusedArgs<float>&, unsigned, hipStream_t);
+extern template void launch_multi_kernel<float, 4>(int, bool, bool, bool, bool, const FusedArgs<float>&, unsigned, hipStream_t);
+extern template void launch_multi_kernel<double, 2>(int, bool, bool, bool, bool, const FusedArgs<double>&, unsigned, hipStream_t);
+extern template void launch_multi_kernel<double, 3>(int, bool, bool, bool, bool, const FusedArgs<double>&, unsigned, hipStream_t);
+extern template void launch_multi_kernel<double, 4>(int, bool, bool, bool, bool, const FusedArgs<double>&, unsigned, hipStream_t);
+
+}  // namespace dxh

@@ -1,0 +1,64 @@
+// One object per (DXH_MULTI_T, DXH_MULTI_K): instantiates k_fused_multi<T, C, COUPLED, ISO, K, NORM> for
+// C in {1, 3} and defines the launch switch declared in dxh_multi.h.  gfx950 only.
+#include <type_traits>
+
+#include "dxh_kernels.h"
+#include "dxh_multi.h"
+
+#ifndef DXH_MULTI_T
+#error "compile with -DDXH_MULTI_T=float|double -DDXH_MULTI_K=2|3|4 (see build.sh)"
+#endif
+
+namespace dxh {
+
+namespace {
+
+template <typename T, int C, bool COUPLED, bool ISO, int K>
+void launch_one(bool want_inc, bool pair, const FusedArgs<T>& a, unsigned grid, hipStream_t stream) {
+#ifdef DXH_ENABLE_PAIR
+    if constexpr (K == 4 && std::is_same<T, float>::value) {
+        if (pair) {
+            if (want_inc)
+                hipLaunchKernelGGL((k_fused_pair<T, C, COUPLED, ISO, true>), dim3(grid), dim3(256), 0, stream, a);
+            else
+                hipLaunchKernelGGL((k_fused_pair<T, C, COUPLED, ISO, false>), dim3(grid), dim3(256), 0, stream, a);
+            return;
+        }
+    }
+#endif
+    (void)pair;
+    if (want_inc)
+        hipLaunchKernelGGL((k_fused_multi<T, C, COUPLED, ISO, K, true>), dim3(grid), dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL((k_fused_multi<T, C, COUPLED, ISO, K, false>), dim3(grid), dim3(256), 0, stream, a);
+}
+
+template <typename T, int C, int K>
+void launch_c(bool coupled, bool iso, bool want_inc, bool pair, const FusedArgs<T>& a, unsigned grid, hipStream_t stream) {
+#ifdef DXH_DEV_FAST  // developer builds: one instantiation only (coupled, anisotropic)
+    (void)coupled; (void)iso;
+    launch_one<T, C, true, false, K>(want_inc, pair, a, grid, stream);
+#else
+    if (coupled) {
+        if (iso) launch_one<T, C, true, true, K>(want_inc, pair, a, grid, stream);
+        else launch_one<T, C, true, false, K>(want_inc, pair, a, grid, stream);
+    } else {
+        if (iso) launch_one<T, C, false, true, K>(want_inc, pair, a, grid, stream);
+        else launch_one<T, C, false, false, K>(want_inc, pair, a, grid, stream);
+    }
+#endif
+}
+
+}  // namespace
+
+template <typename T, int K>
+void launch_multi_kernel(int C, bool coupled, bool iso, bool want_inc, bool pair, const FusedArgs<T>& a, unsigned grid,
+                         hipStream_t stream) {
+    if (C == 1) launch_c<T, 1, K>(coupled, iso, want_inc, pair, a, grid, stream);
+    else launch_c<T, 3, K>(coupled, iso, want_inc, pair, a, grid, stream);
+}
+
+template void launch_multi_kernel<DXH_MULTI_T, DXH_MULTI_K>(int, bool, bool, bool, bool, const FusedArgs<DXH_MULTI_T>&, unsigned,
+                                                            hipStream_t);
+
+}  // namespace dxh

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "dxh_kernels.h"
+#include "dxh_multi.h"
 
 namespace dxh {
 
@@ -210,7 +211,13 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
     a.L = c->g.L;
     a.pitch = c->g.pitch;
     a.nstrips = (int)((c->g.L + SG::STRIDE - 1) / SG::STRIDE);
-    const int nbx = (a.nstrips + 3) / 4;
+    // wave-pair variant (K = 4): a block of 4 waves covers 2 strips
+#ifdef DXH_ENABLE_PAIR
+    const bool pair = K == 4 && std::is_same<T, float>::value && (c->tune & 16);
+#else
+    const bool pair = false;
+#endif
+    const int nbx = pair ? (a.nstrips + 1) / 2 : (a.nstrips + 3) / 4;
     const int64_t target_blocks = (int64_t)c->num_cu * (c->waves_per_cu ? c->waves_per_cu : 16) / 4;
     int64_t nchunks = std::max<int64_t>(1, target_blocks / nbx);
     if (nchunks >= 8) nchunks = nchunks / 8 * 8;
@@ -235,10 +242,8 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
     }
     a.c = make_coef<T>(c);
     a.cp = make_planes<T>(c);
-    if (want_inc)
-        hipLaunchKernelGGL((k_fused_multi<T, C, COUPLED, ISO, K, true>), dim3((unsigned)(nbx * nchunks)), dim3(256), 0, c->stream, a);
-    else
-        hipLaunchKernelGGL((k_fused_multi<T, C, COUPLED, ISO, K, false>), dim3((unsigned)(nbx * nchunks)), dim3(256), 0, c->stream, a);
+    // the kernels are instantiated in dxh_multi.hip (one object per element type and K, built in parallel)
+    launch_multi_kernel<T, K>(C, COUPLED, ISO, want_inc, pair, a, (unsigned)(nbx * nchunks), c->stream);
 }
 
 // channel counts the multi-iteration kernel is instantiated for
