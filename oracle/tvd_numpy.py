@@ -168,8 +168,11 @@ def split_bregman_tvd(
     promotion: str = "numpy2",
     return_state: bool = False,
     adaptive=None,
+    solver=None,
 ):
-    """split_bregman_tvd.py:14-177 with a fresh Jacobi solver.
+    """split_bregman_tvd.py:14-177 with a fresh Jacobi solver, or with ``solver`` (an object with
+    ``update_params(mass_coeff=, diffusion_coeff=, dim=)`` and ``__call__(x0, rhs)``, e.g.
+    oracle.solvers_numpy.MG / CG) in the place of the Jacobi sweeps (split_bregman_tvd.py:63-67,133).
 
     ``adaptive(iteration) -> bool`` (split_bregman_tvd.py:149-158): when true, ``ell`` becomes the per-pixel
     ``1 / max(|grad u|_1, 1e-12)``.  As in the reference, the Jacobi solver keeps the diagonal it cached at
@@ -201,12 +204,17 @@ def split_bregman_tvd(
 
     done = 0
     jac_coef = _coefficients(omega, ell, dim, 1.0, promotion, dt)  # cached by the reference's solver
+    if solver is not None:
+        solver.update_params(mass_coeff=omega, diffusion_coeff=ell, dim=dim)
     for it in range(max_num_iter):
         rhs = np.multiply(omega, img)
         for j in range(dim):
             rhs = rhs + forward_diff(ell * (b[j] - d[j]), j)
-        u_new = jacobi(u, rhs, omega, ell, dim=dim, maxiter=jacobi_maxiter, tol=jacobi_tol,
-                       promotion=promotion, coefficients=jac_coef)
+        if solver is not None:
+            u_new = solver(u, rhs)
+        else:
+            u_new = jacobi(u, rhs, omega, ell, dim=dim, maxiter=jacobi_maxiter, tol=jacobi_tol,
+                           promotion=promotion, coefficients=jac_coef)
         if promotion == "strict":
             u_new = u_new.astype(dt, copy=False)
         q = mu / ell
