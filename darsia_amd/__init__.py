@@ -16,6 +16,8 @@ from .utils.dtype import convert_dtype  # noqa: F401
 from .utils.derivatives import backward_diff, forward_diff, laplace  # noqa: F401
 from .utils.linear_solvers.solver import Solver  # noqa: F401
 from .utils.linear_solvers.jacobi import Jacobi  # noqa: F401
+from .utils.linear_solvers.mg import MG  # noqa: F401
+from .utils.linear_solvers.cg import CG  # noqa: F401
 from .restoration.split_bregman_tvd import DeviceTVD, split_bregman_tvd  # noqa: F401
 from .restoration.h1_regularization import H1_regularization  # noqa: F401
 from .restoration.chambolle import denoise_tv_chambolle  # noqa: F401

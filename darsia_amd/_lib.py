@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("DARSIA_HIP_LIB") or os.path.join(_HERE, "libdarsia_hi
 DXH_F32, DXH_F64 = 0, 1
 NSUM_ALL_AXES, NSUM_SPATIAL = 0, 1
 FLAG_ISOTROPIC, FLAG_NO_FUSED, FLAG_NO_DPP, FLAG_ASYNC, FLAG_EXPLICIT = 1, 2, 4, 8, 16
+SOLVER_JACOBI, SOLVER_MG, SOLVER_CG = 0, 1, 2
 
 # every symbol include/darsia_hip.h declares (tests check that the library exports them all)
 EXPORTS = (
@@ -26,6 +27,8 @@ EXPORTS = (
     "dxh_tvd_download", "dxh_tvd_halo_bytes", "dxh_tvd_pack_rows", "dxh_tvd_unpack_rows",
     "dxh_tvd_partial_norms", "dxh_tvd_sync", "dxh_jacobi_solve", "dxh_diff", "dxh_chambolle",
     "dxh_warp_patches", "dxh_tps_eval", "dxh_affine_color",
+    "dxh_solver_create", "dxh_solver_destroy", "dxh_solver_set_params", "dxh_solver_solve", "dxh_solver_get_params",
+    "dxh_tvd_set_solver",
     "dxh_tvd_energy", "dxh_tvd_adapt_ell", "dxh_tvd_set_base", "dxh_tvd_set_cleaning_filter", "dxh_tvd_upload_signal", "dxh_tvd_download_model",
 )
 
@@ -41,6 +44,17 @@ class TvdDesc(C.Structure):
         ("n0", C.c_int64), ("n1", C.c_int64), ("n2", C.c_int64),
         ("top_is_boundary", C.c_int32), ("bottom_is_boundary", C.c_int32),
         ("stream", C.c_void_p),
+    ]
+
+
+class SolverDesc(C.Structure):
+    """dxh_solver_desc (include/darsia_hip.h)."""
+    _fields_ = [
+        ("struct_size", C.c_int32), ("device", C.c_int32), ("dtype", C.c_int32), ("dim", C.c_int32),
+        ("n0", C.c_int64), ("n1", C.c_int64), ("n2", C.c_int64),
+        ("kind", C.c_int32), ("depth", C.c_int32), ("smoother_iterations", C.c_int32), ("maxiter", C.c_int32),
+        ("heterogeneous", C.c_int32), ("reserved", C.c_int32),
+        ("tol", C.c_double), ("h", C.c_double), ("stream", C.c_void_p),
     ]
 
 
@@ -87,6 +101,12 @@ def _declare(lib):
     lib.dxh_tvd_partial_norms.argtypes = [vp, i64, i64, C.POINTER(dbl), C.POINTER(dbl)]
     lib.dxh_tvd_sync.argtypes = [vp]
     lib.dxh_tvd_energy.argtypes = [vp, i, C.POINTER(dbl)]
+    lib.dxh_solver_create.argtypes = [C.POINTER(vp), C.POINTER(SolverDesc)]
+    lib.dxh_solver_destroy.argtypes = [vp]
+    lib.dxh_solver_set_params.argtypes = [vp, dbl, vp, dbl, vp]
+    lib.dxh_solver_solve.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_int32)]
+    lib.dxh_solver_get_params.argtypes = [vp, vp, vp]
+    lib.dxh_tvd_set_solver.argtypes = [vp, i, i, i, i, dbl]
     lib.dxh_tvd_adapt_ell.argtypes = [vp]
     lib.dxh_jacobi_solve.argtypes = [i, i, i, i, i, i64, i64, i64, vp, vp, vp, dbl, vp, dbl, vp, dbl, i, dbl,
                                      C.POINTER(i)]

@@ -31,6 +31,7 @@ done
 run tvd dxh_tvd.hip
 run chambolle dxh_chambolle.hip
 run dense dxh_dense.hip
+run solvers dxh_solvers.hip
 fail=0
 for i in "${!pids[@]}"; do
     if ! wait "${pids[$i]}"; then

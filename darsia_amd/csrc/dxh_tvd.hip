@@ -11,6 +11,7 @@
 
 #include "dxh_kernels.h"
 #include "dxh_multi.h"
+#include "dxh_solvers.h"
 
 namespace dxh {
 
@@ -72,6 +73,9 @@ struct Ctx {
     double c_ell = 0, c_diag = 0, c_dsc = 0, c_kq = 0;
     double sq_img = -1.0;          // sum img^2 over this slab
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    DeviceSolver* solver = nullptr;  // MG / CG in the place of the Jacobi sweeps (dxh_tvd_set_solver)
+    int solver_kind = DXH_SOLVER_JACOBI;
+    bool solver_params_set = false;
 };
 
 static int alloc_plane(Ctx* c, void** p) {
@@ -337,6 +341,10 @@ static void launch_rhs(Ctx* c, bool iso, bool from_db) {
     auto db = make_db<T>(c);
     auto co = make_coef<T>(c);
     auto cp = make_planes<T>(c);
+    if (c->solver) {  // MG / CG take the right-hand side itself, not rhs / diag: divide by exactly 1
+        co.diag = T(1);
+        cp.diag = nullptr;
+    }
     if (from_db)
         hipLaunchKernelGGL((k_rhs<T, DIM, false, true>), grid, blk, 0, c->stream, c->g, (const T*)c->of, q, db, co, cp, (T*)c->rs);
     else if (iso)
@@ -402,6 +410,16 @@ static int jacobi_sweeps(Ctx* c, int maxiter, double tol, void* tmp, int64_t* la
     return DXH_OK;
 }
 
+// the u-update of one outer iteration: Jacobi sweeps, or the plugged-in solver on (u[cur], rhs) -> u[cur ^ 1]
+template <typename T>
+static int solve_u(Ctx* c, int jacobi_maxiter, double jacobi_tol, void* tmp, int64_t* launches) {
+    if (!c->solver) return jacobi_sweeps<T>(c, jacobi_maxiter, jacobi_tol, tmp, launches, nullptr);
+    const int64_t before = c->solver->launches;
+    int rc = c->solver->solve(c->u[c->cur], c->rs, c->u[c->cur ^ 1], nullptr);
+    *launches += c->solver->launches - before;
+    return rc;
+}
+
 template <typename T>
 static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, double eps, double norm_scale,
                  uint32_t flags, dxh_tvd_result* res) {
@@ -409,8 +427,16 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
     const bool use_eps = eps >= 0.0 && !std::isnan(eps);
     const bool use_tol = jacobi_tol >= 0.0 && !std::isnan(jacobi_tol);
     const bool dpp = !(flags & DXH_FLAG_NO_DPP);
-    bool fused_ok = fused_supported(c) && jacobi_maxiter == 1 && !use_tol && !(flags & DXH_FLAG_NO_FUSED);
+    bool fused_ok = fused_supported(c) && jacobi_maxiter == 1 && !use_tol && !(flags & DXH_FLAG_NO_FUSED) && !c->solver;
     const int dim = c->desc.dim;
+    if (c->solver) {
+        // Solver.update_params(mass_coeff=omega, diffusion_coeff=ell) (split_bregman_tvd.py:63-67, 154-158)
+        if (c->solver_kind == DXH_SOLVER_MG)
+            DXH_REQUIRE(!c->het, "MG inside the TV loop needs scalar omega / ell (the reference's MG() is not heterogeneous and "
+                                 "fails to broadcast array coefficients on its coarse levels)");
+        int rc = c->solver->set_params(c->omega_s, c->het ? c->om_plane : nullptr, c->ell_s, c->het ? c->cp_ell : nullptr);
+        if (rc) return rc;
+    }
     c->last_iso_prev = c->last_iso;
     c->last_iso = iso;
 
@@ -519,7 +545,7 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
             // rhs from explicit planes, Jacobi, shrink back into the planes
             if (dim == 2) launch_rhs<T, 2>(c, iso, true); else launch_rhs<T, 3>(c, iso, true);
             ++launches;
-            int rc = jacobi_sweeps<T>(c, jacobi_maxiter, jacobi_tol, tmp, &launches, nullptr);
+            int rc = solve_u<T>(c, jacobi_maxiter, jacobi_tol, tmp, &launches);
             if (rc) { if (tmp) (void)hipFree(tmp); return rc; }
             {
                 const dim3 grid = elem_grid(c->g), blk(256);
@@ -537,7 +563,7 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
             const bool fdb = c->from_db;
             if (dim == 2) launch_rhs<T, 2>(c, iso, fdb); else launch_rhs<T, 3>(c, iso, fdb);
             ++launches;
-            int rc = jacobi_sweeps<T>(c, jacobi_maxiter, jacobi_tol, tmp, &launches, nullptr);
+            int rc = solve_u<T>(c, jacobi_maxiter, jacobi_tol, tmp, &launches);
             if (rc) { if (tmp) (void)hipFree(tmp); return rc; }
             if (dim == 2) launch_shrink<T, 2>(c, c->u[out], iso, fdb); else launch_shrink<T, 3>(c, c->u[out], iso, fdb);
             ++launches;
@@ -717,6 +743,7 @@ int dxh_tvd_destroy(dxh_tvd_t h) {
     if (!c) return DXH_OK;
     (void)hipSetDevice(c->desc.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    delete c->solver;
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
     fr(c->of); fr(c->u[0]); fr(c->u[1]); fr(c->rs);
     for (int j = 0; j < 3; ++j) { fr(c->q[j][0]); fr(c->q[j][1]); fr(c->dpl[j]); fr(c->bpl[j]); }
@@ -725,6 +752,28 @@ int dxh_tvd_destroy(dxh_tvd_t h) {
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+    return DXH_OK;
+}
+
+int dxh_tvd_set_solver(dxh_tvd_t h, int kind, int depth, int smoother_iterations, int maxiter, double tol) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    DXH_REQUIRE(c, "null context");
+    DXH_REQUIRE(kind == DXH_SOLVER_JACOBI || kind == DXH_SOLVER_MG || kind == DXH_SOLVER_CG, "unknown solver kind %d", kind);
+    int rc = set_device(c);
+    if (rc) return rc;
+    DXH_HIP(hipStreamSynchronize(c->stream));
+    delete c->solver;
+    c->solver = nullptr;
+    c->solver_kind = DXH_SOLVER_JACOBI;
+    if (kind == DXH_SOLVER_JACOBI) return DXH_OK;
+    Geom g = c->g;
+    g.nsum_axes = g.ndim;  // the smoother sums over every array axis (jacobi.py:41)
+    if (kind == DXH_SOLVER_MG)
+        c->solver = make_mg_solver(c->desc.dtype, g, depth, smoother_iterations, maxiter, tol, false, c->stream, &rc);
+    else
+        c->solver = make_cg_solver(c->desc.dtype, g, maxiter, tol, -1.0, c->stream, &rc);
+    if (!c->solver) return rc ? rc : DXH_EHIP;
+    c->solver_kind = kind;
     return DXH_OK;
 }
 

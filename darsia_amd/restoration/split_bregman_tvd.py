@@ -25,7 +25,9 @@ from typing import Optional, Union
 import numpy as np
 
 from .. import _lib
+from ..utils.linear_solvers.cg import CG
 from ..utils.linear_solvers.jacobi import Jacobi
+from ..utils.linear_solvers.mg import MG
 from ..utils.linear_solvers.solver import Solver
 
 
@@ -103,6 +105,19 @@ class DeviceTVD:
                                         -1.0 if eps is None else float(eps), float(norm_scale), flags, C.byref(res)))
         return res
 
+    def set_solver(self, solver) -> None:
+        """Use ``solver`` (Jacobi / MG / CG object) for the u-update (split_bregman_tvd.py:25,133)."""
+        if isinstance(solver, MG):
+            args = (_lib.SOLVER_MG, solver.depth, solver.smoother_iterations, solver.maxiter,
+                    -1.0 if solver.tol is None else float(solver.tol))
+        elif isinstance(solver, CG):
+            if solver.tol is None:
+                raise TypeError("CG needs a tolerance (scipy.sparse.linalg.cg(tol=None) fails in the reference as well)")
+            args = (_lib.SOLVER_CG, 0, 0, solver.maxiter, float(solver.tol))
+        else:
+            args = (_lib.SOLVER_JACOBI, 0, 0, 0, -1.0)
+        _lib.check(self.lib.dxh_tvd_set_solver(self._h, *args))
+
     def adapt_ell(self) -> None:
         """ell <- 1 / max(|grad u|_1, 1e-12) per element (split_bregman_tvd.py:149-158); explicit mode only."""
         _lib.check(self.lib.dxh_tvd_adapt_ell(self._h))
@@ -154,8 +169,11 @@ def split_bregman_tvd(
                         "reference's split variables, SURVEY.md quirk Q5)")
     if solver is None:
         solver = Jacobi()
-    if not isinstance(solver, Jacobi):
-        raise NotImplementedError("only darsia_amd.Jacobi is available as inner solver on the device path")
+    if not isinstance(solver, (Jacobi, MG, CG)):
+        raise NotImplementedError("inner solvers on the device path: darsia_amd.Jacobi, darsia_amd.MG, darsia_amd.CG")
+    if isinstance(solver, MG) and solver.heterogeneous:
+        raise ValueError("an MG solver constructed with coefficient arrays cannot be re-parametrised by the TV loop "
+                         "(the reference's broadcasting fails on its coarse levels as well)")
     # the reference feeds the solver (split_bregman_tvd.py:62-68); kept for callers that inspect it
     solver.update_params(mass_coeff=omega, diffusion_coeff=(2 * mu if ell is None else ell), dim=dim)
 
@@ -168,6 +186,8 @@ def split_bregman_tvd(
 
     with DeviceTVD(img.shape, img.dtype, dim=dim) as st:
         st.set_coeffs(mu, omega, ell, img)
+        if not isinstance(solver, Jacobi):
+            st.set_solver(solver)
         st.upload(img, u0, d0, b0)
         show = (lambda it: verbose) if isinstance(verbose, bool) else (lambda it: verbose > 0 and it % verbose == 0)
         if adaptive is not None:

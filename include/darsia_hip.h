@@ -182,6 +182,54 @@ int dxh_jacobi_solve(int device, int dtype, int ndim, int dim, int nsum, int64_t
                      int* sweeps_done);
 
 /*
+ * Multigrid and conjugate-gradient solvers for  mass * x - diffusion * laplace(x) = rhs
+ * (utils/linear_solvers/mg.py:13-270, cg.py:16-59; plug-in contract utils/linear_solvers/solver.py:12-72).
+ * Arrays have exactly `dim` axes, shape (n0, n1[, n2]), dense host memory.  The object is stateful like the
+ * reference's: MG keeps its smoother's cached diagonal (scalar coefficients) or its coefficient arrays, which
+ * every V-cycle restricts and re-prolongates in place (heterogeneous; mg.py:124-181).
+ *   MG: depth, smoother_iterations, maxiter, tol (< 0: none), heterogeneous (constructor-time flag, mg.py:72-75)
+ *   CG: maxiter, tol (required), h (<= 0: none); stop rule |r| <= tol |b| of scipy.sparse.linalg.cg (SciPy < 1.14)
+ */
+typedef struct dxh_solver_s* dxh_solver_t;
+
+#define DXH_SOLVER_JACOBI 0
+#define DXH_SOLVER_MG 1
+#define DXH_SOLVER_CG 2
+
+typedef struct dxh_solver_desc {
+    int32_t struct_size; /* sizeof(dxh_solver_desc) */
+    int32_t device;
+    int32_t dtype; /* DXH_F32 / DXH_F64 */
+    int32_t dim;   /* 2 or 3 */
+    int64_t n0, n1, n2;
+    int32_t kind; /* DXH_SOLVER_MG / DXH_SOLVER_CG */
+    int32_t depth;
+    int32_t smoother_iterations;
+    int32_t maxiter;
+    int32_t heterogeneous;
+    int32_t reserved;
+    double tol;
+    double h;
+    void* stream; /* hipStream_t or NULL */
+} dxh_solver_desc;
+
+int dxh_solver_create(dxh_solver_t* out, const dxh_solver_desc* desc);
+int dxh_solver_destroy(dxh_solver_t s);
+/* Solver.update_params (solver.py:40-58): scalars or dense host arrays (an array wins over the scalar) */
+int dxh_solver_set_params(dxh_solver_t s, double mass, const void* mass_arr, double diffusion, const void* diffusion_arr);
+/* Solver.__call__(x0, rhs): *iters = V-cycles / CG iterations performed */
+int dxh_solver_solve(dxh_solver_t s, const void* x0, const void* rhs, void* out, int32_t* iters);
+/* current coefficient arrays of a heterogeneous MG (the reference's mutated solver.mass_coeff / diffusion_coeff) */
+int dxh_solver_get_params(dxh_solver_t s, void* mass_out, void* diffusion_out);
+
+/*
+ * Use MG / CG instead of the Jacobi sweeps inside dxh_tvd_run (split_bregman_tvd.py:25,63-67,133: the `solver`
+ * argument).  kind = DXH_SOLVER_JACOBI restores the default.  Scalar omega / ell only (as with the reference,
+ * whose MG() default object is not heterogeneous).
+ */
+int dxh_tvd_set_solver(dxh_tvd_t ctx, int kind, int depth, int smoother_iterations, int maxiter, double tol);
+
+/*
  * Finite differences (utils/derivatives.py:16-59): mode 0 = backward_diff
  * (x[i+1]-x[i], last 0), 1 = forward_diff (x[i]-x[i-1], first 0); h <= 0: no scaling.
  */

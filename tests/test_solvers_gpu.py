@@ -1,0 +1,160 @@
+"""MG / CG on the device (through the C ABI) against the reference's own outputs (tests/golden/solvers_golden.npz)
+and against the NumPy oracle on other shapes.  MG: bit-exact.  CG: to the solver tolerance."""
+import os
+
+import numpy as np
+import pytest
+
+import darsia_amd as da
+from oracle import solvers_numpy as so
+from oracle import tvd_numpy as tv
+
+pytestmark = pytest.mark.gpu
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "solvers_golden.npz"))
+
+
+def g(name, key):
+    return G[f"{name}/{key}"]
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_mg_2d_golden_bit_exact(tag):
+    n = f"mg_2d_{tag}"
+    s = da.MG(depth=2, smoother_iterations=3, maxiter=2, mass_coeff=1.0, diffusion_coeff=0.5, dim=2)
+    out = s(g(n, "x0"), g(n, "rhs"))
+    assert out.dtype == g(n, "out").dtype
+    np.testing.assert_array_equal(out, g(n, "out"))
+
+
+def test_mg_depth0_tol_3d_golden_bit_exact():
+    out = da.MG(depth=0, smoother_iterations=2, maxiter=1, mass_coeff=0.3, diffusion_coeff=1.5, dim=2)(g("mg_d0", "x0"), g("mg_d0", "rhs"))
+    np.testing.assert_array_equal(out, g("mg_d0", "out"))
+    out = da.MG(depth=1, smoother_iterations=4, maxiter=50, tol=1e-3, mass_coeff=1.0, diffusion_coeff=0.2, dim=2)(
+        g("mg_tol", "x0"), g("mg_tol", "rhs"))
+    np.testing.assert_array_equal(out, g("mg_tol", "out"))
+    out = da.MG(depth=1, smoother_iterations=2, maxiter=2, mass_coeff=1.0, diffusion_coeff=0.7, dim=3)(g("mg_3d", "x0"), g("mg_3d", "rhs"))
+    np.testing.assert_array_equal(out, g("mg_3d", "out"))
+
+
+@pytest.mark.parametrize("tag", ["f64", "f32"])
+def test_mg_heterogeneous_two_calls_golden_bit_exact(tag):
+    n = f"mg_het_{tag}"
+    s = da.MG(depth=1, smoother_iterations=2, maxiter=2, mass_coeff=g(n, "mass").copy(), diffusion_coeff=g(n, "diff").copy(), dim=2)
+    o1 = s(g(n, "x0"), g(n, "rhs"))
+    o2 = s(o1.copy(), g(n, "rhs"))
+    np.testing.assert_array_equal(o1, g(n, "out1"))
+    np.testing.assert_array_equal(o2, g(n, "out2"))
+    np.testing.assert_array_equal(s.mass_coeff, g(n, "mass_after"))
+    np.testing.assert_array_equal(s.diffusion_coeff, g(n, "diff_after"))
+
+
+def test_mg_rejects_channel_arrays_and_bad_depth():
+    with pytest.raises(ValueError):
+        da.MG(depth=1, smoother_iterations=1, maxiter=1, mass_coeff=1.0, diffusion_coeff=1.0, dim=2)(
+            np.ones((8, 8, 3)), np.ones((8, 8, 3)))
+    with pytest.raises(ValueError):  # 5 -> 2 -> 1 -> 0 rows
+        da.MG(depth=3, smoother_iterations=1, maxiter=1, mass_coeff=1.0, diffusion_coeff=1.0, dim=2)(
+            np.ones((5, 64)), np.ones((5, 64)))
+    with pytest.raises(ValueError):  # scalar solver, then an array coefficient
+        s = da.MG(depth=1, smoother_iterations=1, maxiter=1, mass_coeff=1.0, diffusion_coeff=1.0, dim=2)
+        s.update_params(diffusion_coeff=np.ones((16, 16)))
+        s(np.ones((16, 16)), np.ones((16, 16)))
+
+
+@pytest.mark.parametrize("shape,dim,dtype,depth", [((257, 391), 2, np.float32, 3), ((130, 96), 2, np.float64, 2),
+                                                   ((33, 47, 29), 3, np.float32, 2), ((64, 40, 18), 3, np.float64, 1)])
+def test_mg_vs_oracle_other_shapes_bit_exact(shape, dim, dtype, depth):
+    rng = np.random.default_rng(3)
+    x0 = rng.random(shape).astype(dtype)
+    rhs = rng.random(shape).astype(dtype)
+    kw = dict(depth=depth, smoother_iterations=3, maxiter=3, mass_coeff=0.9, diffusion_coeff=0.35, dim=dim)
+    np.testing.assert_array_equal(da.MG(**kw)(x0, rhs), so.MG(**kw)(x0, rhs))
+
+
+def test_mg_heterogeneous_3d_vs_oracle_bit_exact():
+    rng = np.random.default_rng(4)
+    shape = (21, 30, 17)
+    x0, rhs = rng.random(shape), rng.random(shape)
+    diff = 0.2 + rng.random(shape)
+    a = da.MG(depth=1, smoother_iterations=2, maxiter=2, mass_coeff=0.6, diffusion_coeff=diff.copy(), dim=3)
+    b = so.MG(depth=1, smoother_iterations=2, maxiter=2, mass_coeff=0.6, diffusion_coeff=diff.copy(), dim=3)
+    np.testing.assert_array_equal(a(x0, rhs), b(x0, rhs))
+    np.testing.assert_array_equal(a.diffusion_coeff, b.diffusion_coeff)
+
+
+def test_mg_keeps_the_first_diagonal_after_update_params():
+    """Quirk Q3 inside MG: the smoother's diagonal is the one of the first call."""
+    rng = np.random.default_rng(5)
+    x0, rhs = rng.random((40, 40)), rng.random((40, 40))
+    a = da.MG(depth=1, smoother_iterations=2, maxiter=1, mass_coeff=1.0, diffusion_coeff=0.5, dim=2)
+    b = so.MG(depth=1, smoother_iterations=2, maxiter=1, mass_coeff=1.0, diffusion_coeff=0.5, dim=2)
+    a(x0, rhs), b(x0, rhs)
+    a.update_params(mass_coeff=2.0, diffusion_coeff=0.1)
+    b.update_params(mass_coeff=2.0, diffusion_coeff=0.1)
+    np.testing.assert_array_equal(a(x0, rhs), b(x0, rhs))
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("cg_2d", dict(mass_coeff=1.0, diffusion_coeff=0.5, dim=2)),
+    ("cg_het", dict(mass_coeff=0.7, diffusion_coeff="diff", dim=2)),
+    ("cg_3d", dict(mass_coeff=1.0, diffusion_coeff=0.5, dim=3)),
+])
+def test_cg_golden_to_solver_tolerance(name, kw):
+    kw = dict(kw)
+    if kw["diffusion_coeff"] == "diff":
+        kw["diffusion_coeff"] = g(name, "diff")
+    out = da.CG(maxiter=500, tol=1e-10, **kw)(g(name, "x0"), g(name, "rhs"))
+    np.testing.assert_allclose(out, g(name, "out"), rtol=0, atol=1e-8)
+    res = g(name, "rhs") - so.CG(maxiter=1, tol=1e-10, **kw).apply(out)
+    assert np.linalg.norm(res) <= 1.5e-10 * np.linalg.norm(g(name, "rhs"))
+
+
+def test_cg_few_iterations_same_recurrence():
+    out = da.CG(maxiter=3, tol=1e-12, mass_coeff=1.0, diffusion_coeff=0.5, dim=2)(g("cg_few", "x0"), g("cg_few", "rhs"))
+    np.testing.assert_allclose(out, g("cg_few", "out"), rtol=1e-11, atol=1e-12)
+
+
+def test_cg_float32_and_grid_spacing_vs_oracle():
+    rng = np.random.default_rng(6)
+    x0 = rng.random((96, 80)).astype(np.float32)
+    rhs = rng.random((96, 80)).astype(np.float32)
+    kw = dict(maxiter=300, tol=1e-5, mass_coeff=1.0, diffusion_coeff=0.8, dim=2)
+    out = da.CG(**kw)(x0, rhs, h=0.5)
+    ref = so.CG(**kw)(x0, rhs, h=0.5)
+    assert out.dtype == np.float32
+    np.testing.assert_allclose(out, ref, rtol=0, atol=2e-4)
+
+
+@pytest.mark.parametrize("name,dim,kw,solver", [
+    ("tvd_mg_f64", 2, dict(mu=0.1, max_num_iter=6), dict(depth=1, smoother_iterations=2, maxiter=1)),
+    ("tvd_mg_f32", 2, dict(mu=0.1, max_num_iter=6), dict(depth=1, smoother_iterations=2, maxiter=1)),
+    ("tvd_mg_3d", 3, dict(mu=0.05, omega=0.8, max_num_iter=4), dict(depth=1, smoother_iterations=2, maxiter=2)),
+])
+def test_tvd_with_mg_golden_bit_exact(name, dim, kw, solver):
+    img = g(name, "img")
+    out = da.split_bregman_tvd(img.copy(), dim=dim, solver=da.MG(**solver), **kw)
+    assert out.dtype == img.dtype
+    np.testing.assert_array_equal(out, g(name, "out"))
+
+
+def test_tvd_with_cg_golden_to_tolerance():
+    img = g("tvd_cg_f64", "img")
+    out = da.split_bregman_tvd(img.copy(), mu=0.1, max_num_iter=5, solver=da.CG(maxiter=200, tol=1e-10))
+    np.testing.assert_allclose(out, g("tvd_cg_f64", "out"), rtol=0, atol=1e-7)
+
+
+def test_tvd_with_mg_isotropic_eps_vs_oracle():
+    from darsia_amd.synthetic import synthetic_image
+    img = np.ascontiguousarray(synthetic_image(180, 250, 3)[..., 1]).astype(np.float64)
+    kw = dict(mu=0.15, omega=1.0, max_num_iter=30, eps=1e-3, isotropic=True)
+    sv = dict(depth=2, smoother_iterations=2, maxiter=1)
+    out = da.split_bregman_tvd(img.copy(), solver=da.MG(**sv), **kw)
+    ref = tv.split_bregman_tvd(img.copy(), promotion="strict", solver=so.MG(**sv), **kw)
+    np.testing.assert_allclose(out, ref, rtol=1e-13, atol=1e-14)  # isotropic: sqrt / division order, cf. G4
+
+
+def test_tvd_with_mg_rejects_channel_images():
+    from darsia_amd.synthetic import synthetic_image
+    with pytest.raises(ValueError):
+        da.split_bregman_tvd(synthetic_image(32, 32, 3), mu=0.1, max_num_iter=2, solver=da.MG(depth=1))
