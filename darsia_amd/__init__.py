@@ -21,6 +21,7 @@ from .utils.linear_solvers.cg import CG  # noqa: F401
 from .restoration.split_bregman_tvd import DeviceTVD, split_bregman_tvd  # noqa: F401
 from .restoration.h1_regularization import H1_regularization  # noqa: F401
 from .restoration.chambolle import denoise_tv_chambolle  # noqa: F401
+from .restoration.bregman_gs import denoise_tv_bregman  # noqa: F401
 from .restoration.tvd import TVD, tvd  # noqa: F401
 
 from .color import AffineBalance, BaseBalance, apply_affine_balance  # noqa: F401

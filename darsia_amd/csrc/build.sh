@@ -32,6 +32,7 @@ run tvd dxh_tvd.hip
 run chambolle dxh_chambolle.hip
 run dense dxh_dense.hip
 run solvers dxh_solvers.hip
+run bregman_gs dxh_bregman_gs.hip
 fail=0
 for i in "${!pids[@]}"; do
     if ! wait "${pids[$i]}"; then

@@ -21,9 +21,9 @@ def denoise_tv_chambolle(image: np.ndarray, weight: float = 0.1, eps: float = 2e
         raise TypeError("image must be a numpy array")
     if image.dtype.kind != "f":
         if image.dtype == np.uint8:
-            image = image / 255.0
+            image = np.multiply(image, 1.0 / 255, dtype=np.float64)  # skimage's img_as_float multiplies
         elif image.dtype == np.uint16:
-            image = image / 65535.0
+            image = np.multiply(image, 1.0 / 65535, dtype=np.float64)
         else:
             raise TypeError(f"dtype {image.dtype} not supported")
     if image.dtype not in (np.float32, np.float64):

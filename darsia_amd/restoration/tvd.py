@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import numpy as np
 
+from .bregman_gs import denoise_tv_bregman
 from .chambolle import denoise_tv_chambolle
 from .split_bregman_tvd import split_bregman_tvd
 
@@ -61,10 +62,9 @@ class TVD:
             # tvd.py:77-83: no channel axis -> colour images are denoised as 3-D volumes
             return denoise_tv_chambolle(img, weight=self.weight, max_num_iter=self.max_num_iter, eps=self.eps)
         elif self.method in _SKIMAGE_BREGMAN:
-            raise NotImplementedError(
-                f"method '{self.method}' is scikit-image's Gauss-Seidel split Bregman (tvd.py:85-101), a "
-                "sequential raster sweep that is not part of the MI355X hot path; use 'chambolle' or "
-                "'heterogeneous bregman'")
+            # tvd.py:85-101: scikit-image's Gauss-Seidel split Bregman, no channel axis
+            return denoise_tv_bregman(img, weight=self.weight, max_num_iter=self.max_num_iter, eps=self.eps,
+                                      isotropic=self.method == "isotropic bregman")
         else:
             raise ValueError(f"Method {self.method} not supported.")
 

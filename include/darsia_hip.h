@@ -230,6 +230,15 @@ int dxh_solver_get_params(dxh_solver_t s, void* mass_out, void* diffusion_out);
 int dxh_tvd_set_solver(dxh_tvd_t ctx, int kind, int depth, int smoother_iterations, int maxiter, double tol);
 
 /*
+ * skimage.restoration.denoise_tv_bregman as DarSIA calls it (restoration/tvd.py:85-101, utils/segmentation.py:117-120;
+ * third-party arithmetic, restated in oracle/bregman_gs_numpy.py): split Bregman with an in-place Gauss-Seidel
+ * u-update over a (rows, cols, dims) image whose channels are independent 2-D problems with a joint stop test.
+ * image, out: dense host arrays of the given dtype (the caller applies img_as_float).  *iters = sweeps done.
+ */
+int dxh_tv_bregman_gs(int device, int dtype, int64_t rows, int64_t cols, int64_t dims, const void* image, void* out,
+                      double weight, int max_iter, double eps, int isotropic, int* iters, double* rmse);
+
+/*
  * Finite differences (utils/derivatives.py:16-59): mode 0 = backward_diff
  * (x[i+1]-x[i], last 0), 1 = forward_diff (x[i]-x[i-1], first 0); h <= 0: no scaling.
  */

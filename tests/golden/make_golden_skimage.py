@@ -16,7 +16,7 @@ import os
 
 import numpy as np
 import skimage
-from skimage.restoration import denoise_tv_chambolle
+from skimage.restoration import denoise_tv_bregman, denoise_tv_chambolle
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -48,6 +48,22 @@ def main():
         out[name + "/img"] = img
         out[name + "/out"] = denoise_tv_chambolle(img.copy(), **kw)
         out[name + "/kw"] = np.array([kw["weight"], kw["eps"], kw["n_iter_max"]], dtype=np.float64)
+    # Gauss-Seidel split Bregman (tvd.py:85-101 calls it without a channel axis = multichannel=False in 0.18.3)
+    bcases = [
+        ("b_aniso_f64", noisy_blocks((40, 56), 31, np.float64), dict(weight=0.3, eps=1e-3, max_iter=100, isotropic=False)),
+        ("b_iso_f64", noisy_blocks((40, 56), 31, np.float64), dict(weight=0.3, eps=1e-3, max_iter=100, isotropic=True)),
+        ("b_aniso_f32", noisy_blocks((40, 56), 31, np.float32), dict(weight=4.0, eps=1e-4, max_iter=60, isotropic=False)),
+        ("b_iso_f32", noisy_blocks((40, 56), 31, np.float32), dict(weight=4.0, eps=1e-4, max_iter=60, isotropic=True)),
+        ("b_rgb_aniso_f32", noisy_blocks((33, 47, 3), 32, np.float32), dict(weight=2.0, eps=2e-4, max_iter=200, isotropic=False)),
+        ("b_rgb_iso_f64", noisy_blocks((33, 47, 3), 32, np.float64), dict(weight=1.0, eps=0.0, max_iter=12, isotropic=True)),
+        ("b_wide_aniso_f64", noisy_blocks((7, 130), 33, np.float64), dict(weight=8.0, eps=0.0, max_iter=9, isotropic=False)),
+        ("b_tall_iso_f32", noisy_blocks((97, 5), 34, np.float32), dict(weight=0.8, eps=0.0, max_iter=7, isotropic=True)),
+        ("b_uint8", (noisy_blocks((24, 31), 35, np.float64) * 255).astype(np.uint8), dict(weight=0.1, eps=1e-4, max_iter=100, isotropic=False)),
+    ]
+    for name, img, kw in bcases:
+        out[name + "/img"] = img
+        out[name + "/out"] = denoise_tv_bregman(img.copy(), multichannel=False, **kw)
+        out[name + "/kw"] = np.array([kw["weight"], kw["eps"], kw["max_iter"], float(kw["isotropic"])], dtype=np.float64)
     path = os.path.join(HERE, "skimage_0_18_3_golden.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB", skimage.__version__)

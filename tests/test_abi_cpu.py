@@ -74,8 +74,8 @@ def test_error_types_match_reference(golden):
         da.TVD()([1, 2, 3])
     with pytest.raises(TypeError):
         da.split_bregman_tvd(np.zeros((4, 4), np.uint8))
-    with pytest.raises(NotImplementedError):
-        da.TVD(method="isotropic bregman")(np.zeros((4, 4), np.float32))  # skimage's Gauss-Seidel sweep
+    with pytest.raises(TypeError):
+        da.TVD(method="isotropic bregman")(np.zeros((4, 4), np.complex64))  # img_as_float rejects it
 
 
 def test_operator_call_signature_is_plain_method():
