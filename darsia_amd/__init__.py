@@ -34,3 +34,9 @@ from .concentration import (ClipModel, CombinedModel, ConcentrationAnalysis, Lin
                             MonochromaticReduction, ScalingModel)
 
 __version__ = "0.1.0"
+from .corrections import (  # noqa: F401,E402
+    BaseCorrection,
+    CurvatureCorrection,
+    extract_quadrilateral_ROI,
+    map_coordinates,
+)

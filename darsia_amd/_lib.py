@@ -28,7 +28,7 @@ EXPORTS = (
     "dxh_tvd_partial_norms", "dxh_tvd_sync", "dxh_jacobi_solve", "dxh_diff", "dxh_chambolle",
     "dxh_warp_patches", "dxh_tps_eval", "dxh_affine_color",
     "dxh_solver_create", "dxh_solver_destroy", "dxh_solver_set_params", "dxh_solver_solve", "dxh_solver_get_params",
-    "dxh_tvd_set_solver", "dxh_tv_bregman_gs",
+    "dxh_tvd_set_solver", "dxh_tv_bregman_gs", "dxh_map_coordinates",
     "dxh_tvd_energy", "dxh_tvd_adapt_ell", "dxh_tvd_set_base", "dxh_tvd_set_cleaning_filter", "dxh_tvd_upload_signal", "dxh_tvd_download_model",
 )
 
@@ -107,6 +107,7 @@ def _declare(lib):
     lib.dxh_solver_solve.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_int32)]
     lib.dxh_solver_get_params.argtypes = [vp, vp, vp]
     lib.dxh_tvd_set_solver.argtypes = [vp, i, i, i, i, dbl]
+    lib.dxh_map_coordinates.argtypes = [i, i, i64, i64, i, vp, i, vp, vp, i64, i, dbl, vp]
     lib.dxh_tv_bregman_gs.argtypes = [i, i, i64, i64, i64, vp, vp, dbl, i, dbl, i, C.POINTER(i), C.POINTER(dbl)]
     lib.dxh_tvd_adapt_ell.argtypes = [vp]
     lib.dxh_jacobi_solve.argtypes = [i, i, i, i, i, i64, i64, i64, vp, vp, vp, dbl, vp, dbl, vp, dbl, i, dbl,

@@ -1,0 +1,293 @@
+"""Shape corrections on the GPU: ``BaseCorrection`` (corrections/basecorrection.py:15-139), the dense gather
+``map_coordinates`` and ``CurvatureCorrection`` (corrections/shape/curvature.py:166-985), plus
+``extract_quadrilateral_ROI`` (image/subregions.py:31-176) which the curvature set-up uses for its crop step.
+
+What runs where: the per-image work of ``CurvatureCorrection`` is ``_transform_image`` -- one
+``scipy.ndimage.map_coordinates(channel, grid, order=1)`` per channel over the cached coordinate grid
+(curvature.py:921-957); that gather runs on the device for all channels in one pass and is bit-identical to
+SciPy's (orders 0 and 1, float32 / float64 / uint8 / uint16).  The one-time set-up (``_transform_coordinates``:
+a handful of float32 NumPy expressions over the pixel mesh) stays on the host exactly as in the reference, but its
+intermediate gathers use the device as well.  The interactive calibration helpers (``pre_bulge_correction``,
+``bulge_correction``, ``stretch_correction``, ``compute_bulge`` ...), TOML parsing and plotting are out of scope.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import math
+from abc import ABC, abstractmethod
+from pathlib import Path
+from typing import Optional, Union
+from warnings import warn
+
+import numpy as np
+
+from . import _lib
+from .geometry import VoxelArray
+from .image import Image  # noqa: F401
+from .registration import _opencv_block_width, get_perspective_transform
+
+_MC_DTYPES = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.uint8): 2, np.dtype(np.uint16): 3}
+
+
+def map_coordinates(img: np.ndarray, grid: np.ndarray, order: int = 1, cval: float = 0.0) -> np.ndarray:
+    """``scipy.ndimage.map_coordinates(img[..., c], grid, order=order)`` (mode "constant") for every channel of an
+    (H, W) or (H, W, C) array; returns (n,) or (n, C) in ``img``'s dtype."""
+    if not isinstance(img, np.ndarray) or img.ndim not in (2, 3):
+        raise ValueError("img must be an (H, W) or (H, W, C) array")
+    if img.dtype not in _MC_DTYPES:
+        raise TypeError(f"dtype {img.dtype} not supported on the device (float32, float64, uint8, uint16)")
+    if order not in (0, 1):
+        raise NotImplementedError("interpolation orders 0 and 1 are available on the device")
+    grid = np.asarray(grid)
+    if grid.ndim != 2 or grid.shape[0] != 2:
+        raise ValueError("grid must have shape (2, n): rows, columns")
+    if grid.dtype not in (np.float32, np.float64):
+        grid = grid.astype(np.float64)
+    _lib.require_gpu()
+    src = np.ascontiguousarray(img)
+    rows, cols = np.ascontiguousarray(grid[0]), np.ascontiguousarray(grid[1])
+    chans = 1 if src.ndim == 2 else src.shape[2]
+    n = rows.shape[0]
+    out = np.empty((n,) if src.ndim == 2 else (n, chans), src.dtype)
+    _lib.check(_lib.load().dxh_map_coordinates(
+        _lib.default_device(), _MC_DTYPES[src.dtype], src.shape[0], src.shape[1], chans, _lib.ptr(src),
+        0 if grid.dtype == np.float32 else 1, _lib.ptr(rows), _lib.ptr(cols), n, int(order), float(cval), _lib.ptr(out)))
+    return out
+
+
+def extract_quadrilateral_ROI(img_src: np.ndarray, pts_src=None, indexing: str = "reverse matrix",
+                              interpolation: str = "inter_linear", **kwargs) -> np.ndarray:
+    """Perspective extraction of a quadrilateral (image/subregions.py:31-176: ``cv2.getPerspectiveTransform`` +
+    ``cv2.warpPerspective(img.astype(float32), P, (width, height), INTER_LINEAR)``, cast back to the input dtype).
+    The warp runs on the device with OpenCV's float32 fixed-point bilinear arithmetic (unpinned)."""
+    if interpolation != "inter_linear":
+        raise NotImplementedError("only 'inter_linear' is available on the device")
+    scalar = img_src.ndim == 2
+    original_shape = img_src.shape[:2]
+    if "width" in kwargs and "height" in kwargs:
+        aspect_ratio = kwargs["width"] / kwargs["height"]
+        original_height, original_width = original_shape
+        width = min(original_width, int(aspect_ratio * float(original_height)))
+        height = min(original_height, int(1.0 / aspect_ratio * float(original_width)))
+    else:
+        height, width = kwargs.get("shape", original_shape)
+    if height > original_shape[0] or width > original_shape[1]:
+        raise NotImplementedError("target larger than the source image")
+    if pts_src is None:
+        pts_src = np.array([[0, 0], [original_shape[0], 0], [original_shape[0], original_shape[1]], [0, original_shape[1]]])
+        if indexing == "reverse matrix":
+            pts_src = np.fliplr(pts_src)
+    else:
+        if isinstance(pts_src, VoxelArray):  # voxels use matrix indexing by definition
+            pts_src = np.fliplr(np.asarray(pts_src))
+        else:
+            pts_src = np.asarray(pts_src)
+            if indexing == "matrix":
+                pts_src = np.fliplr(pts_src)
+    if "pts_dst" in kwargs:
+        pts_dst = kwargs["pts_dst"]
+        if isinstance(pts_dst, VoxelArray):
+            pts_dst = np.fliplr(np.asarray(pts_dst))
+        else:
+            pts_dst = np.asarray(pts_dst)
+            if indexing == "matrix":
+                pts_dst = np.fliplr(pts_dst)
+    else:
+        pts_dst = np.array([[0, 0], [0, height - 1], [width - 1, height - 1], [width - 1, 0]])
+    assert pts_src.shape[0] == pts_dst.shape[0]
+    p = get_perspective_transform(pts_src.astype(np.float32), pts_dst.astype(np.float32))
+    chans = 1 if scalar else img_src.shape[2]
+    if chans not in (1, 3):
+        raise NotImplementedError("scalar or 3-channel images")
+    h, w = original_shape
+    rec = _lib.WarpPatch()
+    rec.minv[:] = list(np.linalg.inv(p).ravel())
+    rec.sr0, rec.sc0, rec.sh, rec.sw = 0, 0, h, w
+    rec.ox, rec.oy, rec.w_eff, rec.h_eff = 0, 0, int(width), int(height)
+    rec.nx, rec.ny = int(width), int(height)
+    rec.bw0 = _opencv_block_width(int(width), int(height))
+    _lib.require_gpu()
+    src = np.ascontiguousarray(img_src, dtype=np.float32)
+    canvas = np.empty_like(src)
+    table = (_lib.WarpPatch * 1)(rec)
+    _lib.check(_lib.load().dxh_warp_patches(_lib.default_device(), h, w, chans, _lib.ptr(src), C.cast(table, C.c_void_p), 1,
+                                             _lib.ptr(canvas)))
+    return np.ascontiguousarray(canvas[:height, :width]).astype(img_src.dtype)
+
+
+class BaseCorrection(ABC):
+    """Abstract correction (basecorrection.py:15-139): ``__call__(image, overwrite=False)`` on arrays and Images."""
+
+    def __call__(self, image, overwrite: bool = False):
+        if isinstance(image, np.ndarray):
+            return self.correct_array(image if overwrite else image.copy())
+        if hasattr(image, "img") and hasattr(image, "metadata"):
+            img = image.img if overwrite else image.img.copy()
+            if getattr(image, "series", False) and hasattr(self, "correct_array_series"):
+                img = self.correct_array_series(img)
+            elif getattr(image, "series", False):
+                slices = [self.correct_array(image.img[..., t] if image.scalar else image.img[..., t, :])
+                          for t in range(image.time_num)]
+                img = np.stack(slices, axis=image.space_dim)
+            else:
+                img = self.correct_array(img)
+            meta_update = self.correct_metadata(image.metadata())
+            if overwrite:
+                image.img = img
+                if hasattr(image, "update_metadata"):
+                    image.update_metadata(meta_update)
+                else:
+                    for k, v in meta_update.items():
+                        setattr(image, k, v)
+                return image
+            meta = image.metadata()
+            meta.update(meta_update)
+            return type(image)(img, **meta)
+        raise TypeError(f"Input type {type(image)} not supported.")
+
+    @abstractmethod
+    def correct_array(self, image: np.ndarray) -> np.ndarray:
+        ...
+
+    def correct_metadata(self, metadata: dict = {}) -> dict:
+        return {}
+
+    @abstractmethod
+    def save(self, path) -> None:
+        ...
+
+    @abstractmethod
+    def load(self, path) -> None:
+        ...
+
+
+class CurvatureCorrection(BaseCorrection):
+    """Polynomial curvature correction (curvature.py:166-985): config sections ``init`` / ``crop`` / ``bulge`` /
+    ``stretch`` applied in that order; the transformed coordinate grid is cached per object."""
+
+    def __init__(self, config: Optional[Union[dict, str, Path]] = None, **kwargs) -> None:
+        if isinstance(config, dict):
+            self.config = {k: (dict(v) if isinstance(v, dict) else v) for k, v in config.items()}
+        elif config is not None:
+            self.config = json.loads(Path(config).read_text())
+        if "image" in kwargs:
+            im_source = kwargs["image"]
+            if not isinstance(im_source, np.ndarray):
+                raise NotImplementedError("provide the reference image as an array (image files need OpenCV)")
+            self.reference_image = im_source
+            self.current_image = np.copy(im_source)
+            self.dtype = self.current_image.dtype
+            self.in_meters = kwargs.get("in_meters", True)
+            self.width = kwargs.get("width", 1.0)
+            self.height = kwargs.get("height", 1.0)
+            if not hasattr(self, "config"):
+                self.config = {}
+        elif not hasattr(self, "config"):
+            warn("No image provided. Please provide an image or a config file.")
+        self.resize_factor = kwargs.get("resize_factor", 1.0)
+        if not math.isclose(self.resize_factor, 1.0) and hasattr(self, "config"):
+            self._adapt_config()
+        self.cache: dict = {}
+        self.use_cache = bool(getattr(self, "config", {}).get("use_cache", False))
+        if self.use_cache:
+            self.cache_path = Path(self.config.get("cache", "./cache/curvature_transformation.npy"))
+            self.cache_path.parents[0].mkdir(parents=True, exist_ok=True)
+        self.interpolation_order: int = kwargs.get("interpolation_order", 1)
+
+    # ---- persistence (curvature.py:312-350: npz with the class name and the config) --------------------------
+    def save(self, path) -> None:
+        np.savez(path, class_name=type(self).__name__, config=self.config)
+
+    def load(self, path) -> None:
+        data = np.load(path, allow_pickle=True)
+        if "config" not in data:
+            raise ValueError("Invalid file format.")
+        self.config = data["config"].item()
+        self.cache = {}
+
+    # ---- application ---------------------------------------------------------------------------------------
+    def correct_array(self, img: np.ndarray) -> np.ndarray:
+        """curvature.py:690-730."""
+        if not (self.use_cache and self.cache_path.exists()) and "grid" not in self.cache:
+            self._precompute_transformed_coordinates(img)
+            if self.use_cache:
+                np.save(self.cache_path, self.cache)
+        elif self.use_cache and self.cache_path.exists():
+            self.cache = np.load(self.cache_path, allow_pickle=True).item()
+        return self._transform_image(img, self.cache["grid"], self.cache["shape"])
+
+    def simple_curvature_correction(self, img: np.ndarray, **kwargs) -> np.ndarray:
+        """curvature.py:734-771."""
+        ny, nx = img.shape[:2]
+        X, Y = np.meshgrid(np.arange(nx, dtype=np.float32), np.arange(ny, dtype=np.float32))
+        X, Y = self._transform_coordinates(X, Y, **kwargs)
+        grid = np.array([Y.ravel(), X.ravel()])
+        return self._transform_image(img, grid, X.shape[:2])
+
+    def _precompute_transformed_coordinates(self, img: np.ndarray) -> None:
+        """curvature.py:775-825: the coordinate images pass through the configured steps themselves."""
+        ny, nx = img.shape[:2]
+        X, Y = np.meshgrid(np.arange(nx, dtype=np.float32), np.arange(ny, dtype=np.float32))
+        coords = {"X": X, "Y": Y}
+        for key, pixels in coords.items():
+            if "init" in self.config:
+                pixels = self.simple_curvature_correction(pixels, **self.config["init"])
+            if "crop" in self.config:
+                pixels = extract_quadrilateral_ROI(pixels, **self.config["crop"])
+            if "bulge" in self.config:
+                pixels = self.simple_curvature_correction(pixels, **self.config["bulge"])
+            if "stretch" in self.config:
+                pixels = self.simple_curvature_correction(pixels, **self.config["stretch"])
+            coords[key] = pixels
+        X, Y = coords["X"], coords["Y"]
+        self.cache["grid"] = np.array([Y.ravel(), X.ravel()])
+        self.cache["shape"] = X.shape[:2]
+
+    def _adapt_config(self) -> None:
+        """curvature.py:827-855."""
+        for mainkey in ("init", "bulge"):
+            if mainkey in self.config:
+                for key in ("horizontal_bulge", "vertical_bulge", "horizontal_center_offset", "vertical_center_offset"):
+                    if key in self.config[mainkey]:
+                        self.config[mainkey][key] *= self.resize_factor
+        if "crop" in self.config:
+            self.config["crop"]["pts_src"] = (self.resize_factor * np.array(self.config["crop"]["pts_src"])).tolist()
+        if "stretch" in self.config:
+            for key in ("horizontal_stretch", "vertical_stretch", "horizontal_center_offset", "vertical_center_offset"):
+                self.config["stretch"][key] *= self.resize_factor
+
+    @staticmethod
+    def _transform_coordinates(X: np.ndarray, Y: np.ndarray, **kwargs):
+        """Bulge and stretch maps of the pixel mesh (curvature.py:857-919); float32 in, float32 out."""
+        horizontal_bulge = kwargs.get("horizontal_bulge", 0.0)
+        horizontal_stretch = kwargs.get("horizontal_stretch", 0.0)
+        horizontal_center_offset = kwargs.get("horizontal_center_offset", 0)
+        vertical_bulge = kwargs.get("vertical_bulge", 0.0)
+        vertical_stretch = kwargs.get("vertical_stretch", 0.0)
+        vertical_center_offset = kwargs.get("vertical_center_offset", 0)
+        ny, nx = X.shape[:2]
+        image_center = [round(nx / 2) + horizontal_center_offset, round(ny / 2) + vertical_center_offset]
+        X -= image_center[0]
+        Y -= image_center[1]
+        x_lo, x_hi, y_lo, y_hi = np.min(X), np.max(X), np.min(Y), np.max(Y)
+        Xmod = X + horizontal_bulge * np.multiply(X, (y_hi - Y) * (Y - y_lo)) + horizontal_stretch * X * (x_hi - X) * (X - x_lo)
+        Ymod = Y + vertical_bulge * np.multiply(Y, (x_hi - X) * (X - x_lo)) + vertical_stretch * Y * (y_hi - Y) * (Y - y_lo)
+        Xmod += image_center[0]
+        Ymod += image_center[1]
+        return Xmod, Ymod
+
+    def _transform_image(self, img: np.ndarray, grid: np.ndarray, shape) -> np.ndarray:
+        """curvature.py:921-957 -- all channels in one device gather."""
+        img3 = np.atleast_3d(img)
+        out = map_coordinates(np.ascontiguousarray(img3), grid, order=self.interpolation_order)
+        return np.squeeze(out.reshape(*shape, img3.shape[2]))
+
+    def correct_metadata(self, metadata: dict = {}) -> dict:
+        """curvature.py:959-985."""
+        meta = {}
+        crop = getattr(self, "config", {}).get("crop", {})
+        if all(key in crop for key in ("width", "height")):
+            meta["dimensions"] = [crop["height"], crop["width"]]
+            meta["origin"] = np.array([0, crop["height"]])
+        return meta

@@ -181,6 +181,66 @@ static int check_device(int device) {
     return DXH_OK;
 }
 
+
+// ---- scipy.ndimage.map_coordinates(channel, grid, order = 0 | 1) with the default mode "constant" ---------------
+// CurvatureCorrection._transform_image (corrections/shape/curvature.py:921-957).  SciPy's arithmetic (third-party,
+// ndimage/src/ni_interpolation.c; restated and checked against SciPy in oracle/map_coordinates_numpy.py):
+// a point with a coordinate < 0 or > n-1 yields cval; otherwise order 1 takes start = floor(c), weights
+// (1 - t, t) in double, out-of-range taps mirrored (they carry weight 0), and sums the four taps row-major as
+// ((v * w_row) * w_col); order 0 takes floor(c + 0.5).  Integer outputs round half away from zero (unsigned: +0.5).
+template <typename T>
+__device__ __forceinline__ T mc_cast(double t);
+template <> __device__ __forceinline__ float mc_cast<float>(double t) { return (float)t; }
+template <> __device__ __forceinline__ double mc_cast<double>(double t) { return t; }
+template <> __device__ __forceinline__ unsigned char mc_cast<unsigned char>(double t) { return (unsigned char)(t > 0 ? t + 0.5 : 0.0); }
+template <> __device__ __forceinline__ unsigned short mc_cast<unsigned short>(double t) { return (unsigned short)(t > 0 ? t + 0.5 : 0.0); }
+
+__device__ __forceinline__ long long mc_mirror(long long i, long long n) {
+    if (n <= 1) return 0;
+    const long long s2 = 2 * n - 2;
+    if (i < 0) i = -i;
+    i %= s2;
+    return i >= n ? s2 - i : i;
+}
+
+template <typename T, typename CT>
+__global__ void __launch_bounds__(256) k_map_coords(const T* __restrict__ img, long long H, long long W, int C,
+                                                     const CT* __restrict__ rows, const CT* __restrict__ cols, long long n,
+                                                     int order, double cval, T* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double cr = (double)rows[i], cc = (double)cols[i];
+    T* o = out + i * C;
+    if (!(cr >= 0.0 && cr <= (double)(H - 1) && cc >= 0.0 && cc <= (double)(W - 1))) {  // also NaN
+        for (int k = 0; k < C; ++k) o[k] = mc_cast<T>(cval);
+        return;
+    }
+    if (order == 0) {
+        const long long r = mc_mirror((long long)floor(cr + 0.5), H), c = mc_mirror((long long)floor(cc + 0.5), W);
+        const T* p = img + (r * W + c) * C;
+        for (int k = 0; k < C; ++k) o[k] = mc_cast<T>((double)p[k]);
+        return;
+    }
+    const double fr = floor(cr), fc = floor(cc);
+    const double tr = cr - fr, tc = cc - fc;
+    const double wr[2] = {1.0 - tr, tr}, wc[2] = {1.0 - tc, tc};
+    const long long r0 = (long long)fr, c0 = (long long)fc;
+    const long long rr[2] = {mc_mirror(r0, H), mc_mirror(r0 + 1, H)}, cl[2] = {mc_mirror(c0, W), mc_mirror(c0 + 1, W)};
+    for (int k = 0; k < C; ++k) {
+        double t = 0.0;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                double v = (double)img[(rr[a] * W + cl[b]) * C + k];
+                v = v * wr[a];
+                v = v * wc[b];
+                t = t + v;
+            }
+        o[k] = mc_cast<T>(t);
+    }
+}
+
 }  // namespace dxh
 
 using namespace dxh;
@@ -290,6 +350,44 @@ int dxh_affine_color(int device, int in_dtype, int64_t npix, const void* img, co
     }
     DXH_HIP(hipGetLastError());
     DXH_HIP(hipMemcpyAsync(out, dout_, sizeof(float) * 3 * (size_t)npix, hipMemcpyDeviceToHost, d.st));
+    DXH_HIP(hipStreamSynchronize(d.st));
+    return DXH_OK;
+}
+
+int dxh_map_coordinates(int device, int dtype, int64_t H, int64_t W, int C, const void* img, int coord_dtype,
+                        const void* rows, const void* cols, int64_t n, int order, double cval, void* out) {
+    DXH_REQUIRE(img && rows && cols && out, "null argument");
+    DXH_REQUIRE(dtype >= 0 && dtype <= 3, "dtype: 0 float32, 1 float64, 2 uint8, 3 uint16");
+    DXH_REQUIRE(coord_dtype == 0 || coord_dtype == 1, "coord_dtype: 0 float32, 1 float64");
+    DXH_REQUIRE(order == 0 || order == 1, "interpolation order %d is not available on the device (0 or 1)", order);
+    DXH_REQUIRE(H >= 1 && W >= 1 && C >= 1 && n >= 0, "bad shape");
+    int rc = check_device(device);
+    if (rc) return rc;
+    if (n == 0) return DXH_OK;
+    const size_t esz = dtype == 0 ? 4 : dtype == 1 ? 8 : dtype == 2 ? 1 : 2;
+    const size_t csz = coord_dtype == 0 ? 4 : 8;
+    Dev d;
+    DXH_HIP(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking));
+    void *dimg = nullptr, *dr = nullptr, *dc = nullptr, *dout_ = nullptr;
+    if ((rc = d.alloc(&dimg, esz * (size_t)H * W * C)) || (rc = d.alloc(&dr, csz * (size_t)n)) || (rc = d.alloc(&dc, csz * (size_t)n)) ||
+        (rc = d.alloc(&dout_, esz * (size_t)n * C)))
+        return rc;
+    DXH_HIP(hipMemcpyAsync(dimg, img, esz * (size_t)H * W * C, hipMemcpyHostToDevice, d.st));
+    DXH_HIP(hipMemcpyAsync(dr, rows, csz * (size_t)n, hipMemcpyHostToDevice, d.st));
+    DXH_HIP(hipMemcpyAsync(dc, cols, csz * (size_t)n, hipMemcpyHostToDevice, d.st));
+    const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
+#define DXH_MC(T_, CT_) hipLaunchKernelGGL((k_map_coords<T_, CT_>), grid, blk, 0, d.st, (const T_*)dimg, (long long)H, (long long)W, C, \
+                                           (const CT_*)dr, (const CT_*)dc, (long long)n, order, cval, (T_*)dout_)
+    if (coord_dtype == 0) {
+        switch (dtype) { case 0: DXH_MC(float, float); break; case 1: DXH_MC(double, float); break;
+                         case 2: DXH_MC(unsigned char, float); break; default: DXH_MC(unsigned short, float); break; }
+    } else {
+        switch (dtype) { case 0: DXH_MC(float, double); break; case 1: DXH_MC(double, double); break;
+                         case 2: DXH_MC(unsigned char, double); break; default: DXH_MC(unsigned short, double); break; }
+    }
+#undef DXH_MC
+    DXH_HIP(hipGetLastError());
+    DXH_HIP(hipMemcpyAsync(out, dout_, esz * (size_t)n * C, hipMemcpyDeviceToHost, d.st));
     DXH_HIP(hipStreamSynchronize(d.st));
     return DXH_OK;
 }

@@ -292,6 +292,15 @@ int dxh_tps_eval(int device, int p, int dout, const double* centers, const doubl
 int dxh_affine_color(int device, int in_dtype, int64_t npix, const void* img, const double* A, const double* b,
                      int clip, float* out);
 
+/*
+ * scipy.ndimage.map_coordinates(channel, grid, order) with mode "constant" for every channel of an (H, W, C) image --
+ * CurvatureCorrection._transform_image (corrections/shape/curvature.py:921-957).  dtype: 0 float32, 1 float64,
+ * 2 uint8, 3 uint16 (output has the input's dtype, integers rounded like SciPy); rows / cols: the two rows of the
+ * reference's `grid` (n coordinates each, float32 or float64); order 0 or 1; out (n, C).
+ */
+int dxh_map_coordinates(int device, int dtype, int64_t H, int64_t W, int C, const void* img, int coord_dtype,
+                        const void* rows, const void* cols, int64_t n, int order, double cval, void* out);
+
 #ifdef __cplusplus
 }
 #endif

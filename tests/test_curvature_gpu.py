@@ -1,0 +1,104 @@
+"""Device gather (dxh_map_coordinates) against SciPy, and CurvatureCorrection against the NumPy / SciPy flow."""
+import numpy as np
+import pytest
+from scipy.ndimage import map_coordinates as sp_map
+
+import darsia_amd as da
+from darsia_amd.synthetic import synthetic_image
+from oracle import curvature_numpy as cu
+from oracle import warp_numpy as wo
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32, np.uint8, np.uint16])
+@pytest.mark.parametrize("order", [0, 1])
+@pytest.mark.parametrize("cdt", [np.float64, np.float32])
+def test_map_coordinates_equals_scipy_bit_for_bit(dt, order, cdt):
+    rng = np.random.default_rng(0)
+    a = (rng.random((13, 17, 3)) * (250 if np.dtype(dt).kind == "u" else 1)).astype(dt)
+    coords = np.stack([rng.uniform(-2, 15, 5000), rng.uniform(-2, 19, 5000)])
+    special = np.array([[0, 0], [12, 16], [12.0, 3.5], [3.5, 16.0], [-0.0, 5], [12.0000001, 5], [-1e-9, 5], [11.999999, 16],
+                        [0.5, 0.5], [6, 8], [np.nan, 3]]).T
+    coords = np.concatenate([coords, special], axis=1).astype(cdt)
+    out = da.map_coordinates(a, coords, order=order)
+    assert out.dtype == a.dtype and out.shape == (coords.shape[1], 3)
+    for c in range(3):
+        np.testing.assert_array_equal(out[:, c], sp_map(a[..., c], coords, order=order))
+    np.testing.assert_array_equal(da.map_coordinates(a[..., 0].copy(), coords, order=order), sp_map(a[..., 0], coords, order=order))
+
+
+def test_map_coordinates_errors():
+    a = np.zeros((4, 4), np.float32)
+    with pytest.raises(NotImplementedError):
+        da.map_coordinates(a, np.zeros((2, 3)), order=3)
+    with pytest.raises(TypeError):
+        da.map_coordinates(a.astype(np.int32), np.zeros((2, 3)))
+    with pytest.raises(ValueError):
+        da.map_coordinates(a, np.zeros((3, 3)))
+
+
+KW = dict(horizontal_bulge=3e-7, vertical_bulge=-2e-7, horizontal_stretch=1e-7, vertical_stretch=-1.5e-7,
+          horizontal_center_offset=5, vertical_center_offset=-3)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.uint8])
+def test_simple_curvature_correction_matches_oracle(dtype):
+    img = synthetic_image(300, 420, 3)
+    if dtype == np.uint8:
+        img = (img * 255).astype(np.uint8)
+    cc = da.CurvatureCorrection(config={})
+    out = cc.simple_curvature_correction(img, **KW)
+    ref = cu.simple_curvature_correction(img, **KW)
+    assert out.dtype == img.dtype and out.shape == img.shape
+    np.testing.assert_array_equal(out, ref)
+    assert not np.array_equal(out, img)
+
+
+def test_correct_array_init_bulge_stretch_matches_oracle_and_caches_grid():
+    img = synthetic_image(240, 320, 3)
+    config = {"init": dict(horizontal_bulge=4e-7, vertical_bulge=1e-7),
+              "bulge": dict(horizontal_bulge=-2e-7, vertical_bulge=3e-7, horizontal_center_offset=4),
+              "stretch": dict(horizontal_stretch=2e-7, vertical_stretch=-1e-7, vertical_center_offset=2)}
+    cc = da.CurvatureCorrection(config=config)
+    out = cc(img)
+    grid, shape = cu.precompute_grid(img.shape, config)
+    np.testing.assert_array_equal(cc.cache["grid"], grid)
+    assert tuple(cc.cache["shape"]) == tuple(shape)
+    np.testing.assert_array_equal(out, cu.transform_image(img, grid, shape))
+    # second image reuses the cached grid; scalar image in, scalar image out
+    gray = np.ascontiguousarray(img[..., 0])
+    np.testing.assert_array_equal(cc(gray), cu.transform_image(gray, grid, shape))
+
+
+def test_crop_step_and_metadata():
+    img = synthetic_image(200, 300, 3)
+    crop = dict(pts_src=[[10, 8], [6, 190], [290, 195], [285, 12]], width=1.5, height=1.0)
+    config = {"crop": crop, "bulge": dict(horizontal_bulge=2e-7)}
+    cc = da.CurvatureCorrection(config=config)
+    out = cc(da.OpticalImage(img, dimensions=[1.0, 1.5]))
+    assert isinstance(out, da.OpticalImage) and out.img.shape == (200, 300, 3)
+    assert out.dimensions == [1.0, 1.5] and list(np.asarray(out.origin)) == [0, 1.0]
+
+    def crop_oracle(pixels, **kw):  # extract_quadrilateral_ROI with the restated OpenCV warp
+        h, w = pixels.shape[:2]
+        ar = kw["width"] / kw["height"]
+        width, height = min(w, int(ar * float(h))), min(h, int(1.0 / ar * float(w)))
+        dst = np.array([[0, 0], [0, height - 1], [width - 1, height - 1], [width - 1, 0]], np.float32)
+        p = wo.get_perspective_transform(np.asarray(kw["pts_src"], np.float32), dst)
+        return wo.warp_perspective(pixels.astype(np.float32), p, width, height).astype(pixels.dtype)
+
+    grid, shape = cu.precompute_grid(img.shape, config, crop=crop_oracle)
+    np.testing.assert_array_equal(cc.cache["grid"], grid)
+    np.testing.assert_array_equal(out.img, cu.transform_image(img, grid, shape))
+
+
+def test_full_size_gather_properties():
+    """4000 x 8000 x 3 float32: the identity grid returns the image; a half-pixel shift is the neighbour mean."""
+    img = synthetic_image(4000, 8000, 3)
+    cc = da.CurvatureCorrection(config={})
+    np.testing.assert_array_equal(cc.simple_curvature_correction(img), img)
+    r, c = np.meshgrid(np.arange(100, dtype=np.float64) + 0.5, np.arange(200, dtype=np.float64), indexing="ij")
+    out = da.map_coordinates(img, np.array([r.ravel(), c.ravel()])).reshape(100, 200, 3)
+    ref = (img[:100, :200].astype(np.float64) * 0.5 + img[1:101, :200].astype(np.float64) * 0.5).astype(np.float32)
+    np.testing.assert_array_equal(out, ref)
