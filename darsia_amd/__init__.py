@@ -40,3 +40,4 @@ from .corrections import (  # noqa: F401,E402
     extract_quadrilateral_ROI,
     map_coordinates,
 )
+from .resizing import Resize, cv_resize, equalize_voxel_size, resize, uniform_refinement  # noqa: F401,E402

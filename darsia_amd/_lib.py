@@ -28,7 +28,7 @@ EXPORTS = (
     "dxh_tvd_partial_norms", "dxh_tvd_sync", "dxh_jacobi_solve", "dxh_diff", "dxh_chambolle",
     "dxh_warp_patches", "dxh_tps_eval", "dxh_affine_color",
     "dxh_solver_create", "dxh_solver_destroy", "dxh_solver_set_params", "dxh_solver_solve", "dxh_solver_get_params",
-    "dxh_tvd_set_solver", "dxh_tv_bregman_gs", "dxh_map_coordinates",
+    "dxh_tvd_set_solver", "dxh_tv_bregman_gs", "dxh_map_coordinates", "dxh_resize",
     "dxh_tvd_energy", "dxh_tvd_adapt_ell", "dxh_tvd_set_base", "dxh_tvd_set_cleaning_filter", "dxh_tvd_upload_signal", "dxh_tvd_download_model",
 )
 
@@ -55,6 +55,16 @@ class SolverDesc(C.Structure):
         ("kind", C.c_int32), ("depth", C.c_int32), ("smoother_iterations", C.c_int32), ("maxiter", C.c_int32),
         ("heterogeneous", C.c_int32), ("reserved", C.c_int32),
         ("tol", C.c_double), ("h", C.c_double), ("stream", C.c_void_p),
+    ]
+
+
+class ResizePlan(C.Structure):
+    """dxh_resize_plan (include/darsia_hip.h)."""
+    _fields_ = [
+        ("struct_size", C.c_int32), ("mode", C.c_int32), ("isx", C.c_int32), ("isy", C.c_int32),
+        ("xi", C.c_void_p), ("xw", C.c_void_p), ("yi", C.c_void_p), ("yw", C.c_void_p),
+        ("xptr", C.c_void_p), ("xsrc", C.c_void_p), ("xalpha", C.c_void_p),
+        ("yptr", C.c_void_p), ("ysrc", C.c_void_p), ("yalpha", C.c_void_p),
     ]
 
 
@@ -107,6 +117,7 @@ def _declare(lib):
     lib.dxh_solver_solve.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_int32)]
     lib.dxh_solver_get_params.argtypes = [vp, vp, vp]
     lib.dxh_tvd_set_solver.argtypes = [vp, i, i, i, i, dbl]
+    lib.dxh_resize.argtypes = [i, i, i64, i64, i, vp, i64, i64, C.POINTER(ResizePlan), vp]
     lib.dxh_map_coordinates.argtypes = [i, i, i64, i64, i, vp, i, vp, vp, i64, i, dbl, vp]
     lib.dxh_tv_bregman_gs.argtypes = [i, i, i64, i64, i64, vp, vp, dbl, i, dbl, i, C.POINTER(i), C.POINTER(dbl)]
     lib.dxh_tvd_adapt_ell.argtypes = [vp]

@@ -184,7 +184,7 @@ static int check_device(int device) {
 
 // ---- scipy.ndimage.map_coordinates(channel, grid, order = 0 | 1) with the default mode "constant" ---------------
 // CurvatureCorrection._transform_image (corrections/shape/curvature.py:921-957).  SciPy's arithmetic (third-party,
-// ndimage/src/ni_interpolation.c; restated and checked against SciPy in oracle/map_coordinates_numpy.py):
+// ndimage/src/ni_interpolation.c; restated and checked against SciPy in oracle/curvature_numpy.py):
 // a point with a coordinate < 0 or > n-1 yields cval; otherwise order 1 takes start = floor(c), weights
 // (1 - t, t) in double, out-of-range taps mirrored (they carry weight 0), and sums the four taps row-major as
 // ((v * w_row) * w_col); order 0 takes floor(c + 0.5).  Integer outputs round half away from zero (unsigned: +0.5).
@@ -238,6 +238,88 @@ __global__ void __launch_bounds__(256) k_map_coords(const T* __restrict__ img, l
                 t = t + v;
             }
         o[k] = mc_cast<T>(t);
+    }
+}
+
+
+// ---- cv2.resize per channel (restoration/resize.py:150-176), OpenCV's generic code paths restated in
+// oracle/resize_numpy.py (third-party arithmetic, parity unpinned: no OpenCV in this image).  The tap / area
+// tables are built on the host (a few thousand entries) exactly as OpenCV builds xofs / alpha / beta / xtab / ytab;
+// one thread per destination pixel and channel applies them with OpenCV's order of operations. ---------------
+struct ResizePlanDev {
+    int mode;  // 0 nearest, 1 bilinear, 2 area with integer scales, 3 area with weight tables
+    int isx, isy;
+    const int* xi; const float* xw; const int* yi; const float* yw;
+    const int* xptr; const int* xsrc; const float* xalpha;
+    const int* yptr; const int* ysrc; const float* yalpha;
+};
+
+template <typename T> struct ResizeWT { typedef float type; };
+template <> struct ResizeWT<double> { typedef double type; };
+template <typename T> __device__ __forceinline__ T rs_cast(float v) { return (T)v; }
+template <> __device__ __forceinline__ unsigned char rs_cast<unsigned char>(float v) {
+    const float r = rintf(v);  // cvRound: half to even
+    return (unsigned char)(r < 0.f ? 0.f : (r > 255.f ? 255.f : r));
+}
+template <typename T> __device__ __forceinline__ T rs_cast_d(double v) { return (T)v; }
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_resize(const T* __restrict__ src, int H, int W, int C, ResizePlanDev p, int DH, int DW,
+                                                 T* __restrict__ dst) {
+    typedef typename ResizeWT<T>::type WT;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)DH * DW * C) return;
+    const int k = (int)(i % C);
+    const int dx = (int)((i / C) % DW), dy = (int)(i / ((long long)C * DW));
+    auto S = [&](int y, int x) -> T { return src[((long long)y * W + x) * C + k]; };
+    if (p.mode == 0) {
+        dst[i] = S(p.yi[dy], p.xi[dx]);
+    } else if (p.mode == 1) {
+        const int x0 = p.xi[dx], x1 = x0 + 1 < W ? x0 + 1 : W - 1, y0 = p.yi[dy], y1 = y0 + 1 < H ? y0 + 1 : H - 1;
+        const float fx = p.xw[dx], fy = p.yw[dy];
+        const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+        if constexpr (sizeof(T) == 1) {
+            auto fix = [](float w) -> int { float r = rintf(w * 2048.f); r = r < -32768.f ? -32768.f : (r > 32767.f ? 32767.f : r); return (int)r; };
+            const int ia0 = fix(a0), ia1 = fix(a1), ib0 = fix(b0), ib1 = fix(b1);
+            const int r0 = (int)S(y0, x0) * ia0 + (int)S(y0, x1) * ia1, r1 = (int)S(y1, x0) * ia0 + (int)S(y1, x1) * ia1;
+            int v = (((ib0 * (r0 >> 4)) >> 16) + ((ib1 * (r1 >> 4)) >> 16) + 2) >> 2;
+            dst[i] = (T)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        } else {
+            const WT r0 = (WT)S(y0, x0) * (WT)a0 + (WT)S(y0, x1) * (WT)a1;
+            const WT r1 = (WT)S(y1, x0) * (WT)a0 + (WT)S(y1, x1) * (WT)a1;
+            dst[i] = (T)(r0 * (WT)b0 + r1 * (WT)b1);
+        }
+    } else if (p.mode == 2) {
+        const int y0 = dy * p.isy, x0 = dx * p.isx;
+        const int ny = y0 + p.isy <= H ? p.isy : (H - y0 > 0 ? H - y0 : 0), nx = x0 + p.isx <= W ? p.isx : (W - x0 > 0 ? W - x0 : 0);
+        const float scl = 1.f / (float)(p.isx * p.isy);
+        if (ny == 0 || nx == 0) {
+            dst[i] = (T)0;
+        } else if constexpr (sizeof(T) == 1) {
+            int s = 0;
+            for (int y = 0; y < ny; ++y)
+                for (int x = 0; x < nx; ++x) s += (int)S(y0 + y, x0 + x);
+            if (ny * nx < p.isx * p.isy) dst[i] = rs_cast<T>((float)s / (float)(ny * nx));
+            else if (p.isx == 2 && p.isy == 2) dst[i] = (T)((s + 2) >> 2);
+            else dst[i] = rs_cast<T>((float)s * scl);
+        } else {
+            WT acc = WT(0);
+            for (int y = 0; y < ny; ++y)
+                for (int x = 0; x < nx; ++x) acc = acc + (WT)S(y0 + y, x0 + x);
+            if (ny * nx < p.isx * p.isy) dst[i] = (T)((float)acc / (float)(ny * nx));
+            else dst[i] = (T)(acc * (WT)scl);
+        }
+    } else {
+        WT sum = WT(0);
+        for (int j = p.yptr[dy]; j < p.yptr[dy + 1]; ++j) {
+            const int sy = p.ysrc[j];
+            WT buf = WT(0);
+            for (int q = p.xptr[dx]; q < p.xptr[dx + 1]; ++q) buf = buf + (WT)S(sy, p.xsrc[q]) * (WT)p.xalpha[q];
+            const WT t = (WT)p.yalpha[j] * buf;
+            sum = j == p.yptr[dy] ? t : sum + t;
+        }
+        if constexpr (sizeof(T) == 1) dst[i] = rs_cast<T>((float)sum);
+        else dst[i] = (T)sum;
     }
 }
 
@@ -388,6 +470,69 @@ int dxh_map_coordinates(int device, int dtype, int64_t H, int64_t W, int C, cons
 #undef DXH_MC
     DXH_HIP(hipGetLastError());
     DXH_HIP(hipMemcpyAsync(out, dout_, esz * (size_t)n * C, hipMemcpyDeviceToHost, d.st));
+    DXH_HIP(hipStreamSynchronize(d.st));
+    return DXH_OK;
+}
+
+int dxh_resize(int device, int dtype, int64_t H, int64_t W, int C, const void* src, int64_t DH, int64_t DW,
+               const dxh_resize_plan* plan, void* dst) {
+    DXH_REQUIRE(src && dst && plan, "null argument");
+    DXH_REQUIRE(plan->struct_size == (int32_t)sizeof(dxh_resize_plan), "dxh_resize_plan size mismatch");
+    DXH_REQUIRE(dtype == 0 || dtype == 1 || dtype == 2, "dtype: 0 float32, 1 float64, 2 uint8");
+    DXH_REQUIRE(H >= 1 && W >= 1 && C >= 1 && DH >= 1 && DW >= 1, "bad shape");
+    DXH_REQUIRE(H < (1 << 30) && W < (1 << 30) && DH < (1 << 30) && DW < (1 << 30), "image too large");
+    DXH_REQUIRE(plan->mode >= 0 && plan->mode <= 3, "unknown resize mode %d", plan->mode);
+    int rc = check_device(device);
+    if (rc) return rc;
+    const size_t esz = dtype == 0 ? 4 : dtype == 1 ? 8 : 1;
+    Dev d;
+    DXH_HIP(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking));
+    ResizePlanDev p{};
+    p.mode = plan->mode; p.isx = plan->isx; p.isy = plan->isy;
+    auto up = [&](const void* host, size_t bytes, const void** devp) -> int {
+        *devp = nullptr;
+        if (!host || !bytes) return DXH_OK;
+        void* q = nullptr;
+        int r = d.alloc(&q, bytes);
+        if (r) return r;
+        DXH_HIP(hipMemcpyAsync(q, host, bytes, hipMemcpyHostToDevice, d.st));
+        *devp = q;
+        return DXH_OK;
+    };
+    if (plan->mode == 0 || plan->mode == 1) {
+        DXH_REQUIRE(plan->xi && plan->yi && (plan->mode == 0 || (plan->xw && plan->yw)), "tap tables missing");
+        for (int64_t x = 0; x < DW; ++x) DXH_REQUIRE(plan->xi[x] >= 0 && plan->xi[x] < W, "x tap %lld out of range", (long long)x);
+        for (int64_t y = 0; y < DH; ++y) DXH_REQUIRE(plan->yi[y] >= 0 && plan->yi[y] < H, "y tap %lld out of range", (long long)y);
+        if ((rc = up(plan->xi, sizeof(int) * DW, (const void**)&p.xi)) || (rc = up(plan->yi, sizeof(int) * DH, (const void**)&p.yi)) ||
+            (rc = up(plan->xw, sizeof(float) * DW, (const void**)&p.xw)) || (rc = up(plan->yw, sizeof(float) * DH, (const void**)&p.yw)))
+            return rc;
+    } else if (plan->mode == 2) {
+        DXH_REQUIRE(plan->isx >= 1 && plan->isy >= 1, "block size must be positive");
+    } else {
+        DXH_REQUIRE(plan->xptr && plan->xsrc && plan->xalpha && plan->yptr && plan->ysrc && plan->yalpha, "area tables missing");
+        const int nxe = plan->xptr[DW], nye = plan->yptr[DH];
+        for (int64_t x = 0; x < DW; ++x) DXH_REQUIRE(plan->xptr[x] <= plan->xptr[x + 1], "x table not monotone");
+        for (int64_t y = 0; y < DH; ++y) DXH_REQUIRE(plan->yptr[y] <= plan->yptr[y + 1], "y table not monotone");
+        for (int q = 0; q < nxe; ++q) DXH_REQUIRE(plan->xsrc[q] >= 0 && plan->xsrc[q] < W, "x table entry %d out of range", q);
+        for (int q = 0; q < nye; ++q) DXH_REQUIRE(plan->ysrc[q] >= 0 && plan->ysrc[q] < H, "y table entry %d out of range", q);
+        if ((rc = up(plan->xptr, sizeof(int) * (DW + 1), (const void**)&p.xptr)) || (rc = up(plan->xsrc, sizeof(int) * nxe, (const void**)&p.xsrc)) ||
+            (rc = up(plan->xalpha, sizeof(float) * nxe, (const void**)&p.xalpha)) || (rc = up(plan->yptr, sizeof(int) * (DH + 1), (const void**)&p.yptr)) ||
+            (rc = up(plan->ysrc, sizeof(int) * nye, (const void**)&p.ysrc)) || (rc = up(plan->yalpha, sizeof(float) * nye, (const void**)&p.yalpha)))
+            return rc;
+    }
+    void *dsrc = nullptr, *ddst = nullptr;
+    const size_t nsrc = esz * (size_t)H * W * C, ndst = esz * (size_t)DH * DW * C;
+    if ((rc = d.alloc(&dsrc, nsrc)) || (rc = d.alloc(&ddst, ndst))) return rc;
+    DXH_HIP(hipMemcpyAsync(dsrc, src, nsrc, hipMemcpyHostToDevice, d.st));
+    const long long total = (long long)DH * DW * C;
+    const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
+    switch (dtype) {
+        case 0: hipLaunchKernelGGL((k_resize<float>), grid, blk, 0, d.st, (const float*)dsrc, (int)H, (int)W, C, p, (int)DH, (int)DW, (float*)ddst); break;
+        case 1: hipLaunchKernelGGL((k_resize<double>), grid, blk, 0, d.st, (const double*)dsrc, (int)H, (int)W, C, p, (int)DH, (int)DW, (double*)ddst); break;
+        default: hipLaunchKernelGGL((k_resize<unsigned char>), grid, blk, 0, d.st, (const unsigned char*)dsrc, (int)H, (int)W, C, p, (int)DH, (int)DW, (unsigned char*)ddst); break;
+    }
+    DXH_HIP(hipGetLastError());
+    DXH_HIP(hipMemcpyAsync(dst, ddst, ndst, hipMemcpyDeviceToHost, d.st));
     DXH_HIP(hipStreamSynchronize(d.st));
     return DXH_OK;
 }

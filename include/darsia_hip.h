@@ -301,6 +301,32 @@ int dxh_affine_color(int device, int in_dtype, int64_t npix, const void* img, co
 int dxh_map_coordinates(int device, int dtype, int64_t H, int64_t W, int C, const void* img, int coord_dtype,
                         const void* rows, const void* cols, int64_t n, int order, double cval, void* out);
 
+/*
+ * cv2.resize of every channel of an (H, W, C) image -- Resize.__call__ (restoration/resize.py:150-176).  The host
+ * builds OpenCV's tap tables (darsia_amd/resizing.py); the device applies them with OpenCV's order of operations.
+ * mode 0: nearest (xi, yi = source indices); 1: bilinear (xi, yi = first tap, xw, yw = float weight of the second
+ * tap); 2: INTER_AREA with integer scales isx, isy; 3: INTER_AREA with weight tables in CSR form (xptr has DW + 1
+ * entries, xsrc / xalpha one per table entry; likewise y).  dtype: 0 float32, 1 float64, 2 uint8.
+ */
+typedef struct dxh_resize_plan {
+    int32_t struct_size; /* sizeof(dxh_resize_plan) */
+    int32_t mode;
+    int32_t isx, isy;
+    const int32_t* xi;
+    const float* xw;
+    const int32_t* yi;
+    const float* yw;
+    const int32_t* xptr;
+    const int32_t* xsrc;
+    const float* xalpha;
+    const int32_t* yptr;
+    const int32_t* ysrc;
+    const float* yalpha;
+} dxh_resize_plan;
+
+int dxh_resize(int device, int dtype, int64_t H, int64_t W, int C, const void* src, int64_t DH, int64_t DW,
+               const dxh_resize_plan* plan, void* dst);
+
 #ifdef __cplusplus
 }
 #endif
