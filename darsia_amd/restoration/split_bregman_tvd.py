@@ -20,6 +20,7 @@ Divergences from the reference, all deliberate:
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Optional, Union
 
 import numpy as np
@@ -128,8 +129,9 @@ class DeviceTVD:
         _lib.check(self.lib.dxh_tvd_energy(self._h, 1 if previous else 0, C.byref(v)))
         return v.value
 
-    def download(self, want_split=False):
-        u = np.empty(self.shape, self.dtype)
+    def download(self, want_split=False, out: Optional[np.ndarray] = None):
+        u = np.empty(self.shape, self.dtype) if out is None else out
+        assert u.shape == self.shape and u.dtype == self.dtype and u.flags.c_contiguous
         if not want_split:
             _lib.check(self.lib.dxh_tvd_download(self._h, _lib.ptr(u), None, None))
             return u
@@ -212,7 +214,29 @@ def split_bregman_tvd(
                 if eps is not None and r.converged:
                     break
         else:
-            st.run(max_num_iter, solver.maxiter, solver.tol, eps=eps, isotropic=isotropic)
+            # The result array is allocated and its pages are touched on this thread WHILE the device iterates (the
+            # blocking C call runs on a helper thread and holds no GIL): a fresh 384 MB array costs ~14 ms of page
+            # faults, which otherwise land inside the device-to-host copy (22-36 ms instead of 7 ms, measured).
+            out = np.empty(img.shape, img.dtype) if x0 is None else None
+            box = {}
+
+            def work():
+                try:
+                    box["r"] = st.run(max_num_iter, solver.maxiter, solver.tol, eps=eps, isotropic=isotropic)
+                except BaseException as e:  # noqa: BLE001 -- re-raised on the calling thread
+                    box["e"] = e
+
+            if out is not None and out.nbytes >= (8 << 20):
+                th = threading.Thread(target=work)
+                th.start()
+                out.reshape(-1)[:: max(1, 4096 // out.itemsize)] = 0
+                th.join()
+            else:
+                work()
+            if "e" in box:
+                raise box["e"]
+            if x0 is None:
+                return st.download(out=out)
         if x0 is None:
             return st.download()
         u, d, b = st.download(want_split=True)
