@@ -331,29 +331,44 @@ struct CoefIn {
     int has_ell;
 };
 
+// the four derived coefficients of one element from the values of the given inputs at that element
+// (mu_v / omega_v / ell_v are only read where the corresponding plane exists)
 template <typename T>
-__global__ void __launch_bounds__(256) k_coef_planes(Geom g, CoefIn<T> in, T* __restrict__ ell_o, T* __restrict__ diag_o,
-                                                      T* __restrict__ dsc_o, T* __restrict__ kq_o) {
-    ElemIdx e;
-    if (!elem_index(g, e)) return;
+__device__ __forceinline__ void derive_coefs(const CoefIn<T>& in, T mu_v, T omega_v, T ell_v, T& ell, T& diag, T& dsc, T& kq) {
     const bool ell_is_arr = in.ell != nullptr || (!in.has_ell && in.mu != nullptr);
-    T ell, lap, ell_h2;
+    T lap, ell_h2;
     if (ell_is_arr) {
-        ell = in.ell ? in.ell[e.off] : T(2) * in.mu[e.off];
-        lap = ((ell * T(2)) * T(in.dim)) / in.h2;
-        ell_h2 = ell / in.h2;
+        ell = in.ell ? ell_v : T(2) * mu_v;
+        lap = (ell * T(2)) * T(in.dim);
+        ell_h2 = ell;
+        if (in.h2 != T(1)) {  // x / 1 == x: skip the two divisions for the usual h = 1
+            lap = lap / in.h2;
+            ell_h2 = ell / in.h2;
+        }
     } else {
         ell = in.ell_s;
         lap = in.two_dim_over_h2_ell_s;
         ell_h2 = in.ell_over_h2_s;
     }
-    const T omega = in.omega ? in.omega[e.off] : in.omega_s;
-    const T diag = omega + lap;
-    const T mu = in.mu ? in.mu[e.off] : in.mu_s;
+    const T omega = in.omega ? omega_v : in.omega_s;
+    diag = omega + lap;
+    const T mu = in.mu ? mu_v : in.mu_s;
+    dsc = diag / ell_h2;
+    kq = mu / ell;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_coef_planes(Geom g, CoefIn<T> in, T* __restrict__ ell_o, T* __restrict__ diag_o,
+                                                      T* __restrict__ dsc_o, T* __restrict__ kq_o) {
+    ElemIdx e;
+    if (!elem_index(g, e)) return;
+    T ell, diag, dsc, kq;
+    derive_coefs<T>(in, in.mu ? in.mu[e.off] : T(0), in.omega ? in.omega[e.off] : T(0), in.ell ? in.ell[e.off] : T(0), ell,
+                    diag, dsc, kq);
     ell_o[e.off] = ell;
     diag_o[e.off] = diag;
-    dsc_o[e.off] = diag / ell_h2;
-    if (kq_o) kq_o[e.off] = mu / ell;
+    dsc_o[e.off] = dsc;
+    if (kq_o) kq_o[e.off] = kq;
 }
 
 // finite differences, utils/derivatives.py:16-59
@@ -556,6 +571,11 @@ struct FusedArgs {
     int remap;         // XCD-aware block -> tile mapping (block_to_tile)
     Coef<T> c;
     CoefPlanes<T> cp;
+    // heterogeneous coefficients: when `derive` is set the kernel reads only the planes the caller gave (mu, omega,
+    // ell -- usually just mu) and recomputes ell / diag / dsc / kq per element (derive_coefs: the very expressions that
+    // filled cp) instead of reading four derived planes: 32 instead of 44 bytes per element for an array-valued mu
+    CoefIn<T> ci;
+    int derive;
     // optional (k_fused_multi): per-wave partial sums of (u_{n+s+1} - u_{n+s})^2 for each fused iteration s,
     // layout [K][nwaves_total]; nullptr = off.  Lets the eps test of split_bregman_tvd.py:161-175 run on
     // K-iteration launches without any extra pass over the data.
@@ -640,7 +660,37 @@ __global__ void __launch_bounds__(256) k_fused(FusedArgs<T> a) {
     const T* p_diag = HET ? a.cp.diag + xl : nullptr;
     const T* p_dsc = HET ? a.cp.dsc + xl : nullptr;
     const T* p_kq = HET ? a.cp.kq + xl : nullptr;
-
+    const bool derive = HET && a.derive != 0;  // uniform
+    // heterogeneous coefficients of one row: the loads (four derived planes, or the given input planes) are issued
+    // early like the other operands; `finish_coefs` turns them into ell / diag / dsc / kq when the row becomes current
+    auto load_raw = [&](int64_t row, T (&c0)[N], T (&c1)[N], T (&c2)[N], T (&c3)[N]) {
+        if (derive) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) c0[j] = c1[j] = c2[j] = c3[j] = T(0);
+            if (a.ci.mu) load_vec(a.ci.mu + xl + row * a.pitch, c0);
+            if (a.ci.omega) load_vec(a.ci.omega + xl + row * a.pitch, c1);
+            if (a.ci.ell) load_vec(a.ci.ell + xl + row * a.pitch, c2);
+        } else {
+            load_vec(p_ell + row * a.pitch, c0);
+            load_vec(p_diag + row * a.pitch, c1);
+            load_vec(p_dsc + row * a.pitch, c2);
+            load_vec(p_kq + row * a.pitch, c3);
+        }
+    };
+    auto finish_coefs = [&](const T (&c0)[N], const T (&c1)[N], const T (&c2)[N], const T (&c3)[N], T (&ell_o)[N],
+                            T (&diag_o)[N], T (&dsc_o)[N], T (&kq_o)[N]) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            if (derive) {
+                derive_coefs<T>(a.ci, c0[j], c1[j], c2[j], ell_o[j], diag_o[j], dsc_o[j], kq_o[j]);
+            } else {
+                ell_o[j] = c0[j];
+                diag_o[j] = c1[j];
+                dsc_o[j] = c2[j];
+                kq_o[j] = c3[j];
+            }
+        }
+    };
     const int64_t P = a.pitch;
     auto clampr = [&](int64_t r) -> int64_t { return r < 0 ? 0 : (r > a.n0 - 1 ? a.n0 - 1 : r); };
 
@@ -663,8 +713,9 @@ __global__ void __launch_bounds__(256) k_fused(FusedArgs<T> a) {
         load_vec(q0_in + rm * P, q0v);
         load_vec(q1_in + rm * P, q1v);
         if constexpr (HET) {
-            load_vec(p_ell + rm * P, ellm);
-            load_vec(p_kq + rm * P, kqm);
+            T r0[N], r1[N], r2[N], r3[N], dg[N], ds[N];
+            load_raw(rm, r0, r1, r2, r3);
+            finish_coefs(r0, r1, r2, r3, ellm, dg, ds, kqm);
         }
 #pragma unroll
         for (int j = 0; j < N; ++j) {
@@ -683,10 +734,9 @@ __global__ void __launch_bounds__(256) k_fused(FusedArgs<T> a) {
     load_vec(q0_in + R0 * P, q0r);
     load_vec(q1_in + R0 * P, q1r);
     if constexpr (HET) {
-        load_vec(p_ell + R0 * P, ell);
-        load_vec(p_diag + R0 * P, diag);
-        load_vec(p_dsc + R0 * P, dsc);
-        load_vec(p_kq + R0 * P, kq);
+        T r0[N], r1[N], r2[N], r3[N];
+        load_raw(R0, r0, r1, r2, r3);
+        finish_coefs(r0, r1, r2, r3, ell, diag, dsc, kq);
     }
 
     for (int64_t r = R0; r <= R1; ++r) {
@@ -698,12 +748,7 @@ __global__ void __launch_bounds__(256) k_fused(FusedArgs<T> a) {
             load_vec(of + rn * P, frn);
             load_vec(q0_in + rn * P, q0n);
             load_vec(q1_in + rn * P, q1n);
-            if constexpr (HET) {
-                load_vec(p_ell + rn * P, elln);
-                load_vec(p_diag + rn * P, diagn);
-                load_vec(p_dsc + rn * P, dscn);
-                load_vec(p_kq + rn * P, kqn);
-            }
+            if constexpr (HET) load_raw(rn, elln, diagn, dscn, kqn);  // raw planes; finished at the rotation
         }
 
         T un[N], b0c[N], t0c[N];
@@ -791,13 +836,8 @@ __global__ void __launch_bounds__(256) k_fused(FusedArgs<T> a) {
             fr[j] = frn[j];
             q0r[j] = q0n[j];
             q1r[j] = q1n[j];
-            if constexpr (HET) {
-                ell[j] = elln[j];
-                diag[j] = diagn[j];
-                dsc[j] = dscn[j];
-                kq[j] = kqn[j];
-            }
         }
+        if constexpr (HET) finish_coefs(elln, diagn, dscn, kqn, ell, diag, dsc, kq);
     }
 }
 
@@ -873,6 +913,8 @@ struct PipeState {
     T q0l[2][N];   // loaded level-0 q0 rows
     T of0[N];      // omega*f of stage 0's row
     T pf[2][4][N]; // prefetch distance 2: rows in flight two steps ahead (u, omega*f, q0, q1), slot = phase parity
+    T coef[K][4][N];  // heterogeneous coefficients (ell, diag, dsc, kq) of each stage's current row
+    T craw[2][3][N];  // prefetched raw coefficient rows (mu, omega, ell as given), slot = phase parity
     T ofr[K][N];   // pair roles: omega*f delay line in registers (ofr[s] = row of local stage s)
     T q1r[K][2][N];// pair roles: inter-stage Q1 hand-off in registers
 };
@@ -889,10 +931,14 @@ struct PipeLds {
 // step<PH, ROLE>: ROLE 0 = SOLO (one wave runs all K stages: HBM in, HBM out), 1 = HEAD (first K stages of a
 // wave pair: HBM in, the pair's shared LDS rings out), 2 = TAIL (last K stages of a pair: shared LDS rings in,
 // HBM out).
-template <typename T, int C, bool COUPLED, bool ISO, int K, bool NTS, bool EDGE, bool NORM>
+// HET: array-valued coefficients.  Each stage carries the derived coefficients (ell, diag, dsc, kq) of its current
+// row in registers; stage 0 derives them from the prefetched rows of the given planes (derive_coefs) and they move
+// down one stage per step.  Divisions are IEEE divisions (the divisors differ per element).
+template <typename T, int C, bool COUPLED, bool ISO, int K, bool NTS, bool EDGE, bool NORM, bool HET = false>
 struct Pipe {
     static constexpr int N = VecOf<T>::N;
     static constexpr bool DPP = true;
+    CoefIn<T> ci;
     T* xlds;            // pair roles: this lane's vector in slot 0 of the pair's shared rings (U, Q0, Q1, of: 4 slots each)
     __device__ __forceinline__ void xput(int slot, const T (&v)[N]) const { store_vec(xlds + slot * (kWave * N), v); }
     __device__ __forceinline__ void xget(int slot, T (&v)[N]) const { load_vec(xlds + slot * (kWave * N), v); }
@@ -928,6 +974,21 @@ struct Pipe {
         return reinterpret_cast<T*>(reinterpret_cast<char*>(plane + row * P) + voff);
     }
 
+    // raw rows of the given coefficient planes (absent planes leave zeros that derive_coefs never reads)
+    __device__ __forceinline__ void load_craw(int64_t row, T (&raw)[3][N]) const {
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int j = 0; j < N; ++j) raw[q][j] = T(0);
+        if (ci.mu) load_vec(at(ci.mu, row), raw[0]);
+        if (ci.omega) load_vec(at(ci.omega, row), raw[1]);
+        if (ci.ell) load_vec(at(ci.ell, row), raw[2]);
+    }
+    __device__ __forceinline__ void finish_coef(const T (&raw)[3][N], T (&cf)[4][N]) const {
+#pragma unroll
+        for (int j = 0; j < N; ++j) derive_coefs<T>(ci, raw[0][j], raw[1][j], raw[2][j], cf[0][j], cf[1][j], cf[2][j], cf[3][j]);
+    }
+
     template <int PH, int ROLE = 0>
     __device__ __forceinline__ void step(PipeState<T, K>& st, float (&inc)[NORM ? K : 1][N], const int64_t r) const {
         constexpr int PFD = (K >= 4 && ROLE == 0) ? 2 : 1;  // prefetch distance in steps
@@ -954,6 +1015,7 @@ struct Pipe {
             load_vec(at(of_p, rn), frn);
             load_vec(at(q0_in, rn), st.q0l[(PH + 1) & 1]);
             load_vec(at(q1_in, rn), st.q1l[(PH + 1) & 1]);
+            if constexpr (HET) load_craw(rn, st.craw[(PH + 1) & 1]);
         } else {
             const int64_t rn = clampr(r + 2);
             load_vec(at(u_in, clampr(r + 3)), st.pf[PH & 1][0]);
@@ -1020,11 +1082,17 @@ struct Pipe {
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 T qq[2] = {(s == 0) ? st.q0l[lcur][j] : q0h[j], q1c[j]}, d[2], b[2];
-                split_vars<T, 2, ISO, true>(qq, kq, d, b);
+                if constexpr (HET) {
+                    split_vars<T, 2, ISO, false>(qq, st.coef[s][3][j], d, b);
+                    t0c[j] = st.coef[s][0][j] * (b[0] - d[0]);
+                    t1c[j] = st.coef[s][0][j] * (b[1] - d[1]);
+                } else {
+                    split_vars<T, 2, ISO, true>(qq, kq, d, b);
+                    t0c[j] = ell * (b[0] - d[0]);
+                    t1c[j] = ell * (b[1] - d[1]);
+                }
                 b0c[j] = b[0];
                 b1c[j] = b[1];
-                t0c[j] = ell * (b[0] - d[0]);
-                t1c[j] = ell * (b[1] - d[1]);
             }
             if (p == 0) {  // replicate the row above the image
 #pragma unroll
@@ -1068,7 +1136,10 @@ struct Pipe {
                 load_vec(at(q0_in, rn), st.q0l[0]);
                 load_vec(at(q1_in, rn), st.q1l[0]);
             }
-            {
+            if constexpr (HET) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) un[j] = rhs[j] / st.coef[s][1][j] + acc[j] / st.coef[s][2][j];
+            } else {
                 T lo = t_min(t_abs(rhs[0]), t_abs(acc[0]));
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
@@ -1140,6 +1211,16 @@ struct Pipe {
                 for (int j = 0; j < N; ++j) q0h[j] = q0o[j];
             }
         });
+        if constexpr (HET) {
+            // the coefficients follow their rows down the pipeline; stage 0 gets the prefetched next row
+#pragma unroll
+            for (int s2 = K - 1; s2 >= 1; --s2)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int j = 0; j < N; ++j) st.coef[s2][q][j] = st.coef[s2 - 1][q][j];
+            finish_coef(st.craw[(PH + 1) & 1], st.coef[0]);
+        }
         if constexpr (ROLE != 0) {
             return;  // tail: the next step reads its rows from the shared rings; head: loaded in place above
         }
@@ -1197,6 +1278,7 @@ __device__ __forceinline__ bool pipe_setup(PipeT& pp, const FusedArgs<T>& a, con
     pp.kq = a.c.kq;
     pp.rdiag = a.c.rdiag;
     pp.rdsc = a.c.rdsc;
+    pp.ci = a.ci;
     return true;
 }
 
@@ -1225,11 +1307,24 @@ __device__ __forceinline__ void pipe_state_zero(PipeState<T, K>& st) {
         for (int j = 0; j < N; ++j) st.q0l[i][j] = st.q1l[i][j] = T(0);
 #pragma unroll
     for (int j = 0; j < N; ++j) st.of0[j] = T(0);
+    // heterogeneous coefficients of the not yet started stages: 1 keeps the discarded leading rows finite
+#pragma unroll
+    for (int l = 0; l < K; ++l)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < N; ++j) st.coef[l][q][j] = T(1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int j = 0; j < N; ++j) st.craw[i][q][j] = T(0);
 }
 
 // Prologue of a wave that reads level 0 from HBM (solo / head): phase 0 at row rs, rows rs-1, rs, rs+1 of u in
 // ring slots 3, 0, 1, the carried (t0, b0) of row rs-1 recomputed from the stored q.
-template <int PFD, bool ISO, typename T, int K, typename PipeT>
+template <int PFD, bool ISO, bool HET = false, typename T, int K, typename PipeT>
 __device__ __forceinline__ void pipe_prologue(const PipeT& pp, PipeState<T, K>& st, const int64_t rs) {
     constexpr int N = VecOf<T>::N;
     load_vec(pp.at(pp.u_in, pp.clampr(rs - 1)), st.U[0][3]);
@@ -1248,11 +1343,24 @@ __device__ __forceinline__ void pipe_prologue(const PipeT& pp, PipeState<T, K>& 
     T q0v[N], q1v[N];
     load_vec(pp.at(pp.q0_in, rm), q0v);
     load_vec(pp.at(pp.q1_in, rm), q1v);
+    T cfm[4][N];
+    if constexpr (HET) {
+        T raw[3][N];
+        pp.load_craw(rm, raw);
+        pp.finish_coef(raw, cfm);
+        pp.load_craw(pp.clampr(rs), raw);
+        pp.finish_coef(raw, st.coef[0]);
+    }
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         T qq[2] = {q0v[j], q1v[j]}, d[2], b[2];
-        split_vars<T, 2, ISO, true>(qq, pp.kq, d, b);
-        st.t0[0][1][j] = pp.ell * (b[0] - d[0]);  // parity "prv" of phase 0
+        if constexpr (HET) {
+            split_vars<T, 2, ISO, false>(qq, cfm[3][j], d, b);
+            st.t0[0][1][j] = cfm[0][j] * (b[0] - d[0]);
+        } else {
+            split_vars<T, 2, ISO, true>(qq, pp.kq, d, b);
+            st.t0[0][1][j] = pp.ell * (b[0] - d[0]);  // parity "prv" of phase 0
+        }
         st.b0[0][1][j] = b[0];
     }
 }
@@ -1272,11 +1380,12 @@ __device__ __forceinline__ void pipe_write_partials(const FusedArgs<T>& a, float
     }
 }
 
-template <typename T, int C, bool COUPLED, bool ISO, int K, bool NTS, bool EDGE, bool NORM>
+template <typename T, int C, bool COUPLED, bool ISO, int K, bool NTS, bool EDGE, bool NORM, bool HET = false>
 __device__ __forceinline__ void fused_pipe_body(const FusedArgs<T>& a, const int strip, const int chunk, const int lane,
                                                 T* lds_lane) {
     constexpr int N = VecOf<T>::N;
-    Pipe<T, C, COUPLED, ISO, K, NTS, EDGE, NORM> pp;
+    static_assert(!HET || K <= 3, "heterogeneous pipelines prefetch at distance 1 (K <= 3)");
+    Pipe<T, C, COUPLED, ISO, K, NTS, EDGE, NORM, HET> pp;
     pp.lds = lds_lane;
     pp.xlds = lds_lane;
     if (!pipe_setup<K, T, C>(pp, a, strip, chunk, lane)) return;
@@ -1293,7 +1402,7 @@ __device__ __forceinline__ void fused_pipe_body(const FusedArgs<T>& a, const int
         for (int i = 0; i < PipeLds<K>::SLOTS; ++i) pp.lds_put(i, z);
     }
     const int64_t rs = pp.R0 - (K - 1);
-    pipe_prologue<(K >= 4 ? 2 : 1), ISO>(pp, st, rs);
+    pipe_prologue<(K >= 4 ? 2 : 1), ISO, HET>(pp, st, rs);
     // the last stage must reach row R1: steps rs .. R1 + K - 1, rounded up to whole groups of 4
     // (extra steps touch clamped rows only and store nothing)
     const int64_t r_end = pp.R1 + (K - 1);
@@ -1420,8 +1529,8 @@ __global__ void __launch_bounds__(256, DXH_PAIR_LB) k_fused_pair(FusedArgs<T> a)
 }
 #endif  // DXH_ENABLE_PAIR
 
-template <typename T, int C, bool COUPLED, bool ISO, int K, bool NORM = false, bool NTS = true>
-__global__ void __launch_bounds__(256, (K >= 3 ? DXH_LB4 : 3)) k_fused_multi(FusedArgs<T> a) {
+template <typename T, int C, bool COUPLED, bool ISO, int K, bool NORM = false, bool NTS = true, bool HET = false>
+__global__ void __launch_bounds__(256, ((K >= 3 || HET) ? DXH_LB4 : 3)) k_fused_multi(FusedArgs<T> a) {
     constexpr int N = VecOf<T>::N;
     using SG = StripGeomK<T, C, K>;
     const int lane = threadIdx.x & (kWave - 1);
@@ -1437,9 +1546,9 @@ __global__ void __launch_bounds__(256, (K >= 3 ? DXH_LB4 : 3)) k_fused_multi(Fus
     __shared__ typename VecOf<T>::type lds_rings[WPB * PipeLds<K>::SLOTS * kWave];
     T* lds_lane = reinterpret_cast<T*>(lds_rings + (size_t)wave * PipeLds<K>::SLOTS * kWave + lane);
     if (edge)
-        fused_pipe_body<T, C, COUPLED, ISO, K, NTS, true, NORM>(a, strip, chunk, lane, lds_lane);
+        fused_pipe_body<T, C, COUPLED, ISO, K, NTS, true, NORM, HET>(a, strip, chunk, lane, lds_lane);
     else
-        fused_pipe_body<T, C, COUPLED, ISO, K, NTS, false, NORM>(a, strip, chunk, lane, lds_lane);
+        fused_pipe_body<T, C, COUPLED, ISO, K, NTS, false, NORM, HET>(a, strip, chunk, lane, lds_lane);
 }
 
 }  // namespace dxh

@@ -9,6 +9,9 @@ namespace dxh {
 template <typename T>
 struct FusedArgs;
 
+// Array-valued coefficients (a.derive != 0) are supported for K = kHetFuseK only.
+constexpr int kHetFuseK = 3;
+
 // C in {1, 3}; `pair` selects the experimental wave-pair kernel (only with -DDXH_ENABLE_PAIR, float, K = 4)
 template <typename T, int K>
 void launch_multi_kernel(int C, bool coupled, bool iso, bool want_inc, bool pair, const FusedArgs<T>& a, unsigned grid,

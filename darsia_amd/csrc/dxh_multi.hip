@@ -9,12 +9,25 @@
 #error "compile with -DDXH_MULTI_T=float|double -DDXH_MULTI_K=2|3|4 (see build.sh)"
 #endif
 
+#ifndef DXH_HET_K
+#define DXH_HET_K 3  // the K for which the heterogeneous-coefficient pipeline is instantiated (dxh_multi.h)
+#endif
+
 namespace dxh {
 
 namespace {
 
 template <typename T, int C, bool COUPLED, bool ISO, int K>
 void launch_one(bool want_inc, bool pair, const FusedArgs<T>& a, unsigned grid, hipStream_t stream) {
+    if constexpr (K == DXH_HET_K) {
+        if (a.derive) {  // array-valued coefficients
+            if (want_inc)
+                hipLaunchKernelGGL((k_fused_multi<T, C, COUPLED, ISO, K, true, true, true>), dim3(grid), dim3(256), 0, stream, a);
+            else
+                hipLaunchKernelGGL((k_fused_multi<T, C, COUPLED, ISO, K, false, true, true>), dim3(grid), dim3(256), 0, stream, a);
+            return;
+        }
+    }
 #ifdef DXH_ENABLE_PAIR
     if constexpr (K == 4 && std::is_same<T, float>::value) {
         if (pair) {

@@ -50,6 +50,12 @@ struct Ctx {
     void* cp_diag = nullptr;
     void* cp_dsc = nullptr;
     void* cp_kq = nullptr;
+    void* in_mu = nullptr;         // the coefficient arrays as given (heterogeneous fused sweep derives from these)
+    void* in_om = nullptr;
+    void* in_ell = nullptr;
+    bool in_valid = false;         // cp_* still equal derive_coefs(in_*) (false after dxh_tvd_adapt_ell)
+    int in_has_ell = 0;
+    double in_h = 1.0;
     void* om_plane = nullptr;      // omega as a plane (array-valued omega only)
     void* mu_plane = nullptr;      // mu as a plane (array-valued mu; needed by the adaptive update)
     bool explicit_db = false;      // split variables live in dpl / bpl instead of the compressed q planes
@@ -116,6 +122,26 @@ static CoefPlanes<T> make_planes(const Ctx* c) {
     return p;
 }
 
+template <typename T>
+static CoefIn<T> make_coefin(const Ctx* c) {
+    CoefIn<T> in{};
+    const double h2 = c->in_h * c->in_h;
+    const int dim = c->desc.dim;
+    in.mu = (const T*)c->in_mu;
+    in.omega = (const T*)c->in_om;
+    in.ell = (const T*)c->in_ell;
+    in.mu_s = (T)c->mu_s;
+    in.omega_s = (T)c->omega_s;
+    in.ell_s = (T)c->ell_s;
+    in.two_dim_over_h2_ell_s = (T)(c->ell_s * 2 * dim / h2);
+    in.ell_over_h2_s = (T)(c->ell_s / h2);
+    in.h2 = (T)h2;
+    in.two_dim = (T)(2 * dim);
+    in.dim = dim;
+    in.has_ell = c->in_has_ell;
+    return in;
+}
+
 static int set_device(const Ctx* c) {
     DXH_HIP(hipSetDevice(c->desc.device));
     return DXH_OK;
@@ -180,6 +206,8 @@ static void launch_fused_v(Ctx* c, int in, int out) {
     a.nwaves_total = 0;
     a.c = make_coef<T>(c);
     a.cp = make_planes<T>(c);
+    a.ci = make_coefin<T>(c);
+    a.derive = (HET && c->in_valid && !(c->tune & 32)) ? 1 : 0;  // DXH_FUSED_TUNE bit 32: read the four derived planes
     hipLaunchKernelGGL((k_fused<T, C, COUPLED, ISO, HET, DPP, ALIGN, NTS>), dim3((unsigned)(nbx * nchunks)), dim3(256), 0,
                        c->stream, a);
 }
@@ -246,16 +274,26 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
     }
     a.c = make_coef<T>(c);
     a.cp = make_planes<T>(c);
+    a.ci = make_coefin<T>(c);
+    a.derive = c->het ? 1 : 0;  // array coefficients (multi_supported: only with the given planes at hand, K = kHetFuseK)
     // the kernels are instantiated in dxh_multi.hip (one object per element type and K, built in parallel)
     launch_multi_kernel<T, K>(C, COUPLED, ISO, want_inc, pair, a, (unsigned)(nbx * nchunks), c->stream);
 }
 
 // channel counts the multi-iteration kernel is instantiated for
 static bool multi_supported(const Ctx* c) {
-    if (!(c->desc.dim == 2 && !c->het && (c->g.n2 == 1 || c->g.n2 == 3))) return false;
+    if (!(c->desc.dim == 2 && (c->g.n2 == 1 || c->g.n2 == 3)) || (c->tune & 8)) return false;
+    if (c->het) return c->in_valid && !(c->tune & 32);  // array coefficients: derived in the kernel from the given planes
     // k_fused_multi divides through precomputed reciprocals: the divisors must be in a comfortable range
     auto ok = [](double d) { return std::isfinite(d) && std::fabs(d) >= 0x1p-20 && std::fabs(d) <= 0x1p+20; };
-    return ok(c->c_diag) && ok(c->c_dsc) && !(c->tune & 8);
+    return ok(c->c_diag) && ok(c->c_dsc);
+}
+
+// iterations of the next launch when `left` iterations remain (array coefficients: their pipeline exists for one K
+// only, shorter remainders run as single-iteration sweeps)
+static int pick_k(const Ctx* c, int left) {
+    if (c->het) return (c->fuse_k >= kHetFuseK && left >= kHetFuseK) ? kHetFuseK : 1;
+    return std::max(1, std::min(c->fuse_k, left));
 }
 
 template <typename T, int C>
@@ -487,11 +525,11 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
     if (!async) DXH_HIP(hipEventRecord(c->ev0, c->stream));
     for (int it = 0; it < n_iter; ++it) {
         const int in = c->cur, out = c->cur ^ 1;
-        if (fused_ok && !c->from_db && use_eps && dpp && multi_supported(c) && c->fuse_k >= 2 && n_iter - it >= 2) {
+        if (fused_ok && !c->from_db && use_eps && dpp && multi_supported(c) && pick_k(c, n_iter - it) >= 2) {
             // eps with temporal blocking: one launch does K iterations and also reduces every iteration's
             // squared increment; if the test fires at an inner iteration j, the K-iteration result is
             // discarded (the input buffers still hold iteration `it`) and exactly j+1 iterations are redone
-            const int K = std::min(c->fuse_k, n_iter - it);
+            const int K = pick_k(c, n_iter - it);
             launch_fused_multi<T>(c, in, out, iso, K, true);
             ++launches;
             if (!c->inc_partial) { set_error("out of device memory for the increment partials"); if (tmp) (void)hipFree(tmp); return DXH_ENOMEM; }
@@ -519,7 +557,7 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
                 // redo exactly hit+1 iterations from the untouched input state
                 int left = hit + 1, a_in = in, a_out = out;
                 while (left > 0) {
-                    const int k2 = left >= 2 ? std::min(left, c->fuse_k) : 1;
+                    const int k2 = pick_k(c, left);
                     if (k2 >= 2) launch_fused_multi<T>(c, a_in, a_out, iso, k2, false);
                     else launch_fused<T>(c, a_in, a_out, iso, dpp);
                     ++launches;
@@ -532,7 +570,7 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
         } else if (fused_ok && !c->from_db) {
             // temporal blocking: fuse_k iterations per launch while enough iterations remain and no
             // per-iteration host test is requested
-            const int K = (!use_eps && dpp && multi_supported(c)) ? std::min(c->fuse_k, n_iter - it) : 1;
+            const int K = (!use_eps && dpp && multi_supported(c)) ? pick_k(c, n_iter - it) : 1;
             if (K >= 2) {
                 launch_fused_multi<T>(c, in, out, iso, K);
                 it += K - 1;
@@ -610,6 +648,10 @@ static int set_coeffs_t(Ctx* c, double mu, const void* mu_arr, double omega, con
     c->het = mu_arr || omega_arr || ell_arr;
     c->mu_s = mu;
     c->omega_s = omega;
+    for (void** p : {&c->in_mu, &c->in_om, &c->in_ell}) {
+        if (*p) { DXH_HIP(hipFree(*p)); *p = nullptr; }
+    }
+    c->in_valid = false;
     if (!c->het) {
         // all-scalar: fold in double like Python floats, round once where the value meets an array
         const double ell_d = has_ell ? ell : 2.0 * mu;
@@ -653,8 +695,14 @@ static int set_coeffs_t(Ctx* c, double mu, const void* mu_arr, double omega, con
                        (T*)c->cp_diag, (T*)c->cp_dsc, want_kq ? (T*)c->cp_kq : nullptr);
     DXH_HIP(hipGetLastError());
     DXH_HIP(hipStreamSynchronize(c->stream));
-    for (void* p : {d_mu, d_om, d_ell})
-        if (p) DXH_HIP(hipFree(p));
+    // the given arrays stay on the device: the fused heterogeneous sweep derives its coefficients from them
+    c->in_mu = d_mu;
+    c->in_om = d_om;
+    c->in_ell = d_ell;
+    c->ell_s = ell_d;
+    c->in_has_ell = has_ell;
+    c->in_h = h;
+    c->in_valid = want_kq;  // (mass, diffusion) solves without mu never use the fused sweep
     return DXH_OK;
 }
 
@@ -747,6 +795,7 @@ int dxh_tvd_destroy(dxh_tvd_t h) {
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
     fr(c->of); fr(c->u[0]); fr(c->u[1]); fr(c->rs);
     for (int j = 0; j < 3; ++j) { fr(c->q[j][0]); fr(c->q[j][1]); fr(c->dpl[j]); fr(c->bpl[j]); }
+    fr(c->in_mu); fr(c->in_om); fr(c->in_ell);
     fr(c->cp_ell); fr(c->cp_diag); fr(c->cp_dsc); fr(c->cp_kq); fr(c->om_plane); fr(c->mu_plane); fr(c->base_img); fr(c->clean_filter); fr(c->probe_buf); fr(c->stage); fr(c->partial); fr(c->red_out); fr(c->inc_partial);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1160,6 +1209,7 @@ int dxh_tvd_adapt_ell(dxh_tvd_t h) {
         DXH_HIP(hipGetLastError());
         c->het = true;
     }
+    c->in_valid = false;  // the coefficient planes no longer follow from the given arrays
     const void* u = c->u[c->cur];
 #define DXH_AD(T, DIM) hipLaunchKernelGGL((k_adapt_ell<T, DIM>), grid, blk, 0, c->stream, c->g, (const T*)u, (T)c->mu_s, \
                                           (const T*)c->mu_plane, (T*)c->cp_ell, (T*)c->cp_kq)

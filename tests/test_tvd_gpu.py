@@ -370,3 +370,37 @@ def test_adaptive_regularisation(golden, name, kw, sched):
         ref = golden[name + "/out"].astype(np.float64)
         rel = np.abs(out - ref) / (np.abs(ref) + 1.0)
         assert np.median(rel) < 1e-4 and np.mean(rel < 1e-2) > 0.98
+
+
+@pytest.mark.parametrize("iso", [False, True])
+@pytest.mark.parametrize("n_iter", [3, 7, 8])
+def test_heterogeneous_temporal_blocking_bit_exact(iso, n_iter, monkeypatch):
+    """Array-valued mu / omega: the K-iteration pipeline derives the coefficients in the kernel from the given planes;
+    same bits as single-iteration sweeps reading the four derived planes, and as the oracle."""
+    from darsia_amd.synthetic import synthetic_image
+    img = synthetic_image(203, 517, 3)
+    rng = np.random.default_rng(11)
+    mu = (0.05 + 0.3 * rng.random(img.shape)).astype(np.float32)
+    omega = (0.5 + rng.random(img.shape)).astype(np.float32)
+    kw = dict(mu=mu, omega=omega, max_num_iter=n_iter, isotropic=iso)
+    out = da.split_bregman_tvd(img, **kw)
+    monkeypatch.setenv("DXH_FUSE_K", "1")
+    monkeypatch.setenv("DXH_FUSED_TUNE", "32")
+    ref = da.split_bregman_tvd(img, **kw)
+    np.testing.assert_array_equal(out, ref)
+    if not iso:
+        assert_bits(out, O.split_bregman_tvd(img, promotion="strict", **kw))
+
+
+@pytest.mark.parametrize("eps,expect", [(5e-3, 4), (2e-3, 6), (1e-3, 8), (5e-4, 13)])
+def test_heterogeneous_eps_stop_with_temporal_blocking(eps, expect):
+    """The stop iteration falls at every position inside the 3-iteration launches."""
+    rng = np.random.default_rng(5)
+    y, x = np.mgrid[0:160, 0:240]
+    img = (0.5 + 0.25 * np.sign(np.sin(x / 20.0)) * np.sign(np.sin(y / 15.0)) + rng.normal(0, 0.01, (160, 240))).astype(np.float32)
+    mu = np.full(img.shape, 0.02, np.float32)
+    mu[:, 120:] = 0.05
+    out = da.split_bregman_tvd(img, mu=mu, max_num_iter=60, eps=eps)
+    ref, _, _, done = O.split_bregman_tvd(img, mu=mu, max_num_iter=60, eps=eps, promotion="strict", return_state=True)
+    assert done == expect
+    assert_bits(out, ref)
