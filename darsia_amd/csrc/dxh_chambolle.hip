@@ -7,7 +7,9 @@
 //   k_ch_p   : g = forward differences of out, n = |g|, partial sums of n, p = (p - tau g) / (1 + n tau / w)
 // Energies are reduced deterministically (per-block partials, then one block) in double; the stop test
 // |E_prev - E| < eps E_0 runs on the host once per iteration, as in the reference.
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "dxh_kernels.h"
@@ -161,6 +163,183 @@ __global__ void __launch_bounds__(256) k_ch_fused(ChFusedArgs<T, NDIM> a) {
     block_sum_store<256>(nsum, a.partial_n);
 }
 
+// --------------------------------------------------------------------------------------------------------------
+// Row-marching form of the fused iteration for 2-D images (C = 1) and for colour images treated as volumes whose
+// third axis is the channel axis (C = n2 = 3; that is how DarSIA's default TVD() runs, tvd.py:77-83): one wave
+// owns a column strip of 64 lanes x 16 bytes and a chunk of rows and walks down the rows like the TV sweep
+// (dxh_kernels.h, k_fused): the rows of p and f are read once with 16-byte loads, the column / channel neighbours
+// come from DPP lane shifts, `out` of the current and the next row live in registers.  Algorithmic traffic
+// (2 ndim + 1) values per element and iteration -- what the one-thread-per-element kernel above also moves from
+// HBM, but through ~30 scalar cache accesses per element (1.52 ms per iteration at 4000 x 8000 x 3 against
+// 0.5 ms here).  Same arithmetic, same order; the energy sums are per-wave partials in double.
+// --------------------------------------------------------------------------------------------------------------
+template <typename T>
+struct ChMarchArgs {
+    const T* f;
+    const T* pin[3];
+    T* pout[3];
+    int64_t n0, L, pitch, rows_per_chunk;
+    int nstrips, nchunks;
+    T tau, tau_over_w;
+    double* partial_d2;  // [nchunks * nstrips]
+    double* partial_n;
+};
+
+template <typename T, int C, bool HAS3>
+__global__ void __launch_bounds__(256) k_ch_march(ChMarchArgs<T> a) {
+    constexpr int N = VecOf<T>::N;
+    using SG = StripGeom<T, C, true>;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const int nbx = (a.nstrips + 3) / 4;
+    int bx, chunk;
+    block_to_tile((int)blockIdx.x, nbx, a.nchunks, bx, chunk);
+    const int strip = bx * 4 + wave;
+    if (strip >= a.nstrips || chunk >= a.nchunks) return;  // wave-uniform
+    const int64_t R0 = (int64_t)chunk * a.rows_per_chunk;
+    const int64_t R1 = (R0 + a.rows_per_chunk < a.n0) ? R0 + a.rows_per_chunk : a.n0;
+    if (R0 >= a.n0) return;
+    const int64_t x0 = (int64_t)strip * SG::STRIDE + (int64_t)(lane - SG::LH) * N;
+    int64_t xl = x0;
+    if (xl < 0) xl = 0;
+    if (xl > a.pitch - N) xl = a.pitch - N;
+    const bool store_lane = lane >= SG::LH && lane < SG::LH + SG::VALID && x0 < a.L;
+    bool edgeL[N], edgeR[N], ch0[N], chLast[N], inL[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int64_t x = x0 + j;
+        edgeL[j] = x < C;
+        edgeR[j] = x >= a.L - C;
+        const int cc = (int)(((x % C) + C) % C);
+        ch0[j] = cc == 0;
+        chLast[j] = cc == C - 1;
+        inL[j] = x >= 0 && x < a.L;
+    }
+    const int64_t P = a.pitch;
+    const T* f = a.f + xl;
+    const T* p0 = a.pin[0] + xl;
+    const T* p1 = a.pin[1] + xl;
+    const T* p2 = HAS3 ? a.pin[2] + xl : nullptr;
+    T* q0 = a.pout[0] + xl;
+    T* q1 = a.pout[1] + xl;
+    T* q2 = HAS3 ? a.pout[2] + xl : nullptr;
+
+    // d and out of one row from its p rows, the p0 row above it and f:  d = -(p0 + p1 [+ p2]) [+ p0 above]
+    // [+ p1 one column left] [+ p2 one channel left]   (same order of additions as k_ch_fused / the reference)
+    auto d_out = [&](const T (&a0)[N], const T (&a1)[N], const T (&a2)[N], const T (&above)[N], bool has_above, const T (&fv)[N],
+                     T (&d)[N], T (&o)[N]) {
+        T l1[N], l2[N];
+        shifted<-C, true>(a1, l1);
+        if constexpr (HAS3) shifted<-1, true>(a2, l2);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            T s = a0[j] + a1[j];
+            if constexpr (HAS3) s = s + a2[j];
+            T v = -s;
+            if (has_above) v = v + above[j];
+            if (!edgeL[j]) v = v + l1[j];
+            if constexpr (HAS3) {
+                if (!ch0[j]) v = v + l2[j];
+            }
+            d[j] = v;
+            o[j] = fv[j] + v;
+        }
+    };
+
+    T zero[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) zero[j] = T(0);
+    // prologue: row R0 (needs the p0 row above it), and the loads of row R0 + 1
+    T pc0[N], pc1[N], pc2[N], dc[N], oc[N];
+    {
+        T ab[N], fv[N];
+        load_vec(p0 + R0 * P, pc0);
+        load_vec(p1 + R0 * P, pc1);
+        if constexpr (HAS3) load_vec(p2 + R0 * P, pc2);
+        load_vec(f + R0 * P, fv);
+        if (R0 > 0) load_vec(p0 + (R0 - 1) * P, ab);
+        d_out(pc0, pc1, HAS3 ? pc2 : zero, R0 > 0 ? ab : zero, R0 > 0, fv, dc, oc);
+    }
+    T pn0[N], pn1[N], pn2[N], fn[N];
+    auto clampr = [&](int64_t r) -> int64_t { return r > a.n0 - 1 ? a.n0 - 1 : r; };
+    {
+        const int64_t rn = clampr(R0 + 1);
+        load_vec(p0 + rn * P, pn0);
+        load_vec(p1 + rn * P, pn1);
+        if constexpr (HAS3) load_vec(p2 + rn * P, pn2);
+        load_vec(f + rn * P, fn);
+    }
+    double sq = 0.0, nsum = 0.0;
+    for (int64_t r = R0; r < R1; ++r) {
+        // prefetch row r + 2
+        T pf0[N], pf1[N], pf2[N], ff[N];
+        {
+            const int64_t rn = clampr(r + 2);
+            load_vec(p0 + rn * P, pf0);
+            load_vec(p1 + rn * P, pf1);
+            if constexpr (HAS3) load_vec(p2 + rn * P, pf2);
+            load_vec(f + rn * P, ff);
+        }
+        // out of row r + 1 (its row above is row r)
+        T dn[N], on[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) dn[j] = on[j] = T(0);
+        const bool has_next = r + 1 < a.n0;
+        if (has_next) d_out(pn0, pn1, HAS3 ? pn2 : zero, pc0, true, fn, dn, on);
+        // gradient of out at row r
+        T o1[N], o2[N];
+        shifted<+C, true>(oc, o1);
+        if constexpr (HAS3) shifted<+1, true>(oc, o2);
+        T r0[N], r1[N], r2[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const T g0 = has_next ? on[j] - oc[j] : T(0);
+            const T g1 = edgeR[j] ? T(0) : o1[j] - oc[j];
+            T s2 = g0 * g0;
+            s2 = s2 + g1 * g1;
+            T g2 = T(0);
+            if constexpr (HAS3) {
+                g2 = chLast[j] ? T(0) : o2[j] - oc[j];
+                s2 = s2 + g2 * g2;
+            }
+            T n = t_sqrt(s2);
+            if (store_lane && inL[j]) {
+                nsum += (double)n;
+                sq += (double)dc[j] * (double)dc[j];
+            }
+            n = n * a.tau_over_w;
+            n = n + T(1);
+            r0[j] = (pc0[j] - a.tau * g0) / n;
+            r1[j] = (pc1[j] - a.tau * g1) / n;
+            if constexpr (HAS3) r2[j] = (pc2[j] - a.tau * g2) / n;
+        }
+        if (store_lane) {
+            store_vec_nt(q0 + r * P, r0);
+            store_vec_nt(q1 + r * P, r1);
+            if constexpr (HAS3) store_vec_nt(q2 + r * P, r2);
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            pc0[j] = pn0[j]; pc1[j] = pn1[j];
+            pn0[j] = pf0[j]; pn1[j] = pf1[j];
+            if constexpr (HAS3) { pc2[j] = pn2[j]; pn2[j] = pf2[j]; }
+            fn[j] = ff[j];
+            dc[j] = dn[j];
+            oc[j] = on[j];
+        }
+    }
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        sq += __shfl_down(sq, off, kWave);
+        nsum += __shfl_down(nsum, off, kWave);
+    }
+    if (lane == 0) {
+        const int wid = chunk * a.nstrips + strip;
+        a.partial_d2[wid] = sq;
+        a.partial_n[wid] = nsum;
+    }
+}
+
 template <typename T>
 static int chambolle_t(int device, int ndim, int64_t n0, int64_t n1, int64_t n2, const void* img, void* out,
                        double weight, double eps, int max_iter, int* iters_done) {
@@ -209,8 +388,31 @@ static int chambolle_t(int device, int ndim, int64_t n0, int64_t n1, int64_t n2,
         DXH_HIP(hipMalloc((void**)&partial_n, sizeof(double) * nblocks));
         extra.push_back(partial_n);
         const double tau = 1.0 / (2.0 * ndim);
+        // row-marching kernel for 2-D images and colour-images-as-volumes; everything else one thread per element
+        const bool march = (ndim == 2 || (ndim == 3 && n2 == 3)) && !getenv("DXH_CHAMBOLLE_NO_MARCH");
+        ChMarchArgs<T> ma{};
+        unsigned march_grid = 0;
+        int nparts = (int)nblocks;
+        if (march) {
+            const int stride = ndim == 2 ? StripGeom<T, 1, true>::STRIDE : StripGeom<T, 3, true>::STRIDE;
+            ma.n0 = n0; ma.L = g.L; ma.pitch = g.pitch;
+            ma.nstrips = (int)((g.L + stride - 1) / stride);
+            const int nbx = (ma.nstrips + 3) / 4;
+            int ncu = 256;
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+            int64_t nchunks = std::max<int64_t>(1, (int64_t)ncu * 3 / nbx);  // ~12 waves per CU
+            if (nchunks >= 8) nchunks = nchunks / 8 * 8;
+            const int64_t rpc = std::max<int64_t>(8, (n0 + nchunks - 1) / nchunks);
+            nchunks = (n0 + rpc - 1) / rpc;
+            ma.rows_per_chunk = rpc;
+            ma.nchunks = (int)nchunks;
+            march_grid = (unsigned)(nbx * nchunks);
+            nparts = (int)(nchunks * ma.nstrips);
+            if ((size_t)nparts > (size_t)nblocks) { set_error("internal: partial buffer too small"); return DXH_EHIP; }
+        }
         auto reduce = [&](double* part, double* host) -> int {
-            hipLaunchKernelGGL(k_sum_partials, dim3(256), dim3(256), 0, st, part, (int)nblocks, stage2);
+            hipLaunchKernelGGL(k_sum_partials, dim3(256), dim3(256), 0, st, part, nparts, stage2);
             hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, stage2, 256, red);
             DXH_HIP(hipGetLastError());
             DXH_HIP(hipMemcpyAsync(host, red, sizeof(double), hipMemcpyDeviceToHost, st));
@@ -225,7 +427,13 @@ static int chambolle_t(int device, int ndim, int64_t n0, int64_t n1, int64_t n2,
         while (it < max_iter) {
             double sum_d2 = 0.0, sum_n = 0.0;
             int r;
-            if (ndim == 2) {
+            if (march) {
+                ma.f = (const T*)bufs[0];
+                for (int ax = 0; ax < 3; ++ax) { ma.pin[ax] = pbuf(ax < ndim ? ax : 0, cur); ma.pout[ax] = pbuf(ax < ndim ? ax : 0, cur ^ 1); }
+                ma.tau = (T)tau; ma.tau_over_w = (T)(tau / weight); ma.partial_d2 = partial; ma.partial_n = partial_n;
+                if (ndim == 2) hipLaunchKernelGGL((k_ch_march<T, 1, false>), dim3(march_grid), dim3(256), 0, st, ma);
+                else hipLaunchKernelGGL((k_ch_march<T, 3, true>), dim3(march_grid), dim3(256), 0, st, ma);
+            } else if (ndim == 2) {
                 ChFusedArgs<T, 2> fa;
                 fa.g = g; fa.f = (const T*)bufs[0];
                 for (int ax = 0; ax < 3; ++ax) { fa.pin[ax] = pbuf(ax < 2 ? ax : 0, cur); fa.pout[ax] = pbuf(ax < 2 ? ax : 0, cur ^ 1); }
