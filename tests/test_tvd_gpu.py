@@ -404,3 +404,29 @@ def test_heterogeneous_eps_stop_with_temporal_blocking(eps, expect):
     ref, _, _, done = O.split_bregman_tvd(img, mu=mu, max_num_iter=60, eps=eps, promotion="strict", return_state=True)
     assert done == expect
     assert_bits(out, ref)
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (1, 7), (7, 1), (2, 2), (3, 250), (250, 3), (1, 1, 3), (2, 5, 3), (5, 1, 3), (9, 2, 1)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_degenerate_shapes_all_paths(shape, dtype):
+    """One-pixel, one-row, one-column and two-wide images: every path (4-iteration pipeline, heterogeneous pipeline,
+    eps, isotropic, Chambolle, Gauss-Seidel Bregman) against its oracle, bit for bit."""
+    from oracle import bregman_gs_numpy as BG
+    from oracle import chambolle_numpy as CH
+    rng = np.random.default_rng(sum(shape))
+    img = rng.random(shape).astype(dtype)
+    for kw in (dict(mu=0.1, max_num_iter=9), dict(mu=0.05, max_num_iter=6, isotropic=True), dict(mu=0.07, max_num_iter=20, eps=1e-2)):
+        iso = kw.get("isotropic", False)
+        ref = O.split_bregman_tvd(img, promotion="strict", **kw)
+        out = da.split_bregman_tvd(img, **kw)
+        if iso:
+            np.testing.assert_allclose(out, ref, rtol=1e-6 if dtype == np.float32 else 1e-13, atol=1e-7 if dtype == np.float32 else 1e-15)
+        else:
+            assert_bits(out, ref)
+    mu = (0.03 + 0.1 * rng.random(shape)).astype(dtype)
+    assert_bits(da.split_bregman_tvd(img, mu=mu, max_num_iter=7), O.split_bregman_tvd(img, mu=mu, max_num_iter=7, promotion="strict"))
+    if min(shape[:2]) >= 1 and len(shape) <= 3:
+        np.testing.assert_array_equal(da.denoise_tv_chambolle(img, weight=0.1, eps=0.0, max_num_iter=6),
+                                      CH.denoise_tv_chambolle(img, weight=0.1, eps=0.0, max_num_iter=6))
+        np.testing.assert_array_equal(da.denoise_tv_bregman(img, weight=1.0, max_num_iter=5, eps=0.0, isotropic=False),
+                                      BG.denoise_tv_bregman(img, weight=1.0, max_num_iter=5, eps=0.0, isotropic=False))
