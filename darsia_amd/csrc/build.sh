@@ -4,8 +4,8 @@
 # (element type, K).  Extra arguments are passed to every compile (e.g. -DDXH_DEV_FAST, -DDXH_ENABLE_PAIR).
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-OUT="${HERE}/../libdarsia_hip.so"
-OBJ="${HERE}/_build"
+OUT="${DXH_OUT:-${HERE}/../libdarsia_hip.so}"
+OBJ="${DXH_OBJ:-${HERE}/_build}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 JOBS="${JOBS:-8}"
 mkdir -p "${OBJ}"

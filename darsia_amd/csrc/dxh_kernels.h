@@ -16,7 +16,7 @@
 #include "dxh_common.h"
 
 #ifndef DXH_STRIP_ALIGN_BYTES
-#define DXH_STRIP_ALIGN_BYTES 128  // k_fused_multi: a wave's store range covers whole granules of this size
+#define DXH_STRIP_ALIGN_BYTES 64  // k_fused_multi: a wave's store range covers whole granules of this size
 #endif
 #ifndef DXH_LB4
 #define DXH_LB4 2  // minimum waves per SIMD requested for the K >= 3 pipelines (register cap 256; 3 would spill)

@@ -38,6 +38,7 @@ struct Ctx {
     int num_cu = 256;
     int tune = 0;                  // developer A/B bits (DXH_FUSED_TUNE)
     int fuse_k = 4;                // outer iterations fused per launch (1..4)
+    int force_chunks = 0;          // developer knob DXH_NCHUNKS: row chunks of the K-iteration launches
     int waves_per_cu = 0;          // fused sweep: waves per CU the grid is sized for (0 = 8 for K = 1, 16 for K > 1)
 
     void* of = nullptr;            // omega * img
@@ -253,6 +254,7 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
     const int64_t target_blocks = (int64_t)c->num_cu * (c->waves_per_cu ? c->waves_per_cu : 16) / 4;
     int64_t nchunks = std::max<int64_t>(1, target_blocks / nbx);
     if (nchunks >= 8) nchunks = nchunks / 8 * 8;
+    if (c->force_chunks > 0) nchunks = c->force_chunks;  // developer knob DXH_NCHUNKS
     int64_t rpc = std::max<int64_t>(8 * K, (c->g.n0 + nchunks - 1) / nchunks);
     nchunks = (c->g.n0 + rpc - 1) / rpc;
     a.rows_per_chunk = rpc;
@@ -755,6 +757,7 @@ int dxh_tvd_create(dxh_tvd_t* out, const dxh_tvd_desc* d) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, d->device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
     if (const char* e = getenv("DXH_FUSED_TUNE")) c->tune = atoi(e);
+    if (const char* e = getenv("DXH_NCHUNKS")) c->force_chunks = atoi(e);
     if (const char* e = getenv("DXH_FUSE_K")) {
         const int v = atoi(e);
         if (v >= 1 && v <= 4) c->fuse_k = v;
