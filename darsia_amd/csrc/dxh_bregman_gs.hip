@@ -7,9 +7,20 @@
 // keep those launches coalesced all state lives in a SKEWED layout: element (r, c) of the framed (rows+2, cols+2)
 // array is stored at [k][d = r + c][r]; the five neighbours of a cell are then at [d-1][r-1], [d-1][r], [d+1][r],
 // [d+1][r+1] -- contiguous in r for a whole wavefront.  Channels are independent planes (the reference sweeps them
-// one after the other).  The stop test sqrt(sum (u_new-u_old)^2 / size) > eps is evaluated once per sweep from a
-// plane of increments (fixed reduction tree, double).  gfx950 only.
+// one after the other).
+//
+// A wavefront is tiny (<= min(rows, cols) cells per channel) and the launches of one sweep depend on each other, so
+// a sweep alone is latency-bound (~4 us per wavefront).  Consecutive SWEEPS are therefore pipelined: sweep s + 1 may
+// update diagonal d as soon as sweep s has finished diagonal d + 1, so one launch advances up to S sweeps at once,
+// sweep s working on diagonal t - 2 s -- S sweeps cost rows + cols + 2 S launches instead of S (rows + cols), with
+// exactly the sequential algorithm's data dependences (bit-identical results).  The stop test
+// sqrt(sum (u_new - u_old)^2 / size) > eps needs every sweep's own sum: the blocks write per-sweep partial sums
+// (fixed tree, double), the host looks at them after a batch, and if the criterion fired inside the batch the state
+// is restored from a snapshot taken before the batch and exactly that many sweeps are redone.  gfx950 only.
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <vector>
 
 #include "dxh_kernels.h"
 
@@ -24,7 +35,9 @@ struct GsArgs {
     T* dy;
     T* bx;
     T* by;
-    T* inc;      // u_new - u_old of the last sweep (0 outside the image)
+    double* part;  // per-sweep partial sums of (u_new - u_old)^2: [sweep in batch][diagonal][channel][block]
+    int64_t nd;    // diagonals
+    int nbx;       // blocks per (diagonal, channel)
     const T* f;  // image, skewed like u (frame unused)
     int64_t rows, cols, dims;
     int64_t rs;     // positions per diagonal (>= rows + 2, multiple of 32)
@@ -73,51 +86,70 @@ __global__ void __launch_bounds__(256) k_gs_final(GsArgs<T> a, T* __restrict__ o
     }
 }
 
-// one wavefront: all cells with r + c = d, r in [r_lo, r_hi], every channel
+// one pipeline step t: sweep z of the batch (blockIdx.z) updates its wavefront d = t - 2 z (if that is a diagonal of
+// the image), all cells r in [r_lo, r_hi] of it, channel blockIdx.y
 template <typename T, bool ISO>
-__global__ void __launch_bounds__(256) k_gs_diag(GsArgs<T> a, int64_t d, int64_t r_lo, int64_t r_hi) {
+__global__ void __launch_bounds__(256) k_gs_step(GsArgs<T> a, int64_t t) {
+    const int64_t d = t - 2 * (int64_t)blockIdx.z;
+    if (d < 2 || d > a.rows + a.cols) return;  // block-uniform
+    const int64_t r_lo = d - a.cols > 1 ? d - a.cols : 1, r_hi = d - 1 < a.rows ? d - 1 : a.rows;
     const int64_t r = r_lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r > r_hi) return;
     const int64_t k = blockIdx.y;
-    const int64_t o = k * a.plane + d * a.rs + r;  // (r, c)
-    const int64_t om = o - a.rs;                   // (r, c-1);  om - 1 = (r-1, c)
-    const int64_t op = o + a.rs;                   // (r, c+1);  op + 1 = (r+1, c)
-    const T uprev = a.u[o];
-    const T u_cp = a.u[op], u_rp = a.u[op + 1];
-    const T ux = u_cp - uprev;
-    const T uy = u_rp - uprev;
-    const T bxx = a.bx[o], byy = a.by[o];
-    T acc = u_rp + a.u[om - 1];
-    acc = acc + u_cp;
-    acc = acc + a.u[om];
-    acc = acc + a.dx[om];
-    acc = acc - a.dx[o];
-    acc = acc + a.dy[om - 1];
-    acc = acc - a.dy[o];
-    acc = acc - a.bx[om];
-    acc = acc + bxx;
-    acc = acc - a.by[om - 1];
-    acc = acc + byy;
-    const T unew = (a.lam * acc + a.weight * a.f[o]) / a.norm;
-    a.u[o] = unew;
-    a.inc[o] = unew - uprev;
-    T dxx, dyy;
-    if constexpr (ISO) {
-        const T tx = ux + bxx, ty = uy + byy;
-        const T s = (T)sqrt((double)(tx * tx + ty * ty));
-        const T sl = s * a.lam;
-        const double den = (double)sl + 1.0;
-        dxx = (T)((double)(sl * tx) / den);
-        dyy = (T)((double)(sl * ty) / den);
-    } else {
-        const double sx = (double)(ux + bxx), sy = (double)(uy + byy);
-        dxx = sx > a.th ? (T)(sx - a.th) : (sx < -a.th ? (T)(sx + a.th) : T(0));
-        dyy = sy > a.th ? (T)(sy - a.th) : (sy < -a.th ? (T)(sy + a.th) : T(0));
+    double t2 = 0.0;
+    if (r <= r_hi) {
+        const int64_t o = k * a.plane + d * a.rs + r;  // (r, c)
+        const int64_t om = o - a.rs;                   // (r, c-1);  om - 1 = (r-1, c)
+        const int64_t op = o + a.rs;                   // (r, c+1);  op + 1 = (r+1, c)
+        const T uprev = a.u[o];
+        const T u_cp = a.u[op], u_rp = a.u[op + 1];
+        const T ux = u_cp - uprev;
+        const T uy = u_rp - uprev;
+        const T bxx = a.bx[o], byy = a.by[o];
+        T acc = u_rp + a.u[om - 1];
+        acc = acc + u_cp;
+        acc = acc + a.u[om];
+        acc = acc + a.dx[om];
+        acc = acc - a.dx[o];
+        acc = acc + a.dy[om - 1];
+        acc = acc - a.dy[o];
+        acc = acc - a.bx[om];
+        acc = acc + bxx;
+        acc = acc - a.by[om - 1];
+        acc = acc + byy;
+        const T unew = (a.lam * acc + a.weight * a.f[o]) / a.norm;
+        a.u[o] = unew;
+        const T inc = unew - uprev;
+        t2 = (double)inc * (double)inc;
+        T dxx, dyy;
+        if constexpr (ISO) {
+            const T tx = ux + bxx, ty = uy + byy;
+            const T s = (T)sqrt((double)(tx * tx + ty * ty));
+            const T sl = s * a.lam;
+            const double den = (double)sl + 1.0;
+            dxx = (T)((double)(sl * tx) / den);
+            dyy = (T)((double)(sl * ty) / den);
+        } else {
+            const double sx = (double)(ux + bxx), sy = (double)(uy + byy);
+            dxx = sx > a.th ? (T)(sx - a.th) : (sx < -a.th ? (T)(sx + a.th) : T(0));
+            dyy = sy > a.th ? (T)(sy - a.th) : (sy < -a.th ? (T)(sy + a.th) : T(0));
+        }
+        a.dx[o] = dxx;
+        a.dy[o] = dyy;
+        a.bx[o] = bxx + (ux - dxx);
+        a.by[o] = byy + (uy - dyy);
     }
-    a.dx[o] = dxx;
-    a.dy[o] = dyy;
-    a.bx[o] = bxx + (ux - dxx);
-    a.by[o] = byy + (uy - dyy);
+    // deterministic block sum of the squared increments
+    __shared__ double sm[256 / kWave];
+#pragma unroll
+    for (int s = kWave / 2; s > 0; s >>= 1) t2 += __shfl_down(t2, s, kWave);
+    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x / kWave;
+    if (lane == 0) sm[wid] = t2;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sum = 0.0;
+        for (int w = 0; w < 256 / kWave; ++w) sum += sm[w];
+        a.part[(((int64_t)blockIdx.z * a.nd + d) * a.dims + k) * a.nbx + blockIdx.x] = sum;
+    }
 }
 
 template <typename T>
@@ -127,66 +159,95 @@ int run_gs(int64_t rows, int64_t cols, int64_t dims, const void* image, void* ou
     a.rows = rows; a.cols = cols; a.dims = dims;
     a.rs = (rows + 2 + 31) / 32 * 32;
     const int64_t nd = rows + cols + 3;  // diagonals 0 .. rows + cols + 2
+    a.nd = nd;
     a.plane = nd * a.rs;
     a.weight = (T)weight;
     a.lam = T(2) * a.weight;
     a.norm = a.weight + T(4) * a.lam;
     a.th = 1.0 / (double)a.lam;
+    const int64_t longest = rows < cols ? rows : cols;
+    a.nbx = (int)((longest + 255) / 256);
+    // sweeps in flight: enough to hide the wavefront latency, few enough that the pipeline fill (2 S steps) stays small
+    int batch = 64;
+    if (const char* e = getenv("DXH_GS_BATCH")) batch = atoi(e);
+    batch = std::max(1, std::min<int>(batch, (int)std::max<int64_t>(1, (rows + cols) / 8)));
     const size_t bytes = (size_t)a.plane * dims * sizeof(T);
     const size_t dense = (size_t)rows * cols * dims * sizeof(T);
-    void* bufs[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const size_t part_per_sweep = (size_t)nd * dims * a.nbx;
+    void* bufs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // u, dx, dy, bx, by, f
+    void* snap[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     void *d_img = nullptr, *d_out = nullptr;
-    double *partial = nullptr, *red = nullptr;
-    const int nb = 1024;
+    double *part = nullptr, *stage = nullptr, *red = nullptr;
     auto cleanup = [&]() {
         for (void* p : bufs) if (p) (void)hipFree(p);
-        if (d_img) (void)hipFree(d_img);
-        if (d_out) (void)hipFree(d_out);
-        if (partial) (void)hipFree(partial);
-        if (red) (void)hipFree(red);
+        for (void* p : snap) if (p) (void)hipFree(p);
+        for (void* p : {d_img, d_out, (void*)part, (void*)stage, (void*)red}) if (p) (void)hipFree(p);
     };
     auto body = [&]() -> int {
         for (void*& p : bufs) {
             DXH_HIP(hipMalloc(&p, bytes));
             DXH_HIP(hipMemsetAsync(p, 0, bytes, nullptr));
         }
+        if (max_iter > 1 && batch > 1)
+            for (void*& p : snap) DXH_HIP(hipMalloc(&p, bytes));
         DXH_HIP(hipMalloc(&d_img, dense));
         DXH_HIP(hipMalloc(&d_out, dense));
-        DXH_HIP(hipMalloc((void**)&partial, sizeof(double) * nb));
-        DXH_HIP(hipMalloc((void**)&red, sizeof(double) * 2));
+        DXH_HIP(hipMalloc((void**)&part, sizeof(double) * part_per_sweep * batch));
+        DXH_HIP(hipMalloc((void**)&stage, sizeof(double) * 256));
+        DXH_HIP(hipMalloc((void**)&red, sizeof(double) * batch));
         DXH_HIP(hipMemcpyAsync(d_img, image, dense, hipMemcpyHostToDevice, nullptr));
         a.u = (T*)bufs[0]; a.dx = (T*)bufs[1]; a.dy = (T*)bufs[2]; a.bx = (T*)bufs[3]; a.by = (T*)bufs[4];
-        a.inc = (T*)bufs[5]; a.f = (const T*)bufs[6];
+        a.f = (const T*)bufs[5];
+        a.part = part;
         hipLaunchKernelGGL((k_gs_init<T>), dim3(2048), dim3(256), 0, nullptr, a, (const T*)d_img);
         DXH_HIP(hipGetLastError());
-        // the increment plane as a (dims * nd, rs) array for the reduction
-        Geom gi{};
-        gi.n0 = dims * nd; gi.n1 = a.rs; gi.n2 = 1; gi.L = a.rs; gi.pitch = a.rs; gi.ndim = 2; gi.dim = 2; gi.nsum_axes = 2;
         const double total = (double)rows * (double)cols * (double)dims;
-        int i = 0;
-        double rmse = INFINITY;
-        while (i < max_iter && rmse > eps) {
-            for (int64_t d = 2; d <= rows + cols; ++d) {
-                const int64_t r_lo = d - cols > 1 ? d - cols : 1, r_hi = d - 1 < rows ? d - 1 : rows;
-                const dim3 grid((unsigned)((r_hi - r_lo + 1 + 255) / 256), (unsigned)dims);
-                if (isotropic)
-                    hipLaunchKernelGGL((k_gs_diag<T, true>), grid, dim3(256), 0, nullptr, a, d, r_lo, r_hi);
-                else
-                    hipLaunchKernelGGL((k_gs_diag<T, false>), grid, dim3(256), 0, nullptr, a, d, r_lo, r_hi);
+        // S pipelined sweeps; sq[s] = sum of squared increments of sweep s
+        auto run_batch = [&](int S, double* sq) -> int {
+            DXH_HIP(hipMemsetAsync(part, 0, sizeof(double) * part_per_sweep * S, nullptr));
+            const dim3 grid((unsigned)a.nbx, (unsigned)dims, (unsigned)S);
+            for (int64_t t = 2; t <= rows + cols + 2 * (int64_t)(S - 1); ++t) {
+                if (isotropic) hipLaunchKernelGGL((k_gs_step<T, true>), grid, dim3(256), 0, nullptr, a, t);
+                else hipLaunchKernelGGL((k_gs_step<T, false>), grid, dim3(256), 0, nullptr, a, t);
             }
-            hipLaunchKernelGGL((k_sqdiff_partial<T>), dim3(nb), dim3(256), 0, nullptr, gi, (const T*)a.inc, (const T*)nullptr,
-                               (int64_t)0, gi.n0, partial);
-            hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, nullptr, partial, nb, red);
+            for (int s2 = 0; s2 < S; ++s2) {
+                hipLaunchKernelGGL(k_sum_partials, dim3(256), dim3(256), 0, nullptr, part + (size_t)s2 * part_per_sweep,
+                                   (int)part_per_sweep, stage);
+                hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, nullptr, stage, 256, red + s2);
+            }
             DXH_HIP(hipGetLastError());
-            double sq = 0.0;
-            DXH_HIP(hipMemcpy(&sq, red, sizeof(double), hipMemcpyDeviceToHost));
-            rmse = std::sqrt(sq / total);
-            ++i;
+            DXH_HIP(hipMemcpy(sq, red, sizeof(double) * S, hipMemcpyDeviceToHost));
+            return DXH_OK;
+        };
+        int done = 0;
+        double rmse = INFINITY;
+        std::vector<double> sq((size_t)batch);
+        while (done < max_iter && rmse > eps) {
+            const int S = std::min(batch, max_iter - done);
+            const bool guard = S > 1;  // even eps = 0 stops the reference when a sweep changes nothing
+            if (guard)
+                for (int q = 0; q < 5; ++q) DXH_HIP(hipMemcpyAsync(snap[q], bufs[q], bytes, hipMemcpyDeviceToDevice, nullptr));
+            int rc2 = run_batch(S, sq.data());
+            if (rc2) return rc2;
+            int stop = -1;  // first sweep of the batch after which the reference would have left its loop
+            for (int s2 = 0; s2 < S; ++s2)
+                if (!(std::sqrt(sq[s2] / total) > eps)) { stop = s2; break; }
+            if (stop >= 0 && stop < S - 1) {
+                // overshoot: back to the state before the batch, then exactly stop + 1 sweeps
+                DXH_REQUIRE(guard, "internal: stop inside an unguarded batch");
+                for (int q = 0; q < 5; ++q) DXH_HIP(hipMemcpyAsync(bufs[q], snap[q], bytes, hipMemcpyDeviceToDevice, nullptr));
+                if ((rc2 = run_batch(stop + 1, sq.data()))) return rc2;
+                done += stop + 1;
+                rmse = std::sqrt(sq[stop] / total);
+                break;
+            }
+            done += S;
+            rmse = std::sqrt(sq[S - 1] / total);
         }
         hipLaunchKernelGGL((k_gs_final<T>), dim3(2048), dim3(256), 0, nullptr, a, (T*)d_out);
         DXH_HIP(hipGetLastError());
         DXH_HIP(hipMemcpy(out, d_out, dense, hipMemcpyDeviceToHost));
-        if (iters) *iters = i;
+        if (iters) *iters = done;
         if (rmse_out) *rmse_out = rmse;
         return DXH_OK;
     };
