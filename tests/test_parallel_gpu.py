@@ -33,7 +33,10 @@ def _worker(rank, world, port, case, out_dir):
         img = np.load(os.path.join(out_dir, "img.npy"))
         plan = make_plan(img.shape[0], world, rank, case["halo_iters"])
         slab = np.ascontiguousarray(img[plan.slab0:plan.slab1])
-        s = SlabTVD(plan, slab, mu=0.1, dim=2, halo_iters=case["halo_iters"], isotropic=case.get("iso", False),
+        mu = 0.1
+        if case.get("het"):
+            mu = np.ascontiguousarray(np.load(os.path.join(out_dir, "mu.npy"))[plan.slab0:plan.slab1])
+        s = SlabTVD(plan, slab, mu=mu, dim=2, halo_iters=case["halo_iters"], isotropic=case.get("iso", False),
                     device=0)
         done = s.run(case["n_iter"], eps=case.get("eps"))
         np.save(os.path.join(out_dir, f"out_{rank}.npy"), s.owned_result())
@@ -48,7 +51,8 @@ def _worker(rank, world, port, case, out_dir):
     dict(shape=(97, 260), world=3, halo_iters=1, n_iter=5),
     dict(shape=(120, 300, 3), world=2, halo_iters=3, n_iter=80, eps=2e-3),
     dict(shape=(90, 270, 3), world=2, halo_iters=2, n_iter=6, iso=True),
-], ids=["rgb_k4", "gray_k1_3ranks", "eps", "iso"])
+    dict(shape=(210, 300, 3), world=2, halo_iters=3, n_iter=11, het=True),
+], ids=["rgb_k4", "gray_k1_3ranks", "eps", "iso", "het_mu_array"])
 def test_two_ranks_one_gpu(tmp_path, case):
     import torch.multiprocessing as mp
 
@@ -57,11 +61,14 @@ def test_two_ranks_one_gpu(tmp_path, case):
     rng = np.random.default_rng(3)
     img = rng.random(case["shape"]).astype(np.float32)
     np.save(tmp_path / "img.npy", img)
+    mu = (0.03 + 0.1 * rng.random(case["shape"])).astype(np.float32) if case.get("het") else 0.1
+    if case.get("het"):
+        np.save(tmp_path / "mu.npy", mu)
     world = case["world"]
     mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
     got = np.concatenate([np.load(tmp_path / f"out_{r}.npy") for r in range(world)], axis=0)
     with da.DeviceTVD(img.shape, img.dtype, dim=2) as st:
-        st.set_coeffs(0.1, 1.0, None, img)
+        st.set_coeffs(mu, 1.0, None, img)
         st.upload(img)
         res = st.run(case["n_iter"], eps=case.get("eps"), isotropic=case.get("iso", False))
         ref = st.download()
