@@ -430,3 +430,25 @@ def test_degenerate_shapes_all_paths(shape, dtype):
                                       CH.denoise_tv_chambolle(img, weight=0.1, eps=0.0, max_num_iter=6))
         np.testing.assert_array_equal(da.denoise_tv_bregman(img, weight=1.0, max_num_iter=5, eps=0.0, isotropic=False),
                                       BG.denoise_tv_bregman(img, weight=1.0, max_num_iter=5, eps=0.0, isotropic=False))
+
+
+def test_reference_regularization_example_flow(capsys):
+    """examples/regularization.py on a synthetic volume: heterogeneous 3-D TVD with Jacobi(maxiter=20), verbose, eps,
+    through ``tvd(img=Image, ...)``; then H1_regularization with a tolerance-controlled Jacobi."""
+    rng = np.random.default_rng(8)
+    z, y, x = np.mgrid[0:36, 0:44, 0:30]
+    vol = (0.5 + 0.3 * np.sign(np.sin(x / 6.0)) * np.sign(np.sin(y / 7.0)) * np.sign(np.sin(z / 5.0)) + rng.normal(0, 0.05, (36, 44, 30)))
+    img = da.Image(vol, space_dim=3, dimensions=[0.1, 0.1, 0.1])
+    mu = np.ones_like(img.img)
+    mu[:, 0:20, :] = 0.5
+    out = da.tvd(img=img, method="heterogeneous bregman", isotropic=False, weight=mu, omega=0.1, max_num_iter=30, eps=1e-6,
+                 dim=3, verbose=True, solver=da.Jacobi(maxiter=20))
+    assert isinstance(out, da.Image) and out.img.shape == vol.shape and out.img is not img.img
+    assert "relative increment" in capsys.readouterr().out
+    # TVD forwards ell = regularization, whose default is 1.0 (tvd.py:37,111; SURVEY quirk Q4), not 2 mu
+    ref = O.split_bregman_tvd(vol, mu=mu, omega=0.1, ell=1.0, max_num_iter=30, eps=1e-6, dim=3, jacobi_maxiter=20,
+                              promotion="strict")
+    assert_bits(out.img, ref)
+    h1 = da.H1_regularization(img=img, mu=1, omega=1, dim=3, solver=da.Jacobi(maxiter=30, tol=1e-6))
+    ref_h1 = O.h1_regularization(vol, mu=1, omega=1, dim=3, jacobi_maxiter=30, jacobi_tol=1e-6, promotion="strict")
+    assert_bits(h1.img, ref_h1)
