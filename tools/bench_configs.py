@@ -56,3 +56,18 @@ def host_chain():
     d = np.clip(probe_img.img - base_img.img, 0, None); s = d[:, :, 0]; m = np.clip(2.0 * s + 0.0, 0.0, 1.0)
     return m
 t("  the same elementwise stages as NumPy passes on the host (no TVD)", host_chain)
+print("heterogeneous coefficients: array-valued mu (device loop)")
+mu = np.full(rgb.shape, 0.1, np.float32); mu[:, W // 2:] = 0.3
+st = da.DeviceTVD(rgb.shape, rgb.dtype); st.set_coeffs(mu, 1.0, None, rgb); st.upload(rgb); st.run(9); r = st.run(99)
+print(f"  device loop mu array: {r.loop_ms/99:.4f} ms/iter  {H*W/(r.loop_ms/99)/1e3:.0f} MPix/s"); st.close()
+print("Gauss-Seidel split Bregman (TVD '* bregman' methods), 64 sweeps, eps off")
+t("denoise_tv_bregman(rgb, 64 sweeps)  [PCIe-inclusive]", lambda: da.denoise_tv_bregman(rgb, weight=1.0, max_num_iter=64, eps=0.0, isotropic=False))
+print("MG inside the TV loop (gray f32, depth 3, 2 smoother sweeps, 1 V-cycle per outer iteration, 20 outer iterations)")
+g2 = np.ascontiguousarray(gray.reshape(H, W))
+t("split_bregman_tvd(gray, solver=MG)  [PCIe-inclusive]", lambda: da.split_bregman_tvd(g2, mu=0.1, max_num_iter=20, solver=da.MG(depth=3, smoother_iterations=2, maxiter=1)))
+print("Resize / CurvatureCorrection")
+t("Resize(fx=fy=0.5, inter_area)(rgb)  [PCIe-inclusive]", lambda: da.Resize(fx=0.5, fy=0.5, interpolation="inter_area")(rgb))
+t("Resize(shape=(3000, 6000), inter_linear)(rgb)  [PCIe-inclusive]", lambda: da.Resize(shape=(3000, 6000), interpolation="inter_linear")(rgb))
+cc = da.CurvatureCorrection(config={"bulge": dict(horizontal_bulge=2e-9, vertical_bulge=-1e-9), "stretch": dict(horizontal_stretch=1e-9)})
+cc(rgb)
+t("CurvatureCorrection(rgb) with the cached grid  [PCIe-inclusive]", lambda: cc(rgb))
