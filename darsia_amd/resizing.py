@@ -122,7 +122,7 @@ def cv_resize(img: np.ndarray, dsize=None, fx=None, fy=None, interpolation: Opti
     _lib.require_gpu()
     src = np.ascontiguousarray(img)
     chans = 1 if src.ndim == 2 else src.shape[2]
-    out = np.empty((dh, dw) if src.ndim == 2 else (dh, dw, chans), src.dtype)
+    out = _lib.empty_prefaulted((dh, dw) if src.ndim == 2 else (dh, dw, chans), src.dtype)
     _lib.check(_lib.load().dxh_resize(_lib.default_device(), _DTYPES[src.dtype], h, w, chans, _lib.ptr(src), dh, dw,
                                        C.byref(plan), _lib.ptr(out)))
     return out
@@ -173,7 +173,9 @@ class Resize:
         if input_is_image:
             assert img.space_dim == 2
         extensive = input_is_image and bool(getattr(img, "extensive", False))
-        arr = img.img.copy() if input_is_image else img.copy()
+        # the reference copies the array first (resize.py:141); the device path never writes into its input, and a
+        # 384 MB host copy costs more than the whole resize
+        arr = img.img if input_is_image else img
         if self.dtype is not None:
             arr = arr.astype(self.dtype)
         original_shape = arr.shape

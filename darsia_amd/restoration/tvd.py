@@ -69,8 +69,16 @@ class TVD:
             raise ValueError(f"Method {self.method} not supported.")
 
     def _tvd_image(self, img):
-        img_copy = img.copy()
-        img_copy.img = self._tvd_array(img.img)
+        result = self._tvd_array(img.img)
+        # tvd.py:127-129 deep-copies the image and replaces its array; copying the container without its pixel array
+        # gives the same object and saves a 384 MB host copy
+        array = img.img
+        try:
+            img.img = array[:0]  # empty view: copy() duplicates the container, not the pixels
+            img_copy = img.copy()
+        finally:
+            img.img = array
+        img_copy.img = result
         return img_copy
 
 
