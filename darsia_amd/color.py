@@ -31,7 +31,7 @@ def apply_affine_balance(img: np.ndarray, scaling: np.ndarray, translation=None,
         raise ValueError("translation must have 3 entries")
     _lib.require_gpu()
     src = np.ascontiguousarray(img)
-    out = _lib.empty_prefaulted(src.shape, np.float32)
+    out = np.empty(src.shape, np.float32)
     _lib.check(_lib.load().dxh_affine_color(_lib.default_device(), _IN_CODES[src.dtype], src.size // 3, _lib.ptr(src),
                                              _lib.ptr(a), _lib.ptr(b), int(bool(clip)), _lib.ptr(out)))
     return out

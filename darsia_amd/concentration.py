@@ -320,7 +320,7 @@ class ConcentrationAnalysis:
         if rest is not None:
             maxiter, tol = (1, None) if solver is None else (solver.maxiter, solver.tol)
             st.run(rest.max_num_iter, maxiter, tol, eps=rest.eps, isotropic=iso)
-        out = _lib.empty_prefaulted((h, w), dt)
+        out = np.empty((h, w), dt)
         _lib.check(st.lib.dxh_tvd_download_model(st._h, _lib.ptr(out), C.cast(_ops_array(post), C.c_void_p), len(post)))
         return out
 

@@ -49,7 +49,7 @@ def map_coordinates(img: np.ndarray, grid: np.ndarray, order: int = 1, cval: flo
     rows, cols = np.ascontiguousarray(grid[0]), np.ascontiguousarray(grid[1])
     chans = 1 if src.ndim == 2 else src.shape[2]
     n = rows.shape[0]
-    out = _lib.empty_prefaulted((n,) if src.ndim == 2 else (n, chans), src.dtype)
+    out = np.empty((n,) if src.ndim == 2 else (n, chans), src.dtype)
     _lib.check(_lib.load().dxh_map_coordinates(
         _lib.default_device(), _MC_DTYPES[src.dtype], src.shape[0], src.shape[1], chans, _lib.ptr(src),
         0 if grid.dtype == np.float32 else 1, _lib.ptr(rows), _lib.ptr(cols), n, int(order), float(cval), _lib.ptr(out)))
@@ -109,7 +109,7 @@ def extract_quadrilateral_ROI(img_src: np.ndarray, pts_src=None, indexing: str =
     rec.bw0 = _opencv_block_width(int(width), int(height))
     _lib.require_gpu()
     src = np.ascontiguousarray(img_src, dtype=np.float32)
-    canvas = _lib.empty_prefaulted(src.shape, src.dtype)
+    canvas = np.empty(src.shape, src.dtype)
     table = (_lib.WarpPatch * 1)(rec)
     _lib.check(_lib.load().dxh_warp_patches(_lib.default_device(), h, w, chans, _lib.ptr(src), C.cast(table, C.c_void_p), 1,
                                              _lib.ptr(canvas)))

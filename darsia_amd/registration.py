@@ -129,7 +129,7 @@ class PiecewisePerspectiveTransform:
                 records.append(rec)
         _lib.require_gpu()
         src = np.ascontiguousarray(base, dtype=np.float32)
-        canvas = _lib.empty_prefaulted(src.shape, src.dtype)
+        canvas = np.empty(src.shape, src.dtype)
         table = (_lib.WarpPatch * max(1, len(records)))(*records)
         _lib.check(_lib.load().dxh_warp_patches(_lib.default_device(), h, w, chans, _lib.ptr(src),
                                                  C.cast(table, C.c_void_p), len(records), _lib.ptr(canvas)))
@@ -161,7 +161,7 @@ def evaluate_rbf_on_grid(rbf, shape, x0=0.0, y0=0.0, dx=1.0, dy=1.0) -> np.ndarr
     y, coeffs, shift, scale, powers, dout, squeeze = _rbf_params(rbf)
     h, w = int(shape[0]), int(shape[1])
     _lib.require_gpu()
-    out = _lib.empty_prefaulted((h * w, dout), np.float64)
+    out = np.empty((h * w, dout), np.float64)
     _lib.check(_lib.load().dxh_tps_eval(_lib.default_device(), y.shape[0], dout, _lib.ptr(y), _lib.ptr(coeffs),
                                          _lib.ptr(shift), _lib.ptr(scale), _lib.ptr(powers), h * w, None, w,
                                          float(x0), float(y0), float(dx), float(dy), _lib.ptr(out)))

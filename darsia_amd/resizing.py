@@ -122,7 +122,7 @@ def cv_resize(img: np.ndarray, dsize=None, fx=None, fy=None, interpolation: Opti
     _lib.require_gpu()
     src = np.ascontiguousarray(img)
     chans = 1 if src.ndim == 2 else src.shape[2]
-    out = _lib.empty_prefaulted((dh, dw) if src.ndim == 2 else (dh, dw, chans), src.dtype)
+    out = np.empty((dh, dw) if src.ndim == 2 else (dh, dw, chans), src.dtype)
     _lib.check(_lib.load().dxh_resize(_lib.default_device(), _DTYPES[src.dtype], h, w, chans, _lib.ptr(src), dh, dw,
                                        C.byref(plan), _lib.ptr(out)))
     return out

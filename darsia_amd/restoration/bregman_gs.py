@@ -45,7 +45,7 @@ def denoise_tv_bregman(image: np.ndarray, weight: float = 5.0, max_num_iter: int
         return (res, [o[1] for o in outs]) if return_iters else res
     _lib.require_gpu()
     src = np.ascontiguousarray(image)
-    out = _lib.empty_prefaulted(src.shape, src.dtype)
+    out = np.empty(src.shape, src.dtype)
     dims = src.shape[2] if src.ndim == 3 else 1
     done = C.c_int(0)
     rmse = C.c_double(0.0)

@@ -32,7 +32,7 @@ def denoise_tv_chambolle(image: np.ndarray, weight: float = 0.1, eps: float = 2e
         raise ValueError("arrays with 2 or 3 axes are supported")
     _lib.require_gpu()
     src = np.ascontiguousarray(image)
-    out = _lib.empty_prefaulted(src.shape, src.dtype)
+    out = np.empty(src.shape, src.dtype)
     n2 = src.shape[2] if src.ndim == 3 else 1
     done = C.c_int(0)
     _lib.check(_lib.load().dxh_chambolle(_lib.default_device(), _lib.dtype_code(src.dtype), src.ndim, src.shape[0],

@@ -33,7 +33,7 @@ def _h1_array(img: np.ndarray, mu: float, omega: float, dim: int, solver: Solver
     else:
         raise ValueError(f"image with {img.ndim} axes and dim={dim} not supported")
     rhs = np.ascontiguousarray(omega * src, dtype=img.dtype)
-    out = _lib.empty_prefaulted(src.shape, src.dtype)
+    out = np.empty(src.shape, src.dtype)
     done = C.c_int(0)
     _lib.check(_lib.load().dxh_jacobi_solve(
         _lib.default_device(), code, ndim, dim, nsum, n0, n1, n2, _lib.ptr(src), _lib.ptr(rhs), _lib.ptr(out),

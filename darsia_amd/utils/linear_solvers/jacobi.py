@@ -41,7 +41,7 @@ class Jacobi(Solver):
         m_s, m_a = _coef(self.mass_coeff, x0)
         k_s, k_a = _coef(self.diffusion_coeff, x0)
         src = np.ascontiguousarray(x0)
-        out = _lib.empty_prefaulted(src.shape, src.dtype)
+        out = np.empty(src.shape, src.dtype)
         done = C.c_int(0)
         tol = -1.0 if self.tol is None else float(self.tol)
         _lib.check(_lib.load().dxh_jacobi_solve(

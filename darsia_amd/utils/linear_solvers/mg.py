@@ -72,7 +72,7 @@ class _DeviceSolverHandle:
     def solve(self, x0, rhs):
         x0 = np.ascontiguousarray(x0, dtype=self.dtype)
         rhs = np.ascontiguousarray(rhs, dtype=self.dtype)
-        out = _lib.empty_prefaulted(x0.shape, x0.dtype)
+        out = np.empty(x0.shape, x0.dtype)
         n = C.c_int32(0)
         _lib.check(self.lib.dxh_solver_solve(self._h, _lib.ptr(x0), _lib.ptr(rhs), _lib.ptr(out), C.byref(n)))
         return out, n.value
