@@ -183,6 +183,8 @@ int run_gs(int64_t rows, int64_t cols, int64_t dims, const void* image, void* ou
         for (void* p : snap) if (p) (void)hipFree(p);
         for (void* p : {d_img, d_out, (void*)part, (void*)stage, (void*)red}) if (p) (void)hipFree(p);
     };
+    HostPrefault pf;  // map the output pages while the device works
+    pf.start(out, dense);
     auto body = [&]() -> int {
         for (void*& p : bufs) {
             DXH_HIP(hipMalloc(&p, bytes));
@@ -246,6 +248,7 @@ int run_gs(int64_t rows, int64_t cols, int64_t dims, const void* image, void* ou
         }
         hipLaunchKernelGGL((k_gs_final<T>), dim3(2048), dim3(256), 0, nullptr, a, (T*)d_out);
         DXH_HIP(hipGetLastError());
+        pf.join();
         DXH_HIP(hipMemcpy(out, d_out, dense, hipMemcpyDeviceToHost));
         if (iters) *iters = done;
         if (rmse_out) *rmse_out = rmse;

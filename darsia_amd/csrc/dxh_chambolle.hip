@@ -365,6 +365,8 @@ static int chambolle_t(int device, int ndim, int64_t n0, int64_t n1, int64_t n2,
         for (void* b : extra) if (b) (void)hipFree(b);
         if (st) (void)hipStreamDestroy(st);
     };
+    HostPrefault pf;  // map the output pages while the device works
+    pf.start(out, (size_t)n0 * g.L * sizeof(T));
     auto body = [&]() -> int {
         DXH_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         for (int i = 0; i < 2 + ndim; ++i) {
@@ -473,6 +475,7 @@ static int chambolle_t(int device, int ndim, int64_t n0, int64_t n1, int64_t n2,
             DXH_HIP(hipGetLastError());
         }
         if (iters_done) *iters_done = it;
+        pf.join();
         DXH_HIP(hipMemcpy2DAsync(out, g.L * sizeof(T), bufs[1], g.pitch * sizeof(T), g.L * sizeof(T), n0,
                                  hipMemcpyDeviceToHost, st));
         DXH_HIP(hipStreamSynchronize(st));

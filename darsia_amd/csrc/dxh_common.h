@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <thread>
 
 #include "../../include/darsia_hip.h"
 
@@ -32,6 +33,26 @@ void set_error(const char* fmt, ...);
             return DXH_EINVAL;            \
         }                                 \
     } while (0)
+
+// Maps the pages of a (large) host output buffer on a helper thread while the device works.  A device-to-host
+// copy into never-touched pages is slowed down by the page faults (384 MB: 22-36 ms instead of 7 ms, measured); the
+// buffer is going to be overwritten completely, so writing one zero per page beforehand is harmless.  join() before
+// the copy is enqueued.
+struct HostPrefault {
+    std::thread th;
+    void start(void* p, size_t n) {
+        if (!p || n < (size_t(8) << 20)) return;
+        th = std::thread([p, n]() {
+            volatile char* c = static_cast<volatile char*>(p);
+            for (size_t i = 0; i < n; i += 4096) c[i] = 0;
+            c[n - 1] = 0;
+        });
+    }
+    void join() {
+        if (th.joinable()) th.join();
+    }
+    ~HostPrefault() { join(); }
+};
 
 constexpr int kWave = 64;
 

@@ -344,6 +344,8 @@ int dxh_warp_patches(int device, int H, int W, int C, const float* base, const d
                     "patch %d: destination rectangle outside the canvas", k);
         DXH_REQUIRE(p.bw0 >= 1, "patch %d: bad block width", k);
     }
+    HostPrefault pf;  // map the output pages while the device works
+    pf.start(canvas, (size_t)H * W * C * sizeof(float));
     Dev d;
     DXH_HIP(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking));
     const size_t bytes = (size_t)H * W * C * sizeof(float);
@@ -358,6 +360,7 @@ int dxh_warp_patches(int device, int H, int W, int C, const float* base, const d
     else
         hipLaunchKernelGGL((k_warp<3>), grid, blk, 0, d.st, (const float*)dbase, H, W, (const WarpPatch*)dpt, npatch, (float*)dcanvas);
     DXH_HIP(hipGetLastError());
+    pf.join();
     DXH_HIP(hipMemcpyAsync(canvas, dcanvas, bytes, hipMemcpyDeviceToHost, d.st));
     DXH_HIP(hipStreamSynchronize(d.st));
     return DXH_OK;
@@ -374,6 +377,8 @@ int dxh_tps_eval(int device, int p, int dout, const double* centers, const doubl
     int rc = check_device(device);
     if (rc) return rc;
     if (n == 0) return DXH_OK;
+    HostPrefault pf;  // map the output pages while the device works
+    pf.start(out, sizeof(double) * (size_t)n * dout);
     Dev d;
     DXH_HIP(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking));
     void *dc = nullptr, *dk = nullptr, *dp = nullptr, *dout_ = nullptr;
@@ -398,6 +403,7 @@ int dxh_tps_eval(int device, int p, int dout, const double* centers, const doubl
     a.out = (double*)dout_;
     hipLaunchKernelGGL(k_tps, dim3((unsigned)((n + 255) / 256)), dim3(256), smem, d.st, a);
     DXH_HIP(hipGetLastError());
+    pf.join();
     DXH_HIP(hipMemcpyAsync(out, dout_, sizeof(double) * (size_t)n * dout, hipMemcpyDeviceToHost, d.st));
     DXH_HIP(hipStreamSynchronize(d.st));
     return DXH_OK;
@@ -412,6 +418,8 @@ int dxh_affine_color(int device, int in_dtype, int64_t npix, const void* img, co
     if (rc) return rc;
     if (npix == 0) return DXH_OK;
     const size_t esz = in_dtype == 0 ? 4 : in_dtype == 1 ? 8 : in_dtype == 2 ? 1 : 2;
+    HostPrefault pf;  // map the output pages while the device works
+    pf.start(out, sizeof(float) * 3 * (size_t)npix);
     Dev d;
     DXH_HIP(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking));
     void *din = nullptr, *dab = nullptr, *dout_ = nullptr;
@@ -431,6 +439,7 @@ int dxh_affine_color(int device, int in_dtype, int64_t npix, const void* img, co
         default: hipLaunchKernelGGL((k_affine_color<unsigned short>), grid, blk, 0, d.st, (const unsigned short*)din, (long long)npix, 65535.0, (const double*)dab, clip, (float*)dout_); break;
     }
     DXH_HIP(hipGetLastError());
+    pf.join();
     DXH_HIP(hipMemcpyAsync(out, dout_, sizeof(float) * 3 * (size_t)npix, hipMemcpyDeviceToHost, d.st));
     DXH_HIP(hipStreamSynchronize(d.st));
     return DXH_OK;
@@ -448,6 +457,8 @@ int dxh_map_coordinates(int device, int dtype, int64_t H, int64_t W, int C, cons
     if (n == 0) return DXH_OK;
     const size_t esz = dtype == 0 ? 4 : dtype == 1 ? 8 : dtype == 2 ? 1 : 2;
     const size_t csz = coord_dtype == 0 ? 4 : 8;
+    HostPrefault pf;  // map the output pages while the device works
+    pf.start(out, (dtype == 0 ? 4 : dtype == 1 ? 8 : dtype == 2 ? 1 : 2) * (size_t)n * C);
     Dev d;
     DXH_HIP(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking));
     void *dimg = nullptr, *dr = nullptr, *dc = nullptr, *dout_ = nullptr;
@@ -469,6 +480,7 @@ int dxh_map_coordinates(int device, int dtype, int64_t H, int64_t W, int C, cons
     }
 #undef DXH_MC
     DXH_HIP(hipGetLastError());
+    pf.join();
     DXH_HIP(hipMemcpyAsync(out, dout_, esz * (size_t)n * C, hipMemcpyDeviceToHost, d.st));
     DXH_HIP(hipStreamSynchronize(d.st));
     return DXH_OK;
@@ -485,6 +497,8 @@ int dxh_resize(int device, int dtype, int64_t H, int64_t W, int C, const void* s
     int rc = check_device(device);
     if (rc) return rc;
     const size_t esz = dtype == 0 ? 4 : dtype == 1 ? 8 : 1;
+    HostPrefault pf;  // map the output pages while the device works
+    pf.start(dst, (dtype == 0 ? 4 : dtype == 1 ? 8 : 1) * (size_t)DH * DW * C);
     Dev d;
     DXH_HIP(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking));
     ResizePlanDev p{};
@@ -532,6 +546,7 @@ int dxh_resize(int device, int dtype, int64_t H, int64_t W, int C, const void* s
         default: hipLaunchKernelGGL((k_resize<unsigned char>), grid, blk, 0, d.st, (const unsigned char*)dsrc, (int)H, (int)W, C, p, (int)DH, (int)DW, (unsigned char*)ddst); break;
     }
     DXH_HIP(hipGetLastError());
+    pf.join();
     DXH_HIP(hipMemcpyAsync(dst, ddst, ndst, hipMemcpyDeviceToHost, d.st));
     DXH_HIP(hipStreamSynchronize(d.st));
     return DXH_OK;
