@@ -658,8 +658,11 @@ int dxh_solver_solve(dxh_solver_t h, const void* x0, const void* rhs, void* out,
     DXH_REQUIRE(o && x0 && rhs && out, "null argument");
     DXH_HIP(hipSetDevice(o->desc.device));
     int rc, n = 0;
+    dxh::HostPrefault pf;  // map the output pages while the device works
+    pf.start(out, (size_t)o->g.n0 * (size_t)o->g.L * o->esz);
     if ((rc = up(o, o->x0, x0)) || (rc = up(o, o->rhs, rhs))) return rc;
     if ((rc = o->impl->solve(o->x0, o->rhs, o->out, &n))) return rc;
+    pf.join();
     if ((rc = down(o, out, o->out))) return rc;
     DXH_HIP(hipStreamSynchronize(o->stream));
     if (iters) *iters = n;

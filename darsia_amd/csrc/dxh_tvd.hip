@@ -1250,6 +1250,8 @@ int dxh_jacobi_solve(int device, int dtype, int ndim, int dim, int nsum, int64_t
     int rc = dxh_tvd_create(&hctx, &d);
     if (rc) return rc;
     Ctx* c = reinterpret_cast<Ctx*>(hctx);
+    HostPrefault pf;  // map the output pages while the device works
+    pf.start(out, (size_t)n0 * (size_t)n1 * (size_t)n2 * (dtype == DXH_F32 ? 4 : 8));
     auto body = [&]() -> int {
         int r;
         // mass plays omega, diffusion plays ell; mu is unused (kq not needed)
@@ -1273,6 +1275,7 @@ int dxh_jacobi_solve(int device, int dtype, int ndim, int dim, int nsum, int64_t
         int64_t launches = 0;
         r = dtype == DXH_F32 ? jacobi_sweeps<float>(c, maxiter, tol, tmp, &launches, sweeps_done)
                              : jacobi_sweeps<double>(c, maxiter, tol, tmp, &launches, sweeps_done);
+        pf.join();
         if (!r) r = d2h_plane(c, out, c->u[1]);
         if (!r && hipStreamSynchronize(c->stream) != hipSuccess) { set_error("stream sync failed"); r = DXH_EHIP; }
         if (tmp) (void)hipFree(tmp);
