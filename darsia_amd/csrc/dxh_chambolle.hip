@@ -340,6 +340,230 @@ __global__ void __launch_bounds__(256) k_ch_march(ChMarchArgs<T> a) {
     }
 }
 
+// --------------------------------------------------------------------------------------------------------------
+// Two Chambolle iterations per pass (temporal blocking as in k_fused_multi): stage 0 turns p^n into p^(n+1) row by
+// row exactly like k_ch_march; stage 1 follows one row behind, takes the p^(n+1) rows straight from stage 0's
+// registers and emits p^(n+2).  p^(n+1) never goes to memory: 28 B per element for TWO iterations.  Each
+// iteration costs C elements of validity on either side of the strip and one extra row at either end of the row
+// chunk.  Both iterations' energy sums are produced (the stop test needs every iteration's energy); when the test
+// fires at the second iteration of a pass the host recomputes that single iteration from the untouched input.
+// --------------------------------------------------------------------------------------------------------------
+template <typename T>
+struct ChMarch2Args {
+    ChMarchArgs<T> m;
+    double* partial_d2_b;  // second iteration of the pass
+    double* partial_n_b;
+};
+
+template <typename T, int C, bool HAS3>
+__global__ void __launch_bounds__(256) k_ch_march2(ChMarch2Args<T> aa) {
+    const ChMarchArgs<T>& a = aa.m;
+    constexpr int N = VecOf<T>::N;
+    using SG = StripGeomK<T, C, 2>;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const int nbx = (a.nstrips + 3) / 4;
+    int bx, chunk;
+    block_to_tile((int)blockIdx.x, nbx, a.nchunks, bx, chunk);
+    const int strip = bx * 4 + wave;
+    if (strip >= a.nstrips || chunk >= a.nchunks) return;  // wave-uniform
+    const int64_t R0 = (int64_t)chunk * a.rows_per_chunk;
+    const int64_t R1 = (R0 + a.rows_per_chunk < a.n0) ? R0 + a.rows_per_chunk : a.n0;
+    if (R0 >= a.n0) return;
+    const int64_t x0 = (int64_t)strip * SG::STRIDE + (int64_t)(lane - SG::LH) * N;
+    int64_t xl = x0;
+    if (xl < 0) xl = 0;
+    if (xl > a.pitch - N) xl = a.pitch - N;
+    const bool store_lane = lane >= SG::LH && lane < SG::LH + SG::VALID && x0 < a.L;
+    bool edgeL[N], edgeR[N], ch0[N], chLast[N], inL[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int64_t x = x0 + j;
+        edgeL[j] = x < C;
+        edgeR[j] = x >= a.L - C;
+        const int cc = (int)(((x % C) + C) % C);
+        ch0[j] = cc == 0;
+        chLast[j] = cc == C - 1;
+        inL[j] = x >= 0 && x < a.L;
+    }
+    const int64_t P = a.pitch;
+    const T* f = a.f + xl;
+    const T* p0 = a.pin[0] + xl;
+    const T* p1 = a.pin[1] + xl;
+    const T* p2 = HAS3 ? a.pin[2] + xl : nullptr;
+    T* q0 = a.pout[0] + xl;
+    T* q1 = a.pout[1] + xl;
+    T* q2 = HAS3 ? a.pout[2] + xl : nullptr;
+
+    auto d_out = [&](const T (&a0)[N], const T (&a1)[N], const T (&a2)[N], const T (&above)[N], bool has_above, const T (&fv)[N],
+                     T (&d)[N], T (&o)[N]) {
+        T l1[N], l2[N];
+        shifted<-C, true>(a1, l1);
+        if constexpr (HAS3) shifted<-1, true>(a2, l2);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            T s = a0[j] + a1[j];
+            if constexpr (HAS3) s = s + a2[j];
+            T v = -s;
+            if (has_above) v = v + above[j];
+            if (!edgeL[j]) v = v + l1[j];
+            if constexpr (HAS3) {
+                if (!ch0[j]) v = v + l2[j];
+            }
+            d[j] = v;
+            o[j] = fv[j] + v;
+        }
+    };
+    // p update of one row from its p, out, the next row's out (has_next) -- returns the new p rows and adds the
+    // row's energy terms when `count`
+    auto p_update = [&](const T (&c0)[N], const T (&c1)[N], const T (&c2)[N], const T (&dc)[N], const T (&oc)[N], const T (&on)[N],
+                        bool has_next, bool count, double& sq, double& nsum, T (&r0)[N], T (&r1)[N], T (&r2)[N]) {
+        T o1[N], o2[N];
+        shifted<+C, true>(oc, o1);
+        if constexpr (HAS3) shifted<+1, true>(oc, o2);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const T g0 = has_next ? on[j] - oc[j] : T(0);
+            const T g1 = edgeR[j] ? T(0) : o1[j] - oc[j];
+            T s2 = g0 * g0;
+            s2 = s2 + g1 * g1;
+            T g2 = T(0);
+            if constexpr (HAS3) {
+                g2 = chLast[j] ? T(0) : o2[j] - oc[j];
+                s2 = s2 + g2 * g2;
+            }
+            T n = t_sqrt(s2);
+            if (count && store_lane && inL[j]) {
+                nsum += (double)n;
+                sq += (double)dc[j] * (double)dc[j];
+            }
+            n = n * a.tau_over_w;
+            n = n + T(1);
+            r0[j] = (c0[j] - a.tau * g0) / n;
+            r1[j] = (c1[j] - a.tau * g1) / n;
+            if constexpr (HAS3) r2[j] = (c2[j] - a.tau * g2) / n;
+            else r2[j] = T(0);
+        }
+    };
+
+    T zero[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) zero[j] = T(0);
+    auto clampr = [&](int64_t r) -> int64_t { return r < 0 ? 0 : (r > a.n0 - 1 ? a.n0 - 1 : r); };
+    // stage 0 emits p^(n+1) of rows e0 .. min(R1, n0 - 1); stage 1 emits p^(n+2) of rows R0 .. R1 - 1
+    const int64_t e0 = R0 > 0 ? R0 - 1 : 0;
+    // ---- stage 0 state: current row e0 of p^n with its d / out, and the loaded next row ----
+    T a0[N], a1[N], a2[N], ad[N], ao[N];
+    {
+        T ab[N], fv[N];
+        load_vec(p0 + e0 * P, a0);
+        load_vec(p1 + e0 * P, a1);
+        if constexpr (HAS3) load_vec(p2 + e0 * P, a2);
+        load_vec(f + e0 * P, fv);
+        if (e0 > 0) load_vec(p0 + (e0 - 1) * P, ab);
+        d_out(a0, a1, HAS3 ? a2 : zero, e0 > 0 ? ab : zero, e0 > 0, fv, ad, ao);
+    }
+    T n0v[N], n1v[N], n2v[N], fn[N];
+    {
+        const int64_t rn = clampr(e0 + 1);
+        load_vec(p0 + rn * P, n0v);
+        load_vec(p1 + rn * P, n1v);
+        if constexpr (HAS3) load_vec(p2 + rn * P, n2v);
+        load_vec(f + rn * P, fn);
+    }
+    // ---- stage 1 state: current row of p^(n+1) (b*), its d / out, the p0^(n+1) row above it, f of its row ----
+    T b0[N], b1[N], b2[N], bd[N], bo[N], babove[N], fcur[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) b0[j] = b1[j] = b2[j] = bd[j] = bo[j] = babove[j] = T(0);
+    load_vec(f + e0 * P, fcur);  // f of the row stage 0 emits in this step = the row that ENTERS stage 1
+    bool b_valid = false, have_above = false;
+    double sqa = 0.0, nsa = 0.0, sqb = 0.0, nsb = 0.0;
+    const int64_t t_last = R1 < a.n0 ? R1 : a.n0 - 1;  // last row stage 0 emits
+    for (int64_t t = e0; t <= R1; ++t) {
+        // prefetch row t + 2 of p^n and f
+        T f0[N], f1[N], f2[N], ff[N];
+        {
+            const int64_t rn = clampr(t + 2);
+            load_vec(p0 + rn * P, f0);
+            load_vec(p1 + rn * P, f1);
+            if constexpr (HAS3) load_vec(p2 + rn * P, f2);
+            load_vec(f + rn * P, ff);
+        }
+        T e_0[N], e_1[N], e_2[N];  // p^(n+1) of row t
+        const bool emit0 = t <= t_last;
+        if (emit0) {
+            T dn[N], on[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) dn[j] = on[j] = T(0);
+            const bool has_next = t + 1 < a.n0;
+            if (has_next) d_out(n0v, n1v, HAS3 ? n2v : zero, a0, true, fn, dn, on);
+            p_update(a0, a1, HAS3 ? a2 : zero, ad, ao, on, has_next, t >= R0 && t < R1, sqa, nsa, e_0, e_1, e_2);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                a0[j] = n0v[j]; a1[j] = n1v[j];
+                if constexpr (HAS3) a2[j] = n2v[j];
+                ad[j] = dn[j];
+                ao[j] = on[j];
+            }
+        }
+        // ---- stage 1: row t of p^(n+1) enters; row t - 1 is emitted ----
+        if (emit0) {
+            T dn[N], on[N];
+            d_out(e_0, e_1, HAS3 ? e_2 : zero, babove, have_above, fcur, dn, on);  // d / out of row t from p^(n+1)
+            if (b_valid) {  // row t - 1 has its out and now the next row's out
+                T r0[N], r1[N], r2[N];
+                p_update(b0, b1, HAS3 ? b2 : zero, bd, bo, on, true, true, sqb, nsb, r0, r1, r2);
+                if (store_lane) {
+                    store_vec_nt(q0 + (t - 1) * P, r0);
+                    store_vec_nt(q1 + (t - 1) * P, r1);
+                    if constexpr (HAS3) store_vec_nt(q2 + (t - 1) * P, r2);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                babove[j] = e_0[j];
+                b0[j] = e_0[j]; b1[j] = e_1[j];
+                if constexpr (HAS3) b2[j] = e_2[j];
+                bd[j] = dn[j];
+                bo[j] = on[j];
+            }
+            have_above = true;
+            b_valid = t >= R0;  // rows before R0 only serve as "row above"
+        } else if (b_valid) {
+            // t == n0: the image's last row leaves stage 1 without a next row
+            T r0[N], r1[N], r2[N];
+            p_update(b0, b1, HAS3 ? b2 : zero, bd, bo, zero, false, true, sqb, nsb, r0, r1, r2);
+            if (store_lane) {
+                store_vec_nt(q0 + (t - 1) * P, r0);
+                store_vec_nt(q1 + (t - 1) * P, r1);
+                if constexpr (HAS3) store_vec_nt(q2 + (t - 1) * P, r2);
+            }
+            b_valid = false;
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            n0v[j] = f0[j]; n1v[j] = f1[j];
+            if constexpr (HAS3) n2v[j] = f2[j];
+            fcur[j] = fn[j];  // f of row t + 1: the row entering stage 1 in the next step
+            fn[j] = ff[j];
+        }
+    }
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        sqa += __shfl_down(sqa, off, kWave);
+        nsa += __shfl_down(nsa, off, kWave);
+        sqb += __shfl_down(sqb, off, kWave);
+        nsb += __shfl_down(nsb, off, kWave);
+    }
+    if (lane == 0) {
+        const int wid = chunk * a.nstrips + strip;
+        a.partial_d2[wid] = sqa;
+        a.partial_n[wid] = nsa;
+        aa.partial_d2_b[wid] = sqb;
+        aa.partial_n_b[wid] = nsb;
+    }
+}
+
 template <typename T>
 static int chambolle_t(int device, int ndim, int64_t n0, int64_t n1, int64_t n2, const void* img, void* out,
                        double weight, double eps, int max_iter, int* iters_done) {
@@ -413,8 +637,34 @@ static int chambolle_t(int device, int ndim, int64_t n0, int64_t n1, int64_t n2,
             nparts = (int)(nchunks * ma.nstrips);
             if ((size_t)nparts > (size_t)nblocks) { set_error("internal: partial buffer too small"); return DXH_EHIP; }
         }
+        // two iterations per pass (k_ch_march2): its own strip geometry (twice the halo)
+        const bool march2 = march && !getenv("DXH_CHAMBOLLE_NO_K2");
+        ChMarch2Args<T> m2{};
+        unsigned march2_grid = 0;
+        int nparts2 = 0;
+        double *partial_d2_b = nullptr, *partial_n_b = nullptr;
+        if (march2) {
+            const int stride = ndim == 2 ? StripGeomK<T, 1, 2>::STRIDE : StripGeomK<T, 3, 2>::STRIDE;
+            m2.m = ma;
+            m2.m.nstrips = (int)((g.L + stride - 1) / stride);
+            const int nbx = (m2.m.nstrips + 3) / 4;
+            int64_t nchunks = std::max<int64_t>(1, (int64_t)ma.nchunks * ((ma.nstrips + 3) / 4) / nbx);
+            if (nchunks >= 8) nchunks = nchunks / 8 * 8;
+            const int64_t rpc = std::max<int64_t>(8, (n0 + nchunks - 1) / nchunks);
+            nchunks = (n0 + rpc - 1) / rpc;
+            m2.m.rows_per_chunk = rpc;
+            m2.m.nchunks = (int)nchunks;
+            march2_grid = (unsigned)(nbx * nchunks);
+            nparts2 = (int)(nchunks * m2.m.nstrips);
+            if ((size_t)nparts2 > (size_t)nblocks) { set_error("internal: partial buffer too small"); return DXH_EHIP; }
+            DXH_HIP(hipMalloc((void**)&partial_d2_b, sizeof(double) * nparts2));
+            extra.push_back(partial_d2_b);
+            DXH_HIP(hipMalloc((void**)&partial_n_b, sizeof(double) * nparts2));
+            extra.push_back(partial_n_b);
+        }
+        int reduce_count = nparts;
         auto reduce = [&](double* part, double* host) -> int {
-            hipLaunchKernelGGL(k_sum_partials, dim3(256), dim3(256), 0, st, part, nparts, stage2);
+            hipLaunchKernelGGL(k_sum_partials, dim3(256), dim3(256), 0, st, part, reduce_count, stage2);
             hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, stage2, 256, red);
             DXH_HIP(hipGetLastError());
             DXH_HIP(hipMemcpyAsync(host, red, sizeof(double), hipMemcpyDeviceToHost, st));
@@ -429,6 +679,53 @@ static int chambolle_t(int device, int ndim, int64_t n0, int64_t n1, int64_t n2,
         while (it < max_iter) {
             double sum_d2 = 0.0, sum_n = 0.0;
             int r;
+            if (march2 && max_iter - it >= 3) {
+                // two iterations in one pass; the last iterations of a run are single ones so that the p the returned
+                // `out` derives from exists in memory
+                m2.m.f = (const T*)bufs[0];
+                for (int ax = 0; ax < 3; ++ax) { m2.m.pin[ax] = pbuf(ax < ndim ? ax : 0, cur); m2.m.pout[ax] = pbuf(ax < ndim ? ax : 0, cur ^ 1); }
+                m2.m.tau = (T)tau; m2.m.tau_over_w = (T)(tau / weight); m2.m.partial_d2 = partial; m2.m.partial_n = partial_n;
+                m2.partial_d2_b = partial_d2_b; m2.partial_n_b = partial_n_b;
+                if (ndim == 2) hipLaunchKernelGGL((k_ch_march2<T, 1, false>), dim3(march2_grid), dim3(256), 0, st, m2);
+                else hipLaunchKernelGGL((k_ch_march2<T, 3, true>), dim3(march2_grid), dim3(256), 0, st, m2);
+                DXH_HIP(hipGetLastError());
+                double d2b = 0.0, nb = 0.0;
+                reduce_count = nparts2;
+                r = reduce(partial, &sum_d2);
+                if (!r) r = reduce(partial_n, &sum_n);
+                if (!r) r = reduce(partial_d2_b, &d2b);
+                if (!r) r = reduce(partial_n_b, &nb);
+                reduce_count = nparts;
+                if (r) return r;
+                // first iteration of the pass: its `out` derives from p[cur], which is untouched
+                out_from = cur;
+                const double ea = (sum_d2 + weight * sum_n) / size;
+                if (it == 0) {
+                    e_init = e_prev = ea;
+                } else {
+                    if (std::fabs(e_prev - ea) < eps * e_init) break;
+                    e_prev = ea;
+                }
+                ++it;
+                // second iteration: its input p^(n+1) lived in registers only
+                const double eb = (d2b + weight * nb) / size;
+                if (std::fabs(e_prev - eb) < eps * e_init) {
+                    // the reference stops here and returns the `out` of this iteration: recompute p^(n+1) alone
+                    ma.f = (const T*)bufs[0];
+                    for (int ax = 0; ax < 3; ++ax) { ma.pin[ax] = pbuf(ax < ndim ? ax : 0, cur); ma.pout[ax] = pbuf(ax < ndim ? ax : 0, cur ^ 1); }
+                    ma.tau = (T)tau; ma.tau_over_w = (T)(tau / weight); ma.partial_d2 = partial; ma.partial_n = partial_n;
+                    if (ndim == 2) hipLaunchKernelGGL((k_ch_march<T, 1, false>), dim3(march_grid), dim3(256), 0, st, ma);
+                    else hipLaunchKernelGGL((k_ch_march<T, 3, true>), dim3(march_grid), dim3(256), 0, st, ma);
+                    DXH_HIP(hipGetLastError());
+                    out_from = cur ^ 1;
+                    break;
+                }
+                e_prev = eb;
+                ++it;
+                cur ^= 1;  // p[cur] = p^(n+2)
+                out_from = -2;  // never used: at least one single iteration follows (max_iter - it >= 1)
+                continue;
+            }
             if (march) {
                 ma.f = (const T*)bufs[0];
                 for (int ax = 0; ax < 3; ++ax) { ma.pin[ax] = pbuf(ax < ndim ? ax : 0, cur); ma.pout[ax] = pbuf(ax < ndim ? ax : 0, cur ^ 1); }
