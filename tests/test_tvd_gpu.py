@@ -452,3 +452,27 @@ def test_reference_regularization_example_flow(capsys):
     h1 = da.H1_regularization(img=img, mu=1, omega=1, dim=3, solver=da.Jacobi(maxiter=30, tol=1e-6))
     ref_h1 = O.h1_regularization(vol, mu=1, omega=1, dim=3, jacobi_maxiter=30, jacobi_tol=1e-6, promotion="strict")
     assert_bits(h1.img, ref_h1)
+
+
+@pytest.mark.parametrize("shape", [(90, 130), (60, 85, 3)])
+def test_chambolle_stop_iteration_inside_two_iteration_passes(shape):
+    """Every stop iteration from 2 to 12 (both positions inside the two-iteration passes, and the single-iteration
+    tail when max_num_iter ends the run): same iteration count and bits as the oracle."""
+    from oracle import chambolle_numpy as CH
+    from darsia_amd.synthetic import synthetic_image
+    img = synthetic_image(shape[0], shape[1], 3).astype(np.float64)
+    img = np.ascontiguousarray(img if len(shape) == 3 else img[..., 0])
+    seen = set()
+    for eps in (3e-2, 2e-2, 1e-2, 5e-3, 2e-3, 1e-3, 7e-4, 5e-4, 3e-4, 2e-4):
+        ref, n_ref = CH.denoise_tv_chambolle(img, weight=0.12, eps=eps, max_num_iter=50, return_iters=True)
+        out, n = da.denoise_tv_chambolle(img, weight=0.12, eps=eps, max_num_iter=50, return_iters=True)
+        assert n == n_ref
+        np.testing.assert_array_equal(out, ref)
+        seen.add(n)
+    # the gray image stops at odd counts (second iteration of a pass), the colour image also at 4 (first iteration)
+    assert ({3, 5, 7, 11} <= seen) if len(shape) == 2 else ({3, 4, 5} <= seen)
+    for m in (1, 2, 3, 4, 5, 6, 7):  # runs ended by max_num_iter
+        ref, n_ref = CH.denoise_tv_chambolle(img, weight=0.12, eps=0.0, max_num_iter=m, return_iters=True)
+        out, n = da.denoise_tv_chambolle(img, weight=0.12, eps=0.0, max_num_iter=m, return_iters=True)
+        assert n == n_ref == m
+        np.testing.assert_array_equal(out, ref)
