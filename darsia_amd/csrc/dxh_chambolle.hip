@@ -627,7 +627,9 @@ static int chambolle_t(int device, int ndim, int64_t n0, int64_t n1, int64_t n2,
             int ncu = 256;
             hipDeviceProp_t prop;
             if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
-            int64_t nchunks = std::max<int64_t>(1, (int64_t)ncu * 3 / nbx);  // ~12 waves per CU
+            int wpc4 = 6;  // blocks (of 4 waves) per CU the grid is sized for (measured best of 2..8)
+            if (const char* e = getenv("DXH_CH_BLOCKS_PER_CU")) wpc4 = std::max(1, atoi(e));
+            int64_t nchunks = std::max<int64_t>(1, (int64_t)ncu * wpc4 / nbx);
             if (nchunks >= 8) nchunks = nchunks / 8 * 8;
             const int64_t rpc = std::max<int64_t>(8, (n0 + nchunks - 1) / nchunks);
             nchunks = (n0 + rpc - 1) / rpc;
