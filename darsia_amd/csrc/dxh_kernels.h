@@ -1551,4 +1551,124 @@ __global__ void __launch_bounds__(256, ((K >= 3 || HET) ? DXH_LB4 : 3)) k_fused_
         fused_pipe_body<T, C, COUPLED, ISO, K, NTS, false, NORM, HET>(a, strip, chunk, lane, lds_lane);
 }
 
+// ============================================================================================
+// K Jacobi sweeps in one pass (Jacobi(maxiter > 1), H1_regularization; jacobi.py:110-114):
+//     x_{s+1} = rs + N(x_s) / dsc        rs = rhs / diag is the same for every sweep
+// Row-marching waves as in the fused TV sweep; stage s applies sweep s to row r - s and takes the row below it
+// from stage s - 1's output of the same step.  Only x_0 and rs are read and x_K written: 12 B per element for K
+// sweeps instead of 12 B per sweep.  Scalar coefficients, dim = 2, no tolerance test.
+// ============================================================================================
+template <typename T>
+struct JacobiMultiArgs {
+    const T* rs;
+    const T* x_in;
+    T* x_out;
+    int64_t n0, L, pitch, rows_per_chunk;
+    int nstrips, nchunks;
+    T dsc;
+};
+
+template <typename T, int C, bool COUPLED, int K>
+__global__ void __launch_bounds__(256) k_jacobi_multi(JacobiMultiArgs<T> a) {
+    constexpr int N = VecOf<T>::N;
+    using SG = StripGeomK<T, C, K>;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    const int nbx = (a.nstrips + 3) / 4;
+    int bx, chunk;
+    block_to_tile((int)blockIdx.x, nbx, a.nchunks, bx, chunk);
+    const int strip = bx * 4 + wave;
+    if (strip >= a.nstrips || chunk >= a.nchunks) return;  // wave-uniform
+    const int64_t R0 = (int64_t)chunk * a.rows_per_chunk;
+    const int64_t R1 = (R0 + a.rows_per_chunk < a.n0) ? R0 + a.rows_per_chunk : a.n0;
+    if (R0 >= a.n0) return;
+    const int64_t x0 = (int64_t)strip * SG::STRIDE + (int64_t)(lane - SG::LH) * N;
+    int64_t xl = x0;
+    if (xl < 0) xl = 0;
+    if (xl > a.pitch - N) xl = a.pitch - N;
+    const bool store_lane = lane >= SG::LH && lane < SG::LH + SG::VALID && x0 < a.L;
+    bool edgeL[N], edgeR[N], ch0[N], chLast[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int64_t x = x0 + j;
+        edgeL[j] = x < C;
+        edgeR[j] = x >= a.L - C;
+        const int cc = (int)(((x % C) + C) % C);
+        ch0[j] = cc == 0;
+        chLast[j] = cc == C - 1;
+    }
+    const int64_t P = a.pitch;
+    const T* rs = a.rs + xl;
+    const T* xin = a.x_in + xl;
+    T* xout = a.x_out + xl;
+    auto clampr = [&](int64_t r) -> int64_t { return r < 0 ? 0 : (r > a.n0 - 1 ? a.n0 - 1 : r); };
+
+    // stage s: um[s], uc[s] = rows p - 1, p of x_s (p = r - s); rsd[s] = rs of row r - s
+    T um[K][N], uc[K][N], rsd[K][N];
+#pragma unroll
+    for (int s2 = 0; s2 < K; ++s2)
+#pragma unroll
+        for (int j = 0; j < N; ++j) um[s2][j] = uc[s2][j] = rsd[s2][j] = T(0);
+    const int64_t rstart = R0 - (K - 1);  // the last stage reaches R0 with valid rows above it
+    load_vec(xin + clampr(rstart - 1) * P, um[0]);
+    load_vec(xin + clampr(rstart) * P, uc[0]);
+    T up0[N], rsn[N];
+    load_vec(xin + clampr(rstart + 1) * P, up0);
+    load_vec(rs + clampr(rstart) * P, rsn);
+    for (int64_t r = rstart; r <= R1 - 1 + (K - 1); ++r) {
+        T upn[N], rsf[N];
+        load_vec(xin + clampr(r + 2) * P, upn);
+        load_vec(rs + clampr(r + 1) * P, rsf);
+        // shift the rs delay line: rsd[s] = rs of row r - s
+#pragma unroll
+        for (int s2 = K - 1; s2 >= 1; --s2)
+#pragma unroll
+            for (int j = 0; j < N; ++j) rsd[s2][j] = rsd[s2 - 1][j];
+#pragma unroll
+        for (int j = 0; j < N; ++j) rsd[0][j] = rsn[j];
+        T below[N];  // row p + 1 of the stage's input level: loaded for stage 0, the previous stage's output otherwise
+#pragma unroll
+        for (int j = 0; j < N; ++j) below[j] = up0[j];
+#pragma unroll
+        for (int s2 = 0; s2 < K; ++s2) {
+            const int64_t p = r - s2;
+            T xn[N];
+            T ul[N], ur[N], ucl[N], ucr[N];
+            shifted<-C, true>(uc[s2], ul);
+            shifted<+C, true>(uc[s2], ur);
+            if constexpr (COUPLED) {
+                shifted<-1, true>(uc[s2], ucl);
+                shifted<+1, true>(uc[s2], ucr);
+            }
+            const bool top = p <= 0, bottom = p >= a.n0 - 1;  // uniform: replicate ghosts (jacobi.py:43,52)
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                T acc = (top ? uc[s2][j] : um[s2][j]) + (bottom ? uc[s2][j] : below[j]);
+                acc = acc + (edgeL[j] ? uc[s2][j] : ul[j]);
+                acc = acc + (edgeR[j] ? uc[s2][j] : ur[j]);
+                if constexpr (COUPLED) {
+                    acc = acc + (ch0[j] ? uc[s2][j] : ucl[j]);
+                    acc = acc + (chLast[j] ? uc[s2][j] : ucr[j]);
+                }
+                xn[j] = rsd[s2][j] + acc / a.dsc;
+            }
+            if (s2 == K - 1) {
+                if (store_lane && p >= R0 && p < R1) store_vec_nt(xout + p * P, xn);
+            }
+            // rotate this stage's window; its output is the row below for the next stage (which sits one row up)
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                um[s2][j] = uc[s2][j];
+                uc[s2][j] = below[j];
+                below[j] = xn[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            up0[j] = upn[j];
+            rsn[j] = rsf[j];
+        }
+    }
+}
+
 }  // namespace dxh

@@ -2,7 +2,9 @@
 // Every kernel evaluates the reference's NumPy expressions operation by operation (-ffp-contract=off), so the
 // multigrid results are bit-identical to the reference's (oracle/solvers_numpy.py states the algorithm and its
 // quirks; tests/golden/solvers_golden.npz holds the reference's own outputs).  gfx950 only.
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -346,6 +348,46 @@ struct MGSolver final : DeviceSolver {
         CoefPlanes<T> cp{};
         cp.dsc = het ? (const T*)L.dsc : nullptr;
         const void* src = in;
+        int sweeps = smooth_it;
+        if (!het && L.g.dim == 2 && L.g.n2 == 1 && sweeps >= 2 && !getenv("DXH_MG_NO_MULTI")) {
+            // several sweeps per pass (k_jacobi_multi, bit-identical to sweep by sweep); a remainder of one sweep and
+            // the final placement in `out` are handled by the loop below
+            int left = sweeps;
+            int flip = 0;
+            while (left >= 2) {
+                const int k = left == 5 ? 3 : std::min(4, left);
+                void* dst = (left - k == 0) ? out : (flip ? L.t1 : L.t0);
+                JacobiMultiArgs<T> ja;
+                ja.rs = (const T*)L.rs; ja.x_in = (const T*)src; ja.x_out = (T*)dst;
+                ja.n0 = L.g.n0; ja.L = L.g.L; ja.pitch = L.g.pitch; ja.dsc = c_dsc;
+#define DXH_MGJ(K_)                                                                                                        \
+    {                                                                                                                      \
+        using SG = StripGeomK<T, 1, K_>;                                                                                  \
+        ja.nstrips = (int)((L.g.L + SG::STRIDE - 1) / SG::STRIDE);                                                        \
+        const int nbx = (ja.nstrips + 3) / 4;                                                                             \
+        int64_t nchunks = std::max<int64_t>(1, (int64_t)1024 / nbx);                                                      \
+        if (nchunks >= 8) nchunks = nchunks / 8 * 8;                                                                      \
+        const int64_t rpc = std::max<int64_t>(8 * K_, (L.g.n0 + nchunks - 1) / nchunks);                                  \
+        nchunks = (L.g.n0 + rpc - 1) / rpc;                                                                               \
+        ja.rows_per_chunk = rpc;                                                                                          \
+        ja.nchunks = (int)nchunks;                                                                                        \
+        hipLaunchKernelGGL((k_jacobi_multi<T, 1, false, K_>), dim3((unsigned)(nbx * nchunks)), dim3(256), 0, stream, ja); \
+    }
+                if (k == 2) DXH_MGJ(2) else if (k == 3) DXH_MGJ(3) else DXH_MGJ(4)
+#undef DXH_MGJ
+                ++launches;
+                src = dst;
+                flip ^= 1;
+                left -= k;
+            }
+            sweeps = left;  // 0 or 1
+            if (sweeps == 1) {
+                hipLaunchKernelGGL((k_jacobi<T>), grid, blk, 0, stream, L.g, (const T*)L.rs, (const T*)src, co, cp, (T*)out);
+                ++launches;
+            }
+            DXH_HIP(hipGetLastError());
+            return DXH_OK;
+        }
         for (int s = 0; s < smooth_it; ++s) {
             void* dst = (s == smooth_it - 1) ? out : (s & 1 ? L.t1 : L.t0);
             hipLaunchKernelGGL((k_jacobi<T>), grid, blk, 0, stream, L.g, (const T*)L.rs, (const T*)src, co, cp, (T*)dst);

@@ -414,6 +414,46 @@ static void launch_jacobi(Ctx* c, const void* xin, void* xout) {
                        make_coef<T>(c), make_planes<T>(c), (T*)xout);
 }
 
+// K Jacobi sweeps in one pass (k_jacobi_multi): dim = 2, scalar coefficients, 1 or 3 channels
+static bool jacobi_multi_supported(const Ctx* c) {
+    return c->desc.dim == 2 && !c->het && (c->g.n2 == 1 || c->g.n2 == 3) && !(c->tune & 64);
+}
+
+template <typename T, int C, bool COUPLED, int K>
+static void launch_jacobi_multi_k(Ctx* c, const void* xin, void* xout) {
+    using SG = StripGeomK<T, C, K>;
+    JacobiMultiArgs<T> a;
+    a.rs = (const T*)c->rs;
+    a.x_in = (const T*)xin;
+    a.x_out = (T*)xout;
+    a.n0 = c->g.n0; a.L = c->g.L; a.pitch = c->g.pitch;
+    a.nstrips = (int)((c->g.L + SG::STRIDE - 1) / SG::STRIDE);
+    const int nbx = (a.nstrips + 3) / 4;
+    int64_t nchunks = std::max<int64_t>(1, (int64_t)c->num_cu * 4 / nbx);
+    if (nchunks >= 8) nchunks = nchunks / 8 * 8;
+    const int64_t rpc = std::max<int64_t>(8 * K, (c->g.n0 + nchunks - 1) / nchunks);
+    nchunks = (c->g.n0 + rpc - 1) / rpc;
+    a.rows_per_chunk = rpc;
+    a.nchunks = (int)nchunks;
+    a.dsc = (T)c->c_dsc;
+    hipLaunchKernelGGL((k_jacobi_multi<T, C, COUPLED, K>), dim3((unsigned)(nbx * nchunks)), dim3(256), 0, c->stream, a);
+}
+
+template <typename T>
+static void launch_jacobi_multi(Ctx* c, const void* xin, void* xout, int K) {
+    const bool coupled = c->g.ndim == 3 && c->g.nsum_axes == 3;
+#define DXH_JM(C_, CP_)                                                        \
+    switch (K) {                                                               \
+        case 2: launch_jacobi_multi_k<T, C_, CP_, 2>(c, xin, xout); break;     \
+        case 3: launch_jacobi_multi_k<T, C_, CP_, 3>(c, xin, xout); break;     \
+        default: launch_jacobi_multi_k<T, C_, CP_, 4>(c, xin, xout); break;    \
+    }
+    if (c->g.n2 == 1) { DXH_JM(1, false) }
+    else if (coupled) { DXH_JM(3, true) }
+    else { DXH_JM(3, false) }
+#undef DXH_JM
+}
+
 // Jacobi.__call__ on device buffers: x0 in u[cur], rs ready; leaves the result in u[cur ^ 1]... or, when
 // the reference returns x0 itself (tol met on the first sweep, or maxiter == 0), copies it there.
 // Needs a third buffer for sweeps > 1: `tmp`.
@@ -431,6 +471,21 @@ static int jacobi_sweeps(Ctx* c, int maxiter, double tol, void* tmp, int64_t* la
     const void* x = c->u[in];
     void* bufs[2] = {c->u[out], tmp};
     int w = 0, done = 0;
+    if (!use_tol && maxiter >= 2 && jacobi_multi_supported(c)) {
+        // several sweeps per pass; a remainder of one sweep goes through the single-sweep kernel below
+        int left = maxiter;
+        while (left >= 2) {
+            const int k = left == 5 ? 3 : std::min(4, left);
+            void* xn = bufs[w];
+            launch_jacobi_multi<T>(c, x, xn, k);
+            ++*launches;
+            x = xn;
+            w ^= 1;
+            left -= k;
+            done += k;
+        }
+        maxiter = left;  // 0 or 1
+    }
     for (int s = 0; s < maxiter; ++s) {
         void* xn = bufs[w];
         launch_jacobi<T>(c, x, xn);

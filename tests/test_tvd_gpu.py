@@ -476,3 +476,21 @@ def test_chambolle_stop_iteration_inside_two_iteration_passes(shape):
         out, n = da.denoise_tv_chambolle(img, weight=0.12, eps=0.0, max_num_iter=m, return_iters=True)
         assert n == n_ref == m
         np.testing.assert_array_equal(out, ref)
+
+
+@pytest.mark.parametrize("maxiter", [2, 3, 4, 5, 6, 7, 9, 20])
+@pytest.mark.parametrize("shape,dtype", [((70, 300, 3), np.float32), ((61, 333), np.float64), ((1, 40), np.float32), ((9, 2, 3), np.float64)])
+def test_multi_sweep_jacobi_bit_exact(maxiter, shape, dtype, monkeypatch):
+    """Jacobi(maxiter > 1): several sweeps per pass (k_jacobi_multi) against the sweep-by-sweep kernel and the oracle,
+    stand-alone, inside the TV loop and through H1_regularization."""
+    rng = np.random.default_rng(maxiter)
+    x0 = rng.random(shape).astype(dtype)
+    rhs = rng.random(shape).astype(dtype)
+    fast = da.Jacobi(maxiter=maxiter, mass_coeff=1.0, diffusion_coeff=0.4, dim=2)(x0, rhs)
+    tv_fast = da.split_bregman_tvd(x0, mu=0.1, max_num_iter=3, solver=da.Jacobi(maxiter=maxiter))
+    h1_fast = da.H1_regularization(x0, mu=0.3, omega=1.0, dim=2, solver=da.Jacobi(maxiter=maxiter))
+    monkeypatch.setenv("DXH_FUSED_TUNE", "64")  # sweep by sweep
+    np.testing.assert_array_equal(fast, da.Jacobi(maxiter=maxiter, mass_coeff=1.0, diffusion_coeff=0.4, dim=2)(x0, rhs))
+    assert_bits(fast, O.jacobi(x0, rhs, 1.0, 0.4, dim=2, maxiter=maxiter, promotion="strict"))
+    assert_bits(tv_fast, O.split_bregman_tvd(x0, mu=0.1, max_num_iter=3, jacobi_maxiter=maxiter, promotion="strict"))
+    assert_bits(h1_fast, O.h1_regularization(x0, mu=0.3, omega=1.0, dim=2, jacobi_maxiter=maxiter, promotion="strict"))
