@@ -17,9 +17,20 @@ from ..utils.linear_solvers.solver import Solver
 def _h1_array(img: np.ndarray, mu: float, omega: float, dim: int, solver: Solver) -> np.ndarray:
     if img.dtype.kind != "f":
         raise TypeError("H1_regularization needs a float32/float64 image")
-    if not isinstance(solver, Jacobi):
-        raise NotImplementedError("only darsia_amd.Jacobi is available on the device path")
     solver.update_params(mass_coeff=omega, diffusion_coeff=mu, dim=dim)
+    if not isinstance(solver, Jacobi):
+        # MG / CG objects (device solvers themselves): the reference's generic flow, channel by channel
+        # (h1_regularization.py:54-70)
+        if not callable(solver):
+            raise TypeError("solver must be a darsia_amd Solver object")
+        if img.ndim != dim:
+            moved = np.moveaxis(img, np.arange(dim).tolist(), np.arange(-dim, 0).tolist())
+            res = np.zeros_like(moved)
+            for idx in np.ndindex(moved.shape[:-dim]):
+                plane = np.ascontiguousarray(moved[idx])
+                res[idx] = solver(plane, omega * plane)
+            return np.ascontiguousarray(np.moveaxis(res, np.arange(-dim, 0).tolist(), np.arange(dim).tolist()))
+        return solver(img, omega * img)
     code = _lib.dtype_code(img.dtype)
     _lib.require_gpu()
     src = np.ascontiguousarray(img)

@@ -158,3 +158,18 @@ def test_tvd_with_mg_rejects_channel_images():
     from darsia_amd.synthetic import synthetic_image
     with pytest.raises(ValueError):
         da.split_bregman_tvd(synthetic_image(32, 32, 3), mu=0.1, max_num_iter=2, solver=da.MG(depth=1))
+
+
+def test_h1_regularization_with_cg_and_mg():
+    """H1_regularization(solver=CG / MG) as in examples/paper/pet_simulations_comparison_block_b.py:680-686."""
+    rng = np.random.default_rng(9)
+    vol = rng.random((24, 30, 20))
+    out = da.H1_regularization(vol, mu=0.1, omega=0.7, dim=3, solver=da.CG(maxiter=10000, tol=1e-9))
+    ref = so.CG(maxiter=10000, tol=1e-9, dim=3, mass_coeff=0.7, diffusion_coeff=0.1)(vol, 0.7 * vol)
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1e-8)
+    img = rng.random((40, 56, 3))
+    out = da.H1_regularization(img, mu=0.2, omega=1.0, dim=2, solver=da.MG(depth=1, smoother_iterations=3, maxiter=2))
+    for c in range(3):
+        ref = so.MG(depth=1, smoother_iterations=3, maxiter=2, dim=2, mass_coeff=1.0, diffusion_coeff=0.2)(
+            np.ascontiguousarray(img[..., c]), 1.0 * np.ascontiguousarray(img[..., c]))
+        np.testing.assert_array_equal(out[..., c], ref)
