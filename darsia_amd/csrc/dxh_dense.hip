@@ -122,8 +122,10 @@ __global__ void __launch_bounds__(256) k_tps(TpsArgs a) {
     const double* cf = sm + nc;
     for (int i = 0; i < a.p; ++i) {
         const double dx = x - sm[2 * i], dy = y - sm[2 * i + 1];
-        const double r = sqrt(dx * dx + dy * dy);
-        const double phi = r == 0.0 ? 0.0 : (r * r) * log(r);
+        // thin-plate spline r^2 log r = 0.5 r^2 log(r^2): no square root (SciPy evaluates r^2 log r; the two forms
+        // differ in the last bits only, tests compare to 1e-10)
+        const double r2 = dx * dx + dy * dy;
+        const double phi = r2 == 0.0 ? 0.0 : 0.5 * r2 * log(r2);
         acc0 += phi * cf[i * a.dout];
         if (a.dout > 1) acc1 += phi * cf[i * a.dout + 1];
     }

@@ -133,9 +133,16 @@ class PiecewisePerspectiveTransform:
         table = (_lib.WarpPatch * max(1, len(records)))(*records)
         _lib.check(_lib.load().dxh_warp_patches(_lib.default_device(), h, w, chans, _lib.ptr(src),
                                                  C.cast(table, C.c_void_p), len(records), _lib.ptr(canvas)))
-        out = canvas.astype(base.dtype)
-        result = copy.copy(patches.base)
-        result = patches.base.copy() if hasattr(patches.base, "copy") else result
+        out = canvas.astype(base.dtype, copy=False)
+        # the reference returns a new image with the base's metadata (piecewiseperspective.py:143-145); copy the
+        # container without its pixel array (a deep copy of the base would cost more than the warp)
+        holder = patches.base
+        pixels = holder.img
+        try:
+            holder.img = pixels[:0]
+            result = holder.copy() if hasattr(holder, "copy") else copy.copy(holder)
+        finally:
+            holder.img = pixels
         result.img = out
         return result
 
