@@ -90,3 +90,17 @@ class OpticalImage(Image):
     def __init__(self, img: np.ndarray, **kwargs) -> None:
         kwargs["scalar"] = False
         super().__init__(img, **kwargs)
+
+
+def with_array(img, array: np.ndarray):
+    """A copy of the Image-like ``img`` (any object with ``.img`` and ``.copy()``, e.g. ``darsia.Image``) that carries
+    ``array`` instead of its pixels.  Equivalent to ``out = img.copy(); out.img = array`` as the reference writes it
+    (tvd.py:127-129, piecewiseperspective.py:143-145) without deep-copying the old pixel array first -- 40 ms per 384 MB."""
+    pixels = img.img
+    try:
+        img.img = pixels[:0]
+        out = img.copy()
+    finally:
+        img.img = pixels
+    out.img = array
+    return out

@@ -22,7 +22,7 @@ from typing import Callable
 import numpy as np
 
 from . import _lib
-from .image import Image
+from .image import Image, with_array
 
 
 def get_perspective_transform(src: np.ndarray, dst: np.ndarray) -> np.ndarray:
@@ -136,15 +136,7 @@ class PiecewisePerspectiveTransform:
         out = canvas.astype(base.dtype, copy=False)
         # the reference returns a new image with the base's metadata (piecewiseperspective.py:143-145); copy the
         # container without its pixel array (a deep copy of the base would cost more than the warp)
-        holder = patches.base
-        pixels = holder.img
-        try:
-            holder.img = pixels[:0]
-            result = holder.copy() if hasattr(holder, "copy") else copy.copy(holder)
-        finally:
-            holder.img = pixels
-        result.img = out
-        return result
+        return with_array(patches.base, out) if hasattr(patches.base, "copy") else out
 
 
 def evaluate_rbf(rbf, points: np.ndarray) -> np.ndarray:

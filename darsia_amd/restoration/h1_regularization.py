@@ -10,6 +10,7 @@ from typing import Optional
 import numpy as np
 
 from .. import _lib
+from ..image import with_array
 from ..utils.linear_solvers.jacobi import Jacobi
 from ..utils.linear_solvers.solver import Solver
 
@@ -60,7 +61,5 @@ def H1_regularization(img, mu: float, omega: float = 1.0, dim: int = 2, solver: 
     if isinstance(img, np.ndarray):
         return _h1_array(img, mu, omega, dim, solver)
     if hasattr(img, "img") and hasattr(img, "copy"):
-        out = img.copy()
-        out.img = _h1_array(img.img, mu, omega, dim, solver)
-        return out
+        return with_array(img, _h1_array(img.img, mu, omega, dim, solver))
     raise TypeError(f"Type {type(img)} not supported.")

@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import numpy as np
 
+from ..image import with_array
 from .bregman_gs import denoise_tv_bregman
 from .chambolle import denoise_tv_chambolle
 from .split_bregman_tvd import split_bregman_tvd
@@ -69,17 +70,8 @@ class TVD:
             raise ValueError(f"Method {self.method} not supported.")
 
     def _tvd_image(self, img):
-        result = self._tvd_array(img.img)
-        # tvd.py:127-129 deep-copies the image and replaces its array; copying the container without its pixel array
-        # gives the same object and saves a 384 MB host copy
-        array = img.img
-        try:
-            img.img = array[:0]  # empty view: copy() duplicates the container, not the pixels
-            img_copy = img.copy()
-        finally:
-            img.img = array
-        img_copy.img = result
-        return img_copy
+        # tvd.py:127-129: a copy of the image with the denoised array
+        return with_array(img, self._tvd_array(img.img))
 
 
 def tvd(img, method: str = "chambolle", weight=1.0, max_num_iter: int = 200, eps: float = 2e-4, **kwargs):
