@@ -327,6 +327,7 @@ struct CoefIn {
     T ell_over_h2_s;         // T(ell/h^2) when ell is scalar
     T h2;                    // T(h^2)
     T two_dim;               // unused helper
+    T diag_s, dsc_s;         // omega AND ell scalar (only mu is an array): the reference's diagonal is a Python float
     int dim;
     int has_ell;
 };
@@ -350,10 +351,16 @@ __device__ __forceinline__ void derive_coefs(const CoefIn<T>& in, T mu_v, T omeg
         lap = in.two_dim_over_h2_ell_s;
         ell_h2 = in.ell_over_h2_s;
     }
-    const T omega = in.omega ? omega_v : in.omega_s;
-    diag = omega + lap;
     const T mu = in.mu ? mu_v : in.mu_s;
-    dsc = diag / ell_h2;
+    if (!ell_is_arr && !in.omega) {
+        // omega + ell*2*dim/h**2 and its quotient by ell/h**2 are folded in double by Python and rounded once
+        diag = in.diag_s;
+        dsc = in.dsc_s;
+    } else {
+        const T omega = in.omega ? omega_v : in.omega_s;
+        diag = omega + lap;
+        dsc = diag / ell_h2;
+    }
     kq = mu / ell;
 }
 

@@ -290,6 +290,8 @@ struct MGSolver final : DeviceSolver {
         const double h2 = h * h;
         in.two_dim_over_h2_ell_s = (T)(diff_s * 2 * L.g.dim / h2);
         in.ell_over_h2_s = (T)(diff_s / h2);
+        in.diag_s = (T)(mass_s + diff_s * 2 * L.g.dim / h2);
+        in.dsc_s = (T)((mass_s + diff_s * 2 * L.g.dim / h2) / (diff_s / h2));
         in.h2 = (T)h2;
         in.two_dim = (T)(2 * L.g.dim);
         in.dim = L.g.dim;

@@ -136,6 +136,11 @@ static CoefIn<T> make_coefin(const Ctx* c) {
     in.ell_s = (T)c->ell_s;
     in.two_dim_over_h2_ell_s = (T)(c->ell_s * 2 * dim / h2);
     in.ell_over_h2_s = (T)(c->ell_s / h2);
+    {
+        const double diag_d = c->omega_s + c->ell_s * 2 * dim / h2;
+        in.diag_s = (T)diag_d;
+        in.dsc_s = (T)(diag_d / (c->ell_s / h2));
+    }
     in.h2 = (T)h2;
     in.two_dim = (T)(2 * dim);
     in.dim = dim;
@@ -448,7 +453,10 @@ static void launch_jacobi_multi(Ctx* c, const void* xin, void* xout, int K) {
         case 3: launch_jacobi_multi_k<T, C_, CP_, 3>(c, xin, xout); break;     \
         default: launch_jacobi_multi_k<T, C_, CP_, 4>(c, xin, xout); break;    \
     }
-    if (c->g.n2 == 1) { DXH_JM(1, false) }
+    if (c->g.n2 == 1) {
+        // an (H, W, 1) array still sums over its third axis: both channel neighbours are the element itself
+        if (coupled) { DXH_JM(1, true) } else { DXH_JM(1, false) }
+    }
     else if (coupled) { DXH_JM(3, true) }
     else { DXH_JM(3, false) }
 #undef DXH_JM
@@ -744,6 +752,11 @@ static int set_coeffs_t(Ctx* c, double mu, const void* mu_arr, double omega, con
     in.ell_s = (T)ell_d;
     in.two_dim_over_h2_ell_s = (T)(ell_d * 2 * dim / h2);
     in.ell_over_h2_s = (T)(ell_d / h2);
+    {
+        const double diag_d = omega + ell_d * 2 * dim / h2;
+        in.diag_s = (T)diag_d;
+        in.dsc_s = (T)(diag_d / (ell_d / h2));
+    }
     in.h2 = (T)h2;
     in.two_dim = (T)(2 * dim);
     in.dim = dim;

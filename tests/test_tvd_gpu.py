@@ -494,3 +494,41 @@ def test_multi_sweep_jacobi_bit_exact(maxiter, shape, dtype, monkeypatch):
     assert_bits(fast, O.jacobi(x0, rhs, 1.0, 0.4, dim=2, maxiter=maxiter, promotion="strict"))
     assert_bits(tv_fast, O.split_bregman_tvd(x0, mu=0.1, max_num_iter=3, jacobi_maxiter=maxiter, promotion="strict"))
     assert_bits(h1_fast, O.h1_regularization(x0, mu=0.3, omega=1.0, dim=2, jacobi_maxiter=maxiter, promotion="strict"))
+
+
+def test_regressions_found_by_the_fuzzer():
+    """(1) (H, W, 1) arrays sum over their length-1 third axis in every sweep of Jacobi(maxiter > 1);
+    (2) array-valued mu with scalar omega and ell: the diagonal is a Python float folded in double."""
+    rng = np.random.default_rng(21)
+    img = rng.random((18, 27, 1))
+    assert_bits(da.split_bregman_tvd(img, mu=0.1, ell=0.3, max_num_iter=3, solver=da.Jacobi(maxiter=2)),
+                O.split_bregman_tvd(img, mu=0.1, ell=0.3, max_num_iter=3, jacobi_maxiter=2, promotion="strict"))
+    for shape in ((68, 331, 3), (61, 159), (29, 24, 3), (13, 617, 2)):
+        img = rng.random(shape).astype(np.float32)
+        mu = (0.02 + 0.2 * rng.random(shape)).astype(np.float32)
+        for n in (1, 4, 7):
+            assert_bits(da.split_bregman_tvd(img, mu=mu, ell=0.3, max_num_iter=n),
+                        O.split_bregman_tvd(img, mu=mu, ell=0.3, max_num_iter=n, promotion="strict"))
+
+
+def test_small_random_sweep_of_parameters():
+    """A short run of tools/fuzz_tvd.py's generator inside the suite."""
+    rng = np.random.default_rng(1234)
+    for _ in range(60):
+        h, w = int(rng.integers(1, 60)), int(rng.integers(1, 500))
+        c = int(rng.choice([0, 1, 2, 3, 4]))
+        shape = (h, w) if c == 0 else (h, w, c)
+        dt = rng.choice([np.float32, np.float64])
+        img = rng.random(shape).astype(dt)
+        kw = dict(max_num_iter=int(rng.integers(1, 12)))
+        het = rng.random() < 0.4
+        kw["mu"] = (0.02 + 0.2 * rng.random(shape)).astype(dt) if het else float(rng.choice([0.05, 0.1, 0.3]))
+        if rng.random() < 0.3:
+            kw["omega"] = (0.5 + rng.random(shape)).astype(dt) if (het and rng.random() < 0.5) else float(rng.choice([0.5, 2.0]))
+        if rng.random() < 0.3:
+            kw["ell"] = float(rng.choice([0.3, 1.0]))
+        if rng.random() < 0.3:
+            kw["eps"] = float(rng.choice([1e-2, 3e-3]))
+        jm = int(rng.choice([1, 1, 2, 3, 5]))
+        assert_bits(da.split_bregman_tvd(img, solver=da.Jacobi(maxiter=jm), **kw),
+                    O.split_bregman_tvd(img, jacobi_maxiter=jm, promotion="strict", **kw))
