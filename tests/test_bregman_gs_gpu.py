@@ -63,3 +63,27 @@ def test_medium_image_properties():
     b = da.denoise_tv_bregman(img, weight=1.0, max_num_iter=4, eps=0.0, isotropic=False)
     np.testing.assert_array_equal(a, b)
     assert np.isfinite(a).all() and abs(float(a.mean()) - float(img.mean())) < 1e-2
+
+
+def test_small_random_sweep_chambolle_and_gauss_seidel():
+    """A short run of tools/fuzz_others.py's generator inside the suite (bit-exact incl. iteration counts)."""
+    from oracle import chambolle_numpy as CH
+    rng = np.random.default_rng(77)
+    for _ in range(30):
+        h, w = int(rng.integers(1, 60)), int(rng.integers(1, 300))
+        c = int(rng.choice([0, 1, 3]))
+        shape = (h, w) if c == 0 else (h, w, c)
+        dt = rng.choice([np.float32, np.float64])
+        img = rng.random(shape).astype(dt)
+        it = int(rng.integers(1, 12))
+        eps = float(rng.choice([0.0, 1e-3, 1e-2]))
+        wgt = float(rng.choice([0.05, 0.2, 1.0]))
+        o, n = da.denoise_tv_chambolle(img, weight=wgt, eps=eps, max_num_iter=it, return_iters=True)
+        r, nr = CH.denoise_tv_chambolle(img, weight=wgt, eps=eps, max_num_iter=it, return_iters=True)
+        assert n == nr
+        np.testing.assert_array_equal(o, r)
+        iso = bool(rng.random() < 0.5)
+        o, n = da.denoise_tv_bregman(img, weight=wgt * 5, max_num_iter=it, eps=eps, isotropic=iso, return_iters=True)
+        r, nr = bg.denoise_tv_bregman(img, weight=wgt * 5, max_num_iter=it, eps=eps, isotropic=iso, return_iterations=True)
+        assert n == nr
+        np.testing.assert_array_equal(o, r)
