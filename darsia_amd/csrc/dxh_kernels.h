@@ -910,6 +910,11 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+// accumulator type of the per-iteration squared increments: the element type (NumPy squares in the array dtype too;
+// a float accumulator for double images would lose small magnitudes entirely)
+template <typename T>
+using IncT = T;
+
 template <typename T, int K>
 struct PipeState {
     static constexpr int N = VecOf<T>::N;
@@ -997,7 +1002,7 @@ struct Pipe {
     }
 
     template <int PH, int ROLE = 0>
-    __device__ __forceinline__ void step(PipeState<T, K>& st, float (&inc)[NORM ? K : 1][N], const int64_t r) const {
+    __device__ __forceinline__ void step(PipeState<T, K>& st, IncT<T> (&inc)[NORM ? K : 1][N], const int64_t r) const {
         constexpr int PFD = (K >= 4 && ROLE == 0) ? 2 : 1;  // prefetch distance in steps
         constexpr bool INTRA_LDS = ROLE == 0;               // of / q1 hand-off between own stages through LDS
         // prefetch the level-0 rows of a later step: distance 1 straight into their ring slots, distance 2
@@ -1170,8 +1175,8 @@ struct Pipe {
             if (NORM && p >= R0 && p < R1) {  // wave-uniform; rows of this chunk only (each element once)
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
-                    const float dlt = (float)(un[j] - uc[j]);
-                    inc[NORM ? s : 0][j] += (store_lane && inL[j]) ? dlt * dlt : 0.f;
+                    const IncT<T> dlt = un[j] - uc[j];
+                    inc[NORM ? s : 0][j] += (store_lane && inL[j]) ? dlt * dlt : IncT<T>(0);
                 }
             }
             T unr[N], q1o[N], q0o[N];
@@ -1373,7 +1378,7 @@ __device__ __forceinline__ void pipe_prologue(const PipeT& pp, PipeState<T, K>& 
 }
 
 template <int KLOC, int G0, typename T>
-__device__ __forceinline__ void pipe_write_partials(const FusedArgs<T>& a, float (&inc)[KLOC][VecOf<T>::N], const int wave_id,
+__device__ __forceinline__ void pipe_write_partials(const FusedArgs<T>& a, IncT<T> (&inc)[KLOC][VecOf<T>::N], const int wave_id,
                                                     const int lane) {
     constexpr int N = VecOf<T>::N;
 #pragma unroll
@@ -1413,11 +1418,11 @@ __device__ __forceinline__ void fused_pipe_body(const FusedArgs<T>& a, const int
     // the last stage must reach row R1: steps rs .. R1 + K - 1, rounded up to whole groups of 4
     // (extra steps touch clamped rows only and store nothing)
     const int64_t r_end = pp.R1 + (K - 1);
-    float inc[NORM ? K : 1][N];
+    IncT<T> inc[NORM ? K : 1][N];
 #pragma unroll
     for (int s = 0; s < (NORM ? K : 1); ++s)
 #pragma unroll
-        for (int j = 0; j < N; ++j) inc[s][j] = 0.f;
+        for (int j = 0; j < N; ++j) inc[s][j] = IncT<T>(0);
     for (int64_t r = rs; r <= r_end; r += 4) {
         pp.template step<0>(st, inc, r);
         pp.template step<1>(st, inc, r + 1);
@@ -1476,11 +1481,11 @@ __device__ __forceinline__ void fused_pair_body(const FusedArgs<T>& a, const int
         pipe_prologue<1, ISO>(pp, st, rs);
     }
     __syncthreads();
-    float inc[NORM ? KH : 1][N];
+    IncT<T> inc[NORM ? KH : 1][N];
 #pragma unroll
     for (int s = 0; s < (NORM ? KH : 1); ++s)
 #pragma unroll
-        for (int j = 0; j < N; ++j) inc[s][j] = 0.f;
+        for (int j = 0; j < N; ++j) inc[s][j] = IncT<T>(0);
     // head steps rs .. R1 + KT - 1, tail steps rs .. R1 + 1 at a lag of kPairLag iterations
     const int64_t r_end = pp.R1 + (KT - KH - 1) + kPairLag;
     for (int64_t r = rs; r <= r_end; r += 4) {

@@ -169,6 +169,8 @@ def split_bregman_tvd(
     if img.dtype.kind != "f":
         raise TypeError("split_bregman_tvd needs a float32/float64 image (integer images break the "
                         "reference's split variables, SURVEY.md quirk Q5)")
+    if np.ndim(mu) == 0 and (ell is None or np.ndim(ell) == 0) and float(2 * mu if ell is None else ell) == 0.0:
+        raise ZeroDivisionError("float division by zero")  # mu / ell of two Python floats (split_bregman_tvd.py:140,145)
     if solver is None:
         solver = Jacobi()
     if not isinstance(solver, (Jacobi, MG, CG)):
