@@ -597,7 +597,10 @@ static int chambolle_t(int device, int ndim, int64_t n0, int64_t n1, int64_t n2,
             DXH_HIP(hipMalloc(&bufs[i], plane));
             DXH_HIP(hipMemsetAsync(bufs[i], 0, plane, st));
         }
-        DXH_HIP(hipMalloc((void**)&partial, sizeof(double) * nblocks));
+        // one slot per block of the element-wise kernels or per wave of the marching kernels (strips are at least 64
+        // elements wide, row chunks at least 8 rows high), whichever is more
+        const size_t npart_alloc = std::max<size_t>(nblocks, (size_t)(g.L / 64 + 2) * (size_t)(n0 / 8 + 2));
+        DXH_HIP(hipMalloc((void**)&partial, sizeof(double) * npart_alloc));
         DXH_HIP(hipMalloc((void**)&red, sizeof(double)));
         DXH_HIP(hipMalloc((void**)&stage2, sizeof(double) * 256));
         DXH_HIP(hipMemcpy2DAsync(bufs[0], g.pitch * sizeof(T), img, g.L * sizeof(T), g.L * sizeof(T), n0,
@@ -611,7 +614,7 @@ static int chambolle_t(int device, int ndim, int64_t n0, int64_t n1, int64_t n2,
             DXH_HIP(hipMemsetAsync(p2[ax], 0, plane, st));
         }
         double* partial_n = nullptr;
-        DXH_HIP(hipMalloc((void**)&partial_n, sizeof(double) * nblocks));
+        DXH_HIP(hipMalloc((void**)&partial_n, sizeof(double) * npart_alloc));
         extra.push_back(partial_n);
         const double tau = 1.0 / (2.0 * ndim);
         // row-marching kernel for 2-D images and colour-images-as-volumes; everything else one thread per element
@@ -637,7 +640,7 @@ static int chambolle_t(int device, int ndim, int64_t n0, int64_t n1, int64_t n2,
             ma.nchunks = (int)nchunks;
             march_grid = (unsigned)(nbx * nchunks);
             nparts = (int)(nchunks * ma.nstrips);
-            if ((size_t)nparts > (size_t)nblocks) { set_error("internal: partial buffer too small"); return DXH_EHIP; }
+            if ((size_t)nparts > npart_alloc) { set_error("internal: partial buffer too small"); return DXH_EHIP; }
         }
         // two iterations per pass (k_ch_march2): its own strip geometry (twice the halo)
         const bool march2 = march && !getenv("DXH_CHAMBOLLE_NO_K2");
@@ -658,7 +661,7 @@ static int chambolle_t(int device, int ndim, int64_t n0, int64_t n1, int64_t n2,
             m2.m.nchunks = (int)nchunks;
             march2_grid = (unsigned)(nbx * nchunks);
             nparts2 = (int)(nchunks * m2.m.nstrips);
-            if ((size_t)nparts2 > (size_t)nblocks) { set_error("internal: partial buffer too small"); return DXH_EHIP; }
+            if ((size_t)nparts2 > npart_alloc) { set_error("internal: partial buffer too small"); return DXH_EHIP; }
             DXH_HIP(hipMalloc((void**)&partial_d2_b, sizeof(double) * nparts2));
             extra.push_back(partial_d2_b);
             DXH_HIP(hipMalloc((void**)&partial_n_b, sizeof(double) * nparts2));

@@ -532,3 +532,13 @@ def test_small_random_sweep_of_parameters():
         jm = int(rng.choice([1, 1, 2, 3, 5]))
         assert_bits(da.split_bregman_tvd(img, solver=da.Jacobi(maxiter=jm), **kw),
                     O.split_bregman_tvd(img, jacobi_maxiter=jm, promotion="strict", **kw))
+
+
+def test_chambolle_single_row_wider_than_a_block():
+    """A one-row image with more marching waves than element-wise blocks (partial-sum buffer sizing; found by the fuzzer)."""
+    from oracle import chambolle_numpy as CH
+    rng = np.random.default_rng(4)
+    for shape in ((1, 250), (1, 300, 3), (2, 900)):
+        img = rng.random(shape)
+        np.testing.assert_array_equal(da.denoise_tv_chambolle(img, weight=0.1, eps=0.0, max_num_iter=5),
+                                      CH.denoise_tv_chambolle(img, weight=0.1, eps=0.0, max_num_iter=5))
