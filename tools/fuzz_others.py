@@ -33,10 +33,14 @@ for case in range(n_cases):
         x0, rhs = rng.random(shape).astype(dt), rng.random(shape).astype(dt)
         kw = dict(depth=int(rng.integers(0, 2)), smoother_iterations=int(rng.integers(1, 6)), maxiter=int(rng.integers(1, 3)), mass_coeff=1.0, diffusion_coeff=0.4, dim=2)
         chk("mg", da.MG(**kw)(x0, rhs), SO.MG(**kw)(x0, rhs), (shape, dt.__name__, kw))
-    if c != 0 or True:
-        a2 = img if img.ndim == 3 else img
-        coords = np.stack([rng.uniform(-1, h, 500), rng.uniform(-1, w, 500)])
-        got = da.map_coordinates(a2, coords, order=int(rng.integers(0, 2)))
+    for src in (img, (img * 255).astype(np.uint8), (img * 65535).astype(np.uint16)):
+        order = int(rng.integers(0, 2))
+        cdt = rng.choice([np.float32, np.float64])
+        coords = np.stack([rng.uniform(-1, h, 500), rng.uniform(-1, w, 500)]).astype(cdt)
+        coords[:, :4] = np.array([[0, h - 1, 0, h - 1], [0, w - 1, w - 1, 0]], dtype=cdt)
+        got = da.map_coordinates(src, coords, order=order)
+        ref = np.stack([sp_map(src[..., k], coords, order=order) for k in range(src.shape[2])], axis=-1) if src.ndim == 3 else sp_map(src, coords, order=order)
+        chk("map_coordinates", got, ref, (shape, src.dtype.name, order, np.dtype(cdt).name))
     if h >= 2 and w >= 2:
         interp = int(rng.choice([R.INTER_NEAREST, R.INTER_LINEAR, R.INTER_AREA]))
         fx, fy = float(rng.uniform(0.3, 1.7)), float(rng.uniform(0.3, 1.7))
@@ -46,5 +50,17 @@ for case in range(n_cases):
             r = [R.resize(ch, fx=fx, fy=fy, interpolation=interp) for ch in chans]
             r = np.stack(r, axis=-1) if img.ndim == 3 else r[0]
             chk("resize", o, r, (shape, dt.__name__, interp, fx, fy))
+            u8 = (img * 255).astype(np.uint8)
+            o = rz.cv_resize(u8, fx=fx, fy=fy, interpolation=interp)
+            chans = [np.ascontiguousarray(u8[..., k]) for k in range(u8.shape[2])] if u8.ndim == 3 else [u8]
+            r = [R.resize(ch, fx=fx, fy=fy, interpolation=interp) for ch in chans]
+            r = np.stack(r, axis=-1) if u8.ndim == 3 else r[0]
+            chk("resize u8", o, r, (shape, interp, fx, fy))
+            dw, dh = int(rng.integers(1, 2 * w + 2)), int(rng.integers(1, 2 * h + 2))
+            o = rz.cv_resize(img, dsize=(dw, dh), interpolation=interp)
+            chans = [np.ascontiguousarray(img[..., k]) for k in range(img.shape[2])] if img.ndim == 3 else [img]
+            r = [R.resize(ch, dsize=(dw, dh), interpolation=interp) for ch in chans]
+            r = np.stack(r, axis=-1) if img.ndim == 3 else r[0]
+            chk("resize dsize", o, r, (shape, dt.__name__, interp, dw, dh))
 print(f"{n_cases} cases, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
 sys.exit(1 if bad else 0)
