@@ -256,7 +256,8 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
     const bool pair = false;
 #endif
     const int nbx = pair ? (a.nstrips + 1) / 2 : (a.nstrips + 3) / 4;
-    const int64_t target_blocks = (int64_t)c->num_cu * (c->waves_per_cu ? c->waves_per_cu : 16) / 4;
+    // grid sized for 16 waves per CU (scalar coefficients) or 24 (array coefficients): measured best of 8..32
+    const int64_t target_blocks = (int64_t)c->num_cu * (c->waves_per_cu ? c->waves_per_cu : (c->het ? 24 : 16)) / 4;
     int64_t nchunks = std::max<int64_t>(1, target_blocks / nbx);
     if (nchunks >= 8) nchunks = nchunks / 8 * 8;
     if (c->force_chunks > 0) nchunks = c->force_chunks;  // developer knob DXH_NCHUNKS
