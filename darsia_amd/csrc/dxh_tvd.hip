@@ -256,10 +256,29 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
     const bool pair = false;
 #endif
     const int nbx = pair ? (a.nstrips + 1) / 2 : (a.nstrips + 3) / 4;
-    // grid sized for 16 waves per CU (scalar coefficients) or 24 (array coefficients): measured best of 8..32
-    const int64_t target_blocks = (int64_t)c->num_cu * (c->waves_per_cu ? c->waves_per_cu : (c->het ? 24 : 16)) / 4;
-    int64_t nchunks = std::max<int64_t>(1, target_blocks / nbx);
-    if (nchunks >= 8) nchunks = nchunks / 8 * 8;
+    // Row chunks.  Array coefficients: grid sized for 24 waves per CU (measured best of 8..32).  Scalar coefficients:
+    // all blocks take the same time, so the cost of a chunk count is (rows per chunk + pipeline fill) x rounds, where
+    // the blocks that fit at once (2 per CU for the K >= 3 pipelines, 3 for K = 2) make one round and a partial
+    // second round costs a whole one unless there are many rounds; candidates are multiples of 8 (XCD-aware tile map).
+    int64_t nchunks;
+    if (c->waves_per_cu || c->het) {
+        const int64_t target_blocks = (int64_t)c->num_cu * (c->waves_per_cu ? c->waves_per_cu : 24) / 4;
+        nchunks = std::max<int64_t>(1, target_blocks / nbx);
+        if (nchunks >= 8) nchunks = nchunks / 8 * 8;
+    } else {
+        const double capacity = (double)c->num_cu * (K >= 3 ? 2 : 3);
+        double best = 1e300;
+        nchunks = 1;
+        for (int64_t nc = 1; nc <= std::max<int64_t>(1, c->g.n0 / (8 * K)); nc = nc < 8 ? nc + 1 : nc + 8) {
+            const int64_t rpc_c = (c->g.n0 + nc - 1) / nc;
+            const int64_t real = (c->g.n0 + rpc_c - 1) / rpc_c;
+            const double ratio = (double)(real * nbx) / capacity;
+            const double rounds = ratio <= 1.0 ? 1.0 : (ratio < 1.5 ? 2.0 : ratio);
+            const double cost = (double)(rpc_c + 2 * K + 2) * rounds;
+            if (cost < best * 0.999) { best = cost; nchunks = real; }
+            if (ratio > 4.5) break;
+        }
+    }
     if (c->force_chunks > 0) nchunks = c->force_chunks;  // developer knob DXH_NCHUNKS
     int64_t rpc = std::max<int64_t>(8 * K, (c->g.n0 + nchunks - 1) / nchunks);
     nchunks = (c->g.n0 + rpc - 1) / rpc;
