@@ -184,7 +184,7 @@ int run_gs(int64_t rows, int64_t cols, int64_t dims, const void* image, void* ou
         for (void* p : {d_img, d_out, (void*)part, (void*)stage, (void*)red}) if (p) (void)hipFree(p);
     };
     HostPrefault pf;  // map the output pages while the device works
-    pf.start(out, dense);
+    pf.start(out, dense, {{image, dense}});
     auto body = [&]() -> int {
         for (void*& p : bufs) {
             DXH_HIP(hipMalloc(&p, bytes));

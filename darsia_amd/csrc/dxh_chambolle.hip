@@ -590,7 +590,7 @@ static int chambolle_t(int device, int ndim, int64_t n0, int64_t n1, int64_t n2,
         if (st) (void)hipStreamDestroy(st);
     };
     HostPrefault pf;  // map the output pages while the device works
-    pf.start(out, (size_t)n0 * g.L * sizeof(T));
+    pf.start(out, (size_t)n0 * g.L * sizeof(T), {{img, (size_t)n0 * g.L * sizeof(T)}});
     auto body = [&]() -> int {
         DXH_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         for (int i = 0; i < 2 + ndim; ++i) {

@@ -9,7 +9,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <initializer_list>
 #include <thread>
+#include <utility>
 
 #include "../../include/darsia_hip.h"
 
@@ -40,8 +42,15 @@ void set_error(const char* fmt, ...);
 // the copy is enqueued.
 struct HostPrefault {
     std::thread th;
-    void start(void* p, size_t n) {
+    // `inputs`: host buffers the call still has to read -- an output that overlaps one of them (in-place use of the
+    // C ABI) must not be touched
+    void start(void* p, size_t n, std::initializer_list<std::pair<const void*, size_t>> inputs = {}) {
         if (!p || n < (size_t(8) << 20)) return;
+        const char* lo = static_cast<const char*>(p);
+        for (const auto& in : inputs) {
+            const char* a = static_cast<const char*>(in.first);
+            if (a && a < lo + n && lo < a + in.second) return;
+        }
         th = std::thread([p, n]() {
             volatile char* c = static_cast<volatile char*>(p);
             for (size_t i = 0; i < n; i += 4096) c[i] = 0;

@@ -347,7 +347,7 @@ int dxh_warp_patches(int device, int H, int W, int C, const float* base, const d
         DXH_REQUIRE(p.bw0 >= 1, "patch %d: bad block width", k);
     }
     HostPrefault pf;  // map the output pages while the device works
-    pf.start(canvas, (size_t)H * W * C * sizeof(float));
+    pf.start(canvas, (size_t)H * W * C * sizeof(float), {{base, (size_t)H * W * C * sizeof(float)}});
     Dev d;
     DXH_HIP(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking));
     const size_t bytes = (size_t)H * W * C * sizeof(float);
@@ -380,7 +380,7 @@ int dxh_tps_eval(int device, int p, int dout, const double* centers, const doubl
     if (rc) return rc;
     if (n == 0) return DXH_OK;
     HostPrefault pf;  // map the output pages while the device works
-    pf.start(out, sizeof(double) * (size_t)n * dout);
+    pf.start(out, sizeof(double) * (size_t)n * dout, {{points, points ? sizeof(double) * 2 * (size_t)n : 0}});
     Dev d;
     DXH_HIP(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking));
     void *dc = nullptr, *dk = nullptr, *dp = nullptr, *dout_ = nullptr;
@@ -421,7 +421,7 @@ int dxh_affine_color(int device, int in_dtype, int64_t npix, const void* img, co
     if (npix == 0) return DXH_OK;
     const size_t esz = in_dtype == 0 ? 4 : in_dtype == 1 ? 8 : in_dtype == 2 ? 1 : 2;
     HostPrefault pf;  // map the output pages while the device works
-    pf.start(out, sizeof(float) * 3 * (size_t)npix);
+    pf.start(out, sizeof(float) * 3 * (size_t)npix, {{img, (size_t)(in_dtype == 0 ? 4 : in_dtype == 1 ? 8 : in_dtype == 2 ? 1 : 2) * 3 * (size_t)npix}});
     Dev d;
     DXH_HIP(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking));
     void *din = nullptr, *dab = nullptr, *dout_ = nullptr;
@@ -460,7 +460,9 @@ int dxh_map_coordinates(int device, int dtype, int64_t H, int64_t W, int C, cons
     const size_t esz = dtype == 0 ? 4 : dtype == 1 ? 8 : dtype == 2 ? 1 : 2;
     const size_t csz = coord_dtype == 0 ? 4 : 8;
     HostPrefault pf;  // map the output pages while the device works
-    pf.start(out, (dtype == 0 ? 4 : dtype == 1 ? 8 : dtype == 2 ? 1 : 2) * (size_t)n * C);
+    pf.start(out, (dtype == 0 ? 4 : dtype == 1 ? 8 : dtype == 2 ? 1 : 2) * (size_t)n * C,
+             {{img, (size_t)(dtype == 0 ? 4 : dtype == 1 ? 8 : dtype == 2 ? 1 : 2) * (size_t)H * W * C},
+              {rows, (size_t)(coord_dtype == 0 ? 4 : 8) * (size_t)n}, {cols, (size_t)(coord_dtype == 0 ? 4 : 8) * (size_t)n}});
     Dev d;
     DXH_HIP(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking));
     void *dimg = nullptr, *dr = nullptr, *dc = nullptr, *dout_ = nullptr;
@@ -500,7 +502,7 @@ int dxh_resize(int device, int dtype, int64_t H, int64_t W, int C, const void* s
     if (rc) return rc;
     const size_t esz = dtype == 0 ? 4 : dtype == 1 ? 8 : 1;
     HostPrefault pf;  // map the output pages while the device works
-    pf.start(dst, (dtype == 0 ? 4 : dtype == 1 ? 8 : 1) * (size_t)DH * DW * C);
+    pf.start(dst, (dtype == 0 ? 4 : dtype == 1 ? 8 : 1) * (size_t)DH * DW * C, {{src, (size_t)(dtype == 0 ? 4 : dtype == 1 ? 8 : 1) * (size_t)H * W * C}});
     Dev d;
     DXH_HIP(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking));
     ResizePlanDev p{};

@@ -703,7 +703,10 @@ int dxh_solver_solve(dxh_solver_t h, const void* x0, const void* rhs, void* out,
     DXH_HIP(hipSetDevice(o->desc.device));
     int rc, n = 0;
     dxh::HostPrefault pf;  // map the output pages while the device works
-    pf.start(out, (size_t)o->g.n0 * (size_t)o->g.L * o->esz);
+    {
+        const size_t nb = (size_t)o->g.n0 * (size_t)o->g.L * o->esz;
+        pf.start(out, nb, {{x0, nb}, {rhs, nb}});
+    }
     if ((rc = up(o, o->x0, x0)) || (rc = up(o, o->rhs, rhs))) return rc;
     if ((rc = o->impl->solve(o->x0, o->rhs, o->out, &n))) return rc;
     pf.join();

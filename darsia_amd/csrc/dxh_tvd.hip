@@ -1339,7 +1339,10 @@ int dxh_jacobi_solve(int device, int dtype, int ndim, int dim, int nsum, int64_t
     if (rc) return rc;
     Ctx* c = reinterpret_cast<Ctx*>(hctx);
     HostPrefault pf;  // map the output pages while the device works
-    pf.start(out, (size_t)n0 * (size_t)n1 * (size_t)n2 * (dtype == DXH_F32 ? 4 : 8));
+    {
+        const size_t nb = (size_t)n0 * (size_t)n1 * (size_t)n2 * (dtype == DXH_F32 ? 4 : 8);
+        pf.start(out, nb, {{x0, nb}, {rhs, nb}});
+    }
     auto body = [&]() -> int {
         int r;
         // mass plays omega, diffusion plays ell; mu is unused (kq not needed)

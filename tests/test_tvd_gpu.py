@@ -542,3 +542,18 @@ def test_chambolle_single_row_wider_than_a_block():
         img = rng.random(shape)
         np.testing.assert_array_equal(da.denoise_tv_chambolle(img, weight=0.1, eps=0.0, max_num_iter=5),
                                       CH.denoise_tv_chambolle(img, weight=0.1, eps=0.0, max_num_iter=5))
+
+
+def test_c_abi_in_place_output_is_safe():
+    """dxh_chambolle with out == image (in-place use of the C ABI) on an array big enough for the page-touch thread:
+    the input must not be clobbered before it is uploaded."""
+    import ctypes as C
+    from darsia_amd import _lib
+    from darsia_amd.synthetic import synthetic_image
+    img = synthetic_image(1200, 2000, 3)  # 28.8 MB > the 8 MB threshold
+    ref = da.denoise_tv_chambolle(img, weight=0.1, eps=0.0, max_num_iter=3)
+    buf = img.copy()
+    done = C.c_int(0)
+    _lib.check(_lib.load().dxh_chambolle(_lib.default_device(), 0, 3, 1200, 2000, 3, _lib.ptr(buf), _lib.ptr(buf), 0.1, 0.0, 3,
+                                          C.byref(done)))
+    np.testing.assert_array_equal(buf, ref)
