@@ -587,12 +587,11 @@ static int chambolle_t(int device, int ndim, int64_t n0, int64_t n1, int64_t n2,
         if (red) (void)hipFree(red);
         if (stage2) (void)hipFree(stage2);
         for (void* b : extra) if (b) (void)hipFree(b);
-        if (st) (void)hipStreamDestroy(st);
     };
     HostPrefault pf;  // map the output pages while the device works
     pf.start(out, (size_t)n0 * g.L * sizeof(T), {{img, (size_t)n0 * g.L * sizeof(T)}});
     auto body = [&]() -> int {
-        DXH_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        DXH_HIP(cached_stream(device, &st));
         for (int i = 0; i < 2 + ndim; ++i) {
             DXH_HIP(hipMalloc(&bufs[i], plane));
             DXH_HIP(hipMemsetAsync(bufs[i], 0, plane, st));

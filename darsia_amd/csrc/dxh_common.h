@@ -36,6 +36,21 @@ void set_error(const char* fmt, ...);
         }                                 \
     } while (0)
 
+// A non-blocking stream per (host thread, device), created on first use and kept: hipStreamCreate costs 10-15 ms on
+// this stack (tools/alloc_probe.hip: more than the 11 device allocations, memsets and frees of a whole call together),
+// and the synchronous entry points need a stream only for the duration of a call.
+inline hipError_t cached_stream(int device, hipStream_t* out) {
+    constexpr int kMax = 64;
+    thread_local hipStream_t streams[kMax] = {};
+    if (device < 0 || device >= kMax) return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+    if (!streams[device]) {
+        hipError_t e = hipStreamCreateWithFlags(&streams[device], hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+    }
+    *out = streams[device];
+    return hipSuccess;
+}
+
 // Maps the pages of a (large) host output buffer on a helper thread while the device works.  A device-to-host
 // copy into never-touched pages is slowed down by the page faults (384 MB: 22-36 ms instead of 7 ms, measured); the
 // buffer is going to be overwritten completely, so writing one zero per page beforehand is harmless.  join() before

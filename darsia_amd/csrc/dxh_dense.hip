@@ -166,7 +166,7 @@ struct Dev {
     hipStream_t st = nullptr;
     ~Dev() {
         for (void* b : bufs) if (b) (void)hipFree(b);
-        if (st) (void)hipStreamDestroy(st);
+        // st is the thread's cached stream (cached_stream): not destroyed
     }
     int alloc(void** p, size_t n) {
         DXH_HIP(hipMalloc(p, n ? n : 1));
@@ -349,7 +349,7 @@ int dxh_warp_patches(int device, int H, int W, int C, const float* base, const d
     HostPrefault pf;  // map the output pages while the device works
     pf.start(canvas, (size_t)H * W * C * sizeof(float), {{base, (size_t)H * W * C * sizeof(float)}});
     Dev d;
-    DXH_HIP(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking));
+    DXH_HIP(cached_stream(device, &d.st));
     const size_t bytes = (size_t)H * W * C * sizeof(float);
     void *dbase = nullptr, *dcanvas = nullptr, *dpt = nullptr;
     if ((rc = d.alloc(&dbase, bytes)) || (rc = d.alloc(&dcanvas, bytes)) || (rc = d.alloc(&dpt, sizeof(WarpPatch) * (size_t)npatch)))
@@ -382,7 +382,7 @@ int dxh_tps_eval(int device, int p, int dout, const double* centers, const doubl
     HostPrefault pf;  // map the output pages while the device works
     pf.start(out, sizeof(double) * (size_t)n * dout, {{points, points ? sizeof(double) * 2 * (size_t)n : 0}});
     Dev d;
-    DXH_HIP(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking));
+    DXH_HIP(cached_stream(device, &d.st));
     void *dc = nullptr, *dk = nullptr, *dp = nullptr, *dout_ = nullptr;
     if ((rc = d.alloc(&dc, sizeof(double) * 2 * p)) || (rc = d.alloc(&dk, sizeof(double) * (p + 3) * dout)) ||
         (rc = d.alloc(&dout_, sizeof(double) * (size_t)n * dout)))
@@ -423,7 +423,7 @@ int dxh_affine_color(int device, int in_dtype, int64_t npix, const void* img, co
     HostPrefault pf;  // map the output pages while the device works
     pf.start(out, sizeof(float) * 3 * (size_t)npix, {{img, (size_t)(in_dtype == 0 ? 4 : in_dtype == 1 ? 8 : in_dtype == 2 ? 1 : 2) * 3 * (size_t)npix}});
     Dev d;
-    DXH_HIP(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking));
+    DXH_HIP(cached_stream(device, &d.st));
     void *din = nullptr, *dab = nullptr, *dout_ = nullptr;
     if ((rc = d.alloc(&din, esz * 3 * (size_t)npix)) || (rc = d.alloc(&dab, sizeof(double) * 12)) ||
         (rc = d.alloc(&dout_, sizeof(float) * 3 * (size_t)npix)))
@@ -464,7 +464,7 @@ int dxh_map_coordinates(int device, int dtype, int64_t H, int64_t W, int C, cons
              {{img, (size_t)(dtype == 0 ? 4 : dtype == 1 ? 8 : dtype == 2 ? 1 : 2) * (size_t)H * W * C},
               {rows, (size_t)(coord_dtype == 0 ? 4 : 8) * (size_t)n}, {cols, (size_t)(coord_dtype == 0 ? 4 : 8) * (size_t)n}});
     Dev d;
-    DXH_HIP(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking));
+    DXH_HIP(cached_stream(device, &d.st));
     void *dimg = nullptr, *dr = nullptr, *dc = nullptr, *dout_ = nullptr;
     if ((rc = d.alloc(&dimg, esz * (size_t)H * W * C)) || (rc = d.alloc(&dr, csz * (size_t)n)) || (rc = d.alloc(&dc, csz * (size_t)n)) ||
         (rc = d.alloc(&dout_, esz * (size_t)n * C)))
@@ -504,7 +504,7 @@ int dxh_resize(int device, int dtype, int64_t H, int64_t W, int C, const void* s
     HostPrefault pf;  // map the output pages while the device works
     pf.start(dst, (dtype == 0 ? 4 : dtype == 1 ? 8 : 1) * (size_t)DH * DW * C, {{src, (size_t)(dtype == 0 ? 4 : dtype == 1 ? 8 : 1) * (size_t)H * W * C}});
     Dev d;
-    DXH_HIP(hipStreamCreateWithFlags(&d.st, hipStreamNonBlocking));
+    DXH_HIP(cached_stream(device, &d.st));
     ResizePlanDev p{};
     p.mode = plan->mode; p.isx = plan->isx; p.isy = plan->isy;
     auto up = [&](const void* host, size_t bytes, const void** devp) -> int {

@@ -857,7 +857,9 @@ int dxh_tvd_create(dxh_tvd_t* out, const dxh_tvd_desc* d) {
     if (d->stream) {
         c->stream = (hipStream_t)d->stream;
     } else {
-        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(DXH_EHIP); }
+        // the thread's cached stream: contexts of one host thread are used one after the other (header: "one ctx per
+        // host thread, not re-entrant"), and creating a stream costs 10-15 ms
+        if (cached_stream(c->desc.device, &c->stream) != hipSuccess) { set_error("hipStreamCreate failed"); return fail(DXH_EHIP); }
         c->own_stream = true;
     }
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { set_error("hipEventCreate failed"); return fail(DXH_EHIP); }
@@ -890,7 +892,6 @@ int dxh_tvd_destroy(dxh_tvd_t h) {
     fr(c->cp_ell); fr(c->cp_diag); fr(c->cp_dsc); fr(c->cp_kq); fr(c->om_plane); fr(c->mu_plane); fr(c->base_img); fr(c->clean_filter); fr(c->probe_buf); fr(c->stage); fr(c->partial); fr(c->red_out); fr(c->inc_partial);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
-    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return DXH_OK;
 }
