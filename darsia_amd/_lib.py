@@ -28,7 +28,7 @@ EXPORTS = (
     "dxh_tvd_partial_norms", "dxh_tvd_sync", "dxh_jacobi_solve", "dxh_diff", "dxh_chambolle",
     "dxh_warp_patches", "dxh_tps_eval", "dxh_affine_color",
     "dxh_solver_create", "dxh_solver_destroy", "dxh_solver_set_params", "dxh_solver_solve", "dxh_solver_get_params",
-    "dxh_tvd_set_solver", "dxh_tv_bregman_gs", "dxh_map_coordinates", "dxh_resize",
+    "dxh_tvd_set_solver", "dxh_tv_bregman_gs", "dxh_map_coordinates", "dxh_resize", "dxh_div3_probe",
     "dxh_tvd_energy", "dxh_tvd_adapt_ell", "dxh_tvd_set_base", "dxh_tvd_set_cleaning_filter", "dxh_tvd_upload_signal", "dxh_tvd_download_model",
 )
 
@@ -110,6 +110,7 @@ def _declare(lib):
     lib.dxh_tvd_unpack_rows.argtypes = [vp, i64, i64, vp]
     lib.dxh_tvd_partial_norms.argtypes = [vp, i64, i64, C.POINTER(dbl), C.POINTER(dbl)]
     lib.dxh_tvd_sync.argtypes = [vp]
+    lib.dxh_div3_probe.argtypes = [i, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_uint)]
     lib.dxh_tvd_energy.argtypes = [vp, i, C.POINTER(dbl)]
     lib.dxh_solver_create.argtypes = [C.POINTER(vp), C.POINTER(SolverDesc)]
     lib.dxh_solver_destroy.argtypes = [vp]

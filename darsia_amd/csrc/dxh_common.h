@@ -222,8 +222,36 @@ __device__ __forceinline__ float t_abs(float x) { return fabsf(x); }
 __device__ __forceinline__ double t_abs(double x) { return fabs(x); }
 __device__ __forceinline__ float t_copysign(float m, float s) { return copysignf(m, s); }
 __device__ __forceinline__ double t_copysign(double m, double s) { return copysign(m, s); }
+__device__ __forceinline__ float t_clamp_sym(float x, float k) { return __builtin_amdgcn_fmed3f(x, -k, k); }
+__device__ __forceinline__ double t_clamp_sym(double x, double k) { return fmin(fmax(x, -k), k); }
 __device__ __forceinline__ float t_sqrt(float x) { return sqrtf(x); }  // correctly rounded (no fast-math)
 __device__ __forceinline__ double t_sqrt(double x) { return sqrt(x); }
+
+// Inside a rarely taken, wave-uniform `if` block: keeps the block a real s_cbranch instead of a run of
+// v_cndmask (if-conversion) that every wave would pay on every row.
+#define DXH_UNIFORM_BRANCH() asm volatile("")
+
+// ---- per-lane selects through bit masks held in VGPRs ----------------------------------------------
+// A lane pattern that never changes (channel position, strip edge) kept as an SGPR-pair mask for v_cndmask
+// costs scalar registers the long pipelines do not have (the masks get spilled to VGPR lanes and come back
+// through v_readlane, one VALU each); as 0 / ~0 words in a VGPR the same select is one v_bfi_b32 per word.
+__device__ __forceinline__ uint32_t lane_mask_bits(bool c) {
+    uint32_t m = c ? 0xffffffffu : 0u;
+    asm volatile("" : "+v"(m));  // opaque: keeps the optimiser from turning the mask back into an i1 select
+    return m;
+}
+__device__ __forceinline__ float sel_bits(uint32_t m, float a, float b) {  // m ? a : b
+    float r;  // spelled out: the optimiser splits (m & a) | (~m & b) into and / and_or with a hoisted ~m
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double sel_bits(uint32_t m, double a, double b) {
+    const uint64_t ua = __builtin_bit_cast(uint64_t, a), ub = __builtin_bit_cast(uint64_t, b);
+    uint32_t lo, hi;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(lo) : "v"(m), "v"(static_cast<uint32_t>(ua)), "v"(static_cast<uint32_t>(ub)));
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(hi) : "v"(m), "v"(static_cast<uint32_t>(ua >> 32)), "v"(static_cast<uint32_t>(ub >> 32)));
+    return __builtin_bit_cast(double, (static_cast<uint64_t>(hi) << 32) | lo);
+}
 
 // ---- division by a wave-invariant divisor ----------------------------------------------------------
 // x / d with r = RN(1/d) supplied by the host: the refinement chain of correctly rounded division
@@ -237,6 +265,8 @@ __device__ __forceinline__ double t_sqrt(double x) { return sqrt(x); }
 // Non-finite numerators give NaN here where the IEEE division would give +-inf; an image with an inf
 // turns into NaNs within one iteration in the reference as well (inf - inf in the differences).
 // 5 VALU instead of the 10-instruction v_div_scale/v_rcp/v_div_fmas/v_div_fixup sequence.
+// For most divisors q1 is already RN(x/d) for EVERY x; in float that is decidable by trying all 2^23
+// mantissas (k_div3_check, run once per coefficient set), and the pipelines then stop after three operations.
 template <typename T>
 struct DivSafe;
 template <>
@@ -253,15 +283,40 @@ __device__ __forceinline__ float t_fma(float a, float b, float c) { return fmaf(
 __device__ __forceinline__ double t_fma(double a, double b, double c) { return fma(a, b, c); }
 
 template <typename T>
-__device__ __forceinline__ T div_by_const(T x, T d, T r) {
+__device__ __forceinline__ T div_by_const3(T x, T d, T r) {  // first three operations: faithful, mostly exact
     const T q0 = x * r;
     const T e0 = t_fma(-d, q0, x);
-    const T q1 = t_fma(e0, r, q0);
+    return t_fma(e0, r, q0);
+}
+template <typename T>
+__device__ __forceinline__ T div_refine(T q1, T x, T d, T r) {  // the second residual correction
     const T e1 = t_fma(-d, q1, x);
     return t_fma(e1, r, q1);
 }
+template <typename T>
+__device__ __forceinline__ T div_by_const(T x, T d, T r) {
+    return div_refine(div_by_const3(x, d, r), x, d, r);
+}
 __device__ __forceinline__ float t_min(float a, float b) { return fminf(a, b); }
 __device__ __forceinline__ double t_min(double a, double b) { return fmin(a, b); }
+// min(|a|, |b|, |c|) in one instruction (float): the screen below runs once per row and stage
+__device__ __forceinline__ float abs_min3(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ double abs_min3(double a, double b, double c) { return fmin(fmin(fabs(a), fabs(b)), fabs(c)); }
+// smallest magnitude among the 2 N numerators of a lane
+template <typename T, int N>
+__device__ __forceinline__ T abs_min_all(const T (&x)[N], const T (&y)[N]) {
+    T lo = abs_min3(x[0], y[0], x[N - 1]);
+    lo = abs_min3(lo, y[N - 1], y[N - 1]);
+    if constexpr (N == 4) {
+        lo = abs_min3(lo, x[1], y[1]);
+        lo = abs_min3(lo, x[2], y[2]);
+    }
+    return lo;
+}
 // numerator x is outside div_by_const's proven range: non-zero but tiny (x == 0 is exact: every term is 0)
 template <typename T>
 __device__ __forceinline__ bool div_unsafe(T x) {
@@ -271,9 +326,10 @@ __device__ __forceinline__ bool div_unsafe(T x) {
 // (d, b) of one pixel from its stored state q = b_old + D(u) ("dub" in the reference):
 //   anisotropic  d = shrink(q, k), b = q - d                    split_bregman_tvd.py:80-81,143-146
 //   isotropic    s = |q|_2, f = max(s-k,0)/(s+1e-18), d = q f, b = q (1-f)       :107-126
-// FASTSIGN (callers guarantee k >= 0): max(|q| - k, 0) * sign(q) only transfers q's sign -- for q == 0
-// the magnitude is max(-k, 0) = 0 as well -- so copysign gives the same value with 3 instructions
-// instead of 8.  For k < 0 or NaN the forms differ at q == 0, hence the flag.
+// FASTSIGN (callers guarantee k >= 0): max(|q| - k, 0) * sign(q) == q - clamp(q, -k, k) bit for bit up to
+// the sign of a zero result (which no later operation can tell apart: b = q - d, t = ell (b - d) and the
+// downloaded d compare equal) -- q > k: RN(q - k); q < -k: RN(q + k) = -RN(|q| - k); else q - q = 0.  One
+// v_med3_f32 and a (packable) subtraction instead of and / sub / max / bfi.  For k < 0 or NaN the forms differ.
 template <typename T, int DIM, bool ISO, bool FASTSIGN = false>
 __device__ __forceinline__ void split_vars(const T (&q)[DIM], T k, T (&d)[DIM], T (&b)[DIM]) {
     if constexpr (ISO) {
@@ -291,7 +347,7 @@ __device__ __forceinline__ void split_vars(const T (&q)[DIM], T k, T (&d)[DIM], 
 #pragma unroll
         for (int j = 0; j < DIM; ++j) {
             if constexpr (FASTSIGN)
-                d[j] = t_copysign(t_max0(t_abs(q[j]) - k), q[j]);
+                d[j] = q[j] - t_clamp_sym(q[j], k);
             else
                 d[j] = t_max0(t_abs(q[j]) - k) * sgn(q[j]);
             b[j] = q[j] - d[j];

@@ -19,7 +19,7 @@
 #define DXH_STRIP_ALIGN_BYTES 64  // k_fused_multi: a wave's store range covers whole granules of this size
 #endif
 #ifndef DXH_LB4
-#define DXH_LB4 2  // minimum waves per SIMD requested for the K >= 3 pipelines (register cap 256; 3 would spill)
+#define DXH_LB4 3  // waves per SIMD requested for the float K >= 3 scalar-coefficient pipelines (register cap 168)
 #endif
 
 namespace dxh {
@@ -31,7 +31,9 @@ struct Coef {       // scalar coefficients, already rounded to T like NumPy's we
     T dsc;          // diag / (ell/h^2)                                    jacobi.py:104-106
     T kq;           // mu / ell (shrinkage threshold)                      split_bregman_tvd.py:140,145
     T rdiag, rdsc;  // RN(1/diag), RN(1/dsc) for div_by_const; 0 = use the IEEE division
+    int div3;       // 1: ONE residual correction already rounds x/diag and x/dsc correctly for every x (k_div3_check)
 };
+
 
 template <typename T>
 struct CoefPlanes {  // heterogeneous coefficients (nullptr = scalar)
@@ -915,6 +917,14 @@ __device__ __forceinline__ void static_for(F&& f) {
 template <typename T>
 using IncT = T;
 
+// Occupancy the pipelines are compiled for (waves per SIMD) and their prefetch distance.  float, scalar
+// coefficients: 3 waves (<= 168 VGPRs; the kernel is VALU-issue bound and a third wave fills issue slots);
+// that budget has no room for the staging registers of a two-step prefetch, and with three waves one step
+// of distance is enough.  double and the array-coefficient pipelines keep 2 waves (they would spill).
+template <typename T, int K, bool HET>
+constexpr int pipe_waves() { return HET ? 2 : (K >= 3 ? (sizeof(T) == 4 ? DXH_LB4 : 2) : 3); }
+template <typename T, int K, bool HET>
+constexpr int pipe_pfd() { return (K >= 4 && pipe_waves<T, K, HET>() <= 2) ? 2 : 1; }
 template <typename T, int K>
 struct PipeState {
     static constexpr int N = VecOf<T>::N;
@@ -963,8 +973,9 @@ struct Pipe {
     T* q1_out;
     int64_t P, nrow, R0, R1;
     T ell, diag, dsc, kq, rdiag, rdsc;
+    bool div3;          // Coef::div3
     bool store_lane;
-    bool edgeL[N], edgeR[N], ch0[N], chLast[N];
+    uint32_t edgeL[N], edgeR[N], ch0[N], chLast[N];  // lane patterns as 0 / ~0 words (sel_bits)
     bool inL[N];        // element inside the row (x < L)
     uint32_t voff;      // this lane's byte offset inside a row: addresses are (uniform row base in SGPRs) + voff
     T* lds;             // this lane's vector in slot 0 of the wave's LDS rings; slot stride = kWave * N elements
@@ -1003,7 +1014,7 @@ struct Pipe {
 
     template <int PH, int ROLE = 0>
     __device__ __forceinline__ void step(PipeState<T, K>& st, IncT<T> (&inc)[NORM ? K : 1][N], const int64_t r) const {
-        constexpr int PFD = (K >= 4 && ROLE == 0) ? 2 : 1;  // prefetch distance in steps
+        constexpr int PFD = ROLE == 0 ? pipe_pfd<T, K, HET>() : 1;  // prefetch distance in steps
         constexpr bool INTRA_LDS = ROLE == 0;               // of / q1 hand-off between own stages through LDS
         // prefetch the level-0 rows of a later step: distance 1 straight into their ring slots, distance 2
         // (K >= 4: a step is long, the registers are there at 2 waves/SIMD; +2.6 % measured) into staging
@@ -1107,6 +1118,7 @@ struct Pipe {
                 b1c[j] = b[1];
             }
             if (p == 0) {  // replicate the row above the image
+                DXH_UNIFORM_BRANCH();
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
                     um[j] = uc[j];
@@ -1126,20 +1138,20 @@ struct Pipe {
             for (int j = 0; j < N; ++j) {
                 rhs[j] = ofv[j] + (t0c[j] - t0m[j]);
                 if constexpr (EDGE)
-                    rhs[j] = rhs[j] + (t1c[j] - (edgeL[j] ? t1c[j] : t1l[j]));
+                    rhs[j] = rhs[j] + (t1c[j] - sel_bits(edgeL[j], t1c[j], t1l[j]));
                 else
                     rhs[j] = rhs[j] + (t1c[j] - t1l[j]);
                 acc[j] = um[j] + up[j];
                 if constexpr (EDGE) {
-                    acc[j] = acc[j] + (edgeL[j] ? uc[j] : ul[j]);
-                    acc[j] = acc[j] + (edgeR[j] ? uc[j] : ur[j]);
+                    acc[j] = acc[j] + sel_bits(edgeL[j], uc[j], ul[j]);
+                    acc[j] = acc[j] + sel_bits(edgeR[j], uc[j], ur[j]);
                 } else {
                     acc[j] = acc[j] + ul[j];
                     acc[j] = acc[j] + ur[j];
                 }
                 if constexpr (COUPLED) {
-                    acc[j] = acc[j] + (ch0[j] ? uc[j] : ucl[j]);
-                    acc[j] = acc[j] + (chLast[j] ? uc[j] : ucr[j]);
+                    acc[j] = acc[j] + sel_bits(ch0[j], uc[j], ucl[j]);
+                    acc[j] = acc[j] + sel_bits(chLast[j], uc[j], ucr[j]);
                 }
             }
             if constexpr (ROLE == 1 && s == 0) {
@@ -1152,12 +1164,23 @@ struct Pipe {
 #pragma unroll
                 for (int j = 0; j < N; ++j) un[j] = rhs[j] / st.coef[s][1][j] + acc[j] / st.coef[s][2][j];
             } else {
-                T lo = t_min(t_abs(rhs[0]), t_abs(acc[0]));
+                const T lo = abs_min_all<T, N>(rhs, acc);
+                T qa[N], qb[N];
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
-                    un[j] = div_by_const(rhs[j], diag, rdiag) + div_by_const(acc[j], dsc, rdsc);
-                    if (j > 0) lo = t_min(lo, t_min(t_abs(rhs[j]), t_abs(acc[j])));
+                    qa[j] = div_by_const3(rhs[j], diag, rdiag);
+                    qb[j] = div_by_const3(acc[j], dsc, rdsc);
                 }
+                if (!div3) {  // divisors whose quotients need the second correction for some x
+                    DXH_UNIFORM_BRANCH();
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {
+                        qa[j] = div_refine(qa[j], rhs[j], diag, rdiag);
+                        qb[j] = div_refine(qb[j], acc[j], dsc, rdsc);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < N; ++j) un[j] = qa[j] + qb[j];
                 if (__builtin_expect(__any(lo < DivSafe<T>::tiny), 0)) {
                     bool unsafe = false;
 #pragma unroll
@@ -1169,6 +1192,7 @@ struct Pipe {
                 }
             }
             if (p >= nrow) {  // below the image: replicate the new iterate
+                DXH_UNIFORM_BRANCH();
 #pragma unroll
                 for (int j = 0; j < N; ++j) un[j] = unm[j];
             }
@@ -1184,7 +1208,7 @@ struct Pipe {
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 if constexpr (EDGE)
-                    q1o[j] = ((edgeR[j] ? un[j] : unr[j]) - un[j]) + b1c[j];
+                    q1o[j] = (sel_bits(edgeR[j], un[j], unr[j]) - un[j]) + b1c[j];
                 else
                     q1o[j] = (unr[j] - un[j]) + b1c[j];
                 q0o[j] = (un[j] - unm[j]) + b0m[j];
@@ -1267,11 +1291,11 @@ __device__ __forceinline__ bool pipe_setup(PipeT& pp, const FusedArgs<T>& a, con
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         const int64_t x = x0 + j;
-        pp.edgeL[j] = x < C;
-        pp.edgeR[j] = x >= a.L - C;
+        pp.edgeL[j] = lane_mask_bits(x < C);
+        pp.edgeR[j] = lane_mask_bits(x >= a.L - C);
         const int cc = (int)(((x % C) + C) % C);
-        pp.ch0[j] = cc == 0;
-        pp.chLast[j] = cc == C - 1;
+        pp.ch0[j] = lane_mask_bits(cc == 0);
+        pp.chLast[j] = lane_mask_bits(cc == C - 1);
         pp.inL[j] = x >= 0 && x < a.L;
     }
     pp.of_p = a.of;
@@ -1290,6 +1314,7 @@ __device__ __forceinline__ bool pipe_setup(PipeT& pp, const FusedArgs<T>& a, con
     pp.kq = a.c.kq;
     pp.rdiag = a.c.rdiag;
     pp.rdsc = a.c.rdsc;
+    pp.div3 = a.c.div3 != 0;
     pp.ci = a.ci;
     return true;
 }
@@ -1414,7 +1439,7 @@ __device__ __forceinline__ void fused_pipe_body(const FusedArgs<T>& a, const int
         for (int i = 0; i < PipeLds<K>::SLOTS; ++i) pp.lds_put(i, z);
     }
     const int64_t rs = pp.R0 - (K - 1);
-    pipe_prologue<(K >= 4 ? 2 : 1), ISO, HET>(pp, st, rs);
+    pipe_prologue<pipe_pfd<T, K, HET>(), ISO, HET>(pp, st, rs);
     // the last stage must reach row R1: steps rs .. R1 + K - 1, rounded up to whole groups of 4
     // (extra steps touch clamped rows only and store nothing)
     const int64_t r_end = pp.R1 + (K - 1);
@@ -1542,7 +1567,7 @@ __global__ void __launch_bounds__(256, DXH_PAIR_LB) k_fused_pair(FusedArgs<T> a)
 #endif  // DXH_ENABLE_PAIR
 
 template <typename T, int C, bool COUPLED, bool ISO, int K, bool NORM = false, bool NTS = true, bool HET = false>
-__global__ void __launch_bounds__(256, ((K >= 3 || HET) ? DXH_LB4 : 3)) k_fused_multi(FusedArgs<T> a) {
+__global__ void __launch_bounds__(256, (pipe_waves<T, K, HET>())) k_fused_multi(FusedArgs<T> a) {
     constexpr int N = VecOf<T>::N;
     using SG = StripGeomK<T, C, K>;
     const int lane = threadIdx.x & (kWave - 1);

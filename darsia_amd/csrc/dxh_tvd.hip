@@ -3,7 +3,11 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <limits>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <new>
 #include <string>
 #include <type_traits>
@@ -78,6 +82,7 @@ struct Ctx {
     bool last_iso = false, last_iso_prev = false;
     double mu_s = 0, omega_s = 1, ell_s = 0;  // scalar views (valid when !het)
     double c_ell = 0, c_diag = 0, c_dsc = 0, c_kq = 0;
+    int c_div3 = 0;  // Coef::div3 of the current scalar coefficients (float only)
     double sq_img = -1.0;          // sum img^2 over this slab
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DeviceSolver* solver = nullptr;  // MG / CG in the place of the Jacobi sweeps (dxh_tvd_set_solver)
@@ -97,6 +102,56 @@ static dim3 elem_grid(const Geom& g) {
     return dim3((unsigned)(bpr * g.n0));
 }
 
+
+// Exhaustive test, one thread per float mantissa, of the three-operation division q0 = x r, e = x - d q0,
+// q = q0 + e r against the IEEE quotient, for the two divisors of a scalar-coefficient solve.  Scaling x by a
+// power of two scales q0, e and q exactly (the callers screen tiny numerators), and rounding to nearest is
+// symmetric in sign, so the 2^23 values of [1, 2) decide it for every x.  Bit 0 / 1 of *bad: diag / dsc fails.
+__global__ void __launch_bounds__(256) k_div3_check(float d0, float r0, float d1, float r1, unsigned* bad) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    const float x = __uint_as_float(0x3f800000u | i);
+    unsigned b = 0;
+    if (div_by_const3(x, d0, r0) != x / d0) b |= 1u;
+    if (div_by_const3(x, d1, r1) != x / d1) b |= 2u;
+    if (b) atomicOr(bad, b);
+}
+
+// one launch of k_div3_check on `stream` and the read-back of its verdict
+static int div3_run_check(hipStream_t stream, float d0, float r0, float d1, float r1, unsigned* bad) {
+    unsigned* flag = nullptr;
+    DXH_HIP(hipMalloc(&flag, sizeof(unsigned)));
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(unsigned), stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_div3_check, dim3(1u << 15), dim3(256), 0, stream, d0, r0, d1, r1, flag);
+        e = hipMemcpyAsync(bad, flag, sizeof(unsigned), hipMemcpyDeviceToHost, stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(flag);
+    if (e != hipSuccess) { set_error("division check failed: %s", hipGetErrorString(e)); return DXH_EHIP; }
+    return DXH_OK;
+}
+
+// Is the three-operation division exact for both divisors of this coefficient set?  float only (2^23 cases each, a
+// ~10 us kernel plus a 4-byte read-back); answers are remembered per divisor pair.
+static int div3_verified(Ctx* c, float diag, float dsc) {
+    static std::mutex mtx;
+    static std::map<std::pair<uint32_t, uint32_t>, int> known;
+    uint32_t kd, ks;
+    std::memcpy(&kd, &diag, 4);
+    std::memcpy(&ks, &dsc, 4);
+    {
+        std::lock_guard<std::mutex> g(mtx);
+        auto it = known.find({kd, ks});
+        if (it != known.end()) return it->second;
+    }
+    unsigned bad = ~0u;
+    const int ok = div3_run_check(c->stream, diag, 1.0f / diag, dsc, 1.0f / dsc, &bad) == DXH_OK && bad == 0;
+    std::lock_guard<std::mutex> g(mtx);
+    if (known.size() > 4096) known.clear();
+    known[{kd, ks}] = ok;
+    return ok;
+}
+
 template <typename T>
 static Coef<T> make_coef(const Ctx* c) {
     Coef<T> k;
@@ -106,10 +161,12 @@ static Coef<T> make_coef(const Ctx* c) {
     k.kq = (T)c->c_kq;
     // reciprocals for div_by_const: only for divisors in a comfortable range, rounded in T by IEEE division
     k.rdiag = k.rdsc = T(0);
+    k.div3 = 0;
     auto ok = [](T d) { return std::isfinite((double)d) && std::fabs((double)d) >= 0x1p-20 && std::fabs((double)d) <= 0x1p+20; };
     if (!c->het && ok(k.diag) && ok(k.dsc)) {
         k.rdiag = T(1) / k.diag;
         k.rdsc = T(1) / k.dsc;
+        k.div3 = c->c_div3;
     }
     return k;
 }
@@ -258,7 +315,7 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
     const int nbx = pair ? (a.nstrips + 1) / 2 : (a.nstrips + 3) / 4;
     // Row chunks.  Array coefficients: grid sized for 24 waves per CU (measured best of 8..32).  Scalar coefficients:
     // all blocks take the same time, so the cost of a chunk count is (rows per chunk + pipeline fill) x rounds, where
-    // the blocks that fit at once (2 per CU for the K >= 3 pipelines, 3 for K = 2) make one round and a partial
+    // the blocks that fit at once (pipe_waves per CU: 3 for float, 2 for double at K >= 3) make one round and a partial
     // second round costs a whole one unless there are many rounds; candidates are multiples of 8 (XCD-aware tile map).
     int64_t nchunks;
     if (c->waves_per_cu || c->het) {
@@ -266,20 +323,34 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
         nchunks = std::max<int64_t>(1, target_blocks / nbx);
         if (nchunks >= 8) nchunks = nchunks / 8 * 8;
     } else {
-        const double capacity = (double)c->num_cu * (K >= 3 ? 2 : 3);
+        constexpr int W = pipe_waves<T, K, false>();  // blocks resident per CU (one wave of each per SIMD)
+        const double capacity = (double)c->num_cu * W;
+        // issue cost of one VALU instruction per SIMD with 1 / 2 / 3 / 4 waves taking turns (tools/valubench.hip)
+        static const double cpi[5] = {0.0, 6.6, 3.7, 3.5, 3.2};  // 3: fitted to chunk sweeps of this kernel (a third wave adds ~8 %)
         double best = 1e300;
         nchunks = 1;
         for (int64_t nc = 1; nc <= std::max<int64_t>(1, c->g.n0 / (8 * K)); nc = nc < 8 ? nc + 1 : nc + 8) {
             const int64_t rpc_c = (c->g.n0 + nc - 1) / nc;
             const int64_t real = (c->g.n0 + rpc_c - 1) / rpc_c;
             const double ratio = (double)(real * nbx) / capacity;
-            const double rounds = ratio <= 1.0 ? 1.0 : (ratio < 1.5 ? 2.0 : ratio);
-            const double cost = (double)(rpc_c + 2 * K + 2) * rounds;
+            double cost;
+            if (W >= 3) {
+                // VALU-bound pipelines (float): the busiest CU decides.  It runs ceil(blocks / CUs) blocks: whole
+                // rounds of W co-resident blocks, then a remainder round at lower occupancy (measured: 24 chunks
+                // = one full round beat 32 chunks by 11 % and 16 chunks by 6 % on the 4000 x 8000 x 3 image)
+                const int64_t per_cu = (real * nbx + c->num_cu - 1) / c->num_cu;
+                const int64_t full = per_cu / W, rem = per_cu - full * W;
+                cost = (double)(rpc_c + 2 * K + 2) * ((double)full * W * cpi[W] + (double)rem * cpi[rem]);
+            } else {
+                const double rounds = ratio <= 1.0 ? 1.0 : (ratio < 1.5 ? 2.0 : ratio);
+                cost = (double)(rpc_c + 2 * K + 2) * rounds;
+            }
             if (cost < best * 0.999) { best = cost; nchunks = real; }
             if (ratio > 4.5) break;
         }
     }
     if (c->force_chunks > 0) nchunks = c->force_chunks;  // developer knob DXH_NCHUNKS
+    if (c->tune & 512) fprintf(stderr, "[dxh] K=%d strips=%d blocks/chunk=%d chunks=%lld div3=%d\n", K, a.nstrips, nbx, (long long)nchunks, c->c_div3);
     int64_t rpc = std::max<int64_t>(8 * K, (c->g.n0 + nchunks - 1) / nchunks);
     nchunks = (c->g.n0 + rpc - 1) / rpc;
     a.rows_per_chunk = rpc;
@@ -313,7 +384,7 @@ static bool multi_supported(const Ctx* c) {
     if (c->het) return c->in_valid && !(c->tune & 32);  // array coefficients: derived in the kernel from the given planes
     // k_fused_multi divides through precomputed reciprocals: the divisors must be in a comfortable range
     auto ok = [](double d) { return std::isfinite(d) && std::fabs(d) >= 0x1p-20 && std::fabs(d) <= 0x1p+20; };
-    return ok(c->c_diag) && ok(c->c_dsc);
+    return ok(c->c_diag) && ok(c->c_dsc) && c->c_kq >= 0;
 }
 
 // iterations of the next launch when `left` iterations remain (array coefficients: their pipeline exists for one K
@@ -362,6 +433,9 @@ static bool fused_supported(const Ctx* c) {
     if (c->desc.dim != 2) return false;
     const int64_t C = c->g.n2;
     if (C < 1 || C > 4) return false;
+    // the scalar-coefficient fused kernels shrink through q - clamp(q, -k, k), which is the reference's
+    // max(|q| - k, 0) sign(q) only for a threshold k = mu / ell >= 0
+    if (!c->het && !(c->c_kq >= 0)) return false;
     return true;
 }
 
@@ -745,6 +819,12 @@ static int set_coeffs_t(Ctx* c, double mu, const void* mu_arr, double omega, con
         c->c_diag = omega + ell_d * 2 * dim / h2;
         c->c_dsc = c->c_diag / (ell_d / h2);
         c->c_kq = mu / ell_d;
+        c->c_div3 = 0;
+        if constexpr (std::is_same<T, float>::value) {
+            const float fd = (float)c->c_diag, fs = (float)c->c_dsc;
+            auto ok = [](float d) { return std::isfinite(d) && std::fabs(d) >= 0x1p-20f && std::fabs(d) <= 0x1p+20f; };
+            if (ok(fd) && ok(fs) && !(c->tune & 128)) c->c_div3 = div3_verified(c, fd, fs);
+        }
         for (void** p : {&c->cp_ell, &c->cp_diag, &c->cp_dsc, &c->cp_kq}) {
             if (*p) { DXH_HIP(hipFree(*p)); *p = nullptr; }
         }
@@ -1320,6 +1400,14 @@ int dxh_tvd_sync(dxh_tvd_t h) {
 }
 
 // ---- one-shot helpers ----------------------------------------------------------------------------
+int dxh_div3_probe(int device, float d0, float r0, float d1, float r1, unsigned* bad) {
+    DXH_REQUIRE(bad, "null argument");
+    DXH_HIP(hipSetDevice(device));
+    hipStream_t stream = nullptr;
+    DXH_HIP(cached_stream(device, &stream));
+    return div3_run_check(stream, d0, r0 != 0.0f ? r0 : 1.0f / d0, d1, r1 != 0.0f ? r1 : 1.0f / d1, bad);
+}
+
 int dxh_jacobi_solve(int device, int dtype, int ndim, int dim, int nsum, int64_t n0, int64_t n1, int64_t n2,
                      const void* x0, const void* rhs, void* out, double mass, const void* mass_arr, double diffusion,
                      const void* diffusion_arr, double h, int maxiter, double tol, int* sweeps_done) {

@@ -170,6 +170,15 @@ int dxh_tvd_sync(dxh_tvd_t ctx);
 int dxh_tvd_energy(dxh_tvd_t ctx, int which, double* value);
 
 /*
+ * Diagnostic.  The scalar-coefficient float pipelines divide by the two wave-invariant Jacobi divisors
+ * (jacobi.py:104-106) through reciprocals; whether ONE residual correction already gives the correctly rounded
+ * quotient for every numerator is decided per coefficient set by trying all 2^23 float mantissas on the device.
+ * This entry runs that test for divisors d0, d1 with reciprocals r0, r1 (0 = RN(1/d)); *bad gets bit 0 / bit 1
+ * set when some x is NOT rounded correctly for d0 / d1.
+ */
+int dxh_div3_probe(int device, float d0, float r0, float d1, float r1, unsigned* bad);
+
+/*
  * One-shot Jacobi solve  mass * x - diffusion * laplace(x) = rhs  (jacobi.py:74-133),
  * used by Jacobi.__call__ and H1_regularization (h1_regularization.py:54-70).
  * x0, rhs, out: host arrays of shape (n0, n1, n2).  Returns the iterate count in

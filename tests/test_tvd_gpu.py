@@ -511,6 +511,28 @@ def test_regressions_found_by_the_fuzzer():
                         O.split_bregman_tvd(img, mu=mu, ell=0.3, max_num_iter=n, promotion="strict"))
 
 
+def test_negative_threshold_and_exact_zeros():
+    """The fused kernels shrink through q - clamp(q, -k, k); a negative k = mu / ell (not meaningful, but the
+    reference evaluates it) must take the generic path, and images with exact zeros / flat regions (q == 0,
+    |q| == k) must agree bit for bit."""
+    rng = np.random.default_rng(5)
+    for dt in (np.float32, np.float64):
+        img = rng.random((40, 300, 3)).astype(dt)
+        img[10:20] = 0.5
+        img[:, 100:140] = 0.0
+        for mu in (-0.1, 0.0, 0.25):
+            for iso in (False, True):
+                for n in (1, 4, 9):
+                    assert_bits(da.split_bregman_tvd(img, mu=mu, ell=0.5, max_num_iter=n, isotropic=iso),
+                                O.split_bregman_tvd(img, mu=mu, ell=0.5, max_num_iter=n, isotropic=iso, promotion="strict"))
+    # steps of exactly 2k: after the first solve several q sit exactly on the threshold
+    img = np.zeros((32, 256), np.float32)
+    img[:, 128:] = 0.5
+    for n in (1, 2, 5, 8):
+        assert_bits(da.split_bregman_tvd(img, mu=0.25, ell=1.0, max_num_iter=n),
+                    O.split_bregman_tvd(img, mu=0.25, ell=1.0, max_num_iter=n, promotion="strict"))
+
+
 def test_small_random_sweep_of_parameters():
     """A short run of tools/fuzz_tvd.py's generator inside the suite."""
     rng = np.random.default_rng(1234)
@@ -557,3 +579,31 @@ def test_c_abi_in_place_output_is_safe():
     _lib.check(_lib.load().dxh_chambolle(_lib.default_device(), 0, 3, 1200, 2000, 3, _lib.ptr(buf), _lib.ptr(buf), 0.1, 0.0, 3,
                                           C.byref(done)))
     np.testing.assert_array_equal(buf, ref)
+
+
+def test_division_check_detects_wrong_quotients_and_both_paths_agree(monkeypatch):
+    """The float pipelines stop the constant division after ONE residual correction when an exhaustive device
+    test says that is exact for the coefficient set.  (1) The test itself: exact reciprocals of ordinary
+    divisors pass, a visibly wrong reciprocal must be caught.  (2) DXH_FUSED_TUNE=128 disables the
+    shortcut; both paths give the oracle's bits."""
+    import ctypes as C
+    from darsia_amd import _lib
+    lib = _lib.load()
+    bad = C.c_uint(7)
+    _lib.check(lib.dxh_div3_probe(0, 1.8, 0.0, 9.0, 0.0, C.byref(bad)))
+    assert bad.value == 0
+    # one correction squares the reciprocal's relative error: 2^-17 off leaves 2^-34, which flips the rounding of
+    # thousands of the 2^23 quotients
+    r_off = float(np.float32(1) / np.float32(1.8) * np.float32(1 + 2.0 ** -17))
+    _lib.check(lib.dxh_div3_probe(0, 1.8, r_off, 9.0, 0.0, C.byref(bad)))
+    assert bad.value == 1
+    # (a small integer divisor like 9 would not do: its quotients stay 1/18 ulp away from every rounding boundary)
+    r_off = float(np.float32(1) / np.float32(1.3) * np.float32(1 - 2.0 ** -17))
+    _lib.check(lib.dxh_div3_probe(0, 1.8, 0.0, 1.3, r_off, C.byref(bad)))
+    assert bad.value == 2
+    rng = np.random.default_rng(11)
+    img = rng.random((50, 420, 3)).astype(np.float32)
+    want = O.split_bregman_tvd(img, mu=0.1, max_num_iter=9, promotion="strict")
+    assert_bits(da.split_bregman_tvd(img, mu=0.1, max_num_iter=9), want)
+    monkeypatch.setenv("DXH_FUSED_TUNE", "128")
+    assert_bits(da.split_bregman_tvd(img, mu=0.1, max_num_iter=9), want)
