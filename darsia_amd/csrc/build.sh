@@ -11,7 +11,9 @@ JOBS="${JOBS:-8}"
 mkdir -p "${OBJ}"
 rm -f "${OBJ}"/*.o "${OBJ}"/*.log
 # -ffp-contract=off: every operation rounds once, as in the NumPy evaluation the results are compared with
-FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function "$@")
+# -fno-slp-vectorize: v_pk_*_f32 issue at half rate on gfx950, so the SLP vectoriser's packed pairs save nothing
+# and the v_mov shuffles that build them cost issue slots (-3 % on the VALU-bound pipelines, measured)
+FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function "$@")
 
 pids=()
 names=()
@@ -23,11 +25,10 @@ run() {  # run NAME SRC [extra flags]
     pids+=($!)
     names+=("${name}")
 }
-# heaviest first.  -fno-slp-vectorize: v_pk_*_f32 issue at half rate on gfx950, so the SLP vectoriser's
-# packed pairs save nothing and the v_mov shuffles that build them cost issue slots (-3 % measured)
+# heaviest first
 for k in 4 3 2; do
-    run "multi_f32_k${k}" dxh_multi.hip -DDXH_MULTI_T=float -DDXH_MULTI_K=${k} -fno-slp-vectorize
-    run "multi_f64_k${k}" dxh_multi.hip -DDXH_MULTI_T=double -DDXH_MULTI_K=${k} -fno-slp-vectorize
+    run "multi_f32_k${k}" dxh_multi.hip -DDXH_MULTI_T=float -DDXH_MULTI_K=${k}
+    run "multi_f64_k${k}" dxh_multi.hip -DDXH_MULTI_T=double -DDXH_MULTI_K=${k}
 done
 run tvd dxh_tvd.hip
 run chambolle dxh_chambolle.hip

@@ -14,6 +14,11 @@ def t(label, f, n=1):
     print(f"{label:70s} {dt*1e3:10.2f} ms", flush=True)
     return r
 
+def loop_ms(st, n, **kw):
+    """ms per iteration of the device loop: one warm-up run of the same length (clock ramp), best of three."""
+    st.run(n, **kw)
+    return min(st.run(n, **kw).loop_ms for _ in range(3)) / n
+
 H, W = 4000, 8000
 rgb = synthetic_image(H, W, 3)
 gray = synthetic_image(H, W, 1)
@@ -21,14 +26,14 @@ print("config 2 whole call (upload + 100 it + download), f32 RGB")
 t("split_bregman_tvd(rgb, mu=.1, 100 it)  [PCIe-inclusive]", lambda: da.split_bregman_tvd(rgb, mu=0.1, max_num_iter=100))
 st = da.DeviceTVD(rgb.shape, rgb.dtype); st.set_coeffs(0.1, 1.0, None, rgb); st.upload(rgb)
 for iso in (False, True):
-    st.run(8, isotropic=iso); r = st.run(100, isotropic=iso)
-    print(f"  device loop {'isotropic' if iso else 'anisotropic'}: {r.loop_ms/100:.4f} ms/iter  {H*W/(r.loop_ms/100)/1e3:.0f} MPix/s")
+    ms = loop_ms(st, 100, isotropic=iso)
+    print(f"  device loop {'isotropic' if iso else 'anisotropic'}: {ms:.4f} ms/iter  {H*W/ms/1e3:.0f} MPix/s")
 st.close()
 g64 = gray.astype(np.float64)
-st = da.DeviceTVD(g64.shape, g64.dtype); st.set_coeffs(0.1, 1.0, None, g64); st.upload(g64); st.run(8); r = st.run(100)
-print(f"  device loop float64 gray: {r.loop_ms/100:.4f} ms/iter  {H*W/(r.loop_ms/100)/1e3:.0f} MPix/s"); st.close()
-st = da.DeviceTVD(gray.shape, gray.dtype); st.set_coeffs(0.1, 1.0, None, gray); st.upload(gray); st.run(8); r = st.run(100)
-print(f"  device loop float32 gray: {r.loop_ms/100:.4f} ms/iter  {H*W/(r.loop_ms/100)/1e3:.0f} MPix/s"); st.close()
+st = da.DeviceTVD(g64.shape, g64.dtype); st.set_coeffs(0.1, 1.0, None, g64); st.upload(g64); ms = loop_ms(st, 100)
+print(f"  device loop float64 gray: {ms:.4f} ms/iter  {H*W/ms/1e3:.0f} MPix/s"); st.close()
+st = da.DeviceTVD(gray.shape, gray.dtype); st.set_coeffs(0.1, 1.0, None, gray); st.upload(gray); ms = loop_ms(st, 100)
+print(f"  device loop float32 gray: {ms:.4f} ms/iter  {H*W/ms/1e3:.0f} MPix/s"); st.close()
 print("config 3: colour apply + isotropic TVD")
 A = np.eye(3) + 0.05 * np.random.default_rng(7).normal(size=(3, 3)); b = 0.01 * np.random.default_rng(7).normal(size=3)
 t("apply_affine_balance(rgb f32)  [PCIe-inclusive]", lambda: da.apply_affine_balance(rgb, A, b, clip=True))
@@ -58,8 +63,8 @@ def host_chain():
 t("  the same elementwise stages as NumPy passes on the host (no TVD)", host_chain)
 print("heterogeneous coefficients: array-valued mu (device loop)")
 mu = np.full(rgb.shape, 0.1, np.float32); mu[:, W // 2:] = 0.3
-st = da.DeviceTVD(rgb.shape, rgb.dtype); st.set_coeffs(mu, 1.0, None, rgb); st.upload(rgb); st.run(9); r = st.run(99)
-print(f"  device loop mu array: {r.loop_ms/99:.4f} ms/iter  {H*W/(r.loop_ms/99)/1e3:.0f} MPix/s"); st.close()
+st = da.DeviceTVD(rgb.shape, rgb.dtype); st.set_coeffs(mu, 1.0, None, rgb); st.upload(rgb); ms = loop_ms(st, 99)
+print(f"  device loop mu array: {ms:.4f} ms/iter  {H*W/ms/1e3:.0f} MPix/s"); st.close()
 print("Gauss-Seidel split Bregman (TVD '* bregman' methods), 64 sweeps, eps off")
 t("denoise_tv_bregman(rgb, 64 sweeps)  [PCIe-inclusive]", lambda: da.denoise_tv_bregman(rgb, weight=1.0, max_num_iter=64, eps=0.0, isotropic=False))
 print("MG inside the TV loop (gray f32, depth 3, 2 smoother sweeps, 1 V-cycle per outer iteration, 20 outer iterations)")
