@@ -32,6 +32,7 @@ struct Coef {       // scalar coefficients, already rounded to T like NumPy's we
     T kq;           // mu / ell (shrinkage threshold)                      split_bregman_tvd.py:140,145
     T rdiag, rdsc;  // RN(1/diag), RN(1/dsc) for div_by_const; 0 = use the IEEE division
     int div3;       // 1: ONE residual correction already rounds x/diag and x/dsc correctly for every x (k_div3_check)
+    int const_diag; // array-valued mu with scalar omega and ell: diag / dsc above are the (wave-invariant) divisors
 };
 
 
@@ -974,6 +975,7 @@ struct Pipe {
     int64_t P, nrow, R0, R1;
     T ell, diag, dsc, kq, rdiag, rdsc;
     bool div3;          // Coef::div3
+    bool cdiag;         // Coef::const_diag
     bool store_lane;
     uint32_t edgeL[N], edgeR[N], ch0[N], chLast[N];  // lane patterns as 0 / ~0 words (sel_bits)
     bool inL[N];        // element inside the row (x < L)
@@ -1010,6 +1012,37 @@ struct Pipe {
     __device__ __forceinline__ void finish_coef(const T (&raw)[3][N], T (&cf)[4][N]) const {
 #pragma unroll
         for (int j = 0; j < N; ++j) derive_coefs<T>(ci, raw[0][j], raw[1][j], raw[2][j], cf[0][j], cf[1][j], cf[2][j], cf[3][j]);
+    }
+
+    // un = rhs / diag + acc / dsc with wave-invariant divisors: reciprocal refinement (div_by_const), the second
+    // correction only when the coefficient set needs it, the IEEE division for lanes' numerators that are tiny
+    __device__ __forceinline__ void div_const(const T (&rhs)[N], const T (&acc)[N], T (&un)[N]) const {
+        const T lo = abs_min_all<T, N>(rhs, acc);
+        T qa[N], qb[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            qa[j] = div_by_const3(rhs[j], diag, rdiag);
+            qb[j] = div_by_const3(acc[j], dsc, rdsc);
+        }
+        if (!div3) {  // divisors whose quotients need the second correction for some x
+            DXH_UNIFORM_BRANCH();
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                qa[j] = div_refine(qa[j], rhs[j], diag, rdiag);
+                qb[j] = div_refine(qb[j], acc[j], dsc, rdsc);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) un[j] = qa[j] + qb[j];
+        if (__builtin_expect(__any(lo < DivSafe<T>::tiny), 0)) {
+            bool unsafe = false;
+#pragma unroll
+            for (int j = 0; j < N; ++j) unsafe = unsafe || div_unsafe(rhs[j]) || div_unsafe(acc[j]);
+            if (__any(unsafe)) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) un[j] = rhs[j] / diag + acc[j] / dsc;
+            }
+        }
     }
 
     template <int PH, int ROLE = 0>
@@ -1161,35 +1194,15 @@ struct Pipe {
                 load_vec(at(q1_in, rn), st.q1l[0]);
             }
             if constexpr (HET) {
-#pragma unroll
-                for (int j = 0; j < N; ++j) un[j] = rhs[j] / st.coef[s][1][j] + acc[j] / st.coef[s][2][j];
-            } else {
-                const T lo = abs_min_all<T, N>(rhs, acc);
-                T qa[N], qb[N];
-#pragma unroll
-                for (int j = 0; j < N; ++j) {
-                    qa[j] = div_by_const3(rhs[j], diag, rdiag);
-                    qb[j] = div_by_const3(acc[j], dsc, rdsc);
-                }
-                if (!div3) {  // divisors whose quotients need the second correction for some x
+                if (cdiag) {  // only mu varies: the divisors are wave-invariant like in the scalar pipeline
                     DXH_UNIFORM_BRANCH();
+                    div_const(rhs, acc, un);
+                } else {
 #pragma unroll
-                    for (int j = 0; j < N; ++j) {
-                        qa[j] = div_refine(qa[j], rhs[j], diag, rdiag);
-                        qb[j] = div_refine(qb[j], acc[j], dsc, rdsc);
-                    }
+                    for (int j = 0; j < N; ++j) un[j] = rhs[j] / st.coef[s][1][j] + acc[j] / st.coef[s][2][j];
                 }
-#pragma unroll
-                for (int j = 0; j < N; ++j) un[j] = qa[j] + qb[j];
-                if (__builtin_expect(__any(lo < DivSafe<T>::tiny), 0)) {
-                    bool unsafe = false;
-#pragma unroll
-                    for (int j = 0; j < N; ++j) unsafe = unsafe || div_unsafe(rhs[j]) || div_unsafe(acc[j]);
-                    if (__any(unsafe)) {
-#pragma unroll
-                        for (int j = 0; j < N; ++j) un[j] = rhs[j] / diag + acc[j] / dsc;
-                    }
-                }
+            } else {
+                div_const(rhs, acc, un);
             }
             if (p >= nrow) {  // below the image: replicate the new iterate
                 DXH_UNIFORM_BRANCH();
@@ -1315,6 +1328,7 @@ __device__ __forceinline__ bool pipe_setup(PipeT& pp, const FusedArgs<T>& a, con
     pp.rdiag = a.c.rdiag;
     pp.rdsc = a.c.rdsc;
     pp.div3 = a.c.div3 != 0;
+    pp.cdiag = a.c.const_diag != 0;
     pp.ci = a.ci;
     return true;
 }

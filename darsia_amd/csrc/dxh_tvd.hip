@@ -83,6 +83,7 @@ struct Ctx {
     double mu_s = 0, omega_s = 1, ell_s = 0;  // scalar views (valid when !het)
     double c_ell = 0, c_diag = 0, c_dsc = 0, c_kq = 0;
     int c_div3 = 0;  // Coef::div3 of the current scalar coefficients (float only)
+    bool het_cdiag = false;  // array-valued mu only: omega and ell (hence diag, dsc) are scalars
     double sq_img = -1.0;          // sum img^2 over this slab
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     DeviceSolver* solver = nullptr;  // MG / CG in the place of the Jacobi sweeps (dxh_tvd_set_solver)
@@ -162,11 +163,13 @@ static Coef<T> make_coef(const Ctx* c) {
     // reciprocals for div_by_const: only for divisors in a comfortable range, rounded in T by IEEE division
     k.rdiag = k.rdsc = T(0);
     k.div3 = 0;
+    k.const_diag = 0;
     auto ok = [](T d) { return std::isfinite((double)d) && std::fabs((double)d) >= 0x1p-20 && std::fabs((double)d) <= 0x1p+20; };
-    if (!c->het && ok(k.diag) && ok(k.dsc)) {
+    if ((!c->het || c->het_cdiag) && ok(k.diag) && ok(k.dsc)) {
         k.rdiag = T(1) / k.diag;
         k.rdsc = T(1) / k.dsc;
         k.div3 = c->c_div3;
+        k.const_diag = c->het ? 1 : 0;
     }
     return k;
 }
@@ -811,6 +814,8 @@ static int set_coeffs_t(Ctx* c, double mu, const void* mu_arr, double omega, con
         if (*p) { DXH_HIP(hipFree(*p)); *p = nullptr; }
     }
     c->in_valid = false;
+    c->het_cdiag = false;
+    c->c_div3 = 0;
     if (!c->het) {
         // all-scalar: fold in double like Python floats, round once where the value meets an array
         const double ell_d = has_ell ? ell : 2.0 * mu;
@@ -873,6 +878,19 @@ static int set_coeffs_t(Ctx* c, double mu, const void* mu_arr, double omega, con
     c->in_has_ell = has_ell;
     c->in_h = h;
     c->in_valid = want_kq;  // (mass, diffusion) solves without mu never use the fused sweep
+    // only mu varies (the TVD operator always passes a scalar ell): the Jacobi divisors are the Python floats of
+    // derive_coefs' diag_s / dsc_s, and the fused sweep divides by them through reciprocals like the scalar pipeline
+    const bool ell_is_arr = ell_arr || (!has_ell && mu_arr);
+    if (!ell_is_arr && !omega_arr) {
+        c->c_diag = omega + ell_d * 2 * dim / h2;
+        c->c_dsc = c->c_diag / (ell_d / h2);
+        c->het_cdiag = true;
+        if constexpr (std::is_same<T, float>::value) {
+            const float fd = (float)c->c_diag, fs = (float)c->c_dsc;
+            auto okf = [](float d) { return std::isfinite(d) && std::fabs(d) >= 0x1p-20f && std::fabs(d) <= 0x1p+20f; };
+            if (okf(fd) && okf(fs) && !(c->tune & 128)) c->c_div3 = div3_verified(c, fd, fs);
+        }
+    }
     return DXH_OK;
 }
 

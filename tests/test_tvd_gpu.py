@@ -509,6 +509,17 @@ def test_regressions_found_by_the_fuzzer():
         for n in (1, 4, 7):
             assert_bits(da.split_bregman_tvd(img, mu=mu, ell=0.3, max_num_iter=n),
                         O.split_bregman_tvd(img, mu=mu, ell=0.3, max_num_iter=n, promotion="strict"))
+    # the same (only mu varies: constant Jacobi divisors inside the array-coefficient pipeline) in float64,
+    # isotropic, and with the stopping test
+    img = rng.random((45, 333, 3))
+    mu = 0.02 + 0.2 * rng.random(img.shape)
+    for iso in (False, True):
+        for n in (3, 8):
+            assert_bits(da.split_bregman_tvd(img, mu=mu, omega=1.3, ell=0.7, max_num_iter=n, isotropic=iso),
+                        O.split_bregman_tvd(img, mu=mu, omega=1.3, ell=0.7, max_num_iter=n, isotropic=iso, promotion="strict"))
+    img32, mu32 = img.astype(np.float32), mu.astype(np.float32)
+    assert_bits(da.split_bregman_tvd(img32, mu=mu32, ell=0.7, max_num_iter=30, eps=1e-3),
+                O.split_bregman_tvd(img32, mu=mu32, ell=0.7, max_num_iter=30, eps=1e-3, promotion="strict"))
 
 
 def test_negative_threshold_and_exact_zeros():
