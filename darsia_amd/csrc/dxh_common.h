@@ -209,6 +209,37 @@ __device__ __forceinline__ void shifted(const T (&v)[VecOf<T>::N], T (&w)[VecOf<
     }
 }
 
+// a + row[x0 + J + DELTA] (SUB: a - ...) where the lane holds row[x0 .. x0+N) in v.  When the element lives in
+// a neighbour lane (float), the DPP move is folded into the add itself -- LLVM's DPP combiner leaves most of
+// these as v_mov_b32_dpp + v_add_f32 -- one VALU instead of two.  The leading s_nop covers the two wait states
+// a DPP read needs after a VALU write of its source, which the hazard recogniser cannot see inside an asm.
+template <int DELTA, int J, bool SUB, typename T, int N>
+__device__ __forceinline__ T add_shifted_elem(T a, const T (&v)[N]) {
+    constexpr int idx = J + DELTA;
+    constexpr int lo = floor_div(idx, N);
+    constexpr int e = idx - lo * N;
+    if constexpr (sizeof(T) == 4 && (lo == -1 || lo == 1)) {
+        float r;
+        if constexpr (lo == -1 && !SUB)
+            asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v[e]), "v"(a));
+        else if constexpr (lo == -1 && SUB)
+            asm("s_nop 1\n\tv_subrev_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v[e]), "v"(a));
+        else if constexpr (lo == 1 && !SUB)
+            asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v[e]), "v"(a));
+        else
+            asm("s_nop 1\n\tv_subrev_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v[e]), "v"(a));
+        return r;
+    } else {
+        const T w = lane_from<lo, true>(v[e]);
+        return SUB ? a - w : a + w;
+    }
+}
+// does element J of shifted<DELTA> come from the same (lane, element) as element J2 of shifted<DELTA2>?
+template <int DELTA, int J, int DELTA2, int J2, int N>
+constexpr bool same_shift_source() {
+    return floor_div(J + DELTA, N) == floor_div(J2 + DELTA2, N) && (J + DELTA) - floor_div(J + DELTA, N) * N == (J2 + DELTA2) - floor_div(J2 + DELTA2, N) * N;
+}
+
 // ---- arithmetic shared by all kernels -------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ T sgn(T x) {

@@ -18,6 +18,9 @@
 #ifndef DXH_STRIP_ALIGN_BYTES
 #define DXH_STRIP_ALIGN_BYTES 64  // k_fused_multi: a wave's store range covers whole granules of this size
 #endif
+#ifndef DXH_FUSE_DPP_ADDS
+#define DXH_FUSE_DPP_ADDS 1  // Pipe::step: hand-fused v_add_f32_dpp for the column-neighbour sums of interior strips
+#endif
 #ifndef DXH_LB4
 #define DXH_LB4 3  // waves per SIMD requested for the float K >= 3 scalar-coefficient pipelines (register cap 168)
 #endif
@@ -1167,6 +1170,30 @@ struct Pipe {
                 shifted<+1, DPP>(uc, ucr);
             }
             T rhs[N], acc[N];
+            if constexpr (!EDGE && DXH_FUSE_DPP_ADDS) {
+                // interior strips: the lane shifts ride on the adds themselves (add_shifted_elem); neighbour elements
+                // that the channel selects need as values anyway keep their shared v_mov_dpp
+                static_for<0, N>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    rhs[j] = ofv[j] + (t0c[j] - t0m[j]);
+                    rhs[j] = rhs[j] + add_shifted_elem<-C, j, true>(t1c[j], t1c);
+                    acc[j] = um[j] + up[j];
+                    constexpr bool shl = COUPLED && same_shift_source<-C, j, -1, 0, N>();
+                    constexpr bool shr = COUPLED && same_shift_source<+C, j, +1, N - 1, N>();
+                    if constexpr (shl)
+                        acc[j] = acc[j] + ul[j];
+                    else
+                        acc[j] = add_shifted_elem<-C, j, false>(acc[j], uc);
+                    if constexpr (shr)
+                        acc[j] = acc[j] + ur[j];
+                    else
+                        acc[j] = add_shifted_elem<+C, j, false>(acc[j], uc);
+                    if constexpr (COUPLED) {
+                        acc[j] = acc[j] + sel_bits(ch0[j], uc[j], ucl[j]);
+                        acc[j] = acc[j] + sel_bits(chLast[j], uc[j], ucr[j]);
+                    }
+                });
+            } else {
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 rhs[j] = ofv[j] + (t0c[j] - t0m[j]);
@@ -1186,6 +1213,7 @@ struct Pipe {
                     acc[j] = acc[j] + sel_bits(ch0[j], uc[j], ucl[j]);
                     acc[j] = acc[j] + sel_bits(chLast[j], uc[j], ucr[j]);
                 }
+            }
             }
             if constexpr (ROLE == 1 && s == 0) {
                 const int64_t rn = clampr(r + 1);
