@@ -976,6 +976,8 @@ struct Pipe {
     T* q0_out;
     T* q1_out;
     int64_t P, nrow, R0, R1;
+    int nrow32, R0_32, R1_32;  // the same rows as 32-bit integers: s_cmp_*_i32 for the per-row tests (there is no
+                               // s_cmp_lt_i64, 64-bit tests become v_mov_b64 + v_cmp_*_i64 on the VALU); n0 < 2^31 - 64
     T ell, diag, dsc, kq, rdiag, rdsc;
     bool div3;          // Coef::div3
     bool cdiag;         // Coef::const_diag
@@ -1102,6 +1104,7 @@ struct Pipe {
             constexpr int cur = PH & 1, prv = cur ^ 1;
             constexpr int lcur = (ROLE == 1) ? 0 : cur;  // slot of the loaded q rows (head: single buffer)
             const int64_t p = r - s;
+            const int p32 = (int)p;
             T(&um)[N] = st.U[s][cm];
             T(&uc)[N] = st.U[s][c];
             T(&up)[N] = st.U[s][cp];
@@ -1232,12 +1235,12 @@ struct Pipe {
             } else {
                 div_const(rhs, acc, un);
             }
-            if (p >= nrow) {  // below the image: replicate the new iterate
+            if (p32 >= nrow32) {  // below the image: replicate the new iterate
                 DXH_UNIFORM_BRANCH();
 #pragma unroll
                 for (int j = 0; j < N; ++j) un[j] = unm[j];
             }
-            if (NORM && p >= R0 && p < R1) {  // wave-uniform; rows of this chunk only (each element once)
+            if (NORM && p32 >= R0_32 && p32 < R1_32) {  // wave-uniform; rows of this chunk only (each element once)
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
                     const IncT<T> dlt = un[j] - uc[j];
@@ -1261,7 +1264,7 @@ struct Pipe {
                 xput(4 + cm, q0o);
             } else if constexpr (last) {
                 if (store_lane) {
-                    if (p >= R0 && p < R1) {
+                    if (p32 >= R0_32 && p32 < R1_32) {
                         if constexpr (NTS) {
                             store_vec_nt(at(q1_out, p), q1o);
                             store_vec_nt(at(u_out, p), un);
@@ -1270,7 +1273,7 @@ struct Pipe {
                             store_vec(at(u_out, p), un);
                         }
                     }
-                    if (p - 1 >= R0 && p - 1 < R1) {
+                    if (p32 - 1 >= R0_32 && p32 - 1 < R1_32) {
                         if constexpr (NTS)
                             store_vec_nt(at(q0_out, p - 1), q0o);
                         else
@@ -1349,6 +1352,9 @@ __device__ __forceinline__ bool pipe_setup(PipeT& pp, const FusedArgs<T>& a, con
     pp.voff = (uint32_t)(xl * (int64_t)sizeof(T));
     pp.P = a.pitch;
     pp.nrow = a.n0;
+    pp.nrow32 = (int)a.n0;  // the host keeps n0 below 2^31 - 64 for these kernels (multi_supported)
+    pp.R0_32 = (int)pp.R0;
+    pp.R1_32 = (int)pp.R1;
     pp.ell = a.c.ell;
     pp.diag = a.c.diag;
     pp.dsc = a.c.dsc;

@@ -2,6 +2,7 @@
 // Written for gfx950 (MI355X) only.
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -384,6 +385,7 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
 // channel counts the multi-iteration kernel is instantiated for
 static bool multi_supported(const Ctx* c) {
     if (!(c->desc.dim == 2 && (c->g.n2 == 1 || c->g.n2 == 3)) || (c->tune & 8)) return false;
+    if (c->g.n0 > (int64_t)INT32_MAX - 64) return false;  // the pipelines index rows with 32-bit integers
     if (c->het) return c->in_valid && !(c->tune & 32);  // array coefficients: derived in the kernel from the given planes
     // k_fused_multi divides through precomputed reciprocals: the divisors must be in a comfortable range
     auto ok = [](double d) { return std::isfinite(d) && std::fabs(d) >= 0x1p-20 && std::fabs(d) <= 0x1p+20; };

@@ -42,7 +42,8 @@ if f and w:
     fused = [k for k in fe if "k_fused" in k]
     scale = [k for k in fe if "k_scale" in k]
     if fused:
-        k = max(fused, key=lambda n: fe[n][0])
+        # the kernel the trace found dominant (the 10-iteration PMC runs also launch a K = 2 remainder)
+        k = top["Name"] if top and top["Name"] in fe else max(fused, key=lambda n: (fe[n][1], fe[n][0]))
         fetch_b = fe[k][0] * 1024 * 2.0      # gfx950: FETCH_SIZE reports half the bytes of a coalesced stream
         write_b = wr[k][0] * 1024
         cal = None
