@@ -1651,6 +1651,8 @@ struct JacobiMultiArgs {
     int64_t n0, L, pitch, rows_per_chunk;
     int nstrips, nchunks;
     T dsc;
+    T rdsc;    // RN(1/dsc), 0 = divide the IEEE way
+    int div3;  // Coef::div3 for dsc
 };
 
 template <typename T, int C, bool COUPLED, int K>
@@ -1726,6 +1728,7 @@ __global__ void __launch_bounds__(256) k_jacobi_multi(JacobiMultiArgs<T> a) {
                 shifted<+1, true>(uc[s2], ucr);
             }
             const bool top = p <= 0, bottom = p >= a.n0 - 1;  // uniform: replicate ghosts (jacobi.py:43,52)
+            T accv[N];
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 T acc = (top ? uc[s2][j] : um[s2][j]) + (bottom ? uc[s2][j] : below[j]);
@@ -1735,7 +1738,34 @@ __global__ void __launch_bounds__(256) k_jacobi_multi(JacobiMultiArgs<T> a) {
                     acc = acc + (ch0[j] ? uc[s2][j] : ucl[j]);
                     acc = acc + (chLast[j] ? uc[s2][j] : ucr[j]);
                 }
-                xn[j] = rsd[s2][j] + acc / a.dsc;
+                accv[j] = acc;
+            }
+            // acc / dsc through the host-rounded reciprocal (div_by_const: correctly rounded; the second correction
+            // is skipped when the exhaustive float check allows it); tiny numerators and odd divisors: IEEE division
+            bool ieee = a.rdsc == T(0);
+            if (!ieee) {
+                T q[N];
+#pragma unroll
+                for (int j = 0; j < N; ++j) q[j] = div_by_const3(accv[j], a.dsc, a.rdsc);
+                if (!a.div3) {
+                    DXH_UNIFORM_BRANCH();
+#pragma unroll
+                    for (int j = 0; j < N; ++j) q[j] = div_refine(q[j], accv[j], a.dsc, a.rdsc);
+                }
+#pragma unroll
+                for (int j = 0; j < N; ++j) xn[j] = rsd[s2][j] + q[j];
+                const T lo = abs_min_all<T, N>(accv, accv);
+                if (__builtin_expect(__any(lo < DivSafe<T>::tiny), 0)) {
+                    bool unsafe = false;
+#pragma unroll
+                    for (int j = 0; j < N; ++j) unsafe = unsafe || div_unsafe(accv[j]);
+                    ieee = __any(unsafe);
+                }
+            }
+            if (ieee) {
+                DXH_UNIFORM_BRANCH();
+#pragma unroll
+                for (int j = 0; j < N; ++j) xn[j] = rsd[s2][j] + accv[j] / a.dsc;
             }
             if (s2 == K - 1) {
                 if (store_lane && p >= R0 && p < R1) store_vec_nt(xout + p * P, xn);

@@ -359,9 +359,13 @@ struct MGSolver final : DeviceSolver {
             while (left >= 2) {
                 const int k = left == 5 ? 3 : std::min(4, left);
                 void* dst = (left - k == 0) ? out : (flip ? L.t1 : L.t0);
-                JacobiMultiArgs<T> ja;
+                JacobiMultiArgs<T> ja{};
                 ja.rs = (const T*)L.rs; ja.x_in = (const T*)src; ja.x_out = (T*)dst;
                 ja.n0 = L.g.n0; ja.L = L.g.L; ja.pitch = L.g.pitch; ja.dsc = c_dsc;
+                // reciprocal division (five operations, correctly rounded); the exhaustive three-operation check
+                // belongs to the TVD context and is not consulted for the smoother
+                ja.rdsc = (std::isfinite((double)c_dsc) && std::fabs((double)c_dsc) >= 0x1p-20 && std::fabs((double)c_dsc) <= 0x1p+20) ? T(1) / c_dsc : T(0);
+                ja.div3 = 0;
 #define DXH_MGJ(K_)                                                                                                        \
     {                                                                                                                      \
         using SG = StripGeomK<T, 1, K_>;                                                                                  \

@@ -526,7 +526,7 @@ static bool jacobi_multi_supported(const Ctx* c) {
 template <typename T, int C, bool COUPLED, int K>
 static void launch_jacobi_multi_k(Ctx* c, const void* xin, void* xout) {
     using SG = StripGeomK<T, C, K>;
-    JacobiMultiArgs<T> a;
+    JacobiMultiArgs<T> a{};
     a.rs = (const T*)c->rs;
     a.x_in = (const T*)xin;
     a.x_out = (T*)xout;
@@ -540,6 +540,13 @@ static void launch_jacobi_multi_k(Ctx* c, const void* xin, void* xout) {
     a.rows_per_chunk = rpc;
     a.nchunks = (int)nchunks;
     a.dsc = (T)c->c_dsc;
+    a.rdsc = T(0);
+    a.div3 = 0;
+    if (std::isfinite((double)a.dsc) && std::fabs((double)a.dsc) >= 0x1p-20 && std::fabs((double)a.dsc) <= 0x1p+20) {
+        a.rdsc = T(1) / a.dsc;
+        if constexpr (std::is_same<T, float>::value)
+            if (!(c->tune & 128)) a.div3 = div3_verified(c, a.dsc, a.dsc);  // remembered per divisor after the first call
+    }
     hipLaunchKernelGGL((k_jacobi_multi<T, C, COUPLED, K>), dim3((unsigned)(nbx * nchunks)), dim3(256), 0, c->stream, a);
 }
 
