@@ -48,11 +48,12 @@ def _worker(rank, world, port, case, out_dir):
 
 @pytest.mark.parametrize("case", [
     dict(shape=(300, 530, 3), world=2, halo_iters=4, n_iter=10),
+    dict(shape=(400, 300, 3), world=2, halo_iters=20, n_iter=44),   # bench.py's exchange interval: 5 K=4 launches per round
     dict(shape=(97, 260), world=3, halo_iters=1, n_iter=5),
     dict(shape=(120, 300, 3), world=2, halo_iters=3, n_iter=80, eps=2e-3),
     dict(shape=(90, 270, 3), world=2, halo_iters=2, n_iter=6, iso=True),
     dict(shape=(210, 300, 3), world=2, halo_iters=3, n_iter=11, het=True),
-], ids=["rgb_k4", "gray_k1_3ranks", "eps", "iso", "het_mu_array"])
+], ids=["rgb_k4", "rgb_k20_bench_interval", "gray_k1_3ranks", "eps", "iso", "het_mu_array"])
 def test_two_ranks_one_gpu(tmp_path, case):
     import torch.multiprocessing as mp
 
