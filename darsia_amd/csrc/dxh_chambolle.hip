@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "dxh_kernels.h"
@@ -348,6 +349,9 @@ __global__ void __launch_bounds__(256) k_ch_march(ChMarchArgs<T> a) {
 // chunk.  Both iterations' energy sums are produced (the stop test needs every iteration's energy); when the test
 // fires at the second iteration of a pass the host recomputes that single iteration from the untouched input.
 // --------------------------------------------------------------------------------------------------------------
+#ifndef DXH_CH_STEADY_UNROLL
+#define DXH_CH_STEADY_UNROLL 1  // 3 = unroll the steady loop by the period of the row rotation (no gain measured)
+#endif
 template <typename T>
 struct ChMarch2Args {
     ChMarchArgs<T> m;
@@ -395,7 +399,7 @@ __global__ void __launch_bounds__(256) k_ch_march2(ChMarch2Args<T> aa) {
     T* q1 = a.pout[1] + xl;
     T* q2 = HAS3 ? a.pout[2] + xl : nullptr;
 
-    auto d_out = [&](const T (&a0)[N], const T (&a1)[N], const T (&a2)[N], const T (&above)[N], bool has_above, const T (&fv)[N],
+    auto d_out = [&](const T (&a0)[N], const T (&a1)[N], const T (&a2)[N], const T (&above)[N], auto has_above, const T (&fv)[N],
                      T (&d)[N], T (&o)[N]) {
         T l1[N], l2[N];
         shifted<-C, true>(a1, l1);
@@ -417,7 +421,7 @@ __global__ void __launch_bounds__(256) k_ch_march2(ChMarch2Args<T> aa) {
     // p update of one row from its p, out, the next row's out (has_next) -- returns the new p rows and adds the
     // row's energy terms when `count`
     auto p_update = [&](const T (&c0)[N], const T (&c1)[N], const T (&c2)[N], const T (&dc)[N], const T (&oc)[N], const T (&on)[N],
-                        bool has_next, bool count, double& sq, double& nsum, T (&r0)[N], T (&r1)[N], T (&r2)[N]) {
+                        auto has_next, auto count, double& sq, double& nsum, T (&r0)[N], T (&r1)[N], T (&r2)[N]) {
         T o1[N], o2[N];
         shifted<+C, true>(oc, o1);
         if constexpr (HAS3) shifted<+1, true>(oc, o2);
@@ -479,7 +483,14 @@ __global__ void __launch_bounds__(256) k_ch_march2(ChMarch2Args<T> aa) {
     bool b_valid = false, have_above = false;
     double sqa = 0.0, nsa = 0.0, sqb = 0.0, nsb = 0.0;
     const int64_t t_last = R1 < a.n0 ? R1 : a.n0 - 1;  // last row stage 0 emits
-    for (int64_t t = e0; t <= R1; ++t) {
+    // One step of the march.  `steady` = std::true_type for rows where every border / start-up condition is known
+    // (both stages emit, a next row and a row above exist, both rows are counted): the wave-uniform flags then fold
+    // away instead of costing a v_cndmask per element; all other rows run the same code with run-time flags.
+    auto pick = [](auto steady_c, bool v) {
+        if constexpr (decltype(steady_c)::value) return std::true_type{};
+        else return v;
+    };
+    auto march_step = [&](const int64_t t, auto steady) __attribute__((always_inline)) {
         // prefetch row t + 2 of p^n and f
         T f0[N], f1[N], f2[N], ff[N];
         {
@@ -490,14 +501,14 @@ __global__ void __launch_bounds__(256) k_ch_march2(ChMarch2Args<T> aa) {
             load_vec(f + rn * P, ff);
         }
         T e_0[N], e_1[N], e_2[N];  // p^(n+1) of row t
-        const bool emit0 = t <= t_last;
+        const auto emit0 = pick(steady, t <= t_last);
         if (emit0) {
             T dn[N], on[N];
 #pragma unroll
             for (int j = 0; j < N; ++j) dn[j] = on[j] = T(0);
-            const bool has_next = t + 1 < a.n0;
-            if (has_next) d_out(n0v, n1v, HAS3 ? n2v : zero, a0, true, fn, dn, on);
-            p_update(a0, a1, HAS3 ? a2 : zero, ad, ao, on, has_next, t >= R0 && t < R1, sqa, nsa, e_0, e_1, e_2);
+            const auto has_next = pick(steady, t + 1 < a.n0);
+            if (has_next) d_out(n0v, n1v, HAS3 ? n2v : zero, a0, std::true_type{}, fn, dn, on);
+            p_update(a0, a1, HAS3 ? a2 : zero, ad, ao, on, has_next, pick(steady, t >= R0 && t < R1), sqa, nsa, e_0, e_1, e_2);
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 a0[j] = n0v[j]; a1[j] = n1v[j];
@@ -509,10 +520,10 @@ __global__ void __launch_bounds__(256) k_ch_march2(ChMarch2Args<T> aa) {
         // ---- stage 1: row t of p^(n+1) enters; row t - 1 is emitted ----
         if (emit0) {
             T dn[N], on[N];
-            d_out(e_0, e_1, HAS3 ? e_2 : zero, babove, have_above, fcur, dn, on);  // d / out of row t from p^(n+1)
-            if (b_valid) {  // row t - 1 has its out and now the next row's out
+            d_out(e_0, e_1, HAS3 ? e_2 : zero, babove, pick(steady, have_above), fcur, dn, on);  // d / out of row t from p^(n+1)
+            if (pick(steady, b_valid)) {  // row t - 1 has its out and now the next row's out
                 T r0[N], r1[N], r2[N];
-                p_update(b0, b1, HAS3 ? b2 : zero, bd, bo, on, true, true, sqb, nsb, r0, r1, r2);
+                p_update(b0, b1, HAS3 ? b2 : zero, bd, bo, on, std::true_type{}, std::true_type{}, sqb, nsb, r0, r1, r2);
                 if (store_lane) {
                     store_vec_nt(q0 + (t - 1) * P, r0);
                     store_vec_nt(q1 + (t - 1) * P, r1);
@@ -547,6 +558,21 @@ __global__ void __launch_bounds__(256) k_ch_march2(ChMarch2Args<T> aa) {
             fcur[j] = fn[j];  // f of row t + 1: the row entering stage 1 in the next step
             fn[j] = ff[j];
         }
+        };
+    {
+        const int64_t s_lo = R0 + 1, s_hi = (R1 - 1 < a.n0 - 2) ? R1 - 1 : a.n0 - 2;  // steady rows (may be empty)
+        int64_t t = e0;
+        for (; t <= R1 && t < s_lo; ++t) march_step(t, std::false_type{});
+        // unrolled by 3 = the period of the row rotation (current / next / prefetched): the copies become renaming
+#if DXH_CH_STEADY_UNROLL == 3
+        for (; t + 2 <= s_hi; t += 3) {
+            march_step(t, std::true_type{});
+            march_step(t + 1, std::true_type{});
+            march_step(t + 2, std::true_type{});
+        }
+#endif
+        for (; t <= s_hi; ++t) march_step(t, std::true_type{});
+        for (; t <= R1; ++t) march_step(t, std::false_type{});
     }
 #pragma unroll
     for (int off = kWave / 2; off > 0; off >>= 1) {
