@@ -318,9 +318,9 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
 #endif
     const int nbx = pair ? (a.nstrips + 1) / 2 : (a.nstrips + 3) / 4;
     // Row chunks.  Array coefficients: grid sized for 24 waves per CU (measured best of 8..32).  Scalar coefficients:
-    // all blocks take the same time, so the cost of a chunk count is (rows per chunk + pipeline fill) x rounds, where
-    // the blocks that fit at once (pipe_waves per CU: 3 for float, 2 for double at K >= 3) make one round and a partial
-    // second round costs a whole one unless there are many rounds; candidates are multiples of 8 (XCD-aware tile map).
+    // all blocks take the same time, so the cost of a chunk count is (rows per chunk + pipeline fill) x the issue time of
+    // the busiest CU's blocks, W of them co-resident (pipe_waves: 3 for float, 2 for double at K >= 3); candidates are
+    // multiples of 8 (XCD-aware tile map).
     int64_t nchunks;
     if (c->waves_per_cu || c->het) {
         const int64_t target_blocks = (int64_t)c->num_cu * (c->waves_per_cu ? c->waves_per_cu : 24) / 4;
@@ -337,18 +337,13 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
             const int64_t rpc_c = (c->g.n0 + nc - 1) / nc;
             const int64_t real = (c->g.n0 + rpc_c - 1) / rpc_c;
             const double ratio = (double)(real * nbx) / capacity;
-            double cost;
-            if (W >= 3) {
-                // VALU-bound pipelines (float): the busiest CU decides.  It runs ceil(blocks / CUs) blocks: whole
-                // rounds of W co-resident blocks, then a remainder round at lower occupancy (measured: 24 chunks
-                // = one full round beat 32 chunks by 11 % and 16 chunks by 6 % on the 4000 x 8000 x 3 image)
-                const int64_t per_cu = (real * nbx + c->num_cu - 1) / c->num_cu;
-                const int64_t full = per_cu / W, rem = per_cu - full * W;
-                cost = (double)(rpc_c + 2 * K + 2) * ((double)full * W * cpi[W] + (double)rem * cpi[rem]);
-            } else {
-                const double rounds = ratio <= 1.0 ? 1.0 : (ratio < 1.5 ? 2.0 : ratio);
-                cost = (double)(rpc_c + 2 * K + 2) * rounds;
-            }
+            // The busiest CU decides.  It runs ceil(blocks / CUs) blocks: whole rounds of W co-resident blocks, then a
+            // remainder round at lower occupancy (measured on 4000 x 8000 x 3 float: 24 chunks = one full round beat
+            // 32 chunks by 11 % and 16 chunks by 6 %; the same model picks within 1 % of the best count for float64,
+            // where the earlier "rounds x rows" model was 5-6 % off)
+            const int64_t per_cu = (real * nbx + c->num_cu - 1) / c->num_cu;
+            const int64_t full = per_cu / W, rem = per_cu - full * W;
+            const double cost = (double)(rpc_c + 2 * K + 2) * ((double)full * W * cpi[W] + (double)rem * cpi[rem]);
             if (cost < best * 0.999) { best = cost; nchunks = real; }
             if (ratio > 4.5) break;
         }
