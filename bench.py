@@ -11,11 +11,16 @@ A STEP is one pass of the hot path: ``--iters`` (100) outer iterations of
 off) over the device-resident image.  Steps continue the same iteration
 sequence (no re-upload inside the timed region).
 
-N > 1: weak scaling.  Every rank owns a 4000-row slab of ONE image of 4000*N
-rows (N = 4: the 16000 x 8000 x 3 image of configs[4]) and exchanges halo rows
-with its two neighbours every ``--halo-iters`` iterations (default 20) over RCCL
-(darsia_amd/parallel.py).  ``--scaling strong`` splits the 4000-row image
-instead.
+N > 1: BASELINE.json configs[4] -- ONE 8000 x 16000 x 3 image (rows x columns x
+channels; "16000x8000x3") cut into N row slabs, strong scaling.  Every rank
+owns 8000 / N rows and exchanges halo rows with its two slab neighbours every
+``--halo-iters`` iterations (default 20) by grouped RCCL send/recv issued from
+inside libdarsia_hip.so on a comm stream, overlapped with the interior rows
+(include/darsia_hip.h: dxh_tvd_run_slab).  ``--scaling weak`` gives every rank
+a 4000-row slab of a (4000 N) x 8000 x 3 image instead.  No PyTorch in this
+process: torch.distributed.run is only the launcher that sets RANK / LOCAL_RANK
+/ WORLD_SIZE / MASTER_PORT; the barrier and the max-over-ranks of the timing
+are RCCL all-reduces through the C ABI.
 
 Rank 0 prints ONE JSON line.  ``roofline`` is for the fused sweep kernel
 (k_fused): algorithmic bytes per launch / mean launch duration from HIP events
@@ -48,13 +53,15 @@ def parse():
     p.add_argument("--steps", type=int, default=5)
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--iters", type=int, default=100, help="TV iterations per step")
-    p.add_argument("--height", type=int, default=4000)
-    p.add_argument("--width", type=int, default=8000)
+    p.add_argument("--height", type=int, default=None, help="rows (default: 4000 at N = 1 and weak scaling, 8000 for "
+                                                            "the strong-scaling image of configs[4])")
+    p.add_argument("--width", type=int, default=None, help="columns (default 8000; 16000 for configs[4])")
     p.add_argument("--channels", type=int, default=3)
     p.add_argument("--halo-iters", type=int, default=20,
                    help="iterations between halo exchanges (N > 1); 20 halo rows per side cost 1 %% redundant work on a "
                         "4000-row slab and leave 5 exchanges per 100-iteration step")
-    p.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    p.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                   help="N > 1: strong (default, configs[4]) or weak")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample", default="4000x8000", help="HxW of the CPU baseline sample")
     return p.parse_args()
@@ -103,23 +110,22 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
         a.gpus = world
 
+    # DXH_BENCH_REHEARSAL=1: rehearse the N-rank path on a box with fewer GPUs than ranks (ranks round-robin over the
+    # visible devices, halo rows staged through the host and TCP sockets).  Never used by the driver.
     rehearsal = os.environ.get("DXH_BENCH_REHEARSAL", "")
-    if world > 1:
-        # torch's bundled HIP runtime must initialise before libdarsia_hip.so pulls in the system one
-        import torch
-
-        if rehearsal:
-            local_rank = local_rank % max(1, torch.cuda.device_count())
-        torch.cuda.set_device(local_rank)
-        torch.zeros(1, device="cuda")
 
     from darsia_amd import _lib
     from darsia_amd.synthetic import synthetic_image
 
     _lib.require_gpu()  # no CPU fallback: fail loudly
     C = a.channels
-    H, W = a.height, a.width
     mu = 0.1
+    if a.scaling is None:
+        a.scaling = "strong" if world > 1 else "weak"
+    strong_c5 = world > 1 and a.scaling == "strong"
+    H = a.height if a.height is not None else (8000 if strong_c5 else 4000)
+    W = a.width if a.width is not None else (16000 if strong_c5 else 8000)
+    comm_info = None
 
     if world == 1:
         from darsia_amd.restoration.split_bregman_tvd import DeviceTVD
@@ -142,45 +148,35 @@ def main():
         total_rows, rows_per_rank = H, H
         st.close()
     else:
-        import torch
-        import torch.distributed as dist
+        from darsia_amd.parallel import SlabTVD, init_from_env, make_plan
 
-        from darsia_amd.parallel import SlabTVD, make_plan
-
-        # DXH_BENCH_REHEARSAL=gloo: rehearse the N-rank path on a box with fewer GPUs than ranks (all ranks on
-        # the visible devices round-robin, halo exchange staged through the host).  Never used by the driver.
-        if rehearsal:
-            dist.init_process_group(rehearsal)
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        base_port = int(os.environ.get("MASTER_PORT", "29500")) + 17 if rehearsal else None
+        comm, rank, world, device = init_from_env(rehearsal_base_port=base_port)
         total_rows = H * world if a.scaling == "weak" else H
         plan = make_plan(total_rows, world, rank, a.halo_iters)
         slab = synthetic_image(plan.rows, W, C, row0=plan.slab0)
-        s = SlabTVD(plan, slab, mu=mu, dim=2, halo_iters=a.halo_iters, device=local_rank)
+        s = SlabTVD(plan, slab, mu=mu, dim=2, halo_iters=a.halo_iters, comm=comm)
         rows_per_rank = plan.own1 - plan.own0
 
         def one_step():
-            # a step ends with an exchange so that the next step starts from valid halos
-            s.run(a.iters)
-            s.exchange()
+            # enqueue only; the halos the next step starts from are refreshed behind this step's last launch
+            s.run(a.iters, more_to_come=True, asynchronous=True)
 
         for _ in range(a.warmup):
             one_step()
         s.synchronize()
-        torch.cuda.synchronize()
-        dist.barrier()
+        comm.barrier()
         t0 = time.perf_counter()
         for _ in range(a.steps):
             one_step()
         s.synchronize()
-        torch.cuda.synchronize()
-        dist.barrier()
+        comm.barrier()
         elapsed = time.perf_counter() - t0
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = comm.allreduce([elapsed], "max")[0]
         kernel_ms, launches = None, None
+        comm_info = comm.info()
         s.close()
+        comm.close()
 
     if rank == 0:
         pix_iters = float(total_rows) * W * a.iters * a.steps
@@ -197,18 +193,24 @@ def main():
             "scaling": a.scaling,
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic" if not os.environ.get("DXH_BENCH_REHEARSAL") else "synthetic (REHEARSAL: ranks share GPUs, "
-                    "host-staged exchange; not a valid multi-GPU number)",
+            "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: ranks share GPUs, host-staged exchange; "
+                    "not a valid multi-GPU number)",
             "config": {
-                "workload": f"anisotropic split-Bregman TVD, {total_rows}x{W}x{C} float32 (H x W x C), "
+                "workload": ("BASELINE configs[4]: " if (total_rows, W, C) == (8000, 16000, 3) else
+                             "BASELINE configs[1]: " if (total_rows, W, C) == (4000, 8000, 3) else "") +
+                            f"anisotropic split-Bregman TVD, {total_rows}x{W}x{C} float32 (H x W x C), "
                             f"{a.iters} iterations per step, mu=0.1 omega=1 ell=2mu Jacobi(maxiter=1) eps=off, "
                             "channel-coupled as in the reference",
                 "iters_per_step": a.iters,
                 "rows_per_gpu": rows_per_rank,
                 "parallelism": "single GPU" if world == 1 else f"row slabs x{world}, halo exchange every "
-                               f"{a.halo_iters} iterations over RCCL send/recv",
+                               f"{a.halo_iters} iterations: grouped RCCL send/recv from libdarsia_hip.so, overlapped "
+                               "with the interior rows",
             },
         }
+        if comm_info:
+            out["comm"] = {"transport": comm_info["kind"], "exchanges": comm_info["exchanges"],
+                           "bytes_sent_rank0": comm_info["bytes_sent"]}
         if world == 1:
             elems = float(H) * W * C
             ms_launch = kernel_ms / launches
@@ -246,10 +248,6 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(C, a.cpu_sample)
         print(json.dumps(out), flush=True)
 
-    if world > 1:
-        import torch.distributed as dist
-
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

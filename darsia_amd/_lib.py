@@ -18,6 +18,8 @@ LIB_PATH = os.environ.get("DARSIA_HIP_LIB") or os.path.join(_HERE, "libdarsia_hi
 DXH_F32, DXH_F64 = 0, 1
 NSUM_ALL_AXES, NSUM_SPATIAL = 0, 1
 FLAG_ISOTROPIC, FLAG_NO_FUSED, FLAG_NO_DPP, FLAG_ASYNC, FLAG_EXPLICIT = 1, 2, 4, 8, 16
+FLAG_NO_OVERLAP, FLAG_CONTINUE = 32, 64
+COMM_ID_BYTES = 128
 SOLVER_JACOBI, SOLVER_MG, SOLVER_CG = 0, 1, 2
 
 # every symbol include/darsia_hip.h declares (tests check that the library exports them all)
@@ -30,7 +32,14 @@ EXPORTS = (
     "dxh_solver_create", "dxh_solver_destroy", "dxh_solver_set_params", "dxh_solver_solve", "dxh_solver_get_params",
     "dxh_tvd_set_solver", "dxh_tv_bregman_gs", "dxh_map_coordinates", "dxh_resize", "dxh_div3_probe",
     "dxh_tvd_energy", "dxh_tvd_adapt_ell", "dxh_tvd_set_base", "dxh_tvd_set_cleaning_filter", "dxh_tvd_upload_signal", "dxh_tvd_download_model",
+    "dxh_comm_unique_id", "dxh_comm_create_rccl", "dxh_comm_create_host", "dxh_comm_destroy", "dxh_comm_allreduce",
+    "dxh_comm_barrier", "dxh_comm_info", "dxh_tvd_attach_comm", "dxh_tvd_exchange", "dxh_tvd_run_slab",
 )
+
+# host-staged transport callbacks (include/darsia_hip.h: dxh_comm_exchange_fn, dxh_comm_allreduce_fn)
+COMM_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                               C.POINTER(C.c_void_p), C.POINTER(C.c_size_t))
+COMM_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)
 
 
 class HipError(RuntimeError):
@@ -133,6 +142,16 @@ def _declare(lib):
     lib.dxh_tvd_set_cleaning_filter.argtypes = [vp, vp]
     lib.dxh_tvd_upload_signal.argtypes = [vp, vp, i, i, i, vp, i]
     lib.dxh_tvd_download_model.argtypes = [vp, vp, vp, i]
+    lib.dxh_comm_unique_id.argtypes = [vp]
+    lib.dxh_comm_create_rccl.argtypes = [C.POINTER(vp), i, vp, i, i]
+    lib.dxh_comm_create_host.argtypes = [C.POINTER(vp), i, i, i, COMM_EXCHANGE_FN, COMM_ALLREDUCE_FN, vp]
+    lib.dxh_comm_destroy.argtypes = [vp]
+    lib.dxh_comm_allreduce.argtypes = [vp, C.POINTER(dbl), i, i]
+    lib.dxh_comm_barrier.argtypes = [vp]
+    lib.dxh_comm_info.argtypes = [vp, C.POINTER(i), C.POINTER(i), C.POINTER(i), C.POINTER(i64), C.POINTER(i64)]
+    lib.dxh_tvd_attach_comm.argtypes = [vp, vp, i64, i64]
+    lib.dxh_tvd_exchange.argtypes = [vp]
+    lib.dxh_tvd_run_slab.argtypes = [vp, i, i, dbl, C.c_uint32, C.POINTER(TvdResult)]
     for name in EXPORTS:
         if name != "dxh_last_error":
             getattr(lib, name).restype = i

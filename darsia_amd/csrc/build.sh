@@ -35,6 +35,7 @@ run chambolle dxh_chambolle.hip
 run dense dxh_dense.hip
 run solvers dxh_solvers.hip
 run bregman_gs dxh_bregman_gs.hip
+run comm dxh_comm.hip
 fail=0
 for i in "${!pids[@]}"; do
     if ! wait "${pids[$i]}"; then

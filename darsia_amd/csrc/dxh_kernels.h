@@ -582,6 +582,10 @@ struct FusedArgs {
     int nstrips;       // strips per row
     int nchunks;
     int remap;         // XCD-aware block -> tile mapping (block_to_tile)
+    // A launch may cover a SUBSET of the row chunks (multi-GPU slabs: the chunks next to a slab interface run first, on
+    // their own stream, so that the halo exchange overlaps the interior chunks).  The grid holds chunk_n chunks; launch
+    // index i stands for chunk i (i < chunk_gap_at) or i + chunk_gap.  Whole launch: chunk_n = nchunks, gap 0.
+    int chunk_n, chunk_gap_at, chunk_gap;
     Coef<T> c;
     CoefPlanes<T> cp;
     // heterogeneous coefficients: when `derive` is set the kernel reads only the planes the caller gave (mu, omega,
@@ -619,6 +623,11 @@ __device__ __forceinline__ void block_to_tile(int bid, int nbx, int nchunks, int
     chunk = bid % nchunks;
     bx = bid / nchunks;
 }
+template <typename A>
+__device__ __forceinline__ void block_to_tile_sub(int bid, int nbx, const A& a, int& bx, int& chunk) {
+    block_to_tile(bid, nbx, a.chunk_n, bx, chunk);
+    if (chunk >= a.chunk_gap_at) chunk += a.chunk_gap;
+}
 
 template <typename T, int C, bool COUPLED, bool ISO, bool HET, bool DPP, bool ALIGN = true, bool NTS = true>
 __global__ void __launch_bounds__(256) k_fused(FusedArgs<T> a) {
@@ -630,10 +639,11 @@ __global__ void __launch_bounds__(256) k_fused(FusedArgs<T> a) {
     const int nbx = (a.nstrips + WPB - 1) / WPB;
     int bx, chunk;
     if (a.remap) {
-        block_to_tile((int)blockIdx.x, nbx, a.nchunks, bx, chunk);
+        block_to_tile_sub((int)blockIdx.x, nbx, a, bx, chunk);
     } else {
         bx = blockIdx.x % nbx;
         chunk = blockIdx.x / nbx;
+        if (chunk >= a.chunk_gap_at) chunk += a.chunk_gap;
     }
     const int strip = bx * WPB + wave;
     if (strip >= a.nstrips || chunk >= a.nchunks) return;  // wave-uniform
@@ -1595,7 +1605,7 @@ __global__ void __launch_bounds__(256, DXH_PAIR_LB) k_fused_pair(FusedArgs<T> a)
     const bool tail = ((wave ^ (int)blockIdx.x) & 1) != 0;
     const int nbx = (a.nstrips + PPB - 1) / PPB;
     int bx, chunk;
-    block_to_tile((int)blockIdx.x, nbx, a.nchunks, bx, chunk);
+    block_to_tile_sub((int)blockIdx.x, nbx, a, bx, chunk);
     if (chunk >= a.nchunks) return;  // block-uniform
     int strip = bx * PPB + pair;
     const bool active = strip < a.nstrips;
@@ -1623,7 +1633,7 @@ __global__ void __launch_bounds__(256, (pipe_waves<T, K, HET>())) k_fused_multi(
     constexpr int WPB = 4;
     const int nbx = (a.nstrips + WPB - 1) / WPB;
     int bx, chunk;
-    block_to_tile((int)blockIdx.x, nbx, a.nchunks, bx, chunk);
+    block_to_tile_sub((int)blockIdx.x, nbx, a, bx, chunk);
     const int strip = bx * WPB + wave;
     if (strip >= a.nstrips || chunk >= a.nchunks) return;  // wave-uniform
     const int64_t w0 = (int64_t)strip * SG::STRIDE - SG::LH * N;  // first element of the wave's window

@@ -14,6 +14,7 @@
 #include <type_traits>
 #include <vector>
 
+#include "dxh_comm.h"
 #include "dxh_kernels.h"
 #include "dxh_multi.h"
 #include "dxh_solvers.h"
@@ -90,7 +91,46 @@ struct Ctx {
     DeviceSolver* solver = nullptr;  // MG / CG in the place of the Jacobi sweeps (dxh_tvd_set_solver)
     int solver_kind = DXH_SOLVER_JACOBI;
     bool solver_params_set = false;
+
+    // ---- row slab of a distributed problem (dxh_tvd_attach_comm) ----
+    Comm* comm = nullptr;
+    int64_t halo_top = 0, halo_bot = 0;  // the plan's halo rows (the same on every rank)
+    int64_t top = 0, bot = 0;            // halo rows this slab really has above / below its owned rows
+    int64_t halo_valid = 0;              // rows of the top-side halo budget still valid (a sweep consumes one)
+    hipStream_t s_bnd = nullptr;         // stream of the interface-chunk launches
+    hipEvent_t eM = nullptr, eB = nullptr, eC = nullptr;  // main-stream marker, interface launch done, exchange done
+    bool pendB = false, pendC = false;   // an interface launch / an exchange the main stream has not waited for yet
+    int part = 0;                        // chunk subset of the next fused launch: 0 all, 1 interface chunks, 2 interior
+    hipStream_t part_stream = nullptr;   // its stream (nullptr: the context stream)
+    double global_sq_img = -1.0;         // ||img||^2 over all ranks' owned rows
+    int64_t split_launches = 0;          // statistics: launches that ran as interface + interior parts
 };
+
+// Which row chunks a fused launch covers (Ctx::part).  Interface part: the chunks holding the rows the neighbours need
+// (top .. top + halo_bot, and the last halo_top owned rows) together with the halo rows themselves; the interior part
+// must not read a halo row (K + 2 rows of reach), because the exchange may be writing those while it runs.
+struct ChunkSel { int n, gap_at, gap; };
+static ChunkSel select_chunks(const Ctx* c, int64_t nchunks, int64_t rpc, int K) {
+    ChunkSel all{(int)nchunks, INT32_MAX, 0};
+    if (c->part == 0) return all;
+    int64_t cbt = 0, cbb = 0;
+    if (c->top > 0) cbt = (std::max(c->top + c->halo_bot, c->top + K + 2) + rpc - 1) / rpc;
+    if (c->bot > 0) {
+        const int64_t o1 = c->g.n0 - c->bot;
+        const int64_t lim = std::min(o1 - c->halo_top, o1 - (K + 2));
+        cbb = nchunks - std::max<int64_t>(0, lim / rpc);
+    }
+    if (cbt + cbb >= nchunks) return c->part == 1 ? all : ChunkSel{0, INT32_MAX, 0};  // no interior to speak of
+    if (c->part == 1) return ChunkSel{(int)(cbt + cbb), (int)cbt, (int)(nchunks - cbt - cbb)};
+    return ChunkSel{(int)(nchunks - cbt - cbb), 0, (int)cbt};
+}
+
+// the main stream waits (on the device) for interface launches and exchanges still in flight
+static int slab_join(Ctx* c) {
+    if (c->pendB) { DXH_HIP(hipStreamWaitEvent(c->stream, c->eB, 0)); c->pendB = false; }
+    if (c->pendC) { DXH_HIP(hipStreamWaitEvent(c->stream, c->eC, 0)); c->pendC = false; }
+    return DXH_OK;
+}
 
 static int alloc_plane(Ctx* c, void** p) {
     if (*p) return DXH_OK;
@@ -209,9 +249,9 @@ static CoefIn<T> make_coefin(const Ctx* c) {
     return in;
 }
 
-static int set_device(const Ctx* c) {
+static int set_device(Ctx* c) {
     DXH_HIP(hipSetDevice(c->desc.device));
-    return DXH_OK;
+    return slab_join(c);  // every entry point but dxh_tvd_run_slab orders itself behind slab work in flight
 }
 
 // dense host array (n0, L) <-> pitched device plane
@@ -269,14 +309,19 @@ static void launch_fused_v(Ctx* c, int in, int out) {
     a.rows_per_chunk = rpc;
     a.nchunks = (int)nchunks;
     a.remap = remap ? 1 : 0;
+    const ChunkSel sel = select_chunks(c, nchunks, rpc, 1);
+    if (sel.n == 0) return;
+    a.chunk_n = sel.n;
+    a.chunk_gap_at = sel.gap_at;
+    a.chunk_gap = sel.gap;
     a.inc_partial = nullptr;
     a.nwaves_total = 0;
     a.c = make_coef<T>(c);
     a.cp = make_planes<T>(c);
     a.ci = make_coefin<T>(c);
     a.derive = (HET && c->in_valid && !(c->tune & 32)) ? 1 : 0;  // DXH_FUSED_TUNE bit 32: read the four derived planes
-    hipLaunchKernelGGL((k_fused<T, C, COUPLED, ISO, HET, DPP, ALIGN, NTS>), dim3((unsigned)(nbx * nchunks)), dim3(256), 0,
-                       c->stream, a);
+    hipLaunchKernelGGL((k_fused<T, C, COUPLED, ISO, HET, DPP, ALIGN, NTS>), dim3((unsigned)(nbx * sel.n)), dim3(256), 0,
+                       c->part_stream ? c->part_stream : c->stream, a);
 }
 
 template <typename T, int C, bool COUPLED, bool ISO, bool HET, bool DPP>
@@ -355,6 +400,11 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
     a.rows_per_chunk = rpc;
     a.nchunks = (int)nchunks;
     a.remap = 1;
+    const ChunkSel sel = select_chunks(c, nchunks, rpc, K);
+    if (sel.n == 0) return;
+    a.chunk_n = sel.n;
+    a.chunk_gap_at = sel.gap_at;
+    a.chunk_gap = sel.gap;
     a.inc_partial = nullptr;
     a.nwaves_total = (int)(nchunks * a.nstrips);
     if (want_inc) {
@@ -374,7 +424,8 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
     a.ci = make_coefin<T>(c);
     a.derive = c->het ? 1 : 0;  // array coefficients (multi_supported: only with the given planes at hand, K = kHetFuseK)
     // the kernels are instantiated in dxh_multi.hip (one object per element type and K, built in parallel)
-    launch_multi_kernel<T, K>(C, COUPLED, ISO, want_inc, pair, a, (unsigned)(nbx * nchunks), c->stream);
+    launch_multi_kernel<T, K>(C, COUPLED, ISO, want_inc, pair, a, (unsigned)(nbx * sel.n),
+                              c->part_stream ? c->part_stream : c->stream);
 }
 
 // channel counts the multi-iteration kernel is instantiated for
@@ -806,6 +857,181 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
     return DXH_OK;
 }
 
+// ---- the distributed sweep ----------------------------------------------------------------------------------------
+static int64_t slab_own0(const Ctx* c) { return c->top; }
+static int64_t slab_own1(const Ctx* c) { return c->g.n0 - c->bot; }
+
+// Enqueue one halo exchange on the comm stream, to start when `after` has happened: rows are contiguous in every state
+// plane, so the row blocks go out of / come into the planes directly.  What I send up is what the upper slab keeps as
+// its bottom halo (my first halo_bot owned rows); what I send down is the lower slab's top halo (my last halo_top owned
+// rows).
+static int start_exchange(Ctx* c, hipEvent_t after) {
+    Comm* cm = c->comm;
+    if (c->from_db) { set_error("halo exchange before the first iteration of a warm start is not supported"); return DXH_ESTATE; }
+    DXH_HIP(hipStreamWaitEvent(cm->stream, after, 0));
+    const size_t row_bytes = (size_t)c->g.pitch * c->esz;
+    void* fields[4] = {c->u[c->cur], c->q[0][c->cur], c->q[1][c->cur], c->q[2][c->cur]};
+    const int nf = 1 + c->desc.dim;
+    P2POp ops[16];
+    int n = 0;
+    const int64_t o0 = slab_own0(c), o1 = slab_own1(c);
+    auto rows = [&](int f, int64_t r0) { return static_cast<char*>(fields[f]) + (size_t)r0 * row_bytes; };
+    if (c->top > 0) {
+        for (int f = 0; f < nf; ++f) ops[n++] = P2POp{cm->rank - 1, rows(f, o0), (size_t)c->halo_bot * row_bytes, 1};
+        for (int f = 0; f < nf; ++f) ops[n++] = P2POp{cm->rank - 1, rows(f, 0), (size_t)c->top * row_bytes, 0};
+    }
+    if (c->bot > 0) {
+        for (int f = 0; f < nf; ++f) ops[n++] = P2POp{cm->rank + 1, rows(f, o1 - c->halo_top), (size_t)c->halo_top * row_bytes, 1};
+        for (int f = 0; f < nf; ++f) ops[n++] = P2POp{cm->rank + 1, rows(f, o1), (size_t)c->bot * row_bytes, 0};
+    }
+    int rc = comm_exchange(cm, ops, n);
+    if (rc) return rc;
+    DXH_HIP(hipEventRecord(c->eC, cm->stream));
+    c->pendC = true;
+    c->halo_valid = c->halo_top;
+    return DXH_OK;
+}
+
+// exchange behind everything in flight (no overlap)
+static int exchange_now(Ctx* c) {
+    int rc = slab_join(c);
+    if (rc) return rc;
+    DXH_HIP(hipEventRecord(c->eM, c->stream));
+    return start_exchange(c, c->eM);
+}
+
+template <typename T>
+static void launch_any(Ctx* c, int in, int out, bool iso, bool dpp, int K) {
+    if (K >= 2) launch_fused_multi<T>(c, in, out, iso, K);
+    else launch_fused<T>(c, in, out, iso, dpp);
+}
+
+template <typename T>
+static int run_slab_t(Ctx* c, int n_iter, int m, double eps, uint32_t flags, dxh_tvd_result* res) {
+    Comm* cm = c->comm;
+    const bool dist = cm && cm->world > 1;
+    const bool iso = flags & DXH_FLAG_ISOTROPIC;
+    const bool use_eps = eps >= 0.0 && !std::isnan(eps);
+    const bool dpp = !(flags & DXH_FLAG_NO_DPP);
+    const bool fused_ok = fused_supported(c) && m == 1 && !(flags & DXH_FLAG_NO_FUSED) && !(flags & DXH_FLAG_EXPLICIT) &&
+                          !c->solver && !c->explicit_db && !c->from_db;
+    const bool overlap = dist && fused_ok && !(flags & DXH_FLAG_NO_OVERLAP);
+    const bool async = (flags & DXH_FLAG_ASYNC) && !use_eps;
+    if (dist) DXH_REQUIRE(c->halo_top >= m, "halos of %lld rows cannot carry an iteration of %d Jacobi sweeps",
+                          (long long)c->halo_top, m);
+    if (dist && c->from_db) { set_error("a warm start with explicit split variables is not supported on row slabs"); return DXH_ESTATE; }
+    int rc;
+    double nrm_img = 0.0;
+    if (use_eps) {
+        if (c->global_sq_img < 0.0) {
+            double v = 0.0;
+            if ((rc = slab_join(c))) return rc;
+            if (dist) {
+                DXH_REQUIRE(!std::isnan(c->omega_s) && c->omega_s != 0.0, "the global eps test needs a scalar, non-zero omega");
+                rc = sq_diff<T>(c, c->of, nullptr, slab_own0(c), slab_own1(c) - slab_own0(c), &v, 1);
+                if (rc) return rc;
+                v /= c->omega_s * c->omega_s;
+                if ((rc = comm_allreduce(cm, &v, 1, 0))) return rc;
+            } else {
+                v = c->sq_img;
+            }
+            c->global_sq_img = v;
+        }
+        nrm_img = std::sqrt(c->global_sq_img);
+    }
+    if (fused_ok) { c->last_iso_prev = c->last_iso; c->last_iso = iso; }
+    if (!async) {
+        if ((rc = slab_join(c))) return rc;
+        DXH_HIP(hipEventRecord(c->ev0, c->stream));
+    }
+    int64_t launches = 0;
+    int done = 0, converged = 0;
+    double rel = std::numeric_limits<double>::quiet_NaN();
+    while (done < n_iter) {
+        if (dist && c->halo_valid < m && !c->pendC) {
+            if ((rc = exchange_now(c))) return rc;  // halos used up by an earlier call: nothing to hide this one behind
+        }
+        const int left = n_iter - done;
+        const int cap = dist ? (int)std::min<int64_t>(left, c->halo_valid / m) : left;
+        int K;
+        if (fused_ok) {
+            K = use_eps ? 1 : std::min(pick_k(c, left), cap);
+            if (K >= 2 && !(dpp && multi_supported(c))) K = 1;
+            if (K >= 2 && c->het && K != kHetFuseK) K = 1;
+            const int in = c->cur, out = c->cur ^ 1;
+            const bool xchg_after = dist && (c->halo_valid - (int64_t)K * m < m) &&
+                                    (done + K < n_iter || (flags & DXH_FLAG_CONTINUE)) && !use_eps;
+            if (overlap && (xchg_after || c->pendC)) {
+                // interface chunks on their own stream: behind everything the main stream has been given so far and behind
+                // the exchange in flight (whose rows they read); interior chunks on the main stream, behind the previous
+                // interface launch only
+                DXH_HIP(hipEventRecord(c->eM, c->stream));
+                DXH_HIP(hipStreamWaitEvent(c->s_bnd, c->eM, 0));
+                if (c->pendC) { DXH_HIP(hipStreamWaitEvent(c->s_bnd, c->eC, 0)); c->pendC = false; }
+                if (c->pendB) DXH_HIP(hipStreamWaitEvent(c->stream, c->eB, 0));
+                c->part = 1;
+                c->part_stream = c->s_bnd;
+                launch_any<T>(c, in, out, iso, dpp, K);
+                DXH_HIP(hipEventRecord(c->eB, c->s_bnd));
+                c->pendB = true;
+                c->part = 2;
+                c->part_stream = nullptr;
+                launch_any<T>(c, in, out, iso, dpp, K);
+                c->part = 0;
+                ++c->split_launches;
+            } else {
+                if ((rc = slab_join(c))) return rc;
+                launch_any<T>(c, in, out, iso, dpp, K);
+            }
+            DXH_HIP(hipGetLastError());
+            ++launches;
+            c->cur = out;
+            c->halo_valid -= (int64_t)K * m;
+            if (xchg_after) {
+                if (overlap) rc = start_exchange(c, c->eB);
+                else rc = exchange_now(c);
+                if (rc) return rc;
+            }
+        } else {
+            // three-kernel / solver / multi-sweep paths: whole-slab launches, exchange in between
+            if ((rc = slab_join(c))) return rc;
+            K = use_eps ? 1 : cap;
+            dxh_tvd_result r{};
+            rc = run_t<T>(c, K, m, -1.0, -1.0, 0.0, (flags & (DXH_FLAG_ISOTROPIC | DXH_FLAG_NO_FUSED | DXH_FLAG_NO_DPP | DXH_FLAG_EXPLICIT)) | DXH_FLAG_ASYNC, &r);
+            if (rc) return rc;
+            launches += r.launches;
+            c->halo_valid -= (int64_t)K * m;
+        }
+        done += K;
+        if (use_eps) {
+            double inc = 0.0;
+            if ((rc = slab_join(c))) return rc;
+            rc = sq_diff<T>(c, c->u[c->cur], c->u[c->cur ^ 1], slab_own0(c), slab_own1(c) - slab_own0(c), &inc, 0);
+            if (rc) return rc;
+            if (dist && (rc = comm_allreduce(cm, &inc, 1, 0))) return rc;
+            rel = std::sqrt(inc) / nrm_img;
+            if (rel < eps) { converged = 1; break; }
+        }
+    }
+    float ms = std::numeric_limits<float>::quiet_NaN();
+    if (!(flags & DXH_FLAG_CONTINUE) || !async) {
+        if ((rc = slab_join(c))) return rc;
+    }
+    if (!async) {
+        DXH_HIP(hipEventRecord(c->ev1, c->stream));
+        DXH_HIP(hipStreamSynchronize(c->stream));
+        DXH_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    }
+    if (res) {
+        res->iters_done = done;
+        res->converged = converged;
+        res->rel_increment = rel;
+        res->loop_ms = ms;
+        res->launches = launches;
+    }
+    return DXH_OK;
+}
+
 template <typename T>
 static int set_coeffs_t(Ctx* c, double mu, const void* mu_arr, double omega, const void* omega_arr, int has_ell,
                         double ell, const void* ell_arr, double h, bool want_kq) {
@@ -985,7 +1211,12 @@ int dxh_tvd_destroy(dxh_tvd_t h) {
     Ctx* c = reinterpret_cast<Ctx*>(h);
     if (!c) return DXH_OK;
     (void)hipSetDevice(c->desc.device);
+    if (c->s_bnd) (void)hipStreamSynchronize(c->s_bnd);
+    if (c->comm && c->comm->stream) (void)hipStreamSynchronize(c->comm->stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->s_bnd) (void)hipStreamDestroy(c->s_bnd);
+    for (hipEvent_t e : {c->eM, c->eB, c->eC})
+        if (e) (void)hipEventDestroy(e);
     delete c->solver;
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
     fr(c->of); fr(c->u[0]); fr(c->u[1]); fr(c->rs);
@@ -1102,6 +1333,8 @@ static int finish_upload(Ctx* c, const void* u0, const void* d0, const void* b0)
     }
     DXH_HIP(hipStreamSynchronize(c->stream));
     c->uploaded = true;
+    c->halo_valid = c->halo_top;  // a slab is uploaded with valid halos
+    c->global_sq_img = -1.0;
     return DXH_OK;
 }
 
@@ -1329,6 +1562,66 @@ int dxh_tvd_unpack_rows(dxh_tvd_t h, int64_t row0, int64_t nrows, const void* sr
     return halo_copy(c, row0, nrows, const_cast<void*>(src), false);
 }
 
+int dxh_tvd_attach_comm(dxh_tvd_t h, dxh_comm_t comm, int64_t halo_top_rows, int64_t halo_bottom_rows) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    Comm* cm = reinterpret_cast<Comm*>(comm);
+    DXH_REQUIRE(c && cm, "null argument");
+    DXH_REQUIRE(cm->device == c->desc.device, "communicator lives on device %d, the context on %d", cm->device, c->desc.device);
+    DXH_REQUIRE(halo_top_rows >= 1 && halo_bottom_rows >= halo_top_rows + 1,
+                "halo rows (%lld above, %lld below): need k >= 1 above and at least k + 1 below",
+                (long long)halo_top_rows, (long long)halo_bottom_rows);
+    DXH_REQUIRE((cm->rank == 0) == (c->desc.top_is_boundary != 0), "rank %d of %d: top_is_boundary = %d does not fit",
+                cm->rank, cm->world, c->desc.top_is_boundary);
+    DXH_REQUIRE((cm->rank == cm->world - 1) == (c->desc.bottom_is_boundary != 0),
+                "rank %d of %d: bottom_is_boundary = %d does not fit", cm->rank, cm->world, c->desc.bottom_is_boundary);
+    const int64_t top = c->desc.top_is_boundary ? 0 : halo_top_rows;
+    const int64_t bot = c->desc.bottom_is_boundary ? 0 : halo_bottom_rows;
+    // a slab must own the rows both neighbours ask for
+    DXH_REQUIRE(c->g.n0 - top - bot >= halo_bottom_rows || cm->world == 1,
+                "a slab of %lld owned rows is smaller than the halo (%lld rows): use fewer ranks or shorter halos",
+                (long long)(c->g.n0 - top - bot), (long long)halo_bottom_rows);
+    int rc = set_device(c);
+    if (rc) return rc;
+    if (!c->s_bnd) {
+        int lo = 0, hi = 0;
+        DXH_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        DXH_HIP(hipStreamCreateWithPriority(&c->s_bnd, hipStreamNonBlocking, hi));
+        DXH_HIP(hipEventCreateWithFlags(&c->eM, hipEventDisableTiming));
+        DXH_HIP(hipEventCreateWithFlags(&c->eB, hipEventDisableTiming));
+        DXH_HIP(hipEventCreateWithFlags(&c->eC, hipEventDisableTiming));
+    }
+    c->comm = cm;
+    c->halo_top = halo_top_rows;
+    c->halo_bot = halo_bottom_rows;
+    c->top = top;
+    c->bot = bot;
+    c->halo_valid = halo_top_rows;  // an uploaded slab carries valid halos
+    c->global_sq_img = -1.0;
+    return DXH_OK;
+}
+
+int dxh_tvd_exchange(dxh_tvd_t h) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    DXH_REQUIRE(c, "null context");
+    if (!c->comm) { set_error("dxh_tvd_attach_comm must be called first"); return DXH_ESTATE; }
+    if (!c->uploaded) { set_error("nothing uploaded"); return DXH_ESTATE; }
+    int rc = set_device(c);
+    if (rc) return rc;
+    if (c->comm->world == 1) return DXH_OK;
+    return exchange_now(c);
+}
+
+int dxh_tvd_run_slab(dxh_tvd_t h, int n_iter, int jacobi_maxiter, double eps, uint32_t flags, dxh_tvd_result* result) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    DXH_REQUIRE(c, "null context");
+    if (!c->uploaded) { set_error("dxh_tvd_upload must be called before dxh_tvd_run_slab"); return DXH_ESTATE; }
+    DXH_REQUIRE(n_iter >= 0, "n_iter must be >= 0");
+    DXH_REQUIRE(jacobi_maxiter >= 1, "jacobi_maxiter must be >= 1");
+    DXH_HIP(hipSetDevice(c->desc.device));  // no join here: an exchange left in flight by DXH_FLAG_CONTINUE stays overlapped
+    return c->desc.dtype == DXH_F32 ? run_slab_t<float>(c, n_iter, jacobi_maxiter, eps, flags, result)
+                                    : run_slab_t<double>(c, n_iter, jacobi_maxiter, eps, flags, result);
+}
+
 int dxh_tvd_partial_norms(dxh_tvd_t h, int64_t row0, int64_t nrows, double* sq_inc, double* sq_img) {
     Ctx* c = reinterpret_cast<Ctx*>(h);
     DXH_REQUIRE(c, "null context");
@@ -1417,6 +1710,8 @@ int dxh_tvd_adapt_ell(dxh_tvd_t h) {
 int dxh_tvd_sync(dxh_tvd_t h) {
     Ctx* c = reinterpret_cast<Ctx*>(h);
     DXH_REQUIRE(c, "null context");
+    int rc = set_device(c);
+    if (rc) return rc;
     DXH_HIP(hipStreamSynchronize(c->stream));
     return DXH_OK;
 }

@@ -1,31 +1,49 @@
-"""Row-slab decomposition of one TV problem over several GPUs (one process per
-GPU, ``torch.distributed``; backend ``nccl`` = RCCL over xGMI on MI355X).
+"""Row-slab decomposition of one TV problem over several GPUs: one process per
+GPU, halo rows exchanged between slab neighbours by ``libdarsia_hip`` itself
+(grouped RCCL send/recv over xGMI on a comm stream, overlapped with the interior
+rows -- ``dxh_tvd_run_slab`` in ``include/darsia_hip.h``).  No PyTorch anywhere:
+Python only bootstraps the ranks (``RANK`` / ``WORLD_SIZE`` / ``LOCAL_RANK`` from
+the launcher's environment, the 128-byte RCCL id through a file).
 
 The reference is single-process, so nothing here mirrors
 reference code; what must hold is that the N-rank result equals the 1-rank
-result BIT FOR BIT (same arithmetic per pixel), which ``tests/test_parallel_cpu.py``
-checks with world_size 2 on gloo.
+result BIT FOR BIT (same arithmetic per pixel) -- ``tests/test_parallel_cpu.py``
+(CPU, oracle engine) and ``tests/test_parallel_gpu.py`` (HIP engine) check it.
 
 Decomposition.  The image is cut along axis 0 into contiguous slabs.  One outer
-iteration with ``m`` Jacobi sweeps reads one row above and below per sweep and
-the split variables one row above; the fused kernel additionally needs the new
-iterate one row below.  A slab edge that is not the image boundary therefore
-loses ``m`` valid rows per iteration at the top and ``m`` (+1 once) at the
-bottom.  With halos of ``k*m`` rows above and ``k*m + 1`` below, ``k`` iterations
-can run between two exchanges; the halos are recomputed redundantly, which costs
-(2km+1)/rows extra work and turns 3 small messages per iteration into one
-larger one every ``k`` iterations (xGMI is point-to-point: each slab talks to its
-two neighbours only, no ring, no collective on the data path).
+iteration with ``m`` Jacobi sweeps reads one row above and below per sweep
+(utils/linear_solvers/jacobi.py:43-54) and the split variables one row above
+(restoration/split_bregman_tvd.py:84-89); the fused kernel additionally needs
+the new iterate one row below (:144).  A slab edge that is not the image
+boundary therefore loses ``m`` valid rows per iteration at the top and ``m``
+(+1 once) at the bottom.  With halos of ``k*m`` rows above and ``k*m + 1``
+below, ``k`` iterations run between two exchanges; the halos are recomputed
+redundantly, which costs (2km+1)/rows extra work and turns 3 small messages per
+iteration into one larger one every ``k`` iterations (xGMI is point to point:
+each slab talks to its two neighbours only, no ring, no collective on the data
+path).
 
-A global ``eps`` stopping test needs the increment norm every iteration: then
-``k = 1`` and one 8-byte all-reduce per iteration is added, as in the reference's
-per-iteration test (split_bregman_tvd.py:161-175).
+A global ``eps`` stopping test needs the increment norm every iteration: one
+8-byte all-reduce per iteration is added, as in the reference's per-iteration
+test (split_bregman_tvd.py:161-175).
+
+Transports.  ``Comm.rccl`` is the product path.  ``Comm.host`` stages the halo
+rows through pinned host memory and hands them to a Python transport object
+(``SocketTransport`` here, a gloo one in the tests): for rehearsals and tests on
+boxes with fewer GPUs than ranks, which RCCL refuses.
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
+import os
+import socket
+import struct
+import tempfile
+import threading
+import time
 from dataclasses import dataclass
-from typing import Optional
+from typing import Optional, Sequence
 
 import numpy as np
 
@@ -65,58 +83,279 @@ class SlabPlan:
         return self.top, self.top + (self.own1 - self.own0)
 
 
+def make_plan(H: int, world: int, rank: int, halo_iters: int = 1, jacobi_maxiter: int = 1) -> SlabPlan:
+    km = halo_iters * jacobi_maxiter
+    return SlabPlan(H, world, rank, halo_top_rows=km, halo_bot_rows=km + 1)
+
+
+# ---- host transports (rehearsals, tests) ---------------------------------------------------------------------------
+class SocketTransport:
+    """Neighbour-to-neighbour TCP on localhost: rank r listens on ``base_port + r`` and dials rank r - 1, so every
+    slab interface is one bidirectional connection.  ``exchange`` moves all messages of one call together (sends from
+    helper threads); ``allreduce`` folds the values up the chain of ranks and passes the result back down."""
+
+    def __init__(self, rank: int, world: int, base_port: int, host: str = "127.0.0.1", timeout: float = 120.0):
+        self.rank, self.world = rank, world
+        self.conn = {}
+        listener = None
+        if rank < world - 1:
+            listener = socket.socket()
+            listener.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            listener.bind((host, base_port + rank))
+            listener.listen(1)
+        if rank > 0:
+            t0 = time.time()
+            while True:
+                try:
+                    s = socket.create_connection((host, base_port + rank - 1), timeout=timeout)
+                    break
+                except OSError:
+                    if time.time() - t0 > timeout:
+                        raise
+                    time.sleep(0.05)
+            s.settimeout(timeout)
+            s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            self.conn[rank - 1] = s
+        if listener is not None:
+            listener.settimeout(timeout)
+            s, _ = listener.accept()
+            s.settimeout(timeout)
+            s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            self.conn[rank + 1] = s
+            listener.close()
+
+    @staticmethod
+    def _recv_into(sock, view):
+        got = 0
+        while got < len(view):
+            n = sock.recv_into(view[got:])
+            if n == 0:
+                raise ConnectionError("peer closed the connection")
+            got += n
+
+    def exchange(self, ops):
+        """ops: list of (peer, is_send, buffer) with writable uint8 memoryviews / arrays."""
+        by_peer_send = {}
+        for peer, is_send, buf in ops:
+            if is_send:
+                by_peer_send.setdefault(peer, []).append(buf)
+        errors = []
+
+        def send_all(peer, bufs):
+            try:
+                for b in bufs:
+                    self.conn[peer].sendall(memoryview(b).cast("B"))
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+
+        threads = [threading.Thread(target=send_all, args=(p, b)) for p, b in by_peer_send.items()]
+        for t in threads:
+            t.start()
+        for peer, is_send, buf in ops:
+            if not is_send:
+                self._recv_into(self.conn[peer], memoryview(buf).cast("B"))
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+
+    def allreduce(self, vals: np.ndarray, op: int):
+        """In place over all ranks; op 0 = sum, 1 = max.  The fold order is fixed (rank 0 upwards), so every rank gets
+        the same bits."""
+        n = len(vals)
+        fmt = f"<{n}d"
+        acc = np.array(vals, dtype=np.float64)
+        if self.rank > 0:
+            raw = bytearray(8 * n)
+            self._recv_into(self.conn[self.rank - 1], memoryview(raw))
+            below = np.array(struct.unpack(fmt, raw))
+            acc = below + acc if op == 0 else np.maximum(below, acc)
+        if self.rank < self.world - 1:
+            self.conn[self.rank + 1].sendall(struct.pack(fmt, *acc))
+            raw = bytearray(8 * n)
+            self._recv_into(self.conn[self.rank + 1], memoryview(raw))
+            acc = np.array(struct.unpack(fmt, raw))
+        if self.rank > 0:
+            self.conn[self.rank - 1].sendall(struct.pack(fmt, *acc))
+        vals[:] = acc
+
+    def close(self):
+        for s in self.conn.values():
+            try:
+                s.close()
+            except OSError:
+                pass
+        self.conn = {}
+
+
+# ---- communicators (dxh_comm_t) ------------------------------------------------------------------------------------
+def _rendezvous_path() -> str:
+    explicit = os.environ.get("DXH_RENDEZVOUS_FILE")
+    if explicit:
+        return explicit
+    # ranks of one launch share the launcher as parent and the rendezvous port
+    tag = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}"
+    return os.path.join(tempfile.gettempdir(), f"dxh_rccl_{tag}.id")
+
+
+class Comm:
+    """A ``dxh_comm_t``: RCCL (``Comm.rccl``) or host-staged through a Python transport (``Comm.host``)."""
+
+    def __init__(self, handle, rank, world, device, keep=(), cleanup=None):
+        self.lib = _lib.load()
+        self._h = handle
+        self.rank, self.world, self.device = rank, world, device
+        self._keep = keep          # callback objects must outlive the communicator
+        self._cleanup = cleanup
+
+    @classmethod
+    def rccl(cls, rank: int, world: int, device: int, timeout: float = 300.0) -> "Comm":
+        """Rank 0 draws the RCCL unique id and publishes it through a file (atomic rename); the others poll for it."""
+        lib = _lib.load()
+        _lib.require_gpu()
+        path = _rendezvous_path()
+        buf = (C.c_char * _lib.COMM_ID_BYTES)()
+        if rank == 0:
+            _lib.check(lib.dxh_comm_unique_id(buf))
+            tmp = f"{path}.{os.getpid()}.tmp"
+            with open(tmp, "wb") as f:
+                f.write(bytes(buf))
+            os.replace(tmp, path)
+        else:
+            t0 = time.time()
+            while True:
+                try:
+                    with open(path, "rb") as f:
+                        raw = f.read()
+                    if len(raw) == _lib.COMM_ID_BYTES:
+                        break
+                except FileNotFoundError:
+                    pass
+                if time.time() - t0 > timeout:
+                    raise TimeoutError(f"rank {rank}: no RCCL id at {path} after {timeout:.0f} s (is rank 0 running?)")
+                time.sleep(0.02)
+            C.memmove(buf, raw, _lib.COMM_ID_BYTES)
+        h = C.c_void_p()
+        _lib.check(lib.dxh_comm_create_rccl(C.byref(h), device, buf, rank, world))
+
+        def cleanup():
+            if rank == 0:
+                try:
+                    os.unlink(path)
+                except OSError:
+                    pass
+        comm = cls(h, rank, world, device, cleanup=cleanup)
+        comm.barrier()   # every rank has read the id: rank 0 may remove the file when it is done
+        return comm
+
+    @classmethod
+    def host(cls, transport, device: int) -> "Comm":
+        """Host-staged communicator over ``transport`` (``rank``, ``world``, ``exchange(ops)``, ``allreduce(vals, op)``)."""
+        lib = _lib.load()
+        _lib.require_gpu()
+        failure = []
+
+        def xfn(user, n, peers, is_send, bufs, nbytes):
+            try:
+                ops = []
+                for i in range(n):
+                    arr = (C.c_ubyte * nbytes[i]).from_address(bufs[i])
+                    ops.append((peers[i], bool(is_send[i]), arr))
+                transport.exchange(ops)
+                return 0
+            except Exception as e:  # noqa: BLE001 -- must not propagate through the C frame
+                failure.append(e)
+                return 1
+
+        def afn(user, vals, n, op):
+            try:
+                a = np.ctypeslib.as_array(vals, shape=(n,))
+                transport.allreduce(a, op)
+                return 0
+            except Exception as e:  # noqa: BLE001
+                failure.append(e)
+                return 1
+
+        cx, ca = _lib.COMM_EXCHANGE_FN(xfn), _lib.COMM_ALLREDUCE_FN(afn)
+        h = C.c_void_p()
+        _lib.check(lib.dxh_comm_create_host(C.byref(h), device, transport.rank, transport.world, cx, ca, None))
+        comm = cls(h, transport.rank, transport.world, device, keep=(cx, ca, transport))
+        comm.failure = failure
+        return comm
+
+    def allreduce(self, vals: Sequence[float], op: str = "sum"):
+        a = (C.c_double * len(vals))(*vals)
+        _lib.check(self.lib.dxh_comm_allreduce(self._h, a, len(vals), 0 if op == "sum" else 1))
+        return list(a)
+
+    def barrier(self):
+        _lib.check(self.lib.dxh_comm_barrier(self._h))
+
+    def info(self) -> dict:
+        r, w, k = C.c_int(), C.c_int(), C.c_int()
+        x, b = C.c_int64(), C.c_int64()
+        _lib.check(self.lib.dxh_comm_info(self._h, C.byref(r), C.byref(w), C.byref(k), C.byref(x), C.byref(b)))
+        return dict(rank=r.value, world=w.value, kind="rccl" if k.value == 0 else "host", exchanges=x.value,
+                    bytes_sent=b.value)
+
+    def close(self):
+        if self._h:
+            self.lib.dxh_comm_destroy(self._h)
+            self._h = None
+            if self._cleanup:
+                self._cleanup()
+
+    __del__ = close
+
+
+def init_from_env(device: Optional[int] = None, rehearsal_base_port: Optional[int] = None):
+    """(comm, rank, world, local_rank) from the launcher's environment (``torchrun`` / ``torch.distributed.run`` set
+    RANK, WORLD_SIZE, LOCAL_RANK, MASTER_PORT; the launcher is only a process spawner here).  ``rehearsal_base_port``:
+    host-staged ``SocketTransport`` instead of RCCL, ranks round-robin over the visible GPUs."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if rehearsal_base_port is not None:
+        dev = local_rank % max(1, _lib.device_count()) if device is None else device
+        return Comm.host(SocketTransport(rank, world, rehearsal_base_port), dev), rank, world, dev
+    dev = local_rank if device is None else device
+    return Comm.rccl(rank, world, dev), rank, world, dev
+
+
+# ---- engines ---------------------------------------------------------------------------------------------------------
 class HipSlabEngine:
-    """The product engine: one ``DeviceTVD`` context per rank on a dedicated torch stream,
-    halo rows packed into torch-owned device buffers (plain pointers into the C ABI)."""
+    """The product engine: one ``DeviceTVD`` context per rank with a communicator attached; the whole round loop
+    (launches, exchanges, overlap) runs inside ``dxh_tvd_run_slab``."""
 
-    def __init__(self, slab_img: np.ndarray, dim: int, mu, omega, ell, boundary, device: int):
-        import torch
-
+    def __init__(self, slab_img: np.ndarray, dim: int, mu, omega, ell, boundary, device: int, comm: Comm,
+                 plan: SlabPlan):
         from .restoration.split_bregman_tvd import DeviceTVD
 
-        self.torch = torch
-        self.device = torch.device("cuda", device)
-        torch.cuda.set_device(self.device)
-        self.stream = torch.cuda.Stream(device=self.device)
-        self.st = DeviceTVD(slab_img.shape, slab_img.dtype, dim=dim, device=device, row_slab=boundary,
-                            stream=self.stream.cuda_stream)
+        self.comm = comm
+        self.st = DeviceTVD(slab_img.shape, slab_img.dtype, dim=dim, device=device, row_slab=boundary)
         self.st.set_coeffs(mu, omega, ell, slab_img)
         self.st.upload(slab_img)
+        _lib.check(self.st.lib.dxh_tvd_attach_comm(self.st._h, comm._h, plan.halo_top_rows, plan.halo_bot_rows))
 
-    def run(self, n_iter: int, jacobi_maxiter: int = 1, isotropic: bool = False):
-        with self.torch.cuda.stream(self.stream):
-            # enqueue only: the stream is drained by synchronize() / download()
-            return self.st.run(n_iter, jacobi_maxiter, None, eps=None, isotropic=isotropic, flags=_lib.FLAG_ASYNC)
+    def run_slab(self, n_iter: int, jacobi_maxiter: int, isotropic: bool, eps: Optional[float], flags: int = 0):
+        res = _lib.TvdResult()
+        if isotropic:
+            flags |= _lib.FLAG_ISOTROPIC
+        _lib.check(self.st.lib.dxh_tvd_run_slab(self.st._h, int(n_iter), int(jacobi_maxiter),
+                                                 -1.0 if eps is None else float(eps), flags, C.byref(res)))
+        failure = getattr(self.comm, "failure", None)
+        if failure:
+            raise failure[0]
+        return res
 
-    def halo_buffer(self, nrows: int):
-        import ctypes as C
-
-        n = C.c_size_t(0)
-        _lib.check(self.st.lib.dxh_tvd_halo_bytes(self.st._h, nrows, C.byref(n)))
-        return self.torch.empty(n.value, dtype=self.torch.uint8, device=self.device)
-
-    def pack(self, row0: int, nrows: int, buf):
-        _lib.check(self.st.lib.dxh_tvd_pack_rows(self.st._h, row0, nrows, buf.data_ptr()))
-
-    def unpack(self, row0: int, nrows: int, buf):
-        _lib.check(self.st.lib.dxh_tvd_unpack_rows(self.st._h, row0, nrows, buf.data_ptr()))
-
-    def partial_norms(self, row0: int, nrows: int, want_img: bool):
-        import ctypes as C
-
-        a, b = C.c_double(0.0), C.c_double(0.0)
-        _lib.check(self.st.lib.dxh_tvd_partial_norms(self.st._h, row0, nrows, C.byref(a),
-                                                      C.byref(b) if want_img else None))
-        return a.value, b.value
+    def exchange(self):
+        _lib.check(self.st.lib.dxh_tvd_exchange(self.st._h))
 
     def download(self) -> np.ndarray:
         return self.st.download()
 
     def synchronize(self):
         _lib.check(self.st.lib.dxh_tvd_sync(self.st._h))
-
-    def comm_context(self):
-        return self.torch.cuda.stream(self.stream)
 
     def close(self):
         self.st.close()
@@ -126,22 +365,19 @@ class SlabTVD:
     """Distributed split-Bregman TVD of one image cut into row slabs.
 
     ``slab_img`` is THIS rank's slab (rows ``plan.slab0:plan.slab1`` of the global image, halos
-    included).  ``engine_factory(slab_img, dim, mu, omega, ell, boundary)`` builds the per-rank compute
-    engine; the default is the HIP engine (tests inject a CPU oracle engine to exercise the exchange
-    logic without a GPU)."""
+    included).  Product use: pass ``comm`` (``Comm.rccl`` / ``init_from_env``), the HIP engine does
+    everything inside ``libdarsia_hip``.  Tests inject ``engine_factory(slab_img, dim, mu, omega, ell,
+    boundary)`` (a CPU oracle engine) together with a host ``transport`` to exercise the decomposition and
+    exchange logic without a GPU: that path runs the round loop below in Python."""
 
     def __init__(self, plan: SlabPlan, slab_img: np.ndarray, mu=1.0, omega=1.0, ell=None, dim: int = 2,
                  halo_iters: int = 1, jacobi_maxiter: int = 1, isotropic: bool = False, engine_factory=None,
-                 group=None, device: Optional[int] = None):
-        import torch
-        import torch.distributed as dist
-
-        self.torch, self.dist = torch, dist
+                 comm: Optional[Comm] = None, transport=None, device: Optional[int] = None, flags: int = 0):
         self.plan = plan
         self.k = int(halo_iters)
         self.m = int(jacobi_maxiter)
         self.isotropic = isotropic
-        self.group = group
+        self.flags = flags
         if self.k < 1 or self.m < 1:
             raise ValueError("halo_iters and jacobi_maxiter must be >= 1")
         need_top, need_bot = self.k * self.m, self.k * self.m + 1
@@ -154,96 +390,88 @@ class SlabTVD:
             if isinstance(c, np.ndarray) and c.ndim > 0 and c.shape[0] != plan.rows:
                 raise ValueError(f"array-valued {name} must be given per slab ({plan.rows} rows)")
         boundary = (plan.rank == 0, plan.rank == plan.world - 1)
-        if engine_factory is None:
-            if device is None:
-                device = _lib.default_device()
-            engine_factory = lambda *a: HipSlabEngine(*a, device=device)  # noqa: E731
-        self.engine = engine_factory(slab_img, dim, mu, omega, ell, boundary)
         self.world, self.rank = plan.world, plan.rank
-        if self.world > 1:
-            p = plan
-            # what I send up / receive from above, what I send down / receive from below (slab rows)
-            self._buf = {}
-            if self.rank > 0:
-                self._buf["send_up"] = self.engine.halo_buffer(p.halo_bot_rows)   # my first rows -> upper's bottom halo
-                self._buf["recv_up"] = self.engine.halo_buffer(p.halo_top_rows)   # upper's last rows -> my top halo
-            if self.rank < self.world - 1:
-                self._buf["send_dn"] = self.engine.halo_buffer(p.halo_top_rows)   # my last rows -> lower's top halo
-                self._buf["recv_dn"] = self.engine.halo_buffer(p.halo_bot_rows)   # lower's first rows -> my bottom halo
+        self.transport = transport
+        if engine_factory is None:
+            if comm is None:
+                raise ValueError("SlabTVD needs a communicator (Comm.rccl / Comm.host / init_from_env)")
+            if (comm.rank, comm.world) != (plan.rank, plan.world):
+                raise ValueError("communicator and plan disagree on rank / world")
+            if device is None:
+                device = comm.device
+            self.engine = HipSlabEngine(slab_img, dim, mu, omega, ell, boundary, device, comm, plan)
+        else:
+            if plan.world > 1 and transport is None:
+                raise ValueError("an injected engine needs a host transport")
+            self.engine = engine_factory(slab_img, dim, mu, omega, ell, boundary)
+            self._valid = plan.halo_top_rows   # halo rows still valid (uploaded slabs carry valid halos)
         self.iterations = 0
         self._img_norm = None
 
-    # ---- halo exchange ---------------------------------------------------------------------------
-    def exchange(self):
-        if self.world == 1:
-            return
-        dist, p, eng = self.dist, self.plan, self.engine
+    # ---- host-side round loop (injected engines only) -----------------------------------------------------------
+    def _exchange_host(self):
+        p, eng, tr = self.plan, self.engine, self.transport
         o0, o1 = p.owned_local
-        backend = dist.get_backend(self.group)
-        with eng.comm_context():
-            if self.rank > 0:
-                eng.pack(o0, p.halo_bot_rows, self._buf["send_up"])
-            if self.rank < self.world - 1:
-                eng.pack(o1 - p.halo_top_rows, p.halo_top_rows, self._buf["send_dn"])
-            stage = backend == "gloo" and any(getattr(b, "is_cuda", False) for b in self._buf.values())
-            bufs = {k: (v.cpu() if stage else v) for k, v in self._buf.items()}
-            ops = []
-            if self.rank > 0:
-                ops.append(dist.P2POp(dist.isend, bufs["send_up"], self._peer(self.rank - 1), self.group))
-                ops.append(dist.P2POp(dist.irecv, bufs["recv_up"], self._peer(self.rank - 1), self.group))
-            if self.rank < self.world - 1:
-                ops.append(dist.P2POp(dist.isend, bufs["send_dn"], self._peer(self.rank + 1), self.group))
-                ops.append(dist.P2POp(dist.irecv, bufs["recv_dn"], self._peer(self.rank + 1), self.group))
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-            if stage:
-                for k in ("recv_up", "recv_dn"):
-                    if k in bufs:
-                        self._buf[k].copy_(bufs[k])
-            if self.rank > 0:
-                eng.unpack(0, p.halo_top_rows, self._buf["recv_up"])
-            if self.rank < self.world - 1:
-                eng.unpack(o1, p.halo_bot_rows, self._buf["recv_dn"])
+        ops, recvs = [], []
+        if self.rank > 0:
+            ops.append((self.rank - 1, True, eng.pack(o0, p.halo_bot_rows)))          # my first rows -> upper's bottom halo
+            buf = eng.halo_buffer(p.halo_top_rows)
+            ops.append((self.rank - 1, False, buf))                                     # upper's last rows -> my top halo
+            recvs.append((0, p.halo_top_rows, buf))
+        if self.rank < self.world - 1:
+            ops.append((self.rank + 1, True, eng.pack(o1 - p.halo_top_rows, p.halo_top_rows)))  # -> lower's top halo
+            buf = eng.halo_buffer(p.halo_bot_rows)
+            ops.append((self.rank + 1, False, buf))                                     # lower's first rows -> my bottom halo
+            recvs.append((o1, p.halo_bot_rows, buf))
+        tr.exchange(ops)
+        for row0, nrows, buf in recvs:
+            eng.unpack(row0, nrows, buf)
+        self._valid = p.halo_top_rows
 
-    def _peer(self, r: int) -> int:
-        return r if self.group is None else self.dist.get_global_rank(self.group, r)
-
-    # ---- iteration -------------------------------------------------------------------------------
-    def run(self, n_iter: int, eps: Optional[float] = None) -> int:
-        """Run up to ``n_iter`` outer iterations; returns the number done (all ranks agree)."""
+    def _run_host(self, n_iter: int, eps: Optional[float]) -> int:
         done = 0
-        step = 1 if eps is not None else self.k
         o0, o1 = self.plan.owned_local
         while done < n_iter:
-            k = min(step, n_iter - done)
+            if self.world > 1 and self._valid < self.m:
+                self._exchange_host()
+            left = n_iter - done
+            k = 1 if eps is not None else (min(left, self._valid // self.m) if self.world > 1 else left)
             self.engine.run(k, self.m, self.isotropic)
             done += k
-            self.iterations += k
+            self._valid -= k * self.m
             if eps is not None:
                 inc, img2 = self.engine.partial_norms(o0, o1 - o0, self._img_norm is None)
-                if self._img_norm is None:
-                    t = self.torch.tensor([inc, img2], dtype=self.torch.float64)
-                else:
-                    t = self.torch.tensor([inc, 0.0], dtype=self.torch.float64)
+                vals = np.array([inc, img2 if self._img_norm is None else 0.0])
                 if self.world > 1:
-                    t = self._allreduce_sum(t)
+                    self.transport.allreduce(vals, 0)
                 if self._img_norm is None:
-                    self._img_norm = math.sqrt(float(t[1]))
-                rel = math.sqrt(float(t[0])) / self._img_norm
-                if rel < eps:
+                    self._img_norm = math.sqrt(float(vals[1]))
+                if math.sqrt(float(vals[0])) / self._img_norm < eps:
                     break
-            if done < n_iter:
-                self.exchange()
         return done
 
-    def _allreduce_sum(self, t):
-        dist = self.dist
-        if dist.get_backend(self.group) == "nccl":
-            t = t.to(self.engine.device)
-            dist.all_reduce(t, group=self.group)
-            return t.cpu()
-        dist.all_reduce(t, group=self.group)
-        return t
+    # ---- iteration -------------------------------------------------------------------------------------------------
+    def run(self, n_iter: int, eps: Optional[float] = None, more_to_come: bool = False, asynchronous: bool = False):
+        """Run up to ``n_iter`` outer iterations; returns the number done (all ranks agree).  ``more_to_come``: the
+        halos are refreshed at the end (overlapped with the last launch) so that a following ``run`` starts at once."""
+        if hasattr(self.engine, "run_slab"):
+            flags = self.flags | (_lib.FLAG_CONTINUE if more_to_come else 0) | (_lib.FLAG_ASYNC if asynchronous else 0)
+            res = self.engine.run_slab(n_iter, self.m, self.isotropic, eps, flags)
+            self.last_result = res
+            done = res.iters_done
+        else:
+            done = self._run_host(n_iter, eps)
+        self.iterations += done
+        return done
+
+    def exchange(self):
+        """Refresh the halos now (normally ``run`` decides when)."""
+        if self.world == 1:
+            return
+        if hasattr(self.engine, "run_slab"):
+            self.engine.exchange()
+        else:
+            self._exchange_host()
 
     def owned_result(self) -> np.ndarray:
         o0, o1 = self.plan.owned_local
@@ -254,8 +482,3 @@ class SlabTVD:
 
     def close(self):
         self.engine.close()
-
-
-def make_plan(H: int, world: int, rank: int, halo_iters: int = 1, jacobi_maxiter: int = 1) -> SlabPlan:
-    km = halo_iters * jacobi_maxiter
-    return SlabPlan(H, world, rank, halo_top_rows=km, halo_bot_rows=km + 1)

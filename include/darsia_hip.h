@@ -159,6 +159,61 @@ int dxh_tvd_download_model(dxh_tvd_t ctx, void* out, const dxh_model_op* post_op
 int dxh_tvd_halo_bytes(dxh_tvd_t ctx, int64_t nrows, size_t* bytes);
 int dxh_tvd_pack_rows(dxh_tvd_t ctx, int64_t row0, int64_t nrows, void* dst_device);
 int dxh_tvd_unpack_rows(dxh_tvd_t ctx, int64_t row0, int64_t nrows, const void* src_device);
+
+/*
+ * Multi-GPU TV sweep: one process per GPU, the image cut into row slabs (axis 0), halo rows exchanged between slab
+ * neighbours only -- point to point, as xGMI is; no collective on the data path.  No reference counterpart (the
+ * reference is single-process); what an exchange must deliver follows from the data dependences of one outer
+ * iteration: the Jacobi neighbour sum reads u one row above and below per sweep (utils/linear_solvers/jacobi.py:43-54),
+ * the right-hand side differences ell (b0 - d0) across the row above (restoration/split_bregman_tvd.py:84-89) and the
+ * split update takes D+ of the new iterate across the row below (:144).  With halo_top_rows = k * jacobi_maxiter rows
+ * above and halo_bottom_rows = k * jacobi_maxiter + 1 below the owned rows, k iterations run between two exchanges.
+ *
+ * A communicator is either RCCL (grouped ncclSend / ncclRecv straight from / into the state planes' row blocks on a
+ * dedicated comm stream; librccl is dlopen'ed on first use) or host-staged through caller-provided callbacks (tests
+ * and rehearsals with several ranks on one GPU, which RCCL refuses).  Bootstrap: rank 0 calls dxh_comm_unique_id and
+ * hands the 128 bytes to the other ranks by any means (darsia_amd/parallel.py uses a file next to MASTER_PORT).
+ */
+typedef struct dxh_comm_s* dxh_comm_t;
+#define DXH_COMM_ID_BYTES 128
+
+int dxh_comm_unique_id(void* id /* DXH_COMM_ID_BYTES */);
+int dxh_comm_create_rccl(dxh_comm_t* comm, int device, const void* id, int rank, int world);
+/* host-staged transport: all n_ops transfers of one call progress together (is_send[i] ? send bufs[i] to peers[i] :
+ * receive from peers[i] into bufs[i]); messages between a pair of ranks match in call order.  Return 0 on success. */
+typedef int (*dxh_comm_exchange_fn)(void* user, int n_ops, const int* peers, const int* is_send, void* const* bufs,
+                                    const size_t* bytes);
+/* in-place all-reduce of n doubles over all ranks; op 0 = sum, 1 = max */
+typedef int (*dxh_comm_allreduce_fn)(void* user, double* vals, int n, int op);
+int dxh_comm_create_host(dxh_comm_t* comm, int device, int rank, int world, dxh_comm_exchange_fn exchange,
+                         dxh_comm_allreduce_fn allreduce, void* user);
+int dxh_comm_destroy(dxh_comm_t comm);
+/* blocking all-reduce of n <= 16 host doubles (op 0 = sum, 1 = max); dxh_comm_barrier = all-reduce of one value */
+int dxh_comm_allreduce(dxh_comm_t comm, double* vals, int n, int op);
+int dxh_comm_barrier(dxh_comm_t comm);
+/* any pointer may be NULL; kind 0 = RCCL, 1 = host-staged */
+int dxh_comm_info(dxh_comm_t comm, int* rank, int* world, int* kind, int64_t* exchanges, int64_t* bytes_sent);
+
+/*
+ * Make `ctx` one slab of a distributed problem.  The context's n0 rows are [top halo | owned rows | bottom halo];
+ * a side with desc.top_is_boundary / bottom_is_boundary set has no halo.  All ranks pass the same halo row counts.
+ * The communicator must outlive the context.
+ */
+int dxh_tvd_attach_comm(dxh_tvd_t ctx, dxh_comm_t comm, int64_t halo_top_rows, int64_t halo_bottom_rows);
+/* refresh the halo rows from the neighbours now (enqueued behind everything the context has in flight) */
+int dxh_tvd_exchange(dxh_tvd_t ctx);
+#define DXH_FLAG_NO_OVERLAP 32u /* dxh_tvd_run_slab: whole-slab launches, exchange serialised with compute (A/B, tests) */
+#define DXH_FLAG_CONTINUE 64u   /* dxh_tvd_run_slab: more iterations will follow -- if the halos are used up at the end
+                                   of this call, refresh them now, overlapped with the last launch */
+/*
+ * dxh_tvd_run for a slab: runs n_iter outer iterations, exchanging halos whenever they are used up.  The launch before
+ * an exchange runs the row chunks next to the slab interfaces first (own stream), the exchange starts when they are
+ * done and proceeds while the interior chunks of that launch AND of the next one run; only the next launch's interface
+ * chunks wait for it.  eps (>= 0): global stopping test of split_bregman_tvd.py:161-175 -- one all-reduce of the
+ * owned rows' squared increment per iteration (and of ||img||^2 once); all ranks stop at the same iteration.
+ * result->loop_ms is NaN with DXH_FLAG_ASYNC.
+ */
+int dxh_tvd_run_slab(dxh_tvd_t ctx, int n_iter, int jacobi_maxiter, double eps, uint32_t flags, dxh_tvd_result* result);
 /* sum over rows [row0, row0+nrows) of (u - u_prev)^2 of the last iteration and of img^2 (for a global eps test) */
 int dxh_tvd_partial_norms(dxh_tvd_t ctx, int64_t row0, int64_t nrows, double* sq_increment, double* sq_img);
 /* adaptive regularisation, split_bregman_tvd.py:149-158: ell <- 1 / max(|grad u|_1, 1e-12) per element for the rhs

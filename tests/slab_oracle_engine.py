@@ -1,10 +1,7 @@
-"""Test-only slab engine: the NumPy oracle stepping one row slab (halos included)
-as if it were a stand-alone image.  Lets the distributed driver's decomposition
-and halo-exchange logic run on CPU (gloo) without any HIP code."""
-import contextlib
-
+"""Test-only pieces for the row-slab driver: a slab engine that steps the NumPy oracle over one row slab
+(halos included) as if it were a stand-alone image, and a gloo transport (torch.distributed lives in the
+tests only; the product is torch-free).  They let the decomposition and halo-exchange logic run on CPU."""
 import numpy as np
-import torch
 
 from oracle import tvd_numpy as O
 
@@ -18,7 +15,6 @@ class OracleSlabEngine:
         self.d = [np.zeros_like(slab_img) for _ in range(dim)]
         self.b = [np.zeros_like(slab_img) for _ in range(dim)]
         self.u_prev = None
-        self.device = torch.device("cpu")
 
     def run(self, n_iter, jacobi_maxiter=1, isotropic=False):
         for _ in range(n_iter):
@@ -32,14 +28,14 @@ class OracleSlabEngine:
 
     def halo_buffer(self, nrows):
         n = len(self._fields()) * nrows * int(np.prod(self.img.shape[1:])) * self.img.dtype.itemsize
-        return torch.empty(n, dtype=torch.uint8)
+        return np.empty(n, dtype=np.uint8)
 
-    def pack(self, row0, nrows, buf):
+    def pack(self, row0, nrows):
         raw = b"".join(np.ascontiguousarray(f[row0:row0 + nrows]).tobytes() for f in self._fields())
-        buf.copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+        return np.frombuffer(bytearray(raw), dtype=np.uint8)
 
     def unpack(self, row0, nrows, buf):
-        raw = buf.numpy().tobytes()
+        raw = np.asarray(buf).tobytes()
         per = len(raw) // len(self._fields())
         self.u = self.u.copy()
         self.d = [a.copy() for a in self.d]
@@ -59,8 +55,41 @@ class OracleSlabEngine:
     def synchronize(self):
         pass
 
-    def comm_context(self):
-        return contextlib.nullcontext()
-
     def close(self):
         pass
+
+
+class GlooTransport:
+    """The host-transport protocol of darsia_amd.parallel over an initialised gloo process group."""
+
+    def __init__(self):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    def exchange(self, ops):
+        import torch
+
+        dist = self.dist
+        p2p, back = [], []
+        for peer, is_send, buf in ops:
+            a = np.frombuffer(buf, dtype=np.uint8) if not isinstance(buf, np.ndarray) else buf
+            if is_send:
+                t = torch.from_numpy(np.array(a, copy=True))
+                p2p.append(dist.P2POp(dist.isend, t, peer))
+            else:
+                t = torch.empty(a.size, dtype=torch.uint8)
+                p2p.append(dist.P2POp(dist.irecv, t, peer))
+                back.append((a, t))
+        for w in dist.batch_isend_irecv(p2p):
+            w.wait()
+        for a, t in back:
+            a[:] = t.numpy()
+
+    def allreduce(self, vals, op):
+        import torch
+
+        t = torch.from_numpy(np.array(vals, dtype=np.float64))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM if op == 0 else self.dist.ReduceOp.MAX)
+        vals[:] = t.numpy()

@@ -1,5 +1,5 @@
-"""world_size-2 (and 3) gloo runs of the row-slab driver with the CPU oracle engine:
-the N-rank result must equal the single-image result bit for bit."""
+"""world_size-2 (and 3) runs of the row-slab driver with the CPU oracle engine, over gloo and over the product's
+torch-free socket transport: the N-rank result must equal the single-image result bit for bit."""
 import os
 import socket
 import sys
@@ -22,22 +22,31 @@ def _free_port():
 def _worker(rank, world, port, case, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from darsia_amd.parallel import SlabTVD, SocketTransport, make_plan
+    from slab_oracle_engine import GlooTransport, OracleSlabEngine
+
+    use_gloo = case.get("transport", "gloo") == "gloo"
+    if use_gloo:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        transport = GlooTransport()
+    else:
+        transport = SocketTransport(rank, world, port)
     try:
-        from darsia_amd.parallel import SlabTVD, make_plan
-        from slab_oracle_engine import OracleSlabEngine
 
         img = np.load(os.path.join(out_dir, "img.npy"))
         plan = make_plan(img.shape[0], world, rank, case["halo_iters"], case.get("jm", 1))
         slab = np.ascontiguousarray(img[plan.slab0:plan.slab1])
         s = SlabTVD(plan, slab, mu=case["mu"], omega=case.get("omega", 1.0), ell=case.get("ell"), dim=2,
                     halo_iters=case["halo_iters"], jacobi_maxiter=case.get("jm", 1),
-                    isotropic=case.get("iso", False), engine_factory=OracleSlabEngine)
+                    isotropic=case.get("iso", False), engine_factory=OracleSlabEngine, transport=transport)
         done = s.run(case["n_iter"], eps=case.get("eps"))
         np.save(os.path.join(out_dir, f"out_{rank}.npy"), s.owned_result())
         np.save(os.path.join(out_dir, f"done_{rank}.npy"), np.int64(done))
     finally:
-        dist.destroy_process_group()
+        if use_gloo:
+            dist.destroy_process_group()
+        else:
+            transport.close()
 
 
 CASES = [
@@ -47,6 +56,8 @@ CASES = [
     dict(shape=(40, 19, 3), world=2, halo_iters=2, mu=0.1, n_iter=5, jm=2),
     dict(shape=(36, 21), world=2, halo_iters=4, mu=0.1, n_iter=9, iso=True, dtype="float64"),
     dict(shape=(44, 20, 3), world=2, halo_iters=3, mu=0.1, n_iter=60, eps=3e-3),
+    dict(shape=(50, 17), world=3, halo_iters=2, mu=0.15, omega=0.8, n_iter=7, transport="socket"),
+    dict(shape=(44, 20, 3), world=3, halo_iters=3, mu=0.1, n_iter=60, eps=3e-3, transport="socket"),
 ]
 
 

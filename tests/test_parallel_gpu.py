@@ -1,8 +1,11 @@
-"""The row-slab driver with the HIP engine: two processes share GPU 0 and
-exchange halos through gloo (host-staged); the result must equal the
-single-context HIP result bit for bit.  (RCCL needs one GPU per rank, which the
-1-GPU test box cannot offer; the RCCL transport differs only in the backend
-string.)"""
+"""The row-slab driver with the HIP engine.
+
+* 2-3 processes share GPU 0 and exchange halos through the library's host-staged transport (RCCL refuses several
+  ranks on one device): the result must equal the single-context HIP result bit for bit, with and without the
+  interface-first / overlapped launch order of ``dxh_tvd_run_slab``.
+* RCCL itself: a one-rank communicator (all-reduce, barrier, slab run) on the 1-GPU box, and -- when the box has at
+  least two GPUs -- one rank per GPU over RCCL send/recv, again bit-exact against one context.
+"""
 import os
 import socket
 import sys
@@ -22,57 +25,141 @@ def _free_port():
 
 
 def _worker(rank, world, port, case, out_dir):
-    import torch.distributed as dist
-
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        from darsia_amd.parallel import SlabTVD, make_plan
+    os.environ["RANK"], os.environ["WORLD_SIZE"], os.environ["LOCAL_RANK"] = str(rank), str(world), str(rank)
+    from darsia_amd import _lib
+    from darsia_amd.parallel import Comm, SlabTVD, SocketTransport, make_plan
 
+    if case.get("rccl"):
+        comm = Comm.rccl(rank, world, device=rank)
+    else:
+        comm = Comm.host(SocketTransport(rank, world, port), device=0)
+    try:
         img = np.load(os.path.join(out_dir, "img.npy"))
-        plan = make_plan(img.shape[0], world, rank, case["halo_iters"])
+        jm = case.get("jm", 1)
+        plan = make_plan(img.shape[0], world, rank, case["halo_iters"], jm)
         slab = np.ascontiguousarray(img[plan.slab0:plan.slab1])
         mu = 0.1
         if case.get("het"):
             mu = np.ascontiguousarray(np.load(os.path.join(out_dir, "mu.npy"))[plan.slab0:plan.slab1])
-        s = SlabTVD(plan, slab, mu=mu, dim=2, halo_iters=case["halo_iters"], isotropic=case.get("iso", False),
-                    device=0)
-        done = s.run(case["n_iter"], eps=case.get("eps"))
+        flags = _lib.FLAG_NO_OVERLAP if case.get("no_overlap") else 0
+        s = SlabTVD(plan, slab, mu=mu, dim=case.get("dim", 2), halo_iters=case["halo_iters"], jacobi_maxiter=jm,
+                    isotropic=case.get("iso", False), comm=comm, flags=flags)
+        done = 0
+        for part in case.get("parts", [case["n_iter"]]):
+            # several calls continue one iteration sequence; all but the last prefetch the halos for the next
+            done += s.run(part, eps=case.get("eps"), more_to_come=(done + part < case["n_iter"]),
+                          asynchronous=case.get("async", False))
         np.save(os.path.join(out_dir, f"out_{rank}.npy"), s.owned_result())
         np.save(os.path.join(out_dir, f"done_{rank}.npy"), np.int64(done))
+        np.save(os.path.join(out_dir, f"xchg_{rank}.npy"), np.int64(comm.info()["exchanges"]))
         s.close()
     finally:
-        dist.destroy_process_group()
+        comm.close()
 
 
-@pytest.mark.parametrize("case", [
-    dict(shape=(300, 530, 3), world=2, halo_iters=4, n_iter=10),
-    dict(shape=(400, 300, 3), world=2, halo_iters=20, n_iter=44),   # bench.py's exchange interval: 5 K=4 launches per round
-    dict(shape=(97, 260), world=3, halo_iters=1, n_iter=5),
-    dict(shape=(120, 300, 3), world=2, halo_iters=3, n_iter=80, eps=2e-3),
-    dict(shape=(90, 270, 3), world=2, halo_iters=2, n_iter=6, iso=True),
-    dict(shape=(210, 300, 3), world=2, halo_iters=3, n_iter=11, het=True),
-], ids=["rgb_k4", "rgb_k20_bench_interval", "gray_k1_3ranks", "eps", "iso", "het_mu_array"])
-def test_two_ranks_one_gpu(tmp_path, case):
-    import torch.multiprocessing as mp
+def _spawn(world, case, tmp_path):
+    import multiprocessing as mp
 
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+
+
+def _reference(img, mu, case):
     import darsia_amd as da
 
+    with da.DeviceTVD(img.shape, img.dtype, dim=case.get("dim", 2)) as st:
+        st.set_coeffs(mu, 1.0, None, img)
+        st.upload(img)
+        res = st.run(case["n_iter"], jacobi_maxiter=case.get("jm", 1), eps=case.get("eps"),
+                     isotropic=case.get("iso", False))
+        return st.download(), res.iters_done
+
+
+CASES = {
+    "rgb_k4": dict(shape=(300, 530, 3), world=2, halo_iters=4, n_iter=10),
+    # bench.py's exchange interval: 5 K=4 launches per round, overlapped exchanges
+    "rgb_k20_bench_interval": dict(shape=(400, 300, 3), world=2, halo_iters=20, n_iter=44),
+    "rgb_k20_no_overlap": dict(shape=(400, 300, 3), world=2, halo_iters=20, n_iter=44, no_overlap=True),
+    # three ranks: the middle one has two interfaces; several chunks per slab so that interface / interior parts differ
+    "rgb_k8_3ranks_tall": dict(shape=(1500, 420, 3), world=3, halo_iters=8, n_iter=30),
+    "rgb_k20_steps": dict(shape=(900, 300, 3), world=2, halo_iters=20, n_iter=100, parts=[40, 40, 20], **{"async": True}),
+    "gray_k1_3ranks": dict(shape=(97, 260), world=3, halo_iters=1, n_iter=5),
+    "gray_k6_tall": dict(shape=(2000, 520), world=2, halo_iters=6, n_iter=19),
+    "eps": dict(shape=(120, 300, 3), world=2, halo_iters=3, n_iter=80, eps=2e-3),
+    "iso": dict(shape=(90, 270, 3), world=2, halo_iters=2, n_iter=6, iso=True),
+    "het_mu_array": dict(shape=(210, 300, 3), world=2, halo_iters=3, n_iter=11, het=True),
+    "jacobi_maxiter2": dict(shape=(160, 200, 3), world=2, halo_iters=3, n_iter=7, jm=2),
+    "f64": dict(shape=(600, 200, 3), world=2, halo_iters=4, n_iter=12, dtype="float64"),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_ranks_on_one_gpu(tmp_path, name):
+    case = CASES[name]
     rng = np.random.default_rng(3)
-    img = rng.random(case["shape"]).astype(np.float32)
+    img = rng.random(case["shape"]).astype(case.get("dtype", "float32"))
     np.save(tmp_path / "img.npy", img)
     mu = (0.03 + 0.1 * rng.random(case["shape"])).astype(np.float32) if case.get("het") else 0.1
     if case.get("het"):
         np.save(tmp_path / "mu.npy", mu)
     world = case["world"]
-    mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
+    _spawn(world, case, tmp_path)
     got = np.concatenate([np.load(tmp_path / f"out_{r}.npy") for r in range(world)], axis=0)
-    with da.DeviceTVD(img.shape, img.dtype, dim=2) as st:
-        st.set_coeffs(mu, 1.0, None, img)
-        st.upload(img)
-        res = st.run(case["n_iter"], eps=case.get("eps"), isotropic=case.get("iso", False))
-        ref = st.download()
+    ref, ref_done = _reference(img, mu, case)
     dones = {int(np.load(tmp_path / f"done_{r}.npy")) for r in range(world)}
-    assert dones == {res.iters_done}
+    assert dones == {ref_done}
+    assert np.array_equal(got, ref), f"max abs {np.abs(got - ref).max():.3e}"
+    if not case.get("eps"):
+        # exchanges happen exactly when the halos are used up: ceil(n / k) - 1 of them
+        k = case["halo_iters"]
+        expect = -(-case["n_iter"] // k) - 1
+        assert {int(np.load(tmp_path / f"xchg_{r}.npy")) for r in range(world)} == {expect}
+
+
+def test_rccl_single_rank_communicator(tmp_path):
+    """RCCL loads, a one-rank communicator initialises on the device, reduces and carries a slab run."""
+    import darsia_amd as da
+    from darsia_amd.parallel import Comm, SlabTVD, make_plan
+
+    os.environ["MASTER_PORT"] = str(_free_port())
+    comm = Comm.rccl(0, 1, device=0)
+    try:
+        assert comm.info()["kind"] == "rccl"
+        assert comm.allreduce([1.5, -2.0], "sum") == [1.5, -2.0]
+        assert comm.allreduce([3.0], "max") == [3.0]
+        comm.barrier()
+        img = np.random.default_rng(5).random((130, 300, 3)).astype(np.float32)
+        plan = make_plan(img.shape[0], 1, 0, 4)
+        s = SlabTVD(plan, img, mu=0.1, halo_iters=4, comm=comm)
+        assert s.run(9) == 9
+        got = s.owned_result()
+        s.close()
+    finally:
+        comm.close()
+    ref = da.split_bregman_tvd(img, mu=0.1, max_num_iter=9)
+    assert np.array_equal(got, ref)
+
+
+def test_rccl_one_rank_per_gpu(tmp_path):
+    """The product transport: one process per GPU, RCCL send/recv between slab neighbours (needs >= 2 GPUs)."""
+    from darsia_amd import _lib
+
+    ngpu = _lib.device_count()
+    if ngpu < 2:
+        pytest.skip("needs at least two GPUs (RCCL refuses two ranks on one device)")
+    world = min(ngpu, 4)
+    case = dict(shape=(1200, 700, 3), world=world, halo_iters=8, n_iter=40, rccl=True)
+    img = np.random.default_rng(11).random(case["shape"]).astype(np.float32)
+    np.save(tmp_path / "img.npy", img)
+    _spawn(world, case, tmp_path)
+    got = np.concatenate([np.load(tmp_path / f"out_{r}.npy") for r in range(world)], axis=0)
+    ref, _ = _reference(img, 0.1, case)
     assert np.array_equal(got, ref), f"max abs {np.abs(got - ref).max():.3e}"
