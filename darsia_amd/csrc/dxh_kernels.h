@@ -578,14 +578,21 @@ struct FusedArgs {
     T* q0_out;
     T* q1_out;
     int64_t n0, L, pitch;
-    int64_t rows_per_chunk;
+    // Row chunks: up to three runs of equally long chunks.  Run s covers rows [seg_row[s], seg_row[s + 1]) with chunks of
+    // seg_rpc[s] rows, the first of which has index seg_chunk[s] (seg_chunk[3] = nchunks).  An ordinary launch uses run
+    // 1 only; a slab launch that is split for the halo exchange puts short chunks next to the slab interfaces (runs 0 and
+    // 2) so that they finish early (chunking never changes results).
+    int64_t seg_row[4];
+    int64_t seg_rpc[3];
+    int seg_chunk[4];
     int nstrips;       // strips per row
     int nchunks;
     int remap;         // XCD-aware block -> tile mapping (block_to_tile)
-    // A launch may cover a SUBSET of the row chunks (multi-GPU slabs: the chunks next to a slab interface run first, on
-    // their own stream, so that the halo exchange overlaps the interior chunks).  The grid holds chunk_n chunks; launch
-    // index i stands for chunk i (i < chunk_gap_at) or i + chunk_gap.  Whole launch: chunk_n = nchunks, gap 0.
-    int chunk_n, chunk_gap_at, chunk_gap;
+    // Slab launches that precede a halo exchange: the chunks of runs 0 and 2 (next to the slab interfaces) are "class A".
+    // Their blocks come first in the grid on every XCD, they are short, and each of their waves bumps *signal when its
+    // rows are in memory, so that the exchange can start while the long interior chunks (class B) are still running.
+    // Ordinary launches have no class A chunks (seg_chunk[1] = 0, seg_chunk[2] = nchunks) and signal = nullptr.
+    unsigned* signal;
     Coef<T> c;
     CoefPlanes<T> cp;
     // heterogeneous coefficients: when `derive` is set the kernel reads only the planes the caller gave (mu, omega,
@@ -623,10 +630,51 @@ __device__ __forceinline__ void block_to_tile(int bid, int nbx, int nchunks, int
     chunk = bid % nchunks;
     bx = bid / nchunks;
 }
+// The same for any number of chunks: XCD x (= bid % 8) works on a contiguous run of tiles in (chunk, column block)
+// order, so neighbouring strips -- and neighbouring chunk rows, which share their fill rows -- meet in one L2.  Class A
+// chunks (FusedArgs::signal) are dealt the same way among themselves and come first on every XCD.  The grid has
+// 8 * (ceil(tilesA / 8) + ceil(tilesB / 8)) blocks (tile_grid on the host); returns false for the surplus ones.
 template <typename A>
-__device__ __forceinline__ void block_to_tile_sub(int bid, int nbx, const A& a, int& bx, int& chunk) {
-    block_to_tile(bid, nbx, a.chunk_n, bx, chunk);
-    if (chunk >= a.chunk_gap_at) chunk += a.chunk_gap;
+__device__ __forceinline__ bool block_to_tile_sub(int bid, int nbx, const A& a, int& bx, int& chunk) {
+    const int c0 = a.seg_chunk[1], c1 = a.seg_chunk[2] - a.seg_chunk[1], c2 = a.seg_chunk[3] - a.seg_chunk[2];
+    const int tiles_a = nbx * (c0 + c2), tiles_b = nbx * c1;
+    const int per_a = (tiles_a + 7) >> 3, per_b = (tiles_b + 7) >> 3;
+    const int xcd = bid & 7;
+    int idx = bid >> 3;
+    if (idx < per_a) {
+        const int t = xcd * per_a + idx;
+        if (t >= tiles_a) return false;
+        const int ca = t / nbx;
+        bx = t - ca * nbx;
+        chunk = ca < c0 ? ca : ca + c1;
+    } else {
+        idx -= per_a;
+        const int t = xcd * per_b + idx;
+        if (t >= tiles_b) return false;
+        const int cb = t / nbx;
+        bx = t - cb * nbx;
+        chunk = c0 + cb;
+    }
+    return true;
+}
+// A class A wave has stored its rows: make them visible device-wide (the reader is a later kernel on another stream,
+// started by a stream wait on the counter), then count the wave.  Recipe of MI355X_MICROARCH.md (inter-workgroup
+// visibility): drain the stores, agent-scope release (writes back this XCD's L2), drain again -- as inline asm, because
+// the compiler drops the wait after buffer_wbl2 when it believes the scoreboard empty --, agent-scope atomic add.
+template <typename A>
+__device__ __forceinline__ void signal_chunk_done(const A& a, int chunk, int lane) {
+    if (a.signal == nullptr) return;                                        // uniform
+    if (chunk >= a.seg_chunk[1] && chunk < a.seg_chunk[2]) return;          // class B (wave-uniform)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(a.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename A>
+__device__ __forceinline__ void chunk_rows(const A& a, int chunk, int64_t& R0, int64_t& R1) {
+    const int s = (chunk >= a.seg_chunk[1] ? 1 : 0) + (chunk >= a.seg_chunk[2] ? 1 : 0);
+    R0 = a.seg_row[s] + (int64_t)(chunk - a.seg_chunk[s]) * a.seg_rpc[s];
+    R1 = (R0 + a.seg_rpc[s] < a.seg_row[s + 1]) ? R0 + a.seg_rpc[s] : a.seg_row[s + 1];
 }
 
 template <typename T, int C, bool COUPLED, bool ISO, bool HET, bool DPP, bool ALIGN = true, bool NTS = true>
@@ -639,17 +687,16 @@ __global__ void __launch_bounds__(256) k_fused(FusedArgs<T> a) {
     const int nbx = (a.nstrips + WPB - 1) / WPB;
     int bx, chunk;
     if (a.remap) {
-        block_to_tile_sub((int)blockIdx.x, nbx, a, bx, chunk);
+        if (!block_to_tile_sub((int)blockIdx.x, nbx, a, bx, chunk)) return;  // block-uniform
     } else {
         bx = blockIdx.x % nbx;
         chunk = blockIdx.x / nbx;
-        if (chunk >= a.chunk_gap_at) chunk += a.chunk_gap;
     }
     const int strip = bx * WPB + wave;
     if (strip >= a.nstrips || chunk >= a.nchunks) return;  // wave-uniform
 
-    const int64_t R0 = (int64_t)chunk * a.rows_per_chunk;
-    const int64_t R1 = (R0 + a.rows_per_chunk < a.n0) ? R0 + a.rows_per_chunk : a.n0;
+    int64_t R0, R1;
+    chunk_rows(a, chunk, R0, R1);
     if (R0 >= a.n0) return;
 
     // element range of this lane: [x0, x0 + N)
@@ -862,6 +909,7 @@ __global__ void __launch_bounds__(256) k_fused(FusedArgs<T> a) {
         }
         if constexpr (HET) finish_coefs(elln, diagn, dscn, kqn, ell, diag, dsc, kq);
     }
+    signal_chunk_done(a, chunk, lane);
 }
 
 
@@ -1334,8 +1382,7 @@ template <int KG, typename T, int C, typename PipeT>
 __device__ __forceinline__ bool pipe_setup(PipeT& pp, const FusedArgs<T>& a, const int strip, const int chunk, const int lane) {
     constexpr int N = VecOf<T>::N;
     using SG = StripGeomK<T, C, KG>;
-    pp.R0 = (int64_t)chunk * a.rows_per_chunk;
-    pp.R1 = (pp.R0 + a.rows_per_chunk < a.n0) ? pp.R0 + a.rows_per_chunk : a.n0;
+    chunk_rows(a, chunk, pp.R0, pp.R1);
     if (pp.R0 >= a.n0) return false;
     const int64_t x0 = (int64_t)strip * SG::STRIDE + (int64_t)(lane - SG::LH) * N;
     int64_t xl = x0;
@@ -1605,7 +1652,7 @@ __global__ void __launch_bounds__(256, DXH_PAIR_LB) k_fused_pair(FusedArgs<T> a)
     const bool tail = ((wave ^ (int)blockIdx.x) & 1) != 0;
     const int nbx = (a.nstrips + PPB - 1) / PPB;
     int bx, chunk;
-    block_to_tile_sub((int)blockIdx.x, nbx, a, bx, chunk);
+    if (!block_to_tile_sub((int)blockIdx.x, nbx, a, bx, chunk)) return;
     if (chunk >= a.nchunks) return;  // block-uniform
     int strip = bx * PPB + pair;
     const bool active = strip < a.nstrips;
@@ -1621,6 +1668,7 @@ __global__ void __launch_bounds__(256, DXH_PAIR_LB) k_fused_pair(FusedArgs<T> a)
         fused_pair_body<T, C, COUPLED, ISO, NTS, true, NORM>(a, strip, chunk, lane, tail, active, xl);
     else
         fused_pair_body<T, C, COUPLED, ISO, NTS, false, NORM>(a, strip, chunk, lane, tail, active, xl);
+    if (active && tail) signal_chunk_done(a, chunk, lane);
 }
 #endif  // DXH_ENABLE_PAIR
 
@@ -1633,7 +1681,7 @@ __global__ void __launch_bounds__(256, (pipe_waves<T, K, HET>())) k_fused_multi(
     constexpr int WPB = 4;
     const int nbx = (a.nstrips + WPB - 1) / WPB;
     int bx, chunk;
-    block_to_tile_sub((int)blockIdx.x, nbx, a, bx, chunk);
+    if (!block_to_tile_sub((int)blockIdx.x, nbx, a, bx, chunk)) return;  // block-uniform
     const int strip = bx * WPB + wave;
     if (strip >= a.nstrips || chunk >= a.nchunks) return;  // wave-uniform
     const int64_t w0 = (int64_t)strip * SG::STRIDE - SG::LH * N;  // first element of the wave's window
@@ -1644,6 +1692,7 @@ __global__ void __launch_bounds__(256, (pipe_waves<T, K, HET>())) k_fused_multi(
         fused_pipe_body<T, C, COUPLED, ISO, K, NTS, true, NORM, HET>(a, strip, chunk, lane, lds_lane);
     else
         fused_pipe_body<T, C, COUPLED, ISO, K, NTS, false, NORM, HET>(a, strip, chunk, lane, lds_lane);
+    signal_chunk_done(a, chunk, lane);
 }
 
 // ============================================================================================

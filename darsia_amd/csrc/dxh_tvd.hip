@@ -97,37 +97,92 @@ struct Ctx {
     int64_t halo_top = 0, halo_bot = 0;  // the plan's halo rows (the same on every rank)
     int64_t top = 0, bot = 0;            // halo rows this slab really has above / below its owned rows
     int64_t halo_valid = 0;              // rows of the top-side halo budget still valid (a sweep consumes one)
-    hipStream_t s_bnd = nullptr;         // stream of the interface-chunk launches
-    hipEvent_t eM = nullptr, eB = nullptr, eC = nullptr;  // main-stream marker, interface launch done, exchange done
-    bool pendB = false, pendC = false;   // an interface launch / an exchange the main stream has not waited for yet
-    int part = 0;                        // chunk subset of the next fused launch: 0 all, 1 interface chunks, 2 interior
-    hipStream_t part_stream = nullptr;   // its stream (nullptr: the context stream)
+    hipEvent_t eM = nullptr, eC = nullptr;  // main-stream marker, exchange done
+    bool pendC = false;                  // an exchange the main stream has not waited for yet
+    bool signalling = false;             // the next fused launch puts the interface chunks first and counts them in *signal
+    unsigned* signal = nullptr;          // device counter bumped by every finished interface wave
+    unsigned signal_target = 0;          // its value once every signalling launch so far has finished its interface chunks
+    unsigned signal_pending = 0;         // waves the launch being built adds to it
+    int wait_mode = 0;                   // how the comm stream waits for it: 1 hipStreamWaitValue32, 2 polling kernel
     double global_sq_img = -1.0;         // ||img||^2 over all ranks' owned rows
-    int64_t split_launches = 0;          // statistics: launches that ran as interface + interior parts
+    int64_t split_launches = 0;          // statistics: launches that carried an overlapped exchange
 };
 
-// Which row chunks a fused launch covers (Ctx::part).  Interface part: the chunks holding the rows the neighbours need
-// (top .. top + halo_bot, and the last halo_top owned rows) together with the halo rows themselves; the interior part
-// must not read a halo row (K + 2 rows of reach), because the exchange may be writing those while it runs.
-struct ChunkSel { int n, gap_at, gap; };
-static ChunkSel select_chunks(const Ctx* c, int64_t nchunks, int64_t rpc, int K) {
-    ChunkSel all{(int)nchunks, INT32_MAX, 0};
-    if (c->part == 0) return all;
-    int64_t cbt = 0, cbb = 0;
-    if (c->top > 0) cbt = (std::max(c->top + c->halo_bot, c->top + K + 2) + rpc - 1) / rpc;
-    if (c->bot > 0) {
-        const int64_t o1 = c->g.n0 - c->bot;
-        const int64_t lim = std::min(o1 - c->halo_top, o1 - (K + 2));
-        cbb = nchunks - std::max<int64_t>(0, lim / rpc);
+// Row-chunk layout of one fused launch (FusedArgs::seg_*).  An ordinary launch is one run of equal chunks.  The slab
+// launch in front of a halo exchange (Ctx::signalling) has three runs: short chunks over the rows next to the top
+// interface [0, A), ordinary chunks over the interior [A, B), short chunks over [B, n0).  The short ("class A") chunks
+// hold the rows the neighbours need (top .. top + halo_bot, and the last halo_top owned rows) and the halo rows
+// themselves; their blocks are dispatched first and finish early, each wave bumps Ctx::signal, and the exchange starts
+// on the comm stream as soon as the counter is complete -- while the interior chunks of the same launch are still
+// running, in the CU slots the class A blocks have vacated.
+struct ChunkLayout {
+    int64_t seg_row[4];
+    int64_t seg_rpc[3];
+    int seg_chunk[4];
+    int nchunks;    // all runs together
+    int class_a;    // chunks of runs 0 and 2
+};
+static void slab_interface_rows(const Ctx* c, int64_t* A, int64_t* B) {
+    *A = c->top > 0 ? c->top + c->halo_bot : 0;
+    *B = c->bot > 0 ? c->g.n0 - c->bot - c->halo_top : c->g.n0;
+}
+// choose_chunks(rows, extra_blocks_per_xcd) -> number of equal chunks for `rows` rows when every XCD also hosts that
+// many other blocks
+template <typename F>
+static ChunkLayout make_layout(const Ctx* c, int nbx, int K, F&& choose_chunks) {
+    ChunkLayout l{};
+    const int64_t n0 = c->g.n0;
+    int64_t A = 0, B = n0;
+    if (c->signalling) slab_interface_rows(c, &A, &B);
+    if (!c->signalling || B - A < 16 * K) {
+        // one run (a slab too short to have an interior worth the name: the whole launch signals as class A below)
+        const int64_t nc = choose_chunks(n0, 0);
+        const int64_t rpc = (n0 + nc - 1) / nc;
+        const int real = (int)((n0 + rpc - 1) / rpc);
+        const bool all_a = c->signalling;
+        l.seg_row[0] = 0;
+        l.seg_row[1] = all_a ? n0 : 0;
+        l.seg_row[2] = l.seg_row[3] = n0;
+        l.seg_rpc[0] = l.seg_rpc[1] = l.seg_rpc[2] = rpc;
+        l.seg_chunk[0] = 0;
+        l.seg_chunk[1] = all_a ? real : 0;
+        l.seg_chunk[2] = l.seg_chunk[3] = real;
+        l.nchunks = real;
+        l.class_a = all_a ? real : 0;
+        return l;
     }
-    if (cbt + cbb >= nchunks) return c->part == 1 ? all : ChunkSel{0, INT32_MAX, 0};  // no interior to speak of
-    if (c->part == 1) return ChunkSel{(int)(cbt + cbb), (int)cbt, (int)(nchunks - cbt - cbb)};
-    return ChunkSel{(int)(nchunks - cbt - cbb), 0, (int)cbt};
+    auto short_run = [&](int64_t rows, int64_t* rpc) -> int {  // chunks of at most ~48 rows
+        if (rows <= 0) { *rpc = 1; return 0; }
+        const int64_t n = (rows + 47) / 48;
+        *rpc = (rows + n - 1) / n;
+        return (int)((rows + *rpc - 1) / *rpc);
+    };
+    const int c0 = short_run(A, &l.seg_rpc[0]);
+    const int c2 = short_run(n0 - B, &l.seg_rpc[2]);
+    const int64_t extra = ((int64_t)nbx * (c0 + c2) + 7) / 8;
+    const int64_t nc = choose_chunks(B - A, extra);
+    l.seg_rpc[1] = (B - A + nc - 1) / nc;
+    const int c1 = (int)((B - A + l.seg_rpc[1] - 1) / l.seg_rpc[1]);
+    l.seg_row[0] = 0; l.seg_row[1] = A; l.seg_row[2] = B; l.seg_row[3] = n0;
+    l.seg_chunk[0] = 0; l.seg_chunk[1] = c0; l.seg_chunk[2] = c0 + c1; l.seg_chunk[3] = c0 + c1 + c2;
+    l.nchunks = c0 + c1 + c2;
+    l.class_a = c0 + c2;
+    return l;
+}
+template <typename T>
+static unsigned apply_layout(Ctx* c, FusedArgs<T>& a, const ChunkLayout& l, int nbx) {
+    for (int i = 0; i < 4; ++i) { a.seg_row[i] = l.seg_row[i]; a.seg_chunk[i] = l.seg_chunk[i]; }
+    for (int i = 0; i < 3; ++i) a.seg_rpc[i] = l.seg_rpc[i];
+    a.nchunks = l.nchunks;
+    a.signal = c->signalling ? c->signal : nullptr;
+    c->signal_pending = c->signalling ? (unsigned)l.class_a * (unsigned)a.nstrips : 0u;
+    // grid of a launch whose blocks are dealt to tiles by block_to_tile_sub
+    const int64_t ta = (int64_t)nbx * l.class_a, tb = (int64_t)nbx * (l.nchunks - l.class_a);
+    return (unsigned)(8 * ((ta + 7) / 8 + (tb + 7) / 8));
 }
 
-// the main stream waits (on the device) for interface launches and exchanges still in flight
+// the main stream waits (on the device) for an exchange still in flight
 static int slab_join(Ctx* c) {
-    if (c->pendB) { DXH_HIP(hipStreamWaitEvent(c->stream, c->eB, 0)); c->pendB = false; }
     if (c->pendC) { DXH_HIP(hipStreamWaitEvent(c->stream, c->eC, 0)); c->pendC = false; }
     return DXH_OK;
 }
@@ -298,30 +353,25 @@ static void launch_fused_v(Ctx* c, int in, int out) {
     a.pitch = c->g.pitch;
     a.nstrips = (int)((c->g.L + SG::STRIDE - 1) / SG::STRIDE);
     const int nbx = (a.nstrips + 3) / 4;
-    // size the grid to the machine: c->waves_per_cu waves per CU, every wave the same number of rows,
-    // the number of row chunks a multiple of 8 (one chunk row per XCD, block_to_tile)
-    const int64_t target_blocks = (int64_t)c->num_cu * (c->waves_per_cu ? c->waves_per_cu : 8) / 4;
-    int64_t nchunks = std::max<int64_t>(1, target_blocks / nbx);
+    // size the grid to the machine: c->waves_per_cu waves per CU, every wave the same number of rows
     const bool remap = !(c->tune & 4);
-    if (remap && nchunks >= 8) nchunks = nchunks / 8 * 8;
-    int64_t rpc = std::max<int64_t>(8, (c->g.n0 + nchunks - 1) / nchunks);
-    nchunks = (c->g.n0 + rpc - 1) / rpc;
-    a.rows_per_chunk = rpc;
-    a.nchunks = (int)nchunks;
+    auto choose = [&](int64_t rows, int64_t extra_per_xcd) -> int64_t {
+        const int64_t target_blocks = (int64_t)c->num_cu * (c->waves_per_cu ? c->waves_per_cu : 8) / 4 - 8 * extra_per_xcd;
+        int64_t nchunks = std::max<int64_t>(1, target_blocks / nbx);
+        const int64_t rpc = std::max<int64_t>(8, (rows + nchunks - 1) / nchunks);
+        return (rows + rpc - 1) / rpc;
+    };
+    const ChunkLayout lay = make_layout(c, nbx, 1, choose);
+    const unsigned grid = apply_layout(c, a, lay, nbx);
     a.remap = remap ? 1 : 0;
-    const ChunkSel sel = select_chunks(c, nchunks, rpc, 1);
-    if (sel.n == 0) return;
-    a.chunk_n = sel.n;
-    a.chunk_gap_at = sel.gap_at;
-    a.chunk_gap = sel.gap;
     a.inc_partial = nullptr;
     a.nwaves_total = 0;
     a.c = make_coef<T>(c);
     a.cp = make_planes<T>(c);
     a.ci = make_coefin<T>(c);
     a.derive = (HET && c->in_valid && !(c->tune & 32)) ? 1 : 0;  // DXH_FUSED_TUNE bit 32: read the four derived planes
-    hipLaunchKernelGGL((k_fused<T, C, COUPLED, ISO, HET, DPP, ALIGN, NTS>), dim3((unsigned)(nbx * sel.n)), dim3(256), 0,
-                       c->part_stream ? c->part_stream : c->stream, a);
+    hipLaunchKernelGGL((k_fused<T, C, COUPLED, ISO, HET, DPP, ALIGN, NTS>),
+                       dim3(remap ? grid : (unsigned)(nbx * lay.nchunks)), dim3(256), 0, c->stream, a);
 }
 
 template <typename T, int C, bool COUPLED, bool ISO, bool HET, bool DPP>
@@ -364,47 +414,44 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
     const int nbx = pair ? (a.nstrips + 1) / 2 : (a.nstrips + 3) / 4;
     // Row chunks.  Array coefficients: grid sized for 24 waves per CU (measured best of 8..32).  Scalar coefficients:
     // all blocks take the same time, so the cost of a chunk count is (rows per chunk + pipeline fill) x the issue time of
-    // the busiest CU's blocks, W of them co-resident (pipe_waves: 3 for float, 2 for double at K >= 3); candidates are
-    // multiples of 8 (XCD-aware tile map).
-    int64_t nchunks;
-    if (c->waves_per_cu || c->het) {
-        const int64_t target_blocks = (int64_t)c->num_cu * (c->waves_per_cu ? c->waves_per_cu : 24) / 4;
-        nchunks = std::max<int64_t>(1, target_blocks / nbx);
-        if (nchunks >= 8) nchunks = nchunks / 8 * 8;
-    } else {
-        constexpr int W = pipe_waves<T, K, false>();  // blocks resident per CU (one wave of each per SIMD)
-        const double capacity = (double)c->num_cu * W;
-        // issue cost of one VALU instruction per SIMD with 1 / 2 / 3 / 4 waves taking turns (tools/valubench.hip)
-        static const double cpi[5] = {0.0, 6.6, 3.7, 3.5, 3.2};  // 3: fitted to chunk sweeps of this kernel (a third wave adds ~8 %)
-        double best = 1e300;
-        nchunks = 1;
-        for (int64_t nc = 1; nc <= std::max<int64_t>(1, c->g.n0 / (8 * K)); nc = nc < 8 ? nc + 1 : nc + 8) {
-            const int64_t rpc_c = (c->g.n0 + nc - 1) / nc;
-            const int64_t real = (c->g.n0 + rpc_c - 1) / rpc_c;
-            const double ratio = (double)(real * nbx) / capacity;
-            // The busiest CU decides.  It runs ceil(blocks / CUs) blocks: whole rounds of W co-resident blocks, then a
-            // remainder round at lower occupancy (measured on 4000 x 8000 x 3 float: 24 chunks = one full round beat
-            // 32 chunks by 11 % and 16 chunks by 6 %; the same model picks within 1 % of the best count for float64,
-            // where the earlier "rounds x rows" model was 5-6 % off)
-            const int64_t per_cu = (real * nbx + c->num_cu - 1) / c->num_cu;
-            const int64_t full = per_cu / W, rem = per_cu - full * W;
-            const double cost = (double)(rpc_c + 2 * K + 2) * ((double)full * W * cpi[W] + (double)rem * cpi[rem]);
-            if (cost < best * 0.999) { best = cost; nchunks = real; }
-            if (ratio > 4.5) break;
+    // the busiest CU's blocks, W of them co-resident (pipe_waves: 3 for float, 2 for double at K >= 3).  Any count
+    // will do: the tile map (block_to_tile_sub) keeps neighbouring tiles on one XCD whatever the count.
+    auto choose = [&](int64_t rows, int64_t extra_per_xcd) -> int64_t {
+        int64_t nchunks;
+        if (c->waves_per_cu || c->het) {
+            const int64_t target_blocks = (int64_t)c->num_cu * (c->waves_per_cu ? c->waves_per_cu : 24) / 4 - 8 * extra_per_xcd;
+            nchunks = std::max<int64_t>(1, target_blocks / nbx);
+        } else {
+            constexpr int W = pipe_waves<T, K, false>();  // blocks resident per CU (one wave of each per SIMD)
+            // issue cost of one VALU instruction per SIMD with 1 / 2 / 3 / 4 waves taking turns (tools/valubench.hip)
+            static const double cpi[5] = {0.0, 6.6, 3.7, 3.5, 3.2};  // 3: fitted to chunk sweeps of this kernel (a third wave adds ~8 %)
+            const int64_t cu_per_xcd = std::max(1, c->num_cu / 8);
+            double best = 1e300;
+            nchunks = 1;
+            const bool any = !(c->tune & 1024);  // DXH_FUSED_TUNE bit 1024: multiples of 8 only (the round-1 rule)
+            for (int64_t nc = 1; nc <= std::max<int64_t>(1, rows / (8 * K)); nc = (any || nc < 8) ? nc + 1 : nc + 8) {
+                const int64_t rpc_c = (rows + nc - 1) / nc;
+                const int64_t real = (rows + rpc_c - 1) / rpc_c;
+                // The busiest CU decides.  An XCD gets ceil(tiles / 8) blocks, its busiest CU ceil(that / CUs per XCD):
+                // whole rounds of W co-resident blocks, then a remainder round at lower occupancy (measured on
+                // 4000 x 8000 x 3 float: 24 chunks = one full round beat 32 chunks by 11 % and 16 chunks by 6 %)
+                const int64_t per_xcd = (real * nbx + 7) / 8 + extra_per_xcd;
+                const int64_t per_cu = (per_xcd + cu_per_xcd - 1) / cu_per_xcd;
+                const int64_t full = per_cu / W, rem = per_cu - full * W;
+                const double cost = (double)(rpc_c + 2 * K + 2) * ((double)full * W * cpi[W] + (double)rem * cpi[rem]);
+                if (cost < best * 0.999) { best = cost; nchunks = real; }
+                if ((double)(real * nbx) / ((double)c->num_cu * W) > 4.5) break;
+            }
         }
-    }
-    if (c->force_chunks > 0) nchunks = c->force_chunks;  // developer knob DXH_NCHUNKS
-    if (c->tune & 512) fprintf(stderr, "[dxh] K=%d strips=%d blocks/chunk=%d chunks=%lld div3=%d\n", K, a.nstrips, nbx, (long long)nchunks, c->c_div3);
-    int64_t rpc = std::max<int64_t>(8 * K, (c->g.n0 + nchunks - 1) / nchunks);
-    nchunks = (c->g.n0 + rpc - 1) / rpc;
-    a.rows_per_chunk = rpc;
-    a.nchunks = (int)nchunks;
+        if (c->force_chunks > 0) nchunks = c->force_chunks;  // developer knob DXH_NCHUNKS
+        const int64_t rpc = std::max<int64_t>(8 * K, (rows + nchunks - 1) / nchunks);
+        return (rows + rpc - 1) / rpc;
+    };
+    const ChunkLayout lay = make_layout(c, nbx, K, choose);
+    const unsigned grid = apply_layout(c, a, lay, nbx);
+    const int64_t nchunks = lay.nchunks;
+    if (c->tune & 512) fprintf(stderr, "[dxh] K=%d strips=%d blocks/chunk=%d chunks=%d (%d interface-first) rpc=%lld div3=%d\n", K, a.nstrips, nbx, lay.nchunks, lay.class_a, (long long)lay.seg_rpc[1], c->c_div3);
     a.remap = 1;
-    const ChunkSel sel = select_chunks(c, nchunks, rpc, K);
-    if (sel.n == 0) return;
-    a.chunk_n = sel.n;
-    a.chunk_gap_at = sel.gap_at;
-    a.chunk_gap = sel.gap;
     a.inc_partial = nullptr;
     a.nwaves_total = (int)(nchunks * a.nstrips);
     if (want_inc) {
@@ -424,8 +471,7 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
     a.ci = make_coefin<T>(c);
     a.derive = c->het ? 1 : 0;  // array coefficients (multi_supported: only with the given planes at hand, K = kHetFuseK)
     // the kernels are instantiated in dxh_multi.hip (one object per element type and K, built in parallel)
-    launch_multi_kernel<T, K>(C, COUPLED, ISO, want_inc, pair, a, (unsigned)(nbx * sel.n),
-                              c->part_stream ? c->part_stream : c->stream);
+    launch_multi_kernel<T, K>(C, COUPLED, ISO, want_inc, pair, a, grid, c->stream);
 }
 
 // channel counts the multi-iteration kernel is instantiated for
@@ -681,6 +727,7 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
     const bool iso = flags & DXH_FLAG_ISOTROPIC;
     const bool use_eps = eps >= 0.0 && !std::isnan(eps);
     const bool use_tol = jacobi_tol >= 0.0 && !std::isnan(jacobi_tol);
+    c->signalling = false;  // only dxh_tvd_run_slab builds signalling launches
     const bool dpp = !(flags & DXH_FLAG_NO_DPP);
     bool fused_ok = fused_supported(c) && jacobi_maxiter == 1 && !use_tol && !(flags & DXH_FLAG_NO_FUSED) && !c->solver;
     const int dim = c->desc.dim;
@@ -865,10 +912,29 @@ static int64_t slab_own1(const Ctx* c) { return c->g.n0 - c->bot; }
 // plane, so the row blocks go out of / come into the planes directly.  What I send up is what the upper slab keeps as
 // its bottom halo (my first halo_bot owned rows); what I send down is the lower slab's top halo (my last halo_top owned
 // rows).
-static int start_exchange(Ctx* c, hipEvent_t after) {
+// Polls the interface-wave counter (fallback when hipStreamWaitValue32 is not available).  One lane; ends when the
+// counter has reached `target` (cyclic compare) or, so that the stream can never hang, after ~10 s of wall clock.
+__global__ void k_wait_counter(const unsigned* counter, unsigned target) {
+    const long long t0 = wall_clock64();
+    while ((int)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        __builtin_amdgcn_s_sleep(32);
+        if (wall_clock64() - t0 > 1000000000LL) break;  // 100 MHz
+    }
+}
+
+static int start_exchange(Ctx* c, bool after_signal) {
     Comm* cm = c->comm;
     if (c->from_db) { set_error("halo exchange before the first iteration of a warm start is not supported"); return DXH_ESTATE; }
-    DXH_HIP(hipStreamWaitEvent(cm->stream, after, 0));
+    if (after_signal) {
+        // start as soon as every interface wave of the launch just enqueued has released its rows
+        if (c->wait_mode == 1)
+            DXH_HIP(hipStreamWaitValue32(cm->stream, c->signal, c->signal_target, hipStreamWaitValueGte, 0xffffffffu));
+        else
+            hipLaunchKernelGGL(k_wait_counter, dim3(1), dim3(1), 0, cm->stream, c->signal, c->signal_target);
+    } else {
+        DXH_HIP(hipEventRecord(c->eM, c->stream));
+        DXH_HIP(hipStreamWaitEvent(cm->stream, c->eM, 0));
+    }
     const size_t row_bytes = (size_t)c->g.pitch * c->esz;
     void* fields[4] = {c->u[c->cur], c->q[0][c->cur], c->q[1][c->cur], c->q[2][c->cur]};
     const int nf = 1 + c->desc.dim;
@@ -876,14 +942,17 @@ static int start_exchange(Ctx* c, hipEvent_t after) {
     int n = 0;
     const int64_t o0 = slab_own0(c), o1 = slab_own1(c);
     auto rows = [&](int f, int64_t r0) { return static_cast<char*>(fields[f]) + (size_t)r0 * row_bytes; };
-    if (c->top > 0) {
-        for (int f = 0; f < nf; ++f) ops[n++] = P2POp{cm->rank - 1, rows(f, o0), (size_t)c->halo_bot * row_bytes, 1};
-        for (int f = 0; f < nf; ++f) ops[n++] = P2POp{cm->rank - 1, rows(f, 0), (size_t)c->top * row_bytes, 0};
-    }
-    if (c->bot > 0) {
-        for (int f = 0; f < nf; ++f) ops[n++] = P2POp{cm->rank + 1, rows(f, o1 - c->halo_top), (size_t)c->halo_top * row_bytes, 1};
-        for (int f = 0; f < nf; ++f) ops[n++] = P2POp{cm->rank + 1, rows(f, o1), (size_t)c->bot * row_bytes, 0};
-    }
+    // A single rank whose slab has halos on both sides is its own neighbour (periodic in axis 0): sends first, then the
+    // receives in the order that pairs them with those sends (what goes up fills a bottom halo).
+    const int up = (cm->rank - 1 + cm->world) % cm->world, down = (cm->rank + 1) % cm->world;
+    if (c->top > 0)
+        for (int f = 0; f < nf; ++f) ops[n++] = P2POp{up, rows(f, o0), (size_t)c->halo_bot * row_bytes, 1};
+    if (c->bot > 0)
+        for (int f = 0; f < nf; ++f) ops[n++] = P2POp{down, rows(f, o1 - c->halo_top), (size_t)c->halo_top * row_bytes, 1};
+    if (c->bot > 0)
+        for (int f = 0; f < nf; ++f) ops[n++] = P2POp{down, rows(f, o1), (size_t)c->bot * row_bytes, 0};
+    if (c->top > 0)
+        for (int f = 0; f < nf; ++f) ops[n++] = P2POp{up, rows(f, 0), (size_t)c->top * row_bytes, 0};
     int rc = comm_exchange(cm, ops, n);
     if (rc) return rc;
     DXH_HIP(hipEventRecord(c->eC, cm->stream));
@@ -896,8 +965,7 @@ static int start_exchange(Ctx* c, hipEvent_t after) {
 static int exchange_now(Ctx* c) {
     int rc = slab_join(c);
     if (rc) return rc;
-    DXH_HIP(hipEventRecord(c->eM, c->stream));
-    return start_exchange(c, c->eM);
+    return start_exchange(c, false);
 }
 
 template <typename T>
@@ -909,7 +977,7 @@ static void launch_any(Ctx* c, int in, int out, bool iso, bool dpp, int K) {
 template <typename T>
 static int run_slab_t(Ctx* c, int n_iter, int m, double eps, uint32_t flags, dxh_tvd_result* res) {
     Comm* cm = c->comm;
-    const bool dist = cm && cm->world > 1;
+    const bool dist = cm && (c->top > 0 || c->bot > 0);
     const bool iso = flags & DXH_FLAG_ISOTROPIC;
     const bool use_eps = eps >= 0.0 && !std::isnan(eps);
     const bool dpp = !(flags & DXH_FLAG_NO_DPP);
@@ -961,35 +1029,22 @@ static int run_slab_t(Ctx* c, int n_iter, int m, double eps, uint32_t flags, dxh
             const int in = c->cur, out = c->cur ^ 1;
             const bool xchg_after = dist && (c->halo_valid - (int64_t)K * m < m) &&
                                     (done + K < n_iter || (flags & DXH_FLAG_CONTINUE)) && !use_eps;
-            if (overlap && (xchg_after || c->pendC)) {
-                // interface chunks on their own stream: behind everything the main stream has been given so far and behind
-                // the exchange in flight (whose rows they read); interior chunks on the main stream, behind the previous
-                // interface launch only
-                DXH_HIP(hipEventRecord(c->eM, c->stream));
-                DXH_HIP(hipStreamWaitEvent(c->s_bnd, c->eM, 0));
-                if (c->pendC) { DXH_HIP(hipStreamWaitEvent(c->s_bnd, c->eC, 0)); c->pendC = false; }
-                if (c->pendB) DXH_HIP(hipStreamWaitEvent(c->stream, c->eB, 0));
-                c->part = 1;
-                c->part_stream = c->s_bnd;
-                launch_any<T>(c, in, out, iso, dpp, K);
-                DXH_HIP(hipEventRecord(c->eB, c->s_bnd));
-                c->pendB = true;
-                c->part = 2;
-                c->part_stream = nullptr;
-                launch_any<T>(c, in, out, iso, dpp, K);
-                c->part = 0;
+            // behind the exchange in flight, whose rows this launch reads
+            if ((rc = slab_join(c))) return rc;
+            // the launch in front of an exchange runs its interface chunks first and counts them (make_layout)
+            c->signalling = overlap && xchg_after;
+            launch_any<T>(c, in, out, iso, dpp, K);
+            if (c->signalling) {
+                c->signal_target += c->signal_pending;
                 ++c->split_launches;
-            } else {
-                if ((rc = slab_join(c))) return rc;
-                launch_any<T>(c, in, out, iso, dpp, K);
             }
             DXH_HIP(hipGetLastError());
             ++launches;
             c->cur = out;
             c->halo_valid -= (int64_t)K * m;
             if (xchg_after) {
-                if (overlap) rc = start_exchange(c, c->eB);
-                else rc = exchange_now(c);
+                rc = c->signalling ? start_exchange(c, true) : exchange_now(c);
+                c->signalling = false;
                 if (rc) return rc;
             }
         } else {
@@ -1211,12 +1266,11 @@ int dxh_tvd_destroy(dxh_tvd_t h) {
     Ctx* c = reinterpret_cast<Ctx*>(h);
     if (!c) return DXH_OK;
     (void)hipSetDevice(c->desc.device);
-    if (c->s_bnd) (void)hipStreamSynchronize(c->s_bnd);
     if (c->comm && c->comm->stream) (void)hipStreamSynchronize(c->comm->stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->s_bnd) (void)hipStreamDestroy(c->s_bnd);
-    for (hipEvent_t e : {c->eM, c->eB, c->eC})
+    for (hipEvent_t e : {c->eM, c->eC})
         if (e) (void)hipEventDestroy(e);
+    if (c->signal) (void)hipFree(c->signal);
     delete c->solver;
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
     fr(c->of); fr(c->u[0]); fr(c->u[1]); fr(c->rs);
@@ -1570,10 +1624,15 @@ int dxh_tvd_attach_comm(dxh_tvd_t h, dxh_comm_t comm, int64_t halo_top_rows, int
     DXH_REQUIRE(halo_top_rows >= 1 && halo_bottom_rows >= halo_top_rows + 1,
                 "halo rows (%lld above, %lld below): need k >= 1 above and at least k + 1 below",
                 (long long)halo_top_rows, (long long)halo_bottom_rows);
-    DXH_REQUIRE((cm->rank == 0) == (c->desc.top_is_boundary != 0), "rank %d of %d: top_is_boundary = %d does not fit",
-                cm->rank, cm->world, c->desc.top_is_boundary);
-    DXH_REQUIRE((cm->rank == cm->world - 1) == (c->desc.bottom_is_boundary != 0),
-                "rank %d of %d: bottom_is_boundary = %d does not fit", cm->rank, cm->world, c->desc.bottom_is_boundary);
+    // one rank with halos on both sides: the slab is its own neighbour, i.e. the problem is periodic along axis 0 (lets
+    // the whole exchange / overlap machinery run on a single GPU)
+    const bool periodic = cm->world == 1 && !c->desc.top_is_boundary && !c->desc.bottom_is_boundary;
+    if (!periodic) {
+        DXH_REQUIRE((cm->rank == 0) == (c->desc.top_is_boundary != 0), "rank %d of %d: top_is_boundary = %d does not fit",
+                    cm->rank, cm->world, c->desc.top_is_boundary);
+        DXH_REQUIRE((cm->rank == cm->world - 1) == (c->desc.bottom_is_boundary != 0),
+                    "rank %d of %d: bottom_is_boundary = %d does not fit", cm->rank, cm->world, c->desc.bottom_is_boundary);
+    }
     const int64_t top = c->desc.top_is_boundary ? 0 : halo_top_rows;
     const int64_t bot = c->desc.bottom_is_boundary ? 0 : halo_bottom_rows;
     // a slab must own the rows both neighbours ask for
@@ -1582,13 +1641,19 @@ int dxh_tvd_attach_comm(dxh_tvd_t h, dxh_comm_t comm, int64_t halo_top_rows, int
                 (long long)(c->g.n0 - top - bot), (long long)halo_bottom_rows);
     int rc = set_device(c);
     if (rc) return rc;
-    if (!c->s_bnd) {
-        int lo = 0, hi = 0;
-        DXH_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        DXH_HIP(hipStreamCreateWithPriority(&c->s_bnd, hipStreamNonBlocking, hi));
+    if (!c->signal) {
         DXH_HIP(hipEventCreateWithFlags(&c->eM, hipEventDisableTiming));
-        DXH_HIP(hipEventCreateWithFlags(&c->eB, hipEventDisableTiming));
         DXH_HIP(hipEventCreateWithFlags(&c->eC, hipEventDisableTiming));
+        DXH_HIP(hipMalloc((void**)&c->signal, 256));
+        DXH_HIP(hipMemset(c->signal, 0, 256));
+        c->signal_target = 0;
+        int can = 0;
+        if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->desc.device) != hipSuccess) can = 0;
+        c->wait_mode = can ? 1 : 2;
+        if (const char* e = getenv("DXH_SLAB_WAIT")) {  // developer knob: 1 stream wait-value, 2 polling kernel
+            const int v = atoi(e);
+            if (v == 1 || v == 2) c->wait_mode = v;
+        }
     }
     c->comm = cm;
     c->halo_top = halo_top_rows;
@@ -1607,7 +1672,7 @@ int dxh_tvd_exchange(dxh_tvd_t h) {
     if (!c->uploaded) { set_error("nothing uploaded"); return DXH_ESTATE; }
     int rc = set_device(c);
     if (rc) return rc;
-    if (c->comm->world == 1) return DXH_OK;
+    if (c->top == 0 && c->bot == 0) return DXH_OK;
     return exchange_now(c);
 }
 

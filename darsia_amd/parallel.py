@@ -58,18 +58,21 @@ class SlabPlan:
     rank: int
     halo_top_rows: int
     halo_bot_rows: int
+    periodic: bool = False   # world == 1 only: the image is periodic along axis 0, the slab is its own neighbour
 
     def __post_init__(self):
         if self.world < 1 or not (0 <= self.rank < self.world):
             raise ValueError("bad rank/world")
+        if self.periodic and self.world != 1:
+            raise ValueError("periodic slabs are a single-rank mode")
         self.own0 = self.rank * self.H // self.world
         self.own1 = (self.rank + 1) * self.H // self.world
-        self.top = 0 if self.rank == 0 else self.halo_top_rows
-        self.bot = 0 if self.rank == self.world - 1 else self.halo_bot_rows
+        self.top = 0 if (self.rank == 0 and not self.periodic) else self.halo_top_rows
+        self.bot = 0 if (self.rank == self.world - 1 and not self.periodic) else self.halo_bot_rows
         self.slab0 = self.own0 - self.top
         self.slab1 = self.own1 + self.bot
         smallest = min((r + 1) * self.H // self.world - r * self.H // self.world for r in range(self.world))
-        if self.world > 1 and smallest < max(self.halo_top_rows, self.halo_bot_rows):
+        if (self.world > 1 or self.periodic) and smallest < max(self.halo_top_rows, self.halo_bot_rows):
             raise ValueError(f"slabs of {smallest} rows are smaller than the halo ({self.halo_bot_rows} rows): "
                              "use fewer ranks or a smaller halo_iters")
 
@@ -83,9 +86,15 @@ class SlabPlan:
         return self.top, self.top + (self.own1 - self.own0)
 
 
-def make_plan(H: int, world: int, rank: int, halo_iters: int = 1, jacobi_maxiter: int = 1) -> SlabPlan:
+def make_plan(H: int, world: int, rank: int, halo_iters: int = 1, jacobi_maxiter: int = 1,
+              periodic: bool = False) -> SlabPlan:
     km = halo_iters * jacobi_maxiter
-    return SlabPlan(H, world, rank, halo_top_rows=km, halo_bot_rows=km + 1)
+    return SlabPlan(H, world, rank, halo_top_rows=km, halo_bot_rows=km + 1, periodic=periodic)
+
+
+def periodic_slab(img: np.ndarray, plan: SlabPlan) -> np.ndarray:
+    """The slab of a periodic single-rank plan: the image with its last rows above and its first rows below."""
+    return np.ascontiguousarray(np.concatenate([img[img.shape[0] - plan.top:], img, img[:plan.bot]], axis=0))
 
 
 # ---- host transports (rehearsals, tests) ---------------------------------------------------------------------------
@@ -389,7 +398,7 @@ class SlabTVD:
         for name, c in (("mu", mu), ("omega", omega), ("ell", ell)):
             if isinstance(c, np.ndarray) and c.ndim > 0 and c.shape[0] != plan.rows:
                 raise ValueError(f"array-valued {name} must be given per slab ({plan.rows} rows)")
-        boundary = (plan.rank == 0, plan.rank == plan.world - 1)
+        boundary = (plan.top == 0, plan.bot == 0)
         self.world, self.rank = plan.world, plan.rank
         self.transport = transport
         if engine_factory is None:

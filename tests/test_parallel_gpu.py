@@ -148,6 +148,44 @@ def test_rccl_single_rank_communicator(tmp_path):
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("case", [
+    dict(shape=(700, 420, 3), halo_iters=8, n_iter=40, flags=0),
+    dict(shape=(700, 420, 3), halo_iters=8, n_iter=40, flags="no_overlap"),
+    dict(shape=(1500, 260), halo_iters=20, n_iter=100, flags=0, parts=[60, 40]),
+    dict(shape=(300, 200, 3), halo_iters=1, n_iter=7, flags=0),
+], ids=["rgb_k8", "rgb_k8_no_overlap", "gray_k20_steps", "rgb_k1"])
+def test_rccl_self_neighbour_periodic(case):
+    """RCCL send/recv on ONE GPU: a single rank whose slab has halos on both sides exchanges with itself, which makes
+    the problem periodic along axis 0.  Reference: the same image tiled three times with replicate ends -- after n
+    iterations the ends have influenced at most n + 1 rows, so the middle copy is the periodic result exactly.  Runs the
+    real RCCL enqueue path, the comm stream, the interface-first launch order and the overlap."""
+    import darsia_amd as da
+    from darsia_amd import _lib
+    from darsia_amd.parallel import Comm, SlabTVD, make_plan, periodic_slab
+
+    img = np.random.default_rng(8).random(case["shape"]).astype(np.float32)
+    H, n = img.shape[0], case["n_iter"]
+    assert n + 2 < H
+    os.environ["MASTER_PORT"] = str(_free_port())
+    comm = Comm.rccl(0, 1, device=0)
+    try:
+        plan = make_plan(H, 1, 0, case["halo_iters"], periodic=True)
+        flags = _lib.FLAG_NO_OVERLAP if case["flags"] == "no_overlap" else 0
+        s = SlabTVD(plan, periodic_slab(img, plan), mu=0.1, halo_iters=case["halo_iters"], comm=comm, flags=flags)
+        done = 0
+        for part in case.get("parts", [n]):
+            done += s.run(part, more_to_come=done + part < n, asynchronous=True)
+        got = s.owned_result()
+        xchg = comm.info()["exchanges"]
+        s.close()
+    finally:
+        comm.close()
+    tiled = np.ascontiguousarray(np.concatenate([img, img, img], axis=0))
+    ref = da.split_bregman_tvd(tiled, mu=0.1, max_num_iter=n)[H:2 * H]
+    assert np.array_equal(got, ref), f"max abs {np.abs(got - ref).max():.3e}"
+    assert xchg == -(-n // case["halo_iters"]) - 1
+
+
 def test_rccl_one_rank_per_gpu(tmp_path):
     """The product transport: one process per GPU, RCCL send/recv between slab neighbours (needs >= 2 GPUs)."""
     from darsia_amd import _lib
