@@ -34,6 +34,7 @@ EXPORTS = (
     "dxh_tvd_energy", "dxh_tvd_adapt_ell", "dxh_tvd_set_base", "dxh_tvd_set_cleaning_filter", "dxh_tvd_upload_signal", "dxh_tvd_download_model",
     "dxh_comm_unique_id", "dxh_comm_create_rccl", "dxh_comm_create_host", "dxh_comm_destroy", "dxh_comm_allreduce",
     "dxh_comm_barrier", "dxh_comm_info", "dxh_tvd_attach_comm", "dxh_tvd_exchange", "dxh_tvd_run_slab",
+    "dxh_mem_alloc", "dxh_mem_free", "dxh_mem_copy",
 )
 
 # host-staged transport callbacks (include/darsia_hip.h: dxh_comm_exchange_fn, dxh_comm_allreduce_fn)
@@ -142,6 +143,9 @@ def _declare(lib):
     lib.dxh_tvd_set_cleaning_filter.argtypes = [vp, vp]
     lib.dxh_tvd_upload_signal.argtypes = [vp, vp, i, i, i, vp, i]
     lib.dxh_tvd_download_model.argtypes = [vp, vp, vp, i]
+    lib.dxh_mem_alloc.argtypes = [i, C.c_size_t, C.POINTER(vp)]
+    lib.dxh_mem_free.argtypes = [i, vp]
+    lib.dxh_mem_copy.argtypes = [i, vp, vp, C.c_size_t]
     lib.dxh_comm_unique_id.argtypes = [vp]
     lib.dxh_comm_create_rccl.argtypes = [C.POINTER(vp), i, vp, i, i]
     lib.dxh_comm_create_host.argtypes = [C.POINTER(vp), i, i, i, COMM_EXCHANGE_FN, COMM_ALLREDUCE_FN, vp]
@@ -206,9 +210,11 @@ def dtype_code(dt) -> int:
 
 
 def ptr(a):
-    """Pointer to a C-contiguous ndarray (or None)."""
+    """Pointer to a C-contiguous ndarray or a DeviceArray (or None)."""
     if a is None:
         return None
+    if not isinstance(a, np.ndarray):
+        return C.c_void_p(a.ptr)   # darsia_amd.device.DeviceArray: dense by construction
     assert a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(C.c_void_p)
 

@@ -10,6 +10,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import _lib
+from .device import DeviceArray
 
 _IN_CODES = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.uint8): 2, np.dtype(np.uint16): 3}
 
@@ -18,8 +19,8 @@ def apply_affine_balance(img: np.ndarray, scaling: np.ndarray, translation=None,
     """``img_as_float(img) @ scaling + translation`` (optionally clipped to [0, 1]) as float32.
 
     ``img``: (..., 3) array of uint8 / uint16 / float32 / float64 (integer types are scaled to [0, 1] like
-    ``skimage.img_as_float``)."""
-    if not isinstance(img, np.ndarray) or img.shape[-1] != 3:
+    ``skimage.img_as_float``).  A ``DeviceArray`` in gives a ``DeviceArray`` out (nothing crosses PCIe)."""
+    if not isinstance(img, (np.ndarray, DeviceArray)) or img.shape[-1] != 3:
         raise ValueError("img must be an array with a trailing axis of 3 colour channels")
     if img.dtype not in _IN_CODES:
         raise ValueError("Provide image in np.uint8, np.uint16, np.float32, or np.float64 format.")
@@ -30,9 +31,13 @@ def apply_affine_balance(img: np.ndarray, scaling: np.ndarray, translation=None,
     if b.shape != (3,):
         raise ValueError("translation must have 3 entries")
     _lib.require_gpu()
-    src = np.ascontiguousarray(img)
-    out = np.empty(src.shape, np.float32)
-    _lib.check(_lib.load().dxh_affine_color(_lib.default_device(), _IN_CODES[src.dtype], src.size // 3, _lib.ptr(src),
+    if isinstance(img, DeviceArray):
+        src, device = img, img.device
+        out = DeviceArray(src.shape, np.float32, device)
+    else:
+        src, device = np.ascontiguousarray(img), _lib.default_device()
+        out = np.empty(src.shape, np.float32)
+    _lib.check(_lib.load().dxh_affine_color(device, _IN_CODES[src.dtype], src.size // 3, _lib.ptr(src),
                                              _lib.ptr(a), _lib.ptr(b), int(bool(clip)), _lib.ptr(out)))
     return out
 

@@ -197,7 +197,7 @@ int run_gs(int64_t rows, int64_t cols, int64_t dims, const void* image, void* ou
         DXH_HIP(hipMalloc((void**)&part, sizeof(double) * part_per_sweep * batch));
         DXH_HIP(hipMalloc((void**)&stage, sizeof(double) * 256));
         DXH_HIP(hipMalloc((void**)&red, sizeof(double) * batch));
-        DXH_HIP(hipMemcpyAsync(d_img, image, dense, hipMemcpyHostToDevice, nullptr));
+        DXH_HIP(hipMemcpyAsync(d_img, image, dense, hipMemcpyDefault, nullptr));
         a.u = (T*)bufs[0]; a.dx = (T*)bufs[1]; a.dy = (T*)bufs[2]; a.bx = (T*)bufs[3]; a.by = (T*)bufs[4];
         a.f = (const T*)bufs[5];
         a.part = part;
@@ -218,7 +218,7 @@ int run_gs(int64_t rows, int64_t cols, int64_t dims, const void* image, void* ou
                 hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, nullptr, stage, 256, red + s2);
             }
             DXH_HIP(hipGetLastError());
-            DXH_HIP(hipMemcpy(sq, red, sizeof(double) * S, hipMemcpyDeviceToHost));
+            DXH_HIP(hipMemcpy(sq, red, sizeof(double) * S, hipMemcpyDefault));
             return DXH_OK;
         };
         int done = 0;
@@ -249,7 +249,7 @@ int run_gs(int64_t rows, int64_t cols, int64_t dims, const void* image, void* ou
         hipLaunchKernelGGL((k_gs_final<T>), dim3(2048), dim3(256), 0, nullptr, a, (T*)d_out);
         DXH_HIP(hipGetLastError());
         pf.join();
-        DXH_HIP(hipMemcpy(out, d_out, dense, hipMemcpyDeviceToHost));
+        DXH_HIP(hipMemcpy(out, d_out, dense, hipMemcpyDefault));
         if (iters) *iters = done;
         if (rmse_out) *rmse_out = rmse;
         return DXH_OK;

@@ -629,7 +629,7 @@ static int chambolle_t(int device, int ndim, int64_t n0, int64_t n1, int64_t n2,
         DXH_HIP(hipMalloc((void**)&red, sizeof(double)));
         DXH_HIP(hipMalloc((void**)&stage2, sizeof(double) * 256));
         DXH_HIP(hipMemcpy2DAsync(bufs[0], g.pitch * sizeof(T), img, g.L * sizeof(T), g.L * sizeof(T), n0,
-                                 hipMemcpyHostToDevice, st));
+                                 hipMemcpyDefault, st));
         DXH_HIP(hipMemcpyAsync(bufs[1], bufs[0], plane, hipMemcpyDeviceToDevice, st));  // out = image (iteration 0)
         // p is double buffered: pbuf[ax][0/1]; `out` is only written after the loop
         void* p2[3] = {nullptr, nullptr, nullptr};
@@ -697,7 +697,7 @@ static int chambolle_t(int device, int ndim, int64_t n0, int64_t n1, int64_t n2,
             hipLaunchKernelGGL(k_sum_partials, dim3(256), dim3(256), 0, st, part, reduce_count, stage2);
             hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, stage2, 256, red);
             DXH_HIP(hipGetLastError());
-            DXH_HIP(hipMemcpyAsync(host, red, sizeof(double), hipMemcpyDeviceToHost, st));
+            DXH_HIP(hipMemcpyAsync(host, red, sizeof(double), hipMemcpyDefault, st));
             DXH_HIP(hipStreamSynchronize(st));
             return DXH_OK;
         };
@@ -804,7 +804,7 @@ static int chambolle_t(int device, int ndim, int64_t n0, int64_t n1, int64_t n2,
         if (iters_done) *iters_done = it;
         pf.join();
         DXH_HIP(hipMemcpy2DAsync(out, g.L * sizeof(T), bufs[1], g.pitch * sizeof(T), g.L * sizeof(T), n0,
-                                 hipMemcpyDeviceToHost, st));
+                                 hipMemcpyDefault, st));
         DXH_HIP(hipStreamSynchronize(st));
         return DXH_OK;
     };

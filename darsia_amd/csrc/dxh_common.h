@@ -51,6 +51,19 @@ inline hipError_t cached_stream(int device, hipStream_t* out) {
     return hipSuccess;
 }
 
+// Image arrays handed to the C ABI may live on the host or on the device (dxh_mem_alloc): every copy of caller data
+// uses hipMemcpyDefault, which resolves the direction from the pointers.  This tells the two apart where host-only
+// work (page touching) is concerned; an address the runtime does not know is ordinary host memory.
+inline bool is_device_ptr(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return at.type == hipMemoryTypeDevice;
+}
+
 // Maps the pages of a (large) host output buffer on a helper thread while the device works.  A device-to-host
 // copy into never-touched pages is slowed down by the page faults (384 MB: 22-36 ms instead of 7 ms, measured); the
 // buffer is going to be overwritten completely, so writing one zero per page beforehand is harmless.  join() before
@@ -60,7 +73,7 @@ struct HostPrefault {
     // `inputs`: host buffers the call still has to read -- an output that overlaps one of them (in-place use of the
     // C ABI) must not be touched
     void start(void* p, size_t n, std::initializer_list<std::pair<const void*, size_t>> inputs = {}) {
-        if (!p || n < (size_t(8) << 20)) return;
+        if (!p || n < (size_t(8) << 20) || is_device_ptr(p)) return;
         const char* lo = static_cast<const char*>(p);
         for (const auto& in : inputs) {
             const char* a = static_cast<const char*>(in.first);

@@ -8,11 +8,15 @@
 namespace dxh {
 
 // ---- piecewise perspective warp -------------------------------------------------------------------
-// One thread per canvas pixel (all channels).  It visits the patch table in the reference's loop order
+// One thread per canvas pixel (all channels).  It visits the patches in the reference's loop order
 // (piecewiseperspective.py:71-133) and, for every patch whose effective destination rectangle covers
 // the pixel, evaluates OpenCV's float32 bilinear perspective sample (see oracle/warp_numpy.py for the
 // restated algorithm) and adds it to the pixel in float32 -- the same order of additions as the
 // reference's  canvas[roi] += tmp , hence deterministic and free of atomics.
+// A block covers kWarpBW x 1 pixels and looks only at the patches whose rectangle meets its
+// kWarpBW x kWarpBH bin of the canvas (CSR lists built on the host, table order kept): one to four
+// candidates instead of the whole table (200 records for 10 x 20 patches), and the list is block-uniform,
+// so the records come in through scalar loads.
 struct WarpPatch {
     double minv[9];              // inverse homography: destination (patch-local) -> source (patch-local)
     int sr0, sc0, sh, sw;        // source patch: origin in the base image and size
@@ -30,17 +34,22 @@ __device__ __forceinline__ long long round_half_even_clamped(double v) {
     return (long long)rint(v);            // round half to even, like cvRound / lrint
 }
 
+constexpr int kWarpBW = 256, kWarpBH = 16;
+
 template <int C>
 __global__ void __launch_bounds__(256) k_warp(const float* __restrict__ base, int H, int W, const WarpPatch* __restrict__ pt,
-                                               int npatch, float* __restrict__ canvas) {
+                                               const int* __restrict__ bin_off, const int* __restrict__ bin_idx,
+                                               float* __restrict__ canvas) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= W || y >= H) return;
     float acc[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) acc[c] = 0.f;
-    for (int k = 0; k < npatch; ++k) {
-        const WarpPatch& p = pt[k];
+    const int bin = (y / kWarpBH) * gridDim.x + blockIdx.x;
+    const int k0 = bin_off[bin], k1 = bin_off[bin + 1];
+    for (int kk = k0; kk < k1; ++kk) {
+        const WarpPatch& p = pt[bin_idx[kk]];
         const int tx = x - p.ox, ty = y - p.oy;
         if (tx < 0 || ty < 0 || tx >= p.nx || ty >= p.ny) continue;
         const int bx = (tx / p.bw0) * p.bw0;
@@ -351,20 +360,55 @@ int dxh_warp_patches(int device, int H, int W, int C, const float* base, const d
     Dev d;
     DXH_HIP(cached_stream(device, &d.st));
     const size_t bytes = (size_t)H * W * C * sizeof(float);
-    void *dbase = nullptr, *dcanvas = nullptr, *dpt = nullptr;
-    if ((rc = d.alloc(&dbase, bytes)) || (rc = d.alloc(&dcanvas, bytes)) || (rc = d.alloc(&dpt, sizeof(WarpPatch) * (size_t)npatch)))
+    // candidate lists per kWarpBW x kWarpBH bin of the canvas, patches in table order (= the reference's loop order)
+    const int nbx = (W + kWarpBW - 1) / kWarpBW, nby = (H + kWarpBH - 1) / kWarpBH;
+    std::vector<int> off((size_t)nbx * nby + 1, 0), idx;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int k = 0; k < npatch; ++k) {
+            const dxh_warp_patch& p = patches[k];
+            if (p.nx <= 0 || p.ny <= 0) continue;
+            const int bx0 = p.ox / kWarpBW, bx1 = (p.ox + p.nx - 1) / kWarpBW;
+            const int by0 = p.oy / kWarpBH, by1 = (p.oy + p.ny - 1) / kWarpBH;
+            for (int by = by0; by <= by1; ++by)
+                for (int bx = bx0; bx <= bx1; ++bx) {
+                    const size_t b = (size_t)by * nbx + bx;
+                    if (pass == 0) ++off[b + 1];
+                    else idx[off[b]++] = k;
+                }
+        }
+        if (pass == 0) {
+            for (size_t b = 0; b < (size_t)nbx * nby; ++b) off[b + 1] += off[b];
+            idx.resize((size_t)off.back() + 1);
+        } else {
+            // the fill pass advanced every offset to the end of its list: shift back
+            for (size_t b = (size_t)nbx * nby; b > 0; --b) off[b] = off[b - 1];
+            off[0] = 0;
+        }
+    }
+    void *dbase = nullptr, *dcanvas = nullptr, *dpt = nullptr, *doff = nullptr, *didx = nullptr;
+    const bool base_on_device = is_device_ptr(base), canvas_on_device = is_device_ptr(canvas);
+    DXH_REQUIRE(!(base_on_device && canvas_on_device && (const void*)base == (const void*)canvas),
+                "a device-resident canvas must not be the base image itself");
+    if ((rc = d.alloc(&dpt, sizeof(WarpPatch) * (size_t)npatch)) || (rc = d.alloc(&doff, sizeof(int) * off.size())) ||
+        (rc = d.alloc(&didx, sizeof(int) * idx.size())))
         return rc;
-    DXH_HIP(hipMemcpyAsync(dbase, base, bytes, hipMemcpyHostToDevice, d.st));
-    if (npatch) DXH_HIP(hipMemcpyAsync(dpt, patches, sizeof(WarpPatch) * (size_t)npatch, hipMemcpyHostToDevice, d.st));
-    const dim3 grid((W + 255) / 256, H), blk(256);
+    if (base_on_device) dbase = const_cast<float*>(base);
+    else if ((rc = d.alloc(&dbase, bytes))) return rc;
+    if (canvas_on_device) dcanvas = canvas;
+    else if ((rc = d.alloc(&dcanvas, bytes))) return rc;
+    if (!base_on_device) DXH_HIP(hipMemcpyAsync(dbase, base, bytes, hipMemcpyDefault, d.st));
+    if (npatch) DXH_HIP(hipMemcpyAsync(dpt, patches, sizeof(WarpPatch) * (size_t)npatch, hipMemcpyDefault, d.st));
+    DXH_HIP(hipMemcpyAsync(doff, off.data(), sizeof(int) * off.size(), hipMemcpyDefault, d.st));
+    DXH_HIP(hipMemcpyAsync(didx, idx.data(), sizeof(int) * idx.size(), hipMemcpyDefault, d.st));
+    const dim3 grid(nbx, H), blk(kWarpBW);
     if (C == 1)
-        hipLaunchKernelGGL((k_warp<1>), grid, blk, 0, d.st, (const float*)dbase, H, W, (const WarpPatch*)dpt, npatch, (float*)dcanvas);
+        hipLaunchKernelGGL((k_warp<1>), grid, blk, 0, d.st, (const float*)dbase, H, W, (const WarpPatch*)dpt, (const int*)doff, (const int*)didx, (float*)dcanvas);
     else
-        hipLaunchKernelGGL((k_warp<3>), grid, blk, 0, d.st, (const float*)dbase, H, W, (const WarpPatch*)dpt, npatch, (float*)dcanvas);
+        hipLaunchKernelGGL((k_warp<3>), grid, blk, 0, d.st, (const float*)dbase, H, W, (const WarpPatch*)dpt, (const int*)doff, (const int*)didx, (float*)dcanvas);
     DXH_HIP(hipGetLastError());
     pf.join();
-    DXH_HIP(hipMemcpyAsync(canvas, dcanvas, bytes, hipMemcpyDeviceToHost, d.st));
-    DXH_HIP(hipStreamSynchronize(d.st));
+    if (!canvas_on_device) DXH_HIP(hipMemcpyAsync(canvas, dcanvas, bytes, hipMemcpyDefault, d.st));
+    DXH_HIP(hipStreamSynchronize(d.st));  // also keeps the host-side tables alive until their copies are done
     return DXH_OK;
 }
 
@@ -387,11 +431,11 @@ int dxh_tps_eval(int device, int p, int dout, const double* centers, const doubl
     if ((rc = d.alloc(&dc, sizeof(double) * 2 * p)) || (rc = d.alloc(&dk, sizeof(double) * (p + 3) * dout)) ||
         (rc = d.alloc(&dout_, sizeof(double) * (size_t)n * dout)))
         return rc;
-    DXH_HIP(hipMemcpyAsync(dc, centers, sizeof(double) * 2 * p, hipMemcpyHostToDevice, d.st));
-    DXH_HIP(hipMemcpyAsync(dk, coeffs, sizeof(double) * (p + 3) * dout, hipMemcpyHostToDevice, d.st));
+    DXH_HIP(hipMemcpyAsync(dc, centers, sizeof(double) * 2 * p, hipMemcpyDefault, d.st));
+    DXH_HIP(hipMemcpyAsync(dk, coeffs, sizeof(double) * (p + 3) * dout, hipMemcpyDefault, d.st));
     if (points) {
         if ((rc = d.alloc(&dp, sizeof(double) * 2 * (size_t)n))) return rc;
-        DXH_HIP(hipMemcpyAsync(dp, points, sizeof(double) * 2 * (size_t)n, hipMemcpyHostToDevice, d.st));
+        DXH_HIP(hipMemcpyAsync(dp, points, sizeof(double) * 2 * (size_t)n, hipMemcpyDefault, d.st));
     }
     TpsArgs a;
     a.centers = (const double*)dc;
@@ -406,8 +450,39 @@ int dxh_tps_eval(int device, int p, int dout, const double* centers, const doubl
     hipLaunchKernelGGL(k_tps, dim3((unsigned)((n + 255) / 256)), dim3(256), smem, d.st, a);
     DXH_HIP(hipGetLastError());
     pf.join();
-    DXH_HIP(hipMemcpyAsync(out, dout_, sizeof(double) * (size_t)n * dout, hipMemcpyDeviceToHost, d.st));
+    DXH_HIP(hipMemcpyAsync(out, dout_, sizeof(double) * (size_t)n * dout, hipMemcpyDefault, d.st));
     DXH_HIP(hipStreamSynchronize(d.st));
+    return DXH_OK;
+}
+
+int dxh_mem_alloc(int device, size_t bytes, void** ptr) {
+    DXH_REQUIRE(ptr, "null argument");
+    int rc = check_device(device);
+    if (rc) return rc;
+    DXH_HIP(hipMalloc(ptr, bytes ? bytes : 1));
+    return DXH_OK;
+}
+
+int dxh_mem_free(int device, void* ptr) {
+    if (!ptr) return DXH_OK;
+    int rc = check_device(device);
+    if (rc) return rc;
+    DXH_HIP(hipFree(ptr));
+    return DXH_OK;
+}
+
+int dxh_mem_copy(int device, void* dst, const void* src, size_t bytes) {
+    DXH_REQUIRE((dst && src) || bytes == 0, "null argument");
+    int rc = check_device(device);
+    if (rc) return rc;
+    if (bytes == 0) return DXH_OK;
+    hipStream_t st;
+    DXH_HIP(cached_stream(device, &st));
+    HostPrefault pf;  // a fresh host destination: map its pages while the copy is being set up
+    pf.start(dst, bytes, {{src, bytes}});
+    pf.join();
+    DXH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, st));
+    DXH_HIP(hipStreamSynchronize(st));
     return DXH_OK;
 }
 
@@ -431,8 +506,8 @@ int dxh_affine_color(int device, int in_dtype, int64_t npix, const void* img, co
     double ab[12];
     for (int i = 0; i < 9; ++i) ab[i] = A[i];
     for (int i = 0; i < 3; ++i) ab[9 + i] = b[i];
-    DXH_HIP(hipMemcpyAsync(din, img, esz * 3 * (size_t)npix, hipMemcpyHostToDevice, d.st));
-    DXH_HIP(hipMemcpyAsync(dab, ab, sizeof ab, hipMemcpyHostToDevice, d.st));
+    DXH_HIP(hipMemcpyAsync(din, img, esz * 3 * (size_t)npix, hipMemcpyDefault, d.st));
+    DXH_HIP(hipMemcpyAsync(dab, ab, sizeof ab, hipMemcpyDefault, d.st));
     const dim3 grid((unsigned)((npix + 255) / 256)), blk(256);
     switch (in_dtype) {
         case 0: hipLaunchKernelGGL((k_affine_color<float>), grid, blk, 0, d.st, (const float*)din, (long long)npix, 1.0, (const double*)dab, clip, (float*)dout_); break;
@@ -442,7 +517,7 @@ int dxh_affine_color(int device, int in_dtype, int64_t npix, const void* img, co
     }
     DXH_HIP(hipGetLastError());
     pf.join();
-    DXH_HIP(hipMemcpyAsync(out, dout_, sizeof(float) * 3 * (size_t)npix, hipMemcpyDeviceToHost, d.st));
+    DXH_HIP(hipMemcpyAsync(out, dout_, sizeof(float) * 3 * (size_t)npix, hipMemcpyDefault, d.st));
     DXH_HIP(hipStreamSynchronize(d.st));
     return DXH_OK;
 }
@@ -469,9 +544,9 @@ int dxh_map_coordinates(int device, int dtype, int64_t H, int64_t W, int C, cons
     if ((rc = d.alloc(&dimg, esz * (size_t)H * W * C)) || (rc = d.alloc(&dr, csz * (size_t)n)) || (rc = d.alloc(&dc, csz * (size_t)n)) ||
         (rc = d.alloc(&dout_, esz * (size_t)n * C)))
         return rc;
-    DXH_HIP(hipMemcpyAsync(dimg, img, esz * (size_t)H * W * C, hipMemcpyHostToDevice, d.st));
-    DXH_HIP(hipMemcpyAsync(dr, rows, csz * (size_t)n, hipMemcpyHostToDevice, d.st));
-    DXH_HIP(hipMemcpyAsync(dc, cols, csz * (size_t)n, hipMemcpyHostToDevice, d.st));
+    DXH_HIP(hipMemcpyAsync(dimg, img, esz * (size_t)H * W * C, hipMemcpyDefault, d.st));
+    DXH_HIP(hipMemcpyAsync(dr, rows, csz * (size_t)n, hipMemcpyDefault, d.st));
+    DXH_HIP(hipMemcpyAsync(dc, cols, csz * (size_t)n, hipMemcpyDefault, d.st));
     const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
 #define DXH_MC(T_, CT_) hipLaunchKernelGGL((k_map_coords<T_, CT_>), grid, blk, 0, d.st, (const T_*)dimg, (long long)H, (long long)W, C, \
                                            (const CT_*)dr, (const CT_*)dc, (long long)n, order, cval, (T_*)dout_)
@@ -485,7 +560,7 @@ int dxh_map_coordinates(int device, int dtype, int64_t H, int64_t W, int C, cons
 #undef DXH_MC
     DXH_HIP(hipGetLastError());
     pf.join();
-    DXH_HIP(hipMemcpyAsync(out, dout_, esz * (size_t)n * C, hipMemcpyDeviceToHost, d.st));
+    DXH_HIP(hipMemcpyAsync(out, dout_, esz * (size_t)n * C, hipMemcpyDefault, d.st));
     DXH_HIP(hipStreamSynchronize(d.st));
     return DXH_OK;
 }
@@ -513,7 +588,7 @@ int dxh_resize(int device, int dtype, int64_t H, int64_t W, int C, const void* s
         void* q = nullptr;
         int r = d.alloc(&q, bytes);
         if (r) return r;
-        DXH_HIP(hipMemcpyAsync(q, host, bytes, hipMemcpyHostToDevice, d.st));
+        DXH_HIP(hipMemcpyAsync(q, host, bytes, hipMemcpyDefault, d.st));
         *devp = q;
         return DXH_OK;
     };
@@ -541,7 +616,7 @@ int dxh_resize(int device, int dtype, int64_t H, int64_t W, int C, const void* s
     void *dsrc = nullptr, *ddst = nullptr;
     const size_t nsrc = esz * (size_t)H * W * C, ndst = esz * (size_t)DH * DW * C;
     if ((rc = d.alloc(&dsrc, nsrc)) || (rc = d.alloc(&ddst, ndst))) return rc;
-    DXH_HIP(hipMemcpyAsync(dsrc, src, nsrc, hipMemcpyHostToDevice, d.st));
+    DXH_HIP(hipMemcpyAsync(dsrc, src, nsrc, hipMemcpyDefault, d.st));
     const long long total = (long long)DH * DW * C;
     const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
     switch (dtype) {
@@ -551,7 +626,7 @@ int dxh_resize(int device, int dtype, int64_t H, int64_t W, int C, const void* s
     }
     DXH_HIP(hipGetLastError());
     pf.join();
-    DXH_HIP(hipMemcpyAsync(dst, ddst, ndst, hipMemcpyDeviceToHost, d.st));
+    DXH_HIP(hipMemcpyAsync(dst, ddst, ndst, hipMemcpyDefault, d.st));
     DXH_HIP(hipStreamSynchronize(d.st));
     return DXH_OK;
 }

@@ -181,7 +181,7 @@ struct Reducer {
         hipLaunchKernelGGL((k_dot_partial<T>), dim3(nb), dim3(256), 0, stream, g, (const T*)a, (const T*)b, partial);
         hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, stream, partial, nb, out);
         DXH_HIP(hipGetLastError());
-        DXH_HIP(hipMemcpyAsync(host, out, sizeof(double), hipMemcpyDeviceToHost, stream));
+        DXH_HIP(hipMemcpyAsync(host, out, sizeof(double), hipMemcpyDefault, stream));
         DXH_HIP(hipStreamSynchronize(stream));
         return DXH_OK;
     }
@@ -192,7 +192,7 @@ struct Reducer {
                            g.n0, partial);
         hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, stream, partial, nb, out);
         DXH_HIP(hipGetLastError());
-        DXH_HIP(hipMemcpyAsync(host, out, sizeof(double), hipMemcpyDeviceToHost, stream));
+        DXH_HIP(hipMemcpyAsync(host, out, sizeof(double), hipMemcpyDefault, stream));
         DXH_HIP(hipStreamSynchronize(stream));
         return DXH_OK;
     }
@@ -625,12 +625,12 @@ struct SolverObj {
 
 int up(SolverObj* o, void* dst, const void* src) {
     DXH_HIP(hipMemcpy2DAsync(dst, o->g.pitch * o->esz, src, o->g.L * o->esz, o->g.L * o->esz, o->g.n0,
-                             hipMemcpyHostToDevice, o->stream));
+                             hipMemcpyDefault, o->stream));
     return DXH_OK;
 }
 int down(SolverObj* o, void* dst, const void* src) {
     DXH_HIP(hipMemcpy2DAsync(dst, o->g.L * o->esz, src, o->g.pitch * o->esz, o->g.L * o->esz, o->g.n0,
-                             hipMemcpyDeviceToHost, o->stream));
+                             hipMemcpyDefault, o->stream));
     return DXH_OK;
 }
 

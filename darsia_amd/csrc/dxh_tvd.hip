@@ -220,7 +220,7 @@ static int div3_run_check(hipStream_t stream, float d0, float r0, float d1, floa
     hipError_t e = hipMemsetAsync(flag, 0, sizeof(unsigned), stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_div3_check, dim3(1u << 15), dim3(256), 0, stream, d0, r0, d1, r1, flag);
-        e = hipMemcpyAsync(bad, flag, sizeof(unsigned), hipMemcpyDeviceToHost, stream);
+        e = hipMemcpyAsync(bad, flag, sizeof(unsigned), hipMemcpyDefault, stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     (void)hipFree(flag);
@@ -312,12 +312,12 @@ static int set_device(Ctx* c) {
 // dense host array (n0, L) <-> pitched device plane
 static int h2d_plane(Ctx* c, void* dst, const void* src) {
     DXH_HIP(hipMemcpy2DAsync(dst, c->g.pitch * c->esz, src, c->g.L * c->esz, c->g.L * c->esz, c->g.n0,
-                             hipMemcpyHostToDevice, c->stream));
+                             hipMemcpyDefault, c->stream));
     return DXH_OK;
 }
 static int d2h_plane(Ctx* c, void* dst, const void* src) {
     DXH_HIP(hipMemcpy2DAsync(dst, c->g.L * c->esz, src, c->g.pitch * c->esz, c->g.L * c->esz, c->g.n0,
-                             hipMemcpyDeviceToHost, c->stream));
+                             hipMemcpyDefault, c->stream));
     return DXH_OK;
 }
 
@@ -330,7 +330,7 @@ static int sq_diff(Ctx* c, const void* a, const void* b, int64_t row0, int64_t n
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->partial, nb, c->red_out + slot);
     DXH_HIP(hipGetLastError());
     if (out_host) {
-        DXH_HIP(hipMemcpyAsync(out_host, c->red_out + slot, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        DXH_HIP(hipMemcpyAsync(out_host, c->red_out + slot, sizeof(double), hipMemcpyDefault, c->stream));
         DXH_HIP(hipStreamSynchronize(c->stream));
     }
     return DXH_OK;
@@ -800,7 +800,7 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
             hipLaunchKernelGGL(k_sum_partials, dim3(K), dim3(256), 0, c->stream, c->inc_partial, K * c->inc_nwaves,
                                c->red_out + 2);
             double incs[4] = {0, 0, 0, 0};
-            DXH_HIP(hipMemcpyAsync(incs, c->red_out + 2, sizeof(double) * K, hipMemcpyDeviceToHost, c->stream));
+            DXH_HIP(hipMemcpyAsync(incs, c->red_out + 2, sizeof(double) * K, hipMemcpyDefault, c->stream));
             DXH_HIP(hipStreamSynchronize(c->stream));
             int hit = -1;
             for (int j = 0; j < K; ++j) {
@@ -1372,7 +1372,7 @@ static int finish_upload(Ctx* c, const void* u0, const void* d0, const void* b0)
             void** pl = pass == 0 ? c->dpl : c->bpl;
             for (int j = 0; j < dim; ++j)
                 if ((rc = alloc_plane(c, &pl[j]))) return rc;
-            DXH_HIP(hipMemcpyAsync(c->stage, pass == 0 ? d0 : b0, dense, hipMemcpyHostToDevice, c->stream));
+            DXH_HIP(hipMemcpyAsync(c->stage, pass == 0 ? d0 : b0, dense, hipMemcpyDefault, c->stream));
             if (f32) {
                 if (dim == 2) hipLaunchKernelGGL((k_deinterleave<float, 2>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const float*)c->stage, (float*)pl[0], (float*)pl[1], (float*)pl[2]);
                 else hipLaunchKernelGGL((k_deinterleave<float, 3>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const float*)c->stage, (float*)pl[0], (float*)pl[1], (float*)pl[2]);
@@ -1420,7 +1420,7 @@ static int set_dense(Ctx* c, void** slot, const void* host, size_t bytes) {
     if (*slot) { DXH_HIP(hipFree(*slot)); *slot = nullptr; }
     if (!host) return DXH_OK;
     DXH_HIP(hipMalloc(slot, bytes));
-    DXH_HIP(hipMemcpyAsync(*slot, host, bytes, hipMemcpyHostToDevice, c->stream));
+    DXH_HIP(hipMemcpyAsync(*slot, host, bytes, hipMemcpyDefault, c->stream));
     DXH_HIP(hipStreamSynchronize(c->stream));
     return DXH_OK;
 }
@@ -1467,7 +1467,7 @@ int dxh_tvd_upload_signal(dxh_tvd_t h, const void* probe, int channels, int diff
         DXH_HIP(hipMalloc(&c->probe_buf, bytes));
         c->probe_bytes = bytes;
     }
-    DXH_HIP(hipMemcpyAsync(c->probe_buf, probe, bytes, hipMemcpyHostToDevice, c->stream));
+    DXH_HIP(hipMemcpyAsync(c->probe_buf, probe, bytes, hipMemcpyDefault, c->stream));
     const dim3 grid = elem_grid(c->g), blk(256);
 #define DXH_SIG(T, CH) hipLaunchKernelGGL((k_signal<T, CH>), grid, blk, 0, c->stream, c->g, (const T*)c->probe_buf, \
                                           (const T*)c->base_img, (const T*)c->clean_filter, diff_option, reduction, pre, (T*)c->u[0])
@@ -1496,7 +1496,7 @@ int dxh_tvd_download_model(dxh_tvd_t h, void* out, const dxh_model_op* post_ops,
     else
         hipLaunchKernelGGL((k_model<double>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const double*)c->u[c->cur], post, (double*)c->stage);
     DXH_HIP(hipGetLastError());
-    DXH_HIP(hipMemcpyAsync(out, c->stage, dense, hipMemcpyDeviceToHost, c->stream));
+    DXH_HIP(hipMemcpyAsync(out, c->stage, dense, hipMemcpyDefault, c->stream));
     DXH_HIP(hipStreamSynchronize(c->stream));
     return DXH_OK;
 }
@@ -1541,7 +1541,7 @@ int dxh_tvd_download(dxh_tvd_t h, void* u, void* d, void* b) {
                     else hipLaunchKernelGGL((k_interleave<double, 3>), grid2, blk2, 0, c->stream, c->g, (const double*)pl[0], (const double*)pl[1], (const double*)pl[2], (double*)tmpd);
                 }
                 hipError_t e = hipGetLastError();
-                if (e == hipSuccess) e = hipMemcpyAsync(host, tmpd, dense, hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess) e = hipMemcpyAsync(host, tmpd, dense, hipMemcpyDefault, c->stream);
                 if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
                 if (e != hipSuccess) { (void)hipFree(tmpd); set_error("download failed: %s", hipGetErrorString(e)); return DXH_EHIP; }
             }
@@ -1566,8 +1566,8 @@ int dxh_tvd_download(dxh_tvd_t h, void* u, void* d, void* b) {
         }
 #undef DXH_EXPAND
         DXH_HIP(hipGetLastError());
-        if (d) DXH_HIP(hipMemcpyAsync(d, dd, dense, hipMemcpyDeviceToHost, c->stream));
-        if (b) DXH_HIP(hipMemcpyAsync(b, bb, dense, hipMemcpyDeviceToHost, c->stream));
+        if (d) DXH_HIP(hipMemcpyAsync(d, dd, dense, hipMemcpyDefault, c->stream));
+        if (b) DXH_HIP(hipMemcpyAsync(b, bb, dense, hipMemcpyDefault, c->stream));
         DXH_HIP(hipStreamSynchronize(c->stream));
         if (dd) DXH_HIP(hipFree(dd));
         if (bb) DXH_HIP(hipFree(bb));
@@ -1736,7 +1736,7 @@ int dxh_tvd_energy(dxh_tvd_t h, int which, double* value) {
 #undef DXH_EN
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, part, (int)nb, c->red_out + 6);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(value, c->red_out + 6, sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(value, c->red_out + 6, sizeof(double), hipMemcpyDefault, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(part);
     if (e != hipSuccess) { set_error("energy evaluation failed: %s", hipGetErrorString(e)); return DXH_EHIP; }

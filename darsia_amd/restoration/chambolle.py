@@ -13,10 +13,22 @@ import ctypes as C
 import numpy as np
 
 from .. import _lib
+from ..device import DeviceArray
 
 
 def denoise_tv_chambolle(image: np.ndarray, weight: float = 0.1, eps: float = 2e-4, max_num_iter: int = 200,
                          return_iters: bool = False):
+    if isinstance(image, DeviceArray):
+        # device in, device out (float images only: the integer conversions above are host work)
+        if image.dtype not in (np.float32, np.float64) or image.ndim not in (2, 3):
+            raise TypeError("a device-resident image must be float32 / float64 with 2 or 3 axes")
+        out = DeviceArray(image.shape, image.dtype, image.device)
+        done = C.c_int(0)
+        _lib.check(_lib.load().dxh_chambolle(image.device, _lib.dtype_code(image.dtype), image.ndim, image.shape[0],
+                                              image.shape[1], image.shape[2] if image.ndim == 3 else 1,
+                                              _lib.ptr(image), _lib.ptr(out), float(weight), float(eps),
+                                              int(max_num_iter), C.byref(done)))
+        return (out, done.value) if return_iters else out
     if not isinstance(image, np.ndarray):
         raise TypeError("image must be a numpy array")
     if image.dtype.kind != "f":

@@ -26,13 +26,18 @@ from typing import Optional, Union
 import numpy as np
 
 from .. import _lib
+from ..device import DeviceArray
 from ..utils.linear_solvers.cg import CG
 from ..utils.linear_solvers.jacobi import Jacobi
 from ..utils.linear_solvers.mg import MG
 from ..utils.linear_solvers.solver import Solver
 
 
-def _coef(value, img: np.ndarray, name: str):
+def _coef(value, img, name: str):
+    if isinstance(value, DeviceArray):
+        if value.shape != tuple(img.shape) or value.dtype != img.dtype:
+            raise ValueError(f"a device-resident {name} must have the image's shape and dtype")
+        return 0.0, value
     if isinstance(value, np.ndarray) and value.ndim > 0:
         try:
             arr = np.broadcast_to(value, img.shape)
@@ -92,7 +97,13 @@ class DeviceTVD:
                                                 _lib.ptr(ell_a)))
 
     def upload(self, img, u0=None, d0=None, b0=None):
-        c = lambda a: None if a is None else np.ascontiguousarray(a, dtype=self.dtype)  # noqa: E731
+        def c(a):
+            if a is None or isinstance(a, DeviceArray):
+                if a is not None and a.dtype != self.dtype:
+                    raise TypeError(f"device array of dtype {a.dtype} given to a {self.dtype} context")
+                return a
+            return np.ascontiguousarray(a, dtype=self.dtype)
+
         img, u0, d0, b0 = c(img), c(u0), c(d0), c(b0)
         assert img.shape == self.shape
         _lib.check(self.lib.dxh_tvd_upload(self._h, _lib.ptr(img), _lib.ptr(u0), _lib.ptr(d0), _lib.ptr(b0)))
@@ -129,9 +140,11 @@ class DeviceTVD:
         _lib.check(self.lib.dxh_tvd_energy(self._h, 1 if previous else 0, C.byref(v)))
         return v.value
 
-    def download(self, want_split=False, out: Optional[np.ndarray] = None):
+    def download(self, want_split=False, out=None):
+        """The iterate (and the split variables) as host arrays, or into ``out`` (ndarray or DeviceArray)."""
         u = np.empty(self.shape, self.dtype) if out is None else out
-        assert u.shape == self.shape and u.dtype == self.dtype and u.flags.c_contiguous
+        assert tuple(u.shape) == self.shape and u.dtype == self.dtype
+        assert isinstance(u, DeviceArray) or u.flags.c_contiguous
         if not want_split:
             _lib.check(self.lib.dxh_tvd_download(self._h, _lib.ptr(u), None, None))
             return u
@@ -164,7 +177,8 @@ def split_bregman_tvd(
     Returns:
         array: denoised image, same dtype as ``img``.
     """
-    if not isinstance(img, np.ndarray):
+    on_device = isinstance(img, DeviceArray)
+    if not isinstance(img, np.ndarray) and not on_device:
         raise TypeError(f"Input type {type(img)} not supported.")
     if img.dtype.kind != "f":
         raise TypeError("split_bregman_tvd needs a float32/float64 image (integer images break the "
@@ -185,10 +199,10 @@ def split_bregman_tvd(
     if x0 is not None:
         u0, d0, b0 = x0
         for name, a in (("d0", d0), ("b0", b0)):
-            if not isinstance(a, np.ndarray) or a.shape != img.shape + (dim,):
+            if not isinstance(a, np.ndarray) or a.shape != tuple(img.shape) + (dim,):
                 raise ValueError(f"{name} must have shape (*img.shape, dim) = {img.shape + (dim,)}")
 
-    with DeviceTVD(img.shape, img.dtype, dim=dim) as st:
+    with DeviceTVD(img.shape, img.dtype, dim=dim, device=img.device if on_device else None) as st:
         st.set_coeffs(mu, omega, ell, img)
         if not isinstance(solver, Jacobi):
             st.set_solver(solver)
@@ -219,7 +233,12 @@ def split_bregman_tvd(
             # The result array is allocated and its pages are touched on this thread WHILE the device iterates (the
             # blocking C call runs on a helper thread and holds no GIL): a fresh 384 MB array costs ~14 ms of page
             # faults, which otherwise land inside the device-to-host copy (22-36 ms instead of 7 ms, measured).
-            out = np.empty(img.shape, img.dtype) if x0 is None else None
+            if on_device:
+                # device in, device out: nothing crosses PCIe
+                st.run(max_num_iter, solver.maxiter, solver.tol, eps=eps, isotropic=isotropic)
+                if x0 is None:
+                    return st.download(out=DeviceArray(img.shape, img.dtype, img.device))
+            out = np.empty(img.shape, img.dtype) if (x0 is None and not on_device) else None
             box = {}
 
             def work():
@@ -228,7 +247,9 @@ def split_bregman_tvd(
                 except BaseException as e:  # noqa: BLE001 -- re-raised on the calling thread
                     box["e"] = e
 
-            if out is not None and out.nbytes >= (8 << 20):
+            if on_device:
+                pass
+            elif out is not None and out.nbytes >= (8 << 20):
                 th = threading.Thread(target=work)
                 th.start()
                 out.reshape(-1)[:: max(1, 4096 // out.itemsize)] = 0
@@ -240,8 +261,8 @@ def split_bregman_tvd(
             if x0 is None:
                 return st.download(out=out)
         if x0 is None:
-            return st.download()
-        u, d, b = st.download(want_split=True)
+            return st.download(out=DeviceArray(img.shape, img.dtype, img.device)) if on_device else st.download()
+        u, d, b = st.download(want_split=True, out=DeviceArray(img.shape, img.dtype, img.device) if on_device else None)
         d0[...] = d
         b0[...] = b
         return u

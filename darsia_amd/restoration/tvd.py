@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import numpy as np
 
+from ..device import DeviceArray
 from ..image import with_array
 from .bregman_gs import denoise_tv_bregman
 from .chambolle import denoise_tv_chambolle
@@ -41,7 +42,7 @@ class TVD:
         self.kwargs = kwargs
 
     def __call__(self, img):
-        if isinstance(img, np.ndarray):
+        if isinstance(img, (np.ndarray, DeviceArray)):  # a DeviceArray stays in HBM (darsia_amd.device)
             return self._tvd_array(img)
         elif _is_image(img):
             return self._tvd_image(img)

@@ -61,6 +61,18 @@ int dxh_version(void);
 /* number of visible HIP devices (0 when there is none; never an error) */
 int dxh_device_count(int* count);
 
+/*
+ * Device-resident image arrays.  Wherever an entry point below takes a caller-owned IMAGE array (img, out, src, dst,
+ * base, canvas, x0, rhs ...: the arrays whose size is that of an image), the pointer may be a host array or a dense
+ * device array obtained here: every copy of caller data resolves its direction from the pointers.  Operators can then be
+ * chained without leaving HBM, the way the reference chains them in host memory (image/image.py:188-199,
+ * signals/models/combinedmodel.py:29-52).  Small parameter tables (matrices, patch records, tap tables) are host memory.
+ */
+int dxh_mem_alloc(int device, size_t bytes, void** ptr);
+int dxh_mem_free(int device, void* ptr);
+/* synchronous copy between any two of {host array, device array} */
+int dxh_mem_copy(int device, void* dst, const void* src, size_t bytes);
+
 typedef struct dxh_tvd_ctx* dxh_tvd_t;
 
 typedef struct dxh_tvd_desc {

@@ -303,10 +303,10 @@ def test_early_stop_with_temporal_blocking(golden, monkeypatch, name, eps, fuse_
 
 # ---- BASELINE.json full size (4000 x 8000 x 3 float32) -------------------------------------------------
 def test_full_size_config2_parity_and_invariants(monkeypatch):
-    """configs[1] at its real size: (a) 3 iterations bit-exact against the oracle (the NumPy oracle needs
-    ~3 s per iteration here, so the 100-iteration run is checked through properties instead);
-    (b) 100 iterations: the K = 4 temporally blocked path and the one-iteration-per-launch path give
-    identical bits; (c) the result is finite and has less total variation than the input."""
+    """configs[1] at its real size: (a) 3 iterations bit-exact against the oracle over the whole image (the NumPy
+    oracle needs ~3 s per iteration here); (b) 100 iterations: the K = 4 temporally blocked path and the
+    one-iteration-per-launch path give identical bits; (c) the result is finite and has less total variation than
+    the input; (d) the 100-iteration result equals the oracle's on four 512 x 512 windows (corners and centre)."""
     from darsia_amd.synthetic import synthetic_image
 
     img = synthetic_image(4000, 8000, 3)
@@ -326,6 +326,24 @@ def test_full_size_config2_parity_and_invariants(monkeypatch):
     # TV denoising reduces the total variation of the image
     tv = lambda a: np.abs(np.diff(a, axis=0)).sum(dtype=np.float64) + np.abs(np.diff(a, axis=1)).sum(dtype=np.float64)  # noqa: E731
     assert tv(out_k4) < tv(img)
+    # (d) the 100-iteration result itself against the oracle, through windows.  u_{n+1}(x) depends on u_n within one
+    # pixel of x (and on d_n, b_n at x - 1 .. x, which depend on u_n up to x + 1; split_bregman_tvd.py:84-89, 129-146,
+    # jacobi.py:41-54), so after n iterations a pixel knows nothing beyond n + 1 pixels: the oracle run on a 512 x 512
+    # crop equals the full-size result wherever the crop's cut edges are more than 101 pixels away (a crop edge that IS
+    # the image edge carries the same boundary rule and needs no margin).  Strict flow: bit for bit; the reference's
+    # NumPy-2 float64 promotion: the north-star tolerance rtol 1e-4.
+    H, W, n, m = 4000, 8000, 100, 102
+    for (r0, c0) in ((0, 0), ((H - 512) // 2, (W - 512) // 2), (H - 512, W - 512), (0, W - 512)):
+        crop = np.ascontiguousarray(img[r0:r0 + 512, c0:c0 + 512])
+        ra = 0 if r0 == 0 else m
+        rb = 512 if r0 + 512 == H else 512 - m
+        ca = 0 if c0 == 0 else m
+        cb = 512 if c0 + 512 == W else 512 - m
+        want = O.split_bregman_tvd(crop, mu=0.1, max_num_iter=n, promotion="strict")[ra:rb, ca:cb]
+        got = out_k4[r0 + ra:r0 + rb, c0 + ca:c0 + cb]
+        assert_bits(got, want)
+        want2 = O.split_bregman_tvd(crop, mu=0.1, max_num_iter=n)[ra:rb, ca:cb]  # reference dtype flow
+        np.testing.assert_allclose(got, want2, rtol=RTOL, atol=ATOL)
 
 
 def test_verbose_prints_increment_and_energy(golden, capsys):
