@@ -24,7 +24,10 @@ def test_fused_pipeline_without_restoration(color, option):
     model = da.CombinedModel([da.LinearModel(scaling=2.5, offset=-0.05), da.ClipModel(min_value=0.0, max_value=1.0)])
     ca = da.ConcentrationAnalysis(base, da.MonochromaticReduction(color=color), None, None, model, **{"diff option": option})
     out = ca(probe)
-    ref = OC.concentration(probe.img, base.img, option, color, None, [model.models[0], model.models[1]], None, False)
+    # the checker's model stage: the reference's expressions as plain callables (linearmodel.py:140-149:
+    # scaling * img + offset; clipmodel.py:87-106: np.clip -- the latter pinned by tests/golden/models_golden.npz)
+    ref = OC.concentration(probe.img, base.img, option, color, None,
+                           [lambda x: 2.5 * x + -0.05, lambda x: np.clip(x, 0.0, 1.0)], None, False)
     assert isinstance(out, da.ScalarImage) and out.img.dtype == ref.dtype
     assert np.array_equal(out.img, ref), np.abs(out.img - ref).max()
 
@@ -41,7 +44,7 @@ def test_fused_pipeline_with_tvd_and_cleaning_filter(restoration_first):
     assert ca.threshold_cleaning_filter is not None and ca.threshold_cleaning_filter.dtype == np.float64
     out = ca(probe)
     ref = OC.concentration(probe.img.astype(np.float64), base.img.astype(np.float64), "positive", "red",
-                           ca.threshold_cleaning_filter, [model.models[0], model.models[1]],
+                           ca.threshold_cleaning_filter, [lambda x: 3.0 * x, lambda x: np.clip(x, 0.0, 1.0)],
                            dict(mu=0.05, omega=1.0, ell=0.1, max_num_iter=12), restoration_first)
     assert out.img.dtype == np.float64  # the float64 cleaning filter promotes the signal, as in the reference
     assert np.array_equal(out.img, ref), np.abs(out.img - ref).max()

@@ -86,6 +86,24 @@ def test_affine_colour_balance(dtype):
     assert np.array_equal(bal.apply_balance(img), out)
 
 
+@pytest.mark.parametrize("tag", ["f64", "f32", "u8"])
+def test_affine_colour_balance_against_reference_goldens(tag):
+    """AffineBalance.apply_balance outputs of the imported reference (corrections/color/colorbalance.py:186-196,
+    tests/golden/make_golden_models.py).  The reference returns float64 (float32 input: float64 as well, the matrix
+    is float64); the device path returns ColorCorrection's float32 (colorcorrection.py:388-394), so the golden is
+    cast the way that tail casts it.  Products summed in index order here, in BLAS order there: one unit in the last
+    place of float32 at most."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "models_golden.npz"))
+    bal = da.AffineBalance()
+    bal.balance_scaling, bal.balance_translation = g["balance/A"], g["balance/b"]
+    out = bal.apply_balance(g[f"balance_{tag}/img"])
+    want = g[f"balance_{tag}/out"].astype(np.float32)
+    assert out.dtype == np.float32 and out.shape == want.shape
+    np.testing.assert_allclose(out, want, rtol=2e-7, atol=1e-7)
+
+
 def _textured(h, w, seed):
     rng = np.random.default_rng(seed)
     coarse = rng.random((h // 8 + 2, w // 8 + 2))
