@@ -261,6 +261,12 @@ class ConcentrationAnalysis:
             if not isinstance(red, MonochromaticReduction) or red.color not in MonochromaticReduction._CODES:
                 return None
             reduction, channels = MonochromaticReduction._CODES[red.color], 3
+            if reduction == 5:
+                # cv2's gray conversion works in float32 AFTER the (possibly float64) background subtraction: the fused
+                # float32 pipeline reproduces that only when nothing in front of it is wider than float32
+                wide = probe.dtype if self.base is None else np.result_type(probe.dtype, self.base.img.dtype)
+                if wide != np.float32:
+                    return None
         elif probe.ndim == 2 and self.signal_reduction is None:
             reduction, channels = 0, 1
         else:
@@ -290,9 +296,12 @@ class ConcentrationAnalysis:
 
     def _device_call(self, probe: np.ndarray, plan) -> np.ndarray:
         reduction, channels, ops, solver, iso = plan
-        # dtype as NumPy would promote: a (float64) cleaning filter promotes the signal; gray is float32 in cv2
-        dt = probe.dtype if self.threshold_cleaning_filter is None else np.result_type(probe.dtype, np.float64)
-        if reduction == 5 and self.threshold_cleaning_filter is None:
+        # dtype as NumPy would promote (concentrationanalysis.py:328-395): probe - baseline promotes to the wider of the
+        # two, a (float64) cleaning filter promotes the signal; gray is float32 in cv2
+        dt = probe.dtype if self.base is None else np.result_type(probe.dtype, self.base.img.dtype)
+        if self.threshold_cleaning_filter is not None:
+            dt = np.result_type(dt, np.float64)
+        elif reduction == 5:
             dt = np.dtype(np.float32)
         h, w = probe.shape[:2]
         key = (h, w, np.dtype(dt).str)

@@ -16,6 +16,7 @@
 #include <rccl/rccl.h>
 
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "dxh_comm.h"
@@ -48,11 +49,29 @@ static std::mutex g_mu;
 static int load() {
     std::lock_guard<std::mutex> lk(g_mu);
     if (g_api.handle) return DXH_OK;
-    const char* names[] = {getenv("DXH_RCCL_LIB"), "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    // RCCL must sit on the SAME HIP runtime as this library (streams, events and pointers cross between them).  A process
+    // can hold two ROCm stacks -- e.g. PyTorch's bundled one next to /opt/rocm -- and a bare dlopen("librccl.so.1")
+    // returns whichever copy was loaded first.  So: find the file our own HIP symbols come from and take the librccl
+    // beside it, by absolute path, bound to its own dependency chain (RTLD_DEEPBIND).
+    std::string beside1, beside2;
+    {
+        Dl_info info;
+        if (dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
+            std::string dir(info.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) {
+                dir.resize(slash);
+                beside1 = dir + "/librccl.so.1";
+                beside2 = dir + "/librccl.so";
+            }
+        }
+    }
+    const char* names[] = {getenv("DXH_RCCL_LIB"), beside1.c_str(), beside2.c_str(), "librccl.so.1",
+                           "/opt/rocm/lib/librccl.so.1", "librccl.so"};
     void* h = nullptr;
     for (const char* n : names) {
         if (!n || !*n) continue;
-        h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        h = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
         if (h) break;
     }
     if (!h) {

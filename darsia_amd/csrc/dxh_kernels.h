@@ -189,6 +189,297 @@ __global__ void __launch_bounds__(256) k_shrink(Geom g, const T* __restrict__ un
     }
 }
 
+// ============================================================================================
+// One outer iteration of a dim = 3 problem in ONE pass (examples/regularization.py:8-47 and the PET volumes of
+// examples/paper/pet_simulations_comparison_block_b.py:680-713 are the reference's 3-D use): right-hand side, Jacobi
+// sweep and shrinkage with the very expressions of k_rhs / k_jacobi / k_shrink above, so the bits are the same, but
+// u_new never goes to memory and back: a block computes it for a (B0+1) x (B1+1) x (B2+1) brick -- its tile plus the
+// forward neighbours the differences D_j u_new need -- into LDS, then updates q_j for the tile from there.  HBM traffic:
+// of, u, q_0..2 in and u, q_0..2 out = 9 values per element (the three kernels: ~19); the one-element halos of
+// neighbouring bricks come out of L2.  u and q are double buffered here (other blocks still read the old q next door).
+// ============================================================================================
+constexpr int kB0 = 8, kB1 = 8, kB2 = 64;
+
+template <typename T, bool ISO>
+__device__ __forceinline__ T t_comp_at(const QPlanes<T, 3>& q, int64_t off, int j, T ell, T kq) {
+    // component j of t = ell * (b - d) at `off`; the anisotropic split is per component
+    if constexpr (ISO) {
+        T qq[3], d[3], b[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) qq[i] = q.in[i][off];
+        split_vars<T, 3, true>(qq, kq, d, b);
+        return ell * (b[j] - d[j]);
+    } else {
+        const T qq[1] = {q.in[j][off]};
+        T d[1], b[1];
+        split_vars<T, 1, false>(qq, kq, d, b);
+        return ell * (b[0] - d[0]);
+    }
+}
+
+template <typename T, bool ISO>
+__global__ void __launch_bounds__(256) k_fused3d(Geom g, const T* __restrict__ of, QPlanes<T, 3> q,
+                                                  const T* __restrict__ u_in, T* __restrict__ u_out, Coef<T> c,
+                                                  CoefPlanes<T> cp, int nt1, int nt2) {
+    constexpr int S2 = kB2 + 1, S1 = (kB1 + 1) * S2, NB = (kB0 + 1) * S1;
+    __shared__ T un[NB];
+    const int bid = blockIdx.x;
+    const int tt2 = bid % nt2, tt1 = (bid / nt2) % nt1, tt0 = bid / (nt2 * nt1);
+    const int64_t o0 = (int64_t)tt0 * kB0, o1 = (int64_t)tt1 * kB1, o2 = (int64_t)tt2 * kB2;
+    // ---- phase 1: u_new on the brick
+    for (int idx = threadIdx.x; idx < NB; idx += 256) {
+        const int l0 = idx / S1, r = idx - l0 * S1, l1 = r / S2, l2 = r - l1 * S2;
+        const int64_t i0 = o0 + l0, i1 = o1 + l1, i2 = o2 + l2;
+        if (i0 >= g.n0 || i1 >= g.n1 || i2 >= g.n2) continue;
+        const int64_t off = i0 * g.pitch + i1 * g.n2 + i2;
+        // clamped neighbour offsets (replicate ghosts, jacobi.py:43,52; one-sided ends, derivatives.py:33,57)
+        const int64_t om[3] = {i0 > 0 ? off - g.pitch : off, i1 > 0 ? off - g.n2 : off, i2 > 0 ? off - 1 : off};
+        const int64_t op[3] = {i0 < g.n0 - 1 ? off + g.pitch : off, i1 < g.n1 - 1 ? off + g.n2 : off,
+                               i2 < g.n2 - 1 ? off + 1 : off};
+        const T ell_c = cp.ell ? cp.ell[off] : c.ell;
+        const T kq_c = cp.kq ? cp.kq[off] : c.kq;
+        T tc[3];
+        {
+            T qq[3], d[3], b[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) qq[j] = q.in[j][off];
+            split_vars<T, 3, ISO>(qq, kq_c, d, b);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) tc[j] = ell_c * (b[j] - d[j]);
+        }
+        T rr = of[off];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int64_t o = om[j];
+            const T ell_n = cp.ell ? cp.ell[o] : c.ell;
+            const T kq_n = cp.kq ? cp.kq[o] : c.kq;
+            rr = rr + (tc[j] - t_comp_at<T, ISO>(q, o, j, ell_n, kq_n));
+        }
+        const T diag = cp.diag ? cp.diag[off] : c.diag;
+        const T rs = rr / diag;
+        T acc = T(0);
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) {
+            acc = acc + u_in[om[ax]];
+            acc = acc + u_in[op[ax]];
+        }
+        const T dsc = cp.dsc ? cp.dsc[off] : c.dsc;
+        un[idx] = rs + acc / dsc;
+    }
+    __syncthreads();
+    // ---- phase 2: the tile's u_new goes out, q_j <- D_j u_new + b_j
+    for (int idx = threadIdx.x; idx < kB0 * kB1 * kB2; idx += 256) {
+        const int l0 = idx / (kB1 * kB2), r = idx - l0 * (kB1 * kB2), l1 = r / kB2, l2 = r - l1 * kB2;
+        const int64_t i0 = o0 + l0, i1 = o1 + l1, i2 = o2 + l2;
+        if (i0 >= g.n0 || i1 >= g.n1 || i2 >= g.n2) continue;
+        const int64_t off = i0 * g.pitch + i1 * g.n2 + i2;
+        const int l = l0 * S1 + l1 * S2 + l2;
+        const T uc = un[l];
+        u_out[off] = uc;
+        const T kq = cp.kq ? cp.kq[off] : c.kq;
+        T qq[3], d[3], b[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) qq[j] = q.in[j][off];
+        split_vars<T, 3, ISO>(qq, kq, d, b);
+        const T n0v = i0 < g.n0 - 1 ? un[l + S1] : uc;
+        const T n1v = i1 < g.n1 - 1 ? un[l + S2] : uc;
+        const T n2v = i2 < g.n2 - 1 ? un[l + 1] : uc;
+        q.out[0][off] = (n0v - uc) + b[0];
+        q.out[1][off] = (n1v - uc) + b[1];
+        q.out[2][off] = (n2v - uc) + b[2];
+    }
+}
+
+// ============================================================================================
+// The same iteration as a 2.5-D march.  A block works on a P1 x P2 patch of the (axis 1, axis 2) plane (1024 columns,
+// four per thread; 16 x 64, 8 x 128 or 4 x 256, chosen per volume) and walks down axis 0 through a chunk of planes.  What a
+// column needs from its own past and future along axis 0 (u one plane up and down, t_0 one plane up, u_new one plane
+// down) stays in the owning thread's registers; what it needs from its in-plane neighbours goes through two-slot LDS
+// planes written ONE STEP AHEAD (u, t_1, t_2 of plane p + 1 while plane p is being computed; u_new of plane p for the
+// q update of plane p at the next step), so one barrier per plane is enough.  The patch's last row and last column
+// only compute u_new for the forward differences of their neighbours and store nothing: patches tile the plane with a
+// stride of (P1 - 1, P2 - 1).  Columns on the rim fetch what lies
+// outside from global memory (L2: neighbouring patches run on the same XCD, block_to_patch).  Every global value is read
+// once per owning block: 9 values per element and iteration plus the rim.  Same expressions, same order as k_rhs /
+// k_jacobi / k_shrink: same bits.
+// ============================================================================================
+template <int M2>
+struct MarchGeom {
+    static constexpr int P2 = M2, P1 = 1024 / M2;     // patch with its forward rim: 1024 columns, four per thread
+    static constexpr int kM2 = P2 - 1, kM1 = P1 - 1;   // owned rows / columns = the tiling stride
+    static constexpr int COLS = P1 * P2;
+    static constexpr int PER = (COLS + 255) / 256;
+};
+
+template <typename T, bool ISO, int M2>
+__global__ void __launch_bounds__(256) k_march3d(Geom g, const T* __restrict__ of, QPlanes<T, 3> q,
+                                                  const T* __restrict__ u_in, T* __restrict__ u_out, Coef<T> c,
+                                                  CoefPlanes<T> cp, int nt1, int nt2, int nchunk, int ppc) {
+    using MG = MarchGeom<M2>;
+    constexpr int kM1 = MG::kM1, kM2 = MG::kM2, S2 = MG::P2, COLS = MG::COLS, PER = MG::PER;
+    __shared__ T s_u[2][COLS], s_t1[2][COLS], s_t2[2][COLS], s_un[2][COLS];
+    // XCD x (= blockIdx % 8) takes a contiguous run of patches in (chunk, row of patches, patch) order: the patches that
+    // exchange rim values through L2 sit on the same XCD
+    const int total = nt1 * nt2 * nchunk;
+    const int per_xcd = (total + 7) >> 3;
+    const int bid = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (bid >= total) return;  // block-uniform
+    const int tt2 = bid % nt2, tt1 = (bid / nt2) % nt1, chunk = bid / (nt2 * nt1);
+    const int64_t P0 = (int64_t)chunk * ppc;
+    if (P0 >= g.n0) return;  // block-uniform
+    const int64_t P1 = (P0 + ppc < g.n0) ? P0 + ppc : g.n0;
+    const int64_t Pend = (P1 < g.n0) ? P1 : g.n0 - 1;  // last plane whose u_new is needed
+    const int64_t r0 = (int64_t)tt1 * kM1, c0 = (int64_t)tt2 * kM2;
+
+    // per-column geometry and state
+    int col[PER], l1[PER], l2[PER];
+    int64_t i1[PER], i2[PER], off[PER];
+    bool in[PER], owned[PER];
+    T um[PER], uc[PER], up[PER], t0m[PER], tcur[PER][3], bcur[PER][3], ofc[PER], unm[PER], bm[PER][3];
+
+    auto coef_ell = [&](int64_t o) -> T { return cp.ell ? cp.ell[o] : c.ell; };
+    auto coef_kq = [&](int64_t o) -> T { return cp.kq ? cp.kq[o] : c.kq; };
+    auto split_at = [&](int64_t o, T ell, T kq, T (&t)[3], T (&b)[3]) {
+        T qq[3], d[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) qq[j] = q.in[j][o];
+        split_vars<T, 3, ISO>(qq, kq, d, b);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) t[j] = ell * (b[j] - d[j]);
+    };
+
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        col[k] = (int)threadIdx.x + 256 * k;
+        l1[k] = col[k] / S2;
+        l2[k] = col[k] - l1[k] * S2;
+        i1[k] = r0 + l1[k];
+        i2[k] = c0 + l2[k];
+        in[k] = col[k] < COLS && i1[k] < g.n1 && i2[k] < g.n2;
+        owned[k] = in[k] && l1[k] < kM1 && l2[k] < kM2;
+        off[k] = P0 * g.pitch + i1[k] * g.n2 + i2[k];
+        if (in[k]) {
+            const int64_t o = off[k];
+            uc[k] = u_in[o];
+            um[k] = u_in[P0 > 0 ? o - g.pitch : o];
+            up[k] = u_in[P0 < g.n0 - 1 ? o + g.pitch : o];
+            ofc[k] = of[o];
+            split_at(o, coef_ell(o), coef_kq(o), tcur[k], bcur[k]);
+            if (P0 > 0) {
+                t0m[k] = t_comp_at<T, ISO>(q, o - g.pitch, 0, coef_ell(o - g.pitch), coef_kq(o - g.pitch));
+            } else {
+                t0m[k] = tcur[k][0];  // the one-sided difference at the first plane is t - t (derivatives.py:57)
+            }
+            s_u[P0 & 1][col[k]] = uc[k];
+            s_t1[P0 & 1][col[k]] = tcur[k][1];
+            s_t2[P0 & 1][col[k]] = tcur[k][2];
+        }
+        unm[k] = T(0);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) bm[k][j] = T(0);
+    }
+    __syncthreads();
+
+    for (int64_t p = P0; p <= Pend; ++p) {
+        const int s = (int)(p & 1);
+        const bool have_next = p + 1 <= Pend;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            if (!in[k]) continue;
+            const int64_t o = off[k];
+            // prefetch the next plane of this column (a two-step prefetch was measured: the extra registers cost a
+            // block per CU and 20 % of the speed)
+            T nq[3] = {T(0), T(0), T(0)}, nof = T(0), nu2 = T(0), nell = T(0), nkq = T(0);
+            if (have_next) {
+                const int64_t on = o + g.pitch;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) nq[j] = q.in[j][on];
+                nof = of[on];
+                nu2 = u_in[p + 2 < g.n0 ? on + g.pitch : on];
+                nell = coef_ell(on);
+                nkq = coef_kq(on);
+            }
+            // in-plane neighbours of u(p): the patch's LDS plane, global memory beyond the rim, the value itself at
+            // the array ends (replicate ghosts, jacobi.py:43,52)
+            const bool e1m = i1[k] > 0, e1p = i1[k] < g.n1 - 1, e2m = i2[k] > 0, e2p = i2[k] < g.n2 - 1;
+            const T u_rm = !e1m ? uc[k] : (l1[k] > 0 ? s_u[s][col[k] - S2] : u_in[o - g.n2]);
+            const T u_rp = !e1p ? uc[k] : (l1[k] < kM1 ? s_u[s][col[k] + S2] : u_in[o + g.n2]);
+            const T u_cm = !e2m ? uc[k] : (l2[k] > 0 ? s_u[s][col[k] - 1] : u_in[o - 1]);
+            const T u_cp = !e2p ? uc[k] : (l2[k] < kM2 ? s_u[s][col[k] + 1] : u_in[o + 1]);
+            // t_1 one row up, t_2 one column left (one-sided ends: t - t, derivatives.py:57)
+            T t1n, t2n;
+            if (!e1m) t1n = tcur[k][1];
+            else if (l1[k] > 0) t1n = s_t1[s][col[k] - S2];
+            else t1n = t_comp_at<T, ISO>(q, o - g.n2, 1, coef_ell(o - g.n2), coef_kq(o - g.n2));
+            if (!e2m) t2n = tcur[k][2];
+            else if (l2[k] > 0) t2n = s_t2[s][col[k] - 1];
+            else t2n = t_comp_at<T, ISO>(q, o - 1, 2, coef_ell(o - 1), coef_kq(o - 1));
+            // right-hand side and Jacobi sweep (k_rhs, k_jacobi)
+            T rr = ofc[k];
+            rr = rr + (tcur[k][0] - t0m[k]);
+            rr = rr + (tcur[k][1] - t1n);
+            rr = rr + (tcur[k][2] - t2n);
+            const T rs = rr / (cp.diag ? cp.diag[o] : c.diag);
+            T acc = T(0);
+            acc = acc + um[k];
+            acc = acc + up[k];
+            acc = acc + u_rm;
+            acc = acc + u_rp;
+            acc = acc + u_cm;
+            acc = acc + u_cp;
+            const T unp = rs + acc / (cp.dsc ? cp.dsc[o] : c.dsc);
+            s_un[s][col[k]] = unp;
+            // plane p - 1 is complete now: u_new(p - 1) goes out, q_j <- D_j u_new + b_j (k_shrink)
+            if (p > P0 && owned[k]) {
+                const int sm = s ^ 1;
+                const int64_t ob = o - g.pitch;
+                const T n1v = e1p ? s_un[sm][col[k] + S2] : unm[k];
+                const T n2v = e2p ? s_un[sm][col[k] + 1] : unm[k];
+                u_out[ob] = unm[k];
+                q.out[0][ob] = (unp - unm[k]) + bm[k][0];
+                q.out[1][ob] = (n1v - unm[k]) + bm[k][1];
+                q.out[2][ob] = (n2v - unm[k]) + bm[k][2];
+            }
+            // rotate the column's window and publish plane p + 1 for the neighbours
+            unm[k] = unp;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) bm[k][j] = bcur[k][j];
+            t0m[k] = tcur[k][0];
+            um[k] = uc[k];
+            uc[k] = up[k];
+            up[k] = nu2;
+            off[k] = o + g.pitch;
+            if (have_next) {
+                ofc[k] = nof;
+                T d[3];
+                split_vars<T, 3, ISO>(nq, nkq, d, bcur[k]);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) tcur[k][j] = nell * (bcur[k][j] - d[j]);
+                s_u[s ^ 1][col[k]] = uc[k];
+                s_t1[s ^ 1][col[k]] = tcur[k][1];
+                s_t2[s ^ 1][col[k]] = tcur[k][2];
+            }
+        }
+        __syncthreads();
+    }
+    // the volume's last plane: no plane below, its axis-0 difference is zero
+    if (P1 == g.n0) {
+        const int sm = (int)((g.n0 - 1) & 1);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            if (!owned[k]) continue;
+            const int64_t ob = off[k] - g.pitch;  // off has moved one plane past the last one computed
+            const bool e1p = i1[k] < g.n1 - 1, e2p = i2[k] < g.n2 - 1;
+            const T n1v = e1p ? s_un[sm][col[k] + S2] : unm[k];
+            const T n2v = e2p ? s_un[sm][col[k] + 1] : unm[k];
+            u_out[ob] = unm[k];
+            q.out[0][ob] = (unm[k] - unm[k]) + bm[k][0];
+            q.out[1][ob] = (n1v - unm[k]) + bm[k][1];
+            q.out[2][ob] = (n2v - unm[k]) + bm[k][2];
+        }
+    }
+}
+
 // explicit-(d, b) variant of the shrink step, used when the state cannot be kept compressed (adaptive ell:
 // the threshold changes between the iteration that produced d, b and the one that consumes them)
 template <typename T, int DIM, bool ISO>

@@ -34,6 +34,15 @@ void set_error(const char* fmt, ...) {
 
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 
+// a device temporary that is released on every path out of the scope (hipFree waits for work that still uses it)
+struct DevTmp {
+    void* p = nullptr;
+    DevTmp() = default;
+    DevTmp(const DevTmp&) = delete;
+    DevTmp& operator=(const DevTmp&) = delete;
+    ~DevTmp() { if (p) (void)hipFree(p); }
+};
+
 struct Ctx {
     dxh_tvd_desc desc{};
     Geom g{};
@@ -455,7 +464,7 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
     a.inc_partial = nullptr;
     a.nwaves_total = (int)(nchunks * a.nstrips);
     if (want_inc) {
-        // [K][nwaves] doubles; (re)allocated on demand, zero-filled so that unused slots do not matter
+        // [K][nwaves] doubles; (re)allocated on demand (every wave of the launch writes its slots)
         const size_t need = sizeof(double) * (size_t)K * a.nwaves_total;
         if (c->inc_bytes < need) {
             if (c->inc_partial) (void)hipFree(c->inc_partial);
@@ -604,6 +613,74 @@ static void launch_shrink(Ctx* c, const void* unew, bool iso, bool from_db) {
         hipLaunchKernelGGL((k_shrink<T, DIM, false, false>), grid, blk, 0, c->stream, c->g, (const T*)unew, q, db, co, cp);
 }
 
+// dim = 3: the whole iteration in one pass (k_fused3d)
+template <typename T>
+static void launch_fused3d(Ctx* c, int in, int out, bool iso) {
+    QPlanes<T, 3> q;
+    for (int j = 0; j < 3; ++j) {
+        q.in[j] = (const T*)c->q[j][in];
+        q.out[j] = (T*)c->q[j][out];
+    }
+    // float: the 2.5-D march; double: the brick kernel (the march needs 255 registers there and loses, 0.42 vs 0.39 ms on
+    // 256^3); DXH_FUSED_TUNE bit 4096 forces the bricks, 8192 the march
+    if (((sizeof(T) == 4) && !(c->tune & 4096)) || (c->tune & 8192)) {
+        // 2.5-D march.  Patch shape: the one of 4 x 256, 8 x 128, 16 x 64 (owning one row and one column less)
+        // that wastes the least of its columns on this volume (ties: the widest, whose rims are the shortest); plane
+        // chunks sized for ~4 blocks per CU.
+        int best_m2 = 64;
+        double best = -1.0;
+        for (int m2 : {256, 128, 64}) {
+            const int o1 = 1024 / m2 - 1, o2 = m2 - 1;  // owned
+            const double eff = ((double)c->g.n1 / (double)(((c->g.n1 + o1 - 1) / o1) * (o1 + 1))) *
+                               ((double)c->g.n2 / (double)(((c->g.n2 + o2 - 1) / o2) * (o2 + 1)));
+            if (eff > best * 1.001) { best = eff; best_m2 = m2; }
+        }
+        if (const char* e = getenv("DXH_MARCH_M2")) {  // developer knob
+            const int v = atoi(e);
+            if (v == 64 || v == 128 || v == 256) best_m2 = v;
+        }
+        const int o1 = 1024 / best_m2 - 1, o2 = best_m2 - 1;
+        const int nt1 = (int)((c->g.n1 + o1 - 1) / o1), nt2 = (int)((c->g.n2 + o2 - 1) / o2);
+        // All blocks of a launch take about the same time (same number of planes each), so the launch should fill the
+        // machine's resident-block slots once: as many plane chunks as fit without starting a second round.
+        auto launch = [&](auto kernel) {
+            int bpc = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, kernel, 256, 0) != hipSuccess || bpc < 1) bpc = 2;
+            if (c->waves_per_cu) bpc = std::max(1, c->waves_per_cu / 4);
+            const int64_t slots = (int64_t)c->num_cu * bpc, tiles = (int64_t)nt1 * nt2;
+            int64_t nchunk = std::max<int64_t>(1, slots / tiles);
+            int64_t ppc = std::max<int64_t>(std::min<int64_t>(c->g.n0, 8), (c->g.n0 + nchunk - 1) / nchunk);
+            if (c->force_chunks > 0) ppc = std::max<int64_t>(1, (c->g.n0 + c->force_chunks - 1) / c->force_chunks);
+            nchunk = (c->g.n0 + ppc - 1) / ppc;
+            const int64_t total = nchunk * tiles;
+            if (c->tune & 512) fprintf(stderr, "[dxh] march3d patch %dx%d tiles %lld chunks %lld (%lld planes) blocks/CU %d\n", o1 + 1, o2 + 1, (long long)tiles, (long long)nchunk, (long long)ppc, bpc);
+            hipLaunchKernelGGL(kernel, dim3((unsigned)((total + 7) / 8 * 8)), dim3(256), 0, c->stream, c->g, (const T*)c->of, q,
+                               (const T*)c->u[in], (T*)c->u[out], make_coef<T>(c), make_planes<T>(c), nt1, nt2, (int)nchunk,
+                               (int)ppc);
+        };
+#define DXH_M3(ISO_, M2_) launch(k_march3d<T, ISO_, M2_>)
+        if (iso) { if (best_m2 == 256) DXH_M3(true, 256); else if (best_m2 == 128) DXH_M3(true, 128); else DXH_M3(true, 64); }
+        else     { if (best_m2 == 256) DXH_M3(false, 256); else if (best_m2 == 128) DXH_M3(false, 128); else DXH_M3(false, 64); }
+#undef DXH_M3
+        return;
+    }
+    const int nt0 = (int)((c->g.n0 + kB0 - 1) / kB0), nt1 = (int)((c->g.n1 + kB1 - 1) / kB1),
+              nt2 = (int)((c->g.n2 + kB2 - 1) / kB2);
+    const dim3 grid((unsigned)((int64_t)nt0 * nt1 * nt2)), blk(256);
+    if (iso)
+        hipLaunchKernelGGL((k_fused3d<T, true>), grid, blk, 0, c->stream, c->g, (const T*)c->of, q, (const T*)c->u[in],
+                           (T*)c->u[out], make_coef<T>(c), make_planes<T>(c), nt1, nt2);
+    else
+        hipLaunchKernelGGL((k_fused3d<T, false>), grid, blk, 0, c->stream, c->g, (const T*)c->of, q, (const T*)c->u[in],
+                           (T*)c->u[out], make_coef<T>(c), make_planes<T>(c), nt1, nt2);
+}
+
+static bool fused3d_supported(const Ctx* c) {
+    if (c->desc.dim != 3 || c->desc.ndim != 3 || (c->tune & 2048)) return false;  // DXH_FUSED_TUNE bit 2048: three kernels
+    const int64_t tiles = ((c->g.n0 + kB0 - 1) / kB0) * ((c->g.n1 + kB1 - 1) / kB1) * ((c->g.n2 + kB2 - 1) / kB2);
+    return tiles < (int64_t)INT32_MAX / 4;  // either tiling (bricks, or patches x plane chunks) fits a 1-D grid
+}
+
 template <typename T>
 static void launch_jacobi(Ctx* c, const void* xin, void* xout) {
     hipLaunchKernelGGL((k_jacobi<T>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const T*)c->rs, (const T*)xin,
@@ -742,8 +819,12 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
     c->last_iso_prev = c->last_iso;
     c->last_iso = iso;
 
-    void* tmp = nullptr;
-    const bool need_generic = !fused_ok || c->from_db;
+    DevTmp tmp_guard;
+    void*& tmp = tmp_guard.p;
+    const bool explicit_mode = (flags & DXH_FLAG_EXPLICIT) || c->explicit_db;
+    const bool fused3d_ok = fused3d_supported(c) && jacobi_maxiter == 1 && !use_tol && !(flags & DXH_FLAG_NO_FUSED) &&
+                            !c->solver && !explicit_mode;
+    const bool need_generic = (!fused_ok && !fused3d_ok) || c->from_db;
     if (need_generic) {
         int rc = alloc_plane(c, &c->rs);
         if (rc) return rc;
@@ -751,7 +832,6 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
             DXH_HIP(hipMalloc(&tmp, c->plane_bytes));
         }
     }
-    const bool explicit_mode = (flags & DXH_FLAG_EXPLICIT) || c->explicit_db;
     if (explicit_mode) {
         fused_ok = false;
         int rc = alloc_plane(c, &c->rs);
@@ -796,7 +876,7 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
             const int K = pick_k(c, n_iter - it);
             launch_fused_multi<T>(c, in, out, iso, K, true);
             ++launches;
-            if (!c->inc_partial) { set_error("out of device memory for the increment partials"); if (tmp) (void)hipFree(tmp); return DXH_ENOMEM; }
+            if (!c->inc_partial) { set_error("out of device memory for the increment partials"); return DXH_ENOMEM; }
             hipLaunchKernelGGL(k_sum_partials, dim3(K), dim3(256), 0, c->stream, c->inc_partial, K * c->inc_nwaves,
                                c->red_out + 2);
             double incs[4] = {0, 0, 0, 0};
@@ -843,12 +923,16 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
             }
             ++launches;
             c->cur = out;
+        } else if (fused3d_ok && !c->from_db) {
+            launch_fused3d<T>(c, in, out, iso);
+            ++launches;
+            c->cur = out;
         } else if (explicit_mode) {
             // rhs from explicit planes, Jacobi, shrink back into the planes
             if (dim == 2) launch_rhs<T, 2>(c, iso, true); else launch_rhs<T, 3>(c, iso, true);
             ++launches;
             int rc = solve_u<T>(c, jacobi_maxiter, jacobi_tol, tmp, &launches);
-            if (rc) { if (tmp) (void)hipFree(tmp); return rc; }
+            if (rc) return rc;
             {
                 const dim3 grid = elem_grid(c->g), blk(256);
                 auto co = make_coef<T>(c);
@@ -866,7 +950,7 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
             if (dim == 2) launch_rhs<T, 2>(c, iso, fdb); else launch_rhs<T, 3>(c, iso, fdb);
             ++launches;
             int rc = solve_u<T>(c, jacobi_maxiter, jacobi_tol, tmp, &launches);
-            if (rc) { if (tmp) (void)hipFree(tmp); return rc; }
+            if (rc) return rc;
             if (dim == 2) launch_shrink<T, 2>(c, c->u[out], iso, fdb); else launch_shrink<T, 3>(c, c->u[out], iso, fdb);
             ++launches;
             // the q planes were updated in place in buffer `cur`; move them along with u
@@ -878,7 +962,7 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
         if (use_eps) {
             double inc = 0.0;
             int rc = sq_diff<T>(c, c->u[c->cur], c->u[c->cur ^ 1], 0, c->g.n0, &inc, 0);
-            if (rc) { if (tmp) (void)hipFree(tmp); return rc; }
+            if (rc) return rc;
             rel = std::sqrt(inc) / nrm_img;
             if (rel < eps) { converged = 1; break; }
         }
@@ -890,10 +974,7 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
         DXH_HIP(hipStreamSynchronize(c->stream));
         DXH_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     }
-    if (tmp) {
-        if (async) DXH_HIP(hipStreamSynchronize(c->stream));
-        DXH_HIP(hipFree(tmp));
-    }
+    if (tmp && async) DXH_HIP(hipStreamSynchronize(c->stream));  // tmp_guard frees it
     if (res) {
         res->iters_done = done;
         res->converged = converged;
@@ -1121,7 +1202,9 @@ static int set_coeffs_t(Ctx* c, double mu, const void* mu_arr, double omega, con
         return DXH_OK;
     }
     // heterogeneous: build the four planes on the device with NumPy's evaluation order
-    void *d_mu = nullptr, *d_om = nullptr, *d_ell = nullptr;
+    // (uploaded straight into the context's slots, released above / in dxh_tvd_destroy: nothing leaks on an error return)
+    void *&d_mu = c->in_mu, *&d_om = c->in_om, *&d_ell = c->in_ell;
+    c->in_valid = false;
     auto up = [&](const void* src, void** dst) -> int {
         if (!src) return DXH_OK;
         DXH_HIP(hipMalloc(dst, c->plane_bytes));
@@ -1156,9 +1239,6 @@ static int set_coeffs_t(Ctx* c, double mu, const void* mu_arr, double omega, con
     DXH_HIP(hipGetLastError());
     DXH_HIP(hipStreamSynchronize(c->stream));
     // the given arrays stay on the device: the fused heterogeneous sweep derives its coefficients from them
-    c->in_mu = d_mu;
-    c->in_om = d_om;
-    c->in_ell = d_ell;
     c->ell_s = ell_d;
     c->in_has_ell = has_ell;
     c->in_h = h;
@@ -1549,7 +1629,8 @@ int dxh_tvd_download(dxh_tvd_t h, void* u, void* d, void* b) {
             DXH_HIP(hipStreamSynchronize(c->stream));
             return DXH_OK;
         }
-        void *dd = nullptr, *bb = nullptr;
+        DevTmp dd_guard, bb_guard;
+        void *&dd = dd_guard.p, *&bb = bb_guard.p;
         if (d) DXH_HIP(hipMalloc(&dd, dense));
         if (b) DXH_HIP(hipMalloc(&bb, dense));
         const bool iso = c->last_iso;
@@ -1568,9 +1649,7 @@ int dxh_tvd_download(dxh_tvd_t h, void* u, void* d, void* b) {
         DXH_HIP(hipGetLastError());
         if (d) DXH_HIP(hipMemcpyAsync(d, dd, dense, hipMemcpyDefault, c->stream));
         if (b) DXH_HIP(hipMemcpyAsync(b, bb, dense, hipMemcpyDefault, c->stream));
-        DXH_HIP(hipStreamSynchronize(c->stream));
-        if (dd) DXH_HIP(hipFree(dd));
-        if (bb) DXH_HIP(hipFree(bb));
+        DXH_HIP(hipStreamSynchronize(c->stream));  // dd / bb are released by their guards
     }
     DXH_HIP(hipStreamSynchronize(c->stream));
     return DXH_OK;

@@ -35,6 +35,12 @@ def _h1_array(img: np.ndarray, mu: float, omega: float, dim: int, solver: Solver
     code = _lib.dtype_code(img.dtype)
     _lib.require_gpu()
     src = np.ascontiguousarray(img)
+    if img.ndim == dim + 1 and solver.tol is not None:
+        # with a tolerance every channel stops at its own sweep and returns its own iterate (the reference solves channel
+        # by channel, h1_regularization.py:54-67; Jacobi's stop test is a norm over the array it is given, jacobi.py:116-126)
+        moved = np.moveaxis(src, -1, 0)
+        res = np.stack([_h1_array(np.ascontiguousarray(ch), mu, omega, dim, solver) for ch in moved], axis=0)
+        return np.ascontiguousarray(np.moveaxis(res, 0, -1))
     if img.ndim == dim + 1 and dim == 2:
         # all channels in one launch: neighbour sum restricted to the spatial axes
         ndim, n0, n1, n2 = _lib.shape3(img.shape, dim)

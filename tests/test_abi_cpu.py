@@ -99,3 +99,21 @@ def test_image_container_copy_is_deep():
     assert im.img[0, 0] == 0 and cp.metadata()["name"] == "x" and cp.metadata()["tag"] == "frame 7"
     again = da.Image(cp.img, **cp.metadata())
     assert again.dimensions == im.dimensions and np.array_equal(again.origin, im.origin)
+
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_sources_do_not_import_torch():
+    """North star: no PyTorch in the product or the benchmark process (torch.distributed.run is only the launcher)."""
+    import re
+
+    pat = re.compile(r"^\s*(import torch|from torch)", re.M)
+    offenders = []
+    for base, _, files in os.walk(os.path.join(_ROOT, "darsia_amd")):
+        for f in files:
+            if f.endswith(".py") and pat.search(open(os.path.join(base, f)).read()):
+                offenders.append(os.path.join(base, f))
+    if pat.search(open(os.path.join(_ROOT, "bench.py")).read()):
+        offenders.append("bench.py")
+    assert not offenders, offenders

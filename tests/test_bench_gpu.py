@@ -1,5 +1,5 @@
 """bench.py contract checks on a real GPU: one JSON line with the required fields at N = 1, and the
-N-rank code path in rehearsal mode (ranks share the GPU, gloo-staged exchange)."""
+N-rank code path in rehearsal mode (ranks share the GPU, host-staged exchange over local sockets; no torch in bench.py)."""
 import json
 import os
 import socket
@@ -40,12 +40,21 @@ def test_single_gpu_line_has_contract_fields():
 
 
 def test_two_rank_rehearsal_runs_the_slab_path():
-    env = dict(os.environ, DXH_BENCH_REHEARSAL="gloo")
+    env = dict(os.environ, DXH_BENCH_REHEARSAL="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--height", "256", "--width", "512", "--iters", "16"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _last_json(r.stdout)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["rows_per_gpu"] == 256
+    # default for N > 1: strong scaling, the image's rows are split over the ranks
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["rows_per_gpu"] == 128
     assert "REHEARSAL" in d["data"] and d["value"] > 0
+    assert d["comm"]["transport"] == "host" and d["comm"]["exchanges"] >= 2
+    # weak scaling stays available
+    cmd2 = list(cmd)
+    cmd2[cmd2.index("--master-port") + 1] = str(_free_port())
+    r = subprocess.run(cmd2 + ["--scaling", "weak"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _last_json(r.stdout)
+    assert d["scaling"] == "weak" and d["config"]["rows_per_gpu"] == 256

@@ -4,11 +4,10 @@ import os
 import socket
 import sys
 
+import multiprocessing as mp
+
 import numpy as np
 import pytest
-import torch
-import torch.distributed as dist
-import torch.multiprocessing as mp
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
@@ -27,6 +26,10 @@ def _worker(rank, world, port, case, out_dir):
 
     use_gloo = case.get("transport", "gloo") == "gloo"
     if use_gloo:
+        # torch lives in the worker processes only: importing it into the pytest process would put a second ROCm stack
+        # (PyTorch's bundled one) next to the one libdarsia_hip.so uses
+        import torch.distributed as dist
+
         dist.init_process_group("gloo", rank=rank, world_size=world)
         transport = GlooTransport()
     else:
@@ -69,7 +72,14 @@ def test_slabs_equal_single_image(tmp_path, case):
     img = rng.random(case["shape"]).astype(case.get("dtype", "float32"))
     np.save(tmp_path / "img.npy", img)
     world = case["world"]
-    mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     got = np.concatenate([np.load(tmp_path / f"out_{r}.npy") for r in range(world)], axis=0)
     ref, _, _, done = O.split_bregman_tvd(img, mu=case["mu"], omega=case.get("omega", 1.0), max_num_iter=case["n_iter"],
                                           eps=case.get("eps"), isotropic=case.get("iso", False),

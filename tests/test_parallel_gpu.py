@@ -148,6 +148,34 @@ def test_rccl_single_rank_communicator(tmp_path):
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("order", ["lib_then_torch", "torch_then_lib"])
+def test_rccl_next_to_pytorchs_rocm_stack(order):
+    """A process that also imports PyTorch holds two ROCm stacks (PyTorch bundles its own HIP runtime and RCCL).  The
+    communicator must take the RCCL that sits on the HIP runtime libdarsia_hip.so is bound to, whichever was loaded
+    first (dxh_comm.hip: rccl::load)."""
+    import subprocess
+
+    code = (
+        "import os, sys\n"
+        "sys.path.insert(0, '.')\n"
+        "os.environ['MASTER_PORT'] = '%d'\n"
+        "order = '%s'\n"
+        "if order == 'torch_then_lib':\n"
+        "    import torch\n"
+        "from darsia_amd import _lib\n"
+        "_lib.require_gpu()\n"
+        "if order == 'lib_then_torch':\n"
+        "    import torch\n"
+        "from darsia_amd.parallel import Comm\n"
+        "c = Comm.rccl(0, 1, device=0)\n"
+        "assert c.allreduce([2.0, 3.0]) == [2.0, 3.0]\n"
+        "c.close()\n"
+        "print('RCCL_OK')\n") % (_free_port(), order)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
 @pytest.mark.parametrize("case", [
     dict(shape=(700, 420, 3), halo_iters=8, n_iter=40, flags=0),
     dict(shape=(700, 420, 3), halo_iters=8, n_iter=40, flags="no_overlap"),

@@ -301,6 +301,33 @@ def test_early_stop_with_temporal_blocking(golden, monkeypatch, name, eps, fuse_
     assert_bits(out2, O.split_bregman_tvd(img, mu=0.1, max_num_iter=7, promotion="strict"))
 
 
+@pytest.mark.parametrize("shape", [(24, 24, 24), (9, 17, 70), (1, 5, 3), (33, 8, 129), (8, 9, 64), (17, 1, 1)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("kind", ["aniso", "iso", "het"])
+def test_fused_volume_sweep_equals_three_kernels_and_oracle(shape, dtype, kind):
+    """dim = 3: the one-pass sweep (k_fused3d: bricks of 8 x 8 x 64 with their forward neighbours in LDS) against the
+    three-kernel path and the oracle, on shapes that do not fill whole bricks (examples/regularization.py:8-47 shape
+    class; split_bregman_tvd.py:84-89,129-146, jacobi.py:41-54)."""
+    rng = np.random.default_rng(21)
+    vol = rng.random(shape).astype(dtype)
+    mu = (0.03 + 0.2 * rng.random(shape)).astype(dtype) if kind == "het" else 0.1
+    iso = kind == "iso"
+    n = 5
+    outs = {}
+    for name, flags in (("fused3d", 0), ("three_kernel", _lib.FLAG_NO_FUSED)):
+        with da.DeviceTVD(vol.shape, vol.dtype, dim=3) as st:
+            st.set_coeffs(mu, 0.7, None, vol)
+            st.upload(vol)
+            res = st.run(n, isotropic=iso, flags=flags)
+            outs[name] = st.download(want_split=True)
+            launches = res.launches
+        assert launches == (n if name == "fused3d" else 3 * n)
+    for a, b in zip(outs["fused3d"], outs["three_kernel"]):
+        assert_bits(a, b)
+    ref = O.split_bregman_tvd(vol, mu=mu, omega=0.7, dim=3, max_num_iter=n, isotropic=iso, promotion="strict")
+    assert_bits(outs["fused3d"][0], ref)
+
+
 # ---- BASELINE.json full size (4000 x 8000 x 3 float32) -------------------------------------------------
 def test_full_size_config2_parity_and_invariants(monkeypatch):
     """configs[1] at its real size: (a) 3 iterations bit-exact against the oracle over the whole image (the NumPy
