@@ -26,9 +26,11 @@ run() {  # run NAME SRC [extra flags]
     names+=("${name}")
 }
 # heaviest first
-for k in 4 3 2; do
-    run "multi_f32_k${k}" dxh_multi.hip -DDXH_MULTI_T=float -DDXH_MULTI_K=${k}
-    run "multi_f64_k${k}" dxh_multi.hip -DDXH_MULTI_T=double -DDXH_MULTI_K=${k}
+for k in 3 4 2; do
+    for cs in 0 1; do   # channel sets: {1, 3} and {2, 4}
+        run "multi_f32_k${k}_c${cs}" dxh_multi.hip -DDXH_MULTI_T=float -DDXH_MULTI_K=${k} -DDXH_MULTI_CSET=${cs}
+        run "multi_f64_k${k}_c${cs}" dxh_multi.hip -DDXH_MULTI_T=double -DDXH_MULTI_K=${k} -DDXH_MULTI_CSET=${cs}
+    done
 done
 run tvd dxh_tvd.hip
 run chambolle dxh_chambolle.hip

@@ -12,10 +12,15 @@ struct FusedArgs;
 // Array-valued coefficients (a.derive != 0) are supported for K = kHetFuseK only.
 constexpr int kHetFuseK = 3;
 
-// C in {1, 3}; `pair` selects the experimental wave-pair kernel (only with -DDXH_ENABLE_PAIR, float, K = 4)
+// C in {1, 3} (launch_multi_kernel) or {2, 4} (launch_multi_kernel_c24); `pair` selects the experimental wave-pair kernel (only with -DDXH_ENABLE_PAIR, float, K = 4)
 template <typename T, int K>
 void launch_multi_kernel(int C, bool coupled, bool iso, bool want_inc, bool pair, const FusedArgs<T>& a, unsigned grid,
                          hipStream_t stream);
+
+// the same for C in {2, 4} (objects built with -DDXH_MULTI_CSET=1)
+template <typename T, int K>
+void launch_multi_kernel_c24(int C, bool coupled, bool iso, bool want_inc, bool pair, const FusedArgs<T>& a, unsigned grid,
+                             hipStream_t stream);
 
 extern template void launch_multi_kernel<float, 2>(int, bool, bool, bool, bool, const FusedArgs<float>&, unsigned, hipStream_t);
 extern template void launch_multi_kernel<float, 3>(int, bool, bool, bool, bool, const FusedArgs<float>&, unsigned, hipStream_t);
@@ -23,5 +28,11 @@ extern template void launch_multi_kernel<float, 4>(int, bool, bool, bool, bool, 
 extern template void launch_multi_kernel<double, 2>(int, bool, bool, bool, bool, const FusedArgs<double>&, unsigned, hipStream_t);
 extern template void launch_multi_kernel<double, 3>(int, bool, bool, bool, bool, const FusedArgs<double>&, unsigned, hipStream_t);
 extern template void launch_multi_kernel<double, 4>(int, bool, bool, bool, bool, const FusedArgs<double>&, unsigned, hipStream_t);
+extern template void launch_multi_kernel_c24<float, 2>(int, bool, bool, bool, bool, const FusedArgs<float>&, unsigned, hipStream_t);
+extern template void launch_multi_kernel_c24<float, 3>(int, bool, bool, bool, bool, const FusedArgs<float>&, unsigned, hipStream_t);
+extern template void launch_multi_kernel_c24<float, 4>(int, bool, bool, bool, bool, const FusedArgs<float>&, unsigned, hipStream_t);
+extern template void launch_multi_kernel_c24<double, 2>(int, bool, bool, bool, bool, const FusedArgs<double>&, unsigned, hipStream_t);
+extern template void launch_multi_kernel_c24<double, 3>(int, bool, bool, bool, bool, const FusedArgs<double>&, unsigned, hipStream_t);
+extern template void launch_multi_kernel_c24<double, 4>(int, bool, bool, bool, bool, const FusedArgs<double>&, unsigned, hipStream_t);
 
 }  // namespace dxh

@@ -1,5 +1,6 @@
-// One object per (DXH_MULTI_T, DXH_MULTI_K): instantiates k_fused_multi<T, C, COUPLED, ISO, K, NORM> for
-// C in {1, 3} and defines the launch switch declared in dxh_multi.h.  gfx950 only.
+// One object per (DXH_MULTI_T, DXH_MULTI_K, DXH_MULTI_CSET): instantiates k_fused_multi<T, C, COUPLED, ISO, K, NORM> for
+// C in {1, 3} (channel set 0: scalar and RGB images) or C in {2, 4} (set 1) and defines the launch switch declared in
+// dxh_multi.h.  gfx950 only.
 #include <type_traits>
 
 #include "dxh_kernels.h"
@@ -7,6 +8,10 @@
 
 #ifndef DXH_MULTI_T
 #error "compile with -DDXH_MULTI_T=float|double -DDXH_MULTI_K=2|3|4 (see build.sh)"
+#endif
+
+#ifndef DXH_MULTI_CSET
+#define DXH_MULTI_CSET 0
 #endif
 
 #ifndef DXH_HET_K
@@ -64,6 +69,7 @@ void launch_c(bool coupled, bool iso, bool want_inc, bool pair, const FusedArgs<
 
 }  // namespace
 
+#if DXH_MULTI_CSET == 0
 template <typename T, int K>
 void launch_multi_kernel(int C, bool coupled, bool iso, bool want_inc, bool pair, const FusedArgs<T>& a, unsigned grid,
                          hipStream_t stream) {
@@ -73,5 +79,16 @@ void launch_multi_kernel(int C, bool coupled, bool iso, bool want_inc, bool pair
 
 template void launch_multi_kernel<DXH_MULTI_T, DXH_MULTI_K>(int, bool, bool, bool, bool, const FusedArgs<DXH_MULTI_T>&, unsigned,
                                                             hipStream_t);
+#else
+template <typename T, int K>
+void launch_multi_kernel_c24(int C, bool coupled, bool iso, bool want_inc, bool pair, const FusedArgs<T>& a, unsigned grid,
+                             hipStream_t stream) {
+    if (C == 2) launch_c<T, 2, K>(coupled, iso, want_inc, pair, a, grid, stream);
+    else launch_c<T, 4, K>(coupled, iso, want_inc, pair, a, grid, stream);
+}
+
+template void launch_multi_kernel_c24<DXH_MULTI_T, DXH_MULTI_K>(int, bool, bool, bool, bool, const FusedArgs<DXH_MULTI_T>&,
+                                                                unsigned, hipStream_t);
+#endif
 
 }  // namespace dxh

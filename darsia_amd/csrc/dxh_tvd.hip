@@ -480,12 +480,13 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
     a.ci = make_coefin<T>(c);
     a.derive = c->het ? 1 : 0;  // array coefficients (multi_supported: only with the given planes at hand, K = kHetFuseK)
     // the kernels are instantiated in dxh_multi.hip (one object per element type and K, built in parallel)
-    launch_multi_kernel<T, K>(C, COUPLED, ISO, want_inc, pair, a, grid, c->stream);
+    if constexpr (C == 1 || C == 3) launch_multi_kernel<T, K>(C, COUPLED, ISO, want_inc, pair, a, grid, c->stream);
+    else launch_multi_kernel_c24<T, K>(C, COUPLED, ISO, want_inc, pair, a, grid, c->stream);
 }
 
 // channel counts the multi-iteration kernel is instantiated for
 static bool multi_supported(const Ctx* c) {
-    if (!(c->desc.dim == 2 && (c->g.n2 == 1 || c->g.n2 == 3)) || (c->tune & 8)) return false;
+    if (!(c->desc.dim == 2 && c->g.n2 >= 1 && c->g.n2 <= 4) || (c->tune & 8)) return false;
     if (c->g.n0 > (int64_t)INT32_MAX - 64) return false;  // the pipelines index rows with 32-bit integers
     if (c->het) return c->in_valid && !(c->tune & 32);  // array coefficients: derived in the kernel from the given planes
     // k_fused_multi divides through precomputed reciprocals: the divisors must be in a comfortable range
@@ -516,8 +517,12 @@ static void launch_fused_multi_c(Ctx* c, int in, int out, bool iso, int K, bool 
 
 template <typename T>
 static void launch_fused_multi(Ctx* c, int in, int out, bool iso, int K, bool want_inc = false) {
-    if (c->g.n2 == 1) launch_fused_multi_c<T, 1>(c, in, out, iso, K, want_inc);
-    else launch_fused_multi_c<T, 3>(c, in, out, iso, K, want_inc);
+    switch ((int)c->g.n2) {
+        case 1: launch_fused_multi_c<T, 1>(c, in, out, iso, K, want_inc); break;
+        case 2: launch_fused_multi_c<T, 2>(c, in, out, iso, K, want_inc); break;
+        case 3: launch_fused_multi_c<T, 3>(c, in, out, iso, K, want_inc); break;
+        default: launch_fused_multi_c<T, 4>(c, in, out, iso, K, want_inc); break;
+    }
 }
 
 template <typename T, int C, bool COUPLED>

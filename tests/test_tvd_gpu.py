@@ -328,6 +328,28 @@ def test_fused_volume_sweep_equals_three_kernels_and_oracle(shape, dtype, kind):
     assert_bits(outs["fused3d"][0], ref)
 
 
+@pytest.mark.parametrize("channels", [2, 4])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("fuse_k", [1, 2, 3, 4])
+def test_two_and_four_channel_images_run_the_temporally_blocked_sweep(monkeypatch, channels, dtype, fuse_k):
+    """(H, W, 2) and (H, W, 4) arrays (all axes coupled as in jacobi.py:41) through the K-iterations-per-launch
+    pipelines: same bits as the oracle, for iteration counts that are and are not multiples of K, with the eps
+    test, anisotropic and isotropic; and K iterations really are one launch."""
+    monkeypatch.setenv("DXH_FUSE_K", str(fuse_k))
+    rng = np.random.default_rng(100 + channels)
+    for shape in ((37, 300, channels), (130, 1030, channels)):
+        img = rng.random(shape).astype(dtype)
+        for n_iter, iso in ((fuse_k * 2, False), (fuse_k * 2 + 1, False), (5, True)):
+            out, res = run_device(img, mu=0.1, n_iter=n_iter, isotropic=iso)
+            assert_bits(out, O.split_bregman_tvd(img, mu=0.1, max_num_iter=n_iter, isotropic=iso, promotion="strict"))
+            assert res.launches == -(-n_iter // fuse_k)
+    img = rng.random((64, 300, channels)).astype(dtype)
+    ref, _, _, done = O.split_bregman_tvd(img, mu=0.1, max_num_iter=60, eps=2e-3, promotion="strict", return_state=True)
+    out, res = run_device(img, mu=0.1, n_iter=60, eps=2e-3)
+    assert res.converged == 1 and res.iters_done == done and 1 < done < 60
+    assert_bits(out, ref)
+
+
 # ---- BASELINE.json full size (4000 x 8000 x 3 float32) -------------------------------------------------
 def test_full_size_config2_parity_and_invariants(monkeypatch):
     """configs[1] at its real size: (a) 3 iterations bit-exact against the oracle over the whole image (the NumPy
