@@ -63,6 +63,7 @@ def parse():
     p.add_argument("--scaling", choices=("weak", "strong"), default=None,
                    help="N > 1: strong (default, configs[4]) or weak")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-self-check", action="store_true", help="skip the K = 1 replay of the timed iterations (N = 1)")
     p.add_argument("--cpu-sample", default="4000x8000", help="HxW of the CPU baseline sample")
     return p.parse_args()
 
@@ -146,6 +147,28 @@ def main():
         _lib.check(st.lib.dxh_tvd_sync(st._h))
         elapsed = time.perf_counter() - t0
         total_rows, rows_per_rank = H, H
+        # Outside the timed region: the state the timed launches left behind must be, bit for bit, what the
+        # one-iteration-per-launch sweep (the kernel that tests/test_tvd_gpu.py pins against the oracle at this very size)
+        # produces for the same number of iterations -- a benchmark that skipped work would fail here.
+        self_check = None
+        if not a.no_self_check:
+            import hashlib
+
+            got = st.download()
+            st.close()
+            os.environ["DXH_FUSE_K"] = "1"
+            st = DeviceTVD(img.shape, img.dtype, dim=2, device=local_rank)
+            st.set_coeffs(mu, 1.0, None, img)
+            st.upload(img)
+            n_total = a.iters * (a.warmup + a.steps)
+            r1 = st.run(n_total)
+            want = st.download()
+            del os.environ["DXH_FUSE_K"]
+            self_check = {"iterations": n_total, "k1_replay_launches": int(r1.launches),
+                          "bit_identical_to_k1_replay": bool(np.array_equal(got, want)),
+                          "sha256_of_result": hashlib.sha256(got.tobytes()).hexdigest()[:16]}
+            if not self_check["bit_identical_to_k1_replay"]:
+                raise SystemExit("bench self-check failed: timed state differs from the one-iteration-per-launch replay")
         st.close()
     else:
         from darsia_amd.parallel import SlabTVD, init_from_env, make_plan
@@ -244,6 +267,8 @@ def main():
             }
             if traffic:
                 out["roofline"]["traffic_source"] = traffic.get("source")
+            if self_check:
+                out["self_check"] = self_check
             if not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(C, a.cpu_sample)
         print(json.dumps(out), flush=True)

@@ -38,6 +38,15 @@ print("config 3: colour apply + isotropic TVD")
 A = np.eye(3) + 0.05 * np.random.default_rng(7).normal(size=(3, 3)); b = 0.01 * np.random.default_rng(7).normal(size=3)
 t("apply_affine_balance(rgb f32)  [PCIe-inclusive]", lambda: da.apply_affine_balance(rgb, A, b, clip=True))
 t("split_bregman_tvd(rgb, isotropic, 100 it) [PCIe-inclusive]", lambda: da.split_bregman_tvd(rgb, mu=0.1, max_num_iter=100, isotropic=True))
+u8 = (rgb * 255.0 + 0.5).astype(np.uint8)
+def chain_device():
+    d = da.DeviceArray.from_host(u8)
+    out = da.split_bregman_tvd(da.apply_affine_balance(d, A, b), mu=0.1, max_num_iter=100, isotropic=True)
+    return out.get()
+def chain_host():
+    return da.split_bregman_tvd(da.apply_affine_balance(u8, A, b), mu=0.1, max_num_iter=100, isotropic=True)
+t("config 3 chain, device-resident (uint8 up, colour, 100 it isotropic, float32 down)", chain_device)
+t("config 3 chain through host arrays between the operators", chain_host)
 print("default TVD(): chambolle on RGB-as-volume, eps 2e-4")
 out, iters = da.denoise_tv_chambolle(rgb, weight=0.1, return_iters=True)
 t0 = time.perf_counter(); out, iters = da.denoise_tv_chambolle(rgb, weight=0.1, return_iters=True); dt = time.perf_counter() - t0
@@ -70,6 +79,10 @@ t("denoise_tv_bregman(rgb, 64 sweeps)  [PCIe-inclusive]", lambda: da.denoise_tv_
 print("MG inside the TV loop (gray f32, depth 3, 2 smoother sweeps, 1 V-cycle per outer iteration, 20 outer iterations)")
 g2 = np.ascontiguousarray(gray.reshape(H, W))
 t("split_bregman_tvd(gray, solver=MG)  [PCIe-inclusive]", lambda: da.split_bregman_tvd(g2, mu=0.1, max_num_iter=20, solver=da.MG(depth=3, smoother_iterations=2, maxiter=1)))
+print("dim = 3 volume 256^3 float32 (device loop)")
+vol = np.random.default_rng(0).random((256, 256, 256)).astype(np.float32)
+st = da.DeviceTVD(vol.shape, vol.dtype, dim=3); st.set_coeffs(0.1, 1.0, None, vol); st.upload(vol); ms = loop_ms(st, 40)
+print(f"  fused 3-D sweep: {ms:.4f} ms/iter  {vol.size/ms/1e6:.1f} GVox/s"); st.close()
 print("Resize / CurvatureCorrection")
 t("Resize(fx=fy=0.5, inter_area)(rgb)  [PCIe-inclusive]", lambda: da.Resize(fx=0.5, fy=0.5, interpolation="inter_area")(rgb))
 t("Resize(shape=(3000, 6000), inter_linear)(rgb)  [PCIe-inclusive]", lambda: da.Resize(shape=(3000, 6000), interpolation="inter_linear")(rgb))

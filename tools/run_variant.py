@@ -1,0 +1,30 @@
+"""A few launches of one pipeline at the BASELINE size, for profiling (tools/sq_any.sh).
+usage: run_variant.py aniso|iso|het|chambolle|warp|vol3d|gray|f64"""
+import sys
+sys.path.insert(0, ".")
+import numpy as np
+import darsia_amd as da
+from darsia_amd.synthetic import synthetic_image
+v = sys.argv[1] if len(sys.argv) > 1 else "aniso"
+H, W = 4000, 8000
+if v in ("aniso", "iso", "het"):
+    img = synthetic_image(H, W, 3)
+    mu = 0.1
+    if v == "het":
+        mu = np.full(img.shape, 0.1, np.float32); mu[:, W // 2:] = 0.3
+    st = da.DeviceTVD(img.shape, img.dtype); st.set_coeffs(mu, 1.0, None, img); st.upload(img)
+    r = st.run(24, isotropic=(v == "iso")); print(v, "ms/iter", r.loop_ms / 24, "launches", r.launches); st.close()
+elif v in ("gray", "f64"):
+    img = synthetic_image(H, W, 1).astype(np.float64 if v == "f64" else np.float32)
+    st = da.DeviceTVD(img.shape, img.dtype); st.set_coeffs(0.1, 1.0, None, img); st.upload(img)
+    r = st.run(24); print(v, "ms/iter", r.loop_ms / 24); st.close()
+elif v == "chambolle":
+    img = synthetic_image(H, W, 3)
+    out, it = da.denoise_tv_chambolle(img, weight=0.1, max_num_iter=12, eps=0.0, return_iters=True); print("chambolle iterations", it)
+elif v == "warp":
+    img = da.Image(synthetic_image(H, W, 1)); patches = da.Patches(img, [10, 20])
+    disp = lambda p: np.array([6 * np.sin(np.pi * p[:, 0] / W), 4 * np.sin(np.pi * p[:, 1] / H)])
+    da.PiecewisePerspectiveTransform().find_and_warp(patches, disp)
+elif v == "vol3d":
+    vol = np.random.default_rng(0).random((256, 256, 256)).astype(np.float32)
+    st = da.DeviceTVD(vol.shape, vol.dtype, dim=3); st.set_coeffs(0.1, 1.0, None, vol); st.upload(vol); st.run(8); st.close()
