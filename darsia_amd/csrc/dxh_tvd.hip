@@ -113,6 +113,8 @@ struct Ctx {
     unsigned signal_target = 0;          // its value once every signalling launch so far has finished its interface chunks
     unsigned signal_pending = 0;         // waves the launch being built adds to it
     int wait_mode = 0;                   // how the comm stream waits for it: 1 hipStreamWaitValue32, 2 polling kernel
+    char* xbuf[4] = {nullptr, nullptr, nullptr, nullptr};  // staging: send up, send down, receive from below, receive from above
+    size_t xbytes[4] = {0, 0, 0, 0};
     double global_sq_img = -1.0;         // ||img||^2 over all ranks' owned rows
     int64_t split_launches = 0;          // statistics: launches that carried an overlapped exchange
 };
@@ -998,6 +1000,37 @@ static int64_t slab_own1(const Ctx* c) { return c->g.n0 - c->bot; }
 // plane, so the row blocks go out of / come into the planes directly.  What I send up is what the upper slab keeps as
 // its bottom halo (my first halo_bot owned rows); what I send down is the lower slab's top halo (my last halo_top owned
 // rows).
+// Up to eight device-to-device block copies in one launch (gather / scatter of halo rows); sizes are multiples of 16 B
+// (row pitch is a multiple of 128 B).
+struct CopySegs {
+    char* dst[8];
+    const char* src[8];
+    unsigned long long vec[8];  // 16-byte vectors per segment
+    unsigned long long total;
+    int n;
+    void add(void* d, const void* s_, size_t bytes) {
+        dst[n] = static_cast<char*>(d);
+        src[n] = static_cast<const char*>(s_);
+        vec[n] = bytes / 16;
+        total += bytes / 16;
+        ++n;
+    }
+};
+__global__ void __launch_bounds__(256) k_copy_segs(CopySegs a) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < a.total; i += stride) {
+        unsigned long long j = i;
+        int sgm = 0;
+        while (sgm < a.n - 1 && j >= a.vec[sgm]) { j -= a.vec[sgm]; ++sgm; }
+        reinterpret_cast<float4*>(a.dst[sgm])[j] = reinterpret_cast<const float4*>(a.src[sgm])[j];
+    }
+}
+static void launch_copy_segs(const CopySegs& a, hipStream_t st) {
+    if (a.n == 0 || a.total == 0) return;
+    const unsigned blocks = (unsigned)std::min<unsigned long long>((a.total + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_copy_segs, dim3(blocks), dim3(256), 0, st, a);
+}
+
 // Polls the interface-wave counter (fallback when hipStreamWaitValue32 is not available).  One lane; ends when the
 // counter has reached `target` (cyclic compare) or, so that the stream can never hang, after ~10 s of wall clock.
 __global__ void k_wait_counter(const unsigned* counter, unsigned target) {
@@ -1021,26 +1054,40 @@ static int start_exchange(Ctx* c, bool after_signal) {
         DXH_HIP(hipEventRecord(c->eM, c->stream));
         DXH_HIP(hipStreamWaitEvent(cm->stream, c->eM, 0));
     }
+    // The rows of the 1 + dim state planes are gathered into one staging block per direction, so that an exchange is four
+    // messages (RCCL packs up to eight point-to-point operations into one kernel: twelve row blocks took two kernels, the
+    // second of which started only when the first had ended), and scattered into the halo rows on arrival.
     const size_t row_bytes = (size_t)c->g.pitch * c->esz;
     void* fields[4] = {c->u[c->cur], c->q[0][c->cur], c->q[1][c->cur], c->q[2][c->cur]};
     const int nf = 1 + c->desc.dim;
-    P2POp ops[16];
-    int n = 0;
     const int64_t o0 = slab_own0(c), o1 = slab_own1(c);
     auto rows = [&](int f, int64_t r0) { return static_cast<char*>(fields[f]) + (size_t)r0 * row_bytes; };
+    const size_t up_b = (size_t)c->halo_bot * row_bytes, dn_b = (size_t)c->halo_top * row_bytes;  // per field
+    CopySegs pack{}, unpack{};
+    if (c->top > 0)
+        for (int f = 0; f < nf; ++f) {
+            pack.add(c->xbuf[0] + f * up_b, rows(f, o0), up_b);                       // my first rows -> upper's bottom halo
+            unpack.add(rows(f, 0), c->xbuf[3] + f * dn_b, (size_t)c->top * row_bytes);  // upper's last rows -> my top halo
+        }
+    if (c->bot > 0)
+        for (int f = 0; f < nf; ++f) {
+            pack.add(c->xbuf[1] + f * dn_b, rows(f, o1 - c->halo_top), dn_b);          // my last rows -> lower's top halo
+            unpack.add(rows(f, o1), c->xbuf[2] + f * up_b, (size_t)c->bot * row_bytes);  // lower's first rows -> my bottom halo
+        }
+    launch_copy_segs(pack, cm->stream);
     // A single rank whose slab has halos on both sides is its own neighbour (periodic in axis 0): sends first, then the
     // receives in the order that pairs them with those sends (what goes up fills a bottom halo).
     const int up = (cm->rank - 1 + cm->world) % cm->world, down = (cm->rank + 1) % cm->world;
-    if (c->top > 0)
-        for (int f = 0; f < nf; ++f) ops[n++] = P2POp{up, rows(f, o0), (size_t)c->halo_bot * row_bytes, 1};
-    if (c->bot > 0)
-        for (int f = 0; f < nf; ++f) ops[n++] = P2POp{down, rows(f, o1 - c->halo_top), (size_t)c->halo_top * row_bytes, 1};
-    if (c->bot > 0)
-        for (int f = 0; f < nf; ++f) ops[n++] = P2POp{down, rows(f, o1), (size_t)c->bot * row_bytes, 0};
-    if (c->top > 0)
-        for (int f = 0; f < nf; ++f) ops[n++] = P2POp{up, rows(f, 0), (size_t)c->top * row_bytes, 0};
+    P2POp ops[4];
+    int n = 0;
+    if (c->top > 0) ops[n++] = P2POp{up, c->xbuf[0], nf * up_b, 1};
+    if (c->bot > 0) ops[n++] = P2POp{down, c->xbuf[1], nf * dn_b, 1};
+    if (c->bot > 0) ops[n++] = P2POp{down, c->xbuf[2], nf * up_b, 0};
+    if (c->top > 0) ops[n++] = P2POp{up, c->xbuf[3], nf * dn_b, 0};
     int rc = comm_exchange(cm, ops, n);
     if (rc) return rc;
+    launch_copy_segs(unpack, cm->stream);
+    DXH_HIP(hipGetLastError());
     DXH_HIP(hipEventRecord(c->eC, cm->stream));
     c->pendC = true;
     c->halo_valid = c->halo_top;
@@ -1356,6 +1403,8 @@ int dxh_tvd_destroy(dxh_tvd_t h) {
     for (hipEvent_t e : {c->eM, c->eC})
         if (e) (void)hipEventDestroy(e);
     if (c->signal) (void)hipFree(c->signal);
+    for (char* b : c->xbuf)
+        if (b) (void)hipFree(b);
     delete c->solver;
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
     fr(c->of); fr(c->u[0]); fr(c->u[1]); fr(c->rs);
@@ -1744,6 +1793,17 @@ int dxh_tvd_attach_comm(dxh_tvd_t h, dxh_comm_t comm, int64_t halo_top_rows, int
     c->halo_bot = halo_bottom_rows;
     c->top = top;
     c->bot = bot;
+    {
+        const size_t row_bytes = (size_t)c->g.pitch * c->esz, nf = 1 + (size_t)c->desc.dim;
+        const size_t need[4] = {top ? nf * halo_bottom_rows * row_bytes : 0, bot ? nf * halo_top_rows * row_bytes : 0,
+                                bot ? nf * halo_bottom_rows * row_bytes : 0, top ? nf * halo_top_rows * row_bytes : 0};
+        for (int i = 0; i < 4; ++i) {
+            if (c->xbytes[i] >= need[i]) continue;
+            if (c->xbuf[i]) { DXH_HIP(hipFree(c->xbuf[i])); c->xbuf[i] = nullptr; c->xbytes[i] = 0; }
+            DXH_HIP(hipMalloc((void**)&c->xbuf[i], need[i]));
+            c->xbytes[i] = need[i];
+        }
+    }
     c->halo_valid = halo_top_rows;  // an uploaded slab carries valid halos
     c->global_sq_img = -1.0;
     return DXH_OK;
