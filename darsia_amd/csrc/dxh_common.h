@@ -268,7 +268,29 @@ __device__ __forceinline__ float t_copysign(float m, float s) { return copysignf
 __device__ __forceinline__ double t_copysign(double m, double s) { return copysign(m, s); }
 __device__ __forceinline__ float t_clamp_sym(float x, float k) { return __builtin_amdgcn_fmed3f(x, -k, k); }
 __device__ __forceinline__ double t_clamp_sym(double x, double k) { return fmin(fmax(x, -k), k); }
-__device__ __forceinline__ float t_sqrt(float x) { return sqrtf(x); }  // correctly rounded (no fast-math)
+// Correctly rounded square root of a sum of squares (x >= 0 or NaN).  float: the compiler's IEEE expansion is ~16
+// instructions (scaling for denormals, v_sqrt_f32, two neighbour residuals, selects).  For x in [2^-100, inf) the
+// five-instruction chain  y = rsq(x); g = x y; h = y / 2; r = fma(-g, g, x); s = fma(r, h, g)  gives the SAME float for
+// every input -- decided by trying all of them on the device (k_sqrt_check / dxh_sqrt_probe, 1.9e9 values, a few
+// milliseconds; tests/test_tvd_gpu.py runs it).  x = 0 falls out right (rsq sees max(x, 2^-100): g = 0 y = 0); inputs
+// in (0, 2^-100) -- |q| below 1e-15 -- and +inf take the IEEE path on a rarely executed branch.
+constexpr float kSqrtFastMin = 0x1p-100f;
+__device__ __forceinline__ float t_sqrt_chain(float x) {
+    const float y = __builtin_amdgcn_rsqf(fmaxf(x, kSqrtFastMin));
+    const float g = x * y, h = 0.5f * y;
+    const float r = fmaf(-g, g, x);
+    return fmaf(r, h, g);
+}
+__device__ __forceinline__ float t_sqrt(float x) {
+#ifdef DXH_SQRT_IEEE  // A/B builds: the compiler's expansion everywhere
+    return sqrtf(x);
+#endif
+    float s = t_sqrt_chain(x);
+    const unsigned u = __float_as_uint(x);
+    // outside [2^-100, inf) and not zero (NaN and negative bit patterns included): the IEEE square root
+    if (__builtin_expect((u - 0x0D800000u) >= (0x7F800000u - 0x0D800000u) && u != 0u, 0)) s = sqrtf(x);
+    return s;
+}
 __device__ __forceinline__ double t_sqrt(double x) { return sqrt(x); }
 
 // Inside a rarely taken, wave-uniform `if` block: keeps the block a real s_cbranch instead of a run of

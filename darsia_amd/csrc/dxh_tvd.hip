@@ -1926,6 +1926,43 @@ int dxh_tvd_sync(dxh_tvd_t h) {
 }
 
 // ---- one-shot helpers ----------------------------------------------------------------------------
+// every float bit pattern: t_sqrt (the five-instruction chain with its rarely taken IEEE branch, dxh_common.h) against
+// the compiler's correctly rounded sqrtf; NaN results compare equal to NaN
+__global__ void __launch_bounds__(256) k_sqrt_check(unsigned long long* mismatches, unsigned long long* chain_inputs) {
+    unsigned long long bad = 0, fast = 0;
+    for (unsigned long long b = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; b < (1ull << 32);
+         b += (unsigned long long)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float((unsigned)b);
+        const float want = sqrtf(x), got = t_sqrt(x);
+        const bool same = (want != want) ? (got != got) : (__float_as_uint(want) == __float_as_uint(got));
+        bad += same ? 0 : 1;
+        const unsigned u = (unsigned)b;
+        fast += ((u - 0x0D800000u) < (0x7F800000u - 0x0D800000u) || u == 0u) ? 1 : 0;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+    atomicAdd(chain_inputs, fast);
+}
+
+int dxh_sqrt_probe(int device, unsigned long long* mismatches, unsigned long long* chain_inputs) {
+    DXH_REQUIRE(mismatches && chain_inputs, "null argument");
+    int ndev = 0;
+    DXH_HIP(hipGetDeviceCount(&ndev));
+    DXH_REQUIRE(device >= 0 && device < ndev, "device %d not available", device);
+    DXH_HIP(hipSetDevice(device));
+    unsigned long long* d = nullptr;
+    DXH_HIP(hipMalloc((void**)&d, 16));
+    DevTmp guard;
+    guard.p = d;
+    DXH_HIP(hipMemset(d, 0, 16));
+    hipLaunchKernelGGL(k_sqrt_check, dim3(8192), dim3(256), 0, 0, d, d + 1);
+    DXH_HIP(hipGetLastError());
+    unsigned long long h[2] = {0, 0};
+    DXH_HIP(hipMemcpy(h, d, 16, hipMemcpyDeviceToHost));
+    *mismatches = h[0];
+    *chain_inputs = h[1];
+    return DXH_OK;
+}
+
 int dxh_div3_probe(int device, float d0, float r0, float d1, float r1, unsigned* bad) {
     DXH_REQUIRE(bad, "null argument");
     DXH_HIP(hipSetDevice(device));

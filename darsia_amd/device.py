@@ -63,6 +63,13 @@ class DeviceArray:
             _lib.check(self.lib.dxh_mem_copy(self.device, _lib.ptr(out), self.ptr, self.nbytes))
         return out
 
+    def copy(self) -> "DeviceArray":
+        """A device-to-device copy (what ``CombinedModel`` starts from, signals/models/combinedmodel.py:39)."""
+        d = DeviceArray(self.shape, self.dtype, self.device)
+        if self.nbytes:
+            _lib.check(self.lib.dxh_mem_copy(self.device, d.ptr, self.ptr, self.nbytes))
+        return d
+
     def reshape(self, *shape) -> "DeviceArray":
         """A view with another shape (shares the memory; keep the original alive)."""
         shape = shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else shape

@@ -19,6 +19,7 @@ from typing import Optional
 import numpy as np
 
 from . import _lib
+from .device import DeviceArray
 
 INTER_NEAREST, INTER_LINEAR, INTER_AREA = 0, 1, 3  # cv2's flag values
 _DTYPES = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.uint8): 2}
@@ -70,8 +71,9 @@ def _area_table(n_src: int, n_dst: int, scale: float):
 
 
 def cv_resize(img: np.ndarray, dsize=None, fx=None, fy=None, interpolation: Optional[int] = None) -> np.ndarray:
-    """``cv2.resize`` of every channel of an (H, W) or (H, W, C) array (``dsize`` = (width, height) as in cv2)."""
-    if not isinstance(img, np.ndarray) or img.ndim not in (2, 3):
+    """``cv2.resize`` of every channel of an (H, W) or (H, W, C) array (``dsize`` = (width, height) as in cv2).
+    A ``DeviceArray`` in gives a ``DeviceArray`` out (only the small tap tables cross PCIe)."""
+    if not isinstance(img, (np.ndarray, DeviceArray)) or img.ndim not in (2, 3):
         raise ValueError("img must be an (H, W) or (H, W, C) array")
     if img.dtype not in _DTYPES:
         raise TypeError(f"dtype {img.dtype} not supported on the device (float32, float64, uint8)")
@@ -120,11 +122,13 @@ def cv_resize(img: np.ndarray, dsize=None, fx=None, fy=None, interpolation: Opti
         yi, yw = _linear_taps(dh, h, scale_y, inv_y, area_mode)
         put("xi", xi), put("xw", xw), put("yi", yi), put("yw", yw)
     _lib.require_gpu()
-    src = np.ascontiguousarray(img)
+    on_device = isinstance(img, DeviceArray)
+    src = img if on_device else np.ascontiguousarray(img)
     chans = 1 if src.ndim == 2 else src.shape[2]
-    out = np.empty((dh, dw) if src.ndim == 2 else (dh, dw, chans), src.dtype)
-    _lib.check(_lib.load().dxh_resize(_lib.default_device(), _DTYPES[src.dtype], h, w, chans, _lib.ptr(src), dh, dw,
-                                       C.byref(plan), _lib.ptr(out)))
+    out_shape = (dh, dw) if src.ndim == 2 else (dh, dw, chans)
+    out = DeviceArray(out_shape, src.dtype, src.device) if on_device else np.empty(out_shape, src.dtype)
+    _lib.check(_lib.load().dxh_resize(src.device if on_device else _lib.default_device(), _DTYPES[src.dtype], h, w, chans,
+                                       _lib.ptr(src), dh, dw, C.byref(plan), _lib.ptr(out)))
     return out
 
 
@@ -176,6 +180,17 @@ class Resize:
         # the reference copies the array first (resize.py:141); the device path never writes into its input, and a
         # 384 MB host copy costs more than the whole resize
         arr = img.img if input_is_image else img
+        if isinstance(arr, DeviceArray):
+            # device in, device out: the chain Resize -> TVD -> Resize of the presets
+            # (presets/fluidflower/benchmarkco2model.py:78-84) stays in HBM
+            if self.dtype is not None and np.dtype(self.dtype) != arr.dtype:
+                raise TypeError("a device-resident array cannot change dtype in Resize")
+            if arr.ndim not in (2, 3):
+                raise ValueError("device-resident arrays with 2 or 3 axes are supported")
+            resized = cv_resize(arr, dsize=self.dsize, fx=self.fx, fy=self.fy, interpolation=self.interpolation)
+            if self.is_conservative:
+                raise NotImplementedError("conservative rescaling of a device-resident array")
+            return resized
         if self.dtype is not None:
             arr = arr.astype(self.dtype)
         original_shape = arr.shape

@@ -245,6 +245,13 @@ int dxh_tvd_energy(dxh_tvd_t ctx, int which, double* value);
  * set when some x is NOT rounded correctly for d0 / d1.
  */
 int dxh_div3_probe(int device, float d0, float r0, float d1, float r1, unsigned* bad);
+/*
+ * Diagnostic.  The float kernels take the square root of the isotropic shrinkage (split_bregman_tvd.py:107-126) and of
+ * Chambolle's gradient norm through a five-instruction reciprocal-square-root chain where that equals the correctly
+ * rounded square root, and through the IEEE sequence elsewhere.  This entry compares the function the kernels use with
+ * sqrtf on ALL 2^32 float bit patterns: *mismatches must come back 0; *chain_inputs = how many inputs took the chain.
+ */
+int dxh_sqrt_probe(int device, unsigned long long* mismatches, unsigned long long* chain_inputs);
 
 /*
  * One-shot Jacobi solve  mass * x - diffusion * laplace(x) = rhs  (jacobi.py:74-133),

@@ -140,3 +140,22 @@ def test_config4_registration_of_two_full_size_frames():
     got = field.reshape(H, WID, 2)[rr.ravel(), cc.ravel()]
     np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-12)
     assert isinstance(ta.interpolator_translation_x, RBFInterpolator)
+
+
+def test_resize_tvd_resize_chain_stays_on_the_device():
+    """The presets' "scale by downsampling" chain, CombinedModel([Resize, TVD, Resize])
+    (presets/fluidflower/benchmarkco2model.py:78-84, signals/models/combinedmodel.py:29-52): given a DeviceArray it
+    runs without a host hop and returns a DeviceArray whose bits equal the chain through host arrays."""
+    sig = synthetic_image(1500, 2200, 1)
+    chain = da.CombinedModel([
+        da.Resize(fx=0.5, fy=0.5, interpolation="inter_area"),
+        da.TVD(method="heterogeneous bregman", weight=0.05, regularization=0.1, max_num_iter=30, eps=None),
+        da.Resize(shape=sig.shape, interpolation="inter_linear"),
+    ])
+    host = chain(sig)
+    dev = chain(da.DeviceArray.from_host(sig))
+    assert isinstance(dev, da.DeviceArray) and dev.shape == sig.shape and dev.dtype == sig.dtype
+    assert np.array_equal(dev.get(), host)
+    # the default TVD() method (Chambolle) chains the same way
+    chain2 = da.CombinedModel([da.Resize(fx=0.5, fy=0.5, interpolation="inter_area"), da.TVD(weight=0.1, max_num_iter=20)])
+    assert np.array_equal(chain2(da.DeviceArray.from_host(sig)).get(), chain2(sig))

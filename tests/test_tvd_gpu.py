@@ -350,6 +350,17 @@ def test_two_and_four_channel_images_run_the_temporally_blocked_sweep(monkeypatc
     assert_bits(out, ref)
 
 
+def test_square_root_chain_is_the_correctly_rounded_square_root_for_every_float():
+    """The float kernels' square root (isotropic shrinkage, Chambolle's norm) is a five-instruction rsq chain on
+    [2^-100, inf) and the IEEE sequence elsewhere; the device compares it with sqrtf on all 2^32 bit patterns."""
+    import ctypes as C
+
+    bad, chain = C.c_ulonglong(1), C.c_ulonglong(0)
+    _lib.check(_lib.load().dxh_sqrt_probe(_lib.default_device(), C.byref(bad), C.byref(chain)))
+    assert bad.value == 0
+    assert chain.value == (0x7F800000 - 0x0D800000) + 1   # every float in [2^-100, inf) and +0
+
+
 # ---- BASELINE.json full size (4000 x 8000 x 3 float32) -------------------------------------------------
 def test_full_size_config2_parity_and_invariants(monkeypatch):
     """configs[1] at its real size: (a) 3 iterations bit-exact against the oracle over the whole image (the NumPy
