@@ -81,8 +81,12 @@ __global__ void __launch_bounds__(256) k_ch_p(ChArgs<T> a) {
         nsum = (double)n;
         n = n * a.tau_over_w;
         n = n + T(1);
+        T num[NDIM], quo[NDIM];
 #pragma unroll
-        for (int ax = 0; ax < NDIM; ++ax) a.p[ax][e.off] = (a.p[ax][e.off] - a.tau * g[ax]) / n;
+        for (int ax = 0; ax < NDIM; ++ax) num[ax] = a.p[ax][e.off] - a.tau * g[ax];
+        div_shared<T, NDIM>(num, n, quo);
+#pragma unroll
+        for (int ax = 0; ax < NDIM; ++ax) a.p[ax][e.off] = quo[ax];
     }
     block_sum_store<256>(nsum, a.partial);
 }
@@ -154,8 +158,12 @@ __global__ void __launch_bounds__(256) k_ch_fused(ChFusedArgs<T, NDIM> a) {
         nsum = (double)n;
         n = n * a.tau_over_w;
         n = n + T(1);
+        T num[NDIM], quo[NDIM];
 #pragma unroll
-        for (int ax = 0; ax < NDIM; ++ax) a.pout[ax][e.off] = (a.pin[ax][e.off] - a.tau * g[ax]) / n;
+        for (int ax = 0; ax < NDIM; ++ax) num[ax] = a.pin[ax][e.off] - a.tau * g[ax];
+        div_shared<T, NDIM>(num, n, quo);
+#pragma unroll
+        for (int ax = 0; ax < NDIM; ++ax) a.pout[ax][e.off] = quo[ax];
     }
     // two deterministic block sums
     block_sum_store<256>(sq, a.partial_d2);
@@ -310,9 +318,17 @@ __global__ void __launch_bounds__(256) k_ch_march(ChMarchArgs<T> a) {
             }
             n = n * a.tau_over_w;
             n = n + T(1);
-            r0[j] = (pc0[j] - a.tau * g0) / n;
-            r1[j] = (pc1[j] - a.tau * g1) / n;
-            if constexpr (HAS3) r2[j] = (pc2[j] - a.tau * g2) / n;
+            if constexpr (HAS3) {
+                const T num[3] = {pc0[j] - a.tau * g0, pc1[j] - a.tau * g1, pc2[j] - a.tau * g2};
+                T quo[3];
+                div_shared<T, 3>(num, n, quo);
+                r0[j] = quo[0]; r1[j] = quo[1]; r2[j] = quo[2];
+            } else {
+                const T num[2] = {pc0[j] - a.tau * g0, pc1[j] - a.tau * g1};
+                T quo[2];
+                div_shared<T, 2>(num, n, quo);
+                r0[j] = quo[0]; r1[j] = quo[1];
+            }
         }
         if (store_lane) {
             store_vec_nt(q0 + r * P, r0);
@@ -443,10 +459,18 @@ __global__ void __launch_bounds__(256) k_ch_march2(ChMarch2Args<T> aa) {
             }
             n = n * a.tau_over_w;
             n = n + T(1);
-            r0[j] = (c0[j] - a.tau * g0) / n;
-            r1[j] = (c1[j] - a.tau * g1) / n;
-            if constexpr (HAS3) r2[j] = (c2[j] - a.tau * g2) / n;
-            else r2[j] = T(0);
+            if constexpr (HAS3) {
+                const T num[3] = {c0[j] - a.tau * g0, c1[j] - a.tau * g1, c2[j] - a.tau * g2};
+                T quo[3];
+                div_shared<T, 3>(num, n, quo);
+                r0[j] = quo[0]; r1[j] = quo[1]; r2[j] = quo[2];
+            } else {
+                const T num[2] = {c0[j] - a.tau * g0, c1[j] - a.tau * g1};
+                T quo[2];
+                div_shared<T, 2>(num, n, quo);
+                r0[j] = quo[0]; r1[j] = quo[1];
+                r2[j] = T(0);
+            }
         }
     };
 

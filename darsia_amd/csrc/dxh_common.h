@@ -11,6 +11,7 @@
 #include <cstring>
 #include <initializer_list>
 #include <thread>
+#include <type_traits>
 #include <utility>
 
 #include "../../include/darsia_hip.h"
@@ -387,6 +388,58 @@ __device__ __forceinline__ T abs_min_all(const T (&x)[N], const T (&y)[N]) {
 template <typename T>
 __device__ __forceinline__ bool div_unsafe(T x) {
     return t_abs(x) < DivSafe<T>::tiny && x != T(0);
+}
+
+// ---- several quotients with one per-element divisor (Chambolle's p / norm) -----------------------------
+// float: r = rcp(d) refined once,  r = fma(fma(-d, rcp(d), 1), rcp(d), rcp(d)),  IS the correctly rounded reciprocal
+// RN(1/d) for every float d in [2^-100, 2^100] -- decided by trying all of them on the device (k_rcp_check /
+// dxh_rcp_probe; the test suite runs it).  With an exact RN(1/d) the five-operation refinement of div_by_const above
+// yields RN(x/d) (same theorem, same provisos: x zero or not tiny, nothing under- or overflows), so NQ quotients cost
+// 3 + 5 NQ instructions instead of ~14 NQ for the IEEE sequence.  The proven range used here: d and every non-zero |x|
+// within [2^-62, 2^62), hence quotients within (2^-124, 2^124) -- all normal.  The screen lets exact zeros through
+// (bits - 1 wraps a zero to the largest unsigned); anything else takes the IEEE division on a rarely executed branch.
+// A single quotient gains nothing over the IEEE sequence once the screen is paid (the isotropic shrinkage keeps it);
+// double keeps the IEEE division (no exhaustive proof there).
+constexpr float kDivLo = 0x1p-62f, kDivHi = 0x1p+62f;
+__device__ __forceinline__ float t_rcp_rn(float d) {
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    return fmaf(fmaf(-d, r0, 1.0f), r0, r0);
+}
+__device__ __forceinline__ bool div_elem_safe(float x, float d) {
+    const float ax = fabsf(x);
+    return (x == 0.0f || (ax >= kDivLo && ax < kDivHi)) && d >= kDivLo && d < kDivHi;
+}
+// q[i] = x[i] / d for NQ numerators and one positive divisor
+template <typename T, int NQ>
+__device__ __forceinline__ void div_shared(const T (&x)[NQ], T d, T (&q)[NQ]) {
+#ifdef DXH_DIV_IEEE  // A/B builds
+    constexpr bool fast = false;
+#else
+    constexpr bool fast = std::is_same<T, float>::value && NQ >= 2;
+#endif
+    if constexpr (fast) {
+        const float r = t_rcp_rn(d);
+        // screen: every numerator zero or >= 2^-62 in magnitude (bits << 1 drops the sign, - 1 wraps a zero to the
+        // largest unsigned, so zeros never lower the minimum); their magnitudes sum to less than 2^62 (a NaN or inf
+        // numerator makes the sum fail the comparison); the divisor within [2^-62, 2^62)
+        unsigned lo = 0xFFFFFFFFu;
+        float sum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            q[i] = div_by_const<float>(x[i], d, r);
+            lo = min(lo, (__float_as_uint(x[i]) << 1) - 1u);
+            sum = sum + fabsf(x[i]);
+        }
+        const bool ok = lo >= (__float_as_uint(kDivLo) << 1) - 1u && sum < kDivHi && d >= kDivLo && d < kDivHi;
+        if (__builtin_expect(!ok, 0)) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i)
+                if (!div_elem_safe(x[i], d)) q[i] = x[i] / d;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) q[i] = x[i] / d;
+    }
 }
 
 // (d, b) of one pixel from its stored state q = b_old + D(u) ("dub" in the reference):

@@ -1943,24 +1943,96 @@ __global__ void __launch_bounds__(256) k_sqrt_check(unsigned long long* mismatch
     atomicAdd(chain_inputs, fast);
 }
 
-int dxh_sqrt_probe(int device, unsigned long long* mismatches, unsigned long long* chain_inputs) {
-    DXH_REQUIRE(mismatches && chain_inputs, "null argument");
+// every float in [2^-100, 2^100]: t_rcp_rn (v_rcp_f32 + one Newton step, dxh_common.h) against RN(1 / d)
+__global__ void __launch_bounds__(256) k_rcp_check(unsigned long long* mismatches, unsigned long long* tested) {
+    unsigned long long bad = 0, n = 0;
+    const unsigned long long lo = 0x0D800000ull, hi = 0x71800000ull + 1ull;
+    for (unsigned long long b = lo + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; b < hi;
+         b += (unsigned long long)gridDim.x * blockDim.x) {
+        const float d = __uint_as_float((unsigned)b);
+        bad += (__float_as_uint(t_rcp_rn(d)) == __float_as_uint(1.0f / d)) ? 0 : 1;
+        ++n;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+    atomicAdd(tested, n);
+}
+
+// div_shared (three quotients through one reciprocal, dxh_common.h) against the IEEE division on pseudo-random operands:
+// raw bit patterns (every class of float: zeros, denormals, NaN, inf, both signs), operands in the ranges images have, and
+// operands straddling the screen's thresholds.  Statistical, unlike the two exhaustive checks above: the exactness of the
+// refinement given RN(1/d) is Markstein's theorem, this guards the screening logic around it.
+__device__ __forceinline__ unsigned mix32(unsigned long long v) {
+    v ^= v >> 33; v *= 0xff51afd7ed558ccdull; v ^= v >> 33; v *= 0xc4ceb9fe1a85ec53ull; v ^= v >> 33;
+    return (unsigned)v;
+}
+__global__ void __launch_bounds__(256) k_div_shared_check(unsigned long long* mismatches, unsigned long long* tested) {
+    unsigned long long bad = 0, n = 0;
+    const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (unsigned long long it = 0; it < 4096; ++it) {
+        const unsigned long long base = (tid * 4096 + it) * 8;
+        float x[3], d;
+        const unsigned mode = mix32(base + 7) % 3;
+        auto gen = [&](unsigned long long k, bool positive) -> float {
+            const unsigned r = mix32(base + k);
+            if (mode == 0) return __uint_as_float(positive ? (r & 0x7FFFFFFFu) : r);            // any bit pattern
+            if (mode == 1) {                                                                     // image-like magnitudes
+                const float m = 1.0f + (float)(r & 0xFFFFFF) * 0x1p-24f;
+                const int e = (int)((r >> 24) & 31) - 20;
+                const float v = ldexpf(m, e);
+                return (!positive && (r >> 31)) ? -v : ((r >> 29) == 0 ? 0.0f * v : v);
+            }
+            const int e = ((r >> 24) & 1) ? 62 : -62;                                              // around the thresholds
+            const float v = ldexpf(1.0f + (float)(r & 0xFFFFFF) * 0x1p-24f, e + (int)((r >> 25) & 3) - 2);
+            return (!positive && (r >> 31)) ? -v : v;
+        };
+        for (int i = 0; i < 3; ++i) x[i] = gen(i, false);
+        d = gen(3, true);
+        float q[3];
+        div_shared<float, 3>(x, d, q);
+        for (int i = 0; i < 3; ++i) {
+            // numerically equal (a zero quotient may come out as +0 where the IEEE division gives -0: the refinement adds
+            // +0 and -0; no later operation of the algorithm can tell them apart) or both NaN
+            const float want = x[i] / d;
+            const bool same = (want != want) ? (q[i] != q[i]) : (want == q[i]);
+            bad += same ? 0 : 1;
+        }
+        n += 3;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+    atomicAdd(tested, n);
+}
+
+static int run_probe(int device, void (*kernel)(unsigned long long*, unsigned long long*), unsigned long long* a,
+                     unsigned long long* b) {
+    DXH_REQUIRE(a && b, "null argument");
     int ndev = 0;
     DXH_HIP(hipGetDeviceCount(&ndev));
     DXH_REQUIRE(device >= 0 && device < ndev, "device %d not available", device);
     DXH_HIP(hipSetDevice(device));
-    unsigned long long* d = nullptr;
-    DXH_HIP(hipMalloc((void**)&d, 16));
     DevTmp guard;
-    guard.p = d;
+    DXH_HIP(hipMalloc(&guard.p, 16));
+    unsigned long long* d = static_cast<unsigned long long*>(guard.p);
     DXH_HIP(hipMemset(d, 0, 16));
-    hipLaunchKernelGGL(k_sqrt_check, dim3(8192), dim3(256), 0, 0, d, d + 1);
+    hipLaunchKernelGGL(kernel, dim3(8192), dim3(256), 0, 0, d, d + 1);
     DXH_HIP(hipGetLastError());
     unsigned long long h[2] = {0, 0};
     DXH_HIP(hipMemcpy(h, d, 16, hipMemcpyDeviceToHost));
-    *mismatches = h[0];
-    *chain_inputs = h[1];
+    *a = h[0];
+    *b = h[1];
     return DXH_OK;
+}
+
+int dxh_rcp_probe(int device, unsigned long long* mismatches, unsigned long long* tested) {
+    int rc = run_probe(device, k_rcp_check, mismatches, tested);
+    if (rc || *mismatches) return rc;
+    unsigned long long bad2 = 0, n2 = 0;
+    rc = run_probe(device, k_div_shared_check, &bad2, &n2);   // 8192 x 256 x 4096 operand sets
+    *mismatches += bad2;
+    return rc;
+}
+
+int dxh_sqrt_probe(int device, unsigned long long* mismatches, unsigned long long* chain_inputs) {
+    return run_probe(device, k_sqrt_check, mismatches, chain_inputs);
 }
 
 int dxh_div3_probe(int device, float d0, float r0, float d1, float r1, unsigned* bad) {

@@ -252,6 +252,15 @@ int dxh_div3_probe(int device, float d0, float r0, float d1, float r1, unsigned*
  * sqrtf on ALL 2^32 float bit patterns: *mismatches must come back 0; *chain_inputs = how many inputs took the chain.
  */
 int dxh_sqrt_probe(int device, unsigned long long* mismatches, unsigned long long* chain_inputs);
+/*
+ * Diagnostic.  Chambolle's update divides the components of p by one per-element norm (skimage _denoise.py:379-384, as
+ * called from restoration/tvd.py:77-83).  The float kernels form ONE reciprocal, v_rcp_f32 refined by a Newton step, and
+ * refine each quotient with exact residuals; that is the correctly rounded quotient provided the reciprocal is RN(1/d).
+ * This entry checks it for every float d in [2^-100, 2^100] (*tested = how many d) and then compares the whole
+ * three-quotient routine, screening included, with the IEEE division on 2.6e10 pseudo-random operand sets (all classes of
+ * floats, image-like magnitudes, values around the screen's thresholds): *mismatches must come back 0.
+ */
+int dxh_rcp_probe(int device, unsigned long long* mismatches, unsigned long long* tested);
 
 /*
  * One-shot Jacobi solve  mass * x - diffusion * laplace(x) = rhs  (jacobi.py:74-133),

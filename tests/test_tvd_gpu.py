@@ -359,6 +359,10 @@ def test_square_root_chain_is_the_correctly_rounded_square_root_for_every_float(
     _lib.check(_lib.load().dxh_sqrt_probe(_lib.default_device(), C.byref(bad), C.byref(chain)))
     assert bad.value == 0
     assert chain.value == (0x7F800000 - 0x0D800000) + 1   # every float in [2^-100, inf) and +0
+    # the shared reciprocal of Chambolle's three quotients: v_rcp_f32 + one Newton step == RN(1 / d) on [2^-100, 2^100]
+    bad, n = C.c_ulonglong(1), C.c_ulonglong(0)
+    _lib.check(_lib.load().dxh_rcp_probe(_lib.default_device(), C.byref(bad), C.byref(n)))
+    assert bad.value == 0 and n.value == 0x71800000 - 0x0D800000 + 1
 
 
 # ---- BASELINE.json full size (4000 x 8000 x 3 float32) -------------------------------------------------

@@ -21,6 +21,9 @@ elif v in ("gray", "f64"):
 elif v == "chambolle":
     img = synthetic_image(H, W, 3)
     out, it = da.denoise_tv_chambolle(img, weight=0.1, max_num_iter=12, eps=0.0, return_iters=True); print("chambolle iterations", it)
+elif v == "chambolle60":
+    img = synthetic_image(H, W, 3)
+    da.denoise_tv_chambolle(img, weight=0.1, max_num_iter=60, eps=0.0)
 elif v == "warp":
     img = da.Image(synthetic_image(H, W, 1)); patches = da.Patches(img, [10, 20])
     disp = lambda p: np.array([6 * np.sin(np.pi * p[:, 0] / W), 4 * np.sin(np.pi * p[:, 1] / H)])
