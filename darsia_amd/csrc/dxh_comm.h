@@ -24,6 +24,8 @@ struct Comm {
     double* d_red = nullptr;       // 16 doubles of device scratch for all-reduces
     char* h_stage = nullptr;       // pinned staging of the host transport
     size_t h_stage_bytes = 0;
+    int refs = 0;                  // contexts attached (dxh_tvd_attach_comm); destruction waits for the last one
+    bool dead = false;             // dxh_comm_destroy was called while contexts were still attached
     int64_t exchanges = 0;         // statistics
     int64_t bytes_sent = 0;
 };
@@ -33,5 +35,7 @@ struct Comm {
 int comm_exchange(Comm* cm, const P2POp* ops, int n);
 // Blocking all-reduce of n <= 16 host doubles over all ranks; op 0 = sum, 1 = max.
 int comm_allreduce(Comm* cm, double* vals, int n, int op);
+// A context lets go of its communicator; frees it if dxh_comm_destroy has been called meanwhile.
+void comm_release(Comm* cm);
 
 }  // namespace dxh

@@ -208,6 +208,11 @@ static void comm_free(Comm* cm) {
     delete cm;
 }
 
+void comm_release(Comm* cm) {
+    if (!cm) return;
+    if (--cm->refs <= 0 && cm->dead) comm_free(cm);
+}
+
 }  // namespace dxh
 
 using namespace dxh;
@@ -273,7 +278,13 @@ int dxh_comm_create_host(dxh_comm_t* out, int device, int rank, int world, dxh_c
 }
 
 int dxh_comm_destroy(dxh_comm_t h) {
-    comm_free(reinterpret_cast<Comm*>(h));
+    Comm* cm = reinterpret_cast<Comm*>(h);
+    if (!cm) return DXH_OK;
+    if (cm->refs > 0) {
+        cm->dead = true;  // contexts still hold it (their streams wait on ours): the last dxh_tvd_destroy frees it
+        return DXH_OK;
+    }
+    comm_free(cm);
     return DXH_OK;
 }
 

@@ -1166,6 +1166,13 @@ static int run_slab_t(Ctx* c, int n_iter, int m, double eps, uint32_t flags, dxh
             if ((rc = slab_join(c))) return rc;
             // the launch in front of an exchange runs its interface chunks first and counts them (make_layout)
             c->signalling = overlap && xchg_after;
+            if (c->signalling && c->signal_target > 0x40000000u) {
+                // far from wrapping, but cheap to rule out: drain and restart the counter
+                DXH_HIP(hipStreamSynchronize(c->stream));
+                DXH_HIP(hipStreamSynchronize(cm->stream));
+                DXH_HIP(hipMemset(c->signal, 0, 256));
+                c->signal_target = 0;
+            }
             launch_any<T>(c, in, out, iso, dpp, K);
             if (c->signalling) {
                 c->signal_target += c->signal_pending;
@@ -1405,6 +1412,7 @@ int dxh_tvd_destroy(dxh_tvd_t h) {
     if (c->signal) (void)hipFree(c->signal);
     for (char* b : c->xbuf)
         if (b) (void)hipFree(b);
+    comm_release(c->comm);
     delete c->solver;
     auto fr = [](void* p) { if (p) (void)hipFree(p); };
     fr(c->of); fr(c->u[0]); fr(c->u[1]); fr(c->rs);
@@ -1787,6 +1795,10 @@ int dxh_tvd_attach_comm(dxh_tvd_t h, dxh_comm_t comm, int64_t halo_top_rows, int
             const int v = atoi(e);
             if (v == 1 || v == 2) c->wait_mode = v;
         }
+    }
+    if (c->comm != cm) {
+        comm_release(c->comm);
+        ++cm->refs;
     }
     c->comm = cm;
     c->halo_top = halo_top_rows;

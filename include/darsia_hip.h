@@ -209,7 +209,8 @@ int dxh_comm_info(dxh_comm_t comm, int* rank, int* world, int* kind, int64_t* ex
 /*
  * Make `ctx` one slab of a distributed problem.  The context's n0 rows are [top halo | owned rows | bottom halo];
  * a side with desc.top_is_boundary / bottom_is_boundary set has no halo.  All ranks pass the same halo row counts.
- * The communicator must outlive the context.  A one-rank communicator with halos on BOTH sides makes the slab its own
+ * A communicator destroyed while contexts are still attached stays alive until the last of them is destroyed (no exchange
+ * may be started after dxh_comm_destroy).  A one-rank communicator with halos on BOTH sides makes the slab its own
  * neighbour: the problem is periodic along axis 0 (exercises exchange and overlap on a single GPU).
  */
 int dxh_tvd_attach_comm(dxh_tvd_t ctx, dxh_comm_t comm, int64_t halo_top_rows, int64_t halo_bottom_rows);
