@@ -164,6 +164,27 @@ __global__ void __launch_bounds__(256) k_jacobi(Geom g, const T* __restrict__ rs
     xout[e.off] = rs[e.off] + acc / dsc;
 }
 
+// The same sweep for volumes (all three axes summed) with the index arithmetic of a 3-D grid -- block = 256 elements
+// of one row of axis 2, blockIdx.y = row, blockIdx.z = plane -- instead of 64-bit divisions per element: the sweep is a
+// 12-byte-per-element stream and the divisions were what it spent its time on (256^3 float32: 0.080 -> see DESIGN.md).
+template <typename T>
+__global__ void __launch_bounds__(256) k_jacobi_vol(Geom g, const T* __restrict__ rs, const T* __restrict__ xin, Coef<T> c,
+                                                     CoefPlanes<T> cp, T* __restrict__ xout) {
+    const int64_t i2 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i2 >= g.n2) return;
+    const int64_t i1 = blockIdx.y, i0 = blockIdx.z;
+    const int64_t off = i0 * g.pitch + i1 * g.n2 + i2;
+    T acc = T(0);
+    acc = acc + xin[i0 > 0 ? off - g.pitch : off];
+    acc = acc + xin[i0 < g.n0 - 1 ? off + g.pitch : off];
+    acc = acc + xin[i1 > 0 ? off - g.n2 : off];
+    acc = acc + xin[i1 < g.n1 - 1 ? off + g.n2 : off];
+    acc = acc + xin[i2 > 0 ? off - 1 : off];
+    acc = acc + xin[i2 < g.n2 - 1 ? off + 1 : off];
+    const T dsc = cp.dsc ? cp.dsc[off] : c.dsc;
+    xout[off] = rs[off] + acc / dsc;
+}
+
 // q_j <- backward_diff(u_new, j) + b_j       split_bregman_tvd.py:136-146 (both branches)
 template <typename T, int DIM, bool ISO, bool FROM_DB>
 __global__ void __launch_bounds__(256) k_shrink(Geom g, const T* __restrict__ unew, QPlanes<T, DIM> q, DBPlanes<T> db,

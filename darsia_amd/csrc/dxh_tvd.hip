@@ -690,11 +690,17 @@ static bool fused3d_supported(const Ctx* c) {
 
 template <typename T>
 static void launch_jacobi(Ctx* c, const void* xin, void* xout) {
+    if (c->g.ndim == 3 && c->g.nsum_axes == 3 && c->g.n2 >= 64 && c->g.n1 <= 65535 && c->g.n0 <= 65535 && !(c->tune & 16384)) {
+        // volumes: 3-D grid, no per-element index divisions (DXH_FUSED_TUNE bit 16384: the generic kernel)
+        const dim3 grid((unsigned)((c->g.n2 + 255) / 256), (unsigned)c->g.n1, (unsigned)c->g.n0);
+        hipLaunchKernelGGL((k_jacobi_vol<T>), grid, dim3(256), 0, c->stream, c->g, (const T*)c->rs, (const T*)xin,
+                           make_coef<T>(c), make_planes<T>(c), (T*)xout);
+        return;
+    }
     hipLaunchKernelGGL((k_jacobi<T>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const T*)c->rs, (const T*)xin,
                        make_coef<T>(c), make_planes<T>(c), (T*)xout);
 }
 
-// K Jacobi sweeps in one pass (k_jacobi_multi): dim = 2, scalar coefficients, 1 or 3 channels
 static bool jacobi_multi_supported(const Ctx* c) {
     return c->desc.dim == 2 && !c->het && (c->g.n2 == 1 || c->g.n2 == 3) && !(c->tune & 64);
 }

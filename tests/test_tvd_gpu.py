@@ -365,6 +365,26 @@ def test_square_root_chain_is_the_correctly_rounded_square_root_for_every_float(
     assert bad.value == 0 and n.value == 0x71800000 - 0x0D800000 + 1
 
 
+@pytest.mark.parametrize("shape", [(24, 24, 24), (9, 17, 70), (40, 33, 129), (3, 5, 2), (70, 26, 57), (1, 1, 9)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("maxiter", [2, 3, 4, 5, 7, 20])
+def test_multi_sweep_jacobi_on_volumes(shape, dtype, maxiter):
+    """Jacobi(maxiter > 1) with dim = 3 (examples/regularization.py:8-47 runs Jacobi(maxiter=20) on a volume) against the
+    oracle's sweeps (jacobi.py:107-114), stand-alone and as the inner solver of the TV loop, on ragged shapes."""
+    rng = np.random.default_rng(31)
+    x0 = rng.random(shape).astype(dtype)
+    rhs = rng.random(shape).astype(dtype)
+    sol = da.Jacobi(maxiter=maxiter, dim=3, mass_coeff=0.7, diffusion_coeff=0.3)
+    got = sol(x0, rhs)
+    want = O.jacobi(x0, rhs, 0.7, 0.3, dim=3, maxiter=maxiter, promotion="strict")
+    assert_bits(got, want)
+    if maxiter in (3, 20) and shape != (1, 1, 9):
+        out, res = run_device(x0, mu=0.1, omega=0.9, dim=3, n_iter=3, jm=maxiter)
+        assert_bits(out, O.split_bregman_tvd(x0, mu=0.1, omega=0.9, dim=3, max_num_iter=3, jacobi_maxiter=maxiter,
+                                             promotion="strict"))
+        assert res.launches == 3 * (2 + maxiter)  # rhs + sweeps + shrink per outer iteration
+
+
 # ---- BASELINE.json full size (4000 x 8000 x 3 float32) -------------------------------------------------
 def test_full_size_config2_parity_and_invariants(monkeypatch):
     """configs[1] at its real size: (a) 3 iterations bit-exact against the oracle over the whole image (the NumPy
