@@ -14,6 +14,10 @@ from darsia_amd.synthetic import synthetic_image
 W, C, K_HALO, ITERS, STEPS = 16000, 3, int(os.environ.get("HALO", "20")), 100, 3
 os.environ.setdefault("MASTER_PORT", "29611")
 comm = Comm.rccl(0, 1, device=0)
+# warm the clocks: the first timed configuration otherwise reads a few per cent slow
+_img = synthetic_image(2000, W, C)
+with da.DeviceTVD(_img.shape, _img.dtype, dim=2) as _st:
+    _st.set_coeffs(0.1, 1.0, None, _img); _st.upload(_img); _st.run(400)
 for n in (8, 4, 2):
     rows = 8000 // n
     img = synthetic_image(rows, W, C)
@@ -24,20 +28,33 @@ for n in (8, 4, 2):
                     flags=_lib.FLAG_NO_OVERLAP if mode == "serial" else 0)
         s.run(ITERS, more_to_come=True, asynchronous=True)
         s.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(STEPS):
-            s.run(ITERS, more_to_come=True, asynchronous=True)
-        s.synchronize()
-        line[mode + "_ms_per_step"] = round((time.perf_counter() - t0) / STEPS * 1e3, 3)
+        best = 1e9
+        for _rep in range(3):
+            t0 = time.perf_counter()
+            for _ in range(STEPS):
+                s.run(ITERS, more_to_come=True, asynchronous=True)
+            s.synchronize()
+            best = min(best, (time.perf_counter() - t0) / STEPS * 1e3)
+        line[mode + "_ms_per_step"] = round(best, 3)
         s.close()
     with da.DeviceTVD(img.shape, img.dtype, dim=2) as st:
         st.set_coeffs(0.1, 1.0, None, img)
         st.upload(img)
         st.run(ITERS)
-        t0 = time.perf_counter()
-        for _ in range(STEPS):
-            st.run(ITERS)
-        line["no_exchange_ms_per_step"] = round((time.perf_counter() - t0) / STEPS * 1e3, 3)
-    line["ideal_share_of_N1_step_ms"] = None
+        best = 1e9
+        for _rep in range(3):
+            t0 = time.perf_counter()
+            for _ in range(STEPS):
+                st.run(ITERS)
+            best = min(best, (time.perf_counter() - t0) / STEPS * 1e3)
+        line["no_exchange_ms_per_step"] = round(best, 3)
     print(line, flush=True)
+# the whole image on one GPU, for the ratio
+img = synthetic_image(8000, W, C)
+with da.DeviceTVD(img.shape, img.dtype, dim=2) as st:
+    st.set_coeffs(0.1, 1.0, None, img); st.upload(img); st.run(ITERS)
+    best = 1e9
+    for _rep in range(3):
+        t0 = time.perf_counter(); st.run(ITERS); best = min(best, (time.perf_counter() - t0) * 1e3)
+print({"ranks": 1, "rows": 8000, "whole_image_ms_per_step": round(best, 3)}, flush=True)
 comm.close()
