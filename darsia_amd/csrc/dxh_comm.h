@@ -30,9 +30,9 @@ struct Comm {
     int64_t bytes_sent = 0;
 };
 
-// Enqueue all ops on comm->stream as ONE group (they progress concurrently).  RCCL: asynchronous; host transport:
-// blocks the calling thread until the transfer is done (rehearsal / tests only).
-int comm_exchange(Comm* cm, const P2POp* ops, int n);
+// Enqueue all ops on `stream` as ONE group (they progress concurrently).  RCCL: asynchronous; host transport: blocks the
+// calling thread until the transfer is done (rehearsal / tests only).
+int comm_exchange(Comm* cm, const P2POp* ops, int n, hipStream_t stream);
 // Blocking all-reduce of n <= 16 host doubles over all ranks; op 0 = sum, 1 = max.
 int comm_allreduce(Comm* cm, double* vals, int n, int op);
 // A context lets go of its communicator; frees it if dxh_comm_destroy has been called meanwhile.

@@ -112,7 +112,7 @@ static int load() {
         }                                                                                                     \
     } while (0)
 
-int comm_exchange(Comm* cm, const P2POp* ops, int n) {
+int comm_exchange(Comm* cm, const P2POp* ops, int n, hipStream_t stream) {
     if (n <= 0) return DXH_OK;
     cm->exchanges += 1;
     for (int i = 0; i < n; ++i)
@@ -121,8 +121,8 @@ int comm_exchange(Comm* cm, const P2POp* ops, int n) {
         DXH_NCCL(rccl::g_api.GroupStart());
         for (int i = 0; i < n; ++i) {
             ncclResult_t r = ops[i].is_send
-                        ? rccl::g_api.Send(ops[i].dev, ops[i].bytes, rccl::kChar, ops[i].peer, (rccl::CommT)cm->nccl, cm->stream)
-                        : rccl::g_api.Recv(ops[i].dev, ops[i].bytes, rccl::kChar, ops[i].peer, (rccl::CommT)cm->nccl, cm->stream);
+                        ? rccl::g_api.Send(ops[i].dev, ops[i].bytes, rccl::kChar, ops[i].peer, (rccl::CommT)cm->nccl, stream)
+                        : rccl::g_api.Recv(ops[i].dev, ops[i].bytes, rccl::kChar, ops[i].peer, (rccl::CommT)cm->nccl, stream);
             if (r != rccl::kSuccess) {
                 (void)rccl::g_api.GroupEnd();
                 set_error("ncclSend/ncclRecv failed: %s", rccl::g_api.GetErrorString(r));
@@ -151,19 +151,19 @@ int comm_exchange(Comm* cm, const P2POp* ops, int n) {
         is_send[i] = ops[i].is_send;
         bufs[i] = cm->h_stage + off;
         bytes[i] = ops[i].bytes;
-        if (ops[i].is_send) DXH_HIP(hipMemcpyAsync(bufs[i], ops[i].dev, ops[i].bytes, hipMemcpyDeviceToHost, cm->stream));
+        if (ops[i].is_send) DXH_HIP(hipMemcpyAsync(bufs[i], ops[i].dev, ops[i].bytes, hipMemcpyDeviceToHost, stream));
         off += (ops[i].bytes + 255) / 256 * 256;
     }
-    DXH_HIP(hipStreamSynchronize(cm->stream));
+    DXH_HIP(hipStreamSynchronize(stream));
     int rc = cm->xfn(cm->user, n, peers.data(), is_send.data(), bufs.data(), bytes.data());
     if (rc != 0) {
         set_error("the host transport callback failed with code %d", rc);
         return DXH_EHIP;
     }
     for (int i = 0; i < n; ++i)
-        if (!ops[i].is_send) DXH_HIP(hipMemcpyAsync(ops[i].dev, bufs[i], ops[i].bytes, hipMemcpyHostToDevice, cm->stream));
+        if (!ops[i].is_send) DXH_HIP(hipMemcpyAsync(ops[i].dev, bufs[i], ops[i].bytes, hipMemcpyHostToDevice, stream));
     // the staging buffer is reused by the next exchange: the copies must have left it
-    DXH_HIP(hipStreamSynchronize(cm->stream));
+    DXH_HIP(hipStreamSynchronize(stream));
     return DXH_OK;
 }
 

@@ -106,8 +106,9 @@ struct Ctx {
     int64_t halo_top = 0, halo_bot = 0;  // the plan's halo rows (the same on every rank)
     int64_t top = 0, bot = 0;            // halo rows this slab really has above / below its owned rows
     int64_t halo_valid = 0;              // rows of the top-side halo budget still valid (a sweep consumes one)
-    hipEvent_t eM = nullptr, eC = nullptr;  // main-stream marker, exchange done
-    bool pendC = false;                  // an exchange the main stream has not waited for yet
+    hipStream_t alt = nullptr;           // the context alternates between two streams: an exchange and everything after it
+    hipStream_t alt_owned = nullptr;     //   go to the other one, so the launch behind an exchange follows it in stream order
+    hipEvent_t eL = nullptr;             // "everything enqueued on the previous stream is done"
     bool signalling = false;             // the next fused launch puts the interface chunks first and counts them in *signal
     unsigned* signal = nullptr;          // device counter bumped by every finished interface wave
     unsigned signal_target = 0;          // its value once every signalling launch so far has finished its interface chunks
@@ -192,11 +193,9 @@ static unsigned apply_layout(Ctx* c, FusedArgs<T>& a, const ChunkLayout& l, int 
     return (unsigned)(8 * ((ta + 7) / 8 + (tb + 7) / 8));
 }
 
-// the main stream waits (on the device) for an exchange still in flight
-static int slab_join(Ctx* c) {
-    if (c->pendC) { DXH_HIP(hipStreamWaitEvent(c->stream, c->eC, 0)); c->pendC = false; }
-    return DXH_OK;
-}
+// Nothing to join: after an exchange the context's work continues on the stream the exchange was enqueued on, so
+// c->stream is always ordered behind everything the context has in flight (start_exchange).
+static int slab_join(Ctx*) { return DXH_OK; }
 
 static int alloc_plane(Ctx* c, void** p) {
     if (*p) return DXH_OK;
@@ -1053,15 +1052,19 @@ __global__ void k_wait_counter(const unsigned* counter, unsigned target) {
 static int start_exchange(Ctx* c, bool after_signal) {
     Comm* cm = c->comm;
     if (c->from_db) { set_error("halo exchange before the first iteration of a warm start is not supported"); return DXH_ESTATE; }
+    // Overlapped exchange: it -- and every launch after it -- goes to the context's OTHER stream (a different hardware
+    // queue: one of the two streams is created with high priority), so that it can start while the signalling launch is
+    // still running, and what follows an exchange follows it in stream order (an event between two streams cost ~80 us
+    // from the end of the scatter to the start of the next launch).  The only cross-stream dependence left is "the
+    // previous stream has drained", which as a rule has happened long before it is looked at.  Serialised exchange: same
+    // stream, plain stream order, no event at all.
+    hipStream_t from = c->stream, to = after_signal ? c->alt : c->stream;
     if (after_signal) {
         // start as soon as every interface wave of the launch just enqueued has released its rows
         if (c->wait_mode == 1)
-            DXH_HIP(hipStreamWaitValue32(cm->stream, c->signal, c->signal_target, hipStreamWaitValueGte, 0xffffffffu));
+            DXH_HIP(hipStreamWaitValue32(to, c->signal, c->signal_target, hipStreamWaitValueGte, 0xffffffffu));
         else
-            hipLaunchKernelGGL(k_wait_counter, dim3(1), dim3(1), 0, cm->stream, c->signal, c->signal_target);
-    } else {
-        DXH_HIP(hipEventRecord(c->eM, c->stream));
-        DXH_HIP(hipStreamWaitEvent(cm->stream, c->eM, 0));
+            hipLaunchKernelGGL(k_wait_counter, dim3(1), dim3(1), 0, to, c->signal, c->signal_target);
     }
     // The rows of the 1 + dim state planes are gathered into one staging block per direction, so that an exchange is four
     // messages (RCCL packs up to eight point-to-point operations into one kernel: twelve row blocks took two kernels, the
@@ -1083,7 +1086,7 @@ static int start_exchange(Ctx* c, bool after_signal) {
             pack.add(c->xbuf[1] + f * dn_b, rows(f, o1 - c->halo_top), dn_b);          // my last rows -> lower's top halo
             unpack.add(rows(f, o1), c->xbuf[2] + f * up_b, (size_t)c->bot * row_bytes);  // lower's first rows -> my bottom halo
         }
-    launch_copy_segs(pack, cm->stream);
+    launch_copy_segs(pack, to);
     // A single rank whose slab has halos on both sides is its own neighbour (periodic in axis 0): sends first, then the
     // receives in the order that pairs them with those sends (what goes up fills a bottom halo).
     const int up = (cm->rank - 1 + cm->world) % cm->world, down = (cm->rank + 1) % cm->world;
@@ -1093,12 +1096,17 @@ static int start_exchange(Ctx* c, bool after_signal) {
     if (c->bot > 0) ops[n++] = P2POp{down, c->xbuf[1], nf * dn_b, 1};
     if (c->bot > 0) ops[n++] = P2POp{down, c->xbuf[2], nf * up_b, 0};
     if (c->top > 0) ops[n++] = P2POp{up, c->xbuf[3], nf * dn_b, 0};
-    int rc = comm_exchange(cm, ops, n);
+    int rc = comm_exchange(cm, ops, n, to);
     if (rc) return rc;
-    launch_copy_segs(unpack, cm->stream);
+    launch_copy_segs(unpack, to);
     DXH_HIP(hipGetLastError());
-    DXH_HIP(hipEventRecord(c->eC, cm->stream));
-    c->pendC = true;
+    if (after_signal) {
+        // the interior chunks of the signalling launch must be done as well before anything overwrites their input
+        DXH_HIP(hipEventRecord(c->eL, from));
+        DXH_HIP(hipStreamWaitEvent(to, c->eL, 0));
+        c->alt = from;
+        c->stream = to;
+    }
     c->halo_valid = c->halo_top;
     return DXH_OK;
 }
@@ -1158,7 +1166,7 @@ static int run_slab_t(Ctx* c, int n_iter, int m, double eps, uint32_t flags, dxh
     int done = 0, converged = 0;
     double rel = std::numeric_limits<double>::quiet_NaN();
     while (done < n_iter) {
-        if (dist && c->halo_valid < m && !c->pendC) {
+        if (dist && c->halo_valid < m) {
             if ((rc = exchange_now(c))) return rc;  // halos used up by an earlier call: nothing to hide this one behind
         }
         const int left = n_iter - done;
@@ -1178,7 +1186,7 @@ static int run_slab_t(Ctx* c, int n_iter, int m, double eps, uint32_t flags, dxh
             if (c->signalling && c->signal_target > 0x40000000u) {
                 // far from wrapping, but cheap to rule out: drain and restart the counter
                 DXH_HIP(hipStreamSynchronize(c->stream));
-                DXH_HIP(hipStreamSynchronize(cm->stream));
+                DXH_HIP(hipStreamSynchronize(c->alt));
                 DXH_HIP(hipMemset(c->signal, 0, 256));
                 c->signal_target = 0;
             }
@@ -1416,8 +1424,9 @@ int dxh_tvd_destroy(dxh_tvd_t h) {
     (void)hipSetDevice(c->desc.device);
     if (c->comm && c->comm->stream) (void)hipStreamSynchronize(c->comm->stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (hipEvent_t e : {c->eM, c->eC})
-        if (e) (void)hipEventDestroy(e);
+    if (c->alt) (void)hipStreamSynchronize(c->alt);
+    if (c->alt_owned) (void)hipStreamDestroy(c->alt_owned);
+    if (c->eL) (void)hipEventDestroy(c->eL);
     if (c->signal) (void)hipFree(c->signal);
     for (char* b : c->xbuf)
         if (b) (void)hipFree(b);
@@ -1792,8 +1801,11 @@ int dxh_tvd_attach_comm(dxh_tvd_t h, dxh_comm_t comm, int64_t halo_top_rows, int
     int rc = set_device(c);
     if (rc) return rc;
     if (!c->signal) {
-        DXH_HIP(hipEventCreateWithFlags(&c->eM, hipEventDisableTiming));
-        DXH_HIP(hipEventCreateWithFlags(&c->eC, hipEventDisableTiming));
+        DXH_HIP(hipEventCreateWithFlags(&c->eL, hipEventDisableTiming));
+        int lo = 0, hi = 0;
+        DXH_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        DXH_HIP(hipStreamCreateWithPriority(&c->alt_owned, hipStreamNonBlocking, hi));  // its own hardware queue
+        c->alt = c->alt_owned;
         DXH_HIP(hipMalloc((void**)&c->signal, 256));
         DXH_HIP(hipMemset(c->signal, 0, 256));
         c->signal_target = 0;
