@@ -6,9 +6,10 @@
 // the row above (restoration/split_bregman_tvd.py:84-89) and the split update needs D+ u_new of the row below (:144).
 //
 // Two transports sit behind the same entry points:
-//   * RCCL (kind 0): grouped ncclSend / ncclRecv straight from / into the row blocks of the state planes (rows are
-//     contiguous, so nothing is packed) on a dedicated comm stream; on MI355X these go peer to peer over xGMI.  RCCL
-//     is loaded with dlopen on first use, so single-GPU users never pay for (or depend on) librccl.
+//   * RCCL (kind 0): grouped ncclSend / ncclRecv of the gathered halo rows -- one message per direction -- on the stream
+//     the caller names (dxh_tvd.hip alternates a slab context between two streams); on MI355X these go peer to peer
+//     over xGMI.  The communicator's own stream serves the small all-reduces.  RCCL is loaded with dlopen on first use,
+//     so single-GPU users never pay for (or depend on) librccl.
 //   * host callbacks (kind 1): the rows are staged through pinned host memory and handed to a caller-provided
 //     function that moves bytes between ranks (tests and rehearsals on boxes with fewer GPUs than ranks: RCCL refuses
 //     two ranks on one device).

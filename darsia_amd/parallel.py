@@ -1,7 +1,8 @@
 """Row-slab decomposition of one TV problem over several GPUs: one process per
 GPU, halo rows exchanged between slab neighbours by ``libdarsia_hip`` itself
-(grouped RCCL send/recv over xGMI on a comm stream, overlapped with the interior
-rows -- ``dxh_tvd_run_slab`` in ``include/darsia_hip.h``).  No PyTorch anywhere:
+(grouped RCCL send/recv over xGMI, started by a device-side counter and
+overlapped with the interior rows -- ``dxh_tvd_run_slab`` in
+``include/darsia_hip.h``).  No PyTorch anywhere:
 Python only bootstraps the ranks (``RANK`` / ``WORLD_SIZE`` / ``LOCAL_RANK`` from
 the launcher's environment, the 128-byte RCCL id through a file).
 

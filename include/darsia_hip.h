@@ -216,14 +216,17 @@ int dxh_comm_info(dxh_comm_t comm, int* rank, int* world, int* kind, int64_t* ex
 int dxh_tvd_attach_comm(dxh_tvd_t ctx, dxh_comm_t comm, int64_t halo_top_rows, int64_t halo_bottom_rows);
 /* refresh the halo rows from the neighbours now (enqueued behind everything the context has in flight) */
 int dxh_tvd_exchange(dxh_tvd_t ctx);
-#define DXH_FLAG_NO_OVERLAP 32u /* dxh_tvd_run_slab: whole-slab launches, exchange serialised with compute (A/B, tests) */
+#define DXH_FLAG_NO_OVERLAP 32u /* dxh_tvd_run_slab: ordinary launches, exchange in stream order behind them (A/B, tests) */
 #define DXH_FLAG_CONTINUE 64u   /* dxh_tvd_run_slab: more iterations will follow -- if the halos are used up at the end
                                    of this call, refresh them now, overlapped with the last launch */
 /*
  * dxh_tvd_run for a slab: runs n_iter outer iterations, exchanging halos whenever they are used up.  The launch before
- * an exchange runs the row chunks next to the slab interfaces first (own stream), the exchange starts when they are
- * done and proceeds while the interior chunks of that launch AND of the next one run; only the next launch's interface
- * chunks wait for it.  eps (>= 0): global stopping test of split_bregman_tvd.py:161-175 -- one all-reduce of the
+ * an exchange puts the row chunks next to the slab interfaces first; each of their waves counts itself on a device counter
+ * when its rows are in memory, and the exchange (stream wait on that counter, gather, one grouped ncclSend / ncclRecv per
+ * direction, scatter) runs on the context's second stream while the interior chunks of that launch are still computing.
+ * The launches after an exchange follow it on that second stream: a slab context alternates between its stream and one
+ * of its own, so work a caller enqueues on desc.stream is NOT ordered against it -- dxh_tvd_sync / dxh_tvd_download are the
+ * synchronisation points.  eps (>= 0): global stopping test of split_bregman_tvd.py:161-175 -- one all-reduce of the
  * owned rows' squared increment per iteration (and of ||img||^2 once); all ranks stop at the same iteration.
  * result->loop_ms is NaN with DXH_FLAG_ASYNC.
  */
