@@ -1,6 +1,8 @@
 // Dense per-pixel kernels around the TV path: piecewise perspective warp (registration), thin-plate
 // spline displacement field, affine colour balance.  gfx950 only.
+#include <atomic>
 #include <cmath>
+#include <thread>
 #include <vector>
 
 #include "dxh_common.h"
@@ -478,9 +480,33 @@ int dxh_mem_copy(int device, void* dst, const void* src, size_t bytes) {
     if (bytes == 0) return DXH_OK;
     hipStream_t st;
     DXH_HIP(cached_stream(device, &st));
-    HostPrefault pf;  // a fresh host destination: map its pages while the copy is being set up
-    pf.start(dst, bytes, {{src, bytes}});
-    pf.join();
+    const bool to_host = !is_device_ptr(dst), from_host = !is_device_ptr(src);
+    constexpr size_t kChunk = size_t(32) << 20;
+    if (to_host && !from_host && bytes >= 2 * kChunk) {
+        // Device -> a (probably fresh) host array: a copy into never-touched pages is slowed down by the page faults
+        // (384 MB: 22-36 ms instead of 7-8), touching them first costs ~15 ms.  Do both at once: a helper thread touches the
+        // pages chunk by chunk, the copy of a chunk starts when its pages are mapped.
+        std::atomic<size_t> touched{0};
+        std::thread toucher([&]() {
+            volatile char* c = static_cast<volatile char*>(dst);
+            for (size_t off = 0; off < bytes; off += kChunk) {
+                const size_t end = off + kChunk < bytes ? off + kChunk : bytes;
+                for (size_t i = off; i < end; i += 4096) c[i] = 0;
+                c[end - 1] = 0;
+                touched.store(end, std::memory_order_release);
+            }
+        });
+        hipError_t e = hipSuccess;
+        for (size_t off = 0; off < bytes && e == hipSuccess; off += kChunk) {
+            const size_t end = off + kChunk < bytes ? off + kChunk : bytes;
+            while (touched.load(std::memory_order_acquire) < end) std::this_thread::yield();
+            e = hipMemcpyAsync(static_cast<char*>(dst) + off, static_cast<const char*>(src) + off, end - off, hipMemcpyDefault, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+        }
+        toucher.join();
+        if (e != hipSuccess) { set_error("device-to-host copy failed: %s", hipGetErrorString(e)); return DXH_EHIP; }
+        return DXH_OK;
+    }
     DXH_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, st));
     DXH_HIP(hipStreamSynchronize(st));
     return DXH_OK;
