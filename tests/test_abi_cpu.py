@@ -50,6 +50,14 @@ def test_fails_loudly_without_gpu():
         da.Jacobi(mass_coeff=1.0, diffusion_coeff=1.0)(np.zeros((4, 4)), np.zeros((4, 4)))
     with pytest.raises(da.HipError):
         da.backward_diff(np.zeros((4, 4)), 0)
+    with pytest.raises(da.HipError):
+        da.DeviceArray((4, 4), np.float32)
+    with pytest.raises(da.HipError):
+        da.DeviceArray.from_host(np.zeros((4, 4), np.float32))
+    from darsia_amd.parallel import Comm
+
+    with pytest.raises(da.HipError):
+        Comm.rccl(0, 1, device=0)
 
 
 def test_tvd_kwarg_parsing_matches_reference(golden):
