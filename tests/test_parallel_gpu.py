@@ -181,8 +181,9 @@ def test_rccl_next_to_pytorchs_rocm_stack(order):
     dict(shape=(700, 420, 3), halo_iters=8, n_iter=40, flags="no_overlap"),
     dict(shape=(1500, 260), halo_iters=20, n_iter=100, flags=0, parts=[60, 40]),
     dict(shape=(300, 200, 3), halo_iters=1, n_iter=7, flags=0),
-], ids=["rgb_k8", "rgb_k8_no_overlap", "gray_k20_steps", "rgb_k1"])
-def test_rccl_self_neighbour_periodic(case):
+    dict(shape=(700, 420, 3), halo_iters=8, n_iter=40, flags=0, wait="2"),
+], ids=["rgb_k8", "rgb_k8_no_overlap", "gray_k20_steps", "rgb_k1", "rgb_k8_polling_kernel"])
+def test_rccl_self_neighbour_periodic(case, monkeypatch):
     """RCCL send/recv on ONE GPU: a single rank whose slab has halos on both sides exchanges with itself, which makes
     the problem periodic along axis 0.  Reference: the same image tiled three times with replicate ends -- after n
     iterations the ends have influenced at most n + 1 rows, so the middle copy is the periodic result exactly.  Runs the
@@ -191,6 +192,10 @@ def test_rccl_self_neighbour_periodic(case):
     from darsia_amd import _lib
     from darsia_amd.parallel import Comm, SlabTVD, make_plan, periodic_slab
 
+    if case.get("wait"):
+        # the comm stream waits for the interface-wave counter with a polling kernel instead of hipStreamWaitValue32
+        # (what a device without that stream operation gets)
+        monkeypatch.setenv("DXH_SLAB_WAIT", case["wait"])
     img = np.random.default_rng(8).random(case["shape"]).astype(np.float32)
     H, n = img.shape[0], case["n_iter"]
     assert n + 2 < H
