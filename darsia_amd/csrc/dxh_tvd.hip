@@ -193,9 +193,8 @@ static unsigned apply_layout(Ctx* c, FusedArgs<T>& a, const ChunkLayout& l, int 
     return (unsigned)(8 * ((ta + 7) / 8 + (tb + 7) / 8));
 }
 
-// Nothing to join: after an exchange the context's work continues on the stream the exchange was enqueued on, so
-// c->stream is always ordered behind everything the context has in flight (start_exchange).
-static int slab_join(Ctx*) { return DXH_OK; }
+// (Nothing has to be joined by the other entry points: after an exchange the context's work continues on the stream the
+// exchange was enqueued on, so c->stream is always ordered behind everything the context has in flight, start_exchange.)
 
 static int alloc_plane(Ctx* c, void** p) {
     if (*p) return DXH_OK;
@@ -316,7 +315,7 @@ static CoefIn<T> make_coefin(const Ctx* c) {
 
 static int set_device(Ctx* c) {
     DXH_HIP(hipSetDevice(c->desc.device));
-    return slab_join(c);  // every entry point but dxh_tvd_run_slab orders itself behind slab work in flight
+    return DXH_OK;
 }
 
 // dense host array (n0, L) <-> pitched device plane
@@ -1111,12 +1110,8 @@ static int start_exchange(Ctx* c, bool after_signal) {
     return DXH_OK;
 }
 
-// exchange behind everything in flight (no overlap)
-static int exchange_now(Ctx* c) {
-    int rc = slab_join(c);
-    if (rc) return rc;
-    return start_exchange(c, false);
-}
+// exchange in stream order behind everything in flight (no overlap)
+static int exchange_now(Ctx* c) { return start_exchange(c, false); }
 
 template <typename T>
 static void launch_any(Ctx* c, int in, int out, bool iso, bool dpp, int K) {
@@ -1143,7 +1138,6 @@ static int run_slab_t(Ctx* c, int n_iter, int m, double eps, uint32_t flags, dxh
     if (use_eps) {
         if (c->global_sq_img < 0.0) {
             double v = 0.0;
-            if ((rc = slab_join(c))) return rc;
             if (dist) {
                 DXH_REQUIRE(!std::isnan(c->omega_s) && c->omega_s != 0.0, "the global eps test needs a scalar, non-zero omega");
                 rc = sq_diff<T>(c, c->of, nullptr, slab_own0(c), slab_own1(c) - slab_own0(c), &v, 1);
@@ -1159,7 +1153,6 @@ static int run_slab_t(Ctx* c, int n_iter, int m, double eps, uint32_t flags, dxh
     }
     if (fused_ok) { c->last_iso_prev = c->last_iso; c->last_iso = iso; }
     if (!async) {
-        if ((rc = slab_join(c))) return rc;
         DXH_HIP(hipEventRecord(c->ev0, c->stream));
     }
     int64_t launches = 0;
@@ -1179,8 +1172,6 @@ static int run_slab_t(Ctx* c, int n_iter, int m, double eps, uint32_t flags, dxh
             const int in = c->cur, out = c->cur ^ 1;
             const bool xchg_after = dist && (c->halo_valid - (int64_t)K * m < m) &&
                                     (done + K < n_iter || (flags & DXH_FLAG_CONTINUE)) && !use_eps;
-            // behind the exchange in flight, whose rows this launch reads
-            if ((rc = slab_join(c))) return rc;
             // the launch in front of an exchange runs its interface chunks first and counts them (make_layout)
             c->signalling = overlap && xchg_after;
             if (c->signalling && c->signal_target > 0x40000000u) {
@@ -1206,7 +1197,6 @@ static int run_slab_t(Ctx* c, int n_iter, int m, double eps, uint32_t flags, dxh
             }
         } else {
             // three-kernel / solver / multi-sweep paths: whole-slab launches, exchange in between
-            if ((rc = slab_join(c))) return rc;
             K = use_eps ? 1 : cap;
             dxh_tvd_result r{};
             rc = run_t<T>(c, K, m, -1.0, -1.0, 0.0, (flags & (DXH_FLAG_ISOTROPIC | DXH_FLAG_NO_FUSED | DXH_FLAG_NO_DPP | DXH_FLAG_EXPLICIT)) | DXH_FLAG_ASYNC, &r);
@@ -1217,7 +1207,6 @@ static int run_slab_t(Ctx* c, int n_iter, int m, double eps, uint32_t flags, dxh
         done += K;
         if (use_eps) {
             double inc = 0.0;
-            if ((rc = slab_join(c))) return rc;
             rc = sq_diff<T>(c, c->u[c->cur], c->u[c->cur ^ 1], slab_own0(c), slab_own1(c) - slab_own0(c), &inc, 0);
             if (rc) return rc;
             if (dist && (rc = comm_allreduce(cm, &inc, 1, 0))) return rc;
@@ -1226,9 +1215,6 @@ static int run_slab_t(Ctx* c, int n_iter, int m, double eps, uint32_t flags, dxh
         }
     }
     float ms = std::numeric_limits<float>::quiet_NaN();
-    if (!(flags & DXH_FLAG_CONTINUE) || !async) {
-        if ((rc = slab_join(c))) return rc;
-    }
     if (!async) {
         DXH_HIP(hipEventRecord(c->ev1, c->stream));
         DXH_HIP(hipStreamSynchronize(c->stream));
