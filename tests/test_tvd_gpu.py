@@ -720,3 +720,27 @@ def test_division_check_detects_wrong_quotients_and_both_paths_agree(monkeypatch
     assert_bits(da.split_bregman_tvd(img, mu=0.1, max_num_iter=9), want)
     monkeypatch.setenv("DXH_FUSED_TUNE", "128")
     assert_bits(da.split_bregman_tvd(img, mu=0.1, max_num_iter=9), want)
+
+
+def test_planes_larger_than_four_gigabytes():
+    """Maximum sizes: a 36000 x 32000 float32 image has 4.6 GB planes, i.e. byte offsets beyond 2^32 and element offsets
+    beyond 2^30 inside every kernel of the sweep.  Four iterations (one K = 4 launch) and the generic three-kernel path,
+    pinned to the oracle on windows at the far corner, the near corner and across the 4 GB line (dependence radius n + 1)."""
+    H, W, n = 36000, 32000, 4
+    rng = np.random.default_rng(77)
+    img = rng.random((H, W), dtype=np.float32)
+    m = n + 2
+    r4g = (1 << 32) // (4 * W)  # the row in which the 2^32-th byte of a plane lies
+    windows = [(0, 0), (H - 256, W - 256), (r4g - 128, W // 2)]
+    refs = []
+    for (r0, c0) in windows:
+        crop = np.ascontiguousarray(img[r0:r0 + 256, c0:c0 + 256])
+        refs.append(O.split_bregman_tvd(crop, mu=0.1, max_num_iter=n, promotion="strict"))
+    for flags in (0, _lib.FLAG_NO_FUSED):
+        out, res = run_device(img, mu=0.1, n_iter=n, flags=flags)
+        assert res.launches == (1 if flags == 0 else 3 * n)
+        for (r0, c0), ref in zip(windows, refs):
+            ra, rb = (0 if r0 == 0 else m), (256 if r0 + 256 == H else 256 - m)
+            ca, cb = (0 if c0 == 0 else m), (256 if c0 + 256 == W else 256 - m)
+            assert_bits(out[r0 + ra:r0 + rb, c0 + ca:c0 + cb], ref[ra:rb, ca:cb])
+        del out
