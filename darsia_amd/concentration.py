@@ -200,8 +200,9 @@ class ConcentrationAnalysis:
         self._diff_option = kwargs.get("diff option", "absolute")
         self.first_restoration_then_model = kwargs.get("restoration -> model", False)
         self.verbosity = kwargs.get("verbosity", 0)
-        self._ctx = None
-        self._ctx_key = None
+        self._ctxs = [None, None]      # device contexts: [0] on this thread's stream, [1] on the uploader thread's (map)
+        self._ctx_keys = [None, None]
+        self._uploader = None
         self.find_cleaning_filter()
         self.mask = None if self.base is None else np.ones(self.base.img.shape[:2], dtype=bool)
 
@@ -243,12 +244,12 @@ class ConcentrationAnalysis:
             for img in baseline_images:
                 mono = self._reduce_signal(self._subtract_background(img.copy()))
                 self.threshold_cleaning_filter = np.maximum(self.threshold_cleaning_filter, mono)
-        self._ctx_key = None  # device copies are stale
+        self._ctx_keys = [None, None]  # device copies are stale
 
     def update(self, base=None, mask=None) -> None:
         if base is not None:
             self.base = base.copy()
-            self._ctx_key = None
+            self._ctx_keys = [None, None]
         if mask is not None:
             self.mask = mask
 
@@ -294,8 +295,7 @@ class ConcentrationAnalysis:
             return None
         return reduction, channels, ops, solver, iso
 
-    def _device_call(self, probe: np.ndarray, plan) -> np.ndarray:
-        reduction, channels, ops, solver, iso = plan
+    def _signal_dtype(self, probe: np.ndarray, reduction: int):
         # dtype as NumPy would promote (concentrationanalysis.py:328-395): probe - baseline promotes to the wider of the
         # two, a (float64) cleaning filter promotes the signal; gray is float32 in cv2
         dt = probe.dtype if self.base is None else np.result_type(probe.dtype, self.base.img.dtype)
@@ -303,35 +303,138 @@ class ConcentrationAnalysis:
             dt = np.result_type(dt, np.float64)
         elif reduction == 5:
             dt = np.dtype(np.float32)
-        h, w = probe.shape[:2]
-        key = (h, w, np.dtype(dt).str)
-        if self._ctx is None or self._ctx_key != key:
-            if self._ctx is not None:
-                self._ctx.close()
-            self._ctx = DeviceTVD((h, w), dt, dim=2)
-            lib, hd = self._ctx.lib, self._ctx._h
+        return np.dtype(dt)
+
+    def _ctx_for(self, slot: int, key, channels: int) -> DeviceTVD:
+        """Scalar TV context of slot 0 / 1 with the baseline and the cleaning filter resident.  A context takes the
+        stream of the thread that creates it: slot 0 belongs to the caller's thread, slot 1 to the uploader's (map)."""
+        if self._ctxs[slot] is None or self._ctx_keys[slot] != key:
+            if self._ctxs[slot] is not None:
+                self._ctxs[slot].close()
+                self._ctxs[slot] = None
+            h, w, dts = key
+            dt = np.dtype(dts)
+            st = DeviceTVD((h, w), dt, dim=2)
             base = None if self.base is None else np.ascontiguousarray(self.base.img, dtype=dt)
-            _lib.check(lib.dxh_tvd_set_base(hd, _lib.ptr(base), channels))
+            _lib.check(st.lib.dxh_tvd_set_base(st._h, _lib.ptr(base), channels))
             filt = None if self.threshold_cleaning_filter is None else np.ascontiguousarray(self.threshold_cleaning_filter, dtype=dt)
-            _lib.check(lib.dxh_tvd_set_cleaning_filter(hd, _lib.ptr(filt)))
-            self._ctx_key = key
-        st = self._ctx
+            _lib.check(st.lib.dxh_tvd_set_cleaning_filter(st._h, _lib.ptr(filt)))
+            self._ctxs[slot], self._ctx_keys[slot] = st, key
+        return self._ctxs[slot]
+
+    def close(self) -> None:
+        """Release the device contexts and the uploader thread (both come back on demand)."""
+        if getattr(self, "_uploader", None) is not None:
+            self._uploader.shutdown(wait=True)
+            self._uploader = None
+        for i, st in enumerate(getattr(self, "_ctxs", [])):
+            if st is not None:
+                st.close()
+                self._ctxs[i] = None
+
+    def _upload_frame(self, st: DeviceTVD, probe: np.ndarray, plan) -> None:
+        reduction, channels, ops, solver, iso = plan
         rest = self.restoration
-        like = np.empty((h, w), dt)
+        like = np.empty(st.shape, st.dtype)
         if rest is not None:
             st.set_coeffs(rest.weight, rest.omega, rest.regularization, like)
         else:
             st.set_coeffs(1.0, 1.0, None, like)
-        pre, post = (ops, []) if not self.first_restoration_then_model else ([], ops)
-        src = np.ascontiguousarray(probe, dtype=dt)
+        pre = ops if not self.first_restoration_then_model else []
+        src = np.ascontiguousarray(probe, dtype=st.dtype)
         _lib.check(st.lib.dxh_tvd_upload_signal(st._h, _lib.ptr(src), channels, _DIFF[self._diff_option], reduction,
                                                  C.cast(_ops_array(pre), C.c_void_p), len(pre)))
+
+    def _finish_frame(self, st: DeviceTVD, plan) -> np.ndarray:
+        reduction, channels, ops, solver, iso = plan
+        rest = self.restoration
         if rest is not None:
             maxiter, tol = (1, None) if solver is None else (solver.maxiter, solver.tol)
-            st.run(rest.max_num_iter, maxiter, tol, eps=rest.eps, isotropic=iso)
-        out = np.empty((h, w), dt)
+            # nothing to read back without stopping criteria: enqueue only, the download below maps the pages of the
+            # result array meanwhile
+            flags = _lib.FLAG_ASYNC if rest.eps is None and tol is None else 0
+            st.run(rest.max_num_iter, maxiter, tol, eps=rest.eps, isotropic=iso, flags=flags)
+        post = ops if self.first_restoration_then_model else []
+        out = np.empty(st.shape, st.dtype)
         _lib.check(st.lib.dxh_tvd_download_model(st._h, _lib.ptr(out), C.cast(_ops_array(post), C.c_void_p), len(post)))
         return out
+
+    def _device_call(self, probe: np.ndarray, plan) -> np.ndarray:
+        dt = self._signal_dtype(probe, plan[0])
+        st = self._ctx_for(0, (probe.shape[0], probe.shape[1], dt.str), plan[1])
+        self._upload_frame(st, probe, plan)
+        return self._finish_frame(st, plan)
+
+    def _wrap(self, img, concentration: np.ndarray):
+        probe = img.img
+        metadata = img.metadata() if hasattr(img, "metadata") else {}
+        if concentration.ndim == probe.ndim - 1 or concentration.ndim == 2:
+            return ScalarImage(concentration, **{k: v for k, v in metadata.items() if k != "scalar"})
+        if concentration.shape[-1] == 1:
+            return ScalarImage(concentration[..., 0], **{k: v for k, v in metadata.items() if k != "scalar"})
+        return type(img)(concentration, **metadata)
+
+    def map(self, images):
+        """Concentrations of a SERIES of frames (the reference analyses time series frame by frame,
+        concentrationanalysis.py:230-310), yielded in order.  Same results as calling the object on every frame; the
+        frames alternate between two device contexts on two streams, so that the upload of frame i + 1 (8 ms of PCIe
+        for a 4000 x 8000 colour frame) runs while frame i is reduced, denoised and downloaded.  Frames the fused device
+        path cannot take are processed one after the other."""
+        from concurrent.futures import ThreadPoolExecutor
+
+        it = iter(images)
+        try:
+            cur = next(it)
+        except StopIteration:
+            return
+
+        def fusable(img):
+            return self._fusable(img.img) if img.img.dtype in (np.float32, np.float64) else None
+
+        plan = fusable(cur)
+        if plan is None:
+            yield self(cur)
+            for img in it:
+                yield self(img)
+            return
+        dt = self._signal_dtype(cur.img, plan[0])
+        shape, channels = cur.img.shape, plan[1]
+        key = (shape[0], shape[1], dt.str)
+        if self._uploader is None:
+            self._uploader = ThreadPoolExecutor(max_workers=1, thread_name_prefix="dxh-upload")
+        pool = self._uploader
+        self._ctx_for(0, key, channels)   # on this thread; slot 1's is created by the uploader at its first frame
+
+        def upload(slot: int, img):
+            self._upload_frame(self._ctx_for(slot, key, channels), img.img, plan)
+
+        fut = pool.submit(upload, 0, cur)
+        try:
+            k = 0
+            while cur is not None:
+                fut.result()                                      # frame k is on the device (slot k % 2)
+                fut = None
+                nxt = next(it, None)
+                same = nxt is not None and nxt.img.shape == shape and fusable(nxt) == plan and \
+                    self._signal_dtype(nxt.img, plan[0]) == dt
+                if same:
+                    fut = pool.submit(upload, (k + 1) % 2, nxt)   # overlaps the work on frame k below
+                out = self._finish_frame(self._ctxs[k % 2], plan)
+                yield self._wrap(cur, out)
+                if nxt is not None and not same:
+                    # a frame of another kind ends the pipelined stretch
+                    yield self(nxt)
+                    for img in it:
+                        yield self(img)
+                    return
+                cur = nxt
+                k += 1
+        finally:
+            if fut is not None:   # generator abandoned or failed: join the upload in flight
+                try:
+                    fut.result()
+                except Exception:
+                    pass
 
     def __call__(self, img):
         """Extract the concentration from a probing image (concentrationanalysis.py:230-310)."""
@@ -349,9 +452,4 @@ class ConcentrationAnalysis:
                 concentration = self._convert_signal(self._restore_signal(signal), diff)
             else:
                 concentration = self._restore_signal(self._convert_signal(signal, diff))
-        metadata = img.metadata() if hasattr(img, "metadata") else {}
-        if concentration.ndim == probe.ndim - 1 or concentration.ndim == 2:
-            return ScalarImage(concentration, **{k: v for k, v in metadata.items() if k != "scalar"})
-        if concentration.shape[-1] == 1:
-            return ScalarImage(concentration[..., 0], **{k: v for k, v in metadata.items() if k != "scalar"})
-        return type(img)(concentration, **metadata)
+        return self._wrap(img, concentration)

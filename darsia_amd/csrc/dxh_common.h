@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdint>
@@ -70,7 +71,8 @@ inline bool is_device_ptr(const void* p) {
 // buffer is going to be overwritten completely, so writing one zero per page beforehand is harmless.  join() before
 // the copy is enqueued.
 struct HostPrefault {
-    std::thread th;
+    static constexpr int kMaxThreads = 4;  // page faults of one process scale over a few threads, then the mm lock binds
+    std::thread th[kMaxThreads];
     // `inputs`: host buffers the call still has to read -- an output that overlaps one of them (in-place use of the
     // C ABI) must not be touched
     void start(void* p, size_t n, std::initializer_list<std::pair<const void*, size_t>> inputs = {}) {
@@ -80,14 +82,21 @@ struct HostPrefault {
             const char* a = static_cast<const char*>(in.first);
             if (a && a < lo + n && lo < a + in.second) return;
         }
-        th = std::thread([p, n]() {
-            volatile char* c = static_cast<volatile char*>(p);
-            for (size_t i = 0; i < n; i += 4096) c[i] = 0;
-            c[n - 1] = 0;
-        });
+        join();
+        const size_t pages = (n + 4095) / 4096;
+        const int nt = (int)std::min<size_t>(kMaxThreads, std::max<size_t>(1, n >> 25));  // one thread per 32 MB
+        for (int t = 0; t < nt; ++t) {
+            const size_t b = pages * t / nt * 4096, e = std::min(n, pages * (t + 1) / nt * 4096);
+            th[t] = std::thread([p, b, e]() {
+                volatile char* c = static_cast<volatile char*>(p);
+                for (size_t i = b; i < e; i += 4096) c[i] = 0;
+                if (e > b) c[e - 1] = 0;
+            });
+        }
     }
     void join() {
-        if (th.joinable()) th.join();
+        for (auto& t : th)
+            if (t.joinable()) t.join();
     }
     ~HostPrefault() { join(); }
 };

@@ -1,6 +1,7 @@
 // Dense per-pixel kernels around the TV path: piecewise perspective warp (registration), thin-plate
 // spline displacement field, affine colour balance.  gfx950 only.
 #include <atomic>
+#include <memory>
 #include <cmath>
 #include <thread>
 #include <vector>
@@ -486,24 +487,32 @@ int dxh_mem_copy(int device, void* dst, const void* src, size_t bytes) {
         // Device -> a (probably fresh) host array: a copy into never-touched pages is slowed down by the page faults
         // (384 MB: 22-36 ms instead of 7-8), touching them first costs ~15 ms.  Do both at once: a helper thread touches the
         // pages chunk by chunk, the copy of a chunk starts when its pages are mapped.
-        std::atomic<size_t> touched{0};
-        std::thread toucher([&]() {
-            volatile char* c = static_cast<volatile char*>(dst);
-            for (size_t off = 0; off < bytes; off += kChunk) {
-                const size_t end = off + kChunk < bytes ? off + kChunk : bytes;
-                for (size_t i = off; i < end; i += 4096) c[i] = 0;
-                c[end - 1] = 0;
-                touched.store(end, std::memory_order_release);
-            }
-        });
+        // kTouchers threads share every chunk (page faults of one process scale over a few threads).
+        constexpr int kTouchers = HostPrefault::kMaxThreads;
+        const size_t nchunks = (bytes + kChunk - 1) / kChunk;
+        std::unique_ptr<std::atomic<int>[]> mapped(new std::atomic<int>[nchunks]);
+        for (size_t k = 0; k < nchunks; ++k) mapped[k].store(0, std::memory_order_relaxed);
+        std::thread touchers[kTouchers];
+        for (int t = 0; t < kTouchers; ++t)
+            touchers[t] = std::thread([&, t]() {
+                volatile char* c = static_cast<volatile char*>(dst);
+                for (size_t k = 0; k < nchunks; ++k) {
+                    const size_t off = k * kChunk, len = std::min(kChunk, bytes - off), pages = (len + 4095) / 4096;
+                    const size_t b = off + pages * t / kTouchers * 4096, e = std::min(off + len, off + pages * (t + 1) / kTouchers * 4096);
+                    for (size_t i = b; i < e; i += 4096) c[i] = 0;
+                    if (e > b) c[e - 1] = 0;
+                    mapped[k].fetch_add(1, std::memory_order_release);
+                }
+            });
         hipError_t e = hipSuccess;
-        for (size_t off = 0; off < bytes && e == hipSuccess; off += kChunk) {
-            const size_t end = off + kChunk < bytes ? off + kChunk : bytes;
-            while (touched.load(std::memory_order_acquire) < end) std::this_thread::yield();
+        for (size_t k = 0; k < nchunks && e == hipSuccess; ++k) {
+            const size_t off = k * kChunk, end = std::min(off + kChunk, bytes);
+            while (mapped[k].load(std::memory_order_acquire) < kTouchers) std::this_thread::yield();
             e = hipMemcpyAsync(static_cast<char*>(dst) + off, static_cast<const char*>(src) + off, end - off, hipMemcpyDefault, st);
-            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e == hipSuccess && k + 1 == nchunks) e = hipStreamSynchronize(st);
         }
-        toucher.join();
+        if (e != hipSuccess) (void)hipStreamSynchronize(st);
+        for (auto& t : touchers) t.join();
         if (e != hipSuccess) { set_error("device-to-host copy failed: %s", hipGetErrorString(e)); return DXH_EHIP; }
         return DXH_OK;
     }

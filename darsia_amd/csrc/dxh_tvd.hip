@@ -1633,6 +1633,8 @@ int dxh_tvd_download_model(dxh_tvd_t h, void* out, const dxh_model_op* post_ops,
     if (rc) return rc;
     if ((rc = set_device(c))) return rc;
     const size_t dense = (size_t)c->g.n0 * c->g.L * c->esz;
+    HostPrefault pf;  // map the output pages while the device works (the iterations may still be running: DXH_FLAG_ASYNC)
+    pf.start(out, dense);
     if (!c->stage || dense > (size_t)c->g.n0 * c->g.L * c->desc.dim * c->esz) {
         if (c->stage) { DXH_HIP(hipFree(c->stage)); c->stage = nullptr; }
         DXH_HIP(hipMalloc(&c->stage, (size_t)c->g.n0 * c->g.L * c->desc.dim * c->esz));
@@ -1642,6 +1644,7 @@ int dxh_tvd_download_model(dxh_tvd_t h, void* out, const dxh_model_op* post_ops,
     else
         hipLaunchKernelGGL((k_model<double>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const double*)c->u[c->cur], post, (double*)c->stage);
     DXH_HIP(hipGetLastError());
+    pf.join();
     DXH_HIP(hipMemcpyAsync(out, c->stage, dense, hipMemcpyDefault, c->stream));
     DXH_HIP(hipStreamSynchronize(c->stream));
     return DXH_OK;

@@ -72,3 +72,38 @@ def test_scalar_frames_and_generic_fallback_chain():
     sig = sig[:, :, 0] - sig[:, :, 2]
     from oracle import tvd_numpy as O
     assert np.array_equal(out2.img, O.split_bregman_tvd(sig, mu=0.1, ell=1.0, max_num_iter=5, promotion="strict"))
+
+
+@pytest.mark.parametrize("n_frames", [0, 1, 2, 5])
+def test_series_map_equals_frame_by_frame(n_frames):
+    """ConcentrationAnalysis.map pipelines the frames over two contexts / two streams; the results are those of
+    calling the object frame by frame (context re-use after two frames included)."""
+    base, _ = _frames(96, 128, 10)
+    frames = [_frames(96, 128, 20 + i)[1] for i in range(n_frames)]
+    tvd = da.TVD(method="heterogeneous bregman", weight=0.07, omega=1.0, regularization=0.2, max_num_iter=9, eps=None)
+    model = da.CombinedModel([da.LinearModel(scaling=2.0, offset=0.01), da.ClipModel(min_value=0.0, max_value=1.0)])
+    ca = da.ConcentrationAnalysis(base, da.MonochromaticReduction(color="gray"), None, tvd, model, **{"diff option": "absolute"})
+    want = [ca(f).img for f in frames]
+    got = list(ca.map(iter(frames)))
+    assert len(got) == n_frames
+    for g, w_ in zip(got, want):
+        assert isinstance(g, da.ScalarImage) and g.img.dtype == w_.dtype and np.array_equal(g.img, w_)
+
+
+def test_series_map_mixed_frames_and_early_exit():
+    base, _ = _frames(48, 64, 30)
+    a, b = _frames(48, 64, 31)[1], _frames(48, 64, 32)[1]
+    odd = da.OpticalImage(_frames(48, 64, 33, np.float64)[1].img)   # another dtype: leaves the pipelined stretch
+    ca = da.ConcentrationAnalysis(base, da.MonochromaticReduction(color="red"), None,
+                                  da.TVD(method="heterogeneous bregman", weight=0.1, max_num_iter=4, eps=None), None)
+    want = [ca(f).img for f in (a, b, odd, a)]
+    got = [g.img for g in ca.map([a, b, odd, a])]
+    assert all(np.array_equal(g, w_) and g.dtype == w_.dtype for g, w_ in zip(got, want))
+    # abandoning the generator releases the contexts (the in-flight upload is joined first)
+    gen = ca.map([a, b, a, b])
+    first = next(gen)
+    gen.close()
+    assert np.array_equal(first.img, want[0])
+    # frames the device path cannot fuse go one by one
+    ca2 = da.ConcentrationAnalysis(base, da.MonochromaticReduction(color=lambda im: im[:, :, 1]), None, None, None)
+    assert all(np.array_equal(g.img, ca2(f).img) for g, f in zip(ca2.map([a, b]), (a, b)))
