@@ -34,7 +34,7 @@ EXPORTS = (
     "dxh_tvd_energy", "dxh_tvd_adapt_ell", "dxh_tvd_set_base", "dxh_tvd_set_cleaning_filter", "dxh_tvd_upload_signal", "dxh_tvd_download_model",
     "dxh_comm_unique_id", "dxh_comm_create_rccl", "dxh_comm_create_host", "dxh_comm_destroy", "dxh_comm_allreduce",
     "dxh_comm_barrier", "dxh_comm_info", "dxh_tvd_attach_comm", "dxh_tvd_exchange", "dxh_tvd_run_slab",
-    "dxh_mem_alloc", "dxh_mem_free", "dxh_mem_copy", "dxh_sqrt_probe", "dxh_rcp_probe",
+    "dxh_mem_alloc", "dxh_mem_free", "dxh_mem_copy", "dxh_sqrt_probe", "dxh_rcp_probe", "dxh_tvd_solve_banded", "dxh_mem_trim",
 )
 
 # host-staged transport callbacks (include/darsia_hip.h: dxh_comm_exchange_fn, dxh_comm_allreduce_fn)
@@ -143,10 +143,13 @@ def _declare(lib):
     lib.dxh_tvd_set_cleaning_filter.argtypes = [vp, vp]
     lib.dxh_tvd_upload_signal.argtypes = [vp, vp, i, i, i, vp, i]
     lib.dxh_tvd_download_model.argtypes = [vp, vp, vp, i]
+    lib.dxh_tvd_solve_banded.argtypes = [C.POINTER(TvdDesc), vp, vp, dbl, vp, dbl, vp, i, dbl, vp, i, i, C.c_uint32, i,
+                                         C.POINTER(i)]
     lib.dxh_sqrt_probe.argtypes = [i, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     lib.dxh_rcp_probe.argtypes = [i, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     lib.dxh_mem_alloc.argtypes = [i, C.c_size_t, C.POINTER(vp)]
     lib.dxh_mem_free.argtypes = [i, vp]
+    lib.dxh_mem_trim.argtypes = [C.POINTER(C.c_size_t)]
     lib.dxh_mem_copy.argtypes = [i, vp, vp, C.c_size_t]
     lib.dxh_comm_unique_id.argtypes = [vp]
     lib.dxh_comm_create_rccl.argtypes = [C.POINTER(vp), i, vp, i, i]

@@ -11,6 +11,9 @@
 #include <cstdio>
 #include <cstring>
 #include <initializer_list>
+#include <cstdlib>
+#include <vector>
+#include <mutex>
 #include <thread>
 #include <type_traits>
 #include <utility>
@@ -51,6 +54,104 @@ inline hipError_t cached_stream(int device, hipStream_t* out) {
     }
     *out = streams[device];
     return hipSuccess;
+}
+
+// Plane cache: hipFree of a few hundred MB costs 0.1 - 0.3 ms and waits for the device, a whole call releases 10 - 30
+// planes.  Freed planes are kept (exact-size reuse, newest first) up to a budget of 1/16 of the device memory
+// (DXH_POOL_MB overrides; 0 turns the cache off); pool_trim() returns everything to the runtime.  Blocks come back with
+// their old contents: callers clear what they need cleared.
+struct PlanePool {
+    struct Blk { void* p; size_t n; int dev; };
+    std::mutex m;
+    std::vector<Blk> idle;
+    std::vector<Blk> live;   // blocks handed out (a few dozen at most: linear search)
+    size_t cached = 0;
+    long long budget = -1;   // bytes; -1: not yet determined
+};
+inline PlanePool& plane_pool() {
+    static PlanePool* p = new PlanePool();   // never destroyed: contexts may be released during process teardown
+    return *p;
+}
+inline hipError_t pool_malloc(void** out, size_t n) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    PlanePool& pl = plane_pool();
+    {
+        std::lock_guard<std::mutex> lock(pl.m);
+        for (size_t i = pl.idle.size(); i-- > 0;)
+            if (pl.idle[i].n == n && pl.idle[i].dev == dev) {
+                *out = pl.idle[i].p;
+                pl.live.push_back(pl.idle[i]);
+                pl.cached -= n;
+                pl.idle.erase(pl.idle.begin() + i);
+                return hipSuccess;
+            }
+    }
+    e = hipMalloc(out, n);
+    if (e == hipErrorOutOfMemory) {
+        // give the cache back and try once more
+        std::vector<PlanePool::Blk> drop;
+        {
+            std::lock_guard<std::mutex> lock(pl.m);
+            drop.swap(pl.idle);
+            pl.cached = 0;
+        }
+        for (auto& b : drop) (void)hipFree(b.p);
+        (void)hipGetLastError();
+        e = hipMalloc(out, n);
+    }
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(pl.m);
+    pl.live.push_back({*out, n, dev});
+    return hipSuccess;
+}
+// the caller guarantees that no work still uses the block
+inline void pool_free(void* p) {
+    if (!p) return;
+    PlanePool& pl = plane_pool();
+    std::vector<PlanePool::Blk> drop;
+    bool known = false;
+    {
+        std::lock_guard<std::mutex> lock(pl.m);
+        if (pl.budget < 0) {
+            size_t fr = 0, tot = 0;
+            pl.budget = hipMemGetInfo(&fr, &tot) == hipSuccess ? (long long)(tot / 16) : 0;
+            if (const char* e = getenv("DXH_POOL_MB")) pl.budget = atoll(e) * (1ll << 20);
+        }
+        for (size_t i = 0; i < pl.live.size(); ++i)
+            if (pl.live[i].p == p) {
+                PlanePool::Blk b = pl.live[i];
+                pl.live.erase(pl.live.begin() + i);
+                known = true;
+                if ((long long)b.n > pl.budget) { drop.push_back(b); break; }
+                pl.idle.push_back(b);
+                pl.cached += b.n;
+                while ((long long)pl.cached > pl.budget) {   // oldest out
+                    drop.push_back(pl.idle.front());
+                    pl.cached -= pl.idle.front().n;
+                    pl.idle.erase(pl.idle.begin());
+                }
+                break;
+            }
+    }
+    if (!known) { (void)hipFree(p); return; }
+    for (auto& b : drop) (void)hipFree(b.p);
+}
+inline size_t pool_trim() {
+    PlanePool& pl = plane_pool();
+    std::vector<PlanePool::Blk> drop;
+    {
+        std::lock_guard<std::mutex> lock(pl.m);
+        drop.swap(pl.idle);
+        pl.cached = 0;
+    }
+    size_t n = 0;
+    for (auto& b : drop) {
+        (void)hipFree(b.p);
+        n += b.n;
+    }
+    return n;
 }
 
 // Image arrays handed to the C ABI may live on the host or on the device (dxh_mem_alloc): every copy of caller data

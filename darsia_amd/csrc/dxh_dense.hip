@@ -474,6 +474,12 @@ int dxh_mem_free(int device, void* ptr) {
     return DXH_OK;
 }
 
+int dxh_mem_trim(size_t* bytes) {
+    const size_t n = pool_trim();
+    if (bytes) *bytes = n;
+    return DXH_OK;
+}
+
 int dxh_mem_copy(int device, void* dst, const void* src, size_t bytes) {
     DXH_REQUIRE((dst && src) || bytes == 0, "null argument");
     int rc = check_device(device);

@@ -1,6 +1,9 @@
 // libdarsia_hip.so -- host side of the C ABI declared in include/darsia_hip.h.
 // Written for gfx950 (MI355X) only.
 #include <algorithm>
+#include <chrono>
+#include <array>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -11,6 +14,7 @@
 #include <utility>
 #include <new>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -90,6 +94,7 @@ struct Ctx {
 
     int cur = 0;                   // index of the current u / q buffers
     bool have_coefs = false, het = false, uploaded = false, from_db = false;
+    bool pristine = true;   // no upload yet: q planes and u[1] still hold the zeros of their allocation
     bool last_iso = false, last_iso_prev = false;
     double mu_s = 0, omega_s = 1, ell_s = 0;  // scalar views (valid when !het)
     double c_ell = 0, c_diag = 0, c_dsc = 0, c_kq = 0;
@@ -198,7 +203,7 @@ static unsigned apply_layout(Ctx* c, FusedArgs<T>& a, const ChunkLayout& l, int 
 
 static int alloc_plane(Ctx* c, void** p) {
     if (*p) return DXH_OK;
-    DXH_HIP(hipMalloc(p, c->plane_bytes));
+    DXH_HIP(pool_malloc(p, c->plane_bytes));
     DXH_HIP(hipMemsetAsync(*p, 0, c->plane_bytes, c->stream));
     return DXH_OK;
 }
@@ -1259,7 +1264,7 @@ static int set_coeffs_t(Ctx* c, double mu, const void* mu_arr, double omega, con
             if (ok(fd) && ok(fs) && !(c->tune & 128)) c->c_div3 = div3_verified(c, fd, fs);
         }
         for (void** p : {&c->cp_ell, &c->cp_diag, &c->cp_dsc, &c->cp_kq}) {
-            if (*p) { DXH_HIP(hipFree(*p)); *p = nullptr; }
+            if (*p) { DXH_HIP(hipStreamSynchronize(c->stream)); pool_free(*p); *p = nullptr; }
         }
         return DXH_OK;
     }
@@ -1418,7 +1423,7 @@ int dxh_tvd_destroy(dxh_tvd_t h) {
         if (b) (void)hipFree(b);
     comm_release(c->comm);
     delete c->solver;
-    auto fr = [](void* p) { if (p) (void)hipFree(p); };
+    auto fr = [](void* p) { pool_free(p); };   // planes go back to the cache, anything else to the runtime
     fr(c->of); fr(c->u[0]); fr(c->u[1]); fr(c->rs);
     for (int j = 0; j < 3; ++j) { fr(c->q[j][0]); fr(c->q[j][1]); fr(c->dpl[j]); fr(c->bpl[j]); }
     fr(c->in_mu); fr(c->in_om); fr(c->in_ell);
@@ -1467,7 +1472,8 @@ int dxh_tvd_set_coeffs(dxh_tvd_t h, double mu, const void* mu_arr, double omega,
         if ((rc = h2d_plane(c, c->om_plane, omega_arr))) return rc;
         DXH_HIP(hipStreamSynchronize(c->stream));
     } else if (c->om_plane) {
-        DXH_HIP(hipFree(c->om_plane));
+        DXH_HIP(hipStreamSynchronize(c->stream));
+        pool_free(c->om_plane);
         c->om_plane = nullptr;
     }
     if (mu_arr) {
@@ -1475,7 +1481,8 @@ int dxh_tvd_set_coeffs(dxh_tvd_t h, double mu, const void* mu_arr, double omega,
         if ((rc = h2d_plane(c, c->mu_plane, mu_arr))) return rc;
         DXH_HIP(hipStreamSynchronize(c->stream));
     } else if (c->mu_plane) {
-        DXH_HIP(hipFree(c->mu_plane));
+        DXH_HIP(hipStreamSynchronize(c->stream));
+        pool_free(c->mu_plane);
         c->mu_plane = nullptr;
     }
     c->explicit_db = false;
@@ -1486,14 +1493,19 @@ int dxh_tvd_set_coeffs(dxh_tvd_t h, double mu, const void* mu_arr, double omega,
 }
 
 // common tail of the two upload paths: the image is in u[0]; builds ||img||^2, of = omega*img, zeroes the state
-static int finish_upload(Ctx* c, const void* u0, const void* d0, const void* b0) {
+// lean: enqueue only -- no ||img||^2 (the caller runs without a stopping criterion) and no stream synchronisation
+static int finish_upload(Ctx* c, const void* u0, const void* d0, const void* b0, bool lean = false) {
     int rc;
     const bool f32 = c->desc.dtype == DXH_F32;
     const int dim = c->desc.dim;
     c->cur = 0;
-    rc = f32 ? sq_diff<float>(c, c->u[0], nullptr, 0, c->g.n0, &c->sq_img, 1)
-             : sq_diff<double>(c, c->u[0], nullptr, 0, c->g.n0, &c->sq_img, 1);
-    if (rc) return rc;
+    if (lean) {
+        c->sq_img = std::numeric_limits<double>::quiet_NaN();
+    } else {
+        rc = f32 ? sq_diff<float>(c, c->u[0], nullptr, 0, c->g.n0, &c->sq_img, 1)
+                 : sq_diff<double>(c, c->u[0], nullptr, 0, c->g.n0, &c->sq_img, 1);
+        if (rc) return rc;
+    }
     const bool om_arr = std::isnan(c->omega_s);
     if (f32)
         hipLaunchKernelGGL((k_scale<float>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const float*)c->u[0],
@@ -1503,11 +1515,14 @@ static int finish_upload(Ctx* c, const void* u0, const void* d0, const void* b0)
                            c->omega_s, om_arr ? (const double*)c->om_plane : nullptr, (double*)c->of);
     DXH_HIP(hipGetLastError());
     if (u0 && (rc = h2d_plane(c, c->u[0], u0))) return rc;
-    for (int j = 0; j < dim; ++j) {
-        DXH_HIP(hipMemsetAsync(c->q[j][0], 0, c->plane_bytes, c->stream));
-        DXH_HIP(hipMemsetAsync(c->q[j][1], 0, c->plane_bytes, c->stream));
+    if (!c->pristine) {   // a fresh context's planes were cleared when they were allocated
+        for (int j = 0; j < dim; ++j) {
+            DXH_HIP(hipMemsetAsync(c->q[j][0], 0, c->plane_bytes, c->stream));
+            DXH_HIP(hipMemsetAsync(c->q[j][1], 0, c->plane_bytes, c->stream));
+        }
+        DXH_HIP(hipMemsetAsync(c->u[1], 0, c->plane_bytes, c->stream));
     }
-    DXH_HIP(hipMemsetAsync(c->u[1], 0, c->plane_bytes, c->stream));
+    c->pristine = false;
     c->from_db = false;
     c->explicit_db = false;
     if (d0) {
@@ -1531,7 +1546,7 @@ static int finish_upload(Ctx* c, const void* u0, const void* d0, const void* b0)
         }
         c->from_db = true;
     }
-    DXH_HIP(hipStreamSynchronize(c->stream));
+    if (!lean) DXH_HIP(hipStreamSynchronize(c->stream));
     c->uploaded = true;
     c->halo_valid = c->halo_top;  // a slab is uploaded with valid halos
     c->global_sq_img = -1.0;
@@ -1661,6 +1676,204 @@ int dxh_tvd_run(dxh_tvd_t h, int n_iter, int jacobi_maxiter, double jacobi_tol, 
     if (rc) return rc;
     return c->desc.dtype == DXH_F32 ? run_t<float>(c, n_iter, jacobi_maxiter, jacobi_tol, eps, norm_scale, flags, result)
                                     : run_t<double>(c, n_iter, jacobi_maxiter, jacobi_tol, eps, norm_scale, flags, result);
+}
+
+// ---- whole call, host array in / host array out, in row bands -----------------------------------------------------
+// n_iter iterations move information by at most n_iter * m rows upwards and n_iter * m + 1 rows downwards (the same
+// dependence cone as the multi-GPU slabs: jacobi.py:43-54, split_bregman_tvd.py:84-89,144).  A band of rows with that many
+// extra rows on its open sides therefore reproduces the whole-image result on its own rows, bit for bit, without ever
+// talking to its neighbours -- and the bands can go through the device one after the other, band b + 1 being uploaded and
+// band b - 1 downloaded while band b iterates.  The price is the recomputed halo rows.
+static int band_streams(int device, hipStream_t out[3]) {
+    constexpr int kMax = 16;
+    static std::mutex mtx;
+    static hipStream_t streams[kMax][3] = {};
+    if (device < 0 || device >= kMax) { set_error("device %d out of range", device); return DXH_EINVAL; }
+    std::lock_guard<std::mutex> lock(mtx);
+    for (int i = 0; i < 3; ++i) {
+        if (!streams[device][i]) DXH_HIP(hipStreamCreateWithFlags(&streams[device][i], hipStreamNonBlocking));
+        out[i] = streams[device][i];
+    }
+    return DXH_OK;
+}
+
+// Band cuts: S bands over H rows; the first and the last band get `edge` times the height of the others (edge < 1: the
+// first upload and the last download, which nothing hides, get shorter).  cuts has S + 1 entries.
+static void band_cuts(int64_t H, int S, double edge, std::vector<int64_t>* cuts) {
+    cuts->assign(S + 1, 0);
+    const double total = S >= 3 ? (S - 2) + 2 * edge : (double)S;
+    double acc = 0;
+    for (int b = 0; b < S; ++b) {
+        acc += (S >= 3 && (b == 0 || b == S - 1)) ? edge : 1.0;
+        (*cuts)[b + 1] = b + 1 == S ? H : std::min<int64_t>(H, std::max<int64_t>((*cuts)[b] + 1, (int64_t)std::llround(H * acc / total)));
+    }
+}
+
+// finishing time of the bands through upload -> iterate -> download (three engines, each takes the bands in order);
+// sec_up / sec_comp / sec_down per row, per_band: fixed cost of a band's launches
+static double banded_time(const std::vector<int64_t>& cuts, int64_t H, int64_t ht, int64_t hb, double sec_up, double sec_comp,
+                          double sec_down, double per_band) {
+    double tu = 0, tc = 0, td = 0;
+    for (size_t b = 0; b + 1 < cuts.size(); ++b) {
+        const int64_t lo = std::max<int64_t>(0, cuts[b] - ht), hi = std::min<int64_t>(H, cuts[b + 1] + hb);
+        tu += (hi - lo) * sec_up;
+        tc = std::max(tc, tu) + (hi - lo) * sec_comp + per_band;
+        td = std::max(td, tc) + (cuts[b + 1] - cuts[b]) * sec_down;
+    }
+    return td;
+}
+
+int dxh_tvd_solve_banded(const dxh_tvd_desc* desc, const void* img, void* out, double mu, const void* mu_arr, double omega,
+                         const void* omega_arr, int has_ell, double ell, const void* ell_arr, int n_iter,
+                         int jacobi_maxiter, uint32_t flags, int nbands, int* nbands_used) {
+    DXH_REQUIRE(desc && img && out, "null argument");
+    DXH_REQUIRE(desc->struct_size == (int32_t)sizeof(dxh_tvd_desc), "dxh_tvd_desc size mismatch");
+    DXH_REQUIRE(desc->dim == 2, "row bands need dim == 2 (axis 0 is the band axis; a volume's planes are coupled along it "
+                "by the same stencil, but its halos would be whole planes)");
+    DXH_REQUIRE(desc->top_is_boundary && desc->bottom_is_boundary, "the descriptor must describe the whole image");
+    DXH_REQUIRE(n_iter >= 0 && jacobi_maxiter >= 1, "n_iter >= 0 and jacobi_maxiter >= 1 required");
+    DXH_REQUIRE(nbands >= 0 && nbands <= 64, "nbands must be 0 (choose) .. 64");
+    DXH_REQUIRE(!is_device_ptr(img) && !is_device_ptr(out), "host arrays expected (device arrays: dxh_tvd_run)");
+    const int64_t H = desc->n0, L = desc->n1 * desc->n2;
+    const size_t esz = desc->dtype == DXH_F32 ? 4 : 8;
+    const int64_t ht = (int64_t)n_iter * jacobi_maxiter, hb = ht + 1;
+    int S = nbands;
+    double edge = 1.0;
+    std::vector<int64_t> cuts;
+    if (S == 0) {
+        // rates measured on MI355X + PCIe 5 from pageable memory: 50 GB/s each way; per value
+        // and iteration 1.6 ps (float) / 3.6 ps (double) in one piece, isotropic and array-valued coefficients ~1.5x;
+        // bands iterate ~20 % slower than their share of the whole image (fewer row chunks, the copies alongside)
+        const double sec_copy = (double)L * esz / 50e9;
+        double per = desc->dtype == DXH_F32 ? 1.6e-12 : 3.6e-12;
+        if ((flags & DXH_FLAG_ISOTROPIC) || mu_arr || omega_arr || ell_arr) per *= 1.5;
+        const double sec_comp = (double)L * per * n_iter * jacobi_maxiter;
+        band_cuts(H, 1, 1.0, &cuts);
+        double best = banded_time(cuts, H, ht, hb, sec_copy, sec_comp, sec_copy, 0.0);
+        S = 1;
+        for (int k = 2; k <= 8; ++k) {
+            if ((H / k) < 64) break;
+            for (double e : {1.0, 0.7, 0.45}) {
+                if (k < 3 && e != 1.0) continue;
+                band_cuts(H, k, e, &cuts);
+                const double t = banded_time(cuts, H, ht, hb, sec_copy, 1.2 * sec_comp, sec_copy, 0.3e-3);
+                if (t < 0.97 * best) { best = t; S = k; edge = e; }
+            }
+        }
+    }
+    S = (int)std::min<int64_t>(S, std::max<int64_t>(1, H / 8));
+    if (const char* e = getenv("DXH_BAND_EDGE")) edge = std::min(1.0, std::max(0.1, atof(e)));   // developer knob
+    band_cuts(H, S, edge, &cuts);
+    if (nbands_used) *nbands_used = S;
+    DXH_HIP(hipSetDevice(desc->device));
+    hipStream_t streams[3];
+    int rc = band_streams(desc->device, streams);
+    if (rc) return rc;
+    HostPrefault pf;  // map the result's pages while the first band goes up
+    pf.start(out, (size_t)H * L * esz, {{img, (size_t)H * L * esz}});
+
+    struct Band { int64_t own0, own1, lo, hi; dxh_tvd_t ctx = nullptr; hipEvent_t up = nullptr, done = nullptr; std::atomic<int> state{0}; };
+    std::atomic<int> downloaded{0};   // bands whose rows are back on the host (or given up)
+    std::vector<Band> bands(S);
+    for (int b = 0; b < S; ++b) {
+        Band& bd = bands[b];
+        bd.own0 = cuts[b];
+        bd.own1 = cuts[b + 1];
+        bd.lo = std::max<int64_t>(0, bd.own0 - ht);
+        bd.hi = std::min<int64_t>(H, bd.own1 + hb);
+    }
+    std::string worker_err;
+    const bool trace = getenv("DXH_BAND_TRACE") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto now_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
+    std::vector<std::array<double, 6>> tr(S);
+    auto at = [&](const void* base, int64_t row) -> const void* {
+        return base ? static_cast<const char*>(base) + (size_t)row * L * esz : nullptr;
+    };
+    // the uploader: creates band b's context, sends its rows up and enqueues its iterations
+    std::thread uploader([&]() {
+        for (int b = 0; b < S; ++b) {
+            Band& bd = bands[b];
+            dxh_tvd_desc d = *desc;
+            d.n0 = bd.hi - bd.lo;
+            d.top_is_boundary = bd.lo == 0;
+            d.bottom_is_boundary = bd.hi == H;
+            d.stream = streams[b % 3];
+            // three streams in turn: band b re-uses the stream of band b - 3, whose download must have been issued
+            // before anything of band b is enqueued behind it
+            while (downloaded.load(std::memory_order_acquire) < b - 2) std::this_thread::yield();
+            tr[b][0] = now_ms();
+            int r = dxh_tvd_create(&bd.ctx, &d);
+            if (!r) r = dxh_tvd_set_coeffs(bd.ctx, mu, at(mu_arr, bd.lo), omega, at(omega_arr, bd.lo), has_ell, ell, at(ell_arr, bd.lo));
+            tr[b][1] = now_ms();
+            if (!r) {
+                Ctx* c = reinterpret_cast<Ctx*>(bd.ctx);
+                // the uploads go over the bus one after the other (in flight together they would all arrive late)
+                hipError_t e = hipEventCreateWithFlags(&bd.up, hipEventDisableTiming);
+                if (e == hipSuccess && b > 0) e = hipStreamWaitEvent(c->stream, bands[b - 1].up, 0);
+                if (e != hipSuccess) { set_error("band event failed: %s", hipGetErrorString(e)); r = DXH_EHIP; }
+                if (!r) r = h2d_plane(c, c->u[0], at(img, bd.lo));
+                if (!r && hipEventRecord(bd.up, c->stream) != hipSuccess) { set_error("hipEventRecord failed"); r = DXH_EHIP; }
+                if (!r) r = finish_upload(c, nullptr, nullptr, nullptr, /*lean=*/true);
+            }
+            tr[b][2] = now_ms();
+            if (!r) {
+                // ... and the bands iterate one after the other: side by side they would share the CUs and all finish
+                // late, with nothing left to hide the downloads behind
+                Ctx* c = reinterpret_cast<Ctx*>(bd.ctx);
+                hipError_t e = hipEventCreateWithFlags(&bd.done, hipEventDisableTiming);
+                if (e == hipSuccess && b > 0) e = hipStreamWaitEvent(c->stream, bands[b - 1].done, 0);
+                if (e != hipSuccess) { set_error("band event failed: %s", hipGetErrorString(e)); r = DXH_EHIP; }
+            }
+            if (!r) r = dxh_tvd_run(bd.ctx, n_iter, jacobi_maxiter, -1.0, -1.0, 0.0, flags | DXH_FLAG_ASYNC, nullptr);
+            if (!r && hipEventRecord(bd.done, reinterpret_cast<Ctx*>(bd.ctx)->stream) != hipSuccess) { set_error("hipEventRecord failed"); r = DXH_EHIP; }
+            tr[b][3] = now_ms();
+            if (r) {
+                worker_err = dxh_last_error();
+                for (int k = b; k < S; ++k) bands[k].state.store(r, std::memory_order_release);  // negative: failed
+                return;
+            }
+            bd.state.store(1, std::memory_order_release);
+        }
+    });
+    pf.join();
+    rc = DXH_OK;
+    for (int b = 0; b < S && rc == DXH_OK; ++b) {
+        Band& bd = bands[b];
+        int st;
+        while ((st = bd.state.load(std::memory_order_acquire)) == 0) std::this_thread::yield();
+        if (st < 0) { rc = st; break; }
+        Ctx* c = reinterpret_cast<Ctx*>(bd.ctx);
+        tr[b][4] = now_ms();
+        const char* src = static_cast<const char*>(c->u[c->cur]) + (size_t)(bd.own0 - bd.lo) * c->g.pitch * c->esz;
+        hipError_t e = hipMemcpy2DAsync(static_cast<char*>(out) + (size_t)bd.own0 * L * esz, L * esz, src, c->g.pitch * c->esz,
+                                        L * esz, bd.own1 - bd.own0, hipMemcpyDefault, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { set_error("band download failed: %s", hipGetErrorString(e)); rc = DXH_EHIP; }
+        tr[b][5] = now_ms();
+        downloaded.store(b + 1, std::memory_order_release);
+    }
+    downloaded.store(S + 3, std::memory_order_release);   // on an error: let the uploader run out
+    uploader.join();
+    const double t_joined = now_ms();
+    if (rc != DXH_OK && !worker_err.empty()) set_error("%s", worker_err.c_str());
+    for (auto& bd : bands)
+        if (bd.ctx) {
+            (void)hipStreamSynchronize(reinterpret_cast<Ctx*>(bd.ctx)->stream);
+            dxh_tvd_destroy(bd.ctx);
+        }
+    for (auto& bd : bands) {
+        if (bd.up) (void)hipEventDestroy(bd.up);
+        if (bd.done) (void)hipEventDestroy(bd.done);
+    }
+    if (trace) {
+        for (int b = 0; b < S; ++b)
+            fprintf(stderr, "[dxh band %d rows %lld..%lld (+%lld/%lld)] create %.2f-%.2f upload -%.2f enqueue -%.2f | download %.2f-%.2f\n",
+                    b, (long long)bands[b].own0, (long long)bands[b].own1, (long long)(bands[b].own0 - bands[b].lo),
+                    (long long)(bands[b].hi - bands[b].own1), tr[b][0], tr[b][1], tr[b][2], tr[b][3], tr[b][4], tr[b][5]);
+        fprintf(stderr, "[dxh bands] joined %.2f, contexts destroyed %.2f ms\n", t_joined, now_ms());
+    }
+    return rc;
 }
 
 int dxh_tvd_download(dxh_tvd_t h, void* u, void* d, void* b) {

@@ -92,3 +92,13 @@ class DeviceArray:
 
 def is_device_array(x) -> bool:
     return isinstance(x, DeviceArray)
+
+
+def trim_device_cache() -> int:
+    """Hand the device planes the TV contexts keep for re-use back to the HIP runtime (``dxh_mem_trim``); returns the
+    number of bytes released."""
+    import ctypes as C
+
+    n = C.c_size_t(0)
+    _lib.check(_lib.load().dxh_mem_trim(C.byref(n)))
+    return n.value

@@ -154,6 +154,32 @@ class DeviceTVD:
         return u, d, b
 
 
+def solve_banded(img: np.ndarray, mu, omega, ell, n_iter: int, jacobi_maxiter: int = 1, isotropic: bool = False,
+                 nbands: int = 0, device: Optional[int] = None, return_bands: bool = False):
+    """``n_iter`` split-Bregman iterations on a host image in row bands (``dxh_tvd_solve_banded``): band b + 1 is
+    uploaded and band b - 1 downloaded while band b iterates.  ``nbands = 0`` lets the library choose."""
+    lib = _lib.load()
+    _lib.require_gpu()
+    src = np.ascontiguousarray(img)
+    mu_s, mu_a = _coef(mu, src, "mu")
+    om_s, om_a = _coef(omega, src, "omega")
+    has_ell, ell_s, ell_a = (0, 0.0, None) if ell is None else (1, *_coef(ell, src, "ell"))
+    ndim, n0, n1, n2 = _lib.shape3(src.shape, 2)
+    d = _lib.TvdDesc()
+    d.struct_size = C.sizeof(_lib.TvdDesc)
+    d.device = _lib.default_device() if device is None else device
+    d.dtype = _lib.dtype_code(src.dtype)
+    d.ndim, d.dim, d.nsum = ndim, 2, _lib.NSUM_ALL_AXES
+    d.n0, d.n1, d.n2 = n0, n1, n2
+    d.top_is_boundary = d.bottom_is_boundary = 1
+    out = np.empty(src.shape, src.dtype)
+    used = C.c_int(0)
+    _lib.check(lib.dxh_tvd_solve_banded(C.byref(d), _lib.ptr(src), _lib.ptr(out), mu_s, _lib.ptr(mu_a), om_s, _lib.ptr(om_a),
+                                        has_ell, ell_s, _lib.ptr(ell_a), int(n_iter), int(jacobi_maxiter),
+                                        _lib.FLAG_ISOTROPIC if isotropic else 0, int(nbands), C.byref(used)))
+    return (out, used.value) if return_bands else out
+
+
 def split_bregman_tvd(
     img: np.ndarray,
     mu: Union[float, np.ndarray] = 1.0,
@@ -201,6 +227,14 @@ def split_bregman_tvd(
         for name, a in (("d0", d0), ("b0", b0)):
             if not isinstance(a, np.ndarray) or a.shape != tuple(img.shape) + (dim,):
                 raise ValueError(f"{name} must have shape (*img.shape, dim) = {img.shape + (dim,)}")
+
+    quiet = not (verbose if isinstance(verbose, bool) else verbose > 0)
+    if (not on_device and x0 is None and eps is None and adaptive is None and quiet and dim == 2 and img.ndim in (2, 3)
+            and isinstance(solver, Jacobi) and solver.tol is None and solver.maxiter >= 1 and max_num_iter >= 1
+            and img.nbytes >= (32 << 20)):
+        # fixed iteration count on a large host image: row bands through the device, the transfers overlapped with the
+        # iterations (dxh_tvd_solve_banded; bit-identical to the one-piece run below)
+        return solve_banded(img, mu, omega, ell, max_num_iter, solver.maxiter, isotropic)
 
     with DeviceTVD(img.shape, img.dtype, dim=dim, device=img.device if on_device else None) as st:
         st.set_coeffs(mu, omega, ell, img)

@@ -72,6 +72,12 @@ int dxh_mem_alloc(int device, size_t bytes, void** ptr);
 int dxh_mem_free(int device, void* ptr);
 /* synchronous copy between any two of {host array, device array} */
 int dxh_mem_copy(int device, void* dst, const void* src, size_t bytes);
+/*
+ * The TV contexts keep the planes they release in a cache (exact-size re-use; at most 1/16 of the device memory,
+ * DXH_POOL_MB overrides, 0 turns it off): hipFree costs 0.1 - 0.3 ms per plane and waits for the device, a whole call
+ * releases 10 - 30 planes.  This hands everything cached back to the HIP runtime; *bytes (optional) = what was released.
+ */
+int dxh_mem_trim(size_t* bytes);
 
 typedef struct dxh_tvd_ctx* dxh_tvd_t;
 
@@ -134,6 +140,20 @@ int dxh_tvd_run(dxh_tvd_t ctx, int n_iter, int jacobi_maxiter, double jacobi_tol
 
 /* download u and (optionally) the split variables d, b in the reference layout (*img.shape, dim). */
 int dxh_tvd_download(dxh_tvd_t ctx, void* u, void* d, void* b);
+
+/*
+ * The whole of split_bregman_tvd (split_bregman_tvd.py:14-177) for a HOST image with a fixed iteration count (eps and
+ * the inner tolerance off, Jacobi inner solver, no warm start): host array in, host array out, PCIe overlapped with the
+ * iterations.  The image is cut into row bands with n_iter * jacobi_maxiter extra rows above and one more below on
+ * their open sides -- the dependence cone of n_iter iterations (jacobi.py:43-54, split_bregman_tvd.py:84-89,144) -- so
+ * that every band reproduces the whole-image result on its own rows bit for bit; band b + 1 goes up and band b - 1
+ * comes down while band b iterates (three streams, an uploader thread).  desc describes the WHOLE image (dim == 2,
+ * both boundary flags set; desc->stream is ignored); coefficient arrays, if given, have the image's shape.
+ * nbands: 0 = chosen from a transfer / compute / halo-recompute model, 1 = no banding; *nbands_used (optional) reports it.
+ */
+int dxh_tvd_solve_banded(const dxh_tvd_desc* desc, const void* img, void* out, double mu, const void* mu_arr, double omega,
+                         const void* omega_arr, int has_ell, double ell, const void* ell_arr, int n_iter,
+                         int jacobi_maxiter, uint32_t flags, int nbands, int* nbands_used);
 
 /*
  * ConcentrationAnalysis fusion (multi_image_analysis/concentrationanalysis.py:230-310): the elementwise stages

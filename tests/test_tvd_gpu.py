@@ -744,3 +744,81 @@ def test_planes_larger_than_four_gigabytes():
             ca, cb = (0 if c0 == 0 else m), (256 if c0 + 256 == W else 256 - m)
             assert_bits(out[r0 + ra:r0 + rb, c0 + ca:c0 + cb], ref[ra:rb, ca:cb])
         del out
+
+
+# ---- whole call in row bands (dxh_tvd_solve_banded) ------------------------------------------------------------
+def _one_piece(img, mu, omega, ell, n_iter, m=1, iso=False):
+    with da.DeviceTVD(img.shape, img.dtype, dim=2) as st:
+        st.set_coeffs(mu, omega, ell, img)
+        st.upload(img)
+        st.run(n_iter, m, None, eps=None, isotropic=iso)
+        return st.download()
+
+
+@pytest.mark.parametrize("shape,nbands,n_iter,m", [
+    ((200, 96), 2, 7, 1), ((200, 96, 3), 3, 9, 1), ((333, 70, 3), 5, 4, 1), ((257, 130), 4, 3, 2),
+    ((64, 40, 3), 8, 30, 1),      # halos longer than the bands: every band holds nearly the whole image
+    ((97, 33, 2), 3, 5, 1), ((120, 50, 3), 1, 6, 1),
+])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_banded_whole_call_is_bit_identical(shape, nbands, n_iter, m, dtype):
+    from darsia_amd.restoration.split_bregman_tvd import solve_banded
+
+    rng = np.random.default_rng(hash((shape, nbands)) % 2**32)
+    img = rng.random(shape).astype(dtype)
+    want = _one_piece(img, 0.1, 1.0, None, n_iter, m)
+    got, used = solve_banded(img, 0.1, 1.0, None, n_iter, m, nbands=nbands, return_bands=True)
+    assert used == min(nbands, max(1, shape[0] // 8)) and got.dtype == img.dtype
+    assert np.array_equal(got, want)
+
+
+def test_banded_whole_call_variants_and_errors():
+    from darsia_amd.restoration.split_bregman_tvd import solve_banded
+
+    rng = np.random.default_rng(77)
+    img = rng.random((240, 88, 3)).astype(np.float32)
+    # isotropic, array-valued mu / omega / ell (the bands take their rows of the arrays)
+    assert np.array_equal(solve_banded(img, 0.1, 1.0, None, 6, isotropic=True, nbands=3), _one_piece(img, 0.1, 1.0, None, 6, iso=True))
+    mu = (0.05 + 0.1 * rng.random(img.shape)).astype(np.float32)
+    om = (0.5 + rng.random(img.shape)).astype(np.float32)
+    ell = (0.1 + 0.2 * rng.random(img.shape)).astype(np.float32)
+    assert np.array_equal(solve_banded(img, mu, 1.0, None, 5, nbands=4), _one_piece(img, mu, 1.0, None, 5))
+    assert np.array_equal(solve_banded(img, mu, om, ell, 5, nbands=2), _one_piece(img, mu, om, ell, 5))
+    assert np.array_equal(solve_banded(img, 0.2, 2.0, 0.3, 5, nbands=3), _one_piece(img, 0.2, 2.0, 0.3, 5))
+    # the automatic choice keeps a small image in one piece
+    out, used = solve_banded(img, 0.1, 1.0, None, 5, return_bands=True)
+    assert used == 1 and np.array_equal(out, _one_piece(img, 0.1, 1.0, None, 5))
+    with pytest.raises(ValueError):
+        solve_banded(img, 0.1, 1.0, None, 5, nbands=65)
+    with pytest.raises(ValueError):
+        solve_banded(img, 0.1, 1.0, 0.0, 5)   # ell == 0
+
+
+def test_split_bregman_tvd_takes_the_banded_path_for_large_host_images():
+    """32 MB and more, fixed iteration count: split_bregman_tvd() goes through dxh_tvd_solve_banded; same values as the
+    device-resident run, and as the oracle on a window (dependence radius n + 1)."""
+    from oracle import tvd_numpy as O
+
+    rng = np.random.default_rng(5)
+    img = rng.random((2048, 1600, 3)).astype(np.float32)   # 39 MB
+    got = da.split_bregman_tvd(img, mu=0.1, max_num_iter=12)
+    assert np.array_equal(got, _one_piece(img, 0.1, 1.0, None, 12))
+    win = img[1000:1096, 700:780]
+    ref = O.split_bregman_tvd(win, mu=0.1, max_num_iter=12, promotion="strict")
+    assert np.array_equal(got[1000:1096, 700:780][14:-14, 14:-14], ref[14:-14, 14:-14])
+
+
+def test_plane_cache_reuses_and_trims():
+    """Released context planes are kept for exact-size re-use (dxh_common.h: PlanePool); dxh_mem_trim hands them back.
+    A re-used plane comes back cleared: results do not depend on what ran before."""
+    rng = np.random.default_rng(11)
+    img = rng.random((300, 200, 3)).astype(np.float32)
+    da.trim_device_cache()
+    first = _one_piece(img, 0.1, 1.0, None, 5)
+    other = _one_piece(rng.random((300, 200, 3)).astype(np.float32), 0.3, 2.0, 0.7, 9, iso=True)   # dirties the cached planes
+    assert other.shape == img.shape
+    again = _one_piece(img, 0.1, 1.0, None, 5)
+    assert np.array_equal(first, again)
+    released = da.trim_device_cache()
+    assert released >= 7 * 300 * 608 * 4    # of, u x2, q x4 at least (pitch 608)
+    assert da.trim_device_cache() == 0
