@@ -128,13 +128,12 @@ class TranslationAnalysis:
         return pts, len(pts) * [0.0]
 
     def _patch_centers_pixel(self):
-        """Patch centres as (x, y) pixels: metric centre -> voxel (floor) -> flipped, as the reference does."""
+        """Patch centres as (x, y) pixels: metric centre -> voxel (floor) -> flipped (translationanalysis.py:249-255)."""
         cs = self.base.coordinatesystem
         centers = np.empty((self.N_patches[0], self.N_patches[1], 2))
         for i in range(self.N_patches[0]):
             for j in range(self.N_patches[1]):
-                voxel_center = np.mean(self.patches_base.global_corners_voxels[i, j], axis=0)
-                centers[i, j] = np.flip(cs.voxel(cs.coordinate(voxel_center)))
+                centers[i, j] = np.flip(np.asarray(cs.voxel(self.patches_base.global_centers_cartesian[i, j])))
         return centers
 
     def _set_interpolators(self, coords, tx, ty) -> None:
@@ -187,12 +186,18 @@ class TranslationAnalysis:
         self.find_translation()
         return self.translate_image(reverse)
 
-    def return_patch_translation(self, reverse: bool = True) -> np.ndarray:
-        """Displacement (x, y) in pixels at the patch centres, shape (*N_patches, 2)."""
-        centers = self._patch_centers_pixel().reshape(-1, 2)
-        t = self.translation(centers)
-        out = np.stack([t[0], t[1]], axis=-1).reshape(self.N_patches[0], self.N_patches[1], 2)
-        return -out if reverse else out
+    def return_patch_translation(self, reverse: bool = True, units: str = "metric") -> np.ndarray:
+        """Deformation at the patch centres in (row, col) components, metric or pixel units, shape (*N_patches, 2)
+        (translationanalysis.py:406-447)."""
+        patch_centers = self.patches_base.global_centers_voxels
+        shape = patch_centers.shape
+        t = np.array(self.translation(np.fliplr(patch_centers.reshape((-1, 2)))), dtype=float)
+        if reverse:
+            t *= -1.0
+        patch_translation = np.vstack((t[1], t[0])).T   # standard matrix indexing
+        if units == "metric":
+            patch_translation = self.base.coordinatesystem.coordinate_vector(patch_translation)
+        return patch_translation.reshape(shape)
 
     # ---- composition (translationanalysis.py:676-833) ----------------------------------------------
     def deduct_translation_analysis(self, other) -> None:
@@ -241,9 +246,7 @@ class DiffeomorphicImageRegistration:
         """Deformation vectors at arbitrary points (imageregistration.py:166-217)."""
         base = self.translation_analysis.base
         if isinstance(coords, Patches):
-            cs = base.coordinatesystem
-            coords = np.array([[cs.coordinate(np.mean(coords.global_corners_voxels[i, j], axis=0))
-                                for j in range(coords.num_patches[1])] for i in range(coords.num_patches[0])])
+            coords = coords.global_centers_cartesian
         assert coords.shape[-1] == 2
         shape = coords.shape
         coords = coords.reshape(-1, 2)

@@ -49,32 +49,52 @@ def _opencv_block_width(w: int, h: int) -> int:
 
 
 class Patches:
-    """Regular grid of (possibly overlapping) rectangular patches of a 2-D image: the subset of
-    ``darsia.Patches`` (image/patches.py:28-304) the warp needs -- ROIs, corner voxels in patch-local and
-    global coordinates, patch access.  Patch sizes are ``ceil(extent / num_patches)`` voxels like the
-    reference's ``num_voxels`` (coordinatesystem.py:126-147)."""
+    """Regular grid of (possibly overlapping) rectangular patches of a 2-D image: the geometry of
+    ``darsia.Patches`` (image/patches.py:28-304) -- ROIs with overlap, patch centres (metric and voxel), corner voxels in
+    global and patch-local coordinates (both WITHOUT the overlap, as in the reference), patch access.  Sizes follow the
+    reference's arithmetic: metric patch extent = dimensions / num_patches, voxels = ``num_voxels`` of that (ceil,
+    coordinatesystem.py:126-147)."""
 
     def __init__(self, img, num_patches, rel_overlap: float = 0.0) -> None:
+        from .geometry import to_cartesian_indexing
+
         self.base = img if hasattr(img, "img") else Image(np.asarray(img))
-        arr = self.base.img
+        base = self.base
         self.num_patches = [int(n) for n in num_patches]
         self.num_active_spatial_axes = 2
-        nv = arr.shape[:2]
-        pv = [ceil(nv[k] / self.num_patches[k]) for k in range(2)]
-        ov = [ceil(rel_overlap * nv[k] / self.num_patches[k]) for k in range(2)]
+        self.relative_space_overlap = rel_overlap
+        cs = base.coordinatesystem
+        nv = list(base.img.shape[:2])
+        # image/patches.py:74-102
+        pdm = [base.dimensions[k] / self.num_patches[k] for k in range(2)]
+        axes = [to_cartesian_indexing(k, base.indexing) for k in range(2)]
+        pv = [int(cs.num_voxels(pdm[k], axes[k])) for k in range(2)]
+        ov = [int(cs.num_voxels(rel_overlap * pdm[k], axes[k])) for k in range(2)]
+        self.nv, self.pv, self.ov = nv, pv, ov
+        ni, nj = self.num_patches
+        # ROIs with overlap (image/patches.py:121-131); the stop is clamped here, NumPy clamps it when slicing
         self.rois = [[(slice(max(i * pv[0] - ov[0], 0), min((i + 1) * pv[0] + ov[0], nv[0])),
                        slice(max(j * pv[1] - ov[1], 0), min((j + 1) * pv[1] + ov[1], nv[1])))
-                      for j in range(self.num_patches[1])] for i in range(self.num_patches[0])]
-        ni, nj = self.num_patches
+                      for j in range(nj)] for i in range(ni)]
+        # centres: metric, then the voxel that holds them (image/patches.py:171-206)
+        origin = np.asarray(base.origin, dtype=float)
+        self.global_centers_cartesian = np.array(
+            [[origin + np.array([(j + 0.5) * pdm[1], -(i + 0.5) * pdm[0]]) for j in range(nj)] for i in range(ni)])
+        self.global_centers_voxels = np.array(
+            [[np.asarray(cs.voxel(self.global_centers_cartesian[i, j])) for j in range(nj)] for i in range(ni)], dtype=int)
+        # corners, order: top left, bottom left, bottom right, top right (image/patches.py:214-300)
+        self.global_corners_cartesian = np.array(
+            [[np.array([[j * pdm[1], -i * pdm[0]], [j * pdm[1], -(i + 1) * pdm[0]], [(j + 1) * pdm[1], -(i + 1) * pdm[0]],
+                        [(j + 1) * pdm[1], -i * pdm[0]]]) + origin[np.newaxis, :] for j in range(nj)] for i in range(ni)])
         self.global_corners_voxels = np.empty((ni, nj, 4, 2), dtype=int)
         self.local_corners_voxels = np.empty((ni, nj, 4, 2), dtype=int)
         for i in range(ni):
             for j in range(nj):
-                r, c = self.rois[i][j]
-                # corner order: top left, bottom left, bottom right, top right (voxel = (row, col))
-                g = np.array([[r.start, c.start], [r.stop, c.start], [r.stop, c.stop], [r.start, c.stop]])
+                r0, r1 = i * pv[0], min(nv[0], (i + 1) * pv[0])
+                c0, c1 = j * pv[1], min(nv[1], (j + 1) * pv[1])
+                g = np.array([[r0, c0], [r1, c0], [r1, c1], [r0, c1]])
                 self.global_corners_voxels[i, j] = g
-                self.local_corners_voxels[i, j] = g - np.array([r.start, c.start])
+                self.local_corners_voxels[i, j] = g - np.array([r0, c0])
 
     def __call__(self, i: int, j: int) -> Image:
         return Image(self.base.img[self.rois[i][j]])

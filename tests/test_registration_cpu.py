@@ -1,0 +1,156 @@
+"""Host-side geometry and composition logic of the registration path, checked against values worked out by hand from
+the reference's formulas (no GPU, no OpenCV): ``darsia.Patches`` geometry (image/patches.py:74-300), the data points of
+``TranslationAnalysis``'s thin-plate splines incl. the prescribed boundary points (translationanalysis.py:149-404),
+``return_patch_translation`` (:406-447), ``deduct_`` / ``add_translation_analysis`` (:676-833) and
+``DiffeomorphicImageRegistration.evaluate`` (imageregistration.py:166-226)."""
+import numpy as np
+import pytest
+
+import darsia_amd as da
+from darsia_amd.imageregistration import DiffeomorphicImageRegistration, TranslationAnalysis
+from darsia_amd.registration import Patches
+
+
+class TableEstimator:
+    """Stands in for darsia.TranslationEstimator: hands out prescribed patch translations in call order (the analysis
+    visits the patches row by row, translationanalysis.py:214-215); ``None`` = no translation found for that patch."""
+
+    def __init__(self, table):
+        self.table, self.k = list(table), 0
+
+    def find_effective_translation(self, img_src, img_dst, roi_src=None, roi_dst=None, mask_src=None, mask_dst=None,
+                                   plot_matches=False):
+        t = self.table[self.k % len(self.table)]
+        self.k += 1
+        if t is None:
+            return None, False
+        return np.array([[1.0, 0.0, t[0]], [0.0, 1.0, t[1]]]), True
+
+
+def _image(h=100, w=130, dims=(1.0, 1.3), seed=0):
+    return da.Image(np.random.default_rng(seed).random((h, w)).astype(np.float32), dimensions=list(dims))
+
+
+def test_patches_geometry_follows_the_reference_formulas():
+    im = _image()
+    p = Patches(im, [3, 4], rel_overlap=0.1)
+    # voxel size 0.01 both ways; metric patch 1/3 x 0.325 -> ceil -> 34 x 33 voxels; overlap ceil(3.33), ceil(3.25) -> 4, 4
+    assert p.pv == [34, 33] and p.ov == [4, 4]
+    assert p.rois[0][0] == (slice(0, 38), slice(0, 37))
+    assert p.rois[1][1] == (slice(30, 72), slice(29, 70))
+    assert p.rois[2][3] == (slice(64, 100), slice(95, 130))          # stop clamped to the image
+    # corners WITHOUT overlap, last patch cut by the image (patches.py:253-300)
+    assert p.global_corners_voxels[1, 1].tolist() == [[34, 33], [68, 33], [68, 66], [34, 66]]
+    assert p.global_corners_voxels[2, 3].tolist() == [[68, 99], [100, 99], [100, 130], [68, 130]]
+    assert p.local_corners_voxels[2, 3].tolist() == [[0, 0], [32, 0], [32, 31], [0, 31]]
+    # centres: origin + ((j + .5) * 0.325, -(i + .5) / 3), origin = (0, 1) (patches.py:171-206); voxel = floor
+    assert np.allclose(p.global_centers_cartesian[1, 2], [2.5 * 0.325, 1.0 - 1.5 / 3])
+    assert p.global_centers_voxels[0, 0].tolist() == [16, 16]          # floor(16.67), floor(16.25)
+    assert p.global_centers_voxels[2, 3].tolist() == [83, 113]         # floor(83.33), floor(113.75)
+    assert p.global_centers_voxels.dtype.kind == "i"
+    assert np.allclose(p.global_corners_cartesian[1, 1], [[0.325, 1 - 1 / 3], [0.325, 1 - 2 / 3], [0.65, 1 - 2 / 3], [0.65, 1 - 1 / 3]])
+    # patch access returns the overlapping ROI
+    assert p(1, 1).img.shape == (42, 41) and np.array_equal(p(1, 1).img, im.img[30:72, 29:70])
+    # divisible case: no overlap, corners tile the image
+    q = Patches(_image(120, 160, (1.2, 1.6)), [3, 4])
+    assert q.pv == [40, 40] and q.ov == [0, 0]
+    assert q.global_corners_voxels[2, 3].tolist() == [[80, 120], [120, 120], [120, 160], [80, 160]]
+    assert q.global_centers_voxels[1, 1].tolist() == [60, 60]
+
+
+def _analysis(base, n, table):
+    ta = TranslationAnalysis(base, N_patches=n, rel_overlap=0.1, translation_estimator=TableEstimator(table))
+    ta.load_image(base)
+    return ta
+
+
+def _expected_points(base, n):
+    """Data points of the two splines in pixels with reverse matrix indexing (x, y), as the reference assembles them."""
+    h, w = base.img.shape[:2]
+    dy, dx = base.dimensions[0] / n[0], base.dimensions[1] / n[1]
+    vy, vx = base.dimensions[0] / h, base.dimensions[1] / w
+    centres = [np.array([np.floor((j + 0.5) * dx / vx), np.floor((i + 0.5) * dy / vy)]) for i in range(n[0]) for j in range(n[1])]
+    ys = np.linspace(0, h, n[0] + 1)
+    bc_x = [np.array([0, y]) for y in ys] + [np.array([w, y]) for y in ys]        # translationanalysis.py:349-362
+    bc_y = [np.array([x, w]) for x in np.linspace(0, w, n[1] + 1)]                 # :394-402 (y = num_voxels[1], kept)
+    return centres, bc_x, bc_y
+
+
+def test_translation_analysis_spline_data_points_and_boundary_conditions():
+    base = _image()
+    n = [3, 4]
+    table = [(1.0 + 0.1 * k, -2.0 + 0.3 * k) for k in range(12)]
+    table[5] = None                                                     # one patch without a translation
+    ta = _analysis(base, n, table)
+    translation, ok = ta.find_translation()
+    assert ok and ta.have_translation.sum() == 11 and not ta.have_translation[1, 1]
+    centres, bc_x, bc_y = _expected_points(base, n)
+    keep = [k for k in range(12) if k != 5]
+    want_x = np.array([centres[k] for k in keep] + bc_x)
+    want_y = np.array([centres[k] for k in keep] + bc_y)
+    assert np.array_equal(ta.interpolator_translation_x.y, want_x)
+    assert np.array_equal(ta.interpolator_translation_y.y, want_y)
+    assert np.allclose(ta.interpolator_translation_x.d[:, 0], [table[k][0] for k in keep] + [0.0] * len(bc_x))
+    assert np.allclose(ta.interpolator_translation_y.d[:, 0], [table[k][1] for k in keep] + [0.0] * len(bc_y))
+    # the callable returns (2, n): x row, y row; exact at the data points
+    t = translation(np.array([centres[0], centres[7]]))
+    assert t.shape == (2, 2) and np.allclose(t[:, 0], table[0], atol=1e-8) and np.allclose(t[:, 1], table[7], atol=1e-8)
+    assert np.allclose(translation(np.array(bc_x))[0], 0.0, atol=1e-8)
+    assert np.allclose(translation(np.array(bc_y))[1], 0.0, atol=1e-8)
+
+
+def test_return_patch_translation_units_and_orientation():
+    base = _image()
+    n = [3, 4]
+    table = [(2.0, -1.0)] * 12
+    ta = _analysis(base, n, table)
+    ta.find_translation()
+    # at the patch centres the spline returns the prescribed (x, y) = (2, -1) pixels
+    px = ta.return_patch_translation(reverse=False, units="pixel")
+    assert px.shape == (3, 4, 2) and np.allclose(px, [-1.0, 2.0], atol=1e-8)          # (row, col) components
+    assert np.allclose(ta.return_patch_translation(reverse=True, units="pixel"), [1.0, -2.0], atol=1e-8)
+    # metric: x = col * voxel width, y = -row * voxel height (coordinatesystem.py coordinate_vector); voxel size 0.01
+    assert np.allclose(ta.return_patch_translation(reverse=False), [0.02, 0.01], atol=1e-10)
+    assert np.allclose(ta.return_patch_translation(), [-0.02, -0.01], atol=1e-10)
+
+
+def test_deduct_and_add_compose_the_maps_at_the_patch_centres():
+    base = _image(120, 160, (1.2, 1.6), seed=1)
+    n = [3, 4]
+    centres, bc_x, bc_y = _expected_points(base, n)
+    C = np.array(centres)
+    a = _analysis(base, n, [(0.02 * c[0] - 1.0, 0.5 - 0.01 * c[1]) for c in centres])
+    b = _analysis(base, [2, 3], [(1.5, 0.7), (-0.5, 0.2), (0.3, -0.9), (0.8, 0.1), (-1.1, 0.4), (0.6, -0.3)])
+    a.find_translation()
+    b.find_translation()
+    da0 = a.translation(C).copy()
+    # add: total(c) = a(c) + b(c + a(c)) at a's patch centres, a's boundary points keep zero (translationanalysis.py:777-813)
+    want = da0 + b.translation(C + da0.T)
+    a.add_translation_analysis(b)
+    assert np.array_equal(a.interpolator_translation_x.y, np.array(centres + bc_x))
+    assert np.allclose(a.translation(C), want, atol=1e-8)
+    assert np.allclose(a.translation(np.array(bc_x))[0], 0.0, atol=1e-8)
+    assert np.allclose(a.translation(np.array(bc_y))[1], 0.0, atol=1e-8)
+    # deduct OVERWRITES the map with the other analysis sampled at this one's patch centres (:699-721)
+    a.deduct_translation_analysis(b)
+    assert np.allclose(a.translation(C), b.translation(C), atol=1e-8)
+    assert np.array_equal(a.interpolator_translation_y.y, np.array(centres + bc_y))
+    assert np.allclose(a.translation(np.array(bc_y))[1], 0.0, atol=1e-8)
+
+
+def test_registration_evaluate_converts_units_like_the_reference():
+    base = _image()
+    reg = DiffeomorphicImageRegistration(base, N_patches=[3, 4], rel_overlap=0.1,
+                                         translation_estimator=TableEstimator([(2.0, -1.0)] * 12))
+    reg.translation_analysis.load_image(base)
+    reg.translation_analysis.find_translation()
+    patches = Patches(base, [3, 4])
+    # metric in, metric out at the patch centres (imageregistration.py:190-226): (x, y) = (2, -1) px -> (0.02, +0.01)
+    out = reg.evaluate(patches)
+    assert out.shape == (3, 4, 2) and np.allclose(out, [0.02, 0.01], atol=1e-10)
+    assert np.allclose(reg.evaluate(patches, reverse=True), [-0.02, -0.01], atol=1e-10)
+    # pixel in (x, y), pixel out in (row, col) components
+    centres, _, _ = _expected_points(base, [3, 4])
+    assert np.allclose(reg.evaluate(np.array(centres), units="pixel"), [-1.0, 2.0], atol=1e-8)
+    with pytest.raises(ValueError):
+        reg.evaluate(np.zeros((1, 2)), units="furlong")
