@@ -242,6 +242,17 @@ class DiffeomorphicImageRegistration:
             return transformed, self.apply(self.dst, reverse=True)
         return transformed
 
+    def call_with_output(self, img, plot_patch_translation: bool = False, return_patch_translation: bool = False,
+                         mask=None):
+        """Register ``img`` and optionally return the deformation at the patch centres, in the sense img -> dst
+        (imageregistration.py:127-164).  Plotting is not mirrored (matplotlib, out of scope)."""
+        if plot_patch_translation:
+            raise NotImplementedError("plot_translation is not mirrored")
+        transformed = self.translation_analysis(img, mask=mask)
+        if return_patch_translation:
+            return transformed, self.translation_analysis.return_patch_translation(False)
+        return transformed
+
     def evaluate(self, coords: Union[np.ndarray, Patches], reverse: bool = False, units: str = "metric") -> np.ndarray:
         """Deformation vectors at arbitrary points (imageregistration.py:166-217)."""
         base = self.translation_analysis.base
@@ -301,7 +312,7 @@ class MultiscaleDiffeomorphicImageRegistration:
 
     def _single_level_iteration(self, img, mask, config):
         registration = DiffeomorphicImageRegistration(self.img_dst, mask_dst=self.mask_dst, **config)
-        transformed = registration(img, mask=mask)
+        transformed, _ = registration.call_with_output(img, return_patch_translation=True, mask=mask)
         return transformed, registration
 
     def __call__(self, img, mask=None, return_transformed_dst: bool = False):
