@@ -96,8 +96,27 @@ class Patches:
                 self.global_corners_voxels[i, j] = g
                 self.local_corners_voxels[i, j] = g - np.array([r0, c0])
 
+        # pixel ROIs of the area without overlap, relative to the patch with overlap (image/patches.py:136-148)
+        self.relative_rois_without_overlap = [[(slice(0, pv[0]) if i == 0 else slice(ov[0], pv[0] + ov[0]),
+                                                slice(0, pv[1]) if j == 0 else slice(ov[1], pv[1] + ov[1]))
+                                               for j in range(nj)] for i in range(ni)]
+
     def __call__(self, i: int, j: int) -> Image:
         return Image(self.base.img[self.rois[i][j]])
+
+    def assemble(self, update_img: bool = False):
+        """Re-assemble the base image from the patches without their overlap (image/patches.py:498-551)."""
+        rows = []
+        for i in range(self.num_patches[0]):
+            rows.append(np.hstack([self(i, j).img[self.relative_rois_without_overlap[i][j]]
+                                   for j in range(self.num_patches[1])]))
+        assembled = np.vstack(rows)
+        assert assembled.shape == self.base.img.shape
+        meta = self.base.metadata() if hasattr(self.base, "metadata") else {}
+        out = type(self.base)(assembled, **meta)
+        if update_img:
+            self.base = out.copy()
+        return out
 
 
 class PiecewisePerspectiveTransform:

@@ -71,6 +71,11 @@ def test_patches_partition_the_image():
     patches = da.Patches(da.Image(arr, space_dim=2), num_patches=(2, 4))
     got = [[patches(i, j).img.tolist() for j in range(4)] for i in range(2)]
     assert got == [[[[1, 2]], [[3, 4]], [[5, 6]], [[7, 8]]], [[[9, 10]], [[11, 12]], [[13, 14]], [[15, 16]]]]
+    # "Check that assemble works" (tests/unit/test_patches.py:27-28), also with overlapping patches
+    assert np.array_equal(patches.assemble().img, arr)
+    big = np.arange(100 * 130).reshape(100, 130)
+    over = da.Patches(da.Image(big, dimensions=[1.0, 1.3]), num_patches=[3, 4], rel_overlap=0.1)
+    assert np.array_equal(over.assemble().img, big)
 
 
 def test_indexing_helpers():
