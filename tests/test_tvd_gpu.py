@@ -822,3 +822,30 @@ def test_plane_cache_reuses_and_trims():
     released = da.trim_device_cache()
     assert released >= 7 * 300 * 608 * 4    # of, u x2, q x4 at least (pitch 608)
     assert da.trim_device_cache() == 0
+
+
+def test_operator_built_from_a_workflow_configuration_runs_the_heterogeneous_pipeline():
+    """presets/workflows/restoration.py:60-151: porosity weight + ignore mask -> TVD("heterogeneous bregman") with an
+    array-valued weight; the operator's result equals the oracle's for the same coefficients (float64: bit for bit)."""
+    from types import SimpleNamespace
+
+    from darsia_amd.presets.workflows import build_restoration
+    from darsia_amd.presets.workflows.config import RestorationConfig
+    from oracle import tvd_numpy as O
+
+    rng = np.random.default_rng(21)
+    h, w = 40, 56
+    porosity = 0.2 + 0.6 * rng.random((h, w))
+    inside = np.ones((h, w), bool)
+    inside[:, :9] = False
+    rig = SimpleNamespace(baseline=da.ScalarImage(np.zeros((h, w))), image_porosity=da.ScalarImage(porosity),
+                          boolean_porosity=da.ScalarImage(inside))
+    cfg = RestorationConfig().load({"method": "tvd", "ignore": ["boolean_porosity"],
+                                    "options": {"weight": "image_porosity", "max_num_iter": 9, "eps": 1e-12,
+                                                "omega": 1.5, "regularization": 0.4}})
+    op = build_restoration(cfg, rig)
+    assert op.method == "heterogeneous bregman"
+    img = rng.random((h, w))
+    got = op(img)
+    want = O.split_bregman_tvd(img, mu=porosity * inside, omega=1.5, ell=0.4, max_num_iter=9, eps=1e-12, promotion="strict")
+    assert got.dtype == np.float64 and np.array_equal(got, want)
