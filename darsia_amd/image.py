@@ -13,7 +13,7 @@ from .geometry import Coordinate, CoordinateSystem, interpret_indexing
 
 
 class Image:
-    def __init__(self, img: np.ndarray, **kwargs) -> None:
+    def __init__(self, img: np.ndarray, transformations=None, **kwargs) -> None:
         if not isinstance(img, np.ndarray):
             raise TypeError("img must be a numpy array")
         self.img = img
@@ -37,6 +37,11 @@ class Image:
         self.series = False
         self.time_dim = 0
         self.extra_metadata = dict(kwargs)  # user tags travel with the image
+        # corrections given at construction are applied in place, in order (image/image.py:188-199)
+        if transformations is not None:
+            for transformation in transformations:
+                if transformation is not None and hasattr(transformation, "__call__"):
+                    transformation(self, overwrite=True)
 
     @property
     def shape(self):
@@ -71,6 +76,11 @@ class Image:
         meta.update(_copy.deepcopy(self.extra_metadata))
         return meta
 
+    def update_metadata(self, meta=None, **kwargs) -> None:
+        """Set attributes from ``meta`` (keys of ``metadata()``) and keyword arguments (image/image.py:441-454)."""
+        for key, value in {**(meta or {}), **kwargs}.items():
+            setattr(self, key, value)
+
     def copy(self) -> "Image":
         """Deep copy (image/image.py:363-370)."""
         return _copy.deepcopy(self)
@@ -79,17 +89,17 @@ class Image:
 class ScalarImage(Image):
     """Single-channel image (image/image.py:1860)."""
 
-    def __init__(self, img: np.ndarray, **kwargs) -> None:
+    def __init__(self, img: np.ndarray, transformations=None, **kwargs) -> None:
         kwargs["scalar"] = True
-        super().__init__(img, **kwargs)
+        super().__init__(img, transformations, **kwargs)
 
 
 class OpticalImage(Image):
     """Photograph with a trailing colour axis (image/image.py:2081)."""
 
-    def __init__(self, img: np.ndarray, **kwargs) -> None:
+    def __init__(self, img: np.ndarray, transformations=None, **kwargs) -> None:
         kwargs["scalar"] = False
-        super().__init__(img, **kwargs)
+        super().__init__(img, transformations, **kwargs)
 
 
 def with_array(img, array: np.ndarray):

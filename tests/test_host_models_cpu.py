@@ -43,3 +43,44 @@ def test_cleaning_filter_is_the_maximum_reduced_difference():
     expect = np.maximum(np.abs(frames[1].img - frames[0].img)[:, :, 1], np.abs(frames[2].img - frames[0].img)[:, :, 1])
     assert ca.threshold_cleaning_filter.dtype == np.float64
     assert np.array_equal(ca.threshold_cleaning_filter, np.maximum(0.0, expect))
+
+
+def test_correction_protocol_and_transformations_at_construction():
+    """basecorrection.py:15-95 and image/image.py:188-199: a correction maps arrays and Images, copies unless told to
+    overwrite, updates the metadata it declares; corrections handed to the Image constructor run in place, in order."""
+    import darsia_amd as da
+    from darsia_amd.corrections import BaseCorrection
+
+    class Scale(BaseCorrection):
+        def __init__(self, f, name=None):
+            self.f, self.new_name = f, name
+
+        def correct_array(self, image):
+            image *= self.f           # writes into its argument on purpose
+            return image
+
+        def correct_metadata(self, metadata={}):
+            return {} if self.new_name is None else {"name": self.new_name}
+
+        def save(self, path):
+            pass
+
+        def load(self, path):
+            pass
+
+    arr = np.arange(6.0).reshape(2, 3)
+    twice = Scale(2.0)
+    out = twice(arr)
+    assert np.array_equal(out, 2 * np.arange(6.0).reshape(2, 3)) and arr[0, 1] == 1.0      # copy
+    assert twice(arr, overwrite=True) is arr and arr[0, 1] == 2.0                           # in place
+    im = da.ScalarImage(np.ones((2, 3)), name="raw", dimensions=[2.0, 3.0])
+    res = Scale(3.0, name="scaled")(im)
+    assert res is not im and res.name == "scaled" and im.name == "raw" and im.img[0, 0] == 1.0 and res.img[0, 0] == 3.0
+    assert res.dimensions == [2.0, 3.0]
+    same = Scale(3.0, name="scaled")(im, overwrite=True)
+    assert same is im and im.name == "scaled" and im.img[0, 0] == 3.0
+    # transformations at construction: applied in order, None entries skipped
+    built = da.ScalarImage(np.ones((2, 2)), transformations=[Scale(2.0), None, Scale(5.0, name="done")])
+    assert np.array_equal(built.img, np.full((2, 2), 10.0)) and built.name == "done"
+    with pytest.raises(TypeError):
+        twice([1, 2, 3])
