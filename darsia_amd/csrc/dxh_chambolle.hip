@@ -632,38 +632,40 @@ static int chambolle_t(int device, int ndim, int64_t n0, int64_t n1, int64_t n2,
     std::vector<void*> extra;
     int rc = DXH_OK;
     auto cleanup = [&]() {
-        for (void* b : bufs) if (b) (void)hipFree(b);
-        if (partial) (void)hipFree(partial);
-        if (red) (void)hipFree(red);
-        if (stage2) (void)hipFree(stage2);
-        for (void* b : extra) if (b) (void)hipFree(b);
+        // the planes go back to the cache (dxh_common.h: PlanePool), which wants them idle
+        if (st) (void)hipStreamSynchronize(st);
+        for (void* b : bufs) pool_free(b);
+        pool_free(partial);
+        pool_free(red);
+        pool_free(stage2);
+        for (void* b : extra) pool_free(b);
     };
     HostPrefault pf;  // map the output pages while the device works
     pf.start(out, (size_t)n0 * g.L * sizeof(T), {{img, (size_t)n0 * g.L * sizeof(T)}});
     auto body = [&]() -> int {
         DXH_HIP(cached_stream(device, &st));
         for (int i = 0; i < 2 + ndim; ++i) {
-            DXH_HIP(hipMalloc(&bufs[i], plane));
+            DXH_HIP(pool_malloc(&bufs[i], plane));
             DXH_HIP(hipMemsetAsync(bufs[i], 0, plane, st));
         }
         // one slot per block of the element-wise kernels or per wave of the marching kernels (strips are at least 64
         // elements wide, row chunks at least 8 rows high), whichever is more
         const size_t npart_alloc = std::max<size_t>(nblocks, (size_t)(g.L / 64 + 2) * (size_t)(n0 / 8 + 2));
-        DXH_HIP(hipMalloc((void**)&partial, sizeof(double) * npart_alloc));
-        DXH_HIP(hipMalloc((void**)&red, sizeof(double)));
-        DXH_HIP(hipMalloc((void**)&stage2, sizeof(double) * 256));
+        DXH_HIP(pool_malloc((void**)&partial, sizeof(double) * npart_alloc));
+        DXH_HIP(pool_malloc((void**)&red, sizeof(double) * 4));
+        DXH_HIP(pool_malloc((void**)&stage2, sizeof(double) * 4 * 256));
         DXH_HIP(hipMemcpy2DAsync(bufs[0], g.pitch * sizeof(T), img, g.L * sizeof(T), g.L * sizeof(T), n0,
                                  hipMemcpyDefault, st));
         DXH_HIP(hipMemcpyAsync(bufs[1], bufs[0], plane, hipMemcpyDeviceToDevice, st));  // out = image (iteration 0)
         // p is double buffered: pbuf[ax][0/1]; `out` is only written after the loop
         void* p2[3] = {nullptr, nullptr, nullptr};
         for (int ax = 0; ax < ndim; ++ax) {
-            DXH_HIP(hipMalloc(&p2[ax], plane));
+            DXH_HIP(pool_malloc(&p2[ax], plane));
             extra.push_back(p2[ax]);
             DXH_HIP(hipMemsetAsync(p2[ax], 0, plane, st));
         }
         double* partial_n = nullptr;
-        DXH_HIP(hipMalloc((void**)&partial_n, sizeof(double) * npart_alloc));
+        DXH_HIP(pool_malloc((void**)&partial_n, sizeof(double) * npart_alloc));
         extra.push_back(partial_n);
         const double tau = 1.0 / (2.0 * ndim);
         // row-marching kernel for 2-D images and colour-images-as-volumes; everything else one thread per element
@@ -711,17 +713,22 @@ static int chambolle_t(int device, int ndim, int64_t n0, int64_t n1, int64_t n2,
             march2_grid = (unsigned)(nbx * nchunks);
             nparts2 = (int)(nchunks * m2.m.nstrips);
             if ((size_t)nparts2 > npart_alloc) { set_error("internal: partial buffer too small"); return DXH_EHIP; }
-            DXH_HIP(hipMalloc((void**)&partial_d2_b, sizeof(double) * nparts2));
+            DXH_HIP(pool_malloc((void**)&partial_d2_b, sizeof(double) * nparts2));
             extra.push_back(partial_d2_b);
-            DXH_HIP(hipMalloc((void**)&partial_n_b, sizeof(double) * nparts2));
+            DXH_HIP(pool_malloc((void**)&partial_n_b, sizeof(double) * nparts2));
             extra.push_back(partial_n_b);
         }
         int reduce_count = nparts;
-        auto reduce = [&](double* part, double* host) -> int {
-            hipLaunchKernelGGL(k_sum_partials, dim3(256), dim3(256), 0, st, part, reduce_count, stage2);
-            hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, stage2, 256, red);
+        // the energies' partial sums, several lists at once: one launch pair, one read-back, one synchronisation
+        auto reduce_lists = [&](int nl, const double* const* parts, double* host) -> int {
+            SumLists ls{};
+            for (int i = 0; i < 4; ++i) ls.p[i] = parts[i < nl ? i : 0];
+            hipLaunchKernelGGL(k_sum_partials_lists, dim3(256, nl), dim3(256), 0, st, ls, reduce_count, stage2);
+            SumLists l2{};
+            for (int i = 0; i < 4; ++i) l2.p[i] = stage2 + 256 * (i < nl ? i : 0);
+            hipLaunchKernelGGL(k_sum_partials_lists, dim3(1, nl), dim3(256), 0, st, l2, 256, red);
             DXH_HIP(hipGetLastError());
-            DXH_HIP(hipMemcpyAsync(host, red, sizeof(double), hipMemcpyDefault, st));
+            DXH_HIP(hipMemcpyAsync(host, red, sizeof(double) * nl, hipMemcpyDefault, st));
             DXH_HIP(hipStreamSynchronize(st));
             return DXH_OK;
         };
@@ -745,10 +752,12 @@ static int chambolle_t(int device, int ndim, int64_t n0, int64_t n1, int64_t n2,
                 DXH_HIP(hipGetLastError());
                 double d2b = 0.0, nb = 0.0;
                 reduce_count = nparts2;
-                r = reduce(partial, &sum_d2);
-                if (!r) r = reduce(partial_n, &sum_n);
-                if (!r) r = reduce(partial_d2_b, &d2b);
-                if (!r) r = reduce(partial_n_b, &nb);
+                {
+                    const double* lists[4] = {partial, partial_n, partial_d2_b, partial_n_b};
+                    double sums[4] = {0, 0, 0, 0};
+                    r = reduce_lists(4, lists, sums);
+                    sum_d2 = sums[0]; sum_n = sums[1]; d2b = sums[2]; nb = sums[3];
+                }
                 reduce_count = nparts;
                 if (r) return r;
                 // first iteration of the pass: its `out` derives from p[cur], which is untouched
@@ -800,7 +809,12 @@ static int chambolle_t(int device, int ndim, int64_t n0, int64_t n1, int64_t n2,
                 hipLaunchKernelGGL((k_ch_fused<T, 3>), dim3(nblocks), dim3(256), 0, st, fa);
             }
             DXH_HIP(hipGetLastError());
-            if ((r = reduce(partial, &sum_d2)) || (r = reduce(partial_n, &sum_n))) return r;
+            {
+                const double* lists[4] = {partial, partial_n, partial, partial};
+                double sums[2] = {0, 0};
+                if ((r = reduce_lists(2, lists, sums))) return r;
+                sum_d2 = sums[0]; sum_n = sums[1];
+            }
             out_from = cur;        // the iteration just entered computed its `out` from p[cur]
             const double energy = (sum_d2 + weight * sum_n) / size;
             if (it == 0) {

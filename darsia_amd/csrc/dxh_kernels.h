@@ -861,6 +861,25 @@ static __global__ void __launch_bounds__(256) k_sum_partials(const double* __res
     if (threadIdx.x == 0) out[blockIdx.x] = sm[0];
 }
 
+// k_sum_partials over up to four lists of the same length in one launch: blockIdx.y selects the list, the tree of every
+// list is the one k_sum_partials builds (same values); out is [4][gridDim.x].
+struct SumLists { const double* p[4]; };
+static __global__ void __launch_bounds__(256) k_sum_partials_lists(SumLists lists, int n, double* __restrict__ out) {
+    __shared__ double sm[256];
+    const double* __restrict__ partial = lists.p[blockIdx.y];
+    const int chunk = (n + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * chunk, hi = min(n, lo + chunk);
+    double acc = 0.0;
+    for (int i = lo + threadIdx.x; i < hi; i += 256) acc += partial[i];
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.y * gridDim.x + blockIdx.x] = sm[0];
+}
+
 // ============================================================================================
 // Fused sweep (dim = 2, one Jacobi sweep): rhs + Jacobi + shrink of one outer iteration in a single
 // pass.  Algorithmic traffic per element: read of, u, q0, q1; write u, q0, q1  = 7 values.

@@ -49,6 +49,7 @@ t("config 3 chain, device-resident (uint8 up, colour, 100 it isotropic, float32 
 t("config 3 chain through host arrays between the operators", chain_host)
 print("default TVD(): chambolle on RGB-as-volume, eps 2e-4")
 out, iters = da.denoise_tv_chambolle(rgb, weight=0.1, return_iters=True)
+del out   # dropping a 384 MB result costs the host ~20 ms (munmap): keep it out of the timed call
 t0 = time.perf_counter(); out, iters = da.denoise_tv_chambolle(rgb, weight=0.1, return_iters=True); dt = time.perf_counter() - t0
 print(f"  chambolle: {iters} iterations, {dt*1e3:.1f} ms total, {dt/max(iters,1)*1e3:.2f} ms/iteration [PCIe-inclusive]")
 print("config 4: registration dense parts on two 4000 x 8000 gray frames, N_patches = [10, 20]")
