@@ -3,6 +3,7 @@
 #include <atomic>
 #include <memory>
 #include <cmath>
+#include <cstring>
 #include <thread>
 #include <vector>
 
@@ -27,14 +28,15 @@ struct WarpPatch {
     int w_eff, h_eff;            // size of the warped tile (cv2 dsize)
     int nx, ny;                  // part of the tile added to the canvas: canvas[oy:oy+ny, ox:ox+nx]
     int bw0;                     // OpenCV's block width for this tile size
-    int pad;
+    int pad;                     // set by dxh_warp_patches: ceil(2^32 / bw0) for the division by bw0, 0 = divide
 };
 
-__device__ __forceinline__ long long round_half_even_clamped(double v) {
+// saturate_cast<int>(max(INT_MIN, min(INT_MAX, v))) with cvRound's round-half-to-even: the clamped value is an int
+__device__ __forceinline__ int round_half_even_clamped(double v) {
     const double lo = -2147483648.0, hi = 2147483647.0;
-    v = v < lo ? lo : (v > hi ? hi : v);  // max(INT_MIN, min(INT_MAX, v)); NaN falls through to lo below
+    v = v < lo ? lo : (v > hi ? hi : v);  // NaN falls through to lo below
     if (!(v == v)) v = lo;
-    return (long long)rint(v);            // round half to even, like cvRound / lrint
+    return __double2int_rn(v);            // v_cvt_i32_f64: round to nearest even
 }
 
 constexpr int kWarpBW = 256, kWarpBH = 16;
@@ -55,16 +57,18 @@ __global__ void __launch_bounds__(256) k_warp(const float* __restrict__ base, in
         const WarpPatch& p = pt[bin_idx[kk]];
         const int tx = x - p.ox, ty = y - p.oy;
         if (tx < 0 || ty < 0 || tx >= p.nx || ty >= p.ny) continue;
-        const int bx = (tx / p.bw0) * p.bw0;
+        // tx < 2^16 and bw0 < 2^16: the high word of tx * ceil(2^32 / bw0) is the exact quotient
+        const unsigned magic = (unsigned)p.pad;
+        const int bx = (magic ? (int)__umulhi((unsigned)tx, magic) : tx / p.bw0) * p.bw0;
         const double x1 = (double)(tx - bx), fbx = (double)bx, fy_ = (double)ty;
         const double X0 = p.minv[0] * fbx + p.minv[1] * fy_ + p.minv[2];
         const double Y0 = p.minv[3] * fbx + p.minv[4] * fy_ + p.minv[5];
         const double W0 = p.minv[6] * fbx + p.minv[7] * fy_ + p.minv[8];
         double Wd = W0 + p.minv[6] * x1;
         Wd = Wd != 0.0 ? 32.0 / Wd : 0.0;
-        const long long X = round_half_even_clamped((X0 + p.minv[0] * x1) * Wd);
-        const long long Y = round_half_even_clamped((Y0 + p.minv[3] * x1) * Wd);
-        long long sx = X >> 5, sy = Y >> 5;
+        const int X = round_half_even_clamped((X0 + p.minv[0] * x1) * Wd);
+        const int Y = round_half_even_clamped((Y0 + p.minv[3] * x1) * Wd);
+        int sx = X >> 5, sy = Y >> 5;   // arithmetic shifts; saturate_cast<short> below
         sx = sx < -32768 ? -32768 : (sx > 32767 ? 32767 : sx);
         sy = sy < -32768 ? -32768 : (sy > 32767 ? 32767 : sy);
         const float fx = (float)(X & 31) * (1.0f / 32.0f), fy = (float)(Y & 31) * (1.0f / 32.0f);
@@ -77,7 +81,7 @@ __global__ void __launch_bounds__(256) k_warp(const float* __restrict__ base, in
         for (int ky = 0; ky < 2; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 2; ++kx) {
-                const long long yy = sy + ky, xx = sx + kx;
+                const int yy = sy + ky, xx = sx + kx;
                 const bool ok = yy >= 0 && yy < p.sh && xx >= 0 && xx < p.sw;
                 const float wgt = wy[ky] * wx[kx];
                 const float* s = base + ((size_t)(p.sr0 + (ok ? yy : 0)) * W + (p.sc0 + (ok ? xx : 0))) * C;
@@ -400,7 +404,14 @@ int dxh_warp_patches(int device, int H, int W, int C, const float* base, const d
     if (canvas_on_device) dcanvas = canvas;
     else if ((rc = d.alloc(&dcanvas, bytes))) return rc;
     if (!base_on_device) DXH_HIP(hipMemcpyAsync(dbase, base, bytes, hipMemcpyDefault, d.st));
-    if (npatch) DXH_HIP(hipMemcpyAsync(dpt, patches, sizeof(WarpPatch) * (size_t)npatch, hipMemcpyDefault, d.st));
+    // the table with the division constants filled in (kept alive until the synchronisation below)
+    std::vector<WarpPatch> table((size_t)npatch);
+    for (int k = 0; k < npatch; ++k) {
+        std::memcpy(&table[k], &patches[k], sizeof(WarpPatch));
+        const int64_t bw = patches[k].bw0;
+        table[k].pad = (bw >= 2 && bw < 65536 && patches[k].nx <= 65536) ? (int)(uint32_t)(((int64_t(1) << 32) + bw - 1) / bw) : 0;
+    }
+    if (npatch) DXH_HIP(hipMemcpyAsync(dpt, table.data(), sizeof(WarpPatch) * (size_t)npatch, hipMemcpyDefault, d.st));
     DXH_HIP(hipMemcpyAsync(doff, off.data(), sizeof(int) * off.size(), hipMemcpyDefault, d.st));
     DXH_HIP(hipMemcpyAsync(didx, idx.data(), sizeof(int) * idx.size(), hipMemcpyDefault, d.st));
     const dim3 grid(nbx, H), blk(kWarpBW);
