@@ -1,5 +1,6 @@
 // Dense per-pixel kernels around the TV path: piecewise perspective warp (registration), thin-plate
 // spline displacement field, affine colour balance.  gfx950 only.
+#include <array>
 #include <atomic>
 #include <memory>
 #include <cmath>
@@ -105,7 +106,44 @@ __global__ void __launch_bounds__(256) k_warp(const float* __restrict__ base, in
 // RBFInterpolator evaluation for kernel 'thin_plate_spline', epsilon = 1 (translationanalysis.py:285-301,
 // imageregistration.py:265-306).  Points are either given explicitly or are the pixel grid
 // (x = column + 0 , y = row) scaled by an affine map, so that the dense field needs no point upload.
+// log for the spline kernel.  v = 2^e * m, m in [1, 2); the top 7 mantissa bits pick c_j ~ 1 / m from a 128-entry table
+// held in LDS together with -log(c_j) (rounded from long double), r = m c_j - 1 is one FMA with |r| <= 2^-8, and
+// log v = e ln 2 - log c_j + log1p(r) with the series of log1p up to r^7 (next term: 2^-59 relative to r).  Absolute error
+// ~1e-16 (a few ulp of the result away from v ~ 1, where the result itself is tiny and enters r^2 log r with r^2 ~ 1):
+// 11 double-precision operations instead of the ~50 of the library routine.  Denormals, inf, NaN take the library path.
+constexpr int kLogTab = 128;
+__device__ __forceinline__ double tps_log(double v, const double2* __restrict__ tab) {
+    const int hi = __double2hiint(v);
+    const unsigned ex = (unsigned)hi >> 20;                  // v > 0: no sign bit
+    if (ex == 0u || ex >= 0x7ffu) return log(v);
+    const double2 t = tab[(hi >> 13) & (kLogTab - 1)];
+    const double m = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, __double2loint(v));
+    const double r = fma(m, t.x, -1.0);
+    double q = fma(r, 1.0 / 7.0, -1.0 / 6.0);
+    q = fma(q, r, 1.0 / 5.0);
+    q = fma(q, r, -1.0 / 4.0);
+    q = fma(q, r, 1.0 / 3.0);
+    q = fma(q, r, -0.5);
+    q = fma(q * r, r, r);                                    // r - r^2/2 + ...
+    const double e = (double)((int)ex - 1023);
+    return fma(e, 0.6931471805599453094, t.y + q);
+}
+
+static const double* tps_log_table() {
+    static const std::array<double, 2 * kLogTab> tab = [] {
+        std::array<double, 2 * kLogTab> t{};
+        for (int j = 0; j < kLogTab; ++j) {
+            const double c = 1.0 / (1.0 + (j + 0.5) / kLogTab);
+            t[2 * j] = c;
+            t[2 * j + 1] = (double)(-logl((long double)c));
+        }
+        return t;
+    }();
+    return tab.data();
+}
+
 struct TpsArgs {
+    const double* logtab;   // kLogTab x (c, -log c)
     const double* centers;  // (p, 2)
     const double* coeffs;   // (p + 3, dout)
     const double* points;   // (n, 2) or null for the grid
@@ -119,8 +157,11 @@ struct TpsArgs {
 };
 
 __global__ void __launch_bounds__(256) k_tps(TpsArgs a) {
-    extern __shared__ double sm[];  // centers (2p) then coeffs ((p+3) * dout)
+    extern __shared__ __align__(16) double sm_all[];  // log table, then centers (2p), then coeffs ((p+3) * dout)
+    const double2* ltab = reinterpret_cast<const double2*>(sm_all);
+    double* sm = sm_all + 2 * kLogTab;
     const int nc = 2 * a.p, nk = (a.p + 3) * a.dout;
+    for (int i = threadIdx.x; i < 2 * kLogTab; i += blockDim.x) sm_all[i] = a.logtab[i];
     for (int i = threadIdx.x; i < nc; i += blockDim.x) sm[i] = a.centers[i];
     for (int i = threadIdx.x; i < nk; i += blockDim.x) sm[nc + i] = a.coeffs[i];
     __syncthreads();
@@ -141,7 +182,7 @@ __global__ void __launch_bounds__(256) k_tps(TpsArgs a) {
         // thin-plate spline r^2 log r = 0.5 r^2 log(r^2): no square root (SciPy evaluates r^2 log r; the two forms
         // differ in the last bits only, tests compare to 1e-10)
         const double r2 = dx * dx + dy * dy;
-        const double phi = r2 == 0.0 ? 0.0 : 0.5 * r2 * log(r2);
+        const double phi = r2 == 0.0 ? 0.0 : 0.5 * r2 * tps_log(r2, ltab);
         acc0 += phi * cf[i * a.dout];
         if (a.dout > 1) acc1 += phi * cf[i * a.dout + 1];
     }
@@ -153,6 +194,57 @@ __global__ void __launch_bounds__(256) k_tps(TpsArgs a) {
     }
     a.out[n * a.dout] = acc0;
     if (a.dout > 1) a.out[n * a.dout + 1] = acc1;
+}
+
+// Two splines at once on the pixel grid -- the x and y translation maps of a TranslationAnalysis share the patch centres
+// and differ in their boundary points (translationanalysis.py:285-294) -- over the UNION of their centres (a spline
+// that does not have a centre carries a zero weight there): one r^2 log r per centre and pixel serves both.  Every
+// spline keeps its own polynomial tail (SciPy normalises it by the spline's own point cloud).  The result is written as
+// (out_scale[0] * s0, out_scale[1] * s1) per pixel: the (x, y) metric displacement of imageregistration.py:265-306.
+struct TpsPairArgs {
+    const double* logtab;
+    const double* table;      // pu x (cx, cy, w0, w1)
+    int pu;
+    double poly[2][3];        // polynomial coefficients of spline 0 / 1
+    double shift[2][2], scale[2][2];
+    int powers[2][3][2];
+    long long n;
+    int grid_w;
+    double gx0, gy0, gsx, gsy;
+    double out_scale[2];
+    double* out;              // (n, 2)
+};
+
+__global__ void __launch_bounds__(256) k_tps_pair(TpsPairArgs a) {
+    extern __shared__ __align__(16) double sm_all[];  // log table, then the centre table
+    const double2* ltab = reinterpret_cast<const double2*>(sm_all);
+    double* sm = sm_all + 2 * kLogTab;
+    for (int i = threadIdx.x; i < 2 * kLogTab; i += blockDim.x) sm_all[i] = a.logtab[i];
+    for (int i = threadIdx.x; i < 4 * a.pu; i += blockDim.x) sm[i] = a.table[i];
+    __syncthreads();
+    const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= a.n) return;
+    const double x = a.gx0 + a.gsx * (double)(n % a.grid_w);
+    const double y = a.gy0 + a.gsy * (double)(n / a.grid_w);
+    double acc0 = 0.0, acc1 = 0.0;
+    const double2* tb = reinterpret_cast<const double2*>(sm);
+    for (int i = 0; i < a.pu; ++i) {
+        const double2 c = tb[2 * i], w = tb[2 * i + 1];
+        const double dx = x - c.x, dy = y - c.y;
+        const double r2 = dx * dx + dy * dy;
+        const double phi = r2 == 0.0 ? 0.0 : 0.5 * r2 * tps_log(r2, ltab);
+        acc0 += phi * w.x;
+        acc1 += phi * w.y;
+    }
+    double acc[2] = {acc0, acc1};
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        const double xh = (x - a.shift[o][0]) / a.scale[o][0], yh = (y - a.shift[o][1]) / a.scale[o][1];
+        for (int j = 0; j < 3; ++j)
+            acc[o] += pow(xh, (double)a.powers[o][j][0]) * pow(yh, (double)a.powers[o][j][1]) * a.poly[o][j];
+    }
+    a.out[2 * n] = a.out_scale[0] * acc[0];
+    a.out[2 * n + 1] = a.out_scale[1] * acc[1];
 }
 
 // ---- affine colour balance -----------------------------------------------------------------------------
@@ -432,7 +524,7 @@ int dxh_tps_eval(int device, int p, int dout, const double* centers, const doubl
     DXH_REQUIRE(centers && coeffs && shift && scale && powers && out, "null argument");
     DXH_REQUIRE(p >= 1 && (dout == 1 || dout == 2), "p >= 1 and dout in {1, 2} required");
     DXH_REQUIRE(n >= 0 && (points || grid_w >= 1), "bad point set");
-    const size_t smem = sizeof(double) * (2 * (size_t)p + (size_t)(p + 3) * dout);
+    const size_t smem = sizeof(double) * (2 * (size_t)kLogTab + 2 * (size_t)p + (size_t)(p + 3) * dout);
     DXH_REQUIRE(smem <= 64 * 1024, "too many centres (%d) for the LDS-resident table", p);
     int rc = check_device(device);
     if (rc) return rc;
@@ -441,10 +533,11 @@ int dxh_tps_eval(int device, int p, int dout, const double* centers, const doubl
     pf.start(out, sizeof(double) * (size_t)n * dout, {{points, points ? sizeof(double) * 2 * (size_t)n : 0}});
     Dev d;
     DXH_HIP(cached_stream(device, &d.st));
-    void *dc = nullptr, *dk = nullptr, *dp = nullptr, *dout_ = nullptr;
+    void *dc = nullptr, *dk = nullptr, *dp = nullptr, *dout_ = nullptr, *dl = nullptr;
     if ((rc = d.alloc(&dc, sizeof(double) * 2 * p)) || (rc = d.alloc(&dk, sizeof(double) * (p + 3) * dout)) ||
-        (rc = d.alloc(&dout_, sizeof(double) * (size_t)n * dout)))
+        (rc = d.alloc(&dout_, sizeof(double) * (size_t)n * dout)) || (rc = d.alloc(&dl, sizeof(double) * 2 * kLogTab)))
         return rc;
+    DXH_HIP(hipMemcpyAsync(dl, tps_log_table(), sizeof(double) * 2 * kLogTab, hipMemcpyDefault, d.st));
     DXH_HIP(hipMemcpyAsync(dc, centers, sizeof(double) * 2 * p, hipMemcpyDefault, d.st));
     DXH_HIP(hipMemcpyAsync(dk, coeffs, sizeof(double) * (p + 3) * dout, hipMemcpyDefault, d.st));
     if (points) {
@@ -452,6 +545,7 @@ int dxh_tps_eval(int device, int p, int dout, const double* centers, const doubl
         DXH_HIP(hipMemcpyAsync(dp, points, sizeof(double) * 2 * (size_t)n, hipMemcpyDefault, d.st));
     }
     TpsArgs a;
+    a.logtab = (const double*)dl;
     a.centers = (const double*)dc;
     a.coeffs = (const double*)dk;
     a.points = (const double*)dp;
@@ -466,6 +560,79 @@ int dxh_tps_eval(int device, int p, int dout, const double* centers, const doubl
     pf.join();
     DXH_HIP(hipMemcpyAsync(out, dout_, sizeof(double) * (size_t)n * dout, hipMemcpyDefault, d.st));
     DXH_HIP(hipStreamSynchronize(d.st));
+    return DXH_OK;
+}
+
+int dxh_tps_eval_pair(int device, int p0, const double* centers0, const double* coeffs0, const double* shift0,
+                      const double* scale0, const int* powers0, int p1, const double* centers1, const double* coeffs1,
+                      const double* shift1, const double* scale1, const int* powers1, int64_t grid_h, int64_t grid_w,
+                      double gx0, double gy0, double gsx, double gsy, double out_scale0, double out_scale1, double* out) {
+    DXH_REQUIRE(centers0 && coeffs0 && shift0 && scale0 && powers0 && centers1 && coeffs1 && shift1 && scale1 && powers1 && out,
+                "null argument");
+    DXH_REQUIRE(p0 >= 1 && p1 >= 1 && grid_h >= 0 && grid_w >= 1, "bad sizes");
+    int rc = check_device(device);
+    if (rc) return rc;
+    const int64_t n = grid_h * grid_w;
+    if (n == 0) return DXH_OK;
+    // union of the centres, first spline's order first; equal centres are merged
+    std::vector<double> table;
+    table.reserve(4 * (size_t)(p0 + p1));
+    for (int i = 0; i < p0; ++i) {
+        table.push_back(centers0[2 * i]); table.push_back(centers0[2 * i + 1]);
+        table.push_back(coeffs0[i]); table.push_back(0.0);
+    }
+    std::vector<char> merged((size_t)p0, 0);
+    for (int j = 0; j < p1; ++j) {
+        int hit = -1;
+        for (int i = 0; i < p0 && hit < 0; ++i)
+            if (!merged[i] && centers0[2 * i] == centers1[2 * j] && centers0[2 * i + 1] == centers1[2 * j + 1]) hit = i;
+        if (hit >= 0) {
+            merged[hit] = 1;
+            table[4 * hit + 3] = coeffs1[j];
+        } else {
+            table.push_back(centers1[2 * j]); table.push_back(centers1[2 * j + 1]);
+            table.push_back(0.0); table.push_back(coeffs1[j]);
+        }
+    }
+    const int pu = (int)(table.size() / 4);
+    const size_t smem = sizeof(double) * (2 * (size_t)kLogTab + 4 * (size_t)pu);
+    DXH_REQUIRE(smem <= 64 * 1024, "too many centres (%d) for the LDS-resident table", pu);
+    HostPrefault pf;  // map the output pages while the device works
+    pf.start(out, sizeof(double) * 2 * (size_t)n);
+    Dev d;
+    DXH_HIP(cached_stream(device, &d.st));
+    void *dt = nullptr, *dl = nullptr, *dout_ = nullptr;
+    const bool out_on_device = is_device_ptr(out);
+    if ((rc = d.alloc(&dt, sizeof(double) * table.size())) || (rc = d.alloc(&dl, sizeof(double) * 2 * kLogTab))) return rc;
+    if (out_on_device) dout_ = out;
+    else if ((rc = d.alloc(&dout_, sizeof(double) * 2 * (size_t)n))) return rc;
+    DXH_HIP(hipMemcpyAsync(dt, table.data(), sizeof(double) * table.size(), hipMemcpyDefault, d.st));
+    DXH_HIP(hipMemcpyAsync(dl, tps_log_table(), sizeof(double) * 2 * kLogTab, hipMemcpyDefault, d.st));
+    TpsPairArgs a;
+    a.logtab = (const double*)dl;
+    a.table = (const double*)dt;
+    a.pu = pu;
+    const double* sh[2] = {shift0, shift1};
+    const double* sc[2] = {scale0, scale1};
+    const int* pw[2] = {powers0, powers1};
+    const double* cf[2] = {coeffs0 + p0, coeffs1 + p1};
+    for (int o = 0; o < 2; ++o) {
+        for (int i = 0; i < 2; ++i) { a.shift[o][i] = sh[o][i]; a.scale[o][i] = sc[o][i]; }
+        for (int j = 0; j < 3; ++j) {
+            a.poly[o][j] = cf[o][j];
+            for (int i = 0; i < 2; ++i) a.powers[o][j][i] = pw[o][2 * j + i];
+        }
+    }
+    a.n = n;
+    a.grid_w = (int)grid_w;
+    a.gx0 = gx0; a.gy0 = gy0; a.gsx = gsx; a.gsy = gsy;
+    a.out_scale[0] = out_scale0; a.out_scale[1] = out_scale1;
+    a.out = (double*)dout_;
+    hipLaunchKernelGGL(k_tps_pair, dim3((unsigned)((n + 255) / 256)), dim3(256), smem, d.st, a);
+    DXH_HIP(hipGetLastError());
+    pf.join();
+    if (!out_on_device) DXH_HIP(hipMemcpyAsync(out, dout_, sizeof(double) * 2 * (size_t)n, hipMemcpyDefault, d.st));
+    DXH_HIP(hipStreamSynchronize(d.st));  // also keeps `table` alive until its copy is done
     return DXH_OK;
 }
 

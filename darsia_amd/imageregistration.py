@@ -282,16 +282,17 @@ class DiffeomorphicImageRegistration:
     def displacement(self) -> np.ndarray:
         """Displacement in metric units on all pixels, shape (H*W, 2) (imageregistration.py:265-306).
         The two thin-plate splines are evaluated on the GPU over the pixel grid."""
-        from .registration import evaluate_rbf_on_grid
+        from .registration import evaluate_rbf_pair_on_grid
 
         ta = self.translation_analysis
         if ta.interpolator_translation_x is None:
             raise RuntimeError("no translation has been determined yet")
         ny, nx = ta.base.img.shape[:2]
-        tx = evaluate_rbf_on_grid(ta.interpolator_translation_x, (ny, nx)).reshape(-1)
-        ty = evaluate_rbf_on_grid(ta.interpolator_translation_y, (ny, nx)).reshape(-1)
-        displacement = np.transpose(np.vstack((ty, tx)))  # (row, col) order, as in the reference
-        return ta.base.coordinatesystem.coordinate_vector(displacement)
+        # the reference stacks (ty, tx) in (row, col) order and converts with coordinate_vector, which gives
+        # (x, y) = (tx * voxel width, -ty * voxel height): both factors are applied as the field is written
+        vs = ta.base.coordinatesystem.voxel_size
+        return evaluate_rbf_pair_on_grid(ta.interpolator_translation_x, ta.interpolator_translation_y, (ny, nx),
+                                         out_scale=(vs["x"], -vs["y"]))
 
 
 class MultiscaleDiffeomorphicImageRegistration:

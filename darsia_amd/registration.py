@@ -207,6 +207,23 @@ def evaluate_rbf_on_grid(rbf, shape, x0=0.0, y0=0.0, dx=1.0, dy=1.0) -> np.ndarr
     return out[..., 0] if squeeze else out
 
 
+def evaluate_rbf_pair_on_grid(rbf0, rbf1, shape, out_scale=(1.0, 1.0), x0=0.0, y0=0.0, dx=1.0, dy=1.0, out=None):
+    """Two scalar thin-plate splines at every pixel of an (H, W) grid in one pass over the union of their centres
+    (``dxh_tps_eval_pair``): returns (H*W, 2) float64 with columns ``out_scale[0] * rbf0``, ``out_scale[1] * rbf1``."""
+    p0, p1 = _rbf_params(rbf0), _rbf_params(rbf1)
+    if p0[5] != 1 or p1[5] != 1:
+        raise NotImplementedError("scalar-valued splines expected")
+    h, w = int(shape[0]), int(shape[1])
+    _lib.require_gpu()
+    if out is None:
+        out = np.empty((h * w, 2), np.float64)
+    _lib.check(_lib.load().dxh_tps_eval_pair(
+        _lib.default_device(), p0[0].shape[0], _lib.ptr(p0[0]), _lib.ptr(p0[1]), _lib.ptr(p0[2]), _lib.ptr(p0[3]), _lib.ptr(p0[4]),
+        p1[0].shape[0], _lib.ptr(p1[0]), _lib.ptr(p1[1]), _lib.ptr(p1[2]), _lib.ptr(p1[3]), _lib.ptr(p1[4]), h, w,
+        float(x0), float(y0), float(dx), float(dy), float(out_scale[0]), float(out_scale[1]), _lib.ptr(out)))
+    return out
+
+
 def _rbf_params(rbf):
     if getattr(rbf, "kernel", None) != "thin_plate_spline":
         raise NotImplementedError("only kernel='thin_plate_spline' (SciPy's and the reference's default)")

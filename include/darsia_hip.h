@@ -400,6 +400,18 @@ int dxh_warp_patches(int device, int H, int W, int C, const float* base, const d
 int dxh_tps_eval(int device, int p, int dout, const double* centers, const double* coeffs, const double* shift,
                  const double* scale, const int* powers, int64_t n, const double* points, int grid_w, double gx0,
                  double gy0, double gsx, double gsy, double* out);
+/*
+ * Two such splines with scalar values on the pixel grid at once -- the x and y translation maps of a
+ * TranslationAnalysis (translationanalysis.py:285-294) share their patch centres and differ in the boundary points -- as
+ * one pass over the union of their centres.  Point (col, row) = (gx0 + gsx * col, gy0 + gsy * row); coeffs0 / coeffs1 have
+ * p0 + 3 / p1 + 3 entries; out is (grid_h * grid_w, 2) float64 (host or device) and receives
+ * (out_scale0 * s0, out_scale1 * s1): with the voxel sizes (vx, -vy) that IS DiffeomorphicImageRegistration.displacement()
+ * (imageregistration.py:265-306) without any pass over the field on the host.
+ */
+int dxh_tps_eval_pair(int device, int p0, const double* centers0, const double* coeffs0, const double* shift0,
+                      const double* scale0, const int* powers0, int p1, const double* centers1, const double* coeffs1,
+                      const double* shift1, const double* scale1, const int* powers1, int64_t grid_h, int64_t grid_w,
+                      double gx0, double gy0, double gsx, double gsy, double out_scale0, double out_scale1, double* out);
 
 /*
  * out = img_as_float(img) @ A + b, optional clip to [0, 1], float32 -- AffineBalance.apply_balance and the

@@ -63,6 +63,39 @@ def test_thin_plate_spline_field_matches_scipy():
     np.testing.assert_allclose(dense.reshape(-1, 2), rxy(grid_pts), rtol=1e-10, atol=1e-10)
 
 
+def test_spline_pair_on_the_grid_matches_scipy_and_the_table_logarithm_is_accurate():
+    """dxh_tps_eval_pair: the x and y translation splines (shared patch centres, different boundary points) in one pass,
+    scaled per output; the kernel's table-based logarithm (dxh_dense.hip: tps_log) against NumPy's over 40 decades."""
+    from scipy.interpolate import RBFInterpolator
+
+    rng = np.random.default_rng(12)
+    h, w = 37, 53
+    common = rng.random((30, 2)) * np.array([w, h])
+    common[:5] = np.floor(common[:5])                                   # centres ON grid points: r = 0 there
+    bx = np.c_[np.r_[np.zeros(4), np.full(4, w)], np.tile(np.linspace(0, h, 4), 2)]
+    by = np.c_[np.linspace(0, w, 6), np.full(6, float(h))]
+    rx = RBFInterpolator(np.r_[common, bx], np.r_[rng.normal(size=30), np.zeros(8)])
+    ry = RBFInterpolator(np.r_[common, by], np.r_[rng.normal(size=30), np.zeros(6)])
+    from darsia_amd.registration import evaluate_rbf_pair_on_grid
+
+    yy, xx = np.mgrid[0:h, 0:w]
+    pts = np.c_[xx.ravel().astype(float), yy.ravel().astype(float)]
+    got = evaluate_rbf_pair_on_grid(rx, ry, (h, w), out_scale=(0.25, -0.5))
+    assert got.shape == (h * w, 2)
+    np.testing.assert_allclose(got[:, 0], 0.25 * rx(pts), rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(got[:, 1], -0.5 * ry(pts), rtol=1e-10, atol=1e-10)
+    # the logarithm alone: one centre at the origin with weight 1 and a zero polynomial -> out = 0.5 r^2 log(r^2)
+    one = RBFInterpolator(np.array([[0.0, 0.0], [1.0, 0.0], [0.0, 1.0], [1.0, 1.0]]), np.zeros(4))
+    one._coeffs = np.array([[1.0], [0.0], [0.0], [0.0], [0.0], [0.0], [0.0]])
+    for scale in (1e-20, 1e-9, 1e-3, 1.0, 7.3, 1e4, 1e12, 1e20):
+        n = 4096
+        out = da.evaluate_rbf_on_grid(one, (1, n), x0=scale, y0=0.0, dx=scale * 1.37e-3, dy=1.0)
+        x = scale + scale * 1.37e-3 * np.arange(n)
+        r2 = x * x
+        want = 0.5 * r2 * np.log(r2)
+        np.testing.assert_allclose(out.ravel(), want, rtol=4e-15, atol=1e-300 + 3e-16 * r2.max())
+
+
 @pytest.mark.parametrize("dtype", [np.uint8, np.uint16, np.float32, np.float64])
 def test_affine_colour_balance(dtype):
     rng = np.random.default_rng(8)
