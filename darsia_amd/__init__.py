@@ -8,7 +8,7 @@ gfx950); there is no CPU fallback.
 """
 from ._lib import HipError, device_count  # noqa: F401
 from .device import DeviceArray, trim_device_cache  # noqa: F401
-from .image import Image, OpticalImage, ScalarImage  # noqa: F401
+from .image import ExtensiveImage, Image, OpticalImage, ScalarImage  # noqa: F401
 from .geometry import (Coordinate, CoordinateArray, CoordinateSystem, Voxel, VoxelArray, full_like,  # noqa: F401
                        interpret_indexing, make_coordinate, make_voxel, ones_like, roi_to_mask,
                        to_cartesian_indexing, to_matrix_indexing, zeros_like)

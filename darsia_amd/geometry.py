@@ -135,6 +135,20 @@ class CoordinateSystem:
         self.max_coordinate = np.max(corners, axis=0)
         self.min_coordinate = np.min(corners, axis=0)
 
+    @property
+    def voxels(self):
+        """All voxels of the image, first index fastest (image/coordinatesystem.py:89-101)."""
+        if not hasattr(self, "_voxels"):
+            self._voxels = make_voxel(np.indices(self.shape, dtype=int).reshape((self.dim, -1), order="F").T)
+        return self._voxels
+
+    @property
+    def coordinates(self):
+        """Coordinates of all voxels (image/coordinatesystem.py:103-113)."""
+        if not hasattr(self, "_coordinates"):
+            self._coordinates = self.coordinate(self.voxels)
+        return self._coordinates
+
     def length(self, num, axis: str):
         assert axis in self.axes
         return num * self.voxel_size[axis]

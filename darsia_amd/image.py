@@ -94,6 +94,13 @@ class ScalarImage(Image):
         super().__init__(img, transformations, **kwargs)
 
 
+class ExtensiveImage(ScalarImage):
+    """Extensive quantity stored per voxel (image/image.py:2064-2078): resizing it conserves the sum by default
+    (restoration/resize.py:135-190)."""
+
+    extensive = True
+
+
 class OpticalImage(Image):
     """Photograph with a trailing colour axis (image/image.py:2081)."""
 

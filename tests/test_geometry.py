@@ -85,3 +85,34 @@ def test_indexing_helpers():
     assert da.make_voxel([[1, 2]], matrix_indexing=False).tolist() == [[2, 1]]
     with pytest.raises(ValueError):
         da.interpret_indexing("q", "ij")
+
+
+def test_unit_coordinate_system_known_answers():
+    """The known-answer values of the reference's tests/unit/test_coordinatesystem.py (a 3 x 4 image of unit dimensions):
+    attributes, voxel / coordinate lists, length, num_voxels, coordinate, voxel, coordinate_vector, for every input
+    container the reference's test feeds in."""
+    cs = da.Image(np.ones((3, 4), dtype=float), dimensions=[1, 1], space_dim=2).coordinatesystem
+    assert cs.dim == 2 and cs.shape == (3, 4) and cs.axes == "xy" and np.allclose(cs.dimensions, [1, 1])
+    assert np.allclose([cs.voxel_size["x"], cs.voxel_size["y"]], [1 / 4, 1 / 3])
+    assert np.allclose(cs._coordinate_of_origin_voxel, [0, 1]) and np.allclose(cs._coordinate_of_opposite_voxel, [1, 0])
+    assert np.allclose([cs.domain[k] for k in ("xmin", "xmax", "ymin", "ymax")], [0, 1, 0, 1])
+    assert np.allclose(cs.voxels, [[0, 0], [1, 0], [2, 0], [0, 1], [1, 1], [2, 1], [0, 2], [1, 2], [2, 2], [0, 3], [1, 3], [2, 3]])
+    assert np.allclose(cs.coordinates, [[0, 1], [0, 2 / 3], [0, 1 / 3], [1 / 4, 1], [1 / 4, 2 / 3], [1 / 4, 1 / 3],
+                                        [2 / 4, 1], [2 / 4, 2 / 3], [2 / 4, 1 / 3], [3 / 4, 1], [3 / 4, 2 / 3], [3 / 4, 1 / 3]])
+    assert all(np.isclose(cs.length(i, "x"), i / 4) for i in range(4)) and all(np.isclose(cs.length(i, "y"), i / 3) for i in range(3))
+    assert [int(cs.num_voxels(v, ax)) for v, ax in ((1, "x"), (1, "y"), (0.7, "x"), (0.6, "y"), (0.8, "x"), (0.7, "y"))] == [4, 3, 3, 2, 4, 3]
+    for voxel in (np.array([1, 2]), [1, 2], da.Voxel([1, 2])):
+        c = cs.coordinate(voxel)
+        assert isinstance(c, da.Coordinate) and np.allclose(c, [0.5, 2 / 3])
+    for voxels in (np.array([[1, 2], [2, 3]]), [[1, 2], [2, 3]], da.VoxelArray([[1, 2], [2, 3]])):
+        c = cs.coordinate(voxels)
+        assert isinstance(c, da.CoordinateArray) and np.allclose(c, [[0.5, 2 / 3], [0.75, 1 / 3]])
+    for coordinate in (np.array([0.5, 2 / 3]), [0.5, 2 / 3], da.Coordinate([0.5, 2 / 3])):
+        v = cs.voxel(coordinate)
+        assert isinstance(v, da.Voxel) and np.allclose(v, [1, 2])
+    pts = [[0.5, 2 / 3], [0.75, 1 / 3], [0.6, 0.9]]
+    for coordinates in (np.array(pts), pts, da.CoordinateArray(pts)):
+        v = cs.voxel(coordinates)
+        assert isinstance(v, da.VoxelArray) and np.allclose(v, [[1, 2], [2, 3], [0, 2]])
+    assert np.allclose(cs.coordinate_vector(np.array([1, 2])), [0.5, -1 / 3])
+    assert np.allclose(cs.coordinate_vector(np.array([[1, 2], [2, 2]])), [[0.5, -1 / 3], [0.5, -2 / 3]])

@@ -72,3 +72,22 @@ def test_full_size_downsample_for_tvd():
     out = rz.cv_resize(img, fx=0.5, fy=0.5, interpolation=rz.INTER_AREA)
     ref = ((img[0::2, 0::2] + img[0::2, 1::2]) + img[1::2, 0::2] + img[1::2, 1::2]) * np.float32(0.25)
     np.testing.assert_array_equal(out, ref)
+
+
+def test_reference_resize_unit_tests():
+    """tests/unit/test_resize.py of the reference, re-expressed: equalize_voxel_size (default and explicit voxel size)
+    keeps the dimensions and makes the voxels square; resizing an ExtensiveImage conserves its sum by default, through
+    the function and through the object."""
+    image = da.Image(np.ones((10, 10)), width=2, height=1, scalar=True)
+    assert not np.isclose(image.voxel_size[0], image.voxel_size[1])
+    for kwargs in ({}, {"voxel_size": 0.05}):
+        resized = da.equalize_voxel_size(image, **kwargs)
+        assert np.isclose(resized.voxel_size[0], resized.voxel_size[1])
+        assert np.allclose(image.dimensions, resized.dimensions)
+    ext = da.ExtensiveImage(np.arange(1, 17, dtype=float).reshape((4, 4)), dimensions=[1, 1], scalar=True)
+    for out in (da.resize(ext, shape=(2, 2)), da.Resize(shape=(2, 2))(ext)):
+        assert isinstance(out, da.ExtensiveImage) and out.img.shape == (2, 2)
+        assert np.isclose(np.sum(out.img), np.sum(ext.img))
+    # an explicit choice wins over the image type (restoration/resize.py:186-188)
+    plain = da.Resize(shape=(2, 2), **{"resize conservative": False})(ext)
+    assert np.isclose(np.sum(plain.img), np.sum(ext.img) / 4)
