@@ -64,6 +64,7 @@ class DeviceTVD:
         d = _lib.TvdDesc()
         d.struct_size = C.sizeof(_lib.TvdDesc)
         d.device = _lib.default_device() if device is None else device
+        self.device = int(d.device)
         d.dtype = _lib.dtype_code(self.dtype)
         d.ndim, d.dim, d.nsum = ndim, dim, nsum
         d.n0, d.n1, d.n2 = n0, n1, n2

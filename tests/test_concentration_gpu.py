@@ -107,3 +107,27 @@ def test_series_map_mixed_frames_and_early_exit():
     # frames the device path cannot fuse go one by one
     ca2 = da.ConcentrationAnalysis(base, da.MonochromaticReduction(color=lambda im: im[:, :, 1]), None, None, None)
     assert all(np.array_equal(g.img, ca2(f).img) for g, f in zip(ca2.map([a, b]), (a, b)))
+
+
+@pytest.mark.parametrize("restoration_first", [False, True])
+def test_default_tvd_restoration_runs_inside_the_fused_pipeline(restoration_first):
+    """restoration = TVD() (the reference's default method, chambolle) between the elementwise stages, everything on the
+    device: equal to the stage-by-stage chain -- NumPy stages of the checker around the device operator on a host
+    array -- and the series pipeline gives the same frames."""
+    base, probe = _frames(72, 100, 40)
+    tvd = da.TVD(weight=0.08, max_num_iter=30, eps=1e-4)
+    assert tvd.method == "chambolle"
+    model = da.CombinedModel([da.LinearModel(scaling=1.7, offset=0.02), da.ClipModel(min_value=0.0, max_value=1.0)])
+    ca = da.ConcentrationAnalysis(base, da.MonochromaticReduction(color="red+green"), None, tvd, model,
+                                  **{"diff option": "absolute", "restoration -> model": restoration_first})
+    assert ca._fusable(probe.img) is not None
+    out = ca(probe)
+    signal = OC.concentration(probe.img, base.img, "absolute", "red+green", None, [], None, False)   # reduce only
+    stages = [lambda x: 1.7 * x + 0.02, lambda x: np.clip(x, 0.0, 1.0)]
+    apply_model = lambda x: stages[1](stages[0](x))
+    want = apply_model(da.denoise_tv_chambolle(signal, weight=0.08, max_num_iter=30, eps=1e-4)) if restoration_first \
+        else da.denoise_tv_chambolle(apply_model(signal), weight=0.08, max_num_iter=30, eps=1e-4)
+    assert out.img.dtype == want.dtype and np.array_equal(out.img, want)
+    frames = [probe, _frames(72, 100, 41)[1], _frames(72, 100, 42)[1]]
+    series = list(ca.map(frames))
+    assert all(np.array_equal(s.img, ca(f).img) for s, f in zip(series, frames))

@@ -73,6 +73,8 @@ import time as _t
 _r = series(); del _r; _t0 = _t.perf_counter(); _r = series(); _dt = (_t.perf_counter() - _t0) * 1e3 / 8
 print(f"  ConcentrationAnalysis.map over 8 frames (upload of frame i+1 overlaps frame i): {_dt:.2f} ms/frame")
 del _r
+ca_ch = da.ConcentrationAnalysis(base_img, da.MonochromaticReduction(color="red"), None, da.TVD(), model, **{"diff option": "positive"})
+t("ConcentrationAnalysis.__call__ with the default TVD() (chambolle) inside the fused pipeline", lambda: ca_ch(probe_img))
 def host_chain():
     d = np.clip(probe_img.img - base_img.img, 0, None); s = d[:, :, 0]; m = np.clip(2.0 * s + 0.0, 0.0, 1.0)
     return m
