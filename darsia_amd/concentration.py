@@ -12,10 +12,11 @@ express on the device:
   "negative-key" (or no reduction for scalar frames);
 * cleaning: threshold filter;  balancing: none;
 * restoration: ``darsia_amd.TVD(method="heterogeneous bregman")`` (iterates inside the context), the default
-  ``darsia_amd.TVD()`` (chambolle; the operator runs on the device array between the two elementwise stages), or none;
+  ``darsia_amd.TVD()`` (chambolle) and the two scikit-image split-Bregman methods (the operator runs on the device array between the two
+  elementwise stages), or none;
 * model: ``ScalingModel``, ``LinearModel``, ``ClipModel`` or a ``CombinedModel`` of them.
 
-Anything else (callables, other reductions, the Gauss-Seidel methods ...) is applied stage by stage through
+Anything else (callables, other reductions, other restorations ...) is applied stage by stage through
 the objects' own ``__call__`` exactly as the reference does -- the device operators still do their part,
 only the array makes more trips.
 
@@ -276,8 +277,9 @@ class ConcentrationAnalysis:
             return None
         rest = self.restoration
         mode = None if rest is None else "hb"
-        if isinstance(rest, TVD) and rest.method == "chambolle" and not rest.kwargs:
-            # the default TVD(): runs on the device between the two elementwise stages (device array in, device array out)
+        if isinstance(rest, TVD) and rest.method in ("chambolle", "anisotropic bregman", "isotropic bregman") and not rest.kwargs:
+            # the default TVD() and scikit-image's split-Bregman methods: the operator runs on the device between the two
+            # elementwise stages (device array in, device array out)
             mode, solver, iso = "op", None, False
         elif rest is not None:
             if not (isinstance(rest, TVD) and rest.method == "heterogeneous bregman"):

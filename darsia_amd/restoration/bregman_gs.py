@@ -17,6 +17,7 @@ from typing import Optional
 import numpy as np
 
 from .. import _lib
+from ..device import DeviceArray
 
 
 def _img_as_float(image: np.ndarray) -> np.ndarray:
@@ -31,6 +32,20 @@ def _img_as_float(image: np.ndarray) -> np.ndarray:
 
 def denoise_tv_bregman(image: np.ndarray, weight: float = 5.0, max_num_iter: int = 100, eps: float = 1e-3,
                        isotropic: bool = True, *, channel_axis: Optional[int] = None, return_iters: bool = False):
+    if isinstance(image, DeviceArray):
+        # device in, device out (float images, no per-channel splitting: both are host work)
+        if image.dtype not in (np.float32, np.float64) or image.ndim not in (2, 3) or channel_axis is not None:
+            raise TypeError("a device-resident image must be float32 / float64 with 2 or 3 axes (channel_axis=None)")
+        _lib.require_gpu()
+        out = DeviceArray(image.shape, image.dtype, image.device)
+        done, rmse = C.c_int(0), C.c_double(0.0)
+        _lib.check(_lib.load().dxh_tv_bregman_gs(image.device, _lib.dtype_code(image.dtype), image.shape[0], image.shape[1],
+                                                  image.shape[2] if image.ndim == 3 else 1, _lib.ptr(image), _lib.ptr(out),
+                                                  float(weight), int(max_num_iter), float(eps), int(bool(isotropic)),
+                                                  C.byref(done), C.byref(rmse)))
+        if 1 in out.shape:
+            out = out.reshape(tuple(n for n in out.shape if n != 1) or (1,))   # as scikit-image: singleton axes go
+        return (out, done.value) if return_iters else out
     if not isinstance(image, np.ndarray):
         raise TypeError("image must be a numpy array")
     image = _img_as_float(image)

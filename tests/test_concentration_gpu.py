@@ -131,3 +131,21 @@ def test_default_tvd_restoration_runs_inside_the_fused_pipeline(restoration_firs
     frames = [probe, _frames(72, 100, 41)[1], _frames(72, 100, 42)[1]]
     series = list(ca.map(frames))
     assert all(np.array_equal(s.img, ca(f).img) for s, f in zip(series, frames))
+
+
+@pytest.mark.parametrize("method", ["anisotropic bregman", "isotropic bregman"])
+def test_gauss_seidel_restorations_stay_on_the_device(method):
+    """scikit-image's split-Bregman methods take and return device arrays (same bits as the host call), which lets
+    ConcentrationAnalysis keep the frame on the device around them."""
+    rng = np.random.default_rng(50)
+    sig = rng.random((60, 84)).astype(np.float32)
+    op = da.TVD(method=method, weight=0.4, max_num_iter=12, eps=1e-9)
+    want = op(sig)
+    dev = op(da.DeviceArray.from_host(sig))
+    assert isinstance(dev, da.DeviceArray) and np.array_equal(dev.get(), want)
+    base, probe = _frames(60, 84, 51)
+    ca = da.ConcentrationAnalysis(base, da.MonochromaticReduction(color="blue"), None, op, da.ClipModel(min_value=0.0),
+                                  **{"diff option": "plain"})
+    assert ca._fusable(probe.img) is not None
+    signal = OC.concentration(probe.img, base.img, "plain", "blue", None, [], None, False)
+    assert np.array_equal(ca(probe).img, op(np.clip(np.ascontiguousarray(signal), 0.0, None)))
