@@ -25,34 +25,47 @@ import numpy as np
 from . import _lib
 from .geometry import VoxelArray
 from .image import Image  # noqa: F401
+from .device import DeviceArray
 from .registration import _opencv_block_width, get_perspective_transform
 
 _MC_DTYPES = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.uint8): 2, np.dtype(np.uint16): 3}
 
 
-def map_coordinates(img: np.ndarray, grid: np.ndarray, order: int = 1, cval: float = 0.0) -> np.ndarray:
+def map_coordinates(img, grid, order: int = 1, cval: float = 0.0):
     """``scipy.ndimage.map_coordinates(img[..., c], grid, order=order)`` (mode "constant") for every channel of an
-    (H, W) or (H, W, C) array; returns (n,) or (n, C) in ``img``'s dtype."""
-    if not isinstance(img, np.ndarray) or img.ndim not in (2, 3):
+    (H, W) or (H, W, C) array; returns (n,) or (n, C) in ``img``'s dtype.  ``img`` may be a ``DeviceArray`` (the result is
+    one, too); ``grid`` is a (2, n) array of rows and columns or a pair of device arrays ``(rows, cols)`` -- a grid that
+    is used for many frames is best kept on the device."""
+    on_device = isinstance(img, DeviceArray)
+    if not (isinstance(img, np.ndarray) or on_device) or img.ndim not in (2, 3):
         raise ValueError("img must be an (H, W) or (H, W, C) array")
-    if img.dtype not in _MC_DTYPES:
+    if np.dtype(img.dtype) not in _MC_DTYPES:
         raise TypeError(f"dtype {img.dtype} not supported on the device (float32, float64, uint8, uint16)")
     if order not in (0, 1):
         raise NotImplementedError("interpolation orders 0 and 1 are available on the device")
-    grid = np.asarray(grid)
-    if grid.ndim != 2 or grid.shape[0] != 2:
-        raise ValueError("grid must have shape (2, n): rows, columns")
-    if grid.dtype not in (np.float32, np.float64):
-        grid = grid.astype(np.float64)
+    if isinstance(grid, (tuple, list)) and len(grid) == 2 and all(isinstance(g, DeviceArray) for g in grid):
+        rows, cols = grid
+        if rows.dtype != cols.dtype or rows.dtype not in (np.float32, np.float64) or rows.size != cols.size:
+            raise ValueError("device grids must be two float32 / float64 arrays of the same size")
+        coord_dtype = rows.dtype
+    else:
+        grid = np.asarray(grid)
+        if grid.ndim != 2 or grid.shape[0] != 2:
+            raise ValueError("grid must have shape (2, n): rows, columns")
+        if grid.dtype not in (np.float32, np.float64):
+            grid = grid.astype(np.float64)
+        rows, cols = np.ascontiguousarray(grid[0]), np.ascontiguousarray(grid[1])
+        coord_dtype = grid.dtype
     _lib.require_gpu()
-    src = np.ascontiguousarray(img)
-    rows, cols = np.ascontiguousarray(grid[0]), np.ascontiguousarray(grid[1])
+    src = img if on_device else np.ascontiguousarray(img)
     chans = 1 if src.ndim == 2 else src.shape[2]
-    n = rows.shape[0]
-    out = np.empty((n,) if src.ndim == 2 else (n, chans), src.dtype)
+    n = int(rows.size)
+    out_shape = (n,) if src.ndim == 2 else (n, chans)
+    out = DeviceArray(out_shape, src.dtype, src.device) if on_device else np.empty(out_shape, src.dtype)
     _lib.check(_lib.load().dxh_map_coordinates(
-        _lib.default_device(), _MC_DTYPES[src.dtype], src.shape[0], src.shape[1], chans, _lib.ptr(src),
-        0 if grid.dtype == np.float32 else 1, _lib.ptr(rows), _lib.ptr(cols), n, int(order), float(cval), _lib.ptr(out)))
+        src.device if on_device else _lib.default_device(), _MC_DTYPES[np.dtype(src.dtype)], src.shape[0], src.shape[1], chans,
+        _lib.ptr(src), 0 if coord_dtype == np.float32 else 1, _lib.ptr(rows), _lib.ptr(cols), n, int(order), float(cval),
+        _lib.ptr(out)))
     return out
 
 
@@ -124,6 +137,8 @@ class BaseCorrection(ABC):
     _pure = False
 
     def __call__(self, image, overwrite: bool = False):
+        if isinstance(image, DeviceArray):
+            return self.correct_array(image)   # a device-resident frame: the correction returns a new device array
         if isinstance(image, np.ndarray):
             return self.correct_array(image if (overwrite or self._pure) else image.copy())
         if hasattr(image, "img") and hasattr(image, "metadata"):
@@ -283,10 +298,27 @@ class CurvatureCorrection(BaseCorrection):
         Ymod += image_center[1]
         return Xmod, Ymod
 
-    def _transform_image(self, img: np.ndarray, grid: np.ndarray, shape) -> np.ndarray:
-        """curvature.py:921-957 -- all channels in one device gather."""
+    def _device_grid(self, grid: np.ndarray):
+        """The cached coordinate grid as a pair of device arrays, uploaded once per grid (256 MB for 4000 x 8000)."""
+        held = getattr(self, "_grid_dev", None)
+        if held is None or held[0] is not grid:
+            g = np.asarray(grid)
+            if g.dtype not in (np.float32, np.float64):
+                g = g.astype(np.float64)
+            self._grid_dev = (grid, DeviceArray.from_host(np.ascontiguousarray(g[0])), DeviceArray.from_host(np.ascontiguousarray(g[1])))
+        return self._grid_dev[1], self._grid_dev[2]
+
+    def _transform_image(self, img, grid: np.ndarray, shape):
+        """curvature.py:921-957 -- all channels in one device gather.  The object's cached grid stays on the device; a
+        ``DeviceArray`` image gives a ``DeviceArray`` result."""
+        dev_grid = self._device_grid(grid) if grid is self.cache.get("grid") else grid
+        if isinstance(img, DeviceArray):
+            img3 = img if img.ndim == 3 else img.reshape(*img.shape, 1)
+            out = map_coordinates(img3, dev_grid, order=self.interpolation_order)
+            out_shape = tuple(n for n in (*shape, img3.shape[2]) if n != 1) or (1,)
+            return out.reshape(out_shape)
         img3 = np.atleast_3d(img)
-        out = map_coordinates(np.ascontiguousarray(img3), grid, order=self.interpolation_order)
+        out = map_coordinates(np.ascontiguousarray(img3), dev_grid, order=self.interpolation_order)
         return np.squeeze(out.reshape(*shape, img3.shape[2]))
 
     def correct_metadata(self, metadata: dict = {}) -> dict:

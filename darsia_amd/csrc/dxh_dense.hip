@@ -759,13 +759,23 @@ int dxh_map_coordinates(int device, int dtype, int64_t H, int64_t W, int C, cons
               {rows, (size_t)(coord_dtype == 0 ? 4 : 8) * (size_t)n}, {cols, (size_t)(coord_dtype == 0 ? 4 : 8) * (size_t)n}});
     Dev d;
     DXH_HIP(cached_stream(device, &d.st));
+    // device-resident operands are used where they are (a cached coordinate grid is 2 x 4 B per output pixel: 256 MB for
+    // a 4000 x 8000 image, 5 ms over PCIe per call otherwise); host operands are staged
     void *dimg = nullptr, *dr = nullptr, *dc = nullptr, *dout_ = nullptr;
-    if ((rc = d.alloc(&dimg, esz * (size_t)H * W * C)) || (rc = d.alloc(&dr, csz * (size_t)n)) || (rc = d.alloc(&dc, csz * (size_t)n)) ||
-        (rc = d.alloc(&dout_, esz * (size_t)n * C)))
+    auto stage = [&](const void* src, size_t bytes, void** dev) -> int {
+        if (is_device_ptr(src)) { *dev = const_cast<void*>(src); return DXH_OK; }
+        int r = d.alloc(dev, bytes);
+        if (r) return r;
+        DXH_HIP(hipMemcpyAsync(*dev, src, bytes, hipMemcpyDefault, d.st));
+        return DXH_OK;
+    };
+    if ((rc = stage(img, esz * (size_t)H * W * C, &dimg)) || (rc = stage(rows, csz * (size_t)n, &dr)) ||
+        (rc = stage(cols, csz * (size_t)n, &dc)))
         return rc;
-    DXH_HIP(hipMemcpyAsync(dimg, img, esz * (size_t)H * W * C, hipMemcpyDefault, d.st));
-    DXH_HIP(hipMemcpyAsync(dr, rows, csz * (size_t)n, hipMemcpyDefault, d.st));
-    DXH_HIP(hipMemcpyAsync(dc, cols, csz * (size_t)n, hipMemcpyDefault, d.st));
+    const bool out_on_device = is_device_ptr(out);
+    DXH_REQUIRE(!(out_on_device && out == img), "a device-resident output must not be the input image");
+    if (out_on_device) dout_ = out;
+    else if ((rc = d.alloc(&dout_, esz * (size_t)n * C))) return rc;
     const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
 #define DXH_MC(T_, CT_) hipLaunchKernelGGL((k_map_coords<T_, CT_>), grid, blk, 0, d.st, (const T_*)dimg, (long long)H, (long long)W, C, \
                                            (const CT_*)dr, (const CT_*)dc, (long long)n, order, cval, (T_*)dout_)
@@ -779,7 +789,7 @@ int dxh_map_coordinates(int device, int dtype, int64_t H, int64_t W, int C, cons
 #undef DXH_MC
     DXH_HIP(hipGetLastError());
     pf.join();
-    DXH_HIP(hipMemcpyAsync(out, dout_, esz * (size_t)n * C, hipMemcpyDefault, d.st));
+    if (!out_on_device) DXH_HIP(hipMemcpyAsync(out, dout_, esz * (size_t)n * C, hipMemcpyDefault, d.st));
     DXH_HIP(hipStreamSynchronize(d.st));
     return DXH_OK;
 }

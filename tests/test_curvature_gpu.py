@@ -102,3 +102,27 @@ def test_full_size_gather_properties():
     out = da.map_coordinates(img, np.array([r.ravel(), c.ravel()])).reshape(100, 200, 3)
     ref = (img[:100, :200].astype(np.float64) * 0.5 + img[1:101, :200].astype(np.float64) * 0.5).astype(np.float32)
     np.testing.assert_array_equal(out, ref)
+
+
+def test_device_resident_frames_and_grid():
+    """A DeviceArray frame goes through the correction without leaving the device (same values as the host call); the
+    object's cached coordinate grid is uploaded once and re-used; map_coordinates takes device grids."""
+    img = synthetic_image(96, 128, 3)
+    config = {"bulge": dict(horizontal_bulge=5e-6, vertical_bulge=-3e-6), "stretch": dict(horizontal_stretch=2e-6)}
+    cc = da.CurvatureCorrection(config=config)
+    want = cc(img)
+    held = cc._grid_dev
+    dev = cc(da.DeviceArray.from_host(img))
+    assert isinstance(dev, da.DeviceArray) and dev.shape == want.shape and np.array_equal(dev.get(), want)
+    assert cc._grid_dev is held                                   # no second upload of the grid
+    gray = np.ascontiguousarray(img[..., 0])
+    assert np.array_equal(cc(da.DeviceArray.from_host(gray)).get(), cc(gray))
+    # chained: correction -> TV denoising, nothing in between on the host
+    out = da.split_bregman_tvd(cc(da.DeviceArray.from_host(img)), mu=0.1, max_num_iter=5)
+    assert np.array_equal(out.get(), da.split_bregman_tvd(want, mu=0.1, max_num_iter=5))
+    # explicit device grids
+    rng = np.random.default_rng(3)
+    grid = np.stack([rng.uniform(-1, 97, 777), rng.uniform(-1, 129, 777)]).astype(np.float32)
+    rows, cols = da.DeviceArray.from_host(grid[0]), da.DeviceArray.from_host(grid[1])
+    assert np.array_equal(da.map_coordinates(img, (rows, cols)), da.map_coordinates(img, grid))
+    assert np.array_equal(da.map_coordinates(da.DeviceArray.from_host(img), (rows, cols)).get(), da.map_coordinates(img, grid))
