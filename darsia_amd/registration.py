@@ -138,11 +138,28 @@ class PiecewisePerspectiveTransform:
         h, w = base.shape[:2]
         chans = 1 if base.ndim == 2 else 3
         records = []
-        for i in range(patches.num_patches[0]):
-            for j in range(patches.num_patches[1]):
+        # The displacement of all patch corners in ONE call of the map (a thin-plate-spline pair costs ~40 us per call
+        # and per spline whatever the number of points: 200 patches = 8 ms).  The map is pointwise, so the values are
+        # those of the reference's call per patch (piecewiseperspective.py:86-92); a callable that does not return
+        # (2, n) for the stacked points is asked patch by patch instead.
+        ni, nj = patches.num_patches[0], patches.num_patches[1]
+        all_gc = np.fliplr(np.asarray(patches.global_corners_voxels, dtype=np.float64).reshape(-1, 2))
+        try:
+            # in chunks of 1000 patches: darsia_amd's own spline pair evaluates larger point sets on the device, whose last
+            # bits differ from SciPy's -- the corners stay with the evaluation a call per patch would have used
+            parts = [np.asarray(displacement(all_gc[k:k + 4000])) for k in range(0, all_gc.shape[0], 4000)]
+            all_disp = np.concatenate(parts, axis=1) if all(p.ndim == 2 and p.shape[0] == 2 for p in parts) else None
+            if all_disp is not None and all_disp.shape != (2, all_gc.shape[0]):
+                all_disp = None
+        except Exception:  # noqa: BLE001 -- the per-patch calls below raise whatever the callable raises
+            all_disp = None
+        for i in range(ni):
+            for j in range(nj):
                 gc = np.fliplr(np.asarray(patches.global_corners_voxels[i, j], dtype=np.float64))
                 lc = np.fliplr(np.asarray(patches.local_corners_voxels[i, j], dtype=np.float64))
-                pts_dst = gc + (-1.0 if reverse else 1.0) * np.asarray(displacement(gc)).T
+                k = 4 * (i * nj + j)
+                disp = np.asarray(displacement(gc)) if all_disp is None else all_disp[:, k:k + 4]
+                pts_dst = gc + (-1.0 if reverse else 1.0) * disp.T
                 origin = np.array([max(0, np.min(pts_dst[:, 0])), max(0, np.min(pts_dst[:, 1]))]).astype(np.int32)
                 pts_dst_eff = pts_dst - origin
                 w_eff = ceil(min(w, np.max(pts_dst[:, 0])) - max(0, origin[0]))

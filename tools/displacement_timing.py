@@ -20,3 +20,7 @@ for _ in range(3):
     t0 = time.perf_counter(); d = reg.displacement(); dt = (time.perf_counter() - t0) * 1e3
     print("displacement() %.1f ms  shape %s  checksum %.6e" % (dt, d.shape, float(d[::100003].sum())), flush=True)
     del d
+for _ in range(3):
+    t0 = time.perf_counter(); w = reg.apply(img); dt = (time.perf_counter() - t0) * 1e3
+    print("apply() (translate_image: find_and_warp with the spline pair as displacement) %.1f ms" % dt, flush=True)
+    del w
