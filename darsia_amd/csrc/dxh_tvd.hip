@@ -2281,7 +2281,8 @@ int dxh_div3_probe(int device, float d0, float r0, float d1, float r1, unsigned*
 int dxh_jacobi_solve(int device, int dtype, int ndim, int dim, int nsum, int64_t n0, int64_t n1, int64_t n2,
                      const void* x0, const void* rhs, void* out, double mass, const void* mass_arr, double diffusion,
                      const void* diffusion_arr, double h, int maxiter, double tol, int* sweeps_done) {
-    DXH_REQUIRE(x0 && rhs && out, "null argument");
+    DXH_REQUIRE(x0 && out, "null argument");
+    DXH_REQUIRE(rhs || !mass_arr, "rhs = NULL (rhs = mass * x0) needs a scalar mass");
     DXH_REQUIRE(maxiter >= 0, "maxiter must be >= 0");
     DXH_REQUIRE(h > 0.0, "h must be positive");
     dxh_tvd_desc d{};
@@ -2300,7 +2301,7 @@ int dxh_jacobi_solve(int device, int dtype, int ndim, int dim, int nsum, int64_t
     HostPrefault pf;  // map the output pages while the device works
     {
         const size_t nb = (size_t)n0 * (size_t)n1 * (size_t)n2 * (dtype == DXH_F32 ? 4 : 8);
-        pf.start(out, nb, {{x0, nb}, {rhs, nb}});
+        pf.start(out, nb, {{x0, nb}, {rhs, rhs ? nb : 0}});
     }
     auto body = [&]() -> int {
         int r;
@@ -2310,7 +2311,19 @@ int dxh_jacobi_solve(int device, int dtype, int ndim, int dim, int nsum, int64_t
         if (r) return r;
         if ((r = alloc_plane(c, &c->rs))) return r;
         if ((r = h2d_plane(c, c->u[0], x0))) return r;
-        if ((r = h2d_plane(c, c->u[1], rhs))) return r;
+        if (rhs) {
+            if ((r = h2d_plane(c, c->u[1], rhs))) return r;
+        } else {
+            // H1 regularisation: rhs = omega * img (h1_regularization.py:73), the scalar rounded to the image dtype first
+            // as NumPy does for a Python float
+            if (dtype == DXH_F32)
+                hipLaunchKernelGGL((k_scale<float>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const float*)c->u[0],
+                                   (float)mass, (const float*)nullptr, (float*)c->u[1]);
+            else
+                hipLaunchKernelGGL((k_scale<double>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const double*)c->u[0],
+                                   mass, (const double*)nullptr, (double*)c->u[1]);
+            DXH_HIP(hipGetLastError());
+        }
         // rs = rhs / diag
         if (dtype == DXH_F32)
             hipLaunchKernelGGL((k_divide<float>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const float*)c->u[1],

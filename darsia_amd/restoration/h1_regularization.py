@@ -50,7 +50,9 @@ def _h1_array(img: np.ndarray, mu: float, omega: float, dim: int, solver: Solver
         nsum = _lib.NSUM_ALL_AXES
     else:
         raise ValueError(f"image with {img.ndim} axes and dim={dim} not supported")
-    rhs = np.ascontiguousarray(omega * src, dtype=img.dtype)
+    # omega * img: on the device when omega is a Python number (NumPy rounds it to the image dtype and multiplies there:
+    # the kernel does the same); any other scalar type goes through NumPy's own promotion on the host
+    rhs = None if type(omega) in (float, int) else np.ascontiguousarray(omega * src, dtype=img.dtype)
     out = np.empty(src.shape, src.dtype)
     done = C.c_int(0)
     _lib.check(_lib.load().dxh_jacobi_solve(

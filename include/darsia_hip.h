@@ -289,7 +289,8 @@ int dxh_rcp_probe(int device, unsigned long long* mismatches, unsigned long long
 /*
  * One-shot Jacobi solve  mass * x - diffusion * laplace(x) = rhs  (jacobi.py:74-133),
  * used by Jacobi.__call__ and H1_regularization (h1_regularization.py:54-70).
- * x0, rhs, out: host arrays of shape (n0, n1, n2).  Returns the iterate count in
+ * x0, rhs, out: arrays of shape (n0, n1, n2); rhs = NULL stands for rhs = mass * x0 computed on the device (scalar
+ * mass; H1 regularisation's right-hand side, h1_regularization.py:73).  Returns the iterate count in
  * *sweeps_done (with tol the reference returns the iterate BEFORE the one that
  * met the tolerance; kept).
  */

@@ -92,6 +92,7 @@ print("dim = 3 volume 256^3 float32 (device loop)")
 vol = np.random.default_rng(0).random((256, 256, 256)).astype(np.float32)
 st = da.DeviceTVD(vol.shape, vol.dtype, dim=3); st.set_coeffs(0.1, 1.0, None, vol); st.upload(vol); ms = loop_ms(st, 40)
 print(f"  fused 3-D sweep: {ms:.4f} ms/iter  {vol.size/ms/1e6:.1f} GVox/s"); st.close()
+t("H1_regularization(rgb, mu=0.1, Jacobi(maxiter=20))  [PCIe-inclusive]", lambda: da.H1_regularization(rgb, mu=0.1, omega=1.0, solver=da.Jacobi(maxiter=20)))
 print("Resize / CurvatureCorrection")
 t("Resize(fx=fy=0.5, inter_area)(rgb)  [PCIe-inclusive]", lambda: da.Resize(fx=0.5, fy=0.5, interpolation="inter_area")(rgb))
 t("Resize(shape=(3000, 6000), inter_linear)(rgb)  [PCIe-inclusive]", lambda: da.Resize(shape=(3000, 6000), interpolation="inter_linear")(rgb))
