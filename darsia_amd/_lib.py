@@ -34,7 +34,7 @@ EXPORTS = (
     "dxh_tvd_energy", "dxh_tvd_adapt_ell", "dxh_tvd_set_base", "dxh_tvd_set_cleaning_filter", "dxh_tvd_upload_signal", "dxh_tvd_download_model",
     "dxh_comm_unique_id", "dxh_comm_create_rccl", "dxh_comm_create_host", "dxh_comm_destroy", "dxh_comm_allreduce",
     "dxh_comm_barrier", "dxh_comm_info", "dxh_tvd_attach_comm", "dxh_tvd_exchange", "dxh_tvd_run_slab",
-    "dxh_mem_alloc", "dxh_mem_free", "dxh_mem_copy", "dxh_sqrt_probe", "dxh_rcp_probe", "dxh_tvd_solve_banded", "dxh_mem_trim", "dxh_tps_eval_pair",
+    "dxh_mem_alloc", "dxh_mem_free", "dxh_mem_copy", "dxh_sqrt_probe", "dxh_rcp_probe", "dxh_tvd_solve_banded", "dxh_mem_trim", "dxh_tps_eval_pair", "dxh_tvd_set_coeffs_typed",
 )
 
 # host-staged transport callbacks (include/darsia_hip.h: dxh_comm_exchange_fn, dxh_comm_allreduce_fn)
@@ -112,6 +112,7 @@ def _declare(lib):
     lib.dxh_tvd_create.argtypes = [C.POINTER(vp), C.POINTER(TvdDesc)]
     lib.dxh_tvd_destroy.argtypes = [vp]
     lib.dxh_tvd_set_coeffs.argtypes = [vp, dbl, vp, dbl, vp, i, dbl, vp]
+    lib.dxh_tvd_set_coeffs_typed.argtypes = [vp, dbl, vp, i, dbl, vp, i, i, dbl, vp, i]
     lib.dxh_tvd_upload.argtypes = [vp, vp, vp, vp, vp]
     lib.dxh_tvd_run.argtypes = [vp, i, i, dbl, dbl, dbl, C.c_uint32, C.POINTER(TvdResult)]
     lib.dxh_tvd_download.argtypes = [vp, vp, vp, vp]

@@ -1330,6 +1330,13 @@ static int set_coeffs_t(Ctx* c, double mu, const void* mu_arr, double omega, con
 
 using namespace dxh;
 
+// dense array conversion between the two float types (round to nearest, as ndarray.astype)
+template <typename TS, typename TD>
+__global__ void __launch_bounds__(256) k_convert_dense(const TS* __restrict__ src, TD* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = (TD)src[i];
+}
+
 extern "C" {
 
 const char* dxh_last_error(void) { return g_err.c_str(); }
@@ -1490,6 +1497,38 @@ int dxh_tvd_set_coeffs(dxh_tvd_t h, double mu, const void* mu_arr, double omega,
     c->uploaded = false;  // omega*img must be rebuilt
     c->omega_s = omega_arr ? std::numeric_limits<double>::quiet_NaN() : omega;
     return DXH_OK;
+}
+
+int dxh_tvd_set_coeffs_typed(dxh_tvd_t h, double mu, const void* mu_arr, int mu_dtype, double omega, const void* omega_arr,
+                             int omega_dtype, int has_ell, double ell, const void* ell_arr, int ell_dtype) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    DXH_REQUIRE(c, "null context");
+    int rc = set_device(c);
+    if (rc) return rc;
+    const size_t n = (size_t)c->g.n0 * (size_t)c->g.L;
+    DevTmp raw[3], conv[3];
+    const void* arrs[3] = {mu_arr, omega_arr, ell_arr};
+    const int dts[3] = {mu_dtype, omega_dtype, ell_dtype};
+    for (int k = 0; k < 3; ++k) {
+        if (!arrs[k] || dts[k] == c->desc.dtype) continue;
+        DXH_REQUIRE(dts[k] == DXH_F32 || dts[k] == DXH_F64, "coefficient arrays must be float32 or float64");
+        const size_t ssz = dts[k] == DXH_F32 ? 4 : 8;
+        const void* src = arrs[k];
+        if (!is_device_ptr(src)) {
+            DXH_HIP(hipMalloc(&raw[k].p, n * ssz));
+            DXH_HIP(hipMemcpyAsync(raw[k].p, src, n * ssz, hipMemcpyDefault, c->stream));
+            src = raw[k].p;
+        }
+        DXH_HIP(hipMalloc(&conv[k].p, n * c->esz));
+        const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
+        if (dts[k] == DXH_F64) hipLaunchKernelGGL((k_convert_dense<double, float>), grid, blk, 0, c->stream, (const double*)src, (float*)conv[k].p, n);
+        else hipLaunchKernelGGL((k_convert_dense<float, double>), grid, blk, 0, c->stream, (const float*)src, (double*)conv[k].p, n);
+        DXH_HIP(hipGetLastError());
+        arrs[k] = conv[k].p;
+    }
+    rc = dxh_tvd_set_coeffs(h, mu, arrs[0], omega, arrs[1], has_ell, ell, arrs[2]);
+    (void)hipStreamSynchronize(c->stream);   // the temporaries go out of scope
+    return rc;
 }
 
 // common tail of the two upload paths: the image is in u[0]; builds ||img||^2, of = omega*img, zeroes the state

@@ -33,7 +33,9 @@ from ..utils.linear_solvers.mg import MG
 from ..utils.linear_solvers.solver import Solver
 
 
-def _coef(value, img, name: str):
+def _coef(value, img, name: str, keep_float_type: bool = False):
+    """(scalar, array or None).  ``keep_float_type``: a float32 / float64 array stays in its own type -- the library
+    converts it on the device (``dxh_tvd_set_coeffs_typed``) instead of a host pass over it."""
     if isinstance(value, DeviceArray):
         if value.shape != tuple(img.shape) or value.dtype != img.dtype:
             raise ValueError(f"a device-resident {name} must have the image's shape and dtype")
@@ -43,6 +45,8 @@ def _coef(value, img, name: str):
             arr = np.broadcast_to(value, img.shape)
         except ValueError as e:
             raise ValueError(f"{name} is not broadcastable to the image shape {img.shape}") from e
+        if keep_float_type and arr.dtype in (np.float32, np.float64):
+            return 0.0, np.ascontiguousarray(arr)
         return 0.0, np.ascontiguousarray(arr, dtype=img.dtype)
     return float(value), None
 
@@ -87,15 +91,16 @@ class DeviceTVD:
         self.close()
 
     def set_coeffs(self, mu, omega, ell, like: np.ndarray):
-        mu_s, mu_a = _coef(mu, like, "mu")
-        om_s, om_a = _coef(omega, like, "omega")
+        mu_s, mu_a = _coef(mu, like, "mu", True)
+        om_s, om_a = _coef(omega, like, "omega", True)
         if ell is None:
             has_ell, ell_s, ell_a = 0, 0.0, None
         else:
-            ell_s, ell_a = _coef(ell, like, "ell")
+            ell_s, ell_a = _coef(ell, like, "ell", True)
             has_ell = 1
-        _lib.check(self.lib.dxh_tvd_set_coeffs(self._h, mu_s, _lib.ptr(mu_a), om_s, _lib.ptr(om_a), has_ell, ell_s,
-                                                _lib.ptr(ell_a)))
+        code = lambda a: _lib.dtype_code(self.dtype if a is None else a.dtype)
+        _lib.check(self.lib.dxh_tvd_set_coeffs_typed(self._h, mu_s, _lib.ptr(mu_a), code(mu_a), om_s, _lib.ptr(om_a),
+                                                      code(om_a), has_ell, ell_s, _lib.ptr(ell_a), code(ell_a)))
 
     def upload(self, img, u0=None, d0=None, b0=None):
         def c(a):

@@ -111,6 +111,13 @@ int dxh_tvd_destroy(dxh_tvd_t ctx);
  */
 int dxh_tvd_set_coeffs(dxh_tvd_t ctx, double mu, const void* mu_arr, double omega, const void* omega_arr,
                        int has_ell, double ell, const void* ell_arr);
+/*
+ * The same with coefficient arrays of either float type (DXH_F32 / DXH_F64 per array): an array whose type is not the
+ * image's is converted on the device (round to nearest, like ndarray.astype) -- a float64 porosity map as the weight of a
+ * float32 image (presets/workflows/restoration.py:118-140) costs a 2x larger upload instead of a pass over it on the host.
+ */
+int dxh_tvd_set_coeffs_typed(dxh_tvd_t ctx, double mu, const void* mu_arr, int mu_dtype, double omega, const void* omega_arr,
+                             int omega_dtype, int has_ell, double ell, const void* ell_arr, int ell_dtype);
 
 /*
  * Upload the image (split_bregman_tvd.py:99) and, optionally, a warm start

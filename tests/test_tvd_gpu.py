@@ -849,3 +849,24 @@ def test_operator_built_from_a_workflow_configuration_runs_the_heterogeneous_pip
     got = op(img)
     want = O.split_bregman_tvd(img, mu=porosity * inside, omega=1.5, ell=0.4, max_num_iter=9, eps=1e-12, promotion="strict")
     assert got.dtype == np.float64 and np.array_equal(got, want)
+
+
+def test_coefficient_arrays_of_the_other_float_type_are_converted_on_the_device():
+    """A float64 weight map with a float32 image (the workflow's porosity weights) and the reverse: same result as
+    converting the map with ndarray.astype first; omega and ell arrays too; broadcastable shapes still work."""
+    rng = np.random.default_rng(31)
+    img = rng.random((70, 90, 3)).astype(np.float32)
+    mu64 = 0.05 + 0.1 * rng.random(img.shape)
+    om64 = 0.5 + rng.random(img.shape)
+    ell64 = 0.1 + 0.3 * rng.random(img.shape)
+    got = da.split_bregman_tvd(img, mu=mu64, omega=om64, ell=ell64, max_num_iter=6)
+    want = da.split_bregman_tvd(img, mu=mu64.astype(np.float32), omega=om64.astype(np.float32), ell=ell64.astype(np.float32), max_num_iter=6)
+    assert got.dtype == np.float32 and np.array_equal(got, want)
+    img64 = img.astype(np.float64)
+    mu32 = mu64.astype(np.float32)
+    assert np.array_equal(da.split_bregman_tvd(img64, mu=mu32, max_num_iter=5),
+                          da.split_bregman_tvd(img64, mu=mu32.astype(np.float64), max_num_iter=5))
+    gray = np.ascontiguousarray(img[..., 0])
+    col = (0.05 + 0.1 * rng.random((1, 90)))                     # float64, broadcast along the rows
+    assert np.array_equal(da.split_bregman_tvd(gray, mu=col, max_num_iter=5),
+                          da.split_bregman_tvd(gray, mu=np.broadcast_to(col, gray.shape).astype(np.float32), max_num_iter=5))
