@@ -149,3 +149,25 @@ def test_gauss_seidel_restorations_stay_on_the_device(method):
     assert ca._fusable(probe.img) is not None
     signal = OC.concentration(probe.img, base.img, "plain", "blue", None, [], None, False)
     assert np.array_equal(ca(probe).img, op(np.clip(np.ascontiguousarray(signal), 0.0, None)))
+
+
+def test_weight_map_stays_in_the_context_between_frames_and_edits_are_noticed():
+    """Heterogeneous TVD with a porosity-like weight map inside the fused pipeline: the coefficients are set once per
+    context, a map edited in place (or replaced) is uploaded again."""
+    base, probe = _frames(64, 96, 60)
+    rng = np.random.default_rng(61)
+    weight = 0.02 + 0.1 * rng.random((64, 96))
+    tvd = da.TVD(method="heterogeneous bregman", weight=weight, omega=1.0, regularization=0.3, max_num_iter=7, eps=None)
+    ca = da.ConcentrationAnalysis(base, da.MonochromaticReduction(color="green"), None, tvd, None, **{"diff option": "positive"})
+
+    def reference(w):
+        sig = OC.concentration(probe.img, base.img, "positive", "green", None, [], None, False)
+        return da.split_bregman_tvd(np.ascontiguousarray(sig), mu=w.astype(np.float32), omega=1.0, ell=0.3, max_num_iter=7)
+
+    first = ca(probe).img
+    assert np.array_equal(first, reference(weight))
+    assert np.array_equal(ca(probe).img, first)                  # second frame: coefficients already in the context
+    weight[10:40, 20:70] *= 3.0                                  # in-place edit of the map the operator holds
+    assert np.array_equal(ca(probe).img, reference(weight))
+    tvd.weight = 0.5 * weight                                    # another map
+    assert np.array_equal(ca(probe).img, reference(0.5 * weight))
