@@ -85,6 +85,100 @@ class Image:
         """Deep copy (image/image.py:363-370)."""
         return _copy.deepcopy(self)
 
+    # ---- type changes (image/image.py:461-521) ---------------------------------------------------------------
+    def astype(self, data_type):
+        """A copy with the pixel array cast to a scalar type, or re-wrapped as another Image class."""
+        if data_type in (int, float, np.uint8, np.uint16, np.float16, np.float32, np.float64, bool):
+            out = self.copy()
+            out.img = out.img.astype(data_type)
+            return out
+        return data_type(img=self.img.copy(), **self.metadata())
+
+    def img_as(self, data_type):
+        """A copy with the pixel array converted the scikit-image way (range-aware: uint8 <-> [0, 1] floats ...);
+        the conversions of this path -- float, float32, float64, uint8, uint16 -- follow ``darsia_amd.utils.dtype``."""
+        from .utils.dtype import convert_dtype
+
+        out = self.copy()
+        if data_type in (float, np.float64):
+            out.img = convert_dtype(out.img, np.float64) if out.img.dtype.kind != "f" or data_type is np.float64 else out.img
+        elif data_type is np.float32:
+            out.img = convert_dtype(out.img, np.float32)
+        elif data_type is np.uint8:
+            out.img = convert_dtype(np.clip(out.img, -1, 1) if out.img.dtype.kind == "f" else out.img, np.uint8)
+        elif data_type is np.uint16:
+            out.img = convert_dtype(out.img, np.uint16)
+        else:
+            raise NotImplementedError
+        return out
+
+    # ---- extraction (image/image.py:665-746) -----------------------------------------------------------------
+    def subregion(self, roi):
+        """The image restricted to a box: a tuple of slices (voxels), a ``VoxelArray`` or a ``CoordinateArray`` of points
+        spanning the box; dimensions and origin of the result describe the cut-out."""
+        from .geometry import CoordinateArray, VoxelArray, interpret_indexing as _interp
+
+        if isinstance(roi, CoordinateArray):
+            box = self.coordinatesystem.voxel(roi)
+        elif isinstance(roi, VoxelArray):
+            box = roi
+        elif isinstance(roi, tuple):
+            box = None
+        else:
+            raise ValueError(f"roi is of type {type(roi)}, but needs to be tuple of slices, VoxelArray, or CoordinateArray.")
+        voxels = roi if box is None else tuple(
+            slice(max(0, int(np.min(box[:, d]))), min(int(np.max(box[:, d])), self.num_voxels[d])) for d in range(self.space_dim))
+        assert len(voxels) == self.space_dim
+        cs = self.coordinatesystem
+        origin = cs.coordinate([0 if sl.start is None else sl.start for sl in voxels])
+        opposite = cs.coordinate([self.num_voxels[i] if sl.stop is None else sl.stop for i, sl in enumerate(voxels)])
+        extent = np.absolute(np.asarray(opposite) - np.asarray(origin))
+        dimensions = [extent[_interp("ijk"[k], "xyz"[: self.space_dim])[0]] for k in range(self.space_dim)]
+        meta = self.metadata()
+        meta["dimensions"] = dimensions
+        meta["origin"] = origin
+        return type(self)(self.img[voxels], **meta)
+
+    # ---- arithmetic and comparisons (image/image.py:927-1058) -----------------------------------------------
+    def __add__(self, other):
+        if self.img.shape != other.img.shape:
+            raise ValueError("Images have different shapes.")
+        return type(self)(self.img + other.img, **self.metadata())
+
+    def __sub__(self, other):
+        if self.img.shape != other.img.shape:
+            raise ValueError("Images have different shapes.")
+        return type(self)(self.img - other.img, **self.metadata())
+
+    def __mul__(self, weight):
+        if not isinstance(weight, (float, int, np.ndarray)):
+            raise ValueError
+        return type(self)(self.img * weight, **self.metadata())
+
+    __rmul__ = __mul__
+
+    def _compare(self, other, op):
+        result = ScalarImage(np.zeros(self.num_voxels, dtype=bool), **{k: v for k, v in self.metadata().items() if k != "scalar"})
+        result.img = op(self.img, other.img if isinstance(other, Image) else other)
+        return result
+
+    def __lt__(self, other):
+        return self._compare(other, np.less)
+
+    def __gt__(self, other):
+        return self._compare(other, np.greater)
+
+    def __le__(self, other):
+        return self._compare(other, np.less_equal)
+
+    def __ge__(self, other):
+        return self._compare(other, np.greater_equal)
+
+    def __eq__(self, other):
+        return self._compare(other, np.equal)
+
+    __hash__ = object.__hash__   # comparisons are elementwise; identity hashing keeps images usable as dict keys
+
 
 class ScalarImage(Image):
     """Single-channel image (image/image.py:1860)."""

@@ -84,3 +84,43 @@ def test_correction_protocol_and_transformations_at_construction():
     assert np.array_equal(built.img, np.full((2, 2), 10.0)) and built.name == "done"
     with pytest.raises(TypeError):
         twice([1, 2, 3])
+
+
+def test_image_api_surface_subregion_types_arithmetic():
+    """The thin Image container's part of the reference API (image/image.py:461-521, 665-746, 927-1058): values worked
+    out by hand for a 6 x 8 image of 3 x 4 length units (voxel 0.5, origin (0, 3))."""
+    import darsia_amd as da
+
+    im = da.Image(np.arange(48.0).reshape(6, 8), dimensions=[3.0, 4.0], name="full")
+    for roi in ((slice(1, 4), slice(2, 6)), da.VoxelArray([[1, 2], [4, 6]]), da.CoordinateArray([[1.0, 2.5], [3.0, 1.0]])):
+        sub = im.subregion(roi)
+        assert type(sub) is da.Image and np.array_equal(sub.img, im.img[1:4, 2:6]) and sub.name == "full"
+        assert np.allclose(sub.dimensions, [1.5, 2.0]) and np.allclose(sub.origin, [1.0, 2.5])
+        assert np.allclose(sub.coordinatesystem.coordinate([0, 0]), im.coordinatesystem.coordinate([1, 2]))
+    open_ended = im.subregion((slice(None, 2), slice(5, None)))
+    assert open_ended.img.shape == (2, 3) and np.allclose(open_ended.dimensions, [1.0, 1.5]) and np.allclose(open_ended.origin, [2.5, 3.0])
+    with pytest.raises(ValueError):
+        im.subregion([1, 2])
+    # type changes
+    assert im.astype(np.float32).img.dtype == np.float32 and im.img.dtype == np.float64
+    as_scalar = im.astype(da.ScalarImage)
+    assert isinstance(as_scalar, da.ScalarImage) and as_scalar.scalar and as_scalar.img is not im.img
+    u8 = da.Image((np.arange(12).reshape(3, 4) * 20).astype(np.uint8))
+    assert np.allclose(u8.img_as(float).img, u8.img / 255.0) and u8.img_as(np.float32).img.dtype == np.float32
+    assert np.array_equal(da.Image(np.array([[0.5, 2.0, -3.0]])).img_as(np.uint8).img, [[128, 255, 0]])   # clipped to [-1, 1] first
+    assert np.array_equal(u8.img_as(np.uint16).img, u8.img.astype(np.uint16) * 257)
+    with pytest.raises(NotImplementedError):
+        u8.img_as(complex)
+    # arithmetic keeps type and metadata, comparisons give boolean scalar images
+    two = im * 2
+    assert type(two) is da.Image and two.dimensions == [3.0, 4.0] and np.array_equal(two.img, 2 * im.img)
+    assert np.array_equal((3 * im).img, 3 * im.img) and np.array_equal((im + two).img, 3 * im.img)
+    assert np.array_equal((two - im).img, im.img)
+    with pytest.raises(ValueError):
+        im + da.Image(np.zeros((2, 2)))
+    with pytest.raises(ValueError):
+        im * "2"
+    small = im < 5
+    assert isinstance(small, da.ScalarImage) and small.img.dtype == bool and small.img.sum() == 5
+    assert (im >= two).img.sum() == 1 and (im == 3).img.sum() == 1 and (im > two).img.sum() == 0 and (im <= 47).img.all()
+    assert isinstance(hash(im), int)
