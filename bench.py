@@ -198,8 +198,31 @@ def main():
         elapsed = comm.allreduce([elapsed], "max")[0]
         kernel_ms, launches = None, None
         comm_info = comm.info()
+        # Outside the timed region: every rank replays ALL iterations on the WHOLE image alone, on its own GPU, and
+        # compares its own rows of the distributed result with that replay, bit for bit -- the slab decomposition, the
+        # halo exchange over RCCL and the overlap must not change a single value.
+        self_check = None
+        if not a.no_self_check:
+            from darsia_amd.restoration.split_bregman_tvd import DeviceTVD
+
+            n_total = a.iters * (a.warmup + a.steps)
+            mine = s.owned_result()
+            whole = synthetic_image(total_rows, W, C)
+            st = DeviceTVD(whole.shape, whole.dtype, dim=2, device=device)
+            st.set_coeffs(mu, 1.0, None, whole)
+            st.upload(whole)
+            del whole
+            st.run(n_total)
+            replay = st.download()[plan.own0:plan.own1]
+            st.close()
+            same = bool(np.array_equal(mine, replay))
+            n_same = int(round(comm.allreduce([1.0 if same else 0.0], "sum")[0]))
+            self_check = {"iterations": n_total, "ranks_bit_identical_to_single_gpu_replay": n_same, "ranks": world}
+            del mine, replay
         s.close()
         comm.close()
+        if self_check is not None and self_check["ranks_bit_identical_to_single_gpu_replay"] != world:
+            raise SystemExit(f"bench self-check failed: {self_check}")
 
     if rank == 0:
         pix_iters = float(total_rows) * W * a.iters * a.steps
@@ -271,6 +294,8 @@ def main():
                 out["self_check"] = self_check
             if not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(C, a.cpu_sample)
+        elif self_check:
+            out["self_check"] = self_check
         print(json.dumps(out), flush=True)
 
 
