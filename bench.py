@@ -216,13 +216,19 @@ def main():
             replay = st.download()[plan.own0:plan.own1]
             st.close()
             same = bool(np.array_equal(mine, replay))
+            worst = 0.0 if same else float(np.max(np.abs(mine.astype(np.float64) - replay)))
             n_same = int(round(comm.allreduce([1.0 if same else 0.0], "sum")[0]))
-            self_check = {"iterations": n_total, "ranks_bit_identical_to_single_gpu_replay": n_same, "ranks": world}
+            worst = comm.allreduce([worst], "max")[0]
+            self_check = {"iterations": n_total, "ranks_bit_identical_to_single_gpu_replay": n_same, "ranks": world,
+                          "max_abs_difference": worst}
+            if not same:
+                print(f"[bench] rank {rank}: rows {plan.own0}..{plan.own1} differ from the single-GPU replay "
+                      f"(max abs {worst:.3e})", file=sys.stderr, flush=True)
             del mine, replay
         s.close()
         comm.close()
-        if self_check is not None and self_check["ranks_bit_identical_to_single_gpu_replay"] != world:
-            raise SystemExit(f"bench self-check failed: {self_check}")
+        # a mismatch does not abort: the line is printed with the failed check in it (and says so in "data"), so that the
+        # record shows what happened on hardware this builder never sees
 
     if rank == 0:
         pix_iters = float(total_rows) * W * a.iters * a.steps
@@ -296,6 +302,8 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(C, a.cpu_sample)
         elif self_check:
             out["self_check"] = self_check
+            if self_check["ranks_bit_identical_to_single_gpu_replay"] != world:
+                out["data"] += " -- SELF-CHECK FAILED: the distributed result differs from the single-GPU replay, this number is not valid"
         print(json.dumps(out), flush=True)
 
 
