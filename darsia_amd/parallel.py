@@ -328,7 +328,19 @@ def init_from_env(device: Optional[int] = None, rehearsal_base_port: Optional[in
     if rehearsal_base_port is not None:
         dev = local_rank % max(1, _lib.device_count()) if device is None else device
         return Comm.host(SocketTransport(rank, world, rehearsal_base_port), dev), rank, world, dev
-    dev = local_rank if device is None else device
+    if device is None:
+        ndev = _lib.device_count()
+        masked = any(os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+        if local_rank < ndev:
+            dev = local_rank
+        elif ndev == 1 and masked:
+            dev = 0          # the launcher handed every rank its own GPU through a visibility mask
+        else:
+            raise _lib.HipError(f"rank {rank}: LOCAL_RANK {local_rank} but {ndev} visible GPU(s) -- one process per GPU is "
+                                "needed for RCCL (rehearse on fewer GPUs with the host-staged transport: "
+                                "DXH_BENCH_REHEARSAL=1 / init_from_env(rehearsal_base_port=...))")
+    else:
+        dev = device
     return Comm.rccl(rank, world, dev), rank, world, dev
 
 
