@@ -466,7 +466,11 @@ class ConcentrationAnalysis:
     def __call__(self, img):
         """Extract the concentration from a probing image (concentrationanalysis.py:230-310)."""
         if img.img.dtype not in (np.float32, np.float64):
-            raise TypeError("the probing image must be float32/float64 (convert before, e.g. img / 255.)")
+            # concentrationanalysis.py:241-246: converted the scikit-image way (uint8 / 255 ... as float64), with a warning
+            if img.img.dtype not in (np.uint8, np.uint16) or not hasattr(img, "img_as"):
+                raise TypeError("the probing image must be float32 / float64 (or uint8 / uint16, which are converted)")
+            warn("The input for concentration analysis needed to be converted to float.")
+            img = img.img_as(float)
         probe = img.img
         plan = self._fusable(probe)
         if plan is not None:

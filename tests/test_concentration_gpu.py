@@ -171,3 +171,16 @@ def test_weight_map_stays_in_the_context_between_frames_and_edits_are_noticed():
     assert np.array_equal(ca(probe).img, reference(weight))
     tvd.weight = 0.5 * weight                                    # another map
     assert np.array_equal(ca(probe).img, reference(0.5 * weight))
+
+
+def test_integer_frames_are_converted_like_the_reference():
+    """concentrationanalysis.py:241-246: a non-float probing image is converted with img_as(float) and a warning."""
+    base, probe = _frames(40, 56, 70, np.float64)
+    u8 = da.OpticalImage((np.clip(probe.img, 0, 1) * 255).astype(np.uint8))
+    ca = da.ConcentrationAnalysis(base, da.MonochromaticReduction(color="red"), None, None, None, **{"diff option": "plain"})
+    with pytest.warns(UserWarning, match="converted to float"):
+        out = ca(u8)
+    want = np.multiply(u8.img[..., 0], 1.0 / 255, dtype=np.float64) - base.img[..., 0]   # scikit-image multiplies by 1 / 255
+    assert out.img.dtype == np.float64 and np.array_equal(out.img, want)
+    with pytest.raises(TypeError):
+        ca(da.OpticalImage(np.zeros((40, 56, 3), dtype=np.int32)))
