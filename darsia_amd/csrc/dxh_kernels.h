@@ -1375,6 +1375,15 @@ struct Pipe {
     bool inL[N];        // element inside the row (x < L)
     uint32_t voff;      // this lane's byte offset inside a row: addresses are (uniform row base in SGPRs) + voff
     T* lds;             // this lane's vector in slot 0 of the wave's LDS rings; slot stride = kWave * N elements
+    // eps instantiation: the K running sums of squared increments of this lane live in LDS (slot stride kWave
+    // elements), not in registers -- sixteen more live registers do not fit under the 168 of three waves per SIMD (the
+    // register version spilled 15 dwords to scratch, whose traffic shares vmcnt with the row prefetches: +33 % time)
+    T* linc;
+#ifdef DXH_ENABLE_PAIR
+    static constexpr bool LINC = false;
+#else
+    static constexpr bool LINC = NORM;
+#endif
 
 #ifdef DXH_LDS_OPAQUE
     __device__ __forceinline__ void lds_put(int slot, const T (&v)[N]) const { store_vec_opaque(lds + slot * (kWave * N), v); }
@@ -1630,10 +1639,25 @@ struct Pipe {
                 for (int j = 0; j < N; ++j) un[j] = unm[j];
             }
             if (NORM && p32 >= R0_32 && p32 < R1_32) {  // wave-uniform; rows of this chunk only (each element once)
+                if constexpr (LINC) {
+                    // one running sum per lane and stage, kept in LDS through volatile accesses (the optimiser would pull
+                    // it back into a register): the row's elements are summed in order, then added to it.  The lane mask
+                    // (strip halo) does not depend on the row and is applied when the sums are read back (fused_pipe_body)
+                    IncT<T> t = IncT<T>(0);
 #pragma unroll
-                for (int j = 0; j < N; ++j) {
-                    const IncT<T> dlt = un[j] - uc[j];
-                    inc[NORM ? s : 0][j] += (store_lane && inL[j]) ? dlt * dlt : IncT<T>(0);
+                    for (int j = 0; j < N; ++j) {
+                        const IncT<T> dlt = un[j] - uc[j];
+                        const IncT<T> sq = inL[j] ? dlt * dlt : IncT<T>(0);
+                        t = j == 0 ? sq : t + sq;
+                    }
+                    volatile T* slot = linc + s * kWave;
+                    *slot = *slot + t;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {
+                        const IncT<T> dlt = un[j] - uc[j];
+                        inc[NORM ? s : 0][j] += (store_lane && inL[j]) ? dlt * dlt : IncT<T>(0);
+                    }
                 }
             }
             T unr[N], q1o[N], q0o[N];
@@ -1855,12 +1879,14 @@ __device__ __forceinline__ void pipe_write_partials(const FusedArgs<T>& a, IncT<
 
 template <typename T, int C, bool COUPLED, bool ISO, int K, bool NTS, bool EDGE, bool NORM, bool HET = false>
 __device__ __forceinline__ void fused_pipe_body(const FusedArgs<T>& a, const int strip, const int chunk, const int lane,
-                                                T* lds_lane) {
+                                                T* lds_lane, T* linc_lane) {
     constexpr int N = VecOf<T>::N;
     static_assert(!HET || K <= 3, "heterogeneous pipelines prefetch at distance 1 (K <= 3)");
-    Pipe<T, C, COUPLED, ISO, K, NTS, EDGE, NORM, HET> pp;
+    using PipeT = Pipe<T, C, COUPLED, ISO, K, NTS, EDGE, NORM, HET>;
+    PipeT pp;
     pp.lds = lds_lane;
     pp.xlds = lds_lane;
+    pp.linc = linc_lane;
     if (!pipe_setup<K, T, C>(pp, a, strip, chunk, lane)) return;
 
     PipeState<T, K> st;
@@ -1884,11 +1910,24 @@ __device__ __forceinline__ void fused_pipe_body(const FusedArgs<T>& a, const int
     for (int s = 0; s < (NORM ? K : 1); ++s)
 #pragma unroll
         for (int j = 0; j < N; ++j) inc[s][j] = IncT<T>(0);
+    if constexpr (PipeT::LINC) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) *(volatile T*)(linc_lane + i * kWave) = T(0);
+    }
     for (int64_t r = rs; r <= r_end; r += 4) {
         pp.template step<0>(st, inc, r);
         pp.template step<1>(st, inc, r + 1);
         pp.template step<2>(st, inc, r + 2);
         pp.template step<3>(st, inc, r + 3);
+    }
+    if constexpr (PipeT::LINC) {
+        // a wave's LDS operations complete in order: the sums are final here.  Lanes / elements outside the strip's
+        // stored part or outside the row drop out now (their sums may be anything, NaN included)
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            const T v = *(volatile T*)(linc_lane + s * kWave);
+            inc[s][0] = pp.store_lane ? v : IncT<T>(0);   // the lane's whole sum in the first slot, the others stay 0
+        }
     }
     if constexpr (NORM) pipe_write_partials<K, 0>(a, inc, chunk * a.nstrips + strip, lane);
 }
@@ -2019,10 +2058,13 @@ __global__ void __launch_bounds__(256, (pipe_waves<T, K, HET>())) k_fused_multi(
     const bool edge = (w0 < C) || (w0 + kWave * N > a.L - C);     // wave-uniform
     __shared__ typename VecOf<T>::type lds_rings[WPB * PipeLds<K>::SLOTS * kWave];
     T* lds_lane = reinterpret_cast<T*>(lds_rings + (size_t)wave * PipeLds<K>::SLOTS * kWave + lane);
+    // running sums of squared increments of the eps instantiation: [wave][stage][lane]
+    __shared__ T lds_inc[NORM ? WPB * K * kWave : 1];
+    T* linc_lane = NORM ? lds_inc + (size_t)wave * (K * kWave) + lane : lds_inc;
     if (edge)
-        fused_pipe_body<T, C, COUPLED, ISO, K, NTS, true, NORM, HET>(a, strip, chunk, lane, lds_lane);
+        fused_pipe_body<T, C, COUPLED, ISO, K, NTS, true, NORM, HET>(a, strip, chunk, lane, lds_lane, linc_lane);
     else
-        fused_pipe_body<T, C, COUPLED, ISO, K, NTS, false, NORM, HET>(a, strip, chunk, lane, lds_lane);
+        fused_pipe_body<T, C, COUPLED, ISO, K, NTS, false, NORM, HET>(a, strip, chunk, lane, lds_lane, linc_lane);
     signal_chunk_done(a, chunk, lane);
 }
 
