@@ -404,6 +404,10 @@ def test_full_size_config2_parity_and_invariants(monkeypatch):
     out_k1, _ = run_device(img, mu=0.1, n_iter=100)
     assert res.iters_done == 100
     assert_bits(out_k4, out_k1)
+    # the public host-array call takes the row-band path at this size (dxh_tvd_solve_banded): same bits, and so the
+    # window checks (d) below pin what a caller of split_bregman_tvd() gets
+    monkeypatch.delenv("DXH_FUSE_K")
+    assert_bits(da.split_bregman_tvd(img, mu=0.1, max_num_iter=100), out_k4)
     # (the reference's channel-coupled Jacobi sum is not a convex combination -- 6 neighbours over a diagonal
     # built for 4, quirk Q2 -- so the colour result is brighter than the input: no range check here)
     assert np.isfinite(out_k4).all()
