@@ -931,6 +931,8 @@ struct FusedArgs {
     // filled cp) instead of reading four derived planes: 32 instead of 44 bytes per element for an array-valued mu
     CoefIn<T> ci;
     int derive;
+    int kqv;   // array-valued mu only (scalar omega, ell): the scalar pipeline with the shrink threshold mu / ell read per
+               // element from cp.kq (K = kHetFuseK; k_fused_multi<..., KQV>)
     // optional (k_fused_multi): per-wave partial sums of (u_{n+s+1} - u_{n+s})^2 for each fused iteration s,
     // layout [K][nwaves_total]; nullptr = off.  Lets the eps test of split_bregman_tvd.py:161-175 run on
     // K-iteration launches without any extra pass over the data.
@@ -1329,6 +1331,8 @@ struct PipeState {
     T of0[N];      // omega*f of stage 0's row
     T pf[2][4][N]; // prefetch distance 2: rows in flight two steps ahead (u, omega*f, q0, q1), slot = phase parity
     T coef[K][4][N];  // heterogeneous coefficients (ell, diag, dsc, kq) of each stage's current row
+    T kqv[K][N];      // KQV: the shrink threshold mu / ell of each stage's current row
+    T kqn[N];         // KQV: prefetched threshold row (stage 0's next row)
     T craw[2][3][N];  // prefetched raw coefficient rows (mu, omega, ell as given), slot = phase parity
     T ofr[K][N];   // pair roles: omega*f delay line in registers (ofr[s] = row of local stage s)
     T q1r[K][2][N];// pair roles: inter-stage Q1 hand-off in registers
@@ -1349,8 +1353,15 @@ struct PipeLds {
 // HET: array-valued coefficients.  Each stage carries the derived coefficients (ell, diag, dsc, kq) of its current
 // row in registers; stage 0 derives them from the prefetched rows of the given planes (derive_coefs) and they move
 // down one stage per step.  Divisions are IEEE divisions (the divisors differ per element).
-template <typename T, int C, bool COUPLED, bool ISO, int K, bool NTS, bool EDGE, bool NORM, bool HET = false>
+// KQV (scalar pipelines only): an array-valued mu with scalar omega and ell -- what the TVD operator and the workflow's
+// porosity weights produce.  ell, diag, dsc stay the wave-invariant scalars of the scalar pipeline (verified-reciprocal
+// division), only the shrink threshold kq = mu / ell is per element: one more plane read per launch (cp.kq, filled by
+// k_coef_planes with derive_coefs' expression) and K x N registers, instead of the 4 x K x N coefficient registers and
+// the per-row derivation of the general array pipeline -- three waves per SIMD instead of two.
+template <typename T, int C, bool COUPLED, bool ISO, int K, bool NTS, bool EDGE, bool NORM, bool HET = false, bool KQV = false>
 struct Pipe {
+    static_assert(!(HET && KQV), "KQV is a variant of the scalar pipeline");
+    const T* kq_p;
     static constexpr int N = VecOf<T>::N;
     static constexpr bool DPP = true;
     CoefIn<T> ci;
@@ -1475,7 +1486,9 @@ struct Pipe {
             load_vec(at(q0_in, rn), st.q0l[(PH + 1) & 1]);
             load_vec(at(q1_in, rn), st.q1l[(PH + 1) & 1]);
             if constexpr (HET) load_craw(rn, st.craw[(PH + 1) & 1]);
+            if constexpr (KQV) load_vec(at(kq_p, rn), st.kqn);
         } else {
+            static_assert(!KQV, "the per-element threshold is prefetched at distance 1");
             const int64_t rn = clampr(r + 2);
             load_vec(at(u_in, clampr(r + 3)), st.pf[PH & 1][0]);
             load_vec(at(of_p, rn), st.pf[PH & 1][1]);
@@ -1546,6 +1559,10 @@ struct Pipe {
                     split_vars<T, 2, ISO, false>(qq, st.coef[s][3][j], d, b);
                     t0c[j] = st.coef[s][0][j] * (b[0] - d[0]);
                     t1c[j] = st.coef[s][0][j] * (b[1] - d[1]);
+                } else if constexpr (KQV) {
+                    split_vars<T, 2, ISO, false>(qq, st.kqv[s][j], d, b);
+                    t0c[j] = ell * (b[0] - d[0]);
+                    t1c[j] = ell * (b[1] - d[1]);
                 } else {
                     split_vars<T, 2, ISO, true>(qq, kq, d, b);
                     t0c[j] = ell * (b[0] - d[0]);
@@ -1714,6 +1731,14 @@ struct Pipe {
                     for (int j = 0; j < N; ++j) st.coef[s2][q][j] = st.coef[s2 - 1][q][j];
             finish_coef(st.craw[(PH + 1) & 1], st.coef[0]);
         }
+        if constexpr (KQV) {
+#pragma unroll
+            for (int s2 = K - 1; s2 >= 1; --s2)
+#pragma unroll
+                for (int j = 0; j < N; ++j) st.kqv[s2][j] = st.kqv[s2 - 1][j];
+#pragma unroll
+            for (int j = 0; j < N; ++j) st.kqv[0][j] = st.kqn[j];
+        }
         if constexpr (ROLE != 0) {
             return;  // tail: the next step reads its rows from the shared rings; head: loaded in place above
         }
@@ -1776,6 +1801,7 @@ __device__ __forceinline__ bool pipe_setup(PipeT& pp, const FusedArgs<T>& a, con
     pp.div3 = a.c.div3 != 0;
     pp.cdiag = a.c.const_diag != 0;
     pp.ci = a.ci;
+    pp.kq_p = a.cp.kq;
     return true;
 }
 
@@ -1817,11 +1843,18 @@ __device__ __forceinline__ void pipe_state_zero(PipeState<T, K>& st) {
         for (int q = 0; q < 3; ++q)
 #pragma unroll
             for (int j = 0; j < N; ++j) st.craw[i][q][j] = T(0);
+    // thresholds of the not yet started stages: 0 (shrink by nothing) keeps the discarded leading rows finite
+#pragma unroll
+    for (int l = 0; l < K; ++l)
+#pragma unroll
+        for (int j = 0; j < N; ++j) st.kqv[l][j] = T(0);
+#pragma unroll
+    for (int j = 0; j < N; ++j) st.kqn[j] = T(0);
 }
 
 // Prologue of a wave that reads level 0 from HBM (solo / head): phase 0 at row rs, rows rs-1, rs, rs+1 of u in
 // ring slots 3, 0, 1, the carried (t0, b0) of row rs-1 recomputed from the stored q.
-template <int PFD, bool ISO, bool HET = false, typename T, int K, typename PipeT>
+template <int PFD, bool ISO, bool HET = false, bool KQV = false, typename T, int K, typename PipeT>
 __device__ __forceinline__ void pipe_prologue(const PipeT& pp, PipeState<T, K>& st, const int64_t rs) {
     constexpr int N = VecOf<T>::N;
     load_vec(pp.at(pp.u_in, pp.clampr(rs - 1)), st.U[0][3]);
@@ -1848,12 +1881,20 @@ __device__ __forceinline__ void pipe_prologue(const PipeT& pp, PipeState<T, K>& 
         pp.load_craw(pp.clampr(rs), raw);
         pp.finish_coef(raw, st.coef[0]);
     }
+    T kqm[N];
+    if constexpr (KQV) {
+        load_vec(pp.at(pp.kq_p, rm), kqm);
+        load_vec(pp.at(pp.kq_p, pp.clampr(rs)), st.kqv[0]);
+    }
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         T qq[2] = {q0v[j], q1v[j]}, d[2], b[2];
         if constexpr (HET) {
             split_vars<T, 2, ISO, false>(qq, cfm[3][j], d, b);
             st.t0[0][1][j] = cfm[0][j] * (b[0] - d[0]);
+        } else if constexpr (KQV) {
+            split_vars<T, 2, ISO, false>(qq, kqm[j], d, b);
+            st.t0[0][1][j] = pp.ell * (b[0] - d[0]);
         } else {
             split_vars<T, 2, ISO, true>(qq, pp.kq, d, b);
             st.t0[0][1][j] = pp.ell * (b[0] - d[0]);  // parity "prv" of phase 0
@@ -1877,12 +1918,12 @@ __device__ __forceinline__ void pipe_write_partials(const FusedArgs<T>& a, IncT<
     }
 }
 
-template <typename T, int C, bool COUPLED, bool ISO, int K, bool NTS, bool EDGE, bool NORM, bool HET = false>
+template <typename T, int C, bool COUPLED, bool ISO, int K, bool NTS, bool EDGE, bool NORM, bool HET = false, bool KQV = false>
 __device__ __forceinline__ void fused_pipe_body(const FusedArgs<T>& a, const int strip, const int chunk, const int lane,
                                                 T* lds_lane, T* linc_lane) {
     constexpr int N = VecOf<T>::N;
     static_assert(!HET || K <= 3, "heterogeneous pipelines prefetch at distance 1 (K <= 3)");
-    using PipeT = Pipe<T, C, COUPLED, ISO, K, NTS, EDGE, NORM, HET>;
+    using PipeT = Pipe<T, C, COUPLED, ISO, K, NTS, EDGE, NORM, HET, KQV>;
     PipeT pp;
     pp.lds = lds_lane;
     pp.xlds = lds_lane;
@@ -1901,7 +1942,7 @@ __device__ __forceinline__ void fused_pipe_body(const FusedArgs<T>& a, const int
         for (int i = 0; i < PipeLds<K>::SLOTS; ++i) pp.lds_put(i, z);
     }
     const int64_t rs = pp.R0 - (K - 1);
-    pipe_prologue<pipe_pfd<T, K, HET>(), ISO, HET>(pp, st, rs);
+    pipe_prologue<pipe_pfd<T, K, HET>(), ISO, HET, KQV>(pp, st, rs);
     // the last stage must reach row R1: steps rs .. R1 + K - 1, rounded up to whole groups of 4
     // (extra steps touch clamped rows only and store nothing)
     const int64_t r_end = pp.R1 + (K - 1);
@@ -2042,7 +2083,7 @@ __global__ void __launch_bounds__(256, DXH_PAIR_LB) k_fused_pair(FusedArgs<T> a)
 }
 #endif  // DXH_ENABLE_PAIR
 
-template <typename T, int C, bool COUPLED, bool ISO, int K, bool NORM = false, bool NTS = true, bool HET = false>
+template <typename T, int C, bool COUPLED, bool ISO, int K, bool NORM = false, bool NTS = true, bool HET = false, bool KQV = false>
 __global__ void __launch_bounds__(256, (pipe_waves<T, K, HET>())) k_fused_multi(FusedArgs<T> a) {
     constexpr int N = VecOf<T>::N;
     using SG = StripGeomK<T, C, K>;
@@ -2062,9 +2103,9 @@ __global__ void __launch_bounds__(256, (pipe_waves<T, K, HET>())) k_fused_multi(
     __shared__ T lds_inc[NORM ? WPB * K * kWave : 1];
     T* linc_lane = NORM ? lds_inc + (size_t)wave * (K * kWave) + lane : lds_inc;
     if (edge)
-        fused_pipe_body<T, C, COUPLED, ISO, K, NTS, true, NORM, HET>(a, strip, chunk, lane, lds_lane, linc_lane);
+        fused_pipe_body<T, C, COUPLED, ISO, K, NTS, true, NORM, HET, KQV>(a, strip, chunk, lane, lds_lane, linc_lane);
     else
-        fused_pipe_body<T, C, COUPLED, ISO, K, NTS, false, NORM, HET>(a, strip, chunk, lane, lds_lane, linc_lane);
+        fused_pipe_body<T, C, COUPLED, ISO, K, NTS, false, NORM, HET, KQV>(a, strip, chunk, lane, lds_lane, linc_lane);
     signal_chunk_done(a, chunk, lane);
 }
 

@@ -25,6 +25,13 @@ namespace {
 template <typename T, int C, bool COUPLED, bool ISO, int K>
 void launch_one(bool want_inc, bool pair, const FusedArgs<T>& a, unsigned grid, hipStream_t stream) {
     if constexpr (K == DXH_HET_K) {
+        if (a.kqv) {  // array-valued mu with scalar omega / ell: the scalar pipeline with a per-element threshold
+            if (want_inc)
+                hipLaunchKernelGGL((k_fused_multi<T, C, COUPLED, ISO, K, true, true, false, true>), dim3(grid), dim3(256), 0, stream, a);
+            else
+                hipLaunchKernelGGL((k_fused_multi<T, C, COUPLED, ISO, K, false, true, false, true>), dim3(grid), dim3(256), 0, stream, a);
+            return;
+        }
         if (a.derive) {  // array-valued coefficients
             if (want_inc)
                 hipLaunchKernelGGL((k_fused_multi<T, C, COUPLED, ISO, K, true, true, true>), dim3(grid), dim3(256), 0, stream, a);

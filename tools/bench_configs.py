@@ -1,6 +1,6 @@
 """Timings of the BASELINE.json configs other than the headline one (wall time of whole calls; run under
 rocprofv3 --kernel-trace --stats for kernel-only durations)."""
-import sys, time
+import os, sys, time
 import numpy as np
 sys.path.insert(0, ".")
 import darsia_amd as da
@@ -82,7 +82,13 @@ t("  the same elementwise stages as NumPy passes on the host (no TVD)", host_cha
 print("heterogeneous coefficients: array-valued mu (device loop)")
 mu = np.full(rgb.shape, 0.1, np.float32); mu[:, W // 2:] = 0.3
 st = da.DeviceTVD(rgb.shape, rgb.dtype); st.set_coeffs(mu, 1.0, None, rgb); st.upload(rgb); ms = loop_ms(st, 99)
-print(f"  device loop mu array: {ms:.4f} ms/iter  {H*W/ms/1e3:.0f} MPix/s"); st.close()
+print(f"  device loop mu array (ell = 2 mu, array as well): {ms:.4f} ms/iter  {H*W/ms/1e3:.0f} MPix/s"); st.close()
+st = da.DeviceTVD(rgb.shape, rgb.dtype); st.set_coeffs(mu, 1.0, 0.2, rgb); st.upload(rgb); ms = loop_ms(st, 99)
+print(f"  device loop mu array, scalar omega and ell (the TVD operator / porosity weights): {ms:.4f} ms/iter  {H*W/ms/1e3:.0f} MPix/s"); st.close()
+os.environ["DXH_FUSED_TUNE"] = "65536"
+st = da.DeviceTVD(rgb.shape, rgb.dtype); st.set_coeffs(mu, 1.0, 0.2, rgb); st.upload(rgb); ms = loop_ms(st, 99)
+print(f"    the same through the general array pipeline (DXH_FUSED_TUNE=65536): {ms:.4f} ms/iter"); st.close()
+del os.environ["DXH_FUSED_TUNE"]
 print("Gauss-Seidel split Bregman (TVD '* bregman' methods), 64 sweeps, eps off")
 t("denoise_tv_bregman(rgb, 64 sweeps)  [PCIe-inclusive]", lambda: da.denoise_tv_bregman(rgb, weight=1.0, max_num_iter=64, eps=0.0, isotropic=False))
 print("MG inside the TV loop (gray f32, depth 3, 2 smoother sweeps, 1 V-cycle per outer iteration, 20 outer iterations)")
