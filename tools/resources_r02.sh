@@ -16,8 +16,8 @@ R=../../tools/resource_usage.py
 echo "# kernel resource usage, gfx950 (hipcc -Rpass-analysis=kernel-resource-usage); occ = waves per SIMD the registers allow"
 echo "## K = 4 pipelines, float (headline: <float, 3, true, false, 4, false, ...>; isotropic: <float, 3, true, true, 4, ...>; gray: <float, 1, false, false, 4, ...>; the 6th argument is the eps variant)"
 python3 $R $T/k4f.txt "k_fused_multi<float, 3, true, false, 4"; python3 $R $T/k4f.txt "k_fused_multi<float, 3, true, true, 4"; python3 $R $T/k4f.txt "k_fused_multi<float, 1, false, false, 4"
-echo "## K = 3 pipeline with array-valued coefficients (last argument true)"
-python3 $R $T/k3f.txt "k_fused_multi<float, 3, true, false, 3" | grep "true>" || true
+echo "## K = 3 pipelines with array-valued coefficients: general (..., true, false>) and mu-only / per-element threshold (..., false, true>)"
+python3 $R $T/k3f.txt "k_fused_multi<float, 3, true, false, 3" | grep -E "true, false>|false, true>" || true
 echo "## K = 4, double, gray"
 python3 $R $T/k4d.txt "k_fused_multi<double, 1, false, false, 4"
 echo "## Chambolle"
