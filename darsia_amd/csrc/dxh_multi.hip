@@ -25,6 +25,7 @@ namespace {
 template <typename T, int C, bool COUPLED, bool ISO, int K>
 void launch_one(bool want_inc, bool pair, const FusedArgs<T>& a, unsigned grid, hipStream_t stream) {
     if constexpr (K == DXH_HET_K) {
+#if DXH_MULTI_CSET == 0   // scalar and RGB images only (the host never sets kqv for 2 / 4 channels: compile time)
         if (a.kqv) {  // array-valued mu with scalar omega / ell: the scalar pipeline with a per-element threshold
             if (want_inc)
                 hipLaunchKernelGGL((k_fused_multi<T, C, COUPLED, ISO, K, true, true, false, true>), dim3(grid), dim3(256), 0, stream, a);
@@ -32,6 +33,7 @@ void launch_one(bool want_inc, bool pair, const FusedArgs<T>& a, unsigned grid, 
                 hipLaunchKernelGGL((k_fused_multi<T, C, COUPLED, ISO, K, false, true, false, true>), dim3(grid), dim3(256), 0, stream, a);
             return;
         }
+#endif
         if (a.derive) {  // array-valued coefficients
             if (want_inc)
                 hipLaunchKernelGGL((k_fused_multi<T, C, COUPLED, ISO, K, true, true, true>), dim3(grid), dim3(256), 0, stream, a);

@@ -432,7 +432,7 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
     // will do: the tile map (block_to_tile_sub) keeps neighbouring tiles on one XCD whatever the count.
     auto choose = [&](int64_t rows, int64_t extra_per_xcd) -> int64_t {
         int64_t nchunks;
-        const bool kqv_pipe = c->het && c->het_cdiag && c->cp_kq && !(c->tune & 65536) && make_coef<T>(c).const_diag;
+        const bool kqv_pipe = (C == 1 || C == 3) && c->het && c->het_cdiag && c->cp_kq && !(c->tune & 65536) && make_coef<T>(c).const_diag;
         if (c->waves_per_cu || (c->het && !kqv_pipe)) {
             const int64_t target_blocks = (int64_t)c->num_cu * (c->waves_per_cu ? c->waves_per_cu : 24) / 4 - 8 * extra_per_xcd;
             nchunks = std::max<int64_t>(1, target_blocks / nbx);
@@ -486,7 +486,7 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
     a.ci = make_coefin<T>(c);
     // array-valued mu only, divisors usable through reciprocals: the scalar pipeline with a per-element shrink threshold
     // read from cp_kq (DXH_FUSED_TUNE bit 65536: the general array pipeline instead, A/B)
-    a.kqv = (c->het && c->het_cdiag && c->cp_kq && a.c.const_diag && !(c->tune & 65536)) ? 1 : 0;
+    a.kqv = ((C == 1 || C == 3) && c->het && c->het_cdiag && c->cp_kq && a.c.const_diag && !(c->tune & 65536)) ? 1 : 0;
     a.derive = (c->het && !a.kqv) ? 1 : 0;  // array coefficients (multi_supported: only with the given planes at hand, K = kHetFuseK)
     // the kernels are instantiated in dxh_multi.hip (one object per element type and K, built in parallel)
     if constexpr (C == 1 || C == 3) launch_multi_kernel<T, K>(C, COUPLED, ISO, want_inc, pair, a, grid, c->stream);
