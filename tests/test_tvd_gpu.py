@@ -874,3 +874,29 @@ def test_coefficient_arrays_of_the_other_float_type_are_converted_on_the_device(
     col = (0.05 + 0.1 * rng.random((1, 90)))                     # float64, broadcast along the rows
     assert np.array_equal(da.split_bregman_tvd(gray, mu=col, max_num_iter=5),
                           da.split_bregman_tvd(gray, mu=np.broadcast_to(col, gray.shape).astype(np.float32), max_num_iter=5))
+
+
+@pytest.mark.parametrize("shape", [(150, 260), (141, 230, 3)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("iso", [False, True])
+def test_array_mu_with_scalar_omega_ell_runs_the_per_element_threshold_pipeline(shape, dtype, iso, monkeypatch):
+    """mu array, scalar omega and ell (the TVD operator with a weight map): k_fused_multi<..., KQV> -- the scalar pipeline
+    with kq = mu / ell per element.  Bit for bit equal to the oracle, to the general array pipeline
+    (DXH_FUSED_TUNE=65536) and, with a stopping criterion, stopping at the same iteration."""
+    rng = np.random.default_rng(90)
+    img = rng.random(shape).astype(dtype)
+    mu = (0.02 + 0.25 * rng.random(shape)).astype(dtype)
+    mu[5:20, 10:40] = 0.0                                    # zero weight: no shrinkage there
+    kw = dict(mu=mu, omega=1.3, ell=0.35)
+    for n in (1, 2, 3, 7, 12):
+        out, _ = run_device(img, n_iter=n, isotropic=iso, **kw)
+        if iso and img.ndim == 3:
+            ref = O.split_bregman_tvd(img, max_num_iter=n, isotropic=True, promotion="strict", **kw)
+        else:
+            ref = O.split_bregman_tvd(img, max_num_iter=n, isotropic=iso, promotion="strict", **kw)
+        assert_bits(out, ref)
+    out_eps, res = run_device(img, n_iter=60, eps=3e-3, isotropic=iso, **kw)
+    monkeypatch.setenv("DXH_FUSED_TUNE", "65536")
+    general, res_g = run_device(img, n_iter=60, eps=3e-3, isotropic=iso, **kw)
+    assert res.iters_done == res_g.iters_done and 1 < res.iters_done < 60
+    assert_bits(out_eps, general)
