@@ -44,7 +44,7 @@ def _worker(rank, world, port, case, out_dir):
         if case.get("het"):
             mu = np.ascontiguousarray(np.load(os.path.join(out_dir, "mu.npy"))[plan.slab0:plan.slab1])
         flags = _lib.FLAG_NO_OVERLAP if case.get("no_overlap") else 0
-        s = SlabTVD(plan, slab, mu=mu, dim=case.get("dim", 2), halo_iters=case["halo_iters"], jacobi_maxiter=jm,
+        s = SlabTVD(plan, slab, mu=mu, ell=case.get("ell"), dim=case.get("dim", 2), halo_iters=case["halo_iters"], jacobi_maxiter=jm,
                     isotropic=case.get("iso", False), comm=comm, flags=flags)
         done = 0
         for part in case.get("parts", [case["n_iter"]]):
@@ -76,7 +76,7 @@ def _reference(img, mu, case):
     import darsia_amd as da
 
     with da.DeviceTVD(img.shape, img.dtype, dim=case.get("dim", 2)) as st:
-        st.set_coeffs(mu, 1.0, None, img)
+        st.set_coeffs(mu, 1.0, case.get("ell"), img)
         st.upload(img)
         res = st.run(case["n_iter"], jacobi_maxiter=case.get("jm", 1), eps=case.get("eps"),
                      isotropic=case.get("iso", False))
@@ -96,6 +96,9 @@ CASES = {
     "eps": dict(shape=(120, 300, 3), world=2, halo_iters=3, n_iter=80, eps=2e-3),
     "iso": dict(shape=(90, 270, 3), world=2, halo_iters=2, n_iter=6, iso=True),
     "het_mu_array": dict(shape=(210, 300, 3), world=2, halo_iters=3, n_iter=11, het=True),
+    # array-valued mu with a scalar ell: the per-element-threshold pipeline (k_fused_multi<..., KQV>) in slabs, with eps
+    "het_mu_array_scalar_ell": dict(shape=(900, 300, 3), world=3, halo_iters=6, n_iter=25, het=True, ell=0.3),
+    "het_mu_array_scalar_ell_eps": dict(shape=(260, 300, 3), world=2, halo_iters=3, n_iter=60, het=True, ell=0.3, eps=4e-3),
     "jacobi_maxiter2": dict(shape=(160, 200, 3), world=2, halo_iters=3, n_iter=7, jm=2),
     "f64": dict(shape=(600, 200, 3), world=2, halo_iters=4, n_iter=12, dtype="float64"),
 }
