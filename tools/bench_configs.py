@@ -75,6 +75,11 @@ print(f"  ConcentrationAnalysis.map over 8 frames (upload of frame i+1 overlaps 
 del _r
 ca_ch = da.ConcentrationAnalysis(base_img, da.MonochromaticReduction(color="red"), None, da.TVD(), model, **{"diff option": "positive"})
 t("ConcentrationAnalysis.__call__ with the default TVD() (chambolle) inside the fused pipeline", lambda: ca_ch(probe_img))
+porosity = 0.2 + 0.6 * np.random.default_rng(5).random((H, W))          # float64 map, as the workflow's image_porosity
+ca_por = da.ConcentrationAnalysis(base_img, da.MonochromaticReduction(color="red"), None,
+                                  da.TVD(method="heterogeneous bregman", weight=0.1 * porosity, regularization=0.2, max_num_iter=100, eps=None),
+                                  model, **{"diff option": "positive"})
+t("ConcentrationAnalysis.__call__ with a porosity-weighted TVD (float64 weight map, 100 it)", lambda: ca_por(probe_img))
 def host_chain():
     d = np.clip(probe_img.img - base_img.img, 0, None); s = d[:, :, 0]; m = np.clip(2.0 * s + 0.0, 0.0, 1.0)
     return m
