@@ -640,7 +640,9 @@ int dxh_mem_alloc(int device, size_t bytes, void** ptr) {
     DXH_REQUIRE(ptr, "null argument");
     int rc = check_device(device);
     if (rc) return rc;
-    DXH_HIP(hipMalloc(ptr, bytes ? bytes : 1));
+    // image-sized arrays come from / go back to the plane cache (dxh_common.h: PlanePool): a chain of operators allocates
+    // and releases a few of them per frame, always of the same sizes
+    DXH_HIP(pool_malloc(ptr, bytes ? bytes : 1));
     return DXH_OK;
 }
 
@@ -648,7 +650,8 @@ int dxh_mem_free(int device, void* ptr) {
     if (!ptr) return DXH_OK;
     int rc = check_device(device);
     if (rc) return rc;
-    DXH_HIP(hipFree(ptr));
+    DXH_HIP(hipDeviceSynchronize());   // what hipFree would have waited for: nothing may still use the block
+    pool_free(ptr);
     return DXH_OK;
 }
 
