@@ -73,7 +73,7 @@ int dxh_mem_free(int device, void* ptr);
 /* synchronous copy between any two of {host array, device array} */
 int dxh_mem_copy(int device, void* dst, const void* src, size_t bytes);
 /*
- * The TV contexts keep the planes they release in a cache (exact-size re-use; at most 1/16 of the device memory,
+ * The TV contexts and dxh_mem_free keep the planes / arrays they release in a cache (exact-size re-use; at most 1/16 of the device memory,
  * DXH_POOL_MB overrides, 0 turns it off): hipFree costs 0.1 - 0.3 ms per plane and waits for the device, a whole call
  * releases 10 - 30 planes.  This hands everything cached back to the HIP runtime; *bytes (optional) = what was released.
  */
