@@ -273,11 +273,14 @@ struct Dev {
     std::vector<void*> bufs;
     hipStream_t st = nullptr;
     ~Dev() {
-        for (void* b : bufs) if (b) (void)hipFree(b);
+        // buffers go back to the plane cache (dxh_common.h), which wants them idle: every entry point synchronises its
+        // stream before it returns, an early error return has not
+        if (st) (void)hipStreamSynchronize(st);
+        for (void* b : bufs) pool_free(b);
         // st is the thread's cached stream (cached_stream): not destroyed
     }
     int alloc(void** p, size_t n) {
-        DXH_HIP(hipMalloc(p, n ? n : 1));
+        DXH_HIP(pool_malloc(p, n ? n : 1));
         bufs.push_back(*p);
         return DXH_OK;
     }
