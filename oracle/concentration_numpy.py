@@ -1,10 +1,13 @@
 """CPU restatement (NumPy) of the elementwise chain of DarSIA's ConcentrationAnalysis
 (multi_image_analysis/concentrationanalysis.py:230-421) around the TV restoration.
 
-TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  The reference class cannot be imported here (it needs
-darsia.Image -> cv2), so parity is pinned on the formulas of the cited lines: they are one-line NumPy
-expressions.  The only third-party arithmetic is ``cv2.cvtColor(.., COLOR_RGB2GRAY)`` for the "gray"
-reduction (float32 weights 0.299 / 0.587 / 0.114), which is UNPINNED (cv2 absent).
+TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  PINNED: bit for bit on outputs of the reference's own class
+(tests/golden/concentration_golden.npz, made by tests/golden/make_golden_concentration.py, which executes the reference's
+concentrationanalysis.py, monochromatic.py, the model classes and tvd.py under scikit-image 0.18.3 / NumPy 1.26;
+tests/test_concentration_golden_cpu.py): the four difference options, the red / green / blue / red+green / negative-key
+reductions, cleaning filters, Linear / Clip / Scaling / Combined models, TVD("heterogeneous bregman") before and after
+the model, float32 and float64.  The one exception is ``cv2.cvtColor(.., COLOR_RGB2GRAY)`` for the "gray" reduction
+(float32 weights 0.299 / 0.587 / 0.114), which stays UNPINNED (cv2 absent; that reduction is not in the vectors).
 """
 from __future__ import annotations
 

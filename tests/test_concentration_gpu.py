@@ -184,3 +184,35 @@ def test_integer_frames_are_converted_like_the_reference():
     assert out.img.dtype == np.float64 and np.array_equal(out.img, want)
     with pytest.raises(TypeError):
         ca(da.OpticalImage(np.zeros((40, 56, 3), dtype=np.int32)))
+
+
+def _golden_cases():
+    import ast
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "concentration_golden.npz"))
+    return g, sorted({k.split("/")[0] for k in g.files if k.endswith("/spec")}), ast
+
+
+@pytest.mark.parametrize("tag", _golden_cases()[1])
+def test_product_against_outputs_of_the_reference_class(tag):
+    """The fused device pipeline against what the reference's own ConcentrationAnalysis returned for the same inputs
+    (tests/golden/make_golden_concentration.py): float64 bit for bit; float32 with TVD bit for bit as well (the vectors
+    were made under NumPy 1.26, whose value-based casting keeps the reference's iteration in float32)."""
+    g, _, ast = _golden_cases()
+    spec = ast.literal_eval(str(g[f"{tag}/spec"]))
+    base, probe = g[f"{tag}/base"], g[f"{tag}/probe"]
+    extras = [g[f"{tag}/extra{i}"] for i in range(spec["nclean"])]
+    model = {"linear_clip": lambda: da.CombinedModel([da.LinearModel(scaling=2.5, offset=-0.05), da.ClipModel(min_value=0.0, max_value=1.0)]),
+             "clip_only": lambda: da.ClipModel(min_value=0.02), "scaling": lambda: da.ScalingModel(scaling=3.0)}[spec["model"]]()
+    rest = None
+    if spec["rest"] is not None:
+        rest = da.TVD(method="heterogeneous bregman", eps=None, **spec["rest"])
+    bases = [da.OpticalImage(base)] + [da.OpticalImage(e) for e in extras]
+    ca = da.ConcentrationAnalysis(bases if extras else bases[0], da.MonochromaticReduction(color=spec["color"]), None, rest, model,
+                                  **{"diff option": spec["diff"], "restoration -> model": spec["rest_first"]})
+    assert ca._fusable(probe) is not None
+    out = ca(da.OpticalImage(probe, name="frame"))
+    want = g[f"{tag}/out"]
+    assert isinstance(out, da.ScalarImage) and out.name == "frame" and out.img.dtype == want.dtype
+    assert np.array_equal(out.img, want), np.abs(out.img - want).max()
