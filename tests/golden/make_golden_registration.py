@@ -1,0 +1,173 @@
+"""Golden vectors for the host-side geometry of the registration path, produced by running the reference's own code:
+
+    utils/point.py, image/indexing.py, image/coordinatesystem.py    Voxel / Coordinate types, CoordinateSystem
+    image/patches.py                                                 Patches (ROIs, centres, corners)          (:28-304)
+    multi_image_analysis/translationanalysis.py                      TranslationAnalysis: spline data points, boundary
+                                                                     points, return_patch_translation, add_ / deduct_
+
+loaded file by file onto an empty ``darsia`` shim (make_golden.py's way), each source executed unmodified with the
+``annotations`` future flag.  What stands in for the parts of DarSIA that need OpenCV:
+  * ``darsia.Image``: a minimal container with the attributes Patches / CoordinateSystem / TranslationAnalysis read
+    (``img``, ``space_dim``, ``time_dim``, ``indexing``, ``dimensions``, ``origin``, ``num_voxels``, ``voxel_size``,
+    ``coordinatesystem`` -- the REFERENCE's class --, ``subregion`` by slices, ``copy``, ``metadata``).  The real class lives
+    in image/image.py, which imports cv2 / plotly;
+  * the per-patch translation estimator (ORB + RANSAC in OpenCV, SURVEY.md section 2: out of scope): a table that hands out
+    prescribed translations in the order the analysis visits the patches;
+  * ``cv2`` itself is not needed by any of these files.
+Run in the build container under /opt/conda's Python 3.9 (patches.py imports scikit-image; SciPy 1.7.1 has
+RBFInterpolator):
+
+    /opt/conda/bin/python3.9 tests/golden/make_golden_registration.py     # -> registration_golden.npz
+
+TEST INFRASTRUCTURE.  The output holds inputs and expected outputs (data, no source).
+"""
+from __future__ import annotations
+
+import copy
+import os
+import sys
+import types
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+REF = "/root/reference/src/darsia"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _load(da, rel):
+    import __future__
+
+    name = "darsia_ref_" + rel.replace("/", "_")[:-3]
+    path = f"{REF}/{rel}"
+    m = types.ModuleType(name)
+    m.__file__ = path
+    sys.modules[name] = m
+    with open(path) as f:
+        code = compile(f.read(), path, "exec", flags=__future__.annotations.compiler_flag, dont_inherit=True)
+    exec(code, m.__dict__)
+    for k, v in vars(m).items():
+        if not k.startswith("_"):
+            setattr(da, k, v)
+    return m
+
+
+def main():
+    da = types.ModuleType("darsia")
+    sys.modules["darsia"] = da
+    for rel in ("utils/point.py", "image/indexing.py", "image/coordinatesystem.py"):
+        _load(da, rel)
+
+    class Image:
+        def __init__(self, img, dimensions=None, origin=None, **meta):
+            self.img = img
+            self.space_dim, self.time_dim, self.series, self.scalar = 2, 0, False, img.ndim == 2
+            self.indexing = "ij"
+            self.dimensions = list(dimensions) if dimensions is not None else [1, 1]
+            self.origin = da.Coordinate(np.array([0.0, self.dimensions[0]] if origin is None else origin, dtype=float))
+            self.meta = dict(meta)
+
+        @property
+        def shape(self):
+            return self.img.shape
+
+        @property
+        def num_voxels(self):
+            return list(self.img.shape[:2])
+
+        @property
+        def voxel_size(self):
+            return [self.dimensions[i] / self.num_voxels[i] for i in range(2)]
+
+        @property
+        def coordinatesystem(self):
+            return da.CoordinateSystem(self)
+
+        def subregion(self, voxels):
+            return Image(self.img[voxels], dimensions=self.dimensions, **self.meta)   # metadata of the cut-out is not exercised
+
+        def copy(self):
+            return copy.deepcopy(self)
+
+        def metadata(self):
+            return dict(self.meta)
+
+    da.Image = Image
+    _load(da, "image/patches.py")
+    _load(da, "multi_image_analysis/translationanalysis.py")
+
+    class Table:
+        def __init__(self, table):
+            self.table, self.k = list(table), 0
+
+        def find_effective_translation(self, img_src, img_dst, roi_src, roi_dst, mask_src=None, mask_dst=None, plot_matches=False):
+            t = self.table[self.k % len(self.table)]
+            self.k += 1
+            if t is None:
+                return None, False
+            return np.array([[1.0, 0.0, t[0]], [0.0, 1.0, t[1]]]), True
+
+    out = {"meta/numpy": np.array(np.__version__)}
+    rng = np.random.default_rng(5)
+    # ---- Patches geometry
+    for tag, shape, dims, n, ov in (("p0", (100, 130), [1.0, 1.3], [3, 4], 0.1), ("p1", (120, 160), [1.2, 1.6], [3, 4], 0.0),
+                                    ("p2", (97, 211), [0.5, 1.1], [5, 7], 0.25), ("p3", (64, 64), [2.0, 1.0], [1, 2], 0.05)):
+        im = Image(rng.random(shape), dimensions=dims)
+        p = da.Patches(im, n, rel_overlap=ov)
+        out[f"{tag}/shape"], out[f"{tag}/dims"], out[f"{tag}/n"], out[f"{tag}/ov"] = np.array(shape), np.array(dims), np.array(n), np.array(ov)
+        out[f"{tag}/rois"] = np.array([[[r.start, min(r.stop, shape[0]), c.start, min(c.stop, shape[1])] for (r, c) in row] for row in p.rois])
+        out[f"{tag}/centers_cartesian"] = np.array(p.global_centers_cartesian, dtype=float)
+        out[f"{tag}/centers_voxels"] = np.array(p.global_centers_voxels)
+        out[f"{tag}/corners_voxels"] = np.array(p.global_corners_voxels)
+        out[f"{tag}/local_corners_voxels"] = np.array(p.local_corners_voxels)
+        out[f"{tag}/corners_cartesian"] = np.array(p.global_corners_cartesian, dtype=float)
+        out[f"{tag}/patch_1_shape"] = np.array(p(n[0] - 1, n[1] - 1).img.shape)
+    # ---- TranslationAnalysis
+    base = Image(rng.random((100, 130)).astype(np.float32), dimensions=[1.0, 1.3])
+    n = [3, 4]
+    table = [(1.0 + 0.1 * k, -2.0 + 0.3 * k) for k in range(12)]
+    table[5] = None
+    ta = da.TranslationAnalysis(base, N_patches=n, rel_overlap=0.1, translation_estimator=Table(table))
+    ta.load_image(base)
+    translation, ok = ta.find_translation()
+    out["ta/table"] = np.array([(np.nan, np.nan) if t is None else t for t in table])
+    out["ta/ok"], out["ta/have"] = np.array(ok), ta.have_translation
+    out["ta/x_points"], out["ta/x_values"] = np.array(ta.interpolator_translation_x.y), np.array(ta.interpolator_translation_x.d).reshape(-1)
+    out["ta/y_points"], out["ta/y_values"] = np.array(ta.interpolator_translation_y.y), np.array(ta.interpolator_translation_y.d).reshape(-1)
+    bx, bxv = ta.bc_x(["pixel", "pixel"])
+    by, byv = ta.bc_y(["pixel", "pixel"])
+    out["ta/bc_x"], out["ta/bc_y"] = np.array(bx, dtype=float), np.array(by, dtype=float)
+    q = rng.random((9, 2)) * np.array([130, 100])
+    out["ta/query"], out["ta/query_out"] = q, np.array(translation(q))
+    for rev in (True, False):
+        for units in ("metric", "pixel"):
+            out[f"ta/patch_translation_rev{int(rev)}_{units}"] = np.array(ta.return_patch_translation(rev, units))
+    # composition: does the reference's code run (it appends (1,)-arrays and floats to one list)?
+    other = da.TranslationAnalysis(base, N_patches=[2, 3], rel_overlap=0.1,
+                                   translation_estimator=Table([(1.5, 0.7), (-0.5, 0.2), (0.3, -0.9), (0.8, 0.1), (-1.1, 0.4), (0.6, -0.3)]))
+    other.load_image(base)
+    other.find_translation()
+    out["comp/other_x_points"], out["comp/other_x_values"] = np.array(other.interpolator_translation_x.y), np.array(other.interpolator_translation_x.d).reshape(-1)
+    out["comp/other_y_points"], out["comp/other_y_values"] = np.array(other.interpolator_translation_y.y), np.array(other.interpolator_translation_y.d).reshape(-1)
+    for op in ("add", "deduct"):
+        t2 = da.TranslationAnalysis(base, N_patches=n, rel_overlap=0.1, translation_estimator=Table(table))
+        t2.load_image(base)
+        t2.find_translation()
+        try:
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                getattr(t2, f"{op}_translation_analysis")(other)
+            out[f"comp/{op}_status"] = np.array("ok")
+            out[f"comp/{op}_x_points"] = np.array(t2.interpolator_translation_x.y)
+            out[f"comp/{op}_x_values"] = np.array(t2.interpolator_translation_x.d, dtype=float).reshape(-1)
+            out[f"comp/{op}_y_values"] = np.array(t2.interpolator_translation_y.d, dtype=float).reshape(-1)
+            out[f"comp/{op}_query_out"] = np.array(t2.translation(q), dtype=float)
+        except Exception as e:  # noqa: BLE001 -- recorded: what the reference does under this NumPy
+            out[f"comp/{op}_status"] = np.array(f"{type(e).__name__}: {e}"[:300])
+    np.savez_compressed(os.path.join(HERE, "registration_golden.npz"), **out)
+    print("wrote", len(out), "arrays; add:", out["comp/add_status"], "deduct:", out["comp/deduct_status"])
+
+
+if __name__ == "__main__":
+    main()
