@@ -1,7 +1,10 @@
 """CPU restatement of the per-image part of DarSIA's ``CurvatureCorrection`` (corrections/shape/curvature.py) and
 of the SciPy gather it rests on.
 
-TEST INFRASTRUCTURE -- NOT PRODUCT CODE (same rule as oracle/tvd_numpy.py).
+TEST INFRASTRUCTURE -- NOT PRODUCT CODE (same rule as oracle/tvd_numpy.py).  PINNED: grid and corrected image of eight
+configurations equal, bit for bit, what the reference's own CurvatureCorrection returns (tests/golden/curvature_golden.npz, made
+by tests/golden/make_golden_curvature.py, which executes curvature.py / basecorrection.py; tests/test_curvature_golden_cpu.py).
+The "crop" step (cv2.warpPerspective) is not in those vectors and stays unpinned.
 
 * ``map_coordinates``: ``scipy.ndimage.map_coordinates(input2d, grid, order=0|1)`` with the default mode
   "constant", cval 0 (call site curvature.py:943-945).  SciPy is a third-party, unpinned dependency of the

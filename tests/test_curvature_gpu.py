@@ -126,3 +126,38 @@ def test_device_resident_frames_and_grid():
     rows, cols = da.DeviceArray.from_host(grid[0]), da.DeviceArray.from_host(grid[1])
     assert np.array_equal(da.map_coordinates(img, (rows, cols)), da.map_coordinates(img, grid))
     assert np.array_equal(da.map_coordinates(da.DeviceArray.from_host(img), (rows, cols)).get(), da.map_coordinates(img, grid))
+
+
+def _curv_golden():
+    import os
+
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "curvature_golden.npz"))
+
+
+@pytest.mark.parametrize("tag", sorted({k.split("/")[0] for k in _curv_golden().files if k.endswith("/spec")}))
+def test_product_against_outputs_of_the_reference_class(tag):
+    """CurvatureCorrection on the device against what the reference's own class returned for the same image and
+    configuration (tests/golden/make_golden_curvature.py): cached grid and corrected image, bit for bit."""
+    import ast
+    import copy
+
+    from test_curvature_golden_cpu import CONFIGS
+
+    g = _curv_golden()
+    spec = ast.literal_eval(str(g[f"{tag}/spec"]))
+    img = g[f"{tag}/img"]
+    cc = da.CurvatureCorrection(config=copy.deepcopy(CONFIGS[spec["config"]]), interpolation_order=spec["order"],
+                                resize_factor=spec["resize_factor"])
+    out = cc(img)
+    assert np.array_equal(cc.cache["grid"], g[f"{tag}/grid"]) and tuple(cc.cache["shape"]) == tuple(g[f"{tag}/shape"])
+    want = g[f"{tag}/out"]
+    assert out.dtype == want.dtype and np.array_equal(out, want)
+
+
+def test_image_branch_against_the_reference_class():
+    g = _curv_golden()
+    cc = da.CurvatureCorrection(config={"bulge": dict(horizontal_bulge=5e-6, vertical_bulge=-3e-6)})
+    im = da.ScalarImage(g["image/img"], name="frame")
+    res = cc(im)
+    assert bool(g["image/is_new_object"]) and res is not im and res.name == "frame"
+    assert np.array_equal(res.img, g["image/out"])
