@@ -4,6 +4,7 @@
     image/patches.py                                                 Patches (ROIs, centres, corners)          (:28-304)
     multi_image_analysis/translationanalysis.py                      TranslationAnalysis: spline data points, boundary
                                                                      points, return_patch_translation, add_ / deduct_
+    multi_image_analysis/imageregistration.py                        DiffeomorphicImageRegistration.evaluate / displacement
 
 loaded file by file onto an empty ``darsia`` shim (make_golden.py's way), each source executed unmodified with the
 ``annotations`` future flag.  What stands in for the parts of DarSIA that need OpenCV:
@@ -165,6 +166,26 @@ def main():
             out[f"comp/{op}_query_out"] = np.array(t2.translation(q), dtype=float)
         except Exception as e:  # noqa: BLE001 -- recorded: what the reference does under this NumPy
             out[f"comp/{op}_status"] = np.array(f"{type(e).__name__}: {e}"[:300])
+    # ---- DiffeomorphicImageRegistration: evaluate / displacement (imageregistration.py:166-306)
+    _load(da, "multi_image_analysis/imageregistration.py")
+    reg_table = [(0.8 * np.sin(k), 1.1 * np.cos(0.7 * k)) for k in range(6)]
+    da.TranslationEstimator = lambda max_features, tol: Table(reg_table)   # the ORB / RANSAC estimator's stand-in
+    dst = Image(rng.random((40, 52)).astype(np.float32), dimensions=[0.8, 1.04])
+    reg = da.DiffeomorphicImageRegistration(dst, N_patches=[2, 3], rel_overlap=0.1)
+    reg.translation_analysis.load_image(dst)
+    reg.translation_analysis.find_translation()
+    out["reg/table"] = np.array(reg_table)
+    pts_metric = np.c_[rng.random(11) * 1.04, rng.random(11) * 0.8]
+    pts_pixel = np.c_[rng.random(11) * 52, rng.random(11) * 40]
+    out["reg/pts_metric"], out["reg/pts_pixel"] = pts_metric, pts_pixel
+    for rev in (False, True):
+        out[f"reg/evaluate_metric_rev{int(rev)}"] = np.array(reg.evaluate(da.CoordinateArray(pts_metric), rev, "metric"), dtype=float)
+        out[f"reg/evaluate_pixel_rev{int(rev)}"] = np.array(reg.evaluate(pts_pixel.copy(), rev, "pixel"), dtype=float)
+    out["reg/evaluate_patches"] = np.array(reg.evaluate(da.Patches(dst, [2, 2])), dtype=float)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        out["reg/displacement"] = np.array(reg.displacement(), dtype=float)
     np.savez_compressed(os.path.join(HERE, "registration_golden.npz"), **out)
     print("wrote", len(out), "arrays; add:", out["comp/add_status"], "deduct:", out["comp/deduct_status"])
 

@@ -192,3 +192,18 @@ def test_multilevel_registration_handles_a_larger_warp():
     after = np.abs(out.img - dst)[inner].mean()
     assert after < 0.6 * before, (before, after)
     assert np.array_equal(reg.apply(da.Image(src)).img, out.img)
+
+
+def test_displacement_field_equals_the_reference_class():
+    """DiffeomorphicImageRegistration.displacement() (imageregistration.py:265-306) as the reference's own class computes it
+    (tests/golden/make_golden_registration.py): pixel order, (x, y) columns, metric units -- the paired spline kernel to
+    1e-9 (SciPy 1.7 evaluated the golden)."""
+    import os
+
+    from test_registration_cpu import _golden_registration
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "registration_golden.npz"))
+    _, reg = _golden_registration()
+    field = reg.displacement()
+    assert field.shape == g["reg/displacement"].shape == (40 * 52, 2)
+    np.testing.assert_allclose(field, g["reg/displacement"], rtol=1e-9, atol=1e-11)

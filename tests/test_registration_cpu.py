@@ -204,3 +204,24 @@ def test_composition_runs_where_the_reference_raises():
     RBFInterpolator: NumPy >= 1.24 refuses the ragged list (recorded by the golden generator under NumPy 1.26).  The
     product implements what the code intends (test_deduct_and_add_compose_the_maps_at_the_patch_centres)."""
     assert str(_G["comp/add_status"]).startswith("ValueError") and str(_G["comp/deduct_status"]).startswith("ValueError")
+
+
+def _golden_registration():
+    table = [(float(a), float(b)) for a, b in _G["reg/table"]]
+    dst = da.Image(np.zeros((40, 52), np.float32), dimensions=[0.8, 1.04])
+    reg = DiffeomorphicImageRegistration(dst, N_patches=[2, 3], rel_overlap=0.1, translation_estimator=TableEstimator(table))
+    reg.translation_analysis.load_image(dst)
+    reg.translation_analysis.find_translation()
+    return dst, reg
+
+
+def test_evaluate_equals_the_reference_class():
+    """DiffeomorphicImageRegistration.evaluate executed by the golden generator (imageregistration.py:166-226): metric and
+    pixel units, both directions, points and patch centres."""
+    dst, reg = _golden_registration()
+    for rev in (False, True):
+        np.testing.assert_allclose(reg.evaluate(da.CoordinateArray(_G["reg/pts_metric"]), rev, "metric"),
+                                   _G[f"reg/evaluate_metric_rev{int(rev)}"], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(reg.evaluate(_G["reg/pts_pixel"].copy(), rev, "pixel"),
+                                   _G[f"reg/evaluate_pixel_rev{int(rev)}"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(reg.evaluate(Patches(dst, [2, 2])), _G["reg/evaluate_patches"], rtol=1e-9, atol=1e-9)
