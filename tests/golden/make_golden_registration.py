@@ -5,6 +5,7 @@
     multi_image_analysis/translationanalysis.py                      TranslationAnalysis: spline data points, boundary
                                                                      points, return_patch_translation, add_ / deduct_
     multi_image_analysis/imageregistration.py                        DiffeomorphicImageRegistration.evaluate / displacement
+    utils/standard_images.py                                         roi_to_mask, zeros_like                   (:12-137)
 
 loaded file by file onto an empty ``darsia`` shim (make_golden.py's way), each source executed unmodified with the
 ``annotations`` future flag.  What stands in for the parts of DarSIA that need OpenCV:
@@ -186,6 +187,36 @@ def main():
     import io
     with contextlib.redirect_stdout(io.StringIO()):
         out["reg/displacement"] = np.array(reg.displacement(), dtype=float)
+    # ---- roi_to_mask (utils/standard_images.py:73-137): integer / boolean work, bit-exact
+    class ScalarImage(Image):
+        pass
+
+    da.ScalarImage = ScalarImage
+    da.ROI = type("ROI", (), {})   # polygon ROIs live in image/roi.py (shapely); only named in an isinstance test here
+    _load(da, "utils/standard_images.py")
+    ref_img = Image(rng.random((37, 53, 3)), dimensions=[0.74, 1.59])
+    ref_img.dtype = ref_img.img.dtype
+
+    def meta_free(self):   # the stand-in's constructor takes dimensions by keyword
+        return {"dimensions": self.dimensions}
+
+    Image.metadata = meta_free
+    rois = {
+        "interior": da.CoordinateArray([[0.31, 0.52], [0.93, 0.18]]),
+        "partly_outside": da.CoordinateArray([[-0.2, 0.9], [0.4, 0.5]]),
+        "outside": da.CoordinateArray([[2.0, 2.0], [3.0, 3.0]]),
+        "full": da.CoordinateArray([[0.0, 0.74], [1.59, 0.0]]),
+        "on_voxel_edges": da.CoordinateArray([[0.30, 0.60], [0.60, 0.30]]),
+        "voxels": da.VoxelArray([[5, 7], [20, 41]]),
+        "voxels_reversed": da.VoxelArray([[30, 50], [10, 2]]),
+    }
+    out["roi/shape"], out["roi/dims"] = np.array(ref_img.img.shape), np.array(ref_img.dimensions)
+    for name, roi in rois.items():
+        out[f"roi/{name}_in"] = np.array(roi, dtype=float)
+        out[f"roi/{name}_shape_mask"] = np.array(da.roi_to_mask(roi, ref_img).img)
+        out[f"roi/{name}_voxels_mask"] = np.array(da.roi_to_mask(roi, ref_img, mode="voxels").img)
+    out["roi/union_mask"] = np.array(da.roi_to_mask([rois["interior"], rois["voxels"], rois["partly_outside"]], ref_img).img)
+    out["roi/empty_list_mask"] = np.array(da.roi_to_mask([], ref_img).img)
     np.savez_compressed(os.path.join(HERE, "registration_golden.npz"), **out)
     print("wrote", len(out), "arrays; add:", out["comp/add_status"], "deduct:", out["comp/deduct_status"])
 

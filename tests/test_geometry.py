@@ -116,3 +116,24 @@ def test_unit_coordinate_system_known_answers():
         assert isinstance(v, da.VoxelArray) and np.allclose(v, [[1, 2], [2, 3], [0, 2]])
     assert np.allclose(cs.coordinate_vector(np.array([1, 2])), [0.5, -1 / 3])
     assert np.allclose(cs.coordinate_vector(np.array([[1, 2], [2, 2]])), [[0.5, -1 / 3], [0.5, -2 / 3]])
+
+
+def test_roi_masks_equal_the_reference_function():
+    """roi_to_mask / zeros_like of the reference executed by tests/golden/make_golden_registration.py on a 37 x 53 x 3 image
+    of 0.74 x 1.59 length units: metric and voxel ROIs (inside, partly outside, outside, the whole image, on voxel edges,
+    reversed corners), both modes, a union and the empty list -- boolean masks, bit for bit."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "registration_golden.npz"))
+    img = da.Image(np.zeros(tuple(g["roi/shape"])), dimensions=list(g["roi/dims"]))
+    rois = {}
+    for name in ("interior", "partly_outside", "outside", "full", "on_voxel_edges", "voxels", "voxels_reversed"):
+        raw = g[f"roi/{name}_in"]
+        rois[name] = da.VoxelArray(raw.astype(int)) if name.startswith("voxels") else da.CoordinateArray(raw)
+        full = da.roi_to_mask(rois[name], img)
+        vox = da.roi_to_mask(rois[name], img, mode="voxels")
+        assert full.img.dtype == bool and np.array_equal(full.img, g[f"roi/{name}_shape_mask"])
+        assert isinstance(vox, da.ScalarImage) and np.array_equal(vox.img, g[f"roi/{name}_voxels_mask"])
+    union = da.roi_to_mask([rois["interior"], rois["voxels"], rois["partly_outside"]], img)
+    assert np.array_equal(union.img, g["roi/union_mask"])
+    assert np.array_equal(da.roi_to_mask([], img).img, g["roi/empty_list_mask"])
