@@ -8,12 +8,11 @@ the reference's own class: its module and the modules it drives are loaded file 
     restoration/split_bregman_tvd.py, restoration/tvd.py        TVD("heterogeneous bregman"), fresh Jacobi per call
     multi_image_analysis/concentrationanalysis.py               ConcentrationAnalysis
 
-Three things stand in for what the container lacks, none of them on the exercised paths' arithmetic:
+Two things stand in for what the container lacks, neither on the exercised paths' arithmetic:
   * ``cv2`` is registered as an EMPTY module so that ``import cv2`` at the top of those files succeeds; no cv2 function is
     called (the "gray" reduction, which is cv2.cvtColor, is not part of these vectors);
   * ``numba.njit`` is an identity decorator if numba does not import (isotropic shrinkage is not exercised);
-  * ``darsia.Image`` / ``ScalarImage`` are a minimal container (pixel array, ``copy``, ``metadata``, ``img_as`` through
-    scikit-image) for the isinstance / copy / re-wrap steps of ``__call__``.
+  * (the images are the reference's own ``OpticalImage`` / ``ScalarImage``, loaded as make_golden_image.py does).
 scikit-image must be real (``skimage.util.compare_images`` is the "absolute" difference, ``img_as_float`` converts integer
 frames): run under /opt/conda's Python 3.9 (scikit-image 0.18.3, NumPy 1.26):
 
@@ -65,35 +64,12 @@ def main():
         nb = types.ModuleType("numba")
         nb.njit = lambda *a, **k: (lambda f: f)
         sys.modules["numba"] = nb
-    da = types.ModuleType("darsia")
-    sys.modules["darsia"] = da
+    sys.path.insert(0, HERE)
+    from make_golden_image import reference_image_classes
 
-    class Image:
-        def __init__(self, img, **meta):
-            self.img = img
-            self.meta = dict(meta)
-            self.space_dim = 2
-
-        @property
-        def shape(self):
-            return self.img.shape
-
-        def copy(self):
-            return copy.deepcopy(self)
-
-        def metadata(self):
-            return dict(self.meta)
-
-        def img_as(self, data_type):
-            assert data_type is float
-            out = self.copy()
-            out.img = skimage.img_as_float(out.img)
-            return out
-
-    class ScalarImage(Image):
-        pass
-
-    da.Image, da.ScalarImage = Image, ScalarImage
+    # the reference's own Image classes (image/image.py executed with empty ``cv2`` / ``plotly`` modules, make_golden_image.py)
+    da = reference_image_classes()
+    Image, ScalarImage = da.OpticalImage, da.ScalarImage
     for rel in ("utils/array_slice.py", "utils/dtype.py", "utils/derivatives.py", "utils/linear_solvers/solver.py",
                 "utils/linear_solvers/jacobi.py", "restoration/split_bregman_tvd.py", "restoration/tvd.py",
                 "signals/reduction/signalreduction.py", "signals/reduction/monochromatic.py",
@@ -141,7 +117,7 @@ def main():
                                       da.MonochromaticReduction(color=color), None, restoration, model,
                                       **{"diff option": opt, "restoration -> model": rest_first})
         res = ca(Image(probe, name="frame"))
-        assert isinstance(res, ScalarImage) and res.meta == {"name": "frame"}
+        assert isinstance(res, ScalarImage) and res.name == "frame"
         out[f"{tag}/base"], out[f"{tag}/probe"] = base, probe
         for i, e in enumerate(extra):
             out[f"{tag}/extra{i}"] = e

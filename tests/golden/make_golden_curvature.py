@@ -50,23 +50,11 @@ def main():
                 __import__(name)
             except Exception:  # noqa: BLE001
                 sys.modules[name] = types.ModuleType(name)
-    da = types.ModuleType("darsia")
-    sys.modules["darsia"] = da
+    sys.path.insert(0, HERE)
+    from make_golden_image import reference_image_classes
 
-    class Image:
-        def __init__(self, img, **meta):
-            self.img, self.meta, self.series = img, dict(meta), False
-
-        def copy(self):
-            return copy.deepcopy(self)
-
-        def metadata(self):
-            return dict(self.meta)
-
-        def update_metadata(self, meta=None, **kw):
-            self.meta.update(meta or {}, **kw)
-
-    da.Image = Image
+    da = reference_image_classes()      # the reference's own Image classes (make_golden_image.py)
+    Image = da.ScalarImage
     _load(da, "corrections/basecorrection.py")
     _load(da, "corrections/shape/curvature.py")
 
@@ -102,7 +90,7 @@ def main():
     im = Image(rng.random((40, 56)).astype(np.float32), name="frame")
     res = cc(im)
     out["image/img"], out["image/out"] = im.img, res.img
-    out["image/is_new_object"] = np.array(res is not im and res.meta == {"name": "frame"})
+    out["image/is_new_object"] = np.array(res is not im and res.name == "frame")
     np.savez_compressed(os.path.join(HERE, "curvature_golden.npz"), **out)
     print("wrote", len(out), "arrays")
 

@@ -8,11 +8,8 @@
     utils/standard_images.py                                         roi_to_mask, zeros_like                   (:12-137)
 
 loaded file by file onto an empty ``darsia`` shim (make_golden.py's way), each source executed unmodified with the
-``annotations`` future flag.  What stands in for the parts of DarSIA that need OpenCV:
-  * ``darsia.Image``: a minimal container with the attributes Patches / CoordinateSystem / TranslationAnalysis read
-    (``img``, ``space_dim``, ``time_dim``, ``indexing``, ``dimensions``, ``origin``, ``num_voxels``, ``voxel_size``,
-    ``coordinatesystem`` -- the REFERENCE's class --, ``subregion`` by slices, ``copy``, ``metadata``).  The real class lives
-    in image/image.py, which imports cv2 / plotly;
+``annotations`` future flag.  The images are the reference's own ``darsia.Image`` (image/image.py, loaded as make_golden_image.py does: empty ``cv2`` and
+``plotly`` modules satisfy its plotting / I-O imports).  What stands in for the parts of DarSIA that need OpenCV:
   * the per-patch translation estimator (ORB + RANSAC in OpenCV, SURVEY.md section 2: out of scope): a table that hands out
     prescribed translations in the order the analysis visits the patches;
   * ``cv2`` itself is not needed by any of these files.
@@ -55,46 +52,13 @@ def _load(da, rel):
 
 
 def main():
-    da = types.ModuleType("darsia")
-    sys.modules["darsia"] = da
-    for rel in ("utils/point.py", "image/indexing.py", "image/coordinatesystem.py"):
-        _load(da, rel)
+    sys.path.insert(0, HERE)
+    from make_golden_image import reference_image_classes
 
-    class Image:
-        def __init__(self, img, dimensions=None, origin=None, **meta):
-            self.img = img
-            self.space_dim, self.time_dim, self.series, self.scalar = 2, 0, False, img.ndim == 2
-            self.indexing = "ij"
-            self.dimensions = list(dimensions) if dimensions is not None else [1, 1]
-            self.origin = da.Coordinate(np.array([0.0, self.dimensions[0]] if origin is None else origin, dtype=float))
-            self.meta = dict(meta)
-
-        @property
-        def shape(self):
-            return self.img.shape
-
-        @property
-        def num_voxels(self):
-            return list(self.img.shape[:2])
-
-        @property
-        def voxel_size(self):
-            return [self.dimensions[i] / self.num_voxels[i] for i in range(2)]
-
-        @property
-        def coordinatesystem(self):
-            return da.CoordinateSystem(self)
-
-        def subregion(self, voxels):
-            return Image(self.img[voxels], dimensions=self.dimensions, **self.meta)   # metadata of the cut-out is not exercised
-
-        def copy(self):
-            return copy.deepcopy(self)
-
-        def metadata(self):
-            return dict(self.meta)
-
-    da.Image = Image
+    # the reference's own Image / ScalarImage / CoordinateSystem / point types (image/image.py executed with empty ``cv2`` and
+    # ``plotly`` modules for its plotting / I-O imports; see make_golden_image.py)
+    da = reference_image_classes()
+    Image = da.Image
     _load(da, "image/patches.py")
     _load(da, "multi_image_analysis/translationanalysis.py")
 
@@ -188,19 +152,8 @@ def main():
     with contextlib.redirect_stdout(io.StringIO()):
         out["reg/displacement"] = np.array(reg.displacement(), dtype=float)
     # ---- roi_to_mask (utils/standard_images.py:73-137): integer / boolean work, bit-exact
-    class ScalarImage(Image):
-        pass
-
-    da.ScalarImage = ScalarImage
     da.ROI = type("ROI", (), {})   # polygon ROIs live in image/roi.py (shapely); only named in an isinstance test here
-    _load(da, "utils/standard_images.py")
-    ref_img = Image(rng.random((37, 53, 3)), dimensions=[0.74, 1.59])
-    ref_img.dtype = ref_img.img.dtype
-
-    def meta_free(self):   # the stand-in's constructor takes dimensions by keyword
-        return {"dimensions": self.dimensions}
-
-    Image.metadata = meta_free
+    ref_img = Image(rng.random((37, 53, 3)), dimensions=[0.74, 1.59], scalar=False)
     rois = {
         "interior": da.CoordinateArray([[0.31, 0.52], [0.93, 0.18]]),
         "partly_outside": da.CoordinateArray([[-0.2, 0.9], [0.4, 0.5]]),
