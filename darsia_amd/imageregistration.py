@@ -347,31 +347,67 @@ class MultiscaleDiffeomorphicImageRegistration:
 
 
 class ImageRegistration:
-    """Façade (imageregistration.py:490-659): one level for a flat ``N_patches``, multilevel for a list of
-    patch grids (per-level ``rel_overlap`` / estimator options may be lists of the same length)."""
+    """Façade (imageregistration.py:490-659): one level for a flat ``N_patches``, multilevel for a list of patch grids.
+    Keyword handling as in the reference: ``max_features`` (int), ``tol`` (float) and ``rel_overlap`` (float) are broadcast
+    over the levels or given as lists of one entry per level -- anything else is "not compatible"; with
+    ``method="onelevel"`` the first entry of every list is taken.  ``translation_estimator`` (not in the reference, whose
+    estimator is OpenCV's ORB / RANSAC) injects the per-patch estimator, one object or one per level."""
 
     def __init__(self, img_dst, method: Optional[str] = None, **kwargs) -> None:
-        assert method in (None, "multilevel", "onelevel")
+        assert method in [None, "multilevel", "onelevel"]
         n_patches = kwargs.get("N_patches", [1, 1])
+        max_features = kwargs.get("max_features", 200)
+        tol = kwargs.get("tol", 0.05)
+        rel_overlap = kwargs.get("rel_overlap", 0.0)
+        mask_dst = kwargs.get("mask_dst", None)
+        verbosity = kwargs.get("verbosity", 0)
+        estimator = kwargs.get("translation_estimator")
         nested = isinstance(n_patches, list) and all(isinstance(n, list) for n in n_patches)
         if method is None:
             method = "multilevel" if nested else "onelevel"
         self.method = method
         if method == "multilevel":
-            if not nested:
+            if not isinstance(n_patches, list):
                 n_patches = [n_patches]
             levels = len(n_patches)
-            rel_overlap = kwargs.get("rel_overlap", 0.0)
-            if not isinstance(rel_overlap, list):
+            compatible = True
+            if isinstance(max_features, int):
+                max_features = levels * [max_features]
+            else:
+                compatible = compatible and isinstance(max_features, list) and len(max_features) == levels
+            if isinstance(tol, float):
+                tol = levels * [tol]
+            else:
+                compatible = compatible and isinstance(tol, list) and len(tol) == levels
+            if isinstance(rel_overlap, float):
                 rel_overlap = levels * [rel_overlap]
-            if len(rel_overlap) != levels:
-                raise ValueError("rel_overlap must be a scalar or have one entry per level")
-            config = [{"N_patches": n_patches[i], "rel_overlap": rel_overlap[i],
-                       "translation_estimator": kwargs.get("translation_estimator")} for i in range(levels)]
-            self.registration = MultiscaleDiffeomorphicImageRegistration(
-                img_dst, config, mask_dst=kwargs.get("mask_dst", None), verbosity=kwargs.get("verbosity", 0))
+            else:
+                compatible = compatible and isinstance(rel_overlap, list) and len(rel_overlap) == levels
+            if not compatible:
+                raise ValueError("Input for the multilevel image registration is not compatible.")
+            estimators = estimator if isinstance(estimator, list) else levels * [estimator]
+            if len(estimators) != levels:
+                raise ValueError("translation_estimator must be one object or one per level")
+            config = [{"N_patches": n_patches[i], "max_features": max_features[i], "tol": tol[i], "rel_overlap": rel_overlap[i],
+                       "translation_estimator": estimators[i]} for i in range(levels)]
+            self.config = config
+            self.image_registration = MultiscaleDiffeomorphicImageRegistration(img_dst, config, mask_dst=mask_dst, verbosity=verbosity)
         else:
-            self.registration = DiffeomorphicImageRegistration(img_dst, **kwargs)
+            if nested:
+                n_patches = n_patches[0]
+            if isinstance(max_features, list):
+                max_features = max_features[0]
+            if isinstance(tol, list):
+                tol = tol[0]
+            if isinstance(rel_overlap, list):
+                rel_overlap = rel_overlap[0]
+            if isinstance(estimator, list):
+                estimator = estimator[0]
+            config = {"N_patches": n_patches, "max_features": max_features, "tol": tol, "rel_overlap": rel_overlap,
+                      "mask_dst": mask_dst, "verbosity": verbosity, "translation_estimator": estimator}
+            self.config = config
+            self.image_registration = DiffeomorphicImageRegistration(img_dst, **config)
+        self.registration = self.image_registration   # earlier name, kept
 
     def __call__(self, img, mask=None, return_transformed_dst: bool = False):
         return self.registration(img, mask=mask, return_transformed_dst=return_transformed_dst)

@@ -151,6 +151,31 @@ def main():
     import io
     with contextlib.redirect_stdout(io.StringIO()):
         out["reg/displacement"] = np.array(reg.displacement(), dtype=float)
+    # ---- ImageRegistration facade: keyword handling (imageregistration.py:490-606); construction only
+    facade = {}
+    kw_sets = {
+        "flat": dict(N_patches=[2, 3]),
+        "nested": dict(N_patches=[[2, 3], [4, 6]], rel_overlap=0.1),
+        "nested_lists": dict(N_patches=[[1, 2], [2, 3], [4, 4]], rel_overlap=[0.0, 0.1, 0.2], max_features=[100, 200, 300], tol=[0.1, 0.05, 0.02]),
+        "onelevel_of_nested": dict(method="onelevel", N_patches=[[2, 3], [4, 6]], rel_overlap=[0.3, 0.1], tol=[0.2, 0.1], max_features=[50, 60]),
+        "multilevel_of_flat_grid_list": dict(method="multilevel", N_patches=[[3, 3]], rel_overlap=0.25),
+        "bad_int_overlap": dict(N_patches=[[2, 3], [4, 6]], rel_overlap=0),
+        "bad_length": dict(N_patches=[[2, 3], [4, 6]], rel_overlap=[0.1]),
+        "bad_tol_type": dict(N_patches=[[2, 3], [4, 6]], tol=1),
+    }
+    for name, kw in kw_sets.items():
+        kw = dict(kw)
+        method = kw.pop("method", None)
+        try:
+            r = da.ImageRegistration(dst, method, **kw)
+            inner = r.image_registration
+            if type(inner).__name__ == "MultiscaleDiffeomorphicImageRegistration":
+                facade[name] = ("multilevel", [dict(c) for c in inner.config])
+            else:
+                facade[name] = ("onelevel", dict(N_patches=list(inner.N_patches), rel_overlap=inner.rel_overlap))
+        except Exception as e:  # noqa: BLE001
+            facade[name] = ("error", type(e).__name__ + ": " + str(e))
+    out["facade/repr"] = np.array(repr(facade))
     # ---- roi_to_mask (utils/standard_images.py:73-137): integer / boolean work, bit-exact
     da.ROI = type("ROI", (), {})   # polygon ROIs live in image/roi.py (shapely); only named in an isinstance test here
     ref_img = Image(rng.random((37, 53, 3)), dimensions=[0.74, 1.59], scalar=False)

@@ -225,3 +225,40 @@ def test_evaluate_equals_the_reference_class():
         np.testing.assert_allclose(reg.evaluate(_G["reg/pts_pixel"].copy(), rev, "pixel"),
                                    _G[f"reg/evaluate_pixel_rev{int(rev)}"], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(reg.evaluate(Patches(dst, [2, 2])), _G["reg/evaluate_patches"], rtol=1e-9, atol=1e-9)
+
+
+def test_facade_keyword_handling_equals_the_reference_class():
+    """ImageRegistration.__init__ (imageregistration.py:490-606) executed by the golden generator: which driver is built
+    and with which per-level configuration, and which inputs are refused."""
+    import ast
+
+    from darsia_amd.imageregistration import ImageRegistration
+
+    want = ast.literal_eval(str(_G["facade/repr"]))
+    dst = da.Image(np.zeros((40, 52), np.float32), dimensions=[0.8, 1.04])
+    kw_sets = {
+        "flat": dict(N_patches=[2, 3]),
+        "nested": dict(N_patches=[[2, 3], [4, 6]], rel_overlap=0.1),
+        "nested_lists": dict(N_patches=[[1, 2], [2, 3], [4, 4]], rel_overlap=[0.0, 0.1, 0.2], max_features=[100, 200, 300], tol=[0.1, 0.05, 0.02]),
+        "onelevel_of_nested": dict(method="onelevel", N_patches=[[2, 3], [4, 6]], rel_overlap=[0.3, 0.1], tol=[0.2, 0.1], max_features=[50, 60]),
+        "multilevel_of_flat_grid_list": dict(method="multilevel", N_patches=[[3, 3]], rel_overlap=0.25),
+        "bad_int_overlap": dict(N_patches=[[2, 3], [4, 6]], rel_overlap=0),
+        "bad_length": dict(N_patches=[[2, 3], [4, 6]], rel_overlap=[0.1]),
+        "bad_tol_type": dict(N_patches=[[2, 3], [4, 6]], tol=1),
+    }
+    assert set(kw_sets) == set(want)
+    for name, kw in kw_sets.items():
+        kw = dict(kw)
+        method = kw.pop("method", None)
+        kind, payload = want[name]
+        if kind == "error":
+            with pytest.raises(ValueError, match="not compatible"):
+                ImageRegistration(dst, method, **kw)
+            continue
+        r = ImageRegistration(dst, method, **kw)
+        assert r.method == kind
+        if kind == "multilevel":
+            got = [{k: c[k] for k in ("N_patches", "max_features", "tol", "rel_overlap")} for c in r.image_registration.config]
+            assert got == payload
+        else:
+            assert dict(N_patches=list(r.image_registration.N_patches), rel_overlap=r.image_registration.rel_overlap) == payload
