@@ -190,9 +190,13 @@ class PiecewisePerspectiveTransform:
         _lib.check(_lib.load().dxh_warp_patches(_lib.default_device(), h, w, chans, _lib.ptr(src),
                                                  C.cast(table, C.c_void_p), len(records), _lib.ptr(canvas)))
         out = canvas.astype(base.dtype, copy=False)
-        # the reference returns a new image with the base's metadata (piecewiseperspective.py:143-145); copy the
-        # container without its pixel array (a deep copy of the base would cost more than the warp)
-        return with_array(patches.base, out) if hasattr(patches.base, "copy") else out
+        # the reference returns ``darsia.Image(img=..., **patches.base.metadata())`` -- the BASE class, whatever the class of
+        # the patched image (piecewiseperspective.py:143-145)
+        base_obj = patches.base
+        if hasattr(base_obj, "metadata"):
+            image_cls = next((c for c in type(base_obj).__mro__ if c.__name__ == "Image"), type(base_obj))
+            return image_cls(out, **copy.copy(base_obj.metadata()))
+        return with_array(base_obj, out) if hasattr(base_obj, "copy") else out
 
 
 def evaluate_rbf(rbf, points: np.ndarray) -> np.ndarray:

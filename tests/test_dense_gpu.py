@@ -207,3 +207,25 @@ def test_displacement_field_equals_the_reference_class():
     field = reg.displacement()
     assert field.shape == g["reg/displacement"].shape == (40 * 52, 2)
     np.testing.assert_allclose(field, g["reg/displacement"], rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.parametrize("tag", ["gray_f32", "rgb_f32_rev", "gray_u8", "rgb_f64"])
+def test_find_and_warp_against_the_reference_loop(tag):
+    """The device warp against the reference's own find_and_warp loop executed on its own Patches / Image classes, with the
+    two OpenCV calls inside answered by the oracle's restatement (tests/golden/make_golden_warp_assembly.py): canvas bit for
+    bit, and the result is a base-class Image carrying the patched image's metadata, as in the reference."""
+    import os
+
+    from test_warp_assembly_golden_cpu import displacement_for
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "warp_assembly_golden.npz"))
+    img = g[f"{tag}/img"]
+    h, w = img.shape[:2]
+    cls = da.ScalarImage if img.ndim == 2 else da.OpticalImage
+    base = cls(img.copy(), dimensions=[0.5 * h / 100, 0.5 * w / 100], name=tag)
+    patches = da.Patches(base, [int(v) for v in g[f"{tag}/n"]], rel_overlap=0.0)
+    res = da.PiecewisePerspectiveTransform().find_and_warp(patches, displacement_for(tag), bool(g[f"{tag}/reverse"]))
+    want = g[f"{tag}/out"]
+    assert res.img.dtype == want.dtype and np.array_equal(res.img, want)
+    assert [type(res).__name__, str(res.name), str(list(res.dimensions))] == list(g[f"{tag}/meta"])
+    assert res.scalar == (img.ndim == 2)
