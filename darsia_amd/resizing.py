@@ -200,7 +200,9 @@ class Resize:
                             interpolation=interpolation)
         resized = np.reshape(resized, (*resized.shape[:2], *original_shape[2:]))
         if self.is_conservative or (extensive and not self._conservative_explicit):
-            resized = resized * (np.prod(arr.shape[:2]) / np.prod(resized.shape[:2]))
+            # in place, as the reference (resize.py:189-192): the result keeps the array's float type (and an integer
+            # array refuses the float factor there as here)
+            resized *= np.prod(arr.shape[:2]) / np.prod(resized.shape[:2])
         if input_is_image:
             return type(img)(resized, **img.metadata())
         return resized

@@ -91,3 +91,44 @@ def test_reference_resize_unit_tests():
     # an explicit choice wins over the image type (restoration/resize.py:186-188)
     plain = da.Resize(shape=(2, 2), **{"resize conservative": False})(ext)
     assert np.isclose(np.sum(plain.img), np.sum(ext.img) / 4)
+
+
+def test_resize_assembly_against_the_reference_class():
+    """The reference's own Resize / resize / equalize_voxel_size executed on its own Image classes, with cv2.resize / split /
+    merge answered by the oracle's restatement (tests/golden/make_golden_resize_assembly.py): keyword handling and attributes,
+    channel handling, dtype conversion, conservative rescaling, Image re-wrapping -- results bit for bit."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "resize_assembly_golden.npz"))
+    ref = da.OpticalImage(np.zeros((30, 40, 3)), dimensions=[0.3, 0.4])
+    cases = {
+        "keyed": (dict(key="example ", **{"example resize x": 0.5, "example resize y": 0.25, "example resize interpolation": "inter_area",
+                                           "example resize conservative": True}), "rgb"),
+        "general_factor": (dict(**{"resize": 0.5, "resize interpolation": "inter_linear"}), "rgb"),
+        "shape_nearest": (dict(shape=(33, 47), interpolation="inter_nearest"), "gray64"),
+        "shape_default_interp": (dict(shape=(90, 120)), "rgb"),
+        "fx_fy_area": (dict(fx=0.5, fy=0.5, interpolation="inter_area"), "u8"),
+        "dtype_before": (dict(fx=0.5, fy=0.5, interpolation="inter_area", dtype=np.float32), "u8"),
+        "ref_image": (dict(ref_image=ref, interpolation="inter_linear"), "rgb"),
+        "identity": (dict(), "gray64"),
+    }
+    for name, (kw, which) in cases.items():
+        r = da.Resize(**kw)
+        attrs = repr((r.shape, r.dsize, r.fx, r.fy, r.interpolation, r.is_conservative, r._conservative_explicit))
+        assert attrs == str(g[f"{name}/attrs"]), name
+        out = r(g[f"in/{which}"])
+        want = g[f"{name}/out"]
+        assert out.dtype == want.dtype and out.shape == want.shape and np.array_equal(out, want), name
+    assert str(g["bad_interpolation"]) == "NotImplementedError"
+    im = da.OpticalImage(g["in/rgb"].astype(np.float64), dimensions=[0.6, 0.8], name="photo")
+    small = da.resize(im, shape=(30, 40), interpolation="inter_area")
+    assert [type(small).__name__, str(small.name), str(list(small.dimensions))] == list(g["image/meta"])
+    assert np.array_equal(small.img, g["image/out"])
+    ext = da.ExtensiveImage(np.arange(1.0, 17.0).reshape(4, 4), dimensions=[1, 1], scalar=True)
+    assert np.array_equal(da.Resize(shape=(2, 2))(ext).img, g["ext/default"])
+    assert np.array_equal(da.Resize(shape=(2, 2), **{"resize conservative": False})(ext).img, g["ext/explicit_off"])
+    assert np.array_equal(da.resize(ext, shape=(2, 2)).img, g["ext/function"])
+    eq = da.equalize_voxel_size(da.OpticalImage(g["in/rgb"].astype(np.float64), dimensions=[0.6, 1.6]))
+    assert tuple(eq.img.shape) == tuple(g["eq/default_shape"]) and np.array_equal(eq.img, g["eq/default_out"])
+    eq2 = da.equalize_voxel_size(da.Image(np.ones((10, 10)), width=2, height=1, scalar=True), voxel_size=0.05)
+    assert tuple(eq2.img.shape) == tuple(g["eq/explicit_shape"])
