@@ -74,7 +74,9 @@ def extract_quadrilateral_ROI(img_src: np.ndarray, pts_src=None, indexing: str =
     """Perspective extraction of a quadrilateral (image/subregions.py:31-176: ``cv2.getPerspectiveTransform`` +
     ``cv2.warpPerspective(img.astype(float32), P, (width, height), INTER_LINEAR)``, cast back to the input dtype).
     The warp runs on the device with OpenCV's float32 fixed-point bilinear arithmetic (unpinned)."""
-    if interpolation != "inter_linear":
+    if interpolation not in ("inter_linear", "inter_area"):
+        # "inter_area" never sets the flag in the reference (subregions.py:157-158 compares instead of assigning), so
+        # OpenCV's default, INTER_LINEAR, is what it has always run with
         raise NotImplementedError("only 'inter_linear' is available on the device")
     scalar = img_src.ndim == 2
     original_shape = img_src.shape[:2]
@@ -85,8 +87,6 @@ def extract_quadrilateral_ROI(img_src: np.ndarray, pts_src=None, indexing: str =
         height = min(original_height, int(1.0 / aspect_ratio * float(original_width)))
     else:
         height, width = kwargs.get("shape", original_shape)
-    if height > original_shape[0] or width > original_shape[1]:
-        raise NotImplementedError("target larger than the source image")
     if pts_src is None:
         pts_src = np.array([[0, 0], [original_shape[0], 0], [original_shape[0], original_shape[1]], [0, original_shape[1]]])
         if indexing == "reverse matrix":
@@ -122,10 +122,16 @@ def extract_quadrilateral_ROI(img_src: np.ndarray, pts_src=None, indexing: str =
     rec.bw0 = _opencv_block_width(int(width), int(height))
     _lib.require_gpu()
     src = np.ascontiguousarray(img_src, dtype=np.float32)
+    if height > h or width > w:
+        # the kernel writes a canvas of the source's shape: a target larger than the source gets both embedded in their
+        # common bounding shape, the source rectangle (sh, sw) still ends where the image ends
+        big = np.zeros((max(h, int(height)), max(w, int(width))) + src.shape[2:], np.float32)
+        big[:h, :w] = src
+        src = big
     canvas = np.empty(src.shape, src.dtype)
     table = (_lib.WarpPatch * 1)(rec)
-    _lib.check(_lib.load().dxh_warp_patches(_lib.default_device(), h, w, chans, _lib.ptr(src), C.cast(table, C.c_void_p), 1,
-                                             _lib.ptr(canvas)))
+    _lib.check(_lib.load().dxh_warp_patches(_lib.default_device(), src.shape[0], src.shape[1], chans, _lib.ptr(src),
+                                             C.cast(table, C.c_void_p), 1, _lib.ptr(canvas)))
     return np.ascontiguousarray(canvas[:height, :width]).astype(img_src.dtype)
 
 
@@ -181,17 +187,54 @@ class BaseCorrection(ABC):
         ...
 
 
+_CURVATURE_SECTIONS = {
+    # section -> (key, default) the reference keeps (curvature.py:44-93 and 113-162); everything else is dropped
+    "init": (("horizontal_bulge", 0.0), ("vertical_bulge", 0.0)),
+    "crop": (("pts_src", None), ("width", 1.0), ("height", 1.0), ("in meters", True)),
+    "bulge": (("horizontal_bulge", 0.0), ("horizontal_center_offset", 0), ("vertical_bulge", 0.0), ("vertical_center_offset", 0)),
+    "stretch": (("horizontal_stretch", 0.0), ("horizontal_center_offset", 0), ("vertical_stretch", 0.0), ("vertical_center_offset", 0)),
+}
+
+
+def load_curvature_correction_config_from_dict(sec: dict, where: str = "config") -> dict:
+    """The normal form the reference gives a dictionary configuration (curvature.py:97-164): only the four sections, only
+    their known keys with the defaults filled in, and the crop corners as a ``VoxelArray`` -- i.e. ``pts_src`` of a dictionary
+    (or TOML) configuration is read as (row, col), whereas a JSON file, which is taken as it stands, keeps
+    ``extract_quadrilateral_ROI``'s (col, row) reading of plain lists."""
+    from .geometry import make_voxel
+
+    config: dict = {}
+    for name, keys in _CURVATURE_SECTIONS.items():
+        if name not in sec:
+            warn(f"No 'curvature.{name}' section found in {where}.")
+            continue
+        if sec[name] is None:
+            continue
+        config[name] = {k: (make_voxel(sec[name].get(k, [])) if k == "pts_src" else sec[name].get(k, d)) for k, d in keys}
+    return config
+
+
+def load_curvature_correction_config_from_toml(path: Path) -> dict:
+    """curvature.py:20-94: the ``[curvature]`` table of a TOML file, normalised as above."""
+    try:
+        import tomllib
+    except ImportError:  # Python < 3.11
+        raise NotImplementedError("TOML configurations need Python >= 3.11 (tomllib)") from None
+    data = tomllib.loads(Path(path).read_text())
+    if "curvature" not in data:
+        warn(f"No 'curvature' section found in {path}.")
+        return {}
+    return load_curvature_correction_config_from_dict(data["curvature"], str(path))
+
+
 class CurvatureCorrection(BaseCorrection):
     """Polynomial curvature correction (curvature.py:166-985): config sections ``init`` / ``crop`` / ``bulge`` /
     ``stretch`` applied in that order; the transformed coordinate grid is cached per object."""
 
     _pure = True
 
-    def __init__(self, config: Optional[Union[dict, str, Path]] = None, **kwargs) -> None:
-        if isinstance(config, dict):
-            self.config = {k: (dict(v) if isinstance(v, dict) else v) for k, v in config.items()}
-        elif config is not None:
-            self.config = json.loads(Path(config).read_text())
+    def __init__(self, config: Optional[Union[dict, str, Path, list]] = None, **kwargs) -> None:
+        self.setup_config(config)
         if "image" in kwargs:
             im_source = kwargs["image"]
             if not isinstance(im_source, np.ndarray):
@@ -202,19 +245,44 @@ class CurvatureCorrection(BaseCorrection):
             self.in_meters = kwargs.get("in_meters", True)
             self.width = kwargs.get("width", 1.0)
             self.height = kwargs.get("height", 1.0)
-            if not hasattr(self, "config"):
-                self.config = {}
-        elif not hasattr(self, "config"):
+        else:
             warn("No image provided. Please provide an image or a config file.")
         self.resize_factor = kwargs.get("resize_factor", 1.0)
-        if not math.isclose(self.resize_factor, 1.0) and hasattr(self, "config"):
+        if not math.isclose(self.resize_factor, 1.0):
             self._adapt_config()
         self.cache: dict = {}
-        self.use_cache = bool(getattr(self, "config", {}).get("use_cache", False))
+        self.use_cache = bool(self.config.get("use_cache", False))
         if self.use_cache:
             self.cache_path = Path(self.config.get("cache", "./cache/curvature_transformation.npy"))
             self.cache_path.parents[0].mkdir(parents=True, exist_ok=True)
         self.interpolation_order: int = kwargs.get("interpolation_order", 1)
+
+    def setup_config(self, config=None) -> None:
+        """curvature.py:264-288: a dictionary is normalised, a JSON file is taken as it stands, a list of files is merged."""
+        def read(path: Path) -> dict:
+            if path.suffix == ".toml":
+                return load_curvature_correction_config_from_toml(path)
+            return json.loads(path.read_text())
+
+        if isinstance(config, dict):
+            self.config = load_curvature_correction_config_from_dict(config)
+        elif isinstance(config, (str, Path)):
+            self.config = read(Path(config))
+        elif isinstance(config, list):
+            self.config = {}
+            for path in config:
+                self.config.update(read(Path(path)))
+        else:
+            self.config = {}
+
+    def write_config_to_file(self, path) -> None:
+        """curvature.py:292-302."""
+        with open(Path(path), "w") as outfile:
+            json.dump(self.config, outfile, indent=4)
+
+    def read_config_from_file(self, path) -> None:
+        with open(Path(path), "r") as openfile:
+            self.config = json.load(openfile)
 
     # ---- persistence (curvature.py:312-350: npz with the class name and the config) --------------------------
     def save(self, path) -> None:

@@ -4,7 +4,9 @@ of the SciPy gather it rests on.
 TEST INFRASTRUCTURE -- NOT PRODUCT CODE (same rule as oracle/tvd_numpy.py).  PINNED: grid and corrected image of eight
 configurations equal, bit for bit, what the reference's own CurvatureCorrection returns (tests/golden/curvature_golden.npz, made
 by tests/golden/make_golden_curvature.py, which executes curvature.py / basecorrection.py; tests/test_curvature_golden_cpu.py).
-The "crop" step (cv2.warpPerspective) is not in those vectors and stays unpinned.
+The "crop" step: how the reference assembles it (configuration normal form, corner conventions, target size, dtype handling) is
+pinned by tests/golden/make_golden_warp_assembly.py, which executes the reference's class and function with their two OpenCV
+calls answered by oracle/warp_numpy.py; the arithmetic of cv2.warpPerspective itself stays unpinned.
 
 * ``map_coordinates``: ``scipy.ndimage.map_coordinates(input2d, grid, order=0|1)`` with the default mode
   "constant", cval 0 (call site curvature.py:943-945).  SciPy is a third-party, unpinned dependency of the

@@ -9,6 +9,10 @@ algorithms (oracle/warp_numpy.py: get_perspective_transform, warp_perspective). 
 around those two calls on the reference's code, and nothing about the two calls themselves, whose parity with OpenCV
 stays unpinned (oracle/warp_numpy.py header).
 
+The same for ``extract_quadrilateral_ROI`` (image/subregions.py:31-176: corner conventions, target size from a shape or from
+physical width / height, destination points, cast back to the input dtype) and for the "crop" step of ``CurvatureCorrection``
+(corrections/shape/curvature.py), whose coordinate images pass through it.
+
     /opt/conda/bin/python3.9 tests/golden/make_golden_warp_assembly.py      # -> warp_assembly_golden.npz
 
 TEST INFRASTRUCTURE, build container only.  The output holds inputs and expected outputs (data, no source).
@@ -66,6 +70,51 @@ def main():
         out[f"{tag}/img"], out[f"{tag}/out"] = img, res.img
         out[f"{tag}/n"], out[f"{tag}/reverse"], out[f"{tag}/amp"] = np.array(n), np.array(reverse), amp
         out[f"{tag}/meta"] = np.array([type(res).__name__, str(res.name), str(list(res.dimensions))])
+    # ---- extract_quadrilateral_ROI (image/subregions.py:31-176) and the crop step of CurvatureCorrection
+    cv2.INTER_NEAREST, cv2.INTER_AREA = 0, 3
+    if "tomllib" not in sys.modules:
+        try:
+            import tomllib  # noqa: F401
+        except Exception:  # noqa: BLE001
+            sys.modules["tomllib"] = types.ModuleType("tomllib")
+    _load(da, "image/subregions.py")
+    _load(da, "corrections/basecorrection.py")
+    _load(da, "corrections/shape/curvature.py")
+    import warnings
+    warnings.simplefilter("ignore")
+    src32 = rng.random((70, 90)).astype(np.float32)
+    src_rgb8 = (rng.random((64, 80, 3)) * 255).astype(np.uint8)
+    src_rgb64 = rng.random((50, 66, 3))
+    out["roi/src32"], out["roi/src_rgb8"], out["roi/src_rgb64"] = src32, src_rgb8, src_rgb64
+    quad = [[8.0, 5.0], [6.0, 60.0], [80.0, 64.0], [84.0, 3.0]]            # (col, row): reverse matrix indexing
+    out["roi/quad"] = np.array(quad)
+    out["roi/default"] = da.extract_quadrilateral_ROI(src32)
+    out["roi/list_reverse"] = da.extract_quadrilateral_ROI(src32, pts_src=quad)
+    out["roi/list_matrix"] = da.extract_quadrilateral_ROI(src32, pts_src=[[q[1], q[0]] for q in quad], indexing="matrix")
+    out["roi/voxels"] = da.extract_quadrilateral_ROI(src32, pts_src=da.VoxelArray([[int(q[1]), int(q[0])] for q in quad]))
+    out["roi/width_height"] = da.extract_quadrilateral_ROI(src_rgb8, pts_src=[[4, 4], [4, 58], [74, 60], [76, 2]], width=1.5, height=1.0)
+    out["roi/shape_kw"] = da.extract_quadrilateral_ROI(src_rgb64, pts_src=[[3, 2], [2, 45], [60, 47], [62, 4]], shape=(40, 50))
+    out["roi/pts_dst"] = da.extract_quadrilateral_ROI(src32, pts_src=quad, pts_dst=[[0, 0], [0, 50], [70, 50], [70, 0]], shape=(55, 75))
+    crop_cfg = {"init": dict(horizontal_bulge=4e-7, vertical_bulge=1e-7),
+                "crop": dict(pts_src=[[5, 4], [4, 62], [85, 64], [86, 3]], width=1.4, height=1.0),
+                "bulge": dict(horizontal_bulge=-2e-7, vertical_bulge=3e-7)}
+    cc = da.CurvatureCorrection(config=crop_cfg)
+    frame = rng.random((70, 90, 3)).astype(np.float32)
+    res = cc(frame)
+    out["crop/frame"], out["crop/out"] = frame, res
+    out["crop/grid"], out["crop/shape"] = np.array(cc.cache["grid"]), np.array(cc.cache["shape"])
+    out["crop/metadata"] = np.array(repr({k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in cc.correct_metadata().items()}))
+    # what the reference makes of a dictionary configuration (curvature.py:97-164), incl. keys it drops and defaults it adds
+    messy = {"init": dict(horizontal_bulge=1e-7, horizontal_center_offset=9), "crop": dict(pts_src=[[1, 2], [3, 40], [50, 41], [52, 3]]),
+             "stretch": dict(vertical_stretch=2e-7), "use_cache": True, "cache": "somewhere.npy"}
+    plain = lambda cfg: {k: {kk: (np.asarray(vv).tolist() if kk == "pts_src" else vv) for kk, vv in v.items()} for k, v in cfg.items()}
+    norm = da.CurvatureCorrection(config=messy)
+    out["cfg/normalised"] = np.array(repr(plain(norm.config)))
+    out["cfg/pts_type"] = np.array(type(norm.config["crop"]["pts_src"]).__name__)
+    out["cfg/use_cache"] = np.array(norm.use_cache)
+    scaled = da.CurvatureCorrection(config=messy, resize_factor=0.5)
+    out["cfg/scaled"] = np.array(repr(plain(scaled.config)))
+    out["cfg/scaled_pts_type"] = np.array(type(scaled.config["crop"]["pts_src"]).__name__)
     np.savez_compressed(os.path.join(HERE, "warp_assembly_golden.npz"), **out)
     print("wrote", len(out), "arrays;", {k: v.dtype.name for k, v in out.items() if k.endswith("/out")})
 

@@ -85,7 +85,7 @@ def test_crop_step_and_metadata():
         ar = kw["width"] / kw["height"]
         width, height = min(w, int(ar * float(h))), min(h, int(1.0 / ar * float(w)))
         dst = np.array([[0, 0], [0, height - 1], [width - 1, height - 1], [width - 1, 0]], np.float32)
-        p = wo.get_perspective_transform(np.asarray(kw["pts_src"], np.float32), dst)
+        p = wo.get_perspective_transform(np.fliplr(np.asarray(kw["pts_src"], np.float32)), dst)  # dictionary configs: (row, col)
         return wo.warp_perspective(pixels.astype(np.float32), p, width, height).astype(pixels.dtype)
 
     grid, shape = cu.precompute_grid(img.shape, config, crop=crop_oracle)
@@ -161,3 +161,67 @@ def test_image_branch_against_the_reference_class():
     res = cc(im)
     assert bool(g["image/is_new_object"]) and res is not im and res.name == "frame"
     assert np.array_equal(res.img, g["image/out"])
+
+
+def _roi_golden():
+    import os
+
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "warp_assembly_golden.npz"))
+
+
+def test_extract_quadrilateral_roi_against_the_reference_function():
+    """image/subregions.py:31-176 executed as it stands, its two OpenCV calls answered by the oracle's restatement
+    (tests/golden/make_golden_warp_assembly.py): corner conventions (lists in both indexings, VoxelArray), target size from a
+    shape or from physical width / height, destination points, and the cast back to the input's dtype -- bit for bit."""
+    import warnings
+
+    g = _roi_golden()
+    src32, rgb8, rgb64 = g["roi/src32"], g["roi/src_rgb8"], g["roi/src_rgb64"]
+    quad = g["roi/quad"].tolist()
+    cases = {
+        "default": lambda: da.extract_quadrilateral_ROI(src32),
+        "list_reverse": lambda: da.extract_quadrilateral_ROI(src32, pts_src=quad),
+        "list_matrix": lambda: da.extract_quadrilateral_ROI(src32, pts_src=[[q[1], q[0]] for q in quad], indexing="matrix"),
+        "voxels": lambda: da.extract_quadrilateral_ROI(src32, pts_src=da.VoxelArray([[int(q[1]), int(q[0])] for q in quad])),
+        "width_height": lambda: da.extract_quadrilateral_ROI(rgb8, pts_src=[[4, 4], [4, 58], [74, 60], [76, 2]], width=1.5, height=1.0),
+        "shape_kw": lambda: da.extract_quadrilateral_ROI(rgb64, pts_src=[[3, 2], [2, 45], [60, 47], [62, 4]], shape=(40, 50)),
+        "pts_dst": lambda: da.extract_quadrilateral_ROI(src32, pts_src=quad, pts_dst=[[0, 0], [0, 50], [70, 50], [70, 0]], shape=(55, 75)),
+    }
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for name, call in cases.items():
+            got, want = call(), g[f"roi/{name}"]
+            assert got.shape == want.shape and got.dtype == want.dtype, name
+            assert np.array_equal(got, want), name
+        # "inter_area" has always run as INTER_LINEAR in the reference (subregions.py:157-158 never assigns the flag)
+        assert np.array_equal(da.extract_quadrilateral_ROI(src32, pts_src=quad, interpolation="inter_area"), g["roi/list_reverse"])
+        with pytest.raises(NotImplementedError):
+            da.extract_quadrilateral_ROI(src32, pts_src=quad, interpolation="bicubic")
+
+
+def test_extract_quadrilateral_roi_target_larger_than_the_source():
+    img = synthetic_image(40, 60, 3)
+    quad = [[5.0, 4.0], [4.0, 35.0], [55.0, 36.0], [56.0, 3.0]]
+    got = da.extract_quadrilateral_ROI(img, pts_src=quad, shape=(90, 130))
+    dst = np.array([[0, 0], [0, 89], [129, 89], [129, 0]], np.float32)
+    want = wo.warp_perspective(img, wo.get_perspective_transform(np.asarray(quad, np.float32), dst), 130, 90)
+    assert got.shape == (90, 130, 3) and np.array_equal(got, want)
+
+
+def test_crop_step_against_the_reference_class():
+    """CurvatureCorrection with a "crop" entry: the reference's class executed (its extract_quadrilateral_ROI calls answered as
+    above); cached grid, corrected frame and corrected metadata."""
+    import warnings
+
+    g = _roi_golden()
+    cfg = {"init": dict(horizontal_bulge=4e-7, vertical_bulge=1e-7),
+           "crop": dict(pts_src=[[5, 4], [4, 62], [85, 64], [86, 3]], width=1.4, height=1.0),
+           "bulge": dict(horizontal_bulge=-2e-7, vertical_bulge=3e-7)}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cc = da.CurvatureCorrection(config=cfg)
+        out = cc(g["crop/frame"])
+    assert np.array_equal(cc.cache["grid"], g["crop/grid"]) and tuple(cc.cache["shape"]) == tuple(g["crop/shape"])
+    assert out.dtype == g["crop/out"].dtype and np.array_equal(out, g["crop/out"])
+    meta = {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in cc.correct_metadata().items()}
+    assert repr(meta) == str(g["crop/metadata"])
