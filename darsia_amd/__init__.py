@@ -38,6 +38,7 @@ __version__ = "0.1.0"
 from .corrections import (  # noqa: F401,E402
     BaseCorrection,
     CurvatureCorrection,
+    DeformationCorrection,
     load_curvature_correction_config_from_dict,
     load_curvature_correction_config_from_toml,
     extract_quadrilateral_ROI,

@@ -187,6 +187,41 @@ class BaseCorrection(ABC):
         ...
 
 
+class DeformationCorrection(BaseCorrection):
+    """Local deformation correction: ``ImageRegistration`` against a baseline wrapped as a correction
+    (corrections/shape/deformation.py:15-61).  ``config`` holds the registration's keywords (``N_patches``, ``rel_overlap``,
+    ``max_features``, ``tol``, ``mask_dst``, ``verbosity`` ...) and ``active`` (default True); ``None`` switches the
+    correction off and arrays pass through untouched.  As it stands the reference's class cannot be instantiated (it leaves
+    BaseCorrection's abstract ``save`` / ``load`` undefined: TypeError); here they store / restore the configuration."""
+
+    def __init__(self, base, config: Optional[dict]) -> None:
+        self.base = base
+        self._configure(config)
+
+    def _configure(self, config: Optional[dict]) -> None:
+        from .imageregistration import ImageRegistration
+
+        self.config = None if config is None else dict(config)
+        self.active = False if config is None else config.get("active", True)
+        if self.active:
+            self.image_registration = ImageRegistration(self.base, **config)
+
+    def save(self, path) -> None:
+        np.savez(path, class_name=type(self).__name__, config=np.array(self.config, dtype=object))
+
+    def load(self, path) -> None:
+        data = np.load(path, allow_pickle=True)
+        if "config" not in data:
+            raise ValueError("Invalid file format.")
+        self._configure(data["config"].item())
+
+    def correct_array(self, img: np.ndarray) -> np.ndarray:
+        """The array registered onto the baseline; it is read with the baseline's metadata (deformation.py:55-58)."""
+        if not self.active:
+            return img
+        return self.image_registration(Image(img, **self.base.metadata())).img
+
+
 _CURVATURE_SECTIONS = {
     # section -> (key, default) the reference keeps (curvature.py:44-93 and 113-162); everything else is dropped
     "init": (("horizontal_bulge", 0.0), ("vertical_bulge", 0.0)),

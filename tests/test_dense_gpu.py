@@ -175,6 +175,32 @@ def test_registration_end_to_end_recovers_a_known_warp():
     assert np.array_equal(again.img, out.img)
 
 
+def test_deformation_correction_wraps_the_registration(tmp_path):
+    """corrections/shape/deformation.py:15-61: the correction IS the registration against its baseline -- on arrays (read with
+    the baseline's metadata) and on Images (BaseCorrection protocol); ``config=None`` or ``active=False`` pass arrays through."""
+    from scipy.ndimage import map_coordinates
+
+    h, w = 192, 256
+    dst = _textured(h, w, 11)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    field = np.sin(np.pi * yy / h) * np.sin(np.pi * xx / w)
+    src = map_coordinates(dst, [yy - 1.5 * field, xx + 2.5 * field], order=1, mode="nearest").astype(np.float32)
+    base = da.ScalarImage(dst, dimensions=[0.75, 1.0], name="baseline")
+    config = {"N_patches": [4, 4], "rel_overlap": 0.1}
+    want = da.ImageRegistration(base, **config)(da.Image(src, **base.metadata()))
+    corr = da.DeformationCorrection(base, config)
+    assert corr.active and np.array_equal(corr.correct_array(src), want.img)
+    img = da.ScalarImage(src.copy(), dimensions=[0.75, 1.0], name="frame")
+    res = corr(img)
+    assert res is not img and res.name == "frame" and np.array_equal(res.img, want.img) and np.array_equal(img.img, src)
+    corr.save(tmp_path / "deformation.npz")
+    other = da.DeformationCorrection(base, None)
+    other.load(tmp_path / "deformation.npz")
+    assert other.active and np.array_equal(other.correct_array(src), want.img)
+    for off in (da.DeformationCorrection(base, None), da.DeformationCorrection(base, {"active": False, "N_patches": [4, 4]})):
+        assert not off.active and not hasattr(off, "image_registration") and off.correct_array(src) is src
+
+
 def test_multilevel_registration_handles_a_larger_warp():
     from scipy.ndimage import map_coordinates
 
