@@ -26,7 +26,34 @@ ops = {
     "curvature": lambda: da.CurvatureCorrection(config={"bulge": dict(horizontal_bulge=1e-7)})(img),
     "affine": lambda: da.apply_affine_balance(img, np.eye(3), np.zeros(3)),
     "errors": lambda: [None for _ in range(1) if not _try()],
+    # round 2 entry points
+    "tvd banded": lambda: solve_banded(img, 0.1, 1.0, None, 12, nbands=3),
+    "tvd banded het": lambda: solve_banded(img, mu, 1.0, 0.2, 9, nbands=2),
+    "tvd kqv": lambda: da.split_bregman_tvd(img, mu=mu, ell=0.2, max_num_iter=9),
+    "tvd device chain": lambda: _chain(),
+    "concentration call": lambda: ca(frames[0]),
+    "concentration map": lambda: list(ca.map(frames)),
+    "concentration chambolle": lambda: ca_ch(frames[1]),
+    "tps pair / displacement": lambda: reg.displacement(),
+    "registration": lambda: reg(frames_gray[1]),
+    "roi extraction": lambda: da.extract_quadrilateral_ROI(img, pts_src=[[5, 4], [4, 590], [880, 592], [890, 3]], shape=(500, 700)),
 }
+from darsia_amd.restoration.split_bregman_tvd import solve_banded
+base = da.OpticalImage(img)
+frames = [da.OpticalImage(np.clip(img + 0.05 * k, 0, 1).astype(np.float32)) for k in range(1, 4)]
+model = da.CombinedModel([da.LinearModel(scaling=2.0, offset=0.0), da.ClipModel(min_value=0.0, max_value=1.0)])
+ca = da.ConcentrationAnalysis(base, da.MonochromaticReduction(color="red"), None,
+                              da.TVD(method="heterogeneous bregman", weight=0.1, max_num_iter=10, eps=None), model, **{"diff option": "positive"})
+ca_ch = da.ConcentrationAnalysis(base, da.MonochromaticReduction(color="gray"), None, da.TVD(weight=0.1, max_num_iter=8), model)
+frames_gray = [da.ScalarImage(g), da.ScalarImage(np.roll(g, 2, axis=1).copy())]
+reg = da.ImageRegistration(frames_gray[0], N_patches=[3, 4])
+reg(frames_gray[1])
+def _chain():
+    d = da.DeviceArray.from_host(img)
+    out = da.split_bregman_tvd(d, mu=0.1, max_num_iter=4)
+    res = out.get()
+    d.close(); out.close()
+    return res
 def _try():
     try:
         da.MG(depth=9, smoother_iterations=1, maxiter=1, mass_coeff=1.0, diffusion_coeff=1.0)(g[:5, :64].copy(), g[:5, :64].copy())
@@ -34,7 +61,8 @@ def _try():
         return True
     return False
 for name, f in ops.items():
-    f(); b = free_mb()
+    f(); f(); b = free_mb()
     for _ in range(25): f()
     a = free_mb()
     print(f"{name:28s} free before {b:10.1f} MB after {a:10.1f} MB  delta {a - b:+.1f}", flush=True)
+print(f"trim returned {da.trim_device_cache() / 2**20:.1f} MB; free now {free_mb():.1f} MB")
