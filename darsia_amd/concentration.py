@@ -179,6 +179,16 @@ def _ops_array(ops):
 _DIFF = {"plain": 0, "positive": 1, "negative": 2, "absolute": 3}
 
 
+_FRAME_DTYPES = {np.dtype(np.float32): _lib.DXH_F32, np.dtype(np.float64): _lib.DXH_F64, np.dtype(np.uint8): 2, np.dtype(np.uint16): 3}
+
+
+def _float_dtype(dt) -> np.dtype:
+    """The float type a probing frame is subtracted in: float frames as they are, integer frames as float64
+    (concentrationanalysis.py:241-246: ``img_as(float)``)."""
+    dt = np.dtype(dt)
+    return dt if dt.kind == "f" else np.dtype(np.float64)
+
+
 def _fingerprint(value):
     if isinstance(value, np.ndarray) and value.ndim > 0:
         flat = value.reshape(-1) if value.flags.c_contiguous else value.ravel()
@@ -276,7 +286,7 @@ class ConcentrationAnalysis:
             if reduction == 5:
                 # cv2's gray conversion works in float32 AFTER the (possibly float64) background subtraction: the fused
                 # float32 pipeline reproduces that only when nothing in front of it is wider than float32
-                wide = probe.dtype if self.base is None else np.result_type(probe.dtype, self.base.img.dtype)
+                wide = _float_dtype(probe.dtype) if self.base is None else np.result_type(_float_dtype(probe.dtype), self.base.img.dtype)
                 if wide != np.float32:
                     return None
         elif probe.ndim == 2 and self.signal_reduction is None:
@@ -314,7 +324,7 @@ class ConcentrationAnalysis:
     def _signal_dtype(self, probe: np.ndarray, reduction: int):
         # dtype as NumPy would promote (concentrationanalysis.py:328-395): probe - baseline promotes to the wider of the
         # two, a (float64) cleaning filter promotes the signal; gray is float32 in cv2
-        dt = probe.dtype if self.base is None else np.result_type(probe.dtype, self.base.img.dtype)
+        dt = _float_dtype(probe.dtype) if self.base is None else np.result_type(_float_dtype(probe.dtype), self.base.img.dtype)
         if self.threshold_cleaning_filter is not None:
             dt = np.result_type(dt, np.float64)
         elif reduction == 5:
@@ -331,8 +341,13 @@ class ConcentrationAnalysis:
             h, w, dts = key
             dt = np.dtype(dts)
             st = DeviceTVD((h, w), dt, dim=2)
-            base = None if self.base is None else np.ascontiguousarray(self.base.img, dtype=dt)
-            _lib.check(st.lib.dxh_tvd_set_base(st._h, _lib.ptr(base), channels))
+            # the baseline stays in its own float type (probe - baseline is evaluated in NumPy's promotion of the two on the
+            # device): a float32 baseline under a float64 cleaning filter is half the bytes, and no host conversion
+            base = None
+            if self.base is not None:
+                own = self.base.img.dtype in (np.float32, np.float64) and self.base.img.dtype.itemsize <= dt.itemsize
+                base = np.ascontiguousarray(self.base.img, dtype=None if own else dt)
+            _lib.check(st.lib.dxh_tvd_set_base_typed(st._h, _lib.ptr(base), channels, _lib.dtype_code(dt if base is None else base.dtype)))
             filt = None if self.threshold_cleaning_filter is None else np.ascontiguousarray(self.threshold_cleaning_filter, dtype=dt)
             _lib.check(st.lib.dxh_tvd_set_cleaning_filter(st._h, _lib.ptr(filt)))
             self._ctxs[slot], self._ctx_keys[slot] = st, key
@@ -361,9 +376,11 @@ class ConcentrationAnalysis:
             st.set_coeffs(*coefs, like)
             st._coef_mark = mark
         pre = ops if not self.first_restoration_then_model else []
-        src = np.ascontiguousarray(probe, dtype=st.dtype)
-        _lib.check(st.lib.dxh_tvd_upload_signal(st._h, _lib.ptr(src), channels, _DIFF[self._diff_option], reduction,
-                                                 C.cast(_ops_array(pre), C.c_void_p), len(pre)))
+        # the frame goes over as stored (float32 / float64 / uint8 / uint16); the device widens where NumPy would
+        src = np.ascontiguousarray(probe, dtype=None if probe.dtype in _FRAME_DTYPES else st.dtype)
+        _lib.check(st.lib.dxh_tvd_upload_signal_typed(st._h, _lib.ptr(src), _FRAME_DTYPES[src.dtype], channels,
+                                                       _DIFF[self._diff_option], reduction,
+                                                       C.cast(_ops_array(pre), C.c_void_p), len(pre)))
 
     def _finish_frame(self, st: DeviceTVD, plan) -> np.ndarray:
         reduction, channels, ops, solver, iso, mode = plan
@@ -416,7 +433,14 @@ class ConcentrationAnalysis:
             return
 
         def fusable(img):
-            return self._fusable(img.img) if img.img.dtype in (np.float32, np.float64) else None
+            if img.img.dtype not in _FRAME_DTYPES:
+                return None
+            return self._fusable(img.img)
+
+        def submit(slot: int, img):
+            if img.img.dtype.kind != "f":   # concentrationanalysis.py:241-246, once per frame as in a frame-by-frame loop
+                warn("The input for concentration analysis needed to be converted to float.")
+            return pool.submit(upload, slot, img)
 
         plan = fusable(cur)
         if plan is None:
@@ -435,7 +459,7 @@ class ConcentrationAnalysis:
         def upload(slot: int, img):
             self._upload_frame(self._ctx_for(slot, key, channels), img.img, plan)
 
-        fut = pool.submit(upload, 0, cur)
+        fut = submit(0, cur)
         try:
             k = 0
             while cur is not None:
@@ -445,7 +469,7 @@ class ConcentrationAnalysis:
                 same = nxt is not None and nxt.img.shape == shape and fusable(nxt) == plan and \
                     self._signal_dtype(nxt.img, plan[0]) == dt
                 if same:
-                    fut = pool.submit(upload, (k + 1) % 2, nxt)   # overlaps the work on frame k below
+                    fut = submit((k + 1) % 2, nxt)   # overlaps the work on frame k below
                 out = self._finish_frame(self._ctxs[k % 2], plan)
                 yield self._wrap(cur, out)
                 if nxt is not None and not same:
@@ -470,7 +494,8 @@ class ConcentrationAnalysis:
             if img.img.dtype not in (np.uint8, np.uint16) or not hasattr(img, "img_as"):
                 raise TypeError("the probing image must be float32 / float64 (or uint8 / uint16, which are converted)")
             warn("The input for concentration analysis needed to be converted to float.")
-            img = img.img_as(float)
+            if self._fusable(img.img) is None:
+                img = img.img_as(float)   # on the host for the generic chain; the fused path converts on the device
         probe = img.img
         plan = self._fusable(probe)
         if plan is not None:

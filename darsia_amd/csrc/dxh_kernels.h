@@ -745,18 +745,37 @@ __device__ __forceinline__ T diff_value(T v, T bse, bool has_base, int option) {
     }
 }
 
-template <typename T, int C>
-__global__ void __launch_bounds__(256) k_signal(Geom g, const T* __restrict__ probe, const T* __restrict__ base,
+// Element of a probe frame as the float value the reference subtracts the baseline from: float frames as they are, integer
+// frames the scikit-image way (concentrationanalysis.py:241-246 -> img_as(float): np.multiply(x, 1. / imax, dtype=float64)).
+template <typename S> struct SigLoad { using F = S; static __device__ __forceinline__ F get(S v) { return v; } };
+template <> struct SigLoad<unsigned char> {
+    using F = double;
+    static __device__ __forceinline__ double get(unsigned char v) { return (double)v * (1.0 / 255); }
+};
+template <> struct SigLoad<unsigned short> {
+    using F = double;
+    static __device__ __forceinline__ double get(unsigned short v) { return (double)v * (1.0 / 65535); }
+};
+
+// S: stored type of the probe frame, B: of the baseline, T: of the scalar signal (the context).  Difference and reduction run
+// in NumPy's promotion D of probe and baseline; the signal is widened to T where the cleaning filter promotes it
+// (concentrationanalysis.py:328-395).
+template <typename T, int C, typename S, typename B>
+__global__ void __launch_bounds__(256) k_signal(Geom g, const S* __restrict__ probe, const B* __restrict__ base,
                                                  const T* __restrict__ filt, int option, int reduction, ModelOps pre,
                                                  T* __restrict__ out) {
+    using F = typename SigLoad<S>::F;
+    using D = std::conditional_t<(sizeof(F) > sizeof(B)), F, B>;
+    static_assert(sizeof(T) >= sizeof(D), "the signal cannot be narrower than probe - baseline");
     // g describes the SCALAR image (n2 == 1); probe/base are dense (H, W, C)
     ElemIdx e;
     if (!elem_index(g, e)) return;
     const int64_t pix = e.row * g.L + e.x;
-    T d[C];
+    D d[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) d[c] = diff_value<T>(probe[pix * C + c], base ? base[pix * C + c] : T(0), base != nullptr, option);
-    T sig;
+    for (int c = 0; c < C; ++c)
+        d[c] = diff_value<D>((D)SigLoad<S>::get(probe[pix * C + c]), base ? (D)base[pix * C + c] : D(0), base != nullptr, option);
+    D sig;
     if constexpr (C == 1) {
         sig = d[0];
     } else {
@@ -767,18 +786,19 @@ __global__ void __launch_bounds__(256) k_signal(Geom g, const T* __restrict__ pr
             case 4: sig = d[0] + d[1]; break;
             case 5: {  // cv2.COLOR_RGB2GRAY on float32
                 const float gr = (float)d[0] * 0.299f + (float)d[1] * 0.587f + (float)d[2] * 0.114f;
-                sig = (T)gr;
+                sig = (D)gr;
             } break;
             default: {  // negative-key: 1 - min(1 - rgb)
-                const T c0 = T(1) - d[0], c1 = T(1) - d[1], c2 = T(1) - d[2];
-                T key = c0 < c1 ? c0 : c1;
+                const D c0 = D(1) - d[0], c1 = D(1) - d[1], c2 = D(1) - d[2];
+                D key = c0 < c1 ? c0 : c1;
                 key = key < c2 ? key : c2;
-                sig = T(1) - key;
+                sig = D(1) - key;
             }
         }
     }
-    if (filt) sig = t_max0(sig - filt[pix]);  // np.clip(img - filter, 0, None)
-    out[e.off] = apply_model_ops<T>(sig, pre);
+    T s = (T)sig;
+    if (filt) s = t_max0(s - filt[pix]);  // np.clip(img - filter, 0, None)
+    out[e.off] = apply_model_ops<T>(s, pre);
 }
 
 template <typename T>

@@ -81,6 +81,7 @@ struct Ctx {
     bool explicit_db = false;      // split variables live in dpl / bpl instead of the compressed q planes
     void* base_img = nullptr;      // ConcentrationAnalysis: dense baseline (H, W, base_channels)
     int base_channels = 0;
+    int base_dtype = DXH_F32;      // stored type of base_img (dxh_tvd_set_base_typed)
     void* clean_filter = nullptr;  // dense (H, W) threshold cleaning filter
     void* probe_buf = nullptr;     // dense staging for the probe frame
     size_t probe_bytes = 0;
@@ -1342,6 +1343,39 @@ __global__ void __launch_bounds__(256) k_convert_dense(const TS* __restrict__ sr
     if (i < n) dst[i] = (TD)src[i];
 }
 
+namespace {
+// k_signal<T, CH, S, B> for the types the arguments name
+template <typename T, int CH, typename S, typename B>
+void launch_signal(Ctx* c, int diff_option, int reduction, const ModelOps& pre) {
+    hipLaunchKernelGGL((k_signal<T, CH, S, B>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const S*)c->probe_buf,
+                       (const B*)c->base_img, (const T*)c->clean_filter, diff_option, reduction, pre, (T*)c->u[0]);
+}
+
+template <typename T, int CH, typename S>
+int signal_by_base(Ctx* c, int diff_option, int reduction, const ModelOps& pre) {
+    using F = typename SigLoad<S>::F;
+    // without a baseline B only sizes the difference type: take the probe's own float type
+    const int bdt = c->base_img ? c->base_dtype : (sizeof(F) == 4 ? DXH_F32 : DXH_F64);
+    if (bdt == DXH_F32) {
+        if constexpr (sizeof(T) >= sizeof(F)) { launch_signal<T, CH, S, float>(c, diff_option, reduction, pre); return DXH_OK; }
+    } else {
+        if constexpr (sizeof(T) == 8) { launch_signal<T, CH, S, double>(c, diff_option, reduction, pre); return DXH_OK; }
+    }
+    set_error("the context's dtype is narrower than probe - baseline (NumPy would promote to float64)");
+    return DXH_EINVAL;
+}
+
+template <typename T, int CH>
+int signal_by_probe(Ctx* c, int probe_dtype, int diff_option, int reduction, const ModelOps& pre) {
+    switch (probe_dtype) {
+        case DXH_F32: return signal_by_base<T, CH, float>(c, diff_option, reduction, pre);
+        case DXH_F64: return signal_by_base<T, CH, double>(c, diff_option, reduction, pre);
+        case DXH_U8: return signal_by_base<T, CH, unsigned char>(c, diff_option, reduction, pre);
+        default: return signal_by_base<T, CH, unsigned short>(c, diff_option, reduction, pre);
+    }
+}
+}  // namespace
+
 extern "C" {
 
 const char* dxh_last_error(void) { return g_err.c_str(); }
@@ -1630,15 +1664,24 @@ static int set_dense(Ctx* c, void** slot, const void* host, size_t bytes) {
     return DXH_OK;
 }
 
-int dxh_tvd_set_base(dxh_tvd_t h, const void* base, int channels) {
+int dxh_tvd_set_base_typed(dxh_tvd_t h, const void* base, int channels, int dtype) {
     Ctx* c = reinterpret_cast<Ctx*>(h);
     DXH_REQUIRE(c, "null context");
     DXH_REQUIRE(c->desc.ndim == 2, "the signal pipeline needs a scalar (H, W) context");
     DXH_REQUIRE(base == nullptr || channels == 1 || channels == 3, "channels must be 1 or 3");
+    DXH_REQUIRE(dtype == DXH_F32 || dtype == DXH_F64, "the baseline must be float32 or float64");
+    DXH_REQUIRE(dtype <= c->desc.dtype, "a float64 baseline needs a float64 context (NumPy promotes probe - baseline)");
     int rc = set_device(c);
     if (rc) return rc;
     c->base_channels = base ? channels : 0;
-    return set_dense(c, &c->base_img, base, (size_t)c->g.n0 * c->g.L * (base ? channels : 0) * c->esz);
+    c->base_dtype = dtype;
+    return set_dense(c, &c->base_img, base, (size_t)c->g.n0 * c->g.L * (base ? channels : 0) * (dtype == DXH_F32 ? 4 : 8));
+}
+
+int dxh_tvd_set_base(dxh_tvd_t h, const void* base, int channels) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    DXH_REQUIRE(c, "null context");
+    return dxh_tvd_set_base_typed(h, base, channels, c->desc.dtype);
 }
 
 int dxh_tvd_set_cleaning_filter(dxh_tvd_t h, const void* filter) {
@@ -1650,13 +1693,15 @@ int dxh_tvd_set_cleaning_filter(dxh_tvd_t h, const void* filter) {
     return set_dense(c, &c->clean_filter, filter, (size_t)c->g.n0 * c->g.L * c->esz);
 }
 
-int dxh_tvd_upload_signal(dxh_tvd_t h, const void* probe, int channels, int diff_option, int reduction,
-                          const dxh_model_op* pre_ops, int n_pre) {
+int dxh_tvd_upload_signal_typed(dxh_tvd_t h, const void* probe, int probe_dtype, int channels, int diff_option, int reduction,
+                                const dxh_model_op* pre_ops, int n_pre) {
     Ctx* c = reinterpret_cast<Ctx*>(h);
     DXH_REQUIRE(c && probe, "null argument");
     if (!c->have_coefs) { set_error("dxh_tvd_set_coeffs must be called before dxh_tvd_upload_signal"); return DXH_ESTATE; }
     DXH_REQUIRE(c->desc.ndim == 2, "the signal pipeline needs a scalar (H, W) context");
     DXH_REQUIRE(channels == 1 || channels == 3, "channels must be 1 or 3");
+    DXH_REQUIRE(probe_dtype == DXH_F32 || probe_dtype == DXH_F64 || probe_dtype == DXH_U8 || probe_dtype == DXH_U16,
+                "probe dtype %d not supported (float32, float64, uint8, uint16)", probe_dtype);
     DXH_REQUIRE(diff_option >= 0 && diff_option <= 3, "diff_option must be 0..3");
     DXH_REQUIRE((channels == 1 && reduction == 0) || (channels == 3 && reduction >= 1 && reduction <= 6),
                 "reduction %d does not fit %d channel(s)", reduction, channels);
@@ -1666,21 +1711,30 @@ int dxh_tvd_upload_signal(dxh_tvd_t h, const void* probe, int channels, int diff
     int rc = to_ops(pre_ops, n_pre, &pre);
     if (rc) return rc;
     if ((rc = set_device(c))) return rc;
-    const size_t bytes = (size_t)c->g.n0 * c->g.L * channels * c->esz;
+    static const size_t width[4] = {4, 8, 1, 2};
+    const size_t bytes = (size_t)c->g.n0 * c->g.L * channels * width[probe_dtype];
     if (c->probe_bytes < bytes) {
         if (c->probe_buf) { DXH_HIP(hipFree(c->probe_buf)); c->probe_buf = nullptr; c->probe_bytes = 0; }
         DXH_HIP(hipMalloc(&c->probe_buf, bytes));
         c->probe_bytes = bytes;
     }
     DXH_HIP(hipMemcpyAsync(c->probe_buf, probe, bytes, hipMemcpyDefault, c->stream));
-    const dim3 grid = elem_grid(c->g), blk(256);
-#define DXH_SIG(T, CH) hipLaunchKernelGGL((k_signal<T, CH>), grid, blk, 0, c->stream, c->g, (const T*)c->probe_buf, \
-                                          (const T*)c->base_img, (const T*)c->clean_filter, diff_option, reduction, pre, (T*)c->u[0])
-    if (c->desc.dtype == DXH_F32) { if (channels == 1) DXH_SIG(float, 1); else DXH_SIG(float, 3); }
-    else                          { if (channels == 1) DXH_SIG(double, 1); else DXH_SIG(double, 3); }
-#undef DXH_SIG
+    if (c->desc.dtype == DXH_F32)
+        rc = channels == 1 ? signal_by_probe<float, 1>(c, probe_dtype, diff_option, reduction, pre)
+                           : signal_by_probe<float, 3>(c, probe_dtype, diff_option, reduction, pre);
+    else
+        rc = channels == 1 ? signal_by_probe<double, 1>(c, probe_dtype, diff_option, reduction, pre)
+                           : signal_by_probe<double, 3>(c, probe_dtype, diff_option, reduction, pre);
+    if (rc) return rc;
     DXH_HIP(hipGetLastError());
     return finish_upload(c, nullptr, nullptr, nullptr);
+}
+
+int dxh_tvd_upload_signal(dxh_tvd_t h, const void* probe, int channels, int diff_option, int reduction,
+                          const dxh_model_op* pre_ops, int n_pre) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    DXH_REQUIRE(c, "null argument");
+    return dxh_tvd_upload_signal_typed(h, probe, c->desc.dtype, channels, diff_option, reduction, pre_ops, n_pre);
 }
 
 int dxh_tvd_download_model(dxh_tvd_t h, void* out, const dxh_model_op* post_ops, int n_post) {

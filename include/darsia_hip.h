@@ -39,6 +39,8 @@ extern "C" {
 
 #define DXH_F32 0
 #define DXH_F64 1
+#define DXH_U8 2  /* integer frames: dxh_map_coordinates, dxh_tvd_upload_signal_typed */
+#define DXH_U16 3
 
 /* which Jacobi neighbour sum to use */
 #define DXH_NSUM_ALL_AXES 0 /* reference behaviour inside split_bregman_tvd: every array axis
@@ -188,6 +190,17 @@ int dxh_tvd_set_cleaning_filter(dxh_tvd_t ctx, const void* filter);
 int dxh_tvd_upload_signal(dxh_tvd_t ctx, const void* probe, int channels, int diff_option, int reduction,
                           const dxh_model_op* pre_ops, int n_pre);
 int dxh_tvd_download_model(dxh_tvd_t ctx, void* out, const dxh_model_op* post_ops, int n_post);
+/*
+ * The same with frames in the type they are stored in.  The reference subtracts the baseline in NumPy's promotion of the two
+ * arrays and reduces in that type; only the cleaning filter (float64 by construction, concentrationanalysis.py:154-197) widens
+ * the signal.  So a float32 frame against a float32 baseline goes to the device as float32 even when the context is float64,
+ * and integer frames (which the reference converts with img_as(float): x * (1 / 255) resp. (1 / 65535) in float64, with a
+ * warning, concentrationanalysis.py:241-246) go as the bytes they are.  base_dtype: DXH_F32 / DXH_F64, not wider than the
+ * context; probe_dtype: DXH_F32 / DXH_F64 / DXH_U8 / DXH_U16, DXH_EINVAL if probe - baseline would be wider than the context.
+ */
+int dxh_tvd_set_base_typed(dxh_tvd_t ctx, const void* base, int channels, int base_dtype);
+int dxh_tvd_upload_signal_typed(dxh_tvd_t ctx, const void* probe, int probe_dtype, int channels, int diff_option,
+                                int reduction, const dxh_model_op* pre_ops, int n_pre);
 
 /*
  * Row-slab halo plumbing for multi-GPU runs (no reference counterpart: the

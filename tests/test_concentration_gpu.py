@@ -43,7 +43,8 @@ def test_fused_pipeline_with_tvd_and_cleaning_filter(restoration_first):
                                   **{"diff option": "positive", "restoration -> model": restoration_first})
     assert ca.threshold_cleaning_filter is not None and ca.threshold_cleaning_filter.dtype == np.float64
     out = ca(probe)
-    ref = OC.concentration(probe.img.astype(np.float64), base.img.astype(np.float64), "positive", "red",
+    # float32 frames and a float64 filter: the reference subtracts and reduces in float32, the filter then widens the signal
+    ref = OC.concentration(probe.img, base.img, "positive", "red",
                            ca.threshold_cleaning_filter, [lambda x: 3.0 * x, lambda x: np.clip(x, 0.0, 1.0)],
                            dict(mu=0.05, omega=1.0, ell=0.1, max_num_iter=12), restoration_first)
     assert out.img.dtype == np.float64  # the float64 cleaning filter promotes the signal, as in the reference
@@ -51,6 +52,71 @@ def test_fused_pipeline_with_tvd_and_cleaning_filter(restoration_first):
     # second frame re-uses the device context (base and filter stay resident)
     out2 = ca(probe)
     assert np.array_equal(out2.img, out.img)
+
+
+@pytest.mark.parametrize("color", ["red", "red+green", "gray", "negative-key"])
+@pytest.mark.parametrize("option", ["absolute", "positive", "negative", "plain"])
+def test_float32_frames_under_a_float64_filter_subtract_in_float32(color, option):
+    """NumPy's promotion, stage by stage (concentrationanalysis.py:328-395): probe - baseline and the reduction in the frames'
+    own float32, only ``signal - filter`` in float64.  Frames far from their baseline (where a float32 difference rounds) tell
+    this from a pipeline that widens first; the frames go to the device as float32."""
+    rng = np.random.default_rng(21)
+    h, w = 48, 72
+    base = da.OpticalImage((rng.random((h, w, 3)) * 0.2 + 0.01).astype(np.float32))
+    probe = da.OpticalImage((rng.random((h, w, 3)) * 0.9 + 0.05).astype(np.float32))
+    extra = da.OpticalImage((base.img + rng.normal(0, 0.004, base.img.shape)).astype(np.float32))
+    model = da.CombinedModel([da.LinearModel(scaling=1.7, offset=0.01), da.ClipModel(min_value=0.0)])
+    ca = da.ConcentrationAnalysis([base, extra], da.MonochromaticReduction(color=color), None, None, model, **{"diff option": option})
+    assert ca.threshold_cleaning_filter.dtype == np.float64 and ca._fusable(probe.img) is not None
+    out = ca(probe)
+    ref = OC.concentration(probe.img, base.img, option, color, ca.threshold_cleaning_filter,
+                           [lambda x: 1.7 * x + 0.01, lambda x: np.clip(x, 0.0, None)], None, False)
+    widened = OC.concentration(probe.img.astype(np.float64), base.img.astype(np.float64), option, color,
+                               ca.threshold_cleaning_filter, [lambda x: 1.7 * x + 0.01, lambda x: np.clip(x, 0.0, None)], None, False)
+    assert out.img.dtype == ref.dtype == np.float64 and np.array_equal(out.img, ref)
+    # the data does tell the two apart (gray rounds the difference to float32 either way: cv2's conversion is float32)
+    assert np.array_equal(ref, widened) == (color == "gray")
+    assert list(ca.map([probe, probe]))[1].img.tobytes() == out.img.tobytes()
+
+
+@pytest.mark.parametrize("dtype,scale", [(np.uint8, 255), (np.uint16, 65535)])
+@pytest.mark.parametrize("base_dtype", [np.float32, np.float64])
+def test_integer_frames_convert_on_the_device(dtype, scale, base_dtype):
+    """Integer frames travel as they are stored and are converted on the device the way img_as(float) does
+    (x * (1 / imax) in float64, concentrationanalysis.py:241-246), whatever float type the baseline has; with the restoration."""
+    rng = np.random.default_rng(22)
+    h, w = 40, 64
+    base = da.OpticalImage((rng.random((h, w, 3)) * 0.4).astype(base_dtype))
+    raw = (rng.random((h, w, 3)) * scale).astype(dtype)
+    tvd = da.TVD(method="heterogeneous bregman", weight=0.05, omega=1.0, regularization=0.1, max_num_iter=6, eps=None)
+    ca = da.ConcentrationAnalysis(base, da.MonochromaticReduction(color="green"), None, tvd, da.ScalingModel(scaling=2.0),
+                                  **{"diff option": "absolute"})
+    with pytest.warns(UserWarning, match="converted to float"):
+        out = ca(da.OpticalImage(raw))
+    as_float = np.multiply(raw, 1.0 / scale, dtype=np.float64)
+    ref = OC.concentration(as_float, base.img, "absolute", "green", None, [lambda x: 2.0 * x],
+                           dict(mu=0.05, omega=1.0, ell=0.1, max_num_iter=6), False)
+    assert out.img.dtype == np.float64 and np.array_equal(out.img, ref)
+    with pytest.warns(UserWarning, match="converted to float"):
+        series = list(ca.map([da.OpticalImage(raw), da.OpticalImage(as_float), da.OpticalImage(raw)]))
+    assert all(np.array_equal(x.img, ref) for x in series)
+
+
+def test_typed_signal_upload_rejects_what_numpy_would_widen():
+    from darsia_amd import _lib
+    import ctypes as C
+
+    img = np.zeros((16, 24), np.float32)
+    with da.DeviceTVD(img.shape, np.float32) as st:
+        st.set_coeffs(0.1, 1.0, None, img)
+        lib = st.lib
+        base64 = np.zeros((16, 24, 3), np.float64)
+        assert lib.dxh_tvd_set_base_typed(st._h, _lib.ptr(base64), 3, _lib.DXH_F64) == -1          # float64 baseline, float32 context
+        probe8 = np.zeros((16, 24, 3), np.uint8)
+        assert lib.dxh_tvd_upload_signal_typed(st._h, _lib.ptr(probe8), 2, 3, 0, 1, None, 0) == -1   # uint8 -> float64 signal
+        assert lib.dxh_tvd_upload_signal_typed(st._h, _lib.ptr(probe8), 7, 3, 0, 1, None, 0) == -1   # unknown dtype code
+        probe32 = np.ones((16, 24, 3), np.float32)
+        assert lib.dxh_tvd_upload_signal_typed(st._h, _lib.ptr(probe32), _lib.DXH_F32, 3, 0, 2, None, 0) == 0
 
 
 def test_scalar_frames_and_generic_fallback_chain():
