@@ -26,7 +26,7 @@ from . import _lib
 from .geometry import VoxelArray
 from .image import Image  # noqa: F401
 from .device import DeviceArray
-from .registration import _opencv_block_width, get_perspective_transform
+from .registration import _opencv_block_width, get_perspective_transform, warp_patches
 
 _MC_DTYPES = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.uint8): 2, np.dtype(np.uint16): 3}
 
@@ -120,19 +120,13 @@ def extract_quadrilateral_ROI(img_src: np.ndarray, pts_src=None, indexing: str =
     rec.ox, rec.oy, rec.w_eff, rec.h_eff = 0, 0, int(width), int(height)
     rec.nx, rec.ny = int(width), int(height)
     rec.bw0 = _opencv_block_width(int(width), int(height))
-    _lib.require_gpu()
-    src = np.ascontiguousarray(img_src, dtype=np.float32)
+    src = img_src
     if height > h or width > w:
         # the kernel writes a canvas of the source's shape: a target larger than the source gets both embedded in their
         # common bounding shape, the source rectangle (sh, sw) still ends where the image ends
-        big = np.zeros((max(h, int(height)), max(w, int(width))) + src.shape[2:], np.float32)
-        big[:h, :w] = src
-        src = big
-    canvas = np.empty(src.shape, src.dtype)
-    table = (_lib.WarpPatch * 1)(rec)
-    _lib.check(_lib.load().dxh_warp_patches(_lib.default_device(), src.shape[0], src.shape[1], chans, _lib.ptr(src),
-                                             C.cast(table, C.c_void_p), 1, _lib.ptr(canvas)))
-    return np.ascontiguousarray(canvas[:height, :width]).astype(img_src.dtype)
+        src = np.zeros((max(h, int(height)), max(w, int(width))) + img_src.shape[2:], img_src.dtype)
+        src[:h, :w] = img_src
+    return np.ascontiguousarray(warp_patches(src, [rec])[:height, :width])
 
 
 class BaseCorrection(ABC):

@@ -42,10 +42,18 @@ __device__ __forceinline__ int round_half_even_clamped(double v) {
 
 constexpr int kWarpBW = 256, kWarpBH = 16;
 
-template <int C>
-__global__ void __launch_bounds__(256) k_warp(const float* __restrict__ base, int H, int W, const WarpPatch* __restrict__ pt,
+// The float32 canvas value in the image's own type, as ``canvas.astype(dtype)`` gives it on the host
+// (piecewiseperspective.py:133): exact for float64; integer types truncate towards zero through int32 and wrap.
+template <typename S> __device__ __forceinline__ S warp_store(float v) { return (S)v; }
+template <> __device__ __forceinline__ unsigned char warp_store<unsigned char>(float v) { return (unsigned char)(int)v; }
+template <> __device__ __forceinline__ unsigned short warp_store<unsigned short>(float v) { return (unsigned short)(int)v; }
+
+// S: stored type of image and canvas; the patch is read as ``patch.astype(float32)`` (piecewiseperspective.py:121) and the
+// sum over the patches is a float32 canvas, whatever S.
+template <int C, typename S>
+__global__ void __launch_bounds__(256) k_warp(const S* __restrict__ base, int H, int W, const WarpPatch* __restrict__ pt,
                                                const int* __restrict__ bin_off, const int* __restrict__ bin_idx,
-                                               float* __restrict__ canvas) {
+                                               S* __restrict__ canvas) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= W || y >= H) return;
@@ -85,10 +93,10 @@ __global__ void __launch_bounds__(256) k_warp(const float* __restrict__ base, in
                 const int yy = sy + ky, xx = sx + kx;
                 const bool ok = yy >= 0 && yy < p.sh && xx >= 0 && xx < p.sw;
                 const float wgt = wy[ky] * wx[kx];
-                const float* s = base + ((size_t)(p.sr0 + (ok ? yy : 0)) * W + (p.sc0 + (ok ? xx : 0))) * C;
+                const S* s = base + ((size_t)(p.sr0 + (ok ? yy : 0)) * W + (p.sc0 + (ok ? xx : 0))) * C;
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
-                    const float term = (ok ? s[c] : 0.f) * wgt;
+                    const float term = (ok ? (float)s[c] : 0.f) * wgt;
                     v[c] = first ? term : v[c] + term;
                 }
                 first = false;
@@ -96,9 +104,9 @@ __global__ void __launch_bounds__(256) k_warp(const float* __restrict__ base, in
 #pragma unroll
         for (int c = 0; c < C; ++c) acc[c] = acc[c] + v[c];
     }
-    float* o = canvas + ((size_t)y * W + x) * C;
+    S* o = canvas + ((size_t)y * W + x) * C;
 #pragma unroll
-    for (int c = 0; c < C; ++c) o[c] = acc[c];
+    for (int c = 0; c < C; ++c) o[c] = warp_store<S>(acc[c]);
 }
 
 // ---- thin-plate-spline field ------------------------------------------------------------------------
@@ -442,9 +450,13 @@ using namespace dxh;
 
 extern "C" {
 
-int dxh_warp_patches(int device, int H, int W, int C, const float* base, const dxh_warp_patch* patches, int npatch,
-                     float* canvas) {
+int dxh_warp_patches_typed(int device, int H, int W, int C, int dtype, const void* base, const dxh_warp_patch* patches,
+                           int npatch, void* canvas) {
     DXH_REQUIRE(base && canvas && (patches || npatch == 0), "null argument");
+    DXH_REQUIRE(dtype == DXH_F32 || dtype == DXH_F64 || dtype == DXH_U8 || dtype == DXH_U16,
+                "dtype %d not supported (float32, float64, uint8, uint16)", dtype);
+    static const size_t width[4] = {4, 8, 1, 2};
+    const size_t esz = width[dtype];
     DXH_REQUIRE(H >= 1 && W >= 1 && (C == 1 || C == 3), "shape (%d, %d, %d) not supported (C must be 1 or 3)", H, W, C);
     static_assert(sizeof(dxh_warp_patch) == sizeof(WarpPatch), "patch struct mismatch");
     int rc = check_device(device);
@@ -458,10 +470,10 @@ int dxh_warp_patches(int device, int H, int W, int C, const float* base, const d
         DXH_REQUIRE(p.bw0 >= 1, "patch %d: bad block width", k);
     }
     HostPrefault pf;  // map the output pages while the device works
-    pf.start(canvas, (size_t)H * W * C * sizeof(float), {{base, (size_t)H * W * C * sizeof(float)}});
+    pf.start(canvas, (size_t)H * W * C * esz, {{base, (size_t)H * W * C * esz}});
     Dev d;
     DXH_HIP(cached_stream(device, &d.st));
-    const size_t bytes = (size_t)H * W * C * sizeof(float);
+    const size_t bytes = (size_t)H * W * C * esz;
     // candidate lists per kWarpBW x kWarpBH bin of the canvas, patches in table order (= the reference's loop order)
     const int nbx = (W + kWarpBW - 1) / kWarpBW, nby = (H + kWarpBH - 1) / kWarpBH;
     std::vector<int> off((size_t)nbx * nby + 1, 0), idx;
@@ -494,7 +506,7 @@ int dxh_warp_patches(int device, int H, int W, int C, const float* base, const d
     if ((rc = d.alloc(&dpt, sizeof(WarpPatch) * (size_t)npatch)) || (rc = d.alloc(&doff, sizeof(int) * off.size())) ||
         (rc = d.alloc(&didx, sizeof(int) * idx.size())))
         return rc;
-    if (base_on_device) dbase = const_cast<float*>(base);
+    if (base_on_device) dbase = const_cast<void*>(base);
     else if ((rc = d.alloc(&dbase, bytes))) return rc;
     if (canvas_on_device) dcanvas = canvas;
     else if ((rc = d.alloc(&dcanvas, bytes))) return rc;
@@ -510,15 +522,27 @@ int dxh_warp_patches(int device, int H, int W, int C, const float* base, const d
     DXH_HIP(hipMemcpyAsync(doff, off.data(), sizeof(int) * off.size(), hipMemcpyDefault, d.st));
     DXH_HIP(hipMemcpyAsync(didx, idx.data(), sizeof(int) * idx.size(), hipMemcpyDefault, d.st));
     const dim3 grid(nbx, H), blk(kWarpBW);
-    if (C == 1)
-        hipLaunchKernelGGL((k_warp<1>), grid, blk, 0, d.st, (const float*)dbase, H, W, (const WarpPatch*)dpt, (const int*)doff, (const int*)didx, (float*)dcanvas);
-    else
-        hipLaunchKernelGGL((k_warp<3>), grid, blk, 0, d.st, (const float*)dbase, H, W, (const WarpPatch*)dpt, (const int*)doff, (const int*)didx, (float*)dcanvas);
+#define DXH_WARP(CH, S) hipLaunchKernelGGL((k_warp<CH, S>), grid, blk, 0, d.st, (const S*)dbase, H, W, (const WarpPatch*)dpt, \
+                                           (const int*)doff, (const int*)didx, (S*)dcanvas)
+#define DXH_WARP_C(S) do { if (C == 1) DXH_WARP(1, S); else DXH_WARP(3, S); } while (0)
+    switch (dtype) {
+        case DXH_F32: DXH_WARP_C(float); break;
+        case DXH_F64: DXH_WARP_C(double); break;
+        case DXH_U8: DXH_WARP_C(unsigned char); break;
+        default: DXH_WARP_C(unsigned short); break;
+    }
+#undef DXH_WARP_C
+#undef DXH_WARP
     DXH_HIP(hipGetLastError());
     pf.join();
     if (!canvas_on_device) DXH_HIP(hipMemcpyAsync(canvas, dcanvas, bytes, hipMemcpyDefault, d.st));
     DXH_HIP(hipStreamSynchronize(d.st));  // also keeps the host-side tables alive until their copies are done
     return DXH_OK;
+}
+
+int dxh_warp_patches(int device, int H, int W, int C, const float* base, const dxh_warp_patch* patches, int npatch,
+                     float* canvas) {
+    return dxh_warp_patches_typed(device, H, W, C, DXH_F32, base, patches, npatch, canvas);
 }
 
 int dxh_tps_eval(int device, int p, int dout, const double* centers, const double* coeffs, const double* shift,

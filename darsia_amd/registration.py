@@ -119,6 +119,72 @@ class Patches:
         return out
 
 
+def _patch_records(patches, all_disp: np.ndarray, reverse: bool, h: int, w: int) -> np.ndarray:
+    """The warp table of all patches at once: the arithmetic of the reference's loop (piecewiseperspective.py:71-128) on stacked
+    arrays -- same operations per patch, so the same bits (``np.linalg.solve`` / ``inv`` on a stack run LAPACK per matrix) -- as a
+    structured array laid out like ``_lib.WarpPatch``.  ``all_disp``: the map at all patch corners, (2, 4 * patches)."""
+    ni, nj = patches.num_patches[0], patches.num_patches[1]
+    n = ni * nj
+    gc = np.asarray(patches.global_corners_voxels, dtype=np.float64).reshape(n, 4, 2)[:, :, ::-1]
+    lc = np.asarray(patches.local_corners_voxels, dtype=np.float64).reshape(n, 4, 2)[:, :, ::-1]
+    pts_dst = gc + (-1.0 if reverse else 1.0) * all_disp.T.reshape(n, 4, 2)
+    origin = np.maximum(0, pts_dst.min(axis=1)).astype(np.int32)                     # (n, 2): x, y
+    pts_dst_eff = pts_dst - origin[:, None, :]
+    top = pts_dst.max(axis=1)
+    w_eff = np.ceil(np.minimum(w, top[:, 0]) - np.maximum(0, origin[:, 0])).astype(np.int64)
+    h_eff = np.ceil(np.minimum(h, top[:, 1]) - np.maximum(0, origin[:, 1])).astype(np.int64)
+    ox, oy = origin[:, 0].astype(np.int64), origin[:, 1].astype(np.int64)
+    nx, ny = np.minimum(w, ox + w_eff) - ox, np.minimum(h, oy + h_eff) - oy
+    keep = (np.minimum(h_eff, w_eff) > 1) & (nx > 0) & (ny > 0)
+    # cv2.getPerspectiveTransform on float32 corner coordinates (get_perspective_transform above), all patches in one call
+    src = lc.astype(np.float32).astype(np.float64)
+    dst = pts_dst_eff.astype(np.float32).astype(np.float64)
+    x, y, X, Y = src[:, :, 0], src[:, :, 1], dst[:, :, 0], dst[:, :, 1]
+    one, zero = np.ones_like(x), np.zeros_like(x)
+    a = np.concatenate([np.stack([x, y, one, zero, zero, zero, -x * X, -y * X], axis=2),
+                        np.stack([zero, zero, zero, x, y, one, -x * Y, -y * Y], axis=2)], axis=1)   # (n, 8, 8)
+    rhs = np.concatenate([X, Y], axis=1)
+    sel = np.flatnonzero(keep)
+    table = np.zeros(sel.size, dtype=np.dtype(_lib.WarpPatch))
+    if sel.size == 0:
+        return table
+    sol = np.linalg.solve(a[sel], rhs[sel][:, :, None])[:, :, 0]
+    p_eff = np.concatenate([sol, np.ones((sel.size, 1))], axis=1).reshape(-1, 3, 3)
+    table["minv"] = np.linalg.inv(p_eff).reshape(-1, 9)
+    rois = [patches.rois[i][j] for i in range(ni) for j in range(nj)]
+    r0 = np.array([rois[k][0].start for k in sel]); r1 = np.minimum([rois[k][0].stop for k in sel], h)
+    c0 = np.array([rois[k][1].start for k in sel]); c1 = np.minimum([rois[k][1].stop for k in sel], w)
+    table["sr0"], table["sc0"], table["sh"], table["sw"] = r0, c0, r1 - r0, c1 - c0
+    table["ox"], table["oy"], table["w_eff"], table["h_eff"] = ox[sel], oy[sel], w_eff[sel], h_eff[sel]
+    table["nx"], table["ny"] = nx[sel], ny[sel]
+    table["bw0"] = np.minimum(1024 // np.minimum(16, h_eff[sel]), w_eff[sel])     # _opencv_block_width
+    return table
+
+
+_WARP_DTYPES = {np.dtype(np.float32): _lib.DXH_F32, np.dtype(np.float64): _lib.DXH_F64, np.dtype(np.uint8): 2, np.dtype(np.uint16): 3}
+
+
+def warp_patches(base: np.ndarray, records) -> np.ndarray:
+    """The canvas of ``records`` (``_lib.WarpPatch``) over ``base`` ((H, W) or (H, W, 3)), in ``base``'s dtype: what the reference
+    computes as ``patch.astype(float32)`` -> float32 canvas -> ``canvas.astype(dtype)`` (piecewiseperspective.py:121-133).
+    float32 / float64 / uint8 / uint16 images cross PCIe as they are stored and are converted on the device."""
+    _lib.require_gpu()
+    h, w = base.shape[:2]
+    chans = 1 if base.ndim == 2 else base.shape[2]
+    native = base.dtype in _WARP_DTYPES
+    src = np.ascontiguousarray(base, dtype=None if native else np.float32)
+    canvas = np.empty(src.shape, src.dtype)
+    if isinstance(records, np.ndarray):
+        table = np.ascontiguousarray(records, dtype=np.dtype(_lib.WarpPatch))
+        table_ptr = table.ctypes.data_as(C.c_void_p) if len(table) else None
+    else:
+        table = (_lib.WarpPatch * max(1, len(records)))(*records)
+        table_ptr = C.cast(table, C.c_void_p)
+    _lib.check(_lib.load().dxh_warp_patches_typed(_lib.default_device(), h, w, chans, _WARP_DTYPES[src.dtype], _lib.ptr(src),
+                                                   table_ptr, len(records), _lib.ptr(canvas)))
+    return canvas if native else canvas.astype(base.dtype)
+
+
 class PiecewisePerspectiveTransform:
     """Globally continuous, patch-wise defined perspective transform (piecewiseperspective.py:13-145)."""
 
@@ -136,8 +202,6 @@ class PiecewisePerspectiveTransform:
         if base.ndim not in (2, 3) or (base.ndim == 3 and base.shape[2] != 3):
             raise NotImplementedError("2-D scalar or RGB images only")
         h, w = base.shape[:2]
-        chans = 1 if base.ndim == 2 else 3
-        records = []
         # The displacement of all patch corners in ONE call of the map (a thin-plate-spline pair costs ~40 us per call
         # and per spline whatever the number of points: 200 patches = 8 ms).  The map is pointwise, so the values are
         # those of the reference's call per patch (piecewiseperspective.py:86-92); a callable that does not return
@@ -153,12 +217,30 @@ class PiecewisePerspectiveTransform:
                 all_disp = None
         except Exception:  # noqa: BLE001 -- the per-patch calls below raise whatever the callable raises
             all_disp = None
+        if all_disp is not None and hasattr(patches, "rois"):
+            records = _patch_records(patches, all_disp, reverse, h, w)
+        else:
+            records = self._patch_records_one_by_one(patches, displacement, reverse, h, w)
+        out = warp_patches(base, records)
+        # the reference returns ``darsia.Image(img=..., **patches.base.metadata())`` -- the BASE class, whatever the class of
+        # the patched image (piecewiseperspective.py:143-145)
+        base_obj = patches.base
+        if hasattr(base_obj, "metadata"):
+            image_cls = next((c for c in type(base_obj).__mro__ if c.__name__ == "Image"), type(base_obj))
+            return image_cls(out, **copy.copy(base_obj.metadata()))
+        return with_array(base_obj, out) if hasattr(base_obj, "copy") else out
+
+    @staticmethod
+    def _patch_records_one_by_one(patches, displacement: Callable, reverse: bool, h: int, w: int) -> list:
+        """The reference's loop as it stands (piecewiseperspective.py:71-128), one call of the map per patch: for maps that do not
+        take all corners at once.  ``_patch_records`` is the same arithmetic on all patches together."""
+        records = []
+        ni, nj = patches.num_patches[0], patches.num_patches[1]
         for i in range(ni):
             for j in range(nj):
                 gc = np.fliplr(np.asarray(patches.global_corners_voxels[i, j], dtype=np.float64))
                 lc = np.fliplr(np.asarray(patches.local_corners_voxels[i, j], dtype=np.float64))
-                k = 4 * (i * nj + j)
-                disp = np.asarray(displacement(gc)) if all_disp is None else all_disp[:, k:k + 4]
+                disp = np.asarray(displacement(gc))
                 pts_dst = gc + (-1.0 if reverse else 1.0) * disp.T
                 origin = np.array([max(0, np.min(pts_dst[:, 0])), max(0, np.min(pts_dst[:, 1]))]).astype(np.int32)
                 pts_dst_eff = pts_dst - origin
@@ -183,20 +265,7 @@ class PiecewisePerspectiveTransform:
                 rec.nx, rec.ny = int(nx), int(ny)
                 rec.bw0 = _opencv_block_width(int(w_eff), int(h_eff))
                 records.append(rec)
-        _lib.require_gpu()
-        src = np.ascontiguousarray(base, dtype=np.float32)
-        canvas = np.empty(src.shape, src.dtype)
-        table = (_lib.WarpPatch * max(1, len(records)))(*records)
-        _lib.check(_lib.load().dxh_warp_patches(_lib.default_device(), h, w, chans, _lib.ptr(src),
-                                                 C.cast(table, C.c_void_p), len(records), _lib.ptr(canvas)))
-        out = canvas.astype(base.dtype, copy=False)
-        # the reference returns ``darsia.Image(img=..., **patches.base.metadata())`` -- the BASE class, whatever the class of
-        # the patched image (piecewiseperspective.py:143-145)
-        base_obj = patches.base
-        if hasattr(base_obj, "metadata"):
-            image_cls = next((c for c in type(base_obj).__mro__ if c.__name__ == "Image"), type(base_obj))
-            return image_cls(out, **copy.copy(base_obj.metadata()))
-        return with_array(base_obj, out) if hasattr(base_obj, "copy") else out
+        return records
 
 
 def evaluate_rbf(rbf, points: np.ndarray) -> np.ndarray:

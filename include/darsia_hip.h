@@ -411,6 +411,15 @@ typedef struct dxh_warp_patch {
 
 int dxh_warp_patches(int device, int H, int W, int C, const float* base, const dxh_warp_patch* patches, int npatch,
                      float* canvas);
+/*
+ * The same on images in the type they are stored in (dtype: DXH_F32 / DXH_F64 / DXH_U8 / DXH_U16, for base and canvas alike):
+ * the reference reads every patch as patch.astype(float32), sums the warped patches on a float32 canvas and returns
+ * canvas.astype(dtype) (piecewiseperspective.py:121-133) -- the kernel converts on load and on store, so a uint8 frame is
+ * 1 byte per value over PCIe each way instead of 4.  Integer stores truncate towards zero through int32 and wrap, like
+ * NumPy's cast on x86-64.
+ */
+int dxh_warp_patches_typed(int device, int H, int W, int C, int dtype, const void* base, const dxh_warp_patch* patches,
+                           int npatch, void* canvas);
 
 /*
  * Thin-plate-spline evaluation of a fitted scipy.interpolate.RBFInterpolator (kernel 'thin_plate_spline',

@@ -21,12 +21,20 @@ def _smooth_displacement(h, w, ax=3.0, ay=2.0):
     ((61, 97, 3), [4, 5], 0.0, np.float32),
     ((80, 120), [4, 6], 0.1, np.float64),
     ((50, 70, 3), [2, 3], 0.05, np.uint8),
+    ((57, 83), [3, 3], 0.0, np.uint16),
+    ((44, 66, 3), [2, 4], 0.3, np.uint16),      # overlapping patches add up beyond the type's range: the cast wraps
+    ((40, 60), [3, 2], 0.4, np.uint8),
+    ((33, 47), [2, 2], 0.0, np.int32),          # any other type goes through float32 on the host, as in the reference
 ])
 @pytest.mark.parametrize("reverse", [False, True])
 def test_piecewise_perspective_warp_equals_oracle(shape, npatch, overlap, dtype, reverse):
     rng = np.random.default_rng(5)
     img = rng.random(shape)
-    img = (img * 255).astype(np.uint8) if dtype == np.uint8 else img.astype(dtype)
+    if np.dtype(dtype).kind in "ui":
+        # bright images: sums over overlapping patches leave the integer range
+        img = (img * 0.4 * np.iinfo(dtype).max + 0.6 * np.iinfo(dtype).max).astype(dtype) if dtype != np.int32 else (img * 1000).astype(dtype)
+    else:
+        img = img.astype(dtype)
     patches = da.Patches(img, npatch, rel_overlap=overlap)
     disp = _smooth_displacement(shape[0], shape[1])
     out = da.PiecewisePerspectiveTransform().find_and_warp(patches, disp, reverse=reverse)

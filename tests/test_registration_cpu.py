@@ -262,3 +262,35 @@ def test_facade_keyword_handling_equals_the_reference_class():
             assert got == payload
         else:
             assert dict(N_patches=list(r.image_registration.N_patches), rel_overlap=r.image_registration.rel_overlap) == payload
+
+
+@pytest.mark.parametrize("shape,npatch,overlap,reverse,amp", [
+    ((64, 96), [3, 4], 0.0, False, (2.0, 1.5)),
+    ((61, 97), [4, 5], 0.1, True, (3.0, -2.0)),
+    ((400, 800), [10, 20], 0.0, False, (6.0, 4.0)),
+    ((50, 70), [7, 9], 0.3, True, (9.0, 9.0)),       # tiles squeezed to a pixel or pushed off the canvas are dropped
+    ((37, 41), [37, 1], 0.0, False, (0.4, 0.4)),     # one-row patches
+])
+def test_warp_table_of_all_patches_at_once_equals_the_loop(shape, npatch, overlap, reverse, amp):
+    """The piecewise perspective warp's patch table built on stacked arrays against the reference's loop restated patch by patch
+    (piecewiseperspective.py:71-128): every field of every record, bit for bit."""
+    import ctypes as C
+
+    import darsia_amd as da
+    from darsia_amd import _lib
+    from darsia_amd.registration import PiecewisePerspectiveTransform, _patch_records
+
+    h, w = shape
+    patches = da.Patches(np.zeros(shape, np.float32), npatch, rel_overlap=overlap)
+
+    def displacement(p):
+        p = np.asarray(p, dtype=float)
+        return np.array([amp[0] * np.sin(np.pi * p[:, 0] / w) * np.cos(2.0 * p[:, 1] / h) - 1.3, amp[1] * np.sin(np.pi * p[:, 1] / h) + 0.7])
+
+    loop = PiecewisePerspectiveTransform._patch_records_one_by_one(patches, displacement, reverse, h, w)
+    corners = np.fliplr(np.asarray(patches.global_corners_voxels, dtype=np.float64).reshape(-1, 2))
+    table = _patch_records(patches, displacement(corners), reverse, h, w)
+    assert len(table) == len(loop) and table.dtype.itemsize == C.sizeof(_lib.WarpPatch)
+    assert len(loop) > 0
+    want = b"".join(bytes(memoryview(r)) for r in loop)
+    assert table.tobytes() == want
