@@ -31,7 +31,7 @@ EXPORTS = (
     "dxh_warp_patches", "dxh_tps_eval", "dxh_affine_color",
     "dxh_solver_create", "dxh_solver_destroy", "dxh_solver_set_params", "dxh_solver_solve", "dxh_solver_get_params",
     "dxh_tvd_set_solver", "dxh_tv_bregman_gs", "dxh_map_coordinates", "dxh_resize", "dxh_div3_probe",
-    "dxh_tvd_energy", "dxh_tvd_adapt_ell", "dxh_tvd_set_base", "dxh_tvd_set_cleaning_filter", "dxh_tvd_upload_signal", "dxh_tvd_download_model", "dxh_tvd_set_base_typed", "dxh_tvd_upload_signal_typed", "dxh_warp_patches_typed",
+    "dxh_tvd_energy", "dxh_tvd_adapt_ell", "dxh_tvd_set_base", "dxh_tvd_set_cleaning_filter", "dxh_tvd_upload_signal", "dxh_tvd_download_model", "dxh_tvd_set_base_typed", "dxh_tvd_upload_signal_typed", "dxh_warp_patches_typed", "dxh_phase_correlation",
     "dxh_comm_unique_id", "dxh_comm_create_rccl", "dxh_comm_create_host", "dxh_comm_destroy", "dxh_comm_allreduce",
     "dxh_comm_barrier", "dxh_comm_info", "dxh_tvd_attach_comm", "dxh_tvd_exchange", "dxh_tvd_run_slab",
     "dxh_mem_alloc", "dxh_mem_free", "dxh_mem_copy", "dxh_sqrt_probe", "dxh_rcp_probe", "dxh_tvd_solve_banded", "dxh_mem_trim", "dxh_tps_eval_pair", "dxh_tvd_set_coeffs_typed",
@@ -139,6 +139,7 @@ def _declare(lib):
     lib.dxh_chambolle.argtypes = [i, i, i, i64, i64, i64, vp, vp, dbl, dbl, i, C.POINTER(i)]
     lib.dxh_warp_patches.argtypes = [i, i, i, i, vp, vp, i, vp]
     lib.dxh_warp_patches_typed.argtypes = [i, i, i, i, i, vp, vp, i, vp]
+    lib.dxh_phase_correlation.argtypes = [i, i, i, i, i, vp, vp, i, vp, dbl, vp, vp]
     lib.dxh_tps_eval.argtypes = [i, i, i, vp, vp, vp, vp, vp, i64, vp, i, dbl, dbl, dbl, dbl, vp]
     lib.dxh_tps_eval_pair.argtypes = [i, i, vp, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, i64, i64, dbl, dbl, dbl, dbl, dbl, dbl, vp]
     lib.dxh_affine_color.argtypes = [i, i, i64, vp, vp, vp, i, vp]

@@ -1,5 +1,6 @@
 // Dense per-pixel kernels around the TV path: piecewise perspective warp (registration), thin-plate
 // spline displacement field, affine colour balance.  gfx950 only.
+#include <algorithm>
 #include <array>
 #include <atomic>
 #include <memory>
@@ -448,6 +449,277 @@ __global__ void __launch_bounds__(256) k_resize(const T* __restrict__ src, int H
 
 using namespace dxh;
 
+// ---- patch translation by phase correlation ----------------------------------------------------------------------
+// The estimator darsia_amd's registration ships in place of the reference's OpenCV ORB + RANSAC one (no counterpart in
+// the reference; algorithm stated in oracle/phase_correlation_numpy.py): per patch pair, Hann-windowed mean-free patches
+// zero-padded to (P0, P1), cross-power spectrum normalised to unit modulus, inverse transform, peak + parabolic fit.
+// All patches of a call go through the device together, float64 throughout.  The transforms are radix-2 in LDS, one
+// row or column per workgroup: forward passes decimate in frequency (natural order in, bit-reversed out), inverse
+// passes decimate in time (bit-reversed in, natural out) -- the cross-power product in between is elementwise, so no
+// permutation is ever needed.
+struct PcRoi { int r0, r1, c0, c1; };
+
+template <typename S>
+__device__ __forceinline__ double pc_pixel(const S* __restrict__ img, int W, int C, int r, int c) {
+    const S* p = img + ((size_t)r * W + c) * C;
+    if (C == 1) return (double)p[0];
+    double s = (double)p[0];        // ndarray.mean(axis=2) of three channels: ((x0 + x1) + x2) / 3
+    s += (double)p[1];
+    s += (double)p[2];
+    return s / 3.0;
+}
+
+__device__ __forceinline__ double2 pc_cmul(double2 a, double2 b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// np.hanning(M)[k] = 0.5 + 0.5 cos(pi n / (M - 1)), n = 2 k - (M - 1)
+__device__ __forceinline__ double pc_hann(int k, int M) {
+    if (M == 1) return 1.0;
+    return 0.5 + 0.5 * cos(3.14159265358979323846 * (double)(2 * k - (M - 1)) / (double)(M - 1));
+}
+
+// forward: decimation in frequency, twiddles tw[k] = exp(-2 pi i k / N), output bit-reversed; `batch` independent
+// transforms lie one after the other in buf
+__device__ __forceinline__ void pc_fft_dif(double2* buf, int N, int logN, const double2* __restrict__ tw, int batch = 1) {
+    for (int s = logN; s >= 1; --s) {
+        const int half = 1 << (s - 1);
+        const int stride = N >> s;
+        for (int t = threadIdx.x; t < batch * (N / 2); t += blockDim.x) {
+            const int tt = t & (N / 2 - 1);
+            const int k = tt & (half - 1);
+            const int j = (t >> (logN - 1)) * N + ((tt >> (s - 1)) << s) + k;
+            const double2 u = buf[j], v = buf[j + half];
+            buf[j] = make_double2(u.x + v.x, u.y + v.y);
+            buf[j + half] = pc_cmul(make_double2(u.x - v.x, u.y - v.y), tw[k * stride]);
+        }
+        __syncthreads();
+    }
+}
+
+// inverse (unnormalised): decimation in time on bit-reversed input, conjugate twiddles, natural output
+__device__ __forceinline__ void pc_ifft_dit(double2* buf, int N, int logN, const double2* __restrict__ tw, int batch = 1) {
+    for (int s = 1; s <= logN; ++s) {
+        const int half = 1 << (s - 1);
+        const int stride = N >> s;
+        for (int t = threadIdx.x; t < batch * (N / 2); t += blockDim.x) {
+            const int tt = t & (N / 2 - 1);
+            const int k = tt & (half - 1);
+            const int j = (t >> (logN - 1)) * N + ((tt >> (s - 1)) << s) + k;
+            double2 w = tw[k * stride];
+            w.y = -w.y;
+            const double2 u = buf[j], v = pc_cmul(buf[j + half], w);
+            buf[j] = make_double2(u.x + v.x, u.y + v.y);
+            buf[j + half] = make_double2(u.x - v.x, u.y - v.y);
+        }
+        __syncthreads();
+    }
+}
+
+// mean of every patch of both images: grid (npatch, 2)
+template <typename S>
+__global__ void __launch_bounds__(256) k_pc_mean(const S* __restrict__ src, const S* __restrict__ dst, int W, int C,
+                                                  const PcRoi* __restrict__ rois, double* __restrict__ means) {
+    __shared__ double sm[256 / kWave];
+    const PcRoi q = rois[blockIdx.x];
+    const S* img = blockIdx.y ? dst : src;
+    const int ph = q.r1 - q.r0, pw = q.c1 - q.c0;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < ph * pw; i += blockDim.x) acc += pc_pixel(img, W, C, q.r0 + i / pw, q.c0 + i % pw);
+#pragma unroll
+    for (int s = kWave / 2; s > 0; s >>= 1) acc += __shfl_down(acc, s, kWave);
+    if ((threadIdx.x & (kWave - 1)) == 0) sm[threadIdx.x / kWave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = 0.0;
+        for (int w = 0; w < 256 / kWave; ++w) s += sm[w];
+        means[blockIdx.y * gridDim.x + blockIdx.x] = s / ((double)ph * (double)pw);
+    }
+}
+
+// windowed, padded rows -> spectrum along the row.  grid (max patch height, npatch, 2); F[image][patch][P0][P1]
+template <typename S>
+__global__ void __launch_bounds__(256) k_pc_rows(const S* __restrict__ src, const S* __restrict__ dst, int W, int C,
+                                                  const PcRoi* __restrict__ rois, const double* __restrict__ means, int nmeans,
+                                                  int P0, int P1, int logP1, const double2* __restrict__ tw1, double2* __restrict__ FA,
+                                                  double2* __restrict__ FB) {
+    extern __shared__ double2 pc_buf[];
+    const PcRoi q = rois[blockIdx.y];
+    const int ph = q.r1 - q.r0, pw = q.c1 - q.c0, r = blockIdx.x;
+    if (r >= ph) return;
+    const S* img = blockIdx.z ? dst : src;
+    const double mean = means[(size_t)blockIdx.z * nmeans + blockIdx.y], wy = pc_hann(r, ph);
+    for (int c = threadIdx.x; c < P1; c += blockDim.x) {
+        double v = 0.0;
+        if (c < pw) v = ((pc_pixel(img, W, C, q.r0 + r, q.c0 + c) - mean) * wy) * pc_hann(c, pw);
+        pc_buf[c] = make_double2(v, 0.0);
+    }
+    __syncthreads();
+    pc_fft_dif(pc_buf, P1, logP1, tw1);
+    double2* out = (blockIdx.z ? FB : FA) + ((size_t)blockIdx.y * P0 + r) * P1;
+    for (int c = threadIdx.x; c < P1; c += blockDim.x) out[c] = pc_buf[c];
+}
+
+// columns: spectrum of both images, unit-modulus cross-power, inverse along the column.  A workgroup takes CB adjacent
+// columns (CB x 16 B contiguous per row: 8 columns are one 128-byte line), column cb at pc_buf[cb * P0 ...].  grid (P1 / CB, npatch)
+__global__ void __launch_bounds__(256) k_pc_cols(const PcRoi* __restrict__ rois, int P0, int P1, int logP0, int CB,
+                                                  const double2* __restrict__ tw0, double2* __restrict__ FA,
+                                                  double2* __restrict__ FB) {
+    extern __shared__ double2 pc_buf[];
+    const PcRoi q = rois[blockIdx.y];
+    const int ph = q.r1 - q.r0, c = blockIdx.x * CB;
+    double2* a = FA + (size_t)blockIdx.y * P0 * P1 + c;
+    double2* b = FB + (size_t)blockIdx.y * P0 * P1 + c;
+    const int n = P0 * CB;   // element i: row i / CB, column i % CB (CB is a power of two)
+    const int cm = CB - 1, cs = __ffs(CB) - 1;
+    const double2 zero = make_double2(0.0, 0.0);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int r = i >> cs, cb = i & cm;
+        pc_buf[cb * P0 + r] = r < ph ? a[(size_t)r * P1 + cb] : zero;
+    }
+    __syncthreads();
+    pc_fft_dif(pc_buf, P0, logP0, tw0, CB);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {   // re-read below by the same thread
+        const int r = i >> cs, cb = i & cm;
+        a[(size_t)r * P1 + cb] = pc_buf[cb * P0 + r];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int r = i >> cs, cb = i & cm;
+        pc_buf[cb * P0 + r] = r < ph ? b[(size_t)r * P1 + cb] : zero;
+    }
+    __syncthreads();
+    pc_fft_dif(pc_buf, P0, logP0, tw0, CB);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int r = i >> cs, cb = i & cm;
+        const double2 fa = a[(size_t)r * P1 + cb], fb = pc_buf[cb * P0 + r];
+        const double2 x = pc_cmul(fb, make_double2(fa.x, -fa.y));
+        const double mag = fmax(hypot(x.x, x.y), 1e-12);
+        pc_buf[cb * P0 + r] = make_double2(x.x / mag, x.y / mag);
+    }
+    __syncthreads();
+    pc_ifft_dit(pc_buf, P0, logP0, tw0, CB);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int r = i >> cs, cb = i & cm;
+        b[(size_t)r * P1 + cb] = pc_buf[cb * P0 + r];
+    }
+}
+
+// rows back: correlation surface (unnormalised; only its peak and ratios of its values are used).  grid (P0, npatch)
+__global__ void __launch_bounds__(256) k_pc_rows_inv(int P0, int P1, int logP1, const double2* __restrict__ tw1,
+                                                      const double2* __restrict__ FB, double* __restrict__ corr) {
+    extern __shared__ double2 pc_buf[];
+    const size_t row = (size_t)blockIdx.y * P0 + blockIdx.x;
+    const double2* in = FB + row * P1;
+    for (int c = threadIdx.x; c < P1; c += blockDim.x) pc_buf[c] = in[c];
+    __syncthreads();
+    pc_ifft_dit(pc_buf, P1, logP1, tw1);
+    double* out = corr + row * P1;
+    for (int c = threadIdx.x; c < P1; c += blockDim.x) out[c] = pc_buf[c].x;
+}
+
+// peak (first maximum in row-major order, like np.argmax), parabolic refinement, acceptance.  grid (npatch)
+__global__ void __launch_bounds__(1024) k_pc_peak(const PcRoi* __restrict__ rois, int P0, int P1, const double* __restrict__ corr,
+                                                   double max_shift_fraction, double* __restrict__ shifts, int* __restrict__ ok) {
+    __shared__ double sv[1024 / kWave];
+    __shared__ long long si[1024 / kWave];
+    const double* cp = corr + (size_t)blockIdx.x * P0 * P1;
+    const long long n = (long long)P0 * P1;
+    double best = -INFINITY;
+    long long at = n;
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+        const double v = cp[i];
+        if (v > best) { best = v; at = i; }        // ascending i per thread: the first maximum stays
+    }
+#pragma unroll
+    for (int s = kWave / 2; s > 0; s >>= 1) {
+        const double ov = __shfl_down(best, s, kWave);
+        const long long oi = __shfl_down(at, s, kWave);
+        if (ov > best || (ov == best && oi < at)) { best = ov; at = oi; }
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) { sv[threadIdx.x / kWave] = best; si[threadIdx.x / kWave] = at; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (int w = 1; w < (int)(blockDim.x / kWave); ++w)
+        if (sv[w] > best || (sv[w] == best && si[w] < at)) { best = sv[w]; at = si[w]; }
+    const PcRoi q = rois[blockIdx.x];
+    const int ph = q.r1 - q.r0, pw = q.c1 - q.c0;
+    if (at >= n) at = 0;   // all NaN
+    const int py = (int)(at / P1), px = (int)(at % P1);
+    auto refine = [](double cm, double c0, double cq) {
+        const double den = cm - 2 * c0 + cq;
+        return den == 0 ? 0.0 : 0.5 * (cm - cq) / den;
+    };
+    const double c0 = cp[(size_t)py * P1 + px];
+    double dy = py + refine(cp[(size_t)((py + P0 - 1) % P0) * P1 + px], c0, cp[(size_t)((py + 1) % P0) * P1 + px]);
+    double dx = px + refine(cp[(size_t)py * P1 + (px + P1 - 1) % P1], c0, cp[(size_t)py * P1 + (px + 1) % P1]);
+    if (dy > P0 / 2) dy -= P0;
+    if (dx > P1 / 2) dx -= P1;
+    shifts[2 * blockIdx.x] = dx;
+    shifts[2 * blockIdx.x + 1] = dy;
+    ok[blockIdx.x] = !(fabs(dy) > max_shift_fraction * ph || fabs(dx) > max_shift_fraction * pw);
+}
+
+namespace {
+template <typename S>
+int phase_correlation_t(Dev& d, int H, int W, int C, const S* src, const S* dst, int npatch, const PcRoi* rois_h,
+                        double max_shift_fraction, double* shifts, int32_t* ok) {
+    int maxh = 0, maxw = 0;
+    for (int k = 0; k < npatch; ++k) {
+        maxh = std::max(maxh, rois_h[k].r1 - rois_h[k].r0);
+        maxw = std::max(maxw, rois_h[k].c1 - rois_h[k].c0);
+    }
+    int P0 = 8, P1 = 8, l0 = 3, l1 = 3;
+    while (P0 < maxh) { P0 *= 2; ++l0; }
+    while (P1 < maxw) { P1 *= 2; ++l1; }
+    DXH_REQUIRE(P0 <= 8192 && P1 <= 8192, "patches of up to 8192 pixels per side are supported (got %d x %d)", maxh, maxw);
+    // twiddles exp(-2 pi i k / N), k < N / 2, for both lengths
+    std::vector<double> tw((size_t)P0 + P1);
+    for (int k = 0; k < P0 / 2; ++k) { tw[2 * k] = std::cos(2.0 * M_PI * k / P0); tw[2 * k + 1] = -std::sin(2.0 * M_PI * k / P0); }
+    for (int k = 0; k < P1 / 2; ++k) { tw[P0 + 2 * k] = std::cos(2.0 * M_PI * k / P1); tw[P0 + 2 * k + 1] = -std::sin(2.0 * M_PI * k / P1); }
+    int rc;
+    void *dtw = nullptr, *drois = nullptr, *dmeans = nullptr, *dshift = nullptr, *dok = nullptr, *FA = nullptr, *FB = nullptr;
+    // patches per pass: two complex planes of P0 x P1 each, kept below a quarter of the free device memory
+    size_t free_b = 0, total_b = 0;
+    DXH_HIP(hipMemGetInfo(&free_b, &total_b));
+    const size_t per_patch = (size_t)P0 * P1 * sizeof(double2);
+    const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)npatch, free_b / 8 / per_patch));
+    if ((rc = d.alloc(&dtw, sizeof(double) * tw.size())) || (rc = d.alloc(&drois, sizeof(PcRoi) * (size_t)npatch)) ||
+        (rc = d.alloc(&dmeans, sizeof(double) * 2 * (size_t)npatch)) || (rc = d.alloc(&dshift, sizeof(double) * 2 * (size_t)npatch)) ||
+        (rc = d.alloc(&dok, sizeof(int) * (size_t)npatch)) || (rc = d.alloc(&FA, per_patch * chunk)) || (rc = d.alloc(&FB, per_patch * chunk)))
+        return rc;
+    DXH_HIP(hipMemcpyAsync(dtw, tw.data(), sizeof(double) * tw.size(), hipMemcpyDefault, d.st));
+    DXH_HIP(hipMemcpyAsync(drois, rois_h, sizeof(PcRoi) * (size_t)npatch, hipMemcpyDefault, d.st));
+    const double2* tw0 = (const double2*)dtw;
+    const double2* tw1 = tw0 + P0 / 2;
+    // columns per workgroup of the column pass: as many as 64 KB of LDS hold, at most one 128-byte line of them
+    const int CB = std::max(1, std::min(8, 4096 / P0));
+    const size_t lds0 = (size_t)P0 * CB * sizeof(double2), lds1 = (size_t)P1 * sizeof(double2);
+    if (lds1 > 64 * 1024) {
+        DXH_HIP(hipFuncSetAttribute((const void*)k_pc_rows<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        DXH_HIP(hipFuncSetAttribute((const void*)k_pc_rows_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+    }
+    if (lds0 > 64 * 1024) DXH_HIP(hipFuncSetAttribute((const void*)k_pc_cols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0));
+    hipLaunchKernelGGL((k_pc_mean<S>), dim3(npatch, 2), dim3(256), 0, d.st, src, dst, W, C, (const PcRoi*)drois, (double*)dmeans);
+    for (int p0 = 0; p0 < npatch; p0 += chunk) {
+        const int np = std::min(chunk, npatch - p0);
+        const PcRoi* r = (const PcRoi*)drois + p0;
+        // means are laid out [image][patch of the whole call]: the chunk's slice starts at p0, the image stride stays npatch
+        hipLaunchKernelGGL((k_pc_rows<S>), dim3(maxh, np, 2), dim3(256), lds1, d.st, src, dst, W, C, r,
+                           (const double*)dmeans + p0, npatch, P0, P1, l1, tw1, (double2*)FA, (double2*)FB);
+        hipLaunchKernelGGL(k_pc_cols, dim3(P1 / CB, np), dim3(256), lds0, d.st, r, P0, P1, l0, CB, tw0, (double2*)FA, (double2*)FB);
+        hipLaunchKernelGGL(k_pc_rows_inv, dim3(P0, np), dim3(256), lds1, d.st, P0, P1, l1, tw1, (const double2*)FB, (double*)FA);
+        hipLaunchKernelGGL(k_pc_peak, dim3(np), dim3(1024), 0, d.st, r, P0, P1, (const double*)FA, max_shift_fraction,
+                           (double*)dshift + 2 * p0, (int*)dok + p0);
+        DXH_HIP(hipGetLastError());
+    }
+    DXH_HIP(hipMemcpyAsync(shifts, dshift, sizeof(double) * 2 * (size_t)npatch, hipMemcpyDefault, d.st));
+    DXH_HIP(hipMemcpyAsync(ok, dok, sizeof(int) * (size_t)npatch, hipMemcpyDefault, d.st));
+    DXH_HIP(hipStreamSynchronize(d.st));
+    return DXH_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int dxh_warp_patches_typed(int device, int H, int W, int C, int dtype, const void* base, const dxh_warp_patch* patches,
@@ -543,6 +815,43 @@ int dxh_warp_patches_typed(int device, int H, int W, int C, int dtype, const voi
 int dxh_warp_patches(int device, int H, int W, int C, const float* base, const dxh_warp_patch* patches, int npatch,
                      float* canvas) {
     return dxh_warp_patches_typed(device, H, W, C, DXH_F32, base, patches, npatch, canvas);
+}
+
+int dxh_phase_correlation(int device, int H, int W, int C, int dtype, const void* src, const void* dst, int npatch,
+                          const int32_t* rois, double max_shift_fraction, double* shifts, int32_t* ok) {
+    DXH_REQUIRE(src && dst && rois && shifts && ok, "null argument");
+    DXH_REQUIRE(H >= 1 && W >= 1 && (C == 1 || C == 3) && npatch >= 1, "shape (%d, %d, %d) with %d patches not supported", H, W, C, npatch);
+    DXH_REQUIRE(dtype == DXH_F32 || dtype == DXH_F64 || dtype == DXH_U8 || dtype == DXH_U16,
+                "dtype %d not supported (float32, float64, uint8, uint16)", dtype);
+    static_assert(sizeof(PcRoi) == 4 * sizeof(int32_t), "roi layout");
+    const PcRoi* q = reinterpret_cast<const PcRoi*>(rois);
+    for (int k = 0; k < npatch; ++k)
+        DXH_REQUIRE(q[k].r0 >= 0 && q[k].r0 < q[k].r1 && q[k].r1 <= H && q[k].c0 >= 0 && q[k].c0 < q[k].c1 && q[k].c1 <= W,
+                    "patch %d: rectangle outside the image", k);
+    int rc = check_device(device);
+    if (rc) return rc;
+    Dev d;
+    DXH_HIP(cached_stream(device, &d.st));
+    static const size_t width[4] = {4, 8, 1, 2};
+    const size_t bytes = (size_t)H * W * C * width[dtype];
+    const void* dimg[2] = {src, dst};
+    for (int i = 0; i < 2; ++i) {
+        if (is_device_ptr(dimg[i])) continue;
+        void* p = nullptr;
+        if ((rc = d.alloc(&p, bytes))) return rc;
+        DXH_HIP(hipMemcpyAsync(p, dimg[i], bytes, hipMemcpyDefault, d.st));
+        dimg[i] = p;
+    }
+    switch (dtype) {
+        case DXH_F32: rc = phase_correlation_t<float>(d, H, W, C, (const float*)dimg[0], (const float*)dimg[1], npatch, q, max_shift_fraction, shifts, ok); break;
+        case DXH_F64: rc = phase_correlation_t<double>(d, H, W, C, (const double*)dimg[0], (const double*)dimg[1], npatch, q, max_shift_fraction, shifts, ok); break;
+        case DXH_U8: rc = phase_correlation_t<unsigned char>(d, H, W, C, (const unsigned char*)dimg[0], (const unsigned char*)dimg[1], npatch, q, max_shift_fraction, shifts, ok); break;
+        default: rc = phase_correlation_t<unsigned short>(d, H, W, C, (const unsigned short*)dimg[0], (const unsigned short*)dimg[1], npatch, q, max_shift_fraction, shifts, ok); break;
+    }
+    if (rc) return rc;
+    for (int k = 0; k < npatch; ++k)
+        if (std::min(q[k].r1 - q[k].r0, q[k].c1 - q[k].c0) < 8) ok[k] = 0;   // too small to say anything
+    return DXH_OK;
 }
 
 int dxh_tps_eval(int device, int p, int dout, const double* centers, const double* coeffs, const double* shift,

@@ -4,13 +4,13 @@ multi_image_analysis/imageregistration.py:17-306, 490-659).
 
 What runs where:
 
-* per-patch translation estimation -- HOST, injectable.  The reference uses ORB features + RANSAC
+* per-patch translation estimation -- injectable.  The reference uses ORB features + RANSAC
   homographies from OpenCV (corrections/shape/translation.py:36-107), which is sparse, OpenCV-internal
   work and out of scope.  Any object with the reference estimator's
   ``find_effective_translation(img_src, img_dst, roi_src, roi_dst, mask_src=, mask_dst=, plot_matches=)``
-  method can be plugged in (``darsia.TranslationEstimator`` included).  The default here is a small
-  phase-correlation estimator so that the pipeline runs without OpenCV; it is NOT the reference's
-  estimator and produces different translations.
+  method can be plugged in (``darsia.TranslationEstimator`` included).  The default here is a
+  phase-correlation estimator that runs on the GPU for all patches of the image pair in one call
+  (``dxh_phase_correlation``); it is NOT the reference's estimator and produces different translations.
 * thin-plate-spline fit on ~N_patches + boundary points -- HOST, SciPy, as in the reference.
 * dense evaluation of the displacement field and the piecewise perspective warp -- GPU
   (``darsia_amd.registration``).
@@ -26,6 +26,7 @@ from typing import Optional, Union
 import numpy as np
 from scipy.interpolate import RBFInterpolator
 
+from . import _lib
 from .image import Image
 from .registration import Patches, PiecewisePerspectiveTransform, evaluate_rbf
 
@@ -34,45 +35,49 @@ logger = logging.getLogger(__name__)
 _GPU_EVAL_THRESHOLD = 4096  # below this many points SciPy on the host is faster than a launch
 
 
+_PC_DTYPES = {np.dtype(np.float32): _lib.DXH_F32, np.dtype(np.float64): _lib.DXH_F64, np.dtype(np.uint8): 2, np.dtype(np.uint16): 3}
+
+
 class PhaseCorrelationEstimator:
-    """Whole-patch translation by FFT phase correlation with a parabolic sub-pixel fit (host, NumPy).
-    Stand-in for ``darsia.TranslationEstimator`` (ORB + RANSAC), same call signature."""
+    """Whole-patch translation by FFT phase correlation with a parabolic sub-pixel fit, on the device
+    (``dxh_phase_correlation``; the algorithm is stated in oracle/phase_correlation_numpy.py).  Stand-in for
+    ``darsia.TranslationEstimator`` (ORB + RANSAC, OpenCV) with the same call signature; ``find_effective_translations`` takes
+    all patches of an image pair in one call, which is what ``TranslationAnalysis`` uses when an estimator offers it."""
 
     def __init__(self, max_shift_fraction: float = 0.25) -> None:
         self.max_shift_fraction = max_shift_fraction
 
+    def find_effective_translations(self, img_src, img_dst, rois, masks_src=None, masks_dst=None) -> list:
+        """``[(translation, intact)]`` per patch; ``rois``: pairs of slices or rows (r0, r1, c0, c1) -- the same rectangle of both
+        images; ``masks_*``: full-size boolean arrays, a patch without a single active pixel in either is not estimated."""
+        a, b = np.asarray(img_src), np.asarray(img_dst)
+        boxes = np.array([[r[0].start, r[0].stop, r[1].start, r[1].stop] if isinstance(r[0], slice) else list(r) for r in rois],
+                         dtype=np.int32).reshape(-1, 4)
+        if a.shape != b.shape or a.ndim not in (2, 3) or (a.ndim == 3 and a.shape[2] != 3):
+            return [(None, False)] * len(boxes)
+        boxes[:, 1] = np.minimum(boxes[:, 1], a.shape[0])
+        boxes[:, 3] = np.minimum(boxes[:, 3], a.shape[1])
+        if a.dtype != b.dtype or a.dtype not in _PC_DTYPES:
+            a, b = a.astype(np.float64), b.astype(np.float64)
+        a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+        _lib.require_gpu()
+        n = len(boxes)
+        shifts = np.empty((n, 2), np.float64)
+        ok = np.empty(n, np.int32)
+        _lib.check(_lib.load().dxh_phase_correlation(_lib.default_device(), a.shape[0], a.shape[1], 1 if a.ndim == 2 else 3,
+                                                      _PC_DTYPES[a.dtype], _lib.ptr(a), _lib.ptr(b), n, _lib.ptr(boxes),
+                                                      float(self.max_shift_fraction), _lib.ptr(shifts), _lib.ptr(ok)))
+        out = []
+        for k, (r0, r1, c0, c1) in enumerate(boxes):
+            active = ok[k] and (masks_src is None or masks_dst is None or
+                                (np.any(masks_src[r0:r1, c0:c1]) and np.any(masks_dst[r0:r1, c0:c1])))
+            out.append((np.array([[1.0, 0.0, shifts[k, 0]], [0.0, 1.0, shifts[k, 1]]]), True) if active else (None, False))
+        return out
+
     def find_effective_translation(self, img_src, img_dst, roi_src=None, roi_dst=None, mask_src=None, mask_dst=None,
                                    plot_matches: bool = False):
-        a = np.asarray(img_src, dtype=np.float64)
-        b = np.asarray(img_dst, dtype=np.float64)
-        if a.ndim == 3:
-            a, b = a.mean(axis=2), b.mean(axis=2)
-        if a.shape != b.shape or min(a.shape) < 8:
-            return None, False
-        if mask_src is not None and mask_dst is not None and not (np.any(mask_src) and np.any(mask_dst)):
-            return None, False
-        wy, wx = np.hanning(a.shape[0])[:, None], np.hanning(a.shape[1])[None, :]
-        fa = np.fft.rfft2((a - a.mean()) * wy * wx)
-        fb = np.fft.rfft2((b - b.mean()) * wy * wx)
-        cross = fb * np.conj(fa)
-        cross /= np.maximum(np.abs(cross), 1e-12)
-        corr = np.fft.irfft2(cross, s=a.shape)
-        py, px = np.unravel_index(np.argmax(corr), corr.shape)
-
-        def refine(c_m, c_0, c_p):
-            den = c_m - 2 * c_0 + c_p
-            return 0.0 if den == 0 else 0.5 * (c_m - c_p) / den
-
-        h, w = corr.shape
-        dy = py + refine(corr[(py - 1) % h, px], corr[py, px], corr[(py + 1) % h, px])
-        dx = px + refine(corr[py, (px - 1) % w], corr[py, px], corr[py, (px + 1) % w])
-        if dy > h / 2:
-            dy -= h
-        if dx > w / 2:
-            dx -= w
-        if abs(dy) > self.max_shift_fraction * h or abs(dx) > self.max_shift_fraction * w:
-            return None, False
-        return np.array([[1.0, 0.0, dx], [0.0, 1.0, dy]]), True
+        a = np.asarray(img_src)
+        return self.find_effective_translations(img_src, img_dst, [(0, a.shape[0], 0, a.shape[1])], mask_src, mask_dst)[0]
 
 
 class TranslationAnalysis:
@@ -88,6 +93,7 @@ class TranslationAnalysis:
         self.have_translation = np.zeros(tuple(self.N_patches), dtype=bool)
         self.mask_base = (Image(np.ones(base.img.shape[:2], dtype=bool), dimensions=base.dimensions)
                           if mask is None else mask.copy())
+        self._all_true_base = self.mask_base.img if mask is None else None
         self.interpolator_translation_x = None
         self.interpolator_translation_y = None
 
@@ -112,6 +118,7 @@ class TranslationAnalysis:
         self.img = img
         self.mask_img = (Image(np.ones(img.img.shape[:2], dtype=bool), dimensions=img.dimensions)
                          if mask is None else mask.copy())
+        self._all_true_img = self.mask_img.img if mask is None else None   # the array known to be all True, if still in place
 
     # ---- boundary conditions (translationanalysis.py:310-404, pixel units) ----------------------------
     def bc_x(self, units=("pixel", "pixel")):
@@ -161,11 +168,21 @@ class TranslationAnalysis:
         have = np.zeros(tuple(self.N_patches), dtype=bool)
         centers = self._patch_centers_pixel()
         coords, tx, ty = [], [], []
+        batch = getattr(self.translation_estimator, "find_effective_translations", None)
+        if batch is not None:
+            # all patches of the pair in one call (the device estimator): same rectangles, same masks as the loop below
+            flat = batch(self.img.img, self.base.img, [patches_img.rois[i][j] for i in range(self.N_patches[0]) for j in range(self.N_patches[1])],
+                         *((None, None) if (self.mask_img.img is getattr(self, "_all_true_img", None)
+                                            and self.mask_base.img is getattr(self, "_all_true_base", None))
+                           else (self.mask_img.img, self.mask_base.img)))
         for i in range(self.N_patches[0]):
             for j in range(self.N_patches[1]):
-                translation, intact = self.translation_estimator.find_effective_translation(
-                    patches_img(i, j).img, self.patches_base(i, j).img, None, None,
-                    mask_src=patches_mask_img(i, j).img, mask_dst=patches_mask_base(i, j).img, plot_matches=False)
+                if batch is not None:
+                    translation, intact = flat[i * self.N_patches[1] + j]
+                else:
+                    translation, intact = self.translation_estimator.find_effective_translation(
+                        patches_img(i, j).img, self.patches_base(i, j).img, None, None,
+                        mask_src=patches_mask_img(i, j).img, mask_dst=patches_mask_base(i, j).img, plot_matches=False)
                 if intact:
                     have[i, j] = True
                     disp = np.asarray(translation)[:, -1]
