@@ -11,6 +11,31 @@ dst = gaussian_filter(rng.random((H, W)).astype(np.float32), 3.0)
 dst = ((dst - dst.min()) / (dst.max() - dst.min())).astype(np.float32)
 yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
 src = map_coordinates(dst, [yy + 4.0 * np.sin(np.pi * yy / H), xx + 6.0 * np.sin(np.pi * xx / W)], order=1, mode="nearest").astype(np.float32)
+
+
+class HostEstimator:
+    """The estimator as it ran before (per patch, NumPy FFTs on the host), for the comparison only."""
+
+    def find_effective_translation(self, img_src, img_dst, roi_src=None, roi_dst=None, mask_src=None, mask_dst=None, plot_matches=False):
+        a, b = np.asarray(img_src, dtype=np.float64), np.asarray(img_dst, dtype=np.float64)
+        wy, wx = np.hanning(a.shape[0])[:, None], np.hanning(a.shape[1])[None, :]
+        fa = np.fft.rfft2((a - a.mean()) * wy * wx)
+        fb = np.fft.rfft2((b - b.mean()) * wy * wx)
+        cross = fb * np.conj(fa)
+        cross /= np.maximum(np.abs(cross), 1e-12)
+        corr = np.fft.irfft2(cross, s=a.shape)
+        py, px = np.unravel_index(np.argmax(corr), corr.shape)
+        h, w = corr.shape
+        ref = lambda m, c, p: 0.0 if (m - 2 * c + p) == 0 else 0.5 * (m - p) / (m - 2 * c + p)
+        dy = py + ref(corr[(py - 1) % h, px], corr[py, px], corr[(py + 1) % h, px])
+        dx = px + ref(corr[py, (px - 1) % w], corr[py, px], corr[py, (px + 1) % w])
+        dy, dx = (dy - h if dy > h / 2 else dy), (dx - w if dx > w / 2 else dx)
+        return np.array([[1.0, 0.0, dx], [0.0, 1.0, dy]]), True
+
+
+host = da.ImageRegistration(da.Image(dst), N_patches=[10, 20], rel_overlap=0.1, translation_estimator=HostEstimator())
+t0 = time.perf_counter(); res = host(da.Image(src)); t1 = time.perf_counter()
+print(f"with the per-patch NumPy estimator on the host (the path before): whole ImageRegistration.__call__ {1e3 * (t1 - t0):7.1f} ms", flush=True)
 for dtype in (np.float32, np.uint8):
     a = da.Image(src if dtype == np.float32 else (src * 255).astype(np.uint8))
     b = da.Image(dst if dtype == np.float32 else (dst * 255).astype(np.uint8))
