@@ -136,12 +136,7 @@ class TranslationAnalysis:
 
     def _patch_centers_pixel(self):
         """Patch centres as (x, y) pixels: metric centre -> voxel (floor) -> flipped (translationanalysis.py:249-255)."""
-        cs = self.base.coordinatesystem
-        centers = np.empty((self.N_patches[0], self.N_patches[1], 2))
-        for i in range(self.N_patches[0]):
-            for j in range(self.N_patches[1]):
-                centers[i, j] = np.flip(np.asarray(cs.voxel(self.patches_base.global_centers_cartesian[i, j])))
-        return centers
+        return np.asarray(self.patches_base.global_centers_voxels)[..., ::-1].astype(float)   # Patches holds exactly these voxels
 
     def _set_interpolators(self, coords, tx, ty) -> None:
         ex, etx = self.bc_x()
@@ -162,13 +157,16 @@ class TranslationAnalysis:
     def find_translation(self, units=("pixel", "pixel")):
         """translationanalysis.py:149-308 (pixel units)."""
         assert list(units) == ["pixel", "pixel"], "metric units are not mirrored"
-        patches_img = Patches(self.img, self.N_patches, rel_overlap=self.rel_overlap)
-        patches_mask_base = Patches(self.mask_base, self.N_patches, rel_overlap=self.rel_overlap)
-        patches_mask_img = Patches(self.mask_img, self.N_patches, rel_overlap=self.rel_overlap)
+        batch = getattr(self.translation_estimator, "find_effective_translations", None)
+        same_grid = self.img.img.shape[:2] == self.base.img.shape[:2] and list(self.img.dimensions) == list(self.base.dimensions)
+        # the patch rectangles depend on shape, dimensions and the patch grid only: the baseline's serve an image of its geometry
+        patches_img = self.patches_base if (batch is not None and same_grid) else Patches(self.img, self.N_patches, rel_overlap=self.rel_overlap)
+        if batch is None:
+            patches_mask_base = Patches(self.mask_base, self.N_patches, rel_overlap=self.rel_overlap)
+            patches_mask_img = Patches(self.mask_img, self.N_patches, rel_overlap=self.rel_overlap)
         have = np.zeros(tuple(self.N_patches), dtype=bool)
         centers = self._patch_centers_pixel()
         coords, tx, ty = [], [], []
-        batch = getattr(self.translation_estimator, "find_effective_translations", None)
         if batch is not None:
             # all patches of the pair in one call (the device estimator): same rectangles, same masks as the loop below
             flat = batch(self.img.img, self.base.img, [patches_img.rois[i][j] for i in range(self.N_patches[0]) for j in range(self.N_patches[1])],

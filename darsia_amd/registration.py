@@ -78,10 +78,10 @@ class Patches:
                       for j in range(nj)] for i in range(ni)]
         # centres: metric, then the voxel that holds them (image/patches.py:171-206)
         origin = np.asarray(base.origin, dtype=float)
-        self.global_centers_cartesian = np.array(
-            [[origin + np.array([(j + 0.5) * pdm[1], -(i + 0.5) * pdm[0]]) for j in range(nj)] for i in range(ni)])
-        self.global_centers_voxels = np.array(
-            [[np.asarray(cs.voxel(self.global_centers_cartesian[i, j])) for j in range(nj)] for i in range(ni)], dtype=int)
+        # (the same expressions per patch as a loop over i, j would evaluate, on index arrays)
+        ii, jj = np.arange(ni, dtype=float)[:, None], np.arange(nj, dtype=float)[None, :]
+        self.global_centers_cartesian = np.stack(np.broadcast_arrays(origin[0] + (jj + 0.5) * pdm[1], origin[1] + -(ii + 0.5) * pdm[0]), axis=-1)
+        self.global_centers_voxels = np.asarray(cs.voxel(self.global_centers_cartesian.reshape(-1, 2))).reshape(ni, nj, 2).astype(int)
         # corners, order: top left, bottom left, bottom right, top right (image/patches.py:214-300)
         self.global_corners_cartesian = np.array(
             [[np.array([[j * pdm[1], -i * pdm[0]], [j * pdm[1], -(i + 1) * pdm[0]], [(j + 1) * pdm[1], -(i + 1) * pdm[0]],
