@@ -5,6 +5,7 @@
 #include <atomic>
 #include <memory>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -683,7 +684,8 @@ int phase_correlation_t(Dev& d, int H, int W, int C, const S* src, const S* dst,
     size_t free_b = 0, total_b = 0;
     DXH_HIP(hipMemGetInfo(&free_b, &total_b));
     const size_t per_patch = (size_t)P0 * P1 * sizeof(double2);
-    const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)npatch, free_b / 8 / per_patch));
+    int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)npatch, free_b / 8 / per_patch));
+    if (const char* e = std::getenv("DXH_PC_CHUNK")) chunk = std::max(1, std::min(npatch, std::atoi(e)));   // developer knob
     if ((rc = d.alloc(&dtw, sizeof(double) * tw.size())) || (rc = d.alloc(&drois, sizeof(PcRoi) * (size_t)npatch)) ||
         (rc = d.alloc(&dmeans, sizeof(double) * 2 * (size_t)npatch)) || (rc = d.alloc(&dshift, sizeof(double) * 2 * (size_t)npatch)) ||
         (rc = d.alloc(&dok, sizeof(int) * (size_t)npatch)) || (rc = d.alloc(&FA, per_patch * chunk)) || (rc = d.alloc(&FB, per_patch * chunk)))

@@ -74,3 +74,15 @@ def test_large_patches_and_many_patches():
     np.testing.assert_allclose([t[:, 2] for t, ok in got if ok], [s for s, ok in want if ok], rtol=0, atol=1e-7)
     with pytest.raises(Exception, match="8192"):
         PhaseCorrelationEstimator().find_effective_translations(np.zeros((16, 9000), np.float32), np.zeros((16, 9000), np.float32), [(0, 16, 0, 9000)])
+
+
+def test_patches_in_several_passes_give_the_same_shifts(monkeypatch):
+    """When the two complex planes per patch do not fit the memory budget the patches go through in chunks (DXH_PC_CHUNK forces it)."""
+    a, b = _pair(200, 300, 9, shift=(-2.2, 4.4))
+    rois = [(r, r + 64, c, c + 96) for r in (0, 60, 136) for c in (0, 100, 204)]
+    est = PhaseCorrelationEstimator()
+    whole = est.find_effective_translations(a, b, rois)
+    monkeypatch.setenv("DXH_PC_CHUNK", "4")
+    chunked = est.find_effective_translations(a, b, rois)
+    assert [ok for _, ok in whole] == [ok for _, ok in chunked] and all(ok for _, ok in whole)
+    assert all(np.array_equal(t0, t1) for (t0, _), (t1, _) in zip(whole, chunked))
