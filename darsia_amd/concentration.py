@@ -376,13 +376,19 @@ class ConcentrationAnalysis:
             st.set_coeffs(*coefs, like)
             st._coef_mark = mark
         pre = ops if not self.first_restoration_then_model else []
-        # the frame goes over as stored (float32 / float64 / uint8 / uint16); the device widens where NumPy would
-        src = np.ascontiguousarray(probe, dtype=None if probe.dtype in _FRAME_DTYPES else st.dtype)
-        _lib.check(st.lib.dxh_tvd_upload_signal_typed(st._h, _lib.ptr(src), _FRAME_DTYPES[src.dtype], channels,
+        # the frame goes over as stored (float32 / float64 / uint8 / uint16); the device widens where NumPy would.  A frame that
+        # is in HBM already (DeviceArray: e.g. out of the colour or shape correction) is read where it lies.
+        if isinstance(probe, DeviceArray):
+            if np.dtype(probe.dtype) not in _FRAME_DTYPES:
+                raise TypeError(f"device-resident frames must be float32 / float64 / uint8 / uint16, not {probe.dtype}")
+            src = probe
+        else:
+            src = np.ascontiguousarray(probe, dtype=None if probe.dtype in _FRAME_DTYPES else st.dtype)
+        _lib.check(st.lib.dxh_tvd_upload_signal_typed(st._h, _lib.ptr(src), _FRAME_DTYPES[np.dtype(src.dtype)], channels,
                                                        _DIFF[self._diff_option], reduction,
                                                        C.cast(_ops_array(pre), C.c_void_p), len(pre)))
 
-    def _finish_frame(self, st: DeviceTVD, plan) -> np.ndarray:
+    def _finish_frame(self, st: DeviceTVD, plan, on_device: bool = False):
         reduction, channels, ops, solver, iso, mode = plan
         rest = self.restoration
         if mode == "op":
@@ -399,7 +405,7 @@ class ConcentrationAnalysis:
             flags = _lib.FLAG_ASYNC if rest.eps is None and tol is None else 0
             st.run(rest.max_num_iter, maxiter, tol, eps=rest.eps, isotropic=iso, flags=flags)
         post = ops if self.first_restoration_then_model else []
-        out = np.empty(st.shape, st.dtype)
+        out = DeviceArray(st.shape, st.dtype, st.device) if on_device else np.empty(st.shape, st.dtype)
         _lib.check(st.lib.dxh_tvd_download_model(st._h, _lib.ptr(out), C.cast(_ops_array(post), C.c_void_p), len(post)))
         return out
 
@@ -407,7 +413,7 @@ class ConcentrationAnalysis:
         dt = self._signal_dtype(probe, plan[0])
         st = self._ctx_for(0, (probe.shape[0], probe.shape[1], dt.str), plan[1])
         self._upload_frame(st, probe, plan)
-        return self._finish_frame(st, plan)
+        return self._finish_frame(st, plan, isinstance(probe, DeviceArray))   # device frame in, device concentration out
 
     def _wrap(self, img, concentration: np.ndarray):
         probe = img.img
@@ -500,6 +506,9 @@ class ConcentrationAnalysis:
         plan = self._fusable(probe)
         if plan is not None:
             concentration = self._device_call(probe, plan)
+        elif isinstance(probe, DeviceArray):
+            raise NotImplementedError("a device-resident frame needs the fused pipeline (monochromatic reduction, model of "
+                                      "linear / scaling / clip stages, TVD or no restoration, no balancing)")
         else:
             probe_img = copy.deepcopy(img)
             diff = self._subtract_background(probe_img)

@@ -70,6 +70,9 @@ class DeviceArray:
             _lib.check(self.lib.dxh_mem_copy(self.device, d.ptr, self.ptr, self.nbytes))
         return d
 
+    def __deepcopy__(self, memo) -> "DeviceArray":
+        return self.copy()   # Image.copy() is copy.deepcopy: the pixels are copied inside HBM
+
     def reshape(self, *shape) -> "DeviceArray":
         """A view with another shape (shares the memory; keep the original alive)."""
         shape = shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else shape

@@ -14,7 +14,9 @@ from .geometry import Coordinate, CoordinateSystem, interpret_indexing
 
 class Image:
     def __init__(self, img: np.ndarray, transformations=None, **kwargs) -> None:
-        if not isinstance(img, np.ndarray):
+        from .device import DeviceArray
+
+        if not isinstance(img, (np.ndarray, DeviceArray)):   # a DeviceArray: pixels that stay in HBM between device operators
             raise TypeError("img must be a numpy array")
         self.img = img
         self.original_dtype = img.dtype

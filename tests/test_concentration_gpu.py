@@ -282,3 +282,30 @@ def test_product_against_outputs_of_the_reference_class(tag):
     want = g[f"{tag}/out"]
     assert isinstance(out, da.ScalarImage) and out.name == "frame" and out.img.dtype == want.dtype
     assert np.array_equal(out.img, want), np.abs(out.img - want).max()
+
+
+def test_device_resident_frames_stay_on_the_device():
+    """A frame that is in HBM already (out of the colour correction, say) is read where it lies and the concentration comes back
+    as a device array: same bits as the host-array call."""
+    rng = np.random.default_rng(31)
+    h, w = 60, 88
+    base = da.OpticalImage((rng.random((h, w, 3)) * 0.5).astype(np.float32))
+    raw = (rng.random((h, w, 3)) * 255).astype(np.uint8)
+    balance = da.AffineBalance()
+    balance.balance_scaling, balance.balance_translation = np.eye(3) + 0.05 * rng.random((3, 3)), 0.01 * rng.random(3)
+    tvd = da.TVD(method="heterogeneous bregman", weight=0.05, omega=1.0, regularization=0.1, max_num_iter=8, eps=None)
+    model = da.CombinedModel([da.LinearModel(scaling=2.0, offset=0.0), da.ClipModel(min_value=0.0, max_value=1.0)])
+    ca = da.ConcentrationAnalysis(base, da.MonochromaticReduction(color="red"), None, tvd, model, **{"diff option": "positive"})
+    corrected_host = balance.apply_balance(raw)                                   # float32 on the host
+    want = ca(da.OpticalImage(corrected_host))
+    d_raw = da.DeviceArray.from_host(raw)
+    d_corrected = balance.apply_balance(d_raw)                                    # stays in HBM
+    assert isinstance(d_corrected, da.DeviceArray)
+    got = ca(da.OpticalImage(d_corrected, name="frame"))
+    assert isinstance(got, da.ScalarImage) and isinstance(got.img, da.DeviceArray) and got.name == "frame"
+    assert np.array_equal(got.img.get(), want.img)
+    dup = got.copy()                                                              # Image.copy(): a second device array
+    assert dup.img.ptr != got.img.ptr and np.array_equal(dup.img.get(), want.img)
+    generic = da.ConcentrationAnalysis(base, da.MonochromaticReduction(color=lambda im: im[..., 0]), None, None, model)
+    with pytest.raises(NotImplementedError, match="fused pipeline"):
+        generic(da.OpticalImage(d_corrected))
