@@ -50,22 +50,33 @@ class PhaseCorrelationEstimator:
     def find_effective_translations(self, img_src, img_dst, rois, masks_src=None, masks_dst=None) -> list:
         """``[(translation, intact)]`` per patch; ``rois``: pairs of slices or rows (r0, r1, c0, c1) -- the same rectangle of both
         images; ``masks_*``: full-size boolean arrays, a patch without a single active pixel in either is not estimated."""
-        a, b = np.asarray(img_src), np.asarray(img_dst)
+        from .device import DeviceArray
+
+        on_device = isinstance(img_src, DeviceArray) or isinstance(img_dst, DeviceArray)
+        if on_device:
+            # frames that are in HBM already are read where they lie; a host partner of the same dtype is uploaded by the call
+            a, b = (x if isinstance(x, DeviceArray) else np.ascontiguousarray(x) for x in (img_src, img_dst))
+            if np.dtype(a.dtype) != np.dtype(b.dtype) or np.dtype(a.dtype) not in _PC_DTYPES:
+                raise TypeError("device-resident frames must share one of the dtypes float32 / float64 / uint8 / uint16")
+        else:
+            a, b = np.asarray(img_src), np.asarray(img_dst)
         boxes = np.array([[r[0].start, r[0].stop, r[1].start, r[1].stop] if isinstance(r[0], slice) else list(r) for r in rois],
                          dtype=np.int32).reshape(-1, 4)
         if a.shape != b.shape or a.ndim not in (2, 3) or (a.ndim == 3 and a.shape[2] != 3):
             return [(None, False)] * len(boxes)
         boxes[:, 1] = np.minimum(boxes[:, 1], a.shape[0])
         boxes[:, 3] = np.minimum(boxes[:, 3], a.shape[1])
-        if a.dtype != b.dtype or a.dtype not in _PC_DTYPES:
-            a, b = a.astype(np.float64), b.astype(np.float64)
-        a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+        if not on_device:
+            if a.dtype != b.dtype or a.dtype not in _PC_DTYPES:
+                a, b = a.astype(np.float64), b.astype(np.float64)
+            a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
         _lib.require_gpu()
         n = len(boxes)
         shifts = np.empty((n, 2), np.float64)
         ok = np.empty(n, np.int32)
-        _lib.check(_lib.load().dxh_phase_correlation(_lib.default_device(), a.shape[0], a.shape[1], 1 if a.ndim == 2 else 3,
-                                                      _PC_DTYPES[a.dtype], _lib.ptr(a), _lib.ptr(b), n, _lib.ptr(boxes),
+        device = a.device if isinstance(a, DeviceArray) else (b.device if isinstance(b, DeviceArray) else _lib.default_device())
+        _lib.check(_lib.load().dxh_phase_correlation(device, a.shape[0], a.shape[1], 1 if a.ndim == 2 else 3,
+                                                      _PC_DTYPES[np.dtype(a.dtype)], _lib.ptr(a), _lib.ptr(b), n, _lib.ptr(boxes),
                                                       float(self.max_shift_fraction), _lib.ptr(shifts), _lib.ptr(ok)))
         out = []
         for k, (r0, r1, c0, c1) in enumerate(boxes):

@@ -168,19 +168,27 @@ def warp_patches(base: np.ndarray, records) -> np.ndarray:
     """The canvas of ``records`` (``_lib.WarpPatch``) over ``base`` ((H, W) or (H, W, 3)), in ``base``'s dtype: what the reference
     computes as ``patch.astype(float32)`` -> float32 canvas -> ``canvas.astype(dtype)`` (piecewiseperspective.py:121-133).
     float32 / float64 / uint8 / uint16 images cross PCIe as they are stored and are converted on the device."""
+    from .device import DeviceArray
+
     _lib.require_gpu()
     h, w = base.shape[:2]
     chans = 1 if base.ndim == 2 else base.shape[2]
-    native = base.dtype in _WARP_DTYPES
-    src = np.ascontiguousarray(base, dtype=None if native else np.float32)
-    canvas = np.empty(src.shape, src.dtype)
+    native = np.dtype(base.dtype) in _WARP_DTYPES
+    device = _lib.default_device()
+    if isinstance(base, DeviceArray):   # an image in HBM is warped into a new device array
+        if not native:
+            raise TypeError(f"device-resident images must be float32 / float64 / uint8 / uint16, not {base.dtype}")
+        src, canvas, device = base, DeviceArray(base.shape, base.dtype, base.device), base.device
+    else:
+        src = np.ascontiguousarray(base, dtype=None if native else np.float32)
+        canvas = np.empty(src.shape, src.dtype)
     if isinstance(records, np.ndarray):
         table = np.ascontiguousarray(records, dtype=np.dtype(_lib.WarpPatch))
         table_ptr = table.ctypes.data_as(C.c_void_p) if len(table) else None
     else:
         table = (_lib.WarpPatch * max(1, len(records)))(*records)
         table_ptr = C.cast(table, C.c_void_p)
-    _lib.check(_lib.load().dxh_warp_patches_typed(_lib.default_device(), h, w, chans, _WARP_DTYPES[src.dtype], _lib.ptr(src),
+    _lib.check(_lib.load().dxh_warp_patches_typed(device, h, w, chans, _WARP_DTYPES[np.dtype(src.dtype)], _lib.ptr(src),
                                                    table_ptr, len(records), _lib.ptr(canvas)))
     return canvas if native else canvas.astype(base.dtype)
 
