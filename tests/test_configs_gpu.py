@@ -159,3 +159,50 @@ def test_resize_tvd_resize_chain_stays_on_the_device():
     # the default TVD() method (Chambolle) chains the same way
     chain2 = da.CombinedModel([da.Resize(fx=0.5, fy=0.5, interpolation="inter_area"), da.TVD(weight=0.1, max_num_iter=20)])
     assert np.array_equal(chain2(da.DeviceArray.from_host(sig)).get(), chain2(sig))
+
+
+def test_whole_frame_pipeline_stays_in_hbm():
+    """A raw uint8 frame through colour correction, curvature correction, registration onto the baseline and concentration
+    analysis: one upload, one download, every stage reads and writes device arrays -- and the result equals the same chain run
+    operator by operator through host arrays, bit for bit."""
+    import warnings
+
+    from scipy.ndimage import gaussian_filter, map_coordinates
+
+    rng = np.random.default_rng(77)
+    h, w = 240, 352
+    tex = np.stack([gaussian_filter(rng.random((h, w)), 2.5) for _ in range(3)], axis=-1)
+    tex = (tex - tex.min()) / (tex.max() - tex.min())
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    field = np.sin(np.pi * yy / h) * np.sin(np.pi * xx / w)
+    moved = np.stack([map_coordinates(tex[..., c], [yy - 1.2 * field, xx + 2.0 * field], order=1, mode="nearest") for c in range(3)], axis=-1)
+    blob = np.exp(-(((yy - h / 2) / (h / 6)) ** 2 + ((xx - w / 3) / (w / 7)) ** 2))
+    raw_base = (255 * np.clip(0.6 * tex + 0.1, 0, 1)).astype(np.uint8)
+    raw_frame = (255 * np.clip(0.6 * moved + 0.1 + 0.25 * blob[..., None] * np.array([1.0, 0.3, 0.1]), 0, 1)).astype(np.uint8)
+
+    balance = da.AffineBalance()
+    balance.balance_scaling, balance.balance_translation = np.eye(3) + 0.03 * rng.random((3, 3)), 0.005 * rng.random(3)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        curvature = da.CurvatureCorrection(config={"bulge": dict(horizontal_bulge=2e-6, vertical_bulge=-1e-6)})
+    tvd = da.TVD(method="heterogeneous bregman", weight=0.05, omega=1.0, regularization=0.1, max_num_iter=10, eps=None)
+    model = da.CombinedModel([da.LinearModel(scaling=2.0, offset=0.0), da.ClipModel(min_value=0.0, max_value=1.0)])
+
+    def prepare(raw):                       # uint8 (host or device) -> corrected float32 frame of the same kind
+        return curvature(balance.apply_balance(raw))
+
+    # operator by operator through host arrays
+    base_h, frame_h = da.OpticalImage(prepare(raw_base)), da.OpticalImage(prepare(raw_frame))
+    reg_h = da.ImageRegistration(base_h, N_patches=[3, 4], rel_overlap=0.1)
+    aligned_h = reg_h(frame_h)
+    ca = da.ConcentrationAnalysis(base_h, da.MonochromaticReduction(color="red"), None, tvd, model, **{"diff option": "positive"})
+    want = ca(da.OpticalImage(aligned_h.img))
+    # the same with the pixels in HBM from the first stage on
+    base_d, frame_d = prepare(da.DeviceArray.from_host(raw_base)), prepare(da.DeviceArray.from_host(raw_frame))
+    assert isinstance(frame_d, da.DeviceArray) and np.array_equal(frame_d.get(), frame_h.img)
+    reg_d = da.ImageRegistration(da.OpticalImage(base_d), N_patches=[3, 4], rel_overlap=0.1)
+    aligned_d = reg_d(da.OpticalImage(frame_d))
+    assert isinstance(aligned_d.img, da.DeviceArray) and np.array_equal(aligned_d.img.get(), aligned_h.img)
+    got = ca(da.OpticalImage(aligned_d.img))
+    assert isinstance(got.img, da.DeviceArray) and np.array_equal(got.img.get(), want.img)
+    assert want.img.max() > 0.2            # the tracer blob is there
