@@ -476,7 +476,7 @@ class ConcentrationAnalysis:
                     self._signal_dtype(nxt.img, plan[0]) == dt
                 if same:
                     fut = submit((k + 1) % 2, nxt)   # overlaps the work on frame k below
-                out = self._finish_frame(self._ctxs[k % 2], plan)
+                out = self._finish_frame(self._ctxs[k % 2], plan, isinstance(cur.img, DeviceArray))
                 yield self._wrap(cur, out)
                 if nxt is not None and not same:
                     # a frame of another kind ends the pipelined stretch

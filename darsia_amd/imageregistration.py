@@ -15,8 +15,9 @@ What runs where:
 * dense evaluation of the displacement field and the piecewise perspective warp -- GPU
   (``darsia_amd.registration``).
 
-Only the single-level registration is mirrored; the multilevel driver
-(imageregistration.py:309-484) composes single levels with ``add``/``deduct`` and can be built on top.
+Single-level (``DiffeomorphicImageRegistration``) and multilevel (``MultiscaleDiffeomorphicImageRegistration``,
+imageregistration.py:309-484: single levels composed with ``add`` / ``deduct``) registration and the ``ImageRegistration`` façade.
+Images whose pixels are a ``DeviceArray`` stay in HBM through estimator and warp.
 """
 from __future__ import annotations
 

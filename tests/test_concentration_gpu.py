@@ -304,6 +304,9 @@ def test_device_resident_frames_stay_on_the_device():
     got = ca(da.OpticalImage(d_corrected, name="frame"))
     assert isinstance(got, da.ScalarImage) and isinstance(got.img, da.DeviceArray) and got.name == "frame"
     assert np.array_equal(got.img.get(), want.img)
+    series = list(ca.map([da.OpticalImage(d_corrected), da.OpticalImage(corrected_host), da.OpticalImage(d_corrected)]))
+    assert [type(x.img).__name__ for x in series] == ["DeviceArray", "ndarray", "DeviceArray"]
+    assert all(np.array_equal(x.img.get() if isinstance(x.img, da.DeviceArray) else x.img, want.img) for x in series)
     dup = got.copy()                                                              # Image.copy(): a second device array
     assert dup.img.ptr != got.img.ptr and np.array_equal(dup.img.get(), want.img)
     generic = da.ConcentrationAnalysis(base, da.MonochromaticReduction(color=lambda im: im[..., 0]), None, None, model)
