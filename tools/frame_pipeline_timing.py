@@ -50,3 +50,19 @@ for name, f in (("operator by operator through host arrays", through_host), ("pi
         t0 = time.perf_counter(); keep.append(f(raw_frame)); dt = (time.perf_counter() - t0) * 1e3
         print(f"{name:45s} {dt:8.1f} ms per frame", flush=True)
 print("same result:", np.array_equal(keep[3].img, keep[7]))
+
+# stage by stage (every call returns with its stream synchronised)
+def T(): return time.perf_counter()
+for rep in range(3):
+    t0 = T(); d = da.DeviceArray.from_host(raw_frame); t1 = T()
+    c = balance.apply_balance(d); t2 = T()
+    u = curvature(c); t3 = T()
+    ta = reg_d.image_registration.translation_analysis
+    img = da.OpticalImage(u); ta.load_image(img); t4 = T()
+    ta.find_translation(); t5 = T()
+    al = ta.translate_image(reverse=False); t6 = T()
+    con = ca(da.OpticalImage(al.img)); t7 = T()
+    res = con.img.get(); t8 = T()
+    ms = [1e3 * (b - a) for a, b in zip((t0, t1, t2, t3, t4, t5, t6, t7), (t1, t2, t3, t4, t5, t6, t7, t8))]
+    print("upload %.1f  colour %.1f  curvature %.1f  load %.1f  find_translation %.1f  translate_image %.1f  concentration %.1f  download %.1f  = %.1f ms"
+          % (*ms, sum(ms)), flush=True)
