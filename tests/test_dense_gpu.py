@@ -201,6 +201,8 @@ def test_deformation_correction_wraps_the_registration(tmp_path):
     img = da.ScalarImage(src.copy(), dimensions=[0.75, 1.0], name="frame")
     res = corr(img)
     assert res is not img and res.name == "frame" and np.array_equal(res.img, want.img) and np.array_equal(img.img, src)
+    on_device = corr(da.DeviceArray.from_host(src))                       # a frame in HBM comes back as one
+    assert isinstance(on_device, da.DeviceArray) and np.array_equal(on_device.get(), want.img)
     corr.save(tmp_path / "deformation.npz")
     other = da.DeformationCorrection(base, None)
     other.load(tmp_path / "deformation.npz")
