@@ -238,13 +238,19 @@ __global__ void __launch_bounds__(256) k_tps_pair(TpsPairArgs a) {
     const double y = a.gy0 + a.gsy * (double)(n / a.grid_w);
     double acc0 = 0.0, acc1 = 0.0;
     const double2* tb = reinterpret_cast<const double2*>(sm);
-    for (int i = 0; i < a.pu; ++i) {
-        const double2 c = tb[2 * i], w = tb[2 * i + 1];
-        const double dx = x - c.x, dy = y - c.y;
-        const double r2 = dx * dx + dy * dy;
-        const double phi = r2 == 0.0 ? 0.0 : 0.5 * r2 * tps_log(r2, ltab);
-        acc0 += phi * w.x;
-        acc1 += phi * w.y;
+    {
+        // compared with SciPy to a tolerance, not bit for bit: fused multiply-adds are welcome here (the library is built with
+        // -ffp-contract=off for the NumPy-exact kernels), and two centres per trip give the scheduler two independent chains
+#pragma clang fp contract(fast)
+#pragma unroll 2
+        for (int i = 0; i < a.pu; ++i) {
+            const double2 c = tb[2 * i], w = tb[2 * i + 1];
+            const double dx = x - c.x, dy = y - c.y;
+            const double r2 = dx * dx + dy * dy;
+            const double phi = r2 == 0.0 ? 0.0 : 0.5 * r2 * tps_log(r2, ltab);
+            acc0 += phi * w.x;
+            acc1 += phi * w.y;
+        }
     }
     double acc[2] = {acc0, acc1};
 #pragma unroll
