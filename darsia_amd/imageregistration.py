@@ -121,7 +121,35 @@ class TranslationAnalysis:
 
     def update_base(self, base) -> None:
         self.base = base
+        self._drop_device_base()
         self.update_base_patches()
+
+    # ---- the baseline's pixels in HBM, for the device estimator ---------------------------------------
+    def _drop_device_base(self) -> None:
+        held = getattr(self, "_base_dev", None)
+        if held is not None:
+            held[1].close()
+        self._base_dev = None
+
+    def _stages_on_device(self, img) -> bool:
+        """Host frames the device estimator and the warp take as stored: worth one upload for both."""
+        a, b = img.img, self.base.img
+        return (isinstance(self.translation_estimator, PhaseCorrelationEstimator) and isinstance(a, np.ndarray)
+                and isinstance(b, np.ndarray) and a.dtype == b.dtype and a.dtype in _PC_DTYPES and a.shape == b.shape
+                and a.ndim in (2, 3) and (a.ndim == 2 or a.shape[2] == 3))
+
+    def _device_base(self):
+        """The baseline's pixels as a device array, uploaded once and kept while the host array looks unchanged (same object,
+        same fingerprint: shape, dtype and a strided sample of 4096 values)."""
+        from .concentration import _fingerprint
+        from .device import DeviceArray
+
+        mark = (id(self.base.img), _fingerprint(self.base.img))
+        held = getattr(self, "_base_dev", None)
+        if held is None or held[0] != mark:
+            self._drop_device_base()
+            self._base_dev = held = (mark, DeviceArray.from_host(self.base.img))
+        return held[1]
 
     def update_base_patches(self) -> None:
         self.patches_base = Patches(self.base, self.N_patches, rel_overlap=self.rel_overlap)
@@ -181,7 +209,11 @@ class TranslationAnalysis:
         coords, tx, ty = [], [], []
         if batch is not None:
             # all patches of the pair in one call (the device estimator): same rectangles, same masks as the loop below
-            flat = batch(self.img.img, self.base.img, [patches_img.rois[i][j] for i in range(self.N_patches[0]) for j in range(self.N_patches[1])],
+            from .device import DeviceArray
+
+            # a frame staged in HBM (__call__) meets the baseline there: neither crosses PCIe again
+            base_pixels = self._device_base() if isinstance(self.img.img, DeviceArray) and self._stages_on_device(self.base) else self.base.img
+            flat = batch(self.img.img, base_pixels, [patches_img.rois[i][j] for i in range(self.N_patches[0]) for j in range(self.N_patches[1])],
                          *((None, None) if (self.mask_img.img is getattr(self, "_all_true_img", None)
                                             and self.mask_base.img is getattr(self, "_all_true_base", None))
                            else (self.mask_img.img, self.mask_base.img)))
@@ -209,9 +241,26 @@ class TranslationAnalysis:
         return PiecewisePerspectiveTransform().find_and_warp(patches, self.translation, reverse)
 
     def __call__(self, img, reverse: bool = False, mask=None):
-        self.load_image(img, mask)
-        self.find_translation()
-        return self.translate_image(reverse)
+        if not self._stages_on_device(img):
+            self.load_image(img, mask)
+            self.find_translation()
+            return self.translate_image(reverse)
+        # a host frame the device stages take as stored: ONE upload serves the estimator and the warp, one download brings
+        # the result back (otherwise the frame crosses PCIe once per stage)
+        from .device import DeviceArray
+        from .image import with_array
+
+        staged = with_array(img, DeviceArray.from_host(img.img))
+        try:
+            self.load_image(staged, mask)
+            self.find_translation()
+            warped = self.translate_image(reverse)
+            out = with_array(warped, warped.img.get())
+            warped.img.close()
+        finally:
+            self.img = img          # the caller's image is the loaded one, as after a plain load_image
+            staged.img.close()
+        return out
 
     def return_patch_translation(self, reverse: bool = True, units: str = "metric") -> np.ndarray:
         """Deformation at the patch centres in (row, col) components, metric or pixel units, shape (*N_patches, 2)

@@ -234,6 +234,31 @@ def test_registration_of_frames_that_are_in_hbm_already(dtype):
     assert isinstance(mixed.img, np.ndarray) and np.array_equal(mixed.img, want.img)
 
 
+def test_staged_baseline_follows_the_host_array():
+    """Host frames are staged in HBM once per call and meet a cached device copy of the baseline there; the copy is renewed when
+    the baseline's pixels change (update_dst, or an edit in place that the fingerprint sees)."""
+    from scipy.ndimage import map_coordinates
+
+    h, w = 160, 224
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    field = np.sin(np.pi * yy / h) * np.sin(np.pi * xx / w)
+    dst1, dst2 = _textured(h, w, 21), _textured(h, w, 22)
+    src1 = map_coordinates(dst1, [yy - 1.5 * field, xx + 2.0 * field], order=1, mode="nearest").astype(np.float32)
+    src2 = map_coordinates(dst2, [yy + 1.0 * field, xx - 2.5 * field], order=1, mode="nearest").astype(np.float32)
+    reg = da.ImageRegistration(da.Image(dst1.copy()), N_patches=[3, 4])
+    first = reg(da.Image(src1))
+    ta = reg.image_registration.translation_analysis
+    assert ta._base_dev is not None and ta.img.img is not None and isinstance(ta.img.img, np.ndarray)   # caller's image stays loaded
+    assert np.array_equal(first.img, da.ImageRegistration(da.Image(da.DeviceArray.from_host(dst1)), N_patches=[3, 4])(da.Image(da.DeviceArray.from_host(src1))).img.get())
+    ta.base.img[...] = dst2                                              # the baseline changes in place
+    second = reg(da.Image(src2))
+    fresh = da.ImageRegistration(da.Image(dst2.copy()), N_patches=[3, 4])(da.Image(src2))
+    assert np.array_equal(second.img, fresh.img)
+    reg.image_registration.update_dst(da.Image(dst1.copy()))
+    assert ta._base_dev is None
+    assert np.array_equal(reg(da.Image(src1)).img, first.img)
+
+
 def test_multilevel_registration_handles_a_larger_warp():
     from scipy.ndimage import map_coordinates
 
