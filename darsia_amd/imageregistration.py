@@ -237,7 +237,18 @@ class TranslationAnalysis:
 
     def translate_image(self, reverse: bool = True):
         """translationanalysis.py:616-646: piecewise perspective warp of the loaded image (GPU)."""
-        patches = Patches(self.img, self.N_patches, rel_overlap=0.0)
+        # the zero-overlap patch grid depends on shape, dimensions, origin and patch counts only: one per geometry, re-pointed at
+        # the image to warp (the grid holds no pixels)
+        import copy as _copy
+
+        key = (tuple(self.img.img.shape[:2]), tuple(self.img.dimensions), tuple(np.asarray(self.img.origin, dtype=float)), tuple(self.N_patches))
+        held = getattr(self, "_warp_grid", None)
+        if held is None or held[0] != key:
+            grid = Patches(self.img, self.N_patches, rel_overlap=0.0)
+            grid.base = None                      # geometry only: the kept grid must not pin an image
+            self._warp_grid = held = (key, grid)
+        patches = _copy.copy(held[1])
+        patches.base = self.img
         return PiecewisePerspectiveTransform().find_and_warp(patches, self.translation, reverse)
 
     def __call__(self, img, reverse: bool = False, mask=None):
