@@ -312,3 +312,40 @@ def test_device_resident_frames_stay_on_the_device():
     generic = da.ConcentrationAnalysis(base, da.MonochromaticReduction(color=lambda im: im[..., 0]), None, None, model)
     with pytest.raises(NotImplementedError, match="fused pipeline"):
         generic(da.OpticalImage(d_corrected))
+
+
+def test_random_sweep_of_frame_types_against_numpy_promotion():
+    """Sixty random combinations of frame type (float32 / float64 / uint8 / uint16), baseline (none / float32 / float64), cleaning
+    filter, difference option, reduction and shape: the fused device pipeline against the stage-by-stage NumPy chain, whose
+    dtypes are whatever NumPy's promotion makes them (integer frames first converted the img_as(float) way)."""
+    import warnings
+
+    rng = np.random.default_rng(2024)
+    colors = ["red", "green", "blue", "red+green", "negative-key", "gray"]
+    for case in range(60):
+        h, w = int(rng.integers(9, 70)), int(rng.integers(9, 90))
+        frame_dt = [np.float32, np.float64, np.uint8, np.uint16][int(rng.integers(4))]
+        base_dt = [None, np.float32, np.float64][int(rng.integers(3))]
+        with_filter = base_dt is not None and bool(rng.integers(2))
+        option = ["absolute", "positive", "negative", "plain"][int(rng.integers(4))]
+        color = colors[int(rng.integers(len(colors)))]
+        vals = rng.random((h, w, 3)) * 1.2 - 0.1 if np.dtype(frame_dt).kind == "f" else rng.random((h, w, 3))
+        frame = vals.astype(frame_dt) if np.dtype(frame_dt).kind == "f" else (vals * np.iinfo(frame_dt).max).astype(frame_dt)
+        as_float = frame if frame.dtype.kind == "f" else np.multiply(frame, 1.0 / np.iinfo(frame_dt).max, dtype=np.float64)
+        base = None if base_dt is None else (rng.random((h, w, 3)) * 0.5).astype(base_dt)
+        wide = as_float.dtype if base is None else np.result_type(as_float.dtype, base.dtype)
+        if color == "gray" and wide != np.float32:
+            color = "red"                       # cv2's gray conversion is float32-only: the product leaves the fused path there
+        bases = None if base is None else da.OpticalImage(base)
+        if with_filter:
+            bases = [da.OpticalImage(base), da.OpticalImage((base + rng.normal(0, 0.01, base.shape)).astype(base_dt))]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ca = da.ConcentrationAnalysis(bases, da.MonochromaticReduction(color=color), None, None,
+                                          da.LinearModel(scaling=1.5, offset=-0.02), **{"diff option": option})
+            assert ca._fusable(frame) is not None, (case, frame_dt, base_dt, color)
+            out = ca(da.OpticalImage(frame))
+        ref = OC.concentration(as_float, base, option, color, ca.threshold_cleaning_filter, [lambda x: 1.5 * x + -0.02], None, False)
+        assert out.img.dtype == ref.dtype, (case, frame_dt, base_dt, with_filter, out.img.dtype, ref.dtype)
+        assert np.array_equal(out.img, ref), (case, frame_dt, base_dt, with_filter, option, color)
+        ca.close()
