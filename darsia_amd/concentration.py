@@ -34,7 +34,7 @@ import numpy as np
 
 from . import _lib
 from .device import DeviceArray
-from .image import Image, ScalarImage
+from .image import ScalarImage
 from .restoration.split_bregman_tvd import DeviceTVD
 from .restoration.tvd import TVD
 from .utils.linear_solvers.jacobi import Jacobi

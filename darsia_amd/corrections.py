@@ -12,7 +12,6 @@ intermediate gathers use the device as well.  The interactive calibration helper
 """
 from __future__ import annotations
 
-import ctypes as C
 import json
 import math
 from abc import ABC, abstractmethod
