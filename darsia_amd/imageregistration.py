@@ -398,25 +398,62 @@ class MultiscaleDiffeomorphicImageRegistration:
         self.total_config = config[-1] if total_config is None else total_config
         self.verbosity = kwargs.get("verbosity", 0)
 
+    def _level_registration(self, level: int) -> "DiffeomorphicImageRegistration":
+        """The single-level registration of a level against the (fixed) destination.  The reference builds a new one per call
+        (imageregistration.py:382-398); nothing in it depends on the image to register, so it is kept -- with its patch grid and
+        the device copy of the destination's pixels."""
+        if not hasattr(self, "_levels"):
+            self._levels = {}
+        if level not in self._levels:
+            self._levels[level] = DiffeomorphicImageRegistration(self.img_dst, mask_dst=self.mask_dst, **self.config[level])
+        return self._levels[level]
+
     def _single_level_iteration(self, img, mask, config):
         registration = DiffeomorphicImageRegistration(self.img_dst, mask_dst=self.mask_dst, **config)
         transformed, _ = registration.call_with_output(img, return_patch_translation=True, mask=mask)
         return transformed, registration
 
     def __call__(self, img, mask=None, return_transformed_dst: bool = False):
-        transformed_img = img.copy()
-        transformed_mask = mask.copy() if mask is not None else None
-        self.combined_image_registration = DiffeomorphicImageRegistration(transformed_img, **self.total_config)
-        for level in range(self.num_levels):
-            _, registration = self._single_level_iteration(transformed_img, transformed_mask, self.config[level])
-            if level == 0:
-                self.combined_image_registration.deduct(registration)
-            else:
-                self.combined_image_registration.add(registration)
-            if transformed_mask is not None:
-                warped = registration.apply(Image(transformed_mask.img.astype(np.float32), **transformed_mask.metadata()))
-                transformed_mask = Image(warped.img > 0.5, **transformed_mask.metadata())
-            transformed_img = self.combined_image_registration.apply(img)
+        """imageregistration.py:400-452.  Same maps and same result as the reference's loop; what differs is where the pixels
+        are: a host image the device stages take as stored is uploaded once, every level's estimator and every re-warp of the
+        original read it in HBM, and only the final image comes back.  (The warped image a level's own registration would
+        return is never used by the reference either: only its translation map is, so only that is computed.)"""
+        from .device import DeviceArray
+        from .image import with_array
+
+        first = self._level_registration(0).translation_analysis
+        staged = with_array(img, DeviceArray.from_host(img.img)) if first._stages_on_device(img) else None
+        work = img if staged is None else staged
+        try:
+            transformed_img = work
+            transformed_mask = mask.copy() if mask is not None else None
+            self.combined_image_registration = DiffeomorphicImageRegistration(work, **self.total_config)
+            for level in range(self.num_levels):
+                registration = self._level_registration(level)
+                registration.translation_analysis.load_image(transformed_img, transformed_mask)
+                registration.translation_analysis.find_translation()
+                if level == 0:
+                    self.combined_image_registration.deduct(registration)
+                else:
+                    self.combined_image_registration.add(registration)
+                if transformed_mask is not None:
+                    warped = registration.apply(Image(transformed_mask.img.astype(np.float32), **transformed_mask.metadata()))
+                    transformed_mask = Image(warped.img > 0.5, **transformed_mask.metadata())
+                previous = transformed_img
+                transformed_img = self.combined_image_registration.apply(work)
+                if staged is not None and previous is not work:
+                    previous.img.close()
+                registration.translation_analysis.img = img   # the level does not keep a staged frame alive
+            if staged is not None:
+                result = with_array(transformed_img, transformed_img.img.get())
+                transformed_img.img.close()
+                transformed_img = result
+        finally:
+            if staged is not None:
+                # the combined map's geometry comes from the image: point it back at the caller's (same shape, same metadata)
+                ta = self.combined_image_registration.translation_analysis
+                ta.base = ta.img = ta.patches_base.base = self.combined_image_registration.dst = img
+                staged.img.close()
         if return_transformed_dst:
             return transformed_img, self.combined_image_registration.apply(self.dst, reverse=True)
         return transformed_img

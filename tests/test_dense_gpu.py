@@ -232,6 +232,13 @@ def test_registration_of_frames_that_are_in_hbm_already(dtype):
     # a host frame against the device-resident baseline works as well
     mixed = reg(da.Image(src))
     assert isinstance(mixed.img, np.ndarray) and np.array_equal(mixed.img, want.img)
+    # multilevel: host frames (staged in HBM for the duration of the call) and device frames give the same image
+    multi_h = da.ImageRegistration(da.Image(dst), N_patches=[[2, 2], [4, 4]])
+    out_h = multi_h(da.Image(src))
+    out_d = da.ImageRegistration(da.Image(da.DeviceArray.from_host(dst)), N_patches=[[2, 2], [4, 4]])(da.Image(da.DeviceArray.from_host(src)))
+    assert isinstance(out_h.img, np.ndarray) and isinstance(out_d.img, da.DeviceArray) and np.array_equal(out_d.img.get(), out_h.img)
+    assert np.array_equal(multi_h(da.Image(src)).img, out_h.img)                       # the kept level objects serve a second call
+    assert np.array_equal(multi_h.apply(da.Image(src)).img, out_h.img)
 
 
 def test_staged_baseline_follows_the_host_array():

@@ -55,6 +55,10 @@ for dtype in (np.float32, np.uint8):
         t0 = time.perf_counter(); keep.append(reg_d(a_d)); t1 = time.perf_counter()
         print(f"{np.dtype(dtype).name}: both frames already in HBM (DeviceArray pixels): whole ImageRegistration.__call__ {1e3 * (t1 - t0):7.1f} ms", flush=True)
     assert np.array_equal(keep[-1].img.get(), keep[-4].img)
-    out = keep[-4].img.astype(np.float64) / (255 if dtype == np.uint8 else 1)
+    multi = da.ImageRegistration(b, N_patches=[[5, 10], [10, 20]], rel_overlap=0.1)
+    for rep in range(3):
+        t0 = time.perf_counter(); keep.append(multi(a)); t1 = time.perf_counter()
+        print(f"{np.dtype(dtype).name}: multilevel [[5, 10], [10, 20]]: whole ImageRegistration.__call__ {1e3 * (t1 - t0):7.1f} ms", flush=True)
+    out = keep[-7].img.astype(np.float64) / (255 if dtype == np.uint8 else 1)
     inner = (slice(200, H - 200), slice(200, W - 200))
     print(f"   mean |src - dst| {np.abs(src - dst)[inner].mean():.5f} -> after registration {np.abs(out - dst)[inner].mean():.5f}")
