@@ -103,11 +103,38 @@ class TranslationAnalysis:
         self.translation_estimator = translation_estimator
         self.translation = lambda arg: np.zeros((2, np.atleast_2d(arg).shape[0]))
         self.have_translation = np.zeros(tuple(self.N_patches), dtype=bool)
-        self.mask_base = (Image(np.ones(base.img.shape[:2], dtype=bool), dimensions=base.dimensions)
-                          if mask is None else mask.copy())
-        self._all_true_base = self.mask_base.img if mask is None else None
+        # masks nobody gave are all True: they are made when somebody looks at them (32 MB and 3 ms per 4000 x 8000 image)
+        self._mask_base = None if mask is None else mask.copy()
+        self._all_true_base = None
         self.interpolator_translation_x = None
         self.interpolator_translation_y = None
+
+    # ---- masks (translationanalysis.py:60-75: all True unless given) ----------------------------------
+    def _is_all_true(self, which: str) -> bool:
+        held = getattr(self, "_mask_" + which, None)
+        return held is None or held.img is getattr(self, "_all_true_" + which, None)
+
+    def _default_mask(self, which: str, like):
+        mask = Image(np.ones(like.img.shape[:2], dtype=bool), dimensions=like.dimensions)
+        setattr(self, "_mask_" + which, mask)
+        setattr(self, "_all_true_" + which, mask.img)
+        return mask
+
+    @property
+    def mask_base(self):
+        return self._mask_base if self._mask_base is not None else self._default_mask("base", self.base)
+
+    @mask_base.setter
+    def mask_base(self, mask) -> None:
+        self._mask_base, self._all_true_base = mask, None
+
+    @property
+    def mask_img(self):
+        return self._mask_img if self._mask_img is not None else self._default_mask("img", self.img)
+
+    @mask_img.setter
+    def mask_img(self, mask) -> None:
+        self._mask_img, self._all_true_img = mask, None
 
     # ---- set-up ----------------------------------------------------------------------------------
     def update_params(self, N_patches=None, rel_overlap=None) -> None:
@@ -156,9 +183,8 @@ class TranslationAnalysis:
 
     def load_image(self, img, mask=None) -> None:
         self.img = img
-        self.mask_img = (Image(np.ones(img.img.shape[:2], dtype=bool), dimensions=img.dimensions)
-                         if mask is None else mask.copy())
-        self._all_true_img = self.mask_img.img if mask is None else None   # the array known to be all True, if still in place
+        self._mask_img = None if mask is None else mask.copy()
+        self._all_true_img = None     # the array known to be all True, if a default mask was made and is still in place
 
     # ---- boundary conditions (translationanalysis.py:310-404, pixel units) ----------------------------
     def bc_x(self, units=("pixel", "pixel")):
@@ -214,8 +240,7 @@ class TranslationAnalysis:
             # a frame staged in HBM (__call__) meets the baseline there: neither crosses PCIe again
             base_pixels = self._device_base() if isinstance(self.img.img, DeviceArray) and self._stages_on_device(self.base) else self.base.img
             flat = batch(self.img.img, base_pixels, [patches_img.rois[i][j] for i in range(self.N_patches[0]) for j in range(self.N_patches[1])],
-                         *((None, None) if (self.mask_img.img is getattr(self, "_all_true_img", None)
-                                            and self.mask_base.img is getattr(self, "_all_true_base", None))
+                         *((None, None) if (self._is_all_true("img") and self._is_all_true("base"))
                            else (self.mask_img.img, self.mask_base.img)))
         for i in range(self.N_patches[0]):
             for j in range(self.N_patches[1]):
