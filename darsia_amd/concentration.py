@@ -207,6 +207,11 @@ class ConcentrationAnalysis:
         if base is not None:
             if not isinstance(base, list):
                 base = [base]
+            # baselines whose pixels are in HBM (e.g. out of the device corrections) come to the host once: the cleaning filter
+            # is calibrated there, and the device contexts take their own copy when they are made
+            from .image import with_array
+
+            base = [with_array(b, b.img.get()) if isinstance(b.img, DeviceArray) else b for b in base]
             if any(img.img.dtype not in (np.float32, np.float64) for img in base):
                 raise TypeError("baseline images must be float32/float64 (convert before, e.g. img / 255.)")
             self.base = base[0].copy()

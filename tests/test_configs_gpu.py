@@ -205,4 +205,7 @@ def test_whole_frame_pipeline_stays_in_hbm():
     assert isinstance(aligned_d.img, da.DeviceArray) and np.array_equal(aligned_d.img.get(), aligned_h.img)
     got = ca(da.OpticalImage(aligned_d.img))
     assert isinstance(got.img, da.DeviceArray) and np.array_equal(got.img.get(), want.img)
+    # an analysis built on the device-resident baseline is the same analysis
+    ca_d = da.ConcentrationAnalysis(da.OpticalImage(base_d), da.MonochromaticReduction(color="red"), None, tvd, model, **{"diff option": "positive"})
+    assert isinstance(ca_d.base.img, np.ndarray) and np.array_equal(ca_d(da.OpticalImage(aligned_d.img)).img.get(), want.img)
     assert want.img.max() > 0.2            # the tracer blob is there
