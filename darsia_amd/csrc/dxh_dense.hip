@@ -476,6 +476,16 @@ __device__ __forceinline__ double pc_pixel(const S* __restrict__ img, int W, int
     return s / 3.0;
 }
 
+// a patch larger than the longest transform is read in cells of dec x dec pixels (their mean); dec = 1 otherwise
+template <typename S>
+__device__ __forceinline__ double pc_cell(const S* __restrict__ img, int W, int C, int r, int c, int dec) {
+    if (dec == 1) return pc_pixel(img, W, C, r, c);
+    double s = 0.0;
+    for (int i = 0; i < dec; ++i)
+        for (int j = 0; j < dec; ++j) s += pc_pixel(img, W, C, r + i, c + j);
+    return s / (double)(dec * dec);
+}
+
 __device__ __forceinline__ double2 pc_cmul(double2 a, double2 b) {
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
@@ -525,14 +535,14 @@ __device__ __forceinline__ void pc_ifft_dit(double2* buf, int N, int logN, const
 
 // mean of every patch of both images: grid (npatch, 2)
 template <typename S>
-__global__ void __launch_bounds__(256) k_pc_mean(const S* __restrict__ src, const S* __restrict__ dst, int W, int C,
+__global__ void __launch_bounds__(256) k_pc_mean(const S* __restrict__ src, const S* __restrict__ dst, int W, int C, int dec,
                                                   const PcRoi* __restrict__ rois, double* __restrict__ means) {
     __shared__ double sm[256 / kWave];
     const PcRoi q = rois[blockIdx.x];
     const S* img = blockIdx.y ? dst : src;
-    const int ph = q.r1 - q.r0, pw = q.c1 - q.c0;
+    const int ph = (q.r1 - q.r0) / dec, pw = (q.c1 - q.c0) / dec;
     double acc = 0.0;
-    for (int i = threadIdx.x; i < ph * pw; i += blockDim.x) acc += pc_pixel(img, W, C, q.r0 + i / pw, q.c0 + i % pw);
+    for (int i = threadIdx.x; i < ph * pw; i += blockDim.x) acc += pc_cell(img, W, C, q.r0 + (i / pw) * dec, q.c0 + (i % pw) * dec, dec);
 #pragma unroll
     for (int s = kWave / 2; s > 0; s >>= 1) acc += __shfl_down(acc, s, kWave);
     if ((threadIdx.x & (kWave - 1)) == 0) sm[threadIdx.x / kWave] = acc;
@@ -546,19 +556,19 @@ __global__ void __launch_bounds__(256) k_pc_mean(const S* __restrict__ src, cons
 
 // windowed, padded rows -> spectrum along the row.  grid (max patch height, npatch, 2); F[image][patch][P0][P1]
 template <typename S>
-__global__ void __launch_bounds__(256) k_pc_rows(const S* __restrict__ src, const S* __restrict__ dst, int W, int C,
+__global__ void __launch_bounds__(256) k_pc_rows(const S* __restrict__ src, const S* __restrict__ dst, int W, int C, int dec,
                                                   const PcRoi* __restrict__ rois, const double* __restrict__ means, int nmeans,
                                                   int P0, int P1, int logP1, const double2* __restrict__ tw1, double2* __restrict__ FA,
                                                   double2* __restrict__ FB) {
     extern __shared__ double2 pc_buf[];
     const PcRoi q = rois[blockIdx.y];
-    const int ph = q.r1 - q.r0, pw = q.c1 - q.c0, r = blockIdx.x;
+    const int ph = (q.r1 - q.r0) / dec, pw = (q.c1 - q.c0) / dec, r = blockIdx.x;
     if (r >= ph) return;
     const S* img = blockIdx.z ? dst : src;
     const double mean = means[(size_t)blockIdx.z * nmeans + blockIdx.y], wy = pc_hann(r, ph);
     for (int c = threadIdx.x; c < P1; c += blockDim.x) {
         double v = 0.0;
-        if (c < pw) v = ((pc_pixel(img, W, C, q.r0 + r, q.c0 + c) - mean) * wy) * pc_hann(c, pw);
+        if (c < pw) v = ((pc_cell(img, W, C, q.r0 + r * dec, q.c0 + c * dec, dec) - mean) * wy) * pc_hann(c, pw);
         pc_buf[c] = make_double2(v, 0.0);
     }
     __syncthreads();
@@ -569,12 +579,12 @@ __global__ void __launch_bounds__(256) k_pc_rows(const S* __restrict__ src, cons
 
 // columns: spectrum of both images, unit-modulus cross-power, inverse along the column.  A workgroup takes CB adjacent
 // columns (CB x 16 B contiguous per row: 8 columns are one 128-byte line), column cb at pc_buf[cb * P0 ...].  grid (P1 / CB, npatch)
-__global__ void __launch_bounds__(256) k_pc_cols(const PcRoi* __restrict__ rois, int P0, int P1, int logP0, int CB,
+__global__ void __launch_bounds__(256) k_pc_cols(const PcRoi* __restrict__ rois, int dec, int P0, int P1, int logP0, int CB,
                                                   const double2* __restrict__ tw0, double2* __restrict__ FA,
                                                   double2* __restrict__ FB) {
     extern __shared__ double2 pc_buf[];
     const PcRoi q = rois[blockIdx.y];
-    const int ph = q.r1 - q.r0, c = blockIdx.x * CB;
+    const int ph = (q.r1 - q.r0) / dec, c = blockIdx.x * CB;
     double2* a = FA + (size_t)blockIdx.y * P0 * P1 + c;
     double2* b = FB + (size_t)blockIdx.y * P0 * P1 + c;
     const int n = P0 * CB;   // element i: row i / CB, column i % CB (CB is a power of two)
@@ -626,7 +636,7 @@ __global__ void __launch_bounds__(256) k_pc_rows_inv(int P0, int P1, int logP1, 
 }
 
 // peak (first maximum in row-major order, like np.argmax), parabolic refinement, acceptance.  grid (npatch)
-__global__ void __launch_bounds__(1024) k_pc_peak(const PcRoi* __restrict__ rois, int P0, int P1, const double* __restrict__ corr,
+__global__ void __launch_bounds__(1024) k_pc_peak(const PcRoi* __restrict__ rois, int dec, int P0, int P1, const double* __restrict__ corr,
                                                    double max_shift_fraction, double* __restrict__ shifts, int* __restrict__ ok) {
     __shared__ double sv[1024 / kWave];
     __shared__ long long si[1024 / kWave];
@@ -650,7 +660,7 @@ __global__ void __launch_bounds__(1024) k_pc_peak(const PcRoi* __restrict__ rois
     for (int w = 1; w < (int)(blockDim.x / kWave); ++w)
         if (sv[w] > best || (sv[w] == best && si[w] < at)) { best = sv[w]; at = si[w]; }
     const PcRoi q = rois[blockIdx.x];
-    const int ph = q.r1 - q.r0, pw = q.c1 - q.c0;
+    const int ph = (q.r1 - q.r0) / dec, pw = (q.c1 - q.c0) / dec;
     if (at >= n) at = 0;   // all NaN
     const int py = (int)(at / P1), px = (int)(at % P1);
     auto refine = [](double cm, double c0, double cq) {
@@ -662,24 +672,29 @@ __global__ void __launch_bounds__(1024) k_pc_peak(const PcRoi* __restrict__ rois
     double dx = px + refine(cp[(size_t)py * P1 + (px + P1 - 1) % P1], c0, cp[(size_t)py * P1 + (px + 1) % P1]);
     if (dy > P0 / 2) dy -= P0;
     if (dx > P1 / 2) dx -= P1;
-    shifts[2 * blockIdx.x] = dx;
-    shifts[2 * blockIdx.x + 1] = dy;
+    shifts[2 * blockIdx.x] = dx * dec;       // cells -> pixels
+    shifts[2 * blockIdx.x + 1] = dy * dec;
     ok[blockIdx.x] = !(fabs(dy) > max_shift_fraction * ph || fabs(dx) > max_shift_fraction * pw);
 }
 
 namespace {
 template <typename S>
 int phase_correlation_t(Dev& d, int H, int W, int C, const S* src, const S* dst, int npatch, const PcRoi* rois_h,
-                        double max_shift_fraction, double* shifts, int32_t* ok) {
+                        double max_shift_fraction, double* shifts, int32_t* ok, int* dec_out) {
     int maxh = 0, maxw = 0;
     for (int k = 0; k < npatch; ++k) {
         maxh = std::max(maxh, rois_h[k].r1 - rois_h[k].r0);
         maxw = std::max(maxw, rois_h[k].c1 - rois_h[k].c0);
     }
+    // patches longer than the longest transform (8192 points: 128 KB of LDS) are read in cells of dec x dec pixels
+    int dec = 1;
+    while (maxh / dec > 8192 || maxw / dec > 8192) dec *= 2;
+    *dec_out = dec;
+    maxh /= dec;
+    maxw /= dec;
     int P0 = 8, P1 = 8, l0 = 3, l1 = 3;
     while (P0 < maxh) { P0 *= 2; ++l0; }
     while (P1 < maxw) { P1 *= 2; ++l1; }
-    DXH_REQUIRE(P0 <= 8192 && P1 <= 8192, "patches of up to 8192 pixels per side are supported (got %d x %d)", maxh, maxw);
     // twiddles exp(-2 pi i k / N), k < N / 2, for both lengths
     std::vector<double> tw((size_t)P0 + P1);
     for (int k = 0; k < P0 / 2; ++k) { tw[2 * k] = std::cos(2.0 * M_PI * k / P0); tw[2 * k + 1] = -std::sin(2.0 * M_PI * k / P0); }
@@ -708,16 +723,16 @@ int phase_correlation_t(Dev& d, int H, int W, int C, const S* src, const S* dst,
         DXH_HIP(hipFuncSetAttribute((const void*)k_pc_rows_inv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
     }
     if (lds0 > 64 * 1024) DXH_HIP(hipFuncSetAttribute((const void*)k_pc_cols, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0));
-    hipLaunchKernelGGL((k_pc_mean<S>), dim3(npatch, 2), dim3(256), 0, d.st, src, dst, W, C, (const PcRoi*)drois, (double*)dmeans);
+    hipLaunchKernelGGL((k_pc_mean<S>), dim3(npatch, 2), dim3(256), 0, d.st, src, dst, W, C, dec, (const PcRoi*)drois, (double*)dmeans);
     for (int p0 = 0; p0 < npatch; p0 += chunk) {
         const int np = std::min(chunk, npatch - p0);
         const PcRoi* r = (const PcRoi*)drois + p0;
         // means are laid out [image][patch of the whole call]: the chunk's slice starts at p0, the image stride stays npatch
-        hipLaunchKernelGGL((k_pc_rows<S>), dim3(maxh, np, 2), dim3(256), lds1, d.st, src, dst, W, C, r,
+        hipLaunchKernelGGL((k_pc_rows<S>), dim3(maxh, np, 2), dim3(256), lds1, d.st, src, dst, W, C, dec, r,
                            (const double*)dmeans + p0, npatch, P0, P1, l1, tw1, (double2*)FA, (double2*)FB);
-        hipLaunchKernelGGL(k_pc_cols, dim3(P1 / CB, np), dim3(256), lds0, d.st, r, P0, P1, l0, CB, tw0, (double2*)FA, (double2*)FB);
+        hipLaunchKernelGGL(k_pc_cols, dim3(P1 / CB, np), dim3(256), lds0, d.st, r, dec, P0, P1, l0, CB, tw0, (double2*)FA, (double2*)FB);
         hipLaunchKernelGGL(k_pc_rows_inv, dim3(P0, np), dim3(256), lds1, d.st, P0, P1, l1, tw1, (const double2*)FB, (double*)FA);
-        hipLaunchKernelGGL(k_pc_peak, dim3(np), dim3(1024), 0, d.st, r, P0, P1, (const double*)FA, max_shift_fraction,
+        hipLaunchKernelGGL(k_pc_peak, dim3(np), dim3(1024), 0, d.st, r, dec, P0, P1, (const double*)FA, max_shift_fraction,
                            (double*)dshift + 2 * p0, (int*)dok + p0);
         DXH_HIP(hipGetLastError());
     }
@@ -850,15 +865,16 @@ int dxh_phase_correlation(int device, int H, int W, int C, int dtype, const void
         DXH_HIP(hipMemcpyAsync(p, dimg[i], bytes, hipMemcpyDefault, d.st));
         dimg[i] = p;
     }
+    int dec = 1;
     switch (dtype) {
-        case DXH_F32: rc = phase_correlation_t<float>(d, H, W, C, (const float*)dimg[0], (const float*)dimg[1], npatch, q, max_shift_fraction, shifts, ok); break;
-        case DXH_F64: rc = phase_correlation_t<double>(d, H, W, C, (const double*)dimg[0], (const double*)dimg[1], npatch, q, max_shift_fraction, shifts, ok); break;
-        case DXH_U8: rc = phase_correlation_t<unsigned char>(d, H, W, C, (const unsigned char*)dimg[0], (const unsigned char*)dimg[1], npatch, q, max_shift_fraction, shifts, ok); break;
-        default: rc = phase_correlation_t<unsigned short>(d, H, W, C, (const unsigned short*)dimg[0], (const unsigned short*)dimg[1], npatch, q, max_shift_fraction, shifts, ok); break;
+        case DXH_F32: rc = phase_correlation_t<float>(d, H, W, C, (const float*)dimg[0], (const float*)dimg[1], npatch, q, max_shift_fraction, shifts, ok, &dec); break;
+        case DXH_F64: rc = phase_correlation_t<double>(d, H, W, C, (const double*)dimg[0], (const double*)dimg[1], npatch, q, max_shift_fraction, shifts, ok, &dec); break;
+        case DXH_U8: rc = phase_correlation_t<unsigned char>(d, H, W, C, (const unsigned char*)dimg[0], (const unsigned char*)dimg[1], npatch, q, max_shift_fraction, shifts, ok, &dec); break;
+        default: rc = phase_correlation_t<unsigned short>(d, H, W, C, (const unsigned short*)dimg[0], (const unsigned short*)dimg[1], npatch, q, max_shift_fraction, shifts, ok, &dec); break;
     }
     if (rc) return rc;
     for (int k = 0; k < npatch; ++k)
-        if (std::min(q[k].r1 - q[k].r0, q[k].c1 - q[k].c0) < 8) ok[k] = 0;   // too small to say anything
+        if (std::min(q[k].r1 - q[k].r0, q[k].c1 - q[k].c0) / dec < 8) ok[k] = 0;   // too small to say anything
     return DXH_OK;
 }
 

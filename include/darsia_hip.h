@@ -427,7 +427,8 @@ int dxh_warp_patches_typed(int device, int H, int W, int C, int dtype, const voi
  * SURVEY.md section 2; the registration takes any estimator with that signature).  Algorithm: oracle/phase_correlation_numpy.py.
  * Images (H, W) or (H, W, 3) of one dtype (DXH_F32 / DXH_F64 / DXH_U8 / DXH_U16), host or device; rois: npatch x
  * (r0, r1, c0, c1), the pixel rectangle of a patch in both images; shifts: npatch x (dx, dy) in pixels; ok: 1 where the
- * estimate is accepted (patch at least 8 x 8, |shift| <= max_shift_fraction of the patch size).
+ * estimate is accepted (patch at least 8 x 8, |shift| <= max_shift_fraction of the patch size).  Patches longer than 8192 pixels
+ * are read in cells of 2 x 2 (4 x 4 ...) pixels.
  */
 int dxh_phase_correlation(int device, int H, int W, int C, int dtype, const void* img_src, const void* img_dst, int npatch,
                           const int32_t* rois, double max_shift_fraction, double* shifts, int32_t* ok);

@@ -12,6 +12,7 @@ Per patch pair (a = source patch, b = destination patch, same pixel rectangle of
   * colour patches are averaged over their channels; everything is float64
   * a - mean(a) and b - mean(b) are multiplied by the separable Hann window of the PATCH size (np.hanning)
   * both are zero-padded to (P0, P1), powers of two >= the largest patch of the call (at least 8), and transformed
+    (patches longer than 8192 pixels are first reduced to cells of dec x dec pixels, see phase_correlation_patches)
   * cross = F(b) conj(F(a)), divided by max(|cross|, 1e-12); corr = real part of the inverse transform
   * the peak of corr (first maximum in row-major order) is refined by a parabola through its circular neighbours per axis,
     unwrapped to [-P/2, P/2), and rejected when it exceeds ``max_shift_fraction`` of the patch size in either direction
@@ -59,12 +60,32 @@ def phase_correlation(a, b, padded_shape=None, max_shift_fraction: float = 0.25)
     return (dx, dy), True
 
 
+MAX_TRANSFORM = 8192   # longest transform of the device implementation (128 KB of LDS)
+
+
+def cells(a, dec: int):
+    """Patch read in cells of dec x dec pixels (their mean, channels averaged first); rows / columns that do not fill a cell drop."""
+    a = np.asarray(a, dtype=np.float64)
+    if a.ndim == 3:
+        a = a.mean(axis=2)
+    if dec == 1:
+        return a
+    ph, pw = a.shape[0] // dec, a.shape[1] // dec
+    return a[:ph * dec, :pw * dec].reshape(ph, dec, pw, dec).mean(axis=(1, 3))
+
+
 def phase_correlation_patches(img_src, img_dst, rois, max_shift_fraction: float = 0.25):
-    """All patches of a call: ``rois`` = (n, 4) rows r0, r1, c0, c1; one padded shape for the whole call."""
+    """All patches of a call: ``rois`` = (n, 4) rows r0, r1, c0, c1; one padded shape for the whole call.  When the largest patch is
+    longer than MAX_TRANSFORM the patches are read in cells of dec x dec pixels (dec the smallest power of two that fits) and the
+    shifts are scaled back to pixels."""
     rois = np.asarray(rois, dtype=np.int64).reshape(-1, 4)
-    p0 = next_pow2(int((rois[:, 1] - rois[:, 0]).max()))
-    p1 = next_pow2(int((rois[:, 3] - rois[:, 2]).max()))
+    maxh, maxw = int((rois[:, 1] - rois[:, 0]).max()), int((rois[:, 3] - rois[:, 2]).max())
+    dec = 1
+    while maxh // dec > MAX_TRANSFORM or maxw // dec > MAX_TRANSFORM:
+        dec *= 2
+    p0, p1 = next_pow2(maxh // dec), next_pow2(maxw // dec)
     out = []
     for r0, r1, c0, c1 in rois:
-        out.append(phase_correlation(img_src[r0:r1, c0:c1], img_dst[r0:r1, c0:c1], (p0, p1), max_shift_fraction))
+        shift, ok = phase_correlation(cells(img_src[r0:r1, c0:c1], dec), cells(img_dst[r0:r1, c0:c1], dec), (p0, p1), max_shift_fraction)
+        out.append((None if shift is None else (shift[0] * dec, shift[1] * dec), ok))
     return out

@@ -72,8 +72,10 @@ def test_large_patches_and_many_patches():
     want = P.phase_correlation_patches(a, b, [(r[0].start, r[0].stop, r[1].start, r[1].stop) for r in rois])
     assert [ok for _, ok in got] == [ok for _, ok in want]
     np.testing.assert_allclose([t[:, 2] for t, ok in got if ok], [s for s, ok in want if ok], rtol=0, atol=1e-7)
-    with pytest.raises(Exception, match="8192"):
-        PhaseCorrelationEstimator().find_effective_translations(np.zeros((16, 9000), np.float32), np.zeros((16, 9000), np.float32), [(0, 16, 0, 9000)])
+    # longer than the longest transform: read in 2 x 2 cells, shifts back in pixels
+    a, b = _pair(36, 9000, 10, shift=(2.0, -14.0))
+    got = _compare(a, b, [(0, 36, 0, 9000), (3, 30, 100, 8800)], tol=1e-6)
+    assert abs(got[0][0][0, 2] + 14.0) < 1.5 and abs(got[0][0][1, 2] - 2.0) < 1.5
 
 
 def test_patches_in_several_passes_give_the_same_shifts(monkeypatch):
