@@ -66,7 +66,7 @@ def test_medium_image_properties():
 
 
 def test_small_random_sweep_chambolle_and_gauss_seidel():
-    """A short run of tools/fuzz_others.py's generator inside the suite (bit-exact incl. iteration counts)."""
+    """A short run of tests/fuzz/fuzz_others.py's generator inside the suite (bit-exact incl. iteration counts)."""
     from oracle import chambolle_numpy as CH
     rng = np.random.default_rng(77)
     for _ in range(30):

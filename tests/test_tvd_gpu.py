@@ -651,7 +651,7 @@ def test_negative_threshold_and_exact_zeros():
 
 
 def test_small_random_sweep_of_parameters():
-    """A short run of tools/fuzz_tvd.py's generator inside the suite."""
+    """A short run of tests/fuzz/fuzz_tvd.py's generator inside the suite."""
     rng = np.random.default_rng(1234)
     for _ in range(60):
         h, w = int(rng.integers(1, 60)), int(rng.integers(1, 500))
