@@ -232,6 +232,14 @@ def test_registration_of_frames_that_are_in_hbm_already(dtype):
     # a host frame against the device-resident baseline works as well
     mixed = reg(da.Image(src))
     assert isinstance(mixed.img, np.ndarray) and np.array_equal(mixed.img, want.img)
+    # masks and the second return value go with the staged path as well
+    host_reg = da.ImageRegistration(da.Image(dst), N_patches=[4, 4], rel_overlap=0.1)
+    mask = da.Image(np.ones((h, w), dtype=bool))
+    mask.img[:, : w // 4 + 12] = False                 # the left column of patches (with its overlap) has no active pixel: not estimated
+    masked, back = host_reg(da.Image(src), mask=mask, return_transformed_dst=True)
+    have = host_reg.image_registration.translation_analysis.have_translation
+    assert isinstance(masked.img, np.ndarray) and isinstance(back.img, np.ndarray) and back.img.shape == dst.shape
+    assert not have[:, 0].any() and have[:, 1:].all()
     # multilevel: host frames (staged in HBM for the duration of the call) and device frames give the same image
     multi_h = da.ImageRegistration(da.Image(dst), N_patches=[[2, 2], [4, 4]])
     out_h = multi_h(da.Image(src))
