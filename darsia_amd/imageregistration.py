@@ -63,6 +63,8 @@ class PhaseCorrelationEstimator:
             a, b = np.asarray(img_src), np.asarray(img_dst)
         boxes = np.array([[r[0].start, r[0].stop, r[1].start, r[1].stop] if isinstance(r[0], slice) else list(r) for r in rois],
                          dtype=np.int32).reshape(-1, 4)
+        if len(boxes) == 0:
+            return []
         if a.shape != b.shape or a.ndim not in (2, 3) or (a.ndim == 3 and a.shape[2] != 3):
             return [(None, False)] * len(boxes)
         boxes[:, 1] = np.minimum(boxes[:, 1], a.shape[0])
