@@ -189,15 +189,41 @@ def main():
             one_step()
         s.synchronize()
         comm.barrier()
+        stats0 = s.slab_stats()           # (synchronises; the warm-up's counts are subtracted below)
+        comm.barrier()
         t0 = time.perf_counter()
         for _ in range(a.steps):
             one_step()
+        t_enq = time.perf_counter()
         s.synchronize()
+        t_own = time.perf_counter()       # this rank's own stream has drained (its last receive included)
         comm.barrier()
         elapsed = time.perf_counter() - t0
         elapsed = comm.allreduce([elapsed], "max")[0]
         kernel_ms, launches = None, None
         comm_info = comm.info()
+        # Per-rank diagnostics, so that ONE record tells where the time of a disappointing curve went: every rank's own
+        # loop time (enqueue -> its stream drained, before the barrier), and from the library's event triples around each
+        # exchange the time the exchange stream idled until the interface rows were signalled and the time from there to
+        # the end of the scatter (gather + RCCL send/recv, i.e. waiting for the neighbour, + scatter).
+        stats1 = s.slab_stats()
+        d = {k: stats1[k] - stats0[k] for k in ("launches", "signalling_launches", "exchanges", "exchanges_timed",
+                                                "wait_timeouts", "wait_signal_ms", "exchange_ms")}
+        loop_ms = (t_own - t0) * 1e3
+        per_x = max(1, d["exchanges_timed"])
+        mine = [loop_ms, (t_enq - t0) * 1e3, d["wait_signal_ms"] / per_x, d["exchange_ms"] / per_x]
+        mx = comm.allreduce(mine, "max")
+        mn = [-v for v in comm.allreduce([-v for v in mine], "max")]
+        rank_diag = {
+            "loop_ms_per_step": {"min": round(mn[0] / a.steps, 4), "max": round(mx[0] / a.steps, 4)},
+            "host_enqueue_ms_per_step": {"min": round(mn[1] / a.steps, 4), "max": round(mx[1] / a.steps, 4)},
+            "ms_per_exchange_waiting_for_interface_rows": {"min": round(mn[2], 4), "max": round(mx[2], 4)},
+            "ms_per_exchange_signal_to_scatter_end": {"min": round(mn[3], 4), "max": round(mx[3], 4)},
+            "rank0": {"launches": int(d["launches"]), "signalling_launches": int(d["signalling_launches"]),
+                      "exchanges": int(d["exchanges"]), "exchanges_timed": int(d["exchanges_timed"]),
+                      "wait_timeouts": int(d["wait_timeouts"]),
+                      "wait_mode": "hipStreamWaitValue32" if stats1["wait_mode"] == 1 else "polling kernel"},
+        }
         # Outside the timed region: every rank replays ALL iterations on the WHOLE image alone, on its own GPU, and
         # compares its own rows of the distributed result with that replay, bit for bit -- the slab decomposition, the
         # halo exchange over RCCL and the overlap must not change a single value.
@@ -227,8 +253,8 @@ def main():
             del mine, replay
         s.close()
         comm.close()
-        # a mismatch does not abort: the line is printed with the failed check in it (and says so in "data"), so that the
-        # record shows what happened on hardware this builder never sees
+        # a mismatch is printed with the line (value null, "data" says so) so that the record shows what happened on
+        # hardware this builder never sees -- and then every rank exits non-zero
 
     if rank == 0:
         pix_iters = float(total_rows) * W * a.iters * a.steps
@@ -263,6 +289,7 @@ def main():
         if comm_info:
             out["comm"] = {"transport": comm_info["kind"], "exchanges": comm_info["exchanges"],
                            "bytes_sent_rank0": comm_info["bytes_sent"]}
+            out["per_rank"] = rank_diag
         if world == 1:
             elems = float(H) * W * C
             ms_launch = kernel_ms / launches
@@ -304,7 +331,10 @@ def main():
             out["self_check"] = self_check
             if self_check["ranks_bit_identical_to_single_gpu_replay"] != world:
                 out["data"] += " -- SELF-CHECK FAILED: the distributed result differs from the single-GPU replay, this number is not valid"
+                out["value"] = None      # the diagnostics stay in the record, the number does not
         print(json.dumps(out), flush=True)
+    if world > 1 and self_check and self_check["ranks_bit_identical_to_single_gpu_replay"] != world:
+        raise SystemExit(3)              # every rank: an invalid multi-GPU result must not look like a success
 
 
 

@@ -34,7 +34,7 @@ EXPORTS = (
     "dxh_tvd_energy", "dxh_tvd_adapt_ell", "dxh_tvd_set_base", "dxh_tvd_set_cleaning_filter", "dxh_tvd_upload_signal", "dxh_tvd_download_model", "dxh_tvd_set_base_typed", "dxh_tvd_upload_signal_typed", "dxh_warp_patches_typed", "dxh_phase_correlation",
     "dxh_comm_unique_id", "dxh_comm_create_rccl", "dxh_comm_create_host", "dxh_comm_destroy", "dxh_comm_allreduce",
     "dxh_comm_barrier", "dxh_comm_info", "dxh_tvd_attach_comm", "dxh_tvd_exchange", "dxh_tvd_run_slab",
-    "dxh_mem_alloc", "dxh_mem_free", "dxh_mem_copy", "dxh_sqrt_probe", "dxh_rcp_probe", "dxh_tvd_solve_banded", "dxh_mem_trim", "dxh_tps_eval_pair", "dxh_tvd_set_coeffs_typed",
+    "dxh_mem_alloc", "dxh_mem_free", "dxh_mem_copy", "dxh_sqrt_probe", "dxh_rcp_probe", "dxh_tvd_solve_banded", "dxh_mem_trim", "dxh_tps_eval_pair", "dxh_tvd_set_coeffs_typed", "dxh_tvd_slab_stats",
 )
 
 # host-staged transport callbacks (include/darsia_hip.h: dxh_comm_exchange_fn, dxh_comm_allreduce_fn)
@@ -96,6 +96,15 @@ class TvdResult(C.Structure):
     _fields_ = [
         ("iters_done", C.c_int32), ("converged", C.c_int32), ("rel_increment", C.c_double),
         ("loop_ms", C.c_double), ("launches", C.c_int64),
+    ]
+
+
+class SlabStats(C.Structure):
+    """include/darsia_hip.h: dxh_slab_stats."""
+    _fields_ = [
+        ("struct_size", C.c_int32), ("wait_mode", C.c_int32), ("launches", C.c_int64),
+        ("signalling_launches", C.c_int64), ("exchanges", C.c_int64), ("exchanges_timed", C.c_int64),
+        ("wait_timeouts", C.c_int64), ("wait_signal_ms", C.c_double), ("exchange_ms", C.c_double),
     ]
 
 
@@ -167,6 +176,7 @@ def _declare(lib):
     lib.dxh_tvd_attach_comm.argtypes = [vp, vp, i64, i64]
     lib.dxh_tvd_exchange.argtypes = [vp]
     lib.dxh_tvd_run_slab.argtypes = [vp, i, i, dbl, C.c_uint32, C.POINTER(TvdResult)]
+    lib.dxh_tvd_slab_stats.argtypes = [vp, C.POINTER(SlabStats)]
     for name in EXPORTS:
         if name != "dxh_last_error":
             getattr(lib, name).restype = i

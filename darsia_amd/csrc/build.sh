@@ -9,7 +9,15 @@ OBJ="${DXH_OBJ:-${HERE}/_build}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 JOBS="${JOBS:-8}"
 mkdir -p "${OBJ}"
-rm -f "${OBJ}"/*.o "${OBJ}"/*.log
+# DXH_INCREMENTAL=1 (development): keep objects that are newer than their source, every header and this script, and
+# were built with the same extra arguments; the default is a clean build
+INCR="${DXH_INCREMENTAL:-0}"
+ARGSIG="$*"
+if [ "${INCR}" != "1" ] || [ "$(cat "${OBJ}/.args" 2>/dev/null)" != "${ARGSIG}" ]; then
+    rm -f "${OBJ}"/*.o "${OBJ}"/*.log
+fi
+printf '%s' "${ARGSIG}" > "${OBJ}/.args"
+NEWEST_DEP="$(ls -t "${HERE}"/*.h "${HERE}/build.sh" | head -1)"
 # -ffp-contract=off: every operation rounds once, as in the NumPy evaluation the results are compared with
 # -fno-slp-vectorize: v_pk_*_f32 issue at half rate on gfx950, so the SLP vectoriser's packed pairs save nothing
 # and the v_mov shuffles that build them cost issue slots (-3 % on the VALU-bound pipelines, measured)
@@ -20,6 +28,11 @@ names=()
 run() {  # run NAME SRC [extra flags]
     local name="$1" src="$2"
     shift 2
+    if [ "${INCR}" = "1" ] && [ -f "${OBJ}/${name}.o" ] && [ "${OBJ}/${name}.o" -nt "${HERE}/${src}" ] &&
+       [ "${OBJ}/${name}.o" -nt "${NEWEST_DEP}" ]; then
+        return 0
+    fi
+    rm -f "${OBJ}/${name}.o"
     while [ "$(jobs -rp | wc -l)" -ge "${JOBS}" ]; do sleep 0.2; done
     ( "${HIPCC}" "${FLAGS[@]}" "$@" -c "${HERE}/${src}" -o "${OBJ}/${name}.o" > "${OBJ}/${name}.log" 2>&1 ) &
     pids+=($!)

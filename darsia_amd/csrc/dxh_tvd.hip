@@ -124,6 +124,20 @@ struct Ctx {
     size_t xbytes[4] = {0, 0, 0, 0};
     double global_sq_img = -1.0;         // ||img||^2 over all ranks' owned rows
     int64_t split_launches = 0;          // statistics: launches that carried an overlapped exchange
+    // ---- diagnostics of the distributed sweep (dxh_tvd_slab_stats) ----
+    // signal[0] is the interface-wave counter, signal[kTimeoutSlot] counts time-outs of the polling wait kernel: a
+    // time-out means the exchange went ahead on rows that were never signalled, so the state is invalid from then on and
+    // every later synchronising entry point returns DXH_EHIP until the next upload.
+    static constexpr int kTimeoutSlot = 16;
+    unsigned wait_timeout_ms = 10000;    // polling kernel: give up after this long (DXH_SLAB_WAIT_TIMEOUT_MS)
+    bool test_lost_signal = false;       // DXH_SLAB_TEST_LOST_SIGNAL=1: wait for one wave more than will ever signal (tests)
+    bool slab_fault = false;             // a time-out has been seen (sticky until upload)
+    int64_t slab_launches = 0, slab_exchanges = 0, slab_timed = 0, slab_timeouts = 0;
+    double slab_wait_ms = 0.0, slab_xchg_ms = 0.0;
+    struct XEv { hipEvent_t a = nullptr, b = nullptr, c = nullptr; bool busy = false; };
+    static constexpr int kXEv = 64;
+    XEv xev[kXEv];
+    int xev_next = 0;
 };
 
 // Row-chunk layout of one fused launch (FusedArgs::seg_*).  An ordinary launch is one run of equal chunks.  The slab
@@ -1049,13 +1063,68 @@ static void launch_copy_segs(const CopySegs& a, hipStream_t st) {
 }
 
 // Polls the interface-wave counter (fallback when hipStreamWaitValue32 is not available).  One lane; ends when the
-// counter has reached `target` (cyclic compare) or, so that the stream can never hang, after ~10 s of wall clock.
-__global__ void k_wait_counter(const unsigned* counter, unsigned target) {
+// counter has reached `target` (cyclic compare).  So that the stream can never hang it gives up after `ticks` of the
+// 100 MHz wall clock -- and says so in *timeouts: the exchange behind it then packs rows nobody has signalled, so the
+// host turns a non-zero count into DXH_EHIP at the next synchronising call (slab_check_fault).
+__global__ void k_wait_counter(const unsigned* counter, unsigned target, long long ticks, unsigned* timeouts) {
     const long long t0 = wall_clock64();
     while ((int)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
         __builtin_amdgcn_s_sleep(32);
-        if (wall_clock64() - t0 > 1000000000LL) break;  // 100 MHz
+        if (wall_clock64() - t0 > ticks) {
+            __hip_atomic_fetch_add(timeouts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
     }
+}
+
+// The context has drained (the caller synchronised): has a polling wait given up since the last upload?
+static int slab_check_fault(Ctx* c) {
+    if (!c->signal) return DXH_OK;
+    if (!c->slab_fault && c->wait_mode == 2) {
+        unsigned n = 0;
+        DXH_HIP(hipMemcpy(&n, c->signal + Ctx::kTimeoutSlot, sizeof n, hipMemcpyDeviceToHost));
+        if (n) { c->slab_fault = true; c->slab_timeouts += n; }
+    }
+    if (c->slab_fault) {
+        set_error("halo exchange: the wait for the interface rows timed out after %u ms (%lld time-out(s)); the exchange "
+                  "went ahead on rows that had not been signalled, the slab state is invalid -- upload again",
+                  c->wait_timeout_ms, (long long)c->slab_timeouts);
+        return DXH_EHIP;
+    }
+    return DXH_OK;
+}
+
+// fold the event triples of finished exchanges into the running sums; `all`: the context has drained
+static void slab_fold_events(Ctx* c, bool all) {
+    for (auto& e : c->xev) {
+        if (!e.busy) continue;
+        if (!all && hipEventQuery(e.c) != hipSuccess) continue;
+        float w = 0.f, x = 0.f;
+        if (hipEventElapsedTime(&w, e.a, e.b) == hipSuccess && hipEventElapsedTime(&x, e.b, e.c) == hipSuccess) {
+            c->slab_wait_ms += w;
+            c->slab_xchg_ms += x;
+            ++c->slab_timed;
+        }
+        e.busy = false;
+    }
+    (void)hipGetLastError();
+}
+static Ctx::XEv* slab_take_events(Ctx* c) {
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int i = 0; i < Ctx::kXEv; ++i) {
+            Ctx::XEv& e = c->xev[(c->xev_next + i) % Ctx::kXEv];
+            if (e.busy) continue;
+            if (!e.a && (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess ||
+                         hipEventCreate(&e.c) != hipSuccess)) {
+                (void)hipGetLastError();
+                return nullptr;
+            }
+            c->xev_next = (c->xev_next + i + 1) % Ctx::kXEv;
+            return &e;
+        }
+        slab_fold_events(c, false);
+    }
+    return nullptr;  // every triple still in flight: this exchange goes untimed (exchanges_timed < exchanges)
 }
 
 static int start_exchange(Ctx* c, bool after_signal) {
@@ -1068,13 +1137,20 @@ static int start_exchange(Ctx* c, bool after_signal) {
     // previous stream has drained", which as a rule has happened long before it is looked at.  Serialised exchange: same
     // stream, plain stream order, no event at all.
     hipStream_t from = c->stream, to = after_signal ? c->alt : c->stream;
+    // three events per exchange (dxh_tvd_slab_stats): a -> b the exchange stream idles until the interface waves have
+    // signalled, b -> c gather + send / receive + scatter
+    Ctx::XEv* xe = slab_take_events(c);
+    if (xe) DXH_HIP(hipEventRecord(xe->a, to));
     if (after_signal) {
         // start as soon as every interface wave of the launch just enqueued has released its rows
+        const unsigned target = c->signal_target + (c->test_lost_signal ? 1u : 0u);
         if (c->wait_mode == 1)
-            DXH_HIP(hipStreamWaitValue32(to, c->signal, c->signal_target, hipStreamWaitValueGte, 0xffffffffu));
+            DXH_HIP(hipStreamWaitValue32(to, c->signal, target, hipStreamWaitValueGte, 0xffffffffu));
         else
-            hipLaunchKernelGGL(k_wait_counter, dim3(1), dim3(1), 0, to, c->signal, c->signal_target);
+            hipLaunchKernelGGL(k_wait_counter, dim3(1), dim3(1), 0, to, c->signal, target,
+                               (long long)c->wait_timeout_ms * 100000LL, c->signal + Ctx::kTimeoutSlot);
     }
+    if (xe) DXH_HIP(hipEventRecord(xe->b, to));
     // The rows of the 1 + dim state planes are gathered into one staging block per direction, so that an exchange is four
     // messages (RCCL packs up to eight point-to-point operations into one kernel: twelve row blocks took two kernels, the
     // second of which started only when the first had ended), and scattered into the halo rows on arrival.
@@ -1109,6 +1185,11 @@ static int start_exchange(Ctx* c, bool after_signal) {
     if (rc) return rc;
     launch_copy_segs(unpack, to);
     DXH_HIP(hipGetLastError());
+    if (xe) {
+        DXH_HIP(hipEventRecord(xe->c, to));
+        xe->busy = true;
+    }
+    ++c->slab_exchanges;
     if (after_signal) {
         // the interior chunks of the signalling launch must be done as well before anything overwrites their input
         DXH_HIP(hipEventRecord(c->eL, from));
@@ -1225,6 +1306,7 @@ static int run_slab_t(Ctx* c, int n_iter, int m, double eps, uint32_t flags, dxh
         }
     }
     float ms = std::numeric_limits<float>::quiet_NaN();
+    c->slab_launches += launches;
     if (!async) {
         DXH_HIP(hipEventRecord(c->ev1, c->stream));
         DXH_HIP(hipStreamSynchronize(c->stream));
@@ -1237,6 +1319,7 @@ static int run_slab_t(Ctx* c, int n_iter, int m, double eps, uint32_t flags, dxh
         res->loop_ms = ms;
         res->launches = launches;
     }
+    if (!async && (rc = slab_check_fault(c))) return rc;
     return DXH_OK;
 }
 
@@ -1464,6 +1547,9 @@ int dxh_tvd_destroy(dxh_tvd_t h) {
     if (c->alt) (void)hipStreamSynchronize(c->alt);
     if (c->alt_owned) (void)hipStreamDestroy(c->alt_owned);
     if (c->eL) (void)hipEventDestroy(c->eL);
+    for (auto& e : c->xev)
+        for (hipEvent_t ev : {e.a, e.b, e.c})
+            if (ev) (void)hipEventDestroy(ev);
     if (c->signal) (void)hipFree(c->signal);
     for (char* b : c->xbuf)
         if (b) (void)hipFree(b);
@@ -1603,6 +1689,10 @@ static int finish_upload(Ctx* c, const void* u0, const void* d0, const void* b0,
     c->pristine = false;
     c->from_db = false;
     c->explicit_db = false;
+    if (c->signal && c->slab_fault) {  // a fresh state: the time-out of an earlier sequence no longer applies
+        DXH_HIP(hipMemsetAsync(c->signal + Ctx::kTimeoutSlot, 0, sizeof(unsigned), c->stream));
+        c->slab_fault = false;
+    }
     if (d0) {
         // explicit split variables: keep them as planes for the first iteration
         const size_t dense = (size_t)c->g.n0 * c->g.L * dim * c->esz;
@@ -1980,6 +2070,10 @@ int dxh_tvd_download(dxh_tvd_t h, void* u, void* d, void* b) {
     if (!c->uploaded) { set_error("nothing to download"); return DXH_ESTATE; }
     int rc = set_device(c);
     if (rc) return rc;
+    if (c->signal) {  // a slab: a timed-out halo wait makes the state invalid (slab_check_fault)
+        DXH_HIP(hipStreamSynchronize(c->stream));
+        if ((rc = slab_check_fault(c))) return rc;
+    }
     if (u && (rc = d2h_plane(c, u, c->u[c->cur]))) return rc;
     if (d || b) {
         const int dim = c->desc.dim;
@@ -2116,6 +2210,11 @@ int dxh_tvd_attach_comm(dxh_tvd_t h, dxh_comm_t comm, int64_t halo_top_rows, int
             const int v = atoi(e);
             if (v == 1 || v == 2) c->wait_mode = v;
         }
+        if (const char* e = getenv("DXH_SLAB_WAIT_TIMEOUT_MS")) {  // polling kernel: time-out (default 10 s)
+            const long v = atol(e);
+            if (v > 0 && v <= 3600000) c->wait_timeout_ms = (unsigned)v;
+        }
+        if (const char* e = getenv("DXH_SLAB_TEST_LOST_SIGNAL")) c->test_lost_signal = atoi(e) == 1;  // tests only
     }
     if (c->comm != cm) {
         comm_release(c->comm);
@@ -2255,6 +2354,28 @@ int dxh_tvd_sync(dxh_tvd_t h) {
     int rc = set_device(c);
     if (rc) return rc;
     DXH_HIP(hipStreamSynchronize(c->stream));
+    return slab_check_fault(c);
+}
+
+int dxh_tvd_slab_stats(dxh_tvd_t h, dxh_slab_stats* out) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    DXH_REQUIRE(c && out, "null argument");
+    DXH_REQUIRE(out->struct_size == (int32_t)sizeof(dxh_slab_stats), "dxh_slab_stats size mismatch (%d vs %zu)",
+                out->struct_size, sizeof(dxh_slab_stats));
+    int rc = set_device(c);
+    if (rc) return rc;
+    DXH_HIP(hipStreamSynchronize(c->stream));
+    if (c->alt) DXH_HIP(hipStreamSynchronize(c->alt));
+    slab_fold_events(c, true);
+    (void)slab_check_fault(c);  // refreshes the time-out count; the verdict belongs to sync / run / download
+    out->wait_mode = c->wait_mode;
+    out->launches = c->slab_launches;
+    out->signalling_launches = c->split_launches;
+    out->exchanges = c->slab_exchanges;
+    out->exchanges_timed = c->slab_timed;
+    out->wait_timeouts = c->slab_timeouts;
+    out->wait_signal_ms = c->slab_wait_ms;
+    out->exchange_ms = c->slab_xchg_ms;
     return DXH_OK;
 }
 

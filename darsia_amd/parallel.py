@@ -379,6 +379,12 @@ class HipSlabEngine:
     def synchronize(self):
         _lib.check(self.st.lib.dxh_tvd_sync(self.st._h))
 
+    def stats(self) -> dict:
+        st = _lib.SlabStats()
+        st.struct_size = C.sizeof(_lib.SlabStats)
+        _lib.check(self.st.lib.dxh_tvd_slab_stats(self.st._h, C.byref(st)))
+        return {name: getattr(st, name) for name, _ in _lib.SlabStats._fields_ if name != "struct_size"}
+
     def close(self):
         self.st.close()
 
@@ -501,6 +507,10 @@ class SlabTVD:
 
     def synchronize(self):
         self.engine.synchronize()
+
+    def slab_stats(self) -> dict:
+        """Launch / exchange counts and where the exchange stream's time went (``dxh_tvd_slab_stats``); HIP engine only."""
+        return self.engine.stats()
 
     def close(self):
         self.engine.close()

@@ -271,6 +271,28 @@ int dxh_tvd_exchange(dxh_tvd_t ctx);
  * result->loop_ms is NaN with DXH_FLAG_ASYNC.
  */
 int dxh_tvd_run_slab(dxh_tvd_t ctx, int n_iter, int jacobi_maxiter, double eps, uint32_t flags, dxh_tvd_result* result);
+
+/*
+ * Where the time of a slab context went (diagnostics; no reference counterpart).  Every exchange is bracketed by three
+ * events on the stream it runs on: wait_signal_ms sums the time that stream idled until the interface waves of the
+ * signalling launch had released their rows (0 for exchanges in plain stream order), exchange_ms the time from there to
+ * the end of the scatter of the received rows (gather + grouped send / receive -- which includes waiting for the
+ * neighbour -- + scatter).  Synchronises the context.  wait_timeouts > 0: the polling wait (devices without
+ * hipStreamWaitValue32) gave up after DXH_SLAB_WAIT_TIMEOUT_MS (default 10 s); dxh_tvd_sync / dxh_tvd_run_slab /
+ * dxh_tvd_download return DXH_EHIP from then on until the next dxh_tvd_upload.
+ */
+typedef struct dxh_slab_stats {
+    int32_t struct_size;          /* sizeof(dxh_slab_stats), set by the caller */
+    int32_t wait_mode;            /* 1 hipStreamWaitValue32, 2 polling kernel, 0 no communicator attached */
+    int64_t launches;             /* sweep launches enqueued by dxh_tvd_run_slab */
+    int64_t signalling_launches;  /* of these: interface chunks first, followed by an overlapped exchange */
+    int64_t exchanges;            /* halo exchanges enqueued */
+    int64_t exchanges_timed;      /* exchanges that contributed to the two sums below */
+    int64_t wait_timeouts;
+    double wait_signal_ms;
+    double exchange_ms;
+} dxh_slab_stats;
+int dxh_tvd_slab_stats(dxh_tvd_t ctx, dxh_slab_stats* out);
 /* sum over rows [row0, row0+nrows) of (u - u_prev)^2 of the last iteration and of img^2 (for a global eps test) */
 int dxh_tvd_partial_norms(dxh_tvd_t ctx, int64_t row0, int64_t nrows, double* sq_increment, double* sq_img);
 /* adaptive regularisation, split_bregman_tvd.py:149-158: ell <- 1 / max(|grad u|_1, 1e-12) per element for the rhs

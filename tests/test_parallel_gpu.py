@@ -222,6 +222,44 @@ def test_rccl_self_neighbour_periodic(case, monkeypatch):
     assert xchg == -(-n // case["halo_iters"]) - 1
 
 
+def test_polling_wait_timeout_raises(monkeypatch):
+    """The polling wait (devices without hipStreamWaitValue32) gives up after its time-out so that the stream cannot hang;
+    the exchange behind it has then packed rows nobody signalled.  That must surface as an error at the next
+    synchronising call (and stay one until the next upload), not as a silently wrong result.  The lost signal is
+    simulated: the wait is told to expect one wave more than the launch has."""
+    from darsia_amd import _lib
+    from darsia_amd.parallel import Comm, SlabTVD, make_plan, periodic_slab
+
+    monkeypatch.setenv("DXH_SLAB_WAIT", "2")
+    monkeypatch.setenv("DXH_SLAB_WAIT_TIMEOUT_MS", "40")
+    monkeypatch.setenv("DXH_SLAB_TEST_LOST_SIGNAL", "1")
+    img = np.random.default_rng(8).random((300, 200, 3)).astype(np.float32)
+    os.environ["MASTER_PORT"] = str(_free_port())
+    comm = Comm.rccl(0, 1, device=0)
+    try:
+        plan = make_plan(img.shape[0], 1, 0, 4, periodic=True)
+        s = SlabTVD(plan, periodic_slab(img, plan), mu=0.1, halo_iters=4, comm=comm)
+        with pytest.raises(_lib.HipError, match="timed out"):
+            s.run(12)
+        with pytest.raises(_lib.HipError, match="timed out"):
+            s.synchronize()
+        with pytest.raises(_lib.HipError, match="timed out"):
+            s.owned_result()
+        st = s.slab_stats()
+        assert st["wait_timeouts"] >= 1 and st["wait_mode"] == 2
+        # a fresh upload starts a fresh sequence; without the lost signal it runs clean
+        s.close()
+        monkeypatch.delenv("DXH_SLAB_TEST_LOST_SIGNAL")
+        s = SlabTVD(plan, periodic_slab(img, plan), mu=0.1, halo_iters=4, comm=comm)
+        assert s.run(12) == 12
+        st = s.slab_stats()
+        assert st["wait_timeouts"] == 0 and st["exchanges"] == 2 and st["signalling_launches"] == 2
+        assert st["exchanges_timed"] == 2 and st["exchange_ms"] > 0.0
+        s.close()
+    finally:
+        comm.close()
+
+
 def test_rccl_one_rank_per_gpu(tmp_path):
     """The product transport: one process per GPU, RCCL send/recv between slab neighbours (needs >= 2 GPUs)."""
     from darsia_amd import _lib
