@@ -1267,6 +1267,214 @@ __global__ void __launch_bounds__(256) k_fused(FusedArgs<T> a) {
 
 
 // ============================================================================================
+// The reference's OWN dtype flow for a float32 image under NumPy >= 2 ("numpy2" promotion), one outer iteration per
+// pass.  With scalar omega / ell the reference's cached const_diag_scaled is an np.float64 (jacobi.py:101-106), so
+//   rhs        = omega*img + sum_j fd_j(ell (b_j - d_j))       float32   (split_bregman_tvd.py:84-89, in-place +=)
+//   rhs_scaled = rhs / diag                                    float32   (jacobi.py:107)
+//   u_new      = rhs_scaled + N(u) / diag_scaled               float64   (jacobi.py:110-114; N(u) is summed in float32
+//                                                                         while u is still the float32 image, i.e. in
+//                                                                         the first iteration of a call, in float64 after)
+//   dub_j      = D_j u_new + b_j                               float64   (:143)
+//   d_j        = shrink(dub_j, mu / ell)  -> stored float32              (:144; mu / ell: Python float, or a float64
+//                                                                         array when mu is one -- the workflow's weights)
+//   b_j        = dub_j - d_j              -> stored float32              (:145)
+// The context is a DOUBLE context (planes, pitch, halo plumbing of the float64 path): u and the compressed split
+// state q_j = dub_j are float64 planes, omega*img is a float64 plane that holds float32 values.  d, b, t = ell (b - d)
+// and the right-hand side are recomputed / evaluated in float32 exactly as above, so the result equals the
+// reference's bit for bit (tests/golden/tvd_mixed_golden.npz and the float32 cases of tvd_golden.npz).
+// Strip / chunk decomposition, border rules and lane shifts are those of k_fused<double>.
+// ============================================================================================
+struct Np2Coef {
+    double dsc;      // const_diag_scaled (np.float64)
+    double kq;       // mu / ell as a Python float (scalar mu)
+    float ell, diag; // weak Python floats meeting float32 arrays
+    const double* kq_plane;  // mu / ell per element (float64 array-valued mu), or nullptr
+    int first;       // u still holds the float32 image: neighbour sums in float32 (first iteration of a call)
+};
+
+__device__ __forceinline__ void np2_split(double q, double kq, float& d, float& b) {
+    const double d64 = t_max0(fabs(q) - kq) * sgn(q);   // np.maximum(np.abs(x) - k, 0) * np.sign(x), float64
+    d = (float)d64;                                       // d[..., j] = ...   (float32 array)
+    b = (float)(q - (double)d);                           // b[..., j] = dub - d[..., j]
+}
+
+template <int C, bool COUPLED, bool KQARR>
+__global__ void __launch_bounds__(256) k_fused_np2(FusedArgs<double> a, Np2Coef k) {
+    using T = double;
+    constexpr int N = VecOf<T>::N;
+    constexpr bool DPP = true;
+    using SG = StripGeom<T, C, true>;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    constexpr int WPB = 4;
+    const int nbx = (a.nstrips + WPB - 1) / WPB;
+    int bx, chunk;
+    if (!block_to_tile_sub((int)blockIdx.x, nbx, a, bx, chunk)) return;  // block-uniform
+    const int strip = bx * WPB + wave;
+    if (strip >= a.nstrips || chunk >= a.nchunks) return;  // wave-uniform
+    int64_t R0, R1;
+    chunk_rows(a, chunk, R0, R1);
+    if (R0 >= a.n0) return;
+
+    const int64_t x0 = (int64_t)strip * SG::STRIDE + (int64_t)(lane - SG::LH) * N;
+    int64_t xl = x0;
+    if (xl < 0) xl = 0;
+    if (xl > a.pitch - N) xl = a.pitch - N;
+    const bool store_lane = lane >= SG::LH && lane < SG::LH + SG::VALID && x0 < a.L;
+    bool edgeL[N], edgeR[N], ch0[N], chLast[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int64_t x = x0 + j;
+        edgeL[j] = x < C;
+        edgeR[j] = x >= a.L - C;
+        const int cc = (int)(((x % C) + C) % C);
+        ch0[j] = cc == 0;
+        chLast[j] = cc == C - 1;
+    }
+    const T* of = a.of + xl;
+    const T* u_in = a.u_in + xl;
+    const T* q0_in = a.q0_in + xl;
+    const T* q1_in = a.q1_in + xl;
+    T* u_out = a.u_out + xl;
+    T* q0_out = a.q0_out + xl;
+    T* q1_out = a.q1_out + xl;
+    const T* p_kq = KQARR ? k.kq_plane + xl : nullptr;
+    const int64_t P = a.pitch;
+    auto clampr = [&](int64_t r) -> int64_t { return r < 0 ? 0 : (r > a.n0 - 1 ? a.n0 - 1 : r); };
+    const bool first = k.first != 0;  // uniform
+
+    T kq[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) kq[j] = k.kq;
+
+    // ---- prologue: rows R0-1 and R0
+    T um[N], uc[N], up[N], upm[N];
+    float t0m[N], b0m[N];
+    load_vec(u_in + clampr(R0 - 1) * P, um);
+    load_vec(u_in + R0 * P, uc);
+    {
+        const int64_t rm = clampr(R0 - 1);
+        T q0v[N], kqm[N];
+        load_vec(q0_in + rm * P, q0v);
+        if constexpr (KQARR) load_vec(p_kq + rm * P, kqm);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            float d, b;
+            np2_split(q0v[j], KQARR ? kqm[j] : kq[j], d, b);
+            t0m[j] = k.ell * (b - d);
+            upm[j] = T(0);
+            b0m[j] = 0.f;
+        }
+    }
+    T fr[N], q0r[N], q1r[N];
+    load_vec(u_in + clampr(R0 + 1) * P, up);
+    load_vec(of + R0 * P, fr);
+    load_vec(q0_in + R0 * P, q0r);
+    load_vec(q1_in + R0 * P, q1r);
+    if constexpr (KQARR) load_vec(p_kq + R0 * P, kq);
+
+    for (int64_t r = R0; r <= R1; ++r) {
+        T upn[N], frn[N], q0n[N], q1n[N], kqn[N];
+        {
+            const int64_t rn = clampr(r + 1);
+            load_vec(u_in + clampr(r + 2) * P, upn);
+            load_vec(of + rn * P, frn);
+            load_vec(q0_in + rn * P, q0n);
+            load_vec(q1_in + rn * P, q1n);
+            if constexpr (KQARR) load_vec(p_kq + rn * P, kqn);
+        }
+        T un[N];
+        float b0c[N], t0c[N];
+        if (r < a.n0) {
+            float b1c[N];
+            T t1c[N];  // float32 values carried in the lane-shift type
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                float d0, b0, d1, b1;
+                np2_split(q0r[j], kq[j], d0, b0);
+                np2_split(q1r[j], kq[j], d1, b1);
+                b0c[j] = b0;
+                b1c[j] = b1;
+                t0c[j] = k.ell * (b0 - d0);
+                t1c[j] = (T)(k.ell * (b1 - d1));
+            }
+            T t1l[N], ul[N], ur[N], ucl[N], ucr[N];
+            shifted<-C, DPP>(t1c, t1l);
+            shifted<-C, DPP>(uc, ul);
+            shifted<+C, DPP>(uc, ur);
+            if constexpr (COUPLED) {
+                shifted<-1, DPP>(uc, ucl);
+                shifted<+1, DPP>(uc, ucr);
+            }
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                // float32: rhs = omega*img; rhs += fd_0; rhs += fd_1; rhs_scaled = rhs / diag
+                float rhs = (float)fr[j] + (t0c[j] - t0m[j]);
+                rhs = rhs + ((float)t1c[j] - (edgeL[j] ? (float)t1c[j] : (float)t1l[j]));
+                const float rs = rhs / k.diag;
+                const T nl = edgeL[j] ? uc[j] : ul[j], nr = edgeR[j] ? uc[j] : ur[j];
+                T acc;
+                if (first) {  // u is the float32 image: the reference's accumulator is float32 too
+                    float af = (float)um[j] + (float)up[j];
+                    af = af + (float)nl;
+                    af = af + (float)nr;
+                    if constexpr (COUPLED) {
+                        af = af + (float)(ch0[j] ? uc[j] : ucl[j]);
+                        af = af + (float)(chLast[j] ? uc[j] : ucr[j]);
+                    }
+                    acc = (T)af;
+                } else {
+                    acc = um[j] + up[j];
+                    acc = acc + nl;
+                    acc = acc + nr;
+                    if constexpr (COUPLED) {
+                        acc = acc + (ch0[j] ? uc[j] : ucl[j]);
+                        acc = acc + (chLast[j] ? uc[j] : ucr[j]);
+                    }
+                }
+                un[j] = (T)rs + acc / k.dsc;
+            }
+            T unr[N], q1o[N];
+            shifted<+C, DPP>(un, unr);
+#pragma unroll
+            for (int j = 0; j < N; ++j) q1o[j] = ((edgeR[j] ? un[j] : unr[j]) - un[j]) + (T)b1c[j];
+            if (store_lane && r < R1) {
+                store_vec_nt(q1_out + r * P, q1o);
+                store_vec_nt(u_out + r * P, un);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                un[j] = upm[j];
+                b0c[j] = 0.f;
+                t0c[j] = 0.f;
+            }
+        }
+        if (r > R0) {
+            T q0o[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) q0o[j] = (un[j] - upm[j]) + (T)b0m[j];
+            if (store_lane) store_vec_nt(q0_out + (r - 1) * P, q0o);
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            um[j] = uc[j];
+            uc[j] = up[j];
+            up[j] = upn[j];
+            t0m[j] = t0c[j];
+            upm[j] = un[j];
+            b0m[j] = b0c[j];
+            fr[j] = frn[j];
+            q0r[j] = q0n[j];
+            q1r[j] = q1n[j];
+            if constexpr (KQARR) kq[j] = kqn[j];
+        }
+    }
+    signal_chunk_done(a, chunk, lane);
+}
+
+
+// ============================================================================================
 // K outer iterations in ONE pass (temporal blocking of the fused sweep; scalar coefficients).
 //
 // The wave still marches down its column strip, but now runs a K-stage pipeline per step: stage s

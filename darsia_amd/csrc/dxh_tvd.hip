@@ -124,6 +124,8 @@ struct Ctx {
     size_t xbytes[4] = {0, 0, 0, 0};
     double global_sq_img = -1.0;         // ||img||^2 over all ranks' owned rows
     int64_t split_launches = 0;          // statistics: launches that carried an overlapped exchange
+    int64_t row_lo = 0, row_hi = 0;      // rows a fused launch has to produce ([0, n0) when row_hi == 0): a slab launch skips
+                                         //   the halo rows its own iterations would leave invalid (run_slab_t)
     // ---- diagnostics of the distributed sweep (dxh_tvd_slab_stats) ----
     // signal[0] is the interface-wave counter, signal[kTimeoutSlot] counts time-outs of the polling wait kernel: a
     // time-out means the exchange went ahead on rows that were never signalled, so the state is invalid from then on and
@@ -163,18 +165,25 @@ static void slab_interface_rows(const Ctx* c, int64_t* A, int64_t* B) {
 template <typename F>
 static ChunkLayout make_layout(const Ctx* c, int nbx, int K, F&& choose_chunks) {
     ChunkLayout l{};
-    const int64_t n0 = c->g.n0;
-    int64_t A = 0, B = n0;
-    if (c->signalling) slab_interface_rows(c, &A, &B);
+    // rows the launch has to produce: all of them, or -- slab launches between two exchanges -- all but the halo rows
+    // that this launch's iterations would leave invalid anyway (run_slab_t sets row_lo / row_hi)
+    const int64_t lo = c->row_lo, hi = c->row_hi > 0 ? c->row_hi : c->g.n0;
+    const int64_t n0 = hi - lo;
+    int64_t A = lo, B = hi;
+    if (c->signalling) {
+        slab_interface_rows(c, &A, &B);
+        A = std::max(A, lo);
+        B = std::min(B, hi);
+    }
     if (!c->signalling || B - A < 16 * K) {
         // one run (a slab too short to have an interior worth the name: the whole launch signals as class A below)
         const int64_t nc = choose_chunks(n0, 0);
         const int64_t rpc = (n0 + nc - 1) / nc;
         const int real = (int)((n0 + rpc - 1) / rpc);
         const bool all_a = c->signalling;
-        l.seg_row[0] = 0;
-        l.seg_row[1] = all_a ? n0 : 0;
-        l.seg_row[2] = l.seg_row[3] = n0;
+        l.seg_row[0] = lo;
+        l.seg_row[1] = all_a ? hi : lo;
+        l.seg_row[2] = l.seg_row[3] = hi;
         l.seg_rpc[0] = l.seg_rpc[1] = l.seg_rpc[2] = rpc;
         l.seg_chunk[0] = 0;
         l.seg_chunk[1] = all_a ? real : 0;
@@ -189,13 +198,13 @@ static ChunkLayout make_layout(const Ctx* c, int nbx, int K, F&& choose_chunks) 
         *rpc = (rows + n - 1) / n;
         return (int)((rows + *rpc - 1) / *rpc);
     };
-    const int c0 = short_run(A, &l.seg_rpc[0]);
-    const int c2 = short_run(n0 - B, &l.seg_rpc[2]);
+    const int c0 = short_run(A - lo, &l.seg_rpc[0]);
+    const int c2 = short_run(hi - B, &l.seg_rpc[2]);
     const int64_t extra = ((int64_t)nbx * (c0 + c2) + 7) / 8;
     const int64_t nc = choose_chunks(B - A, extra);
     l.seg_rpc[1] = (B - A + nc - 1) / nc;
     const int c1 = (int)((B - A + l.seg_rpc[1] - 1) / l.seg_rpc[1]);
-    l.seg_row[0] = 0; l.seg_row[1] = A; l.seg_row[2] = B; l.seg_row[3] = n0;
+    l.seg_row[0] = lo; l.seg_row[1] = A; l.seg_row[2] = B; l.seg_row[3] = hi;
     l.seg_chunk[0] = 0; l.seg_chunk[1] = c0; l.seg_chunk[2] = c0 + c1; l.seg_chunk[3] = c0 + c1 + c2;
     l.nchunks = c0 + c1 + c2;
     l.class_a = c0 + c2;
@@ -468,7 +477,9 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
                 const int64_t per_xcd = (real * nbx + 7) / 8 + extra_per_xcd;
                 const int64_t per_cu = (per_xcd + cu_per_xcd - 1) / cu_per_xcd;
                 const int64_t full = per_cu / W, rem = per_cu - full * W;
-                const double cost = (double)(rpc_c + 2 * K + 2) * ((double)full * W * cpi[W] + (double)rem * cpi[rem]);
+                // row steps of a chunk: rows R0 - (K - 1) .. R1 + (K - 1), in groups of four (fused_pipe_body)
+                const int64_t steps = (rpc_c + 2 * (K - 1) + 1 + 3) / 4 * 4;
+                const double cost = (double)steps * ((double)full * W * cpi[W] + (double)rem * cpi[rem]);
                 if (cost < best * 0.999) { best = cost; nchunks = real; }
                 if ((double)(real * nbx) / ((double)c->num_cu * W) > 4.5) break;
             }
@@ -840,6 +851,7 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
     const bool use_eps = eps >= 0.0 && !std::isnan(eps);
     const bool use_tol = jacobi_tol >= 0.0 && !std::isnan(jacobi_tol);
     c->signalling = false;  // only dxh_tvd_run_slab builds signalling launches
+    c->row_lo = c->row_hi = 0;
     const bool dpp = !(flags & DXH_FLAG_NO_DPP);
     bool fused_ok = fused_supported(c) && jacobi_maxiter == 1 && !use_tol && !(flags & DXH_FLAG_NO_FUSED) && !c->solver;
     const int dim = c->desc.dim;
@@ -1272,7 +1284,19 @@ static int run_slab_t(Ctx* c, int n_iter, int m, double eps, uint32_t flags, dxh
                 DXH_HIP(hipMemset(c->signal, 0, 256));
                 c->signal_target = 0;
             }
+            if (dist && !(c->tune & 131072)) {
+                // After these K iterations, j sweeps after the last exchange, a non-boundary top has lost its first j rows
+                // and a non-boundary bottom the last j rows of u and q1 and the last j + 1 rows of q0 (file header of
+                // darsia_amd/parallel.py; the one row of q0 more is why the bottom halo has k + 1 rows): the launch need
+                // not produce rows outside [j, n0 - j) -- a launch stores u, q1 of its rows and q0 of the same rows, the
+                // last of which is the invalid one.  What is skipped are halo rows, all rewritten by the next exchange.
+                // (DXH_FUSED_TUNE bit 131072: whole slab every time, A/B)
+                const int64_t j = c->halo_top - c->halo_valid + (int64_t)K * m;
+                c->row_lo = c->top > 0 ? std::min(j, c->top) : 0;
+                c->row_hi = c->bot > 0 ? c->g.n0 - std::min(j, c->bot) : c->g.n0;
+            }
             launch_any<T>(c, in, out, iso, dpp, K);
+            c->row_lo = c->row_hi = 0;
             if (c->signalling) {
                 c->signal_target += c->signal_pending;
                 ++c->split_launches;

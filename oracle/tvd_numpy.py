@@ -209,7 +209,9 @@ def split_bregman_tvd(
     for it in range(max_num_iter):
         rhs = np.multiply(omega, img)
         for j in range(dim):
-            rhs = rhs + forward_diff(ell * (b[j] - d[j]), j)
+            # the reference accumulates IN PLACE (``result += ...``, split_bregman_tvd.py:84-89): the sum keeps the dtype
+            # of omega * img even when ell -- hence the difference -- is a float64 array next to a float32 image
+            rhs = (rhs + forward_diff(ell * (b[j] - d[j]), j)).astype(rhs.dtype, copy=False)
         if solver is not None:
             u_new = solver(u, rhs)
         else:
