@@ -35,6 +35,7 @@ EXPORTS = (
     "dxh_comm_unique_id", "dxh_comm_create_rccl", "dxh_comm_create_host", "dxh_comm_destroy", "dxh_comm_allreduce",
     "dxh_comm_barrier", "dxh_comm_info", "dxh_tvd_attach_comm", "dxh_tvd_exchange", "dxh_tvd_run_slab",
     "dxh_mem_alloc", "dxh_mem_free", "dxh_mem_copy", "dxh_sqrt_probe", "dxh_rcp_probe", "dxh_tvd_solve_banded", "dxh_mem_trim", "dxh_tps_eval_pair", "dxh_tvd_set_coeffs_typed", "dxh_tvd_slab_stats",
+    "dxh_tvd_set_promotion", "dxh_tvd_upload_typed", "dxh_tvd_download_typed",
 )
 
 # host-staged transport callbacks (include/darsia_hip.h: dxh_comm_exchange_fn, dxh_comm_allreduce_fn)
@@ -97,6 +98,9 @@ class TvdResult(C.Structure):
         ("iters_done", C.c_int32), ("converged", C.c_int32), ("rel_increment", C.c_double),
         ("loop_ms", C.c_double), ("launches", C.c_int64),
     ]
+
+
+PROMOTION_NUMPY2, PROMOTION_MU_IS_THRESHOLD = 1, 2   # include/darsia_hip.h: DXH_PROMOTION_*
 
 
 class SlabStats(C.Structure):
@@ -177,6 +181,9 @@ def _declare(lib):
     lib.dxh_tvd_exchange.argtypes = [vp]
     lib.dxh_tvd_run_slab.argtypes = [vp, i, i, dbl, C.c_uint32, C.POINTER(TvdResult)]
     lib.dxh_tvd_slab_stats.argtypes = [vp, C.POINTER(SlabStats)]
+    lib.dxh_tvd_set_promotion.argtypes = [vp, i]
+    lib.dxh_tvd_upload_typed.argtypes = [vp, vp, i]
+    lib.dxh_tvd_download_typed.argtypes = [vp, vp, i]
     for name in EXPORTS:
         if name != "dxh_last_error":
             getattr(lib, name).restype = i

@@ -621,6 +621,13 @@ __global__ void __launch_bounds__(256) k_scale(Geom g, const T* __restrict__ a, 
     out[e.off] = (splane ? splane[e.off] : s) * a[e.off];
 }
 
+// numpy2 flow: omega * img of a float32 image (held exactly in a float64 plane) is a float32 product
+static __global__ void __launch_bounds__(256) k_scale_np2(Geom g, const double* __restrict__ a, float s, double* __restrict__ out) {
+    ElemIdx e;
+    if (!elem_index(g, e)) return;
+    out[e.off] = (double)(s * (float)a[e.off]);
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) k_divide(Geom g, const T* __restrict__ a, T s, const T* __restrict__ splane,
                                                  T* __restrict__ out) {

@@ -107,6 +107,11 @@ struct Ctx {
     int solver_kind = DXH_SOLVER_JACOBI;
     bool solver_params_set = false;
 
+    // ---- the reference's NumPy >= 2 dtype flow for a float32 image (dxh_tvd_set_promotion; k_fused_np2) ----
+    bool np2 = false;            // double context whose planes hold the reference's mixed float32 / float64 state
+    bool np2_first = true;       // u still is the float32 image (first iteration after an upload)
+    bool np2_mu_is_kq = false;   // the given mu array already is the threshold mu / ell (float32 quotient, widened)
+
     // ---- row slab of a distributed problem (dxh_tvd_attach_comm) ----
     Comm* comm = nullptr;
     int64_t halo_top = 0, halo_bot = 0;  // the plan's halo rows (the same on every rank)
@@ -844,6 +849,58 @@ static int solve_u(Ctx* c, int jacobi_maxiter, double jacobi_tol, void* tmp, int
     return rc;
 }
 
+// numpy2 flow (double context): one outer iteration by k_fused_np2
+static int launch_np2(Ctx* c, int in, int out) {
+    FusedArgs<double> a{};
+    a.of = (const double*)c->of;
+    a.u_in = (const double*)c->u[in];
+    a.u_out = (double*)c->u[out];
+    a.q0_in = (const double*)c->q[0][in];
+    a.q1_in = (const double*)c->q[1][in];
+    a.q0_out = (double*)c->q[0][out];
+    a.q1_out = (double*)c->q[1][out];
+    a.n0 = c->g.n0;
+    a.L = c->g.L;
+    a.pitch = c->g.pitch;
+    const int C = (int)c->g.n2;
+    const int stride = C == 1 ? StripGeom<double, 1, true>::STRIDE : C == 2 ? StripGeom<double, 2, true>::STRIDE
+                     : C == 3 ? StripGeom<double, 3, true>::STRIDE : StripGeom<double, 4, true>::STRIDE;
+    a.nstrips = (int)((c->g.L + stride - 1) / stride);
+    const int nbx = (a.nstrips + 3) / 4;
+    auto choose = [&](int64_t rows, int64_t extra_per_xcd) -> int64_t {
+        const int64_t target_blocks = (int64_t)c->num_cu * (c->waves_per_cu ? c->waves_per_cu : 8) / 4 - 8 * extra_per_xcd;
+        const int64_t nchunks = std::max<int64_t>(1, target_blocks / nbx);
+        const int64_t rpc = std::max<int64_t>(8, (rows + nchunks - 1) / nchunks);
+        return (rows + rpc - 1) / rpc;
+    };
+    const ChunkLayout lay = make_layout(c, nbx, 1, choose);
+    const unsigned grid = apply_layout(c, a, lay, nbx);
+    a.remap = 1;
+    Np2Coef k{};
+    k.dsc = c->c_dsc;
+    k.kq = c->c_kq;
+    k.ell = (float)c->c_ell;
+    k.diag = (float)c->c_diag;
+    k.kq_plane = c->het ? (const double*)c->cp_kq : nullptr;
+    k.first = c->np2_first ? 1 : 0;
+    const bool coupled = c->desc.ndim == 3 && c->desc.nsum == DXH_NSUM_ALL_AXES;
+    const bool arr = k.kq_plane != nullptr;
+#define DXH_NP2(C_)                                                                                          \
+    if (coupled) { if (arr) hipLaunchKernelGGL((k_fused_np2<C_, true, true>), dim3(grid), dim3(256), 0, c->stream, a, k);   \
+                   else hipLaunchKernelGGL((k_fused_np2<C_, true, false>), dim3(grid), dim3(256), 0, c->stream, a, k); }    \
+    else         { if (arr) hipLaunchKernelGGL((k_fused_np2<C_, false, true>), dim3(grid), dim3(256), 0, c->stream, a, k);  \
+                   else hipLaunchKernelGGL((k_fused_np2<C_, false, false>), dim3(grid), dim3(256), 0, c->stream, a, k); }
+    switch (C) {
+        case 1: DXH_NP2(1) break;
+        case 2: DXH_NP2(2) break;
+        case 3: DXH_NP2(3) break;
+        default: DXH_NP2(4) break;
+    }
+#undef DXH_NP2
+    DXH_HIP(hipGetLastError());
+    return DXH_OK;
+}
+
 template <typename T>
 static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, double eps, double norm_scale,
                  uint32_t flags, dxh_tvd_result* res) {
@@ -855,6 +912,15 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
     const bool dpp = !(flags & DXH_FLAG_NO_DPP);
     bool fused_ok = fused_supported(c) && jacobi_maxiter == 1 && !use_tol && !(flags & DXH_FLAG_NO_FUSED) && !c->solver;
     const int dim = c->desc.dim;
+    if (c->np2) {
+        // the reference's float32-image flow exists for the default solve only: dim = 2, one Jacobi sweep without a
+        // tolerance, anisotropic shrinkage, scalar omega and ell (mu: scalar or array), state as uploaded
+        DXH_REQUIRE(dim == 2 && c->g.n2 >= 1 && c->g.n2 <= 4, "numpy2 promotion: dim = 2 with 1..4 channels only");
+        DXH_REQUIRE(jacobi_maxiter == 1 && !use_tol && !c->solver, "numpy2 promotion: Jacobi(maxiter=1) without tolerance only");
+        DXH_REQUIRE(!iso, "numpy2 promotion: anisotropic shrinkage only (the reference's isotropic branch is float64-only)");
+        DXH_REQUIRE(!c->from_db && !c->explicit_db && !(flags & DXH_FLAG_EXPLICIT), "numpy2 promotion: no explicit split variables");
+        DXH_REQUIRE(!c->het || (c->het_cdiag && c->cp_kq), "numpy2 promotion: omega and ell must be scalars");
+    }
     if (c->solver) {
         // Solver.update_params(mass_coeff=omega, diffusion_coeff=ell) (split_bregman_tvd.py:63-67, 154-158)
         if (c->solver_kind == DXH_SOLVER_MG)
@@ -916,7 +982,7 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
     if (!async) DXH_HIP(hipEventRecord(c->ev0, c->stream));
     for (int it = 0; it < n_iter; ++it) {
         const int in = c->cur, out = c->cur ^ 1;
-        if (fused_ok && !c->from_db && use_eps && dpp && multi_supported(c) && pick_k(c, n_iter - it) >= 2) {
+        if (!c->np2 && fused_ok && !c->from_db && use_eps && dpp && multi_supported(c) && pick_k(c, n_iter - it) >= 2) {
             // eps with temporal blocking: one launch does K iterations and also reduces every iteration's
             // squared increment; if the test fires at an inner iteration j, the K-iteration result is
             // discarded (the input buffers still hold iteration `it`) and exactly j+1 iterations are redone
@@ -958,6 +1024,14 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
                 c->cur = a_in;  // the buffer written last
             }
             break;
+        } else if (c->np2) {
+            if constexpr (std::is_same<T, double>::value) {
+                int rc = launch_np2(c, in, out);
+                if (rc) return rc;
+            }
+            c->np2_first = false;
+            ++launches;
+            c->cur = out;
         } else if (fused_ok && !c->from_db) {
             // temporal blocking: fuse_k iterations per launch while enough iterations remain and no
             // per-iteration host test is requested
@@ -1233,6 +1307,7 @@ static int run_slab_t(Ctx* c, int n_iter, int m, double eps, uint32_t flags, dxh
                           !c->solver && !c->explicit_db && !c->from_db;
     const bool overlap = dist && fused_ok && !(flags & DXH_FLAG_NO_OVERLAP);
     const bool async = (flags & DXH_FLAG_ASYNC) && !use_eps;
+    DXH_REQUIRE(!c->np2, "numpy2 promotion is not available on row slabs");
     if (dist) DXH_REQUIRE(c->halo_top >= m, "halos of %lld rows cannot carry an iteration of %d Jacobi sweeps",
                           (long long)c->halo_top, m);
     if (dist && c->from_db) { set_error("a warm start with explicit split variables is not supported on row slabs"); return DXH_ESTATE; }
@@ -1622,6 +1697,11 @@ int dxh_tvd_set_coeffs(dxh_tvd_t h, double mu, const void* mu_arr, double omega,
     rc = c->desc.dtype == DXH_F32 ? set_coeffs_t<float>(c, mu, mu_arr, omega, omega_arr, has_ell, ell, ell_arr, 1.0, true)
                                   : set_coeffs_t<double>(c, mu, mu_arr, omega, omega_arr, has_ell, ell, ell_arr, 1.0, true);
     if (rc) return rc;
+    if (c->np2 && c->np2_mu_is_kq && mu_arr && c->cp_kq) {
+        // the caller formed mu / ell in the array's own float32 (what NumPy does for a float32 mu) and widened it
+        DXH_HIP(hipMemcpyAsync(c->cp_kq, c->in_mu, c->plane_bytes, hipMemcpyDeviceToDevice, c->stream));
+        DXH_HIP(hipStreamSynchronize(c->stream));
+    }
     // omega array: kept as a plane, upload multiplies it into the image
     if (omega_arr) {
         if ((rc = alloc_plane(c, &c->om_plane))) return rc;
@@ -1698,10 +1778,15 @@ static int finish_upload(Ctx* c, const void* u0, const void* d0, const void* b0,
     if (f32)
         hipLaunchKernelGGL((k_scale<float>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const float*)c->u[0],
                            (float)c->omega_s, om_arr ? (const float*)c->om_plane : nullptr, (float*)c->of);
+    else if (c->np2)   // np.multiply(omega, img) on the float32 image: a float32 product, kept in the float64 plane
+        hipLaunchKernelGGL(k_scale_np2, elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const double*)c->u[0],
+                           (float)c->omega_s, (double*)c->of);
     else
         hipLaunchKernelGGL((k_scale<double>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const double*)c->u[0],
                            c->omega_s, om_arr ? (const double*)c->om_plane : nullptr, (double*)c->of);
     DXH_HIP(hipGetLastError());
+    c->np2_first = true;
+    if (c->np2) DXH_REQUIRE(!u0 && !d0 && !om_arr, "numpy2 promotion: no warm start, scalar omega");
     if (u0 && (rc = h2d_plane(c, c->u[0], u0))) return rc;
     if (!c->pristine) {   // a fresh context's planes were cleared when they were allocated
         for (int j = 0; j < dim; ++j) {
@@ -2369,6 +2454,70 @@ int dxh_tvd_adapt_ell(dxh_tvd_t h) {
     else     { if (c->desc.dim == 2) DXH_AD(double, 2); else DXH_AD(double, 3); }
 #undef DXH_AD
     DXH_HIP(hipGetLastError());
+    return DXH_OK;
+}
+
+int dxh_tvd_set_promotion(dxh_tvd_t h, int mode) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    DXH_REQUIRE(c, "null context");
+    DXH_REQUIRE(mode == DXH_PROMOTION_NATIVE || mode == DXH_PROMOTION_NUMPY2 || mode == (DXH_PROMOTION_NUMPY2 | DXH_PROMOTION_MU_IS_THRESHOLD),
+                "unknown promotion mode %d", mode);
+    if (mode != DXH_PROMOTION_NATIVE)
+        DXH_REQUIRE(c->desc.dtype == DXH_F64 && c->desc.dim == 2, "numpy2 promotion needs a float64 context with dim = 2 (it holds the "
+                    "reference's float64 iterate of a float32 image)");
+    c->np2 = (mode & DXH_PROMOTION_NUMPY2) != 0;
+    c->np2_mu_is_kq = (mode & DXH_PROMOTION_MU_IS_THRESHOLD) != 0;
+    c->uploaded = false;
+    c->have_coefs = false;
+    return DXH_OK;
+}
+
+// image of another float type than the context's: converted on the device (float32 -> float64 is exact; the other way
+// rounds to nearest like ndarray.astype)
+int dxh_tvd_upload_typed(dxh_tvd_t h, const void* img, int img_dtype) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    DXH_REQUIRE(c && img, "null argument");
+    DXH_REQUIRE(img_dtype == DXH_F32 || img_dtype == DXH_F64, "image dtype must be float32 or float64");
+    if (img_dtype == c->desc.dtype) return dxh_tvd_upload(h, img, nullptr, nullptr, nullptr);
+    int rc = set_device(c);
+    if (rc) return rc;
+    const size_t n = (size_t)c->g.n0 * (size_t)c->g.L, ssz = img_dtype == DXH_F32 ? 4 : 8;
+    DevTmp raw, conv;
+    const void* src = img;
+    if (!is_device_ptr(src)) {
+        DXH_HIP(hipMalloc(&raw.p, n * ssz));
+        DXH_HIP(hipMemcpyAsync(raw.p, src, n * ssz, hipMemcpyDefault, c->stream));
+        src = raw.p;
+    }
+    DXH_HIP(hipMalloc(&conv.p, n * c->esz));
+    const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
+    if (img_dtype == DXH_F64) hipLaunchKernelGGL((k_convert_dense<double, float>), grid, blk, 0, c->stream, (const double*)src, (float*)conv.p, n);
+    else hipLaunchKernelGGL((k_convert_dense<float, double>), grid, blk, 0, c->stream, (const float*)src, (double*)conv.p, n);
+    DXH_HIP(hipGetLastError());
+    rc = dxh_tvd_upload(h, conv.p, nullptr, nullptr, nullptr);
+    (void)hipStreamSynchronize(c->stream);
+    return rc;
+}
+
+int dxh_tvd_download_typed(dxh_tvd_t h, void* u, int out_dtype) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    DXH_REQUIRE(c && u, "null argument");
+    DXH_REQUIRE(out_dtype == DXH_F32 || out_dtype == DXH_F64, "output dtype must be float32 or float64");
+    if (out_dtype == c->desc.dtype) return dxh_tvd_download(h, u, nullptr, nullptr);
+    if (!c->uploaded) { set_error("nothing to download"); return DXH_ESTATE; }
+    int rc = set_device(c);
+    if (rc) return rc;
+    const size_t n = (size_t)c->g.n0 * (size_t)c->g.L, osz = out_dtype == DXH_F32 ? 4 : 8;
+    DevTmp dense, conv;
+    DXH_HIP(hipMalloc(&dense.p, n * c->esz));
+    DXH_HIP(hipMalloc(&conv.p, n * osz));
+    if ((rc = dxh_tvd_download(h, dense.p, nullptr, nullptr))) return rc;   // pitched plane -> dense, inside HBM
+    const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
+    if (out_dtype == DXH_F32) hipLaunchKernelGGL((k_convert_dense<double, float>), grid, blk, 0, c->stream, (const double*)dense.p, (float*)conv.p, n);
+    else hipLaunchKernelGGL((k_convert_dense<float, double>), grid, blk, 0, c->stream, (const float*)dense.p, (double*)conv.p, n);
+    DXH_HIP(hipGetLastError());
+    DXH_HIP(hipMemcpyAsync(u, conv.p, n * osz, hipMemcpyDefault, c->stream));
+    DXH_HIP(hipStreamSynchronize(c->stream));
     return DXH_OK;
 }
 

@@ -10,9 +10,15 @@ Divergences from the reference, all deliberate:
 
 * ``solver=None`` creates a fresh ``Jacobi()`` per call instead of sharing one
   def-time instance whose cached diagonal never updates (quirks Q1, Q3);
-* arithmetic stays in the image dtype; the reference's float32 run promotes the
-  Jacobi iterate to float64 under NumPy >= 2 (results agree to ~1e-6 relative,
-  tests/test_tvd_gpu.py states the tolerance);
+* by default arithmetic stays in the image dtype; the reference's float32 run promotes the
+  Jacobi iterate to float64 under NumPy >= 2 (jacobi.py:101-114).  For ``ell = 2 mu`` (this
+  function's default) the two agree to ~2e-7 after 100 iterations; for ``ell >= 0.5`` the float32
+  flow drifts to ~3e-5 after 100 iterations, past rtol 1e-4 on small values.  ``promotion="numpy2"``
+  (an extra keyword; also ``DXH_PROMOTION=numpy2``) reproduces the reference's mixed float32 /
+  float64 flow BIT FOR BIT (``k_fused_np2``), at ~1 ms instead of ~0.15 ms per iteration on
+  4000 x 8000 x 3.  It is chosen automatically when a float32 image meets a float64 weight array --
+  the workflow's default (presets/workflows/restoration.py:117-148) -- because there the caller
+  handed over float64 data and the reference computes the threshold in it;
 * the isotropic variant also accepts float32 and colour images (the reference's
   numba kernel is float64 / 2-D only);
 * float images only (integer images silently break the reference, quirk Q5).
@@ -20,6 +26,8 @@ Divergences from the reference, all deliberate:
 from __future__ import annotations
 
 import ctypes as C
+import logging
+import os
 import threading
 from typing import Optional, Union
 
@@ -31,6 +39,8 @@ from ..utils.linear_solvers.cg import CG
 from ..utils.linear_solvers.jacobi import Jacobi
 from ..utils.linear_solvers.mg import MG
 from ..utils.linear_solvers.solver import Solver
+
+logger = logging.getLogger(__name__)
 
 
 def _coef(value, img, name: str, keep_float_type: bool = False):
@@ -58,24 +68,34 @@ class DeviceTVD:
     image (multi-GPU decomposition, ``darsia_amd.parallel``)."""
 
     def __init__(self, shape, dtype, dim: int = 2, device: Optional[int] = None, nsum: int = _lib.NSUM_ALL_AXES,
-                 row_slab=(True, True), stream: Optional[int] = None):
+                 row_slab=(True, True), stream: Optional[int] = None, promotion: str = "native"):
         self.lib = _lib.load()
         _lib.require_gpu()
         self.shape = tuple(int(s) for s in shape)
-        self.dtype = np.dtype(dtype)
+        self.dtype = np.dtype(dtype)          # the image's dtype: what upload takes and download returns
+        if promotion not in ("native", "numpy2"):
+            raise ValueError(f"promotion must be 'native' or 'numpy2', not {promotion!r}")
+        self.numpy2 = promotion == "numpy2"
+        if self.numpy2 and self.dtype != np.float32:
+            raise ValueError("promotion='numpy2' is the reference's flow for float32 images (float64 images run natively "
+                             "and match the reference bit for bit as they are)")
+        self.ctx_dtype = np.dtype(np.float64) if self.numpy2 else self.dtype
         self.dim = dim
         ndim, n0, n1, n2 = _lib.shape3(self.shape, dim)
         d = _lib.TvdDesc()
         d.struct_size = C.sizeof(_lib.TvdDesc)
         d.device = _lib.default_device() if device is None else device
         self.device = int(d.device)
-        d.dtype = _lib.dtype_code(self.dtype)
+        d.dtype = _lib.dtype_code(self.ctx_dtype)
         d.ndim, d.dim, d.nsum = ndim, dim, nsum
         d.n0, d.n1, d.n2 = n0, n1, n2
         d.top_is_boundary, d.bottom_is_boundary = int(row_slab[0]), int(row_slab[1])
         d.stream = stream
         self._h = C.c_void_p()
         _lib.check(self.lib.dxh_tvd_create(C.byref(self._h), C.byref(d)))
+        self._promotion_mode = _lib.PROMOTION_NUMPY2 if self.numpy2 else 0
+        if self.numpy2:
+            _lib.check(self.lib.dxh_tvd_set_promotion(self._h, self._promotion_mode))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -91,6 +111,8 @@ class DeviceTVD:
         self.close()
 
     def set_coeffs(self, mu, omega, ell, like: np.ndarray):
+        if self.numpy2:
+            return self._set_coeffs_numpy2(mu, omega, ell, like)
         mu_s, mu_a = _coef(mu, like, "mu", True)
         om_s, om_a = _coef(omega, like, "omega", True)
         if ell is None:
@@ -102,7 +124,39 @@ class DeviceTVD:
         _lib.check(self.lib.dxh_tvd_set_coeffs_typed(self._h, mu_s, _lib.ptr(mu_a), code(mu_a), om_s, _lib.ptr(om_a),
                                                       code(om_a), has_ell, ell_s, _lib.ptr(ell_a), code(ell_a)))
 
+    def _set_coeffs_numpy2(self, mu, omega, ell, like):
+        """Scalar omega and ell; mu a scalar or an array.  A float64 mu array is divided by ell on the device in float64
+        (``mu / ell``, split_bregman_tvd.py:144: float64 array / Python float); a float32 one the way NumPy does it -- the
+        quotient in float32 -- here, and handed over as the threshold itself."""
+        if np.ndim(omega) != 0 or (ell is not None and np.ndim(ell) != 0):
+            raise NotImplementedError("promotion='numpy2': omega and ell must be scalars")
+        mu_s, mu_a = _coef(mu, like, "mu", True)
+        if mu_a is not None and ell is None:
+            raise NotImplementedError("promotion='numpy2': an array-valued mu needs a scalar ell (ell = 2 mu would be an array)")
+        if isinstance(mu_a, DeviceArray):
+            raise NotImplementedError("promotion='numpy2': device-resident coefficient arrays are not supported")
+        mode = _lib.PROMOTION_NUMPY2
+        if mu_a is not None and mu_a.dtype == np.float32:
+            mu_a = (mu_a / float(ell)).astype(np.float64)      # float32 array / Python float -> float32 quotient, widened
+            mode |= _lib.PROMOTION_MU_IS_THRESHOLD
+        if mode != self._promotion_mode:
+            _lib.check(self.lib.dxh_tvd_set_promotion(self._h, mode))
+            self._promotion_mode = mode
+        has_ell, ell_s = (0, 0.0) if ell is None else (1, float(ell))
+        f64 = _lib.dtype_code(np.dtype(np.float64))
+        _lib.check(self.lib.dxh_tvd_set_coeffs_typed(self._h, mu_s, _lib.ptr(mu_a), f64, float(omega), None, f64, has_ell,
+                                                      ell_s, None, f64))
+
     def upload(self, img, u0=None, d0=None, b0=None):
+        if self.numpy2:
+            if u0 is not None or d0 is not None or b0 is not None:
+                raise NotImplementedError("promotion='numpy2': no warm start")
+            if not isinstance(img, DeviceArray):
+                img = np.ascontiguousarray(img, dtype=self.dtype)
+            assert tuple(img.shape) == self.shape and img.dtype == self.dtype
+            _lib.check(self.lib.dxh_tvd_upload_typed(self._h, _lib.ptr(img), _lib.dtype_code(self.dtype)))
+            return
+
         def c(a):
             if a is None or isinstance(a, DeviceArray):
                 if a is not None and a.dtype != self.dtype:
@@ -151,6 +205,12 @@ class DeviceTVD:
         u = np.empty(self.shape, self.dtype) if out is None else out
         assert tuple(u.shape) == self.shape and u.dtype == self.dtype
         assert isinstance(u, DeviceArray) or u.flags.c_contiguous
+        if self.numpy2:
+            if want_split:
+                raise NotImplementedError("promotion='numpy2': the split variables are not downloadable")
+            # convert_dtype(img_iter, float32) (split_bregman_tvd.py:177): the float64 iterate rounded to float32
+            _lib.check(self.lib.dxh_tvd_download_typed(self._h, _lib.ptr(u), _lib.dtype_code(self.dtype)))
+            return u
         if not want_split:
             _lib.check(self.lib.dxh_tvd_download(self._h, _lib.ptr(u), None, None))
             return u
@@ -186,6 +246,27 @@ def solve_banded(img: np.ndarray, mu, omega, ell, n_iter: int, jacobi_maxiter: i
     return (out, used.value) if return_bands else out
 
 
+def numpy2_unsupported(img, mu, omega, ell, dim, x0, isotropic, solver, adaptive, quiet) -> Optional[str]:
+    """None when the reference's NumPy >= 2 flow for a float32 image exists on the device for this call, else why not."""
+    if img.dtype != np.float32:
+        return "the image is not float32"
+    if dim != 2 or img.ndim not in (2, 3) or (img.ndim == 3 and img.shape[2] > 4):
+        return "dim = 2 with at most 4 channels only"
+    if np.ndim(omega) != 0 or (ell is not None and np.ndim(ell) != 0):
+        return "omega and ell must be scalars"
+    if np.ndim(mu) != 0 and ell is None:
+        return "an array-valued mu needs a scalar ell"
+    if isinstance(mu, DeviceArray):
+        return "device-resident coefficient arrays"
+    if x0 is not None or adaptive is not None or not quiet:
+        return "no warm start, adaptive schedule or verbose mode"
+    if isotropic:
+        return "anisotropic only (the reference's isotropic branch is float64-only)"
+    if not isinstance(solver, Jacobi) or solver.maxiter != 1 or solver.tol is not None:
+        return "Jacobi(maxiter=1) without tolerance only"
+    return None
+
+
 def split_bregman_tvd(
     img: np.ndarray,
     mu: Union[float, np.ndarray] = 1.0,
@@ -199,12 +280,18 @@ def split_bregman_tvd(
     verbose: Union[bool, int] = False,
     solver: Optional[Solver] = None,
     adaptive=None,
+    promotion: Optional[str] = None,
 ) -> np.ndarray:
     """Split Bregman algorithm for TV denoising (split_bregman_tvd.py:14-177).
 
     Args: exactly those of ``darsia.split_bregman_tvd``.  ``x0 = (img0, d0, b0)``
     with ``d0``/``b0`` of shape ``(*img.shape, dim)``; as in the reference they are
     updated in place with the final split variables.
+
+    ``promotion`` (extension, see the module docstring): ``"native"`` -- arithmetic in the image dtype;
+    ``"numpy2"`` -- the reference's own mixed flow for float32 images, bit for bit; ``None`` -- ``DXH_PROMOTION`` if
+    set, else ``"numpy2"`` exactly when a float32 image comes with a float64 coefficient array and the configuration
+    has that flow (``numpy2_supported``), ``"native"`` otherwise.
 
     Returns:
         array: denoised image, same dtype as ``img``.
@@ -235,6 +322,27 @@ def split_bregman_tvd(
                 raise ValueError(f"{name} must have shape (*img.shape, dim) = {img.shape + (dim,)}")
 
     quiet = not (verbose if isinstance(verbose, bool) else verbose > 0)
+    why_not = numpy2_unsupported(img, mu, omega, ell, dim, x0, isotropic, solver, adaptive, quiet)
+    if promotion is None:
+        promotion = os.environ.get("DXH_PROMOTION") or None
+        if promotion is None:
+            mixed = img.dtype == np.float32 and any(isinstance(c, np.ndarray) and c.ndim > 0 and c.dtype == np.float64
+                                                    for c in (mu, omega, ell))
+            promotion = "numpy2" if (mixed and why_not is None) else "native"
+            if mixed and why_not is not None:
+                logger.info("float32 image with float64 coefficients: native float32 flow (%s)", why_not)
+        elif promotion == "numpy2" and why_not is not None:
+            promotion = "native"    # the environment variable asks for it wherever it exists
+    if promotion not in ("native", "numpy2"):
+        raise ValueError(f"promotion must be None, 'native' or 'numpy2', not {promotion!r}")
+    if promotion == "numpy2":
+        if why_not is not None:
+            raise NotImplementedError(f"promotion='numpy2': {why_not}")
+        with DeviceTVD(img.shape, img.dtype, dim=dim, device=img.device if on_device else None, promotion="numpy2") as st:
+            st.set_coeffs(mu, omega, ell, img)
+            st.upload(img)
+            st.run(max_num_iter, 1, None, eps=eps)
+            return st.download(out=DeviceArray(img.shape, img.dtype, img.device) if on_device else None)
     if (not on_device and x0 is None and eps is None and adaptive is None and quiet and dim == 2 and img.ndim in (2, 3)
             and isinstance(solver, Jacobi) and solver.tol is None and solver.maxiter >= 1 and max_num_iter >= 1
             and img.nbytes >= (32 << 20)):

@@ -273,6 +273,27 @@ int dxh_tvd_exchange(dxh_tvd_t ctx);
 int dxh_tvd_run_slab(dxh_tvd_t ctx, int n_iter, int jacobi_maxiter, double eps, uint32_t flags, dxh_tvd_result* result);
 
 /*
+ * The reference's own dtype flow for a FLOAT32 image under NumPy >= 2 ("numpy2" promotion).  With scalar omega / ell the
+ * reference iterates u in float64 (utils/linear_solvers/jacobi.py:101-114: const_diag_scaled is an np.float64) while d,
+ * b and the right-hand side stay float32 (restoration/split_bregman_tvd.py:84-89,99-101,129-146); a float64 weight map
+ * next to a float32 image -- what presets/workflows/restoration.py:117-148 builds -- also makes the shrinkage threshold a
+ * float64 array.  The native float32 flow of this library stays within the north-star tolerance of that (rtol 1e-4) for
+ * ell = 2 mu but drifts past it for ell >= 0.5 after ~100 iterations; this mode reproduces the reference bit for bit.
+ * Use: create the context with dtype DXH_F64, call dxh_tvd_set_promotion(ctx, DXH_PROMOTION_NUMPY2) BEFORE
+ * dxh_tvd_set_coeffs, upload the float32 image with dxh_tvd_upload_typed, run with dxh_tvd_run (dim = 2,
+ * jacobi_maxiter = 1, no tolerance, anisotropic, scalar omega and ell; mu scalar or a float64 array), fetch the float32
+ * result with dxh_tvd_download_typed (convert_dtype(img_iter, float32), split_bregman_tvd.py:177).
+ * DXH_PROMOTION_MU_IS_THRESHOLD: the mu array passed to dxh_tvd_set_coeffs already holds mu / ell (a float32 mu array:
+ * NumPy forms the quotient in float32 before it meets the float64 iterate; the caller does that and widens).
+ */
+#define DXH_PROMOTION_NATIVE 0
+#define DXH_PROMOTION_NUMPY2 1
+#define DXH_PROMOTION_MU_IS_THRESHOLD 2
+int dxh_tvd_set_promotion(dxh_tvd_t ctx, int mode);
+int dxh_tvd_upload_typed(dxh_tvd_t ctx, const void* img, int img_dtype);
+int dxh_tvd_download_typed(dxh_tvd_t ctx, void* u, int out_dtype);
+
+/*
  * Where the time of a slab context went (diagnostics; no reference counterpart).  Every exchange is bracketed by three
  * events on the stream it runs on: wait_signal_ms sums the time that stream idled until the interface waves of the
  * signalling launch had released their rows (0 for exchanges in plain stream order), exchange_ms the time from there to

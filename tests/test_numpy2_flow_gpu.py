@@ -1,0 +1,178 @@
+"""The reference's own dtype flow for float32 images on the device (``promotion="numpy2"``, ``k_fused_np2``): u in
+float64, d / b / right-hand side in float32, the shrinkage threshold a Python float or a float64 array
+(restoration/split_bregman_tvd.py:84-101,129-146; utils/linear_solvers/jacobi.py:101-114 under NumPy >= 2).
+
+Bar: BIT-EXACT against vectors produced by executing the reference (tests/golden/tvd_golden.npz float32 cases,
+tests/golden/tvd_mixed_golden.npz: float32 image x float64 weight map, the workflow's default) -- the same bar the
+float64 path has always had.  The native float32 flow is checked against the same vectors at the north-star
+tolerance where it holds."""
+import os
+
+import numpy as np
+import pytest
+
+import darsia_amd as da
+from oracle import tvd_numpy as O
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RTOL, ATOL = 1e-4, 1e-6
+
+
+@pytest.fixture(scope="module")
+def mixed():
+    return np.load(os.path.join(ROOT, "tests", "golden", "tvd_mixed_golden.npz"), allow_pickle=False)
+
+
+def bits(a, b):
+    assert a.dtype == b.dtype and a.shape == b.shape
+    if not np.array_equal(a, b):
+        d = np.abs(a.astype(np.float64) - b)
+        raise AssertionError(f"not bit-exact: {np.count_nonzero(d)} of {d.size} differ, max abs {d.max():.3e}")
+
+
+SCALAR = [
+    ("g2_aniso2d_f32", dict(mu=0.1), 20),
+    ("g3_aniso_rgb_f32", dict(mu=0.1), 10),
+    ("g3_aniso_rgb_odd_f32", dict(mu=0.15, omega=0.7), 7),
+    ("g3_aniso_2ch_odd_f32", dict(mu=0.1), 6),
+    ("g2_aniso2d_odd_f32", dict(mu=0.2, ell=0.3), 9),
+    ("g2_tiny_f32", dict(mu=0.1), 4),
+    ("g2_tiny_col_f32", dict(mu=0.1), 4),
+    ("g2_single_px_f32", dict(mu=0.1), 3),
+]
+
+
+@pytest.mark.parametrize("name,kw,n", SCALAR, ids=[c[0] for c in SCALAR])
+def test_float32_goldens_of_the_reference_bit_for_bit(golden, name, kw, n):
+    img = golden[name + "/img"]
+    assert img.dtype == np.float32
+    bits(da.split_bregman_tvd(img, max_num_iter=n, promotion="numpy2", **kw), golden[name + "/out"])
+
+
+def test_stop_iteration_and_operator_call(golden):
+    for name, eps in (("g7_eps_f32", 1e-3), ("g7_eps_rgb_f32", 2e-3)):
+        img = golden[name + "/img"]
+        ref, _, _, done = O.split_bregman_tvd(img, mu=0.1, max_num_iter=100, eps=eps, return_state=True)
+        assert done == int(golden[name + "/iters"])
+        bits(da.split_bregman_tvd(img, mu=0.1, max_num_iter=100, eps=eps, promotion="numpy2"), golden[name + "/out"])
+    # TVD("heterogeneous bregman") with its regularization default of 1.0 (restoration/tvd.py:37,103-112)
+    img = golden["g13_tvd_call/img"]
+    op = da.TVD(method="heterogeneous bregman", weight=0.1, max_num_iter=6, eps=None, promotion="numpy2")
+    bits(op(img), golden["g13_tvd_call/out"])
+    # the 512 x 512 plumbing case of BASELINE configs[0] in float32: crop of the reference's result
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_golden import noisy_blocks  # pure NumPy helper (nothing of the reference is touched at import)
+    big32 = noisy_blocks((512, 512), 12, np.float64).astype(np.float32)
+    res = da.split_bregman_tvd(big32, mu=0.1, max_num_iter=20, promotion="numpy2")
+    bits(res[248:264, 248:264], golden["g12_512/crop_mid_f32"])
+    assert float(res.astype(np.float64).sum()) == float(golden["g12_512/sum_f32"])
+
+
+MIXED = {
+    "m1_gray_ell1": dict(ell=1.0, max_num_iter=20),
+    "m2_gray_ell02": dict(ell=0.2, omega=0.8, max_num_iter=20),
+    "m4_rgb_ell02": dict(ell=0.2, max_num_iter=20),
+    "m6_gray_ell1_100": dict(ell=1.0, max_num_iter=100),
+    "m8_tvd_operator": dict(ell=1.0, max_num_iter=20),
+}
+
+
+@pytest.mark.parametrize("name", list(MIXED))
+def test_float32_image_with_float64_weights_bit_for_bit(mixed, name):
+    """The DEFAULT call (no promotion keyword): a float32 image with a float64 mu array takes the reference's flow."""
+    img, mu, ref = mixed[name + "/img"], mixed[name + "/mu"], mixed[name + "/out"]
+    bits(da.split_bregman_tvd(img, mu=mu, **MIXED[name]), ref)
+    # device-resident image in, device-resident result out
+    d = da.split_bregman_tvd(da.DeviceArray.from_host(img), mu=mu, **MIXED[name])
+    assert isinstance(d, da.DeviceArray) and d.dtype == np.float32
+    bits(d.get(), ref)
+
+
+def test_native_flow_on_the_same_vectors_at_the_north_star_tolerance(mixed):
+    for name in ("m1_gray_ell1", "m2_gray_ell02", "m4_rgb_ell02", "m8_tvd_operator"):
+        img, mu, ref = mixed[name + "/img"], mixed[name + "/mu"], mixed[name + "/out"]
+        got = da.split_bregman_tvd(img, mu=mu, promotion="native", **MIXED[name])
+        np.testing.assert_allclose(got, ref, rtol=RTOL, atol=ATOL)
+        # ... and it is the oracle's float32 ("strict") flow bit for bit, with the weights rounded to float32 first
+        bits(got, O.split_bregman_tvd(img, mu=mu, promotion="strict", **MIXED[name]))
+    # ell = None makes ell = 2 mu a float64 ARRAY: no numpy2 pipeline for that, the default call runs natively -- and
+    # agrees with the reference to 2e-7 (ell = 2 mu is the benign regime)
+    for name in ("m3_gray_ellnone", "m5_rgb_ellnone"):
+        got = da.split_bregman_tvd(mixed[name + "/img"], mu=mixed[name + "/mu"], max_num_iter=20)
+        np.testing.assert_allclose(got, mixed[name + "/out"], rtol=RTOL, atol=ATOL)
+        assert np.abs(got - mixed[name + "/out"]).max() < 1e-6
+
+
+def test_stop_iteration_on_the_mixed_flow(mixed):
+    img, mu = mixed["m7_gray_eps/img"], mixed["m7_gray_eps/mu"]
+    bits(da.split_bregman_tvd(img, mu=mu, ell=0.2, omega=0.8, max_num_iter=200, eps=2e-3), mixed["m7_gray_eps/out"])
+    with da.DeviceTVD(img.shape, img.dtype, promotion="numpy2") as st:
+        st.set_coeffs(mu, 0.8, 0.2, img)
+        st.upload(img)
+        res = st.run(200, eps=2e-3)
+        assert res.converged == 1 and res.iters_done == int(mixed["m7_gray_eps/iters"])
+
+
+def test_operator_from_build_restoration_on_a_float32_image(mixed):
+    """presets/workflows/restoration.py:117-148: porosity weights arrive as a float64 array, the image as float32."""
+    from types import SimpleNamespace
+
+    from darsia_amd.presets.workflows import build_restoration
+    from darsia_amd.presets.workflows.config import RestorationConfig
+
+    img, mu, ref = mixed["m8_tvd_operator/img"], mixed["m8_tvd_operator/mu"], mixed["m8_tvd_operator/out"]
+    rig = SimpleNamespace(baseline=da.ScalarImage(np.zeros(img.shape)), image_porosity=da.ScalarImage(mu),
+                          boolean_porosity=da.ScalarImage(mu > 0))
+    cfg = RestorationConfig().load({"method": "tvd", "options": {"weight": "image_porosity", "max_num_iter": 20,
+                                                                 "eps": 1e-30, "omega": 1.0, "regularization": 1.0}})
+    op = build_restoration(cfg, rig)
+    assert op.method == "heterogeneous bregman" and op.weight.dtype == np.float64
+    bits(op(img), ref)
+    out_img = op(da.ScalarImage(img))
+    bits(out_img.img, ref)
+
+
+def test_float32_mu_array_and_windows_at_100_iterations():
+    """(a) an explicit numpy2 call with a float32 mu array: NumPy forms mu / ell in float32 before it meets the float64
+    iterate; (b) 512 x 512 windows of a larger image after 100 iterations at ell = 1.0 -- the regime where the native flow
+    leaves the tolerance -- bit for bit against the oracle's reference flow (dependence cone: tests/test_tvd_gpu.py)."""
+    rng = np.random.default_rng(17)
+    img = rng.random((90, 130)).astype(np.float32)
+    mu32 = (0.02 + 0.1 * rng.random(img.shape)).astype(np.float32)
+    bits(da.split_bregman_tvd(img, mu=mu32, ell=0.7, omega=1.2, max_num_iter=15, promotion="numpy2"),
+         O.split_bregman_tvd(img, mu=mu32, ell=0.7, omega=1.2, max_num_iter=15))
+    from darsia_amd.synthetic import synthetic_image
+
+    H, W, n, m, S = 1500, 2100, 100, 102, 512
+    big = synthetic_image(H, W, 1)
+    por = 0.3 + 0.7 * np.random.default_rng(4).random((H, W))
+    por[400:700, 300:900] = 0.0
+    mu = 0.1 * por
+    out = da.split_bregman_tvd(big, mu=mu, ell=1.0, max_num_iter=n)
+    assert out.dtype == np.float32
+    worst_native = 0.0
+    native = da.split_bregman_tvd(big, mu=mu, ell=1.0, max_num_iter=n, promotion="native")
+    for (r0, c0) in ((0, 0), (300, 500), (H - S, W - S)):
+        ra, rb = (0 if r0 == 0 else m), (S if r0 + S == H else S - m)
+        ca, cb = (0 if c0 == 0 else m), (S if c0 + S == W else S - m)
+        want = O.split_bregman_tvd(np.ascontiguousarray(big[r0:r0 + S, c0:c0 + S]), mu=np.ascontiguousarray(mu[r0:r0 + S, c0:c0 + S]),
+                                   ell=1.0, max_num_iter=n)[ra:rb, ca:cb]
+        bits(out[r0 + ra:r0 + rb, c0 + ca:c0 + cb], want)
+        nat = native[r0 + ra:r0 + rb, c0 + ca:c0 + cb]
+        worst_native = max(worst_native, float((np.abs(nat.astype(np.float64) - want) / (ATOL + RTOL * np.abs(want))).max()))
+    print(f"native float32 flow after {n} iterations at ell = 1.0: worst error / tolerance = {worst_native:.2f}")
+
+
+def test_unsupported_configurations_say_so():
+    img = np.random.default_rng(1).random((20, 30)).astype(np.float32)
+    with pytest.raises(NotImplementedError, match="numpy2"):
+        da.split_bregman_tvd(img, mu=0.1, isotropic=True, promotion="numpy2")
+    with pytest.raises(NotImplementedError, match="numpy2"):
+        da.split_bregman_tvd(img, mu=0.1, solver=da.Jacobi(maxiter=3), promotion="numpy2")
+    with pytest.raises(NotImplementedError, match="numpy2"):
+        da.split_bregman_tvd(img.astype(np.float64), mu=0.1, promotion="numpy2")
+    with pytest.raises(ValueError):
+        da.split_bregman_tvd(img, mu=0.1, promotion="float16")

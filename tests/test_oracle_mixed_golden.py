@@ -1,0 +1,60 @@
+"""The NumPy oracle against the reference's own outputs for the MIXED-dtype heterogeneous flow: float32 image x float64
+weight map (tests/golden/make_golden_mixed.py; reference: presets/workflows/restoration.py:117-148,
+restoration/split_bregman_tvd.py:58-101).  Bit for bit, incl. ``ell = 2 mu`` as a float64 ARRAY, whose in-place
+right-hand-side accumulation (split_bregman_tvd.py:84-89) keeps float32 -- a case this golden corrected in the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import tvd_numpy as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CASES = {
+    "m1_gray_ell1": dict(ell=1.0, max_num_iter=20),
+    "m2_gray_ell02": dict(ell=0.2, omega=0.8, max_num_iter=20),
+    "m3_gray_ellnone": dict(max_num_iter=20),
+    "m4_rgb_ell02": dict(ell=0.2, max_num_iter=20),
+    "m5_rgb_ellnone": dict(max_num_iter=20),
+    "m6_gray_ell1_100": dict(ell=1.0, max_num_iter=100),
+    "m8_tvd_operator": dict(ell=1.0, max_num_iter=20),     # TVD's regularization default (restoration/tvd.py:37)
+}
+
+
+@pytest.fixture(scope="module")
+def mixed():
+    return np.load(os.path.join(ROOT, "tests", "golden", "tvd_mixed_golden.npz"), allow_pickle=False)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_oracle_reproduces_the_reference_bit_for_bit(mixed, name):
+    img, mu, ref = mixed[name + "/img"], mixed[name + "/mu"], mixed[name + "/out"]
+    assert img.dtype == np.float32 and mu.dtype == np.float64 and ref.dtype == np.float32
+    got = O.split_bregman_tvd(img, mu=mu, **CASES[name])
+    assert got.dtype == ref.dtype and np.array_equal(got, ref), f"max abs {np.abs(got.astype(np.float64) - ref).max():.3e}"
+
+
+def test_oracle_scalar_case_and_stop_iteration(mixed):
+    ref = mixed["m9_gray_scalar_ell1_100/out"]
+    assert np.array_equal(O.split_bregman_tvd(mixed["m9_gray_scalar_ell1_100/img"], mu=0.05, ell=1.0, max_num_iter=100), ref)
+    out, _, _, done = O.split_bregman_tvd(mixed["m7_gray_eps/img"], mu=mixed["m7_gray_eps/mu"], ell=0.2, omega=0.8,
+                                          max_num_iter=200, eps=2e-3, return_state=True)
+    assert done == int(mixed["m7_gray_eps/iters"]) and 1 < done < 200
+    assert np.array_equal(out, mixed["m7_gray_eps/out"])
+
+
+def test_native_float32_flow_against_the_reference_tolerances(mixed):
+    """What the all-float32 arithmetic of the fast device pipelines does to these cases (the oracle's "strict" flow is
+    that arithmetic, bit for bit -- tests/test_tvd_gpu.py): inside the north-star tolerance at 20 iterations and for
+    ell = 2 mu, OUTSIDE it after 100 iterations at ell = 1.0 -- which is why those calls run the numpy2 flow on the
+    device (darsia_amd/restoration/split_bregman_tvd.py)."""
+    def err_over_tol(name):
+        ref = mixed[name + "/out"]
+        got = O.split_bregman_tvd(mixed[name + "/img"], mu=mixed[name + "/mu"], promotion="strict", **CASES[name])
+        return float((np.abs(got.astype(np.float64) - ref) / (1e-6 + 1e-4 * np.abs(ref))).max())
+
+    assert err_over_tol("m1_gray_ell1") < 0.5
+    assert err_over_tol("m3_gray_ellnone") < 0.01
+    assert err_over_tol("m5_rgb_ellnone") < 0.01
+    assert err_over_tol("m6_gray_ell1_100") > 1.0
