@@ -35,7 +35,7 @@ EXPORTS = (
     "dxh_comm_unique_id", "dxh_comm_create_rccl", "dxh_comm_create_host", "dxh_comm_destroy", "dxh_comm_allreduce",
     "dxh_comm_barrier", "dxh_comm_info", "dxh_tvd_attach_comm", "dxh_tvd_exchange", "dxh_tvd_run_slab",
     "dxh_mem_alloc", "dxh_mem_free", "dxh_mem_copy", "dxh_sqrt_probe", "dxh_rcp_probe", "dxh_tvd_solve_banded", "dxh_mem_trim", "dxh_tps_eval_pair", "dxh_tvd_set_coeffs_typed", "dxh_tvd_slab_stats",
-    "dxh_tvd_set_promotion", "dxh_tvd_upload_typed", "dxh_tvd_download_typed",
+    "dxh_phase_correlation_q", "dxh_tvd_set_promotion", "dxh_tvd_upload_typed", "dxh_tvd_download_typed",
 )
 
 # host-staged transport callbacks (include/darsia_hip.h: dxh_comm_exchange_fn, dxh_comm_allreduce_fn)
@@ -153,6 +153,7 @@ def _declare(lib):
     lib.dxh_warp_patches.argtypes = [i, i, i, i, vp, vp, i, vp]
     lib.dxh_warp_patches_typed.argtypes = [i, i, i, i, i, vp, vp, i, vp]
     lib.dxh_phase_correlation.argtypes = [i, i, i, i, i, vp, vp, i, vp, dbl, vp, vp]
+    lib.dxh_phase_correlation_q.argtypes = [i, i, i, i, i, vp, vp, i, vp, dbl, dbl, vp, vp, vp]
     lib.dxh_tps_eval.argtypes = [i, i, i, vp, vp, vp, vp, vp, i64, vp, i, dbl, dbl, dbl, dbl, vp]
     lib.dxh_tps_eval_pair.argtypes = [i, i, vp, vp, vp, vp, vp, i, vp, vp, vp, vp, vp, i64, i64, dbl, dbl, dbl, dbl, dbl, dbl, vp]
     lib.dxh_affine_color.argtypes = [i, i, i64, vp, vp, vp, i, vp]

@@ -30,6 +30,8 @@ import ctypes as C
 from typing import Optional
 from warnings import warn
 
+import logging
+
 import numpy as np
 
 from . import _lib
@@ -182,6 +184,9 @@ _DIFF = {"plain": 0, "positive": 1, "negative": 2, "absolute": 3}
 _FRAME_DTYPES = {np.dtype(np.float32): _lib.DXH_F32, np.dtype(np.float64): _lib.DXH_F64, np.dtype(np.uint8): 2, np.dtype(np.uint16): 3}
 
 
+logger = logging.getLogger(__name__)
+
+
 def _float_dtype(dt) -> np.dtype:
     """The float type a probing frame is subtracted in: float frames as they are, integer frames as float64
     (concentrationanalysis.py:241-246: ``img_as(float)``)."""
@@ -190,6 +195,12 @@ def _float_dtype(dt) -> np.dtype:
 
 
 def _fingerprint(value):
+    """Identity of a host array for the device-side caches (coefficient planes of a TV context, the registration's
+    baseline): the object, its shape / dtype and the sum of a strided sample of ~4096 values.  The sample is a SAFETY NET,
+    not a guarantee: an in-place edit that misses every sampled element (a region of up to thousands of pixels on a large
+    array) or cancels in the sum goes unseen.  The contract is therefore: arrays handed to these objects are not edited in
+    place; after such an edit call ``refresh()`` (ConcentrationAnalysis, TranslationAnalysis / ImageRegistration), or pass
+    a new array.  Holders keep a reference to the array next to the mark, so ``id()`` cannot be recycled under them."""
     if isinstance(value, np.ndarray) and value.ndim > 0:
         flat = value.reshape(-1) if value.flags.c_contiguous else value.ravel()
         step = max(1, flat.size // 4096)
@@ -281,23 +292,31 @@ class ConcentrationAnalysis:
 
     # ---- fused device path ----------------------------------------------------------------------------------
     def _fusable(self, probe: np.ndarray):
-        if self.balancing is not None or self._diff_option not in _DIFF:
-            return None
+        """The fused device plan for this frame, or None -- then ``self._why_generic`` says what keeps the frame on the
+        stage-by-stage chain (host NumPy for the elementwise stages, the restoration operator on the device)."""
+        plan, self._why_generic = self._fusable_why(probe)
+        return plan
+
+    def _fusable_why(self, probe: np.ndarray):
+        if self.balancing is not None:
+            return None, "a balancing stage is set"
+        if self._diff_option not in _DIFF:
+            return None, f"difference option {self._diff_option!r} has no device stage"
         if probe.ndim == 3 and probe.shape[2] == 3:
             red = self.signal_reduction
             if not isinstance(red, MonochromaticReduction) or red.color not in MonochromaticReduction._CODES:
-                return None
+                return None, "the signal reduction is not a MonochromaticReduction the device knows"
             reduction, channels = MonochromaticReduction._CODES[red.color], 3
             if reduction == 5:
                 # cv2's gray conversion works in float32 AFTER the (possibly float64) background subtraction: the fused
                 # float32 pipeline reproduces that only when nothing in front of it is wider than float32
                 wide = _float_dtype(probe.dtype) if self.base is None else np.result_type(_float_dtype(probe.dtype), self.base.img.dtype)
                 if wide != np.float32:
-                    return None
+                    return None, "gray reduction behind a float64 difference"
         elif probe.ndim == 2 and self.signal_reduction is None:
             reduction, channels = 0, 1
         else:
-            return None
+            return None, f"frame of shape {probe.shape} with signal reduction {type(self.signal_reduction).__name__}"
         rest = self.restoration
         mode = None if rest is None else "hb"
         if isinstance(rest, TVD) and rest.method in ("chambolle", "anisotropic bregman", "isotropic bregman") and not rest.kwargs:
@@ -306,25 +325,36 @@ class ConcentrationAnalysis:
             mode, solver, iso = "op", None, False
         elif rest is not None:
             if not (isinstance(rest, TVD) and rest.method == "heterogeneous bregman"):
-                return None
+                return None, f"restoration {type(rest).__name__} is not a TVD operator"
             kw = dict(rest.kwargs)
             solver = kw.pop("solver", None)
             bad = (kw.pop("dim", 2) != 2 or kw.pop("x0", None) is not None or kw.pop("adaptive", None) is not None
                    or kw.pop("verbose", False) or (solver is not None and not isinstance(solver, Jacobi)))
             if bad:
-                return None
+                return None, "TVD keyword arguments (dim / x0 / adaptive / verbose / solver) outside the fused pipeline"
             iso = bool(kw.pop("isotropic", False))
+            kw.pop("promotion", None)
             if kw:
-                return None
+                return None, f"unknown TVD keyword arguments {sorted(kw)}"
             for coef in (rest.weight, rest.omega, rest.regularization):
                 if isinstance(coef, np.ndarray) and coef.ndim > 0 and coef.shape != probe.shape[:2]:
-                    return None
+                    return None, "coefficient array of another shape than the frame"
+            # a float32 signal with float64 weights (the workflow's porosity maps): the operator itself would run the
+            # reference's mixed dtype flow (promotion "numpy2", restoration/split_bregman_tvd.py) -- so it runs, as an
+            # operator on the device-resident signal between the two elementwise stages, instead of the context's own
+            # float32 iterations
+            from .restoration.split_bregman_tvd import choose_promotion, numpy2_unsupported
+            sig = np.empty((1, 1), self._signal_dtype(probe, reduction))
+            jac = solver if solver is not None else Jacobi()
+            why = numpy2_unsupported(sig, rest.weight, rest.omega, rest.regularization, 2, None, iso, jac, None, True)
+            if choose_promotion(rest.kwargs.get("promotion"), sig.dtype, (rest.weight, rest.omega, rest.regularization), why) == "numpy2":
+                mode = "op"
         else:
             solver, iso = None, False
         ops = _model_ops(self.model)
         if ops is None:
-            return None
-        return reduction, channels, ops, solver, iso, mode
+            return None, f"model {type(self.model).__name__} has no device stage"
+        return (reduction, channels, ops, solver, iso, mode), None
 
     def _signal_dtype(self, probe: np.ndarray, reduction: int):
         # dtype as NumPy would promote (concentrationanalysis.py:328-395): probe - baseline promotes to the wider of the
@@ -358,6 +388,15 @@ class ConcentrationAnalysis:
             self._ctxs[slot], self._ctx_keys[slot] = st, key
         return self._ctxs[slot]
 
+    def refresh(self) -> None:
+        """Drop every device-side copy (baseline, cleaning filter, coefficient planes): the next frame uploads them
+        again.  Needed after an IN-PLACE edit of the baseline image or of a coefficient array of the restoration (new
+        objects are noticed by themselves, ``_fingerprint``)."""
+        self._ctx_keys = [None, None]
+        for st in getattr(self, "_ctxs", []):
+            if st is not None:
+                st._coef_mark = None
+
     def close(self) -> None:
         """Release the device contexts and the uploader thread (both come back on demand)."""
         if getattr(self, "_uploader", None) is not None:
@@ -374,12 +413,13 @@ class ConcentrationAnalysis:
         like = np.empty(st.shape, st.dtype)
         coefs = (rest.weight, rest.omega, rest.regularization) if mode == "hb" else (1.0, 1.0, None)
         # the coefficients stay in the context from frame to frame: a weight map (porosity) is 128 - 256 MB of upload and
-        # three derived planes per frame otherwise.  "Unchanged" = the same objects with the same fingerprint (shape, dtype
-        # and a strided sample of 4096 values, which catches in-place edits of any region larger than a few hundred pixels)
+        # three derived planes per frame otherwise.  "Unchanged" = the same objects with the same fingerprint (_fingerprint:
+        # in-place edits are outside the contract, refresh() drops the copies)
         mark = tuple(_fingerprint(v) for v in coefs)
         if getattr(st, "_coef_mark", None) != mark:
             st.set_coeffs(*coefs, like)
             st._coef_mark = mark
+            st._coef_refs = coefs      # keeps the arrays alive: their id() stays theirs
         pre = ops if not self.first_restoration_then_model else []
         # the frame goes over as stored (float32 / float64 / uint8 / uint16); the device widens where NumPy would.  A frame that
         # is in HBM already (DeviceArray: e.g. out of the colour or shape correction) is read where it lies.
@@ -509,12 +549,17 @@ class ConcentrationAnalysis:
                 img = img.img_as(float)   # on the host for the generic chain; the fused path converts on the device
         probe = img.img
         plan = self._fusable(probe)
+        # which path served the frame: "fused" (one device pipeline from frame to concentration) or "generic" (the
+        # reference's stage-by-stage chain: NumPy on the host for the elementwise stages, the restoration operator on the
+        # device) -- observable, because the two differ by an order of magnitude in time
+        self.last_path, self.last_path_reason = ("fused", None) if plan is not None else ("generic", self._why_generic)
         if plan is not None:
             concentration = self._device_call(probe, plan)
         elif isinstance(probe, DeviceArray):
             raise NotImplementedError("a device-resident frame needs the fused pipeline (monochromatic reduction, model of "
                                       "linear / scaling / clip stages, TVD or no restoration, no balancing)")
         else:
+            logger.info("ConcentrationAnalysis: stage-by-stage chain on the host (%s)", self._why_generic)
             probe_img = copy.deepcopy(img)
             diff = self._subtract_background(probe_img)
             signal = self._balance_signal(self._clean_signal(self._reduce_signal(diff)))

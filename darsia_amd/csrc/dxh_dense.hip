@@ -642,7 +642,8 @@ __global__ void __launch_bounds__(256) k_pc_rows_inv(int P0, int P1, int logP1, 
 
 // peak (first maximum in row-major order, like np.argmax), parabolic refinement, acceptance.  grid (npatch)
 __global__ void __launch_bounds__(1024) k_pc_peak(const PcRoi* __restrict__ rois, int dec, int P0, int P1, const double* __restrict__ corr,
-                                                   double max_shift_fraction, double* __restrict__ shifts, int* __restrict__ ok) {
+                                                   double max_shift_fraction, double min_peak, double* __restrict__ shifts,
+                                                   int* __restrict__ ok, double* __restrict__ peaks) {
     __shared__ double sv[1024 / kWave];
     __shared__ long long si[1024 / kWave];
     const double* cp = corr + (size_t)blockIdx.x * P0 * P1;
@@ -679,13 +680,20 @@ __global__ void __launch_bounds__(1024) k_pc_peak(const PcRoi* __restrict__ rois
     if (dx > P1 / 2) dx -= P1;
     shifts[2 * blockIdx.x] = dx * dec;       // cells -> pixels
     shifts[2 * blockIdx.x + 1] = dy * dec;
-    ok[blockIdx.x] = !(fabs(dy) > max_shift_fraction * ph || fabs(dx) > max_shift_fraction * pw);
+    // accepted: a finite shift within the window AND a peak that stands out.  The correlation surface of a unit-modulus
+    // cross-power spectrum is 1 at the shift of two equal patterns, 0 everywhere for a flat patch (its mean-free
+    // transform is 0) and, for unrelated patterns, noise of standard deviation ~ 1 / sqrt(2 N) whose maximum over the N
+    // cells is ~ sqrt(ln N / N): min_peak is a multiple of that (dxh_phase_correlation_q).  !(x <= y) also rejects NaN.
+    const bool within = fabs(dy) <= max_shift_fraction * ph && fabs(dx) <= max_shift_fraction * pw;
+    const double peak = c0 / (double)n;   // the inverse transforms of this file do not scale by 1 / N
+    ok[blockIdx.x] = within && peak >= min_peak && isfinite(peak);
+    if (peaks) peaks[blockIdx.x] = peak;
 }
 
 namespace {
 template <typename S>
 int phase_correlation_t(Dev& d, int H, int W, int C, const S* src, const S* dst, int npatch, const PcRoi* rois_h,
-                        double max_shift_fraction, double* shifts, int32_t* ok, int* dec_out) {
+                        double max_shift_fraction, double min_peak_ratio, double* shifts, int32_t* ok, double* peaks, int* dec_out) {
     int maxh = 0, maxw = 0;
     for (int k = 0; k < npatch; ++k) {
         maxh = std::max(maxh, rois_h[k].r1 - rois_h[k].r0);
@@ -705,7 +713,9 @@ int phase_correlation_t(Dev& d, int H, int W, int C, const S* src, const S* dst,
     for (int k = 0; k < P0 / 2; ++k) { tw[2 * k] = std::cos(2.0 * M_PI * k / P0); tw[2 * k + 1] = -std::sin(2.0 * M_PI * k / P0); }
     for (int k = 0; k < P1 / 2; ++k) { tw[P0 + 2 * k] = std::cos(2.0 * M_PI * k / P1); tw[P0 + 2 * k + 1] = -std::sin(2.0 * M_PI * k / P1); }
     int rc;
-    void *dtw = nullptr, *drois = nullptr, *dmeans = nullptr, *dshift = nullptr, *dok = nullptr, *FA = nullptr, *FB = nullptr;
+    void *dtw = nullptr, *drois = nullptr, *dmeans = nullptr, *dshift = nullptr, *dok = nullptr, *FA = nullptr, *FB = nullptr, *dpeak = nullptr;
+    const double ncell = (double)P0 * (double)P1;
+    const double min_peak = min_peak_ratio > 0.0 ? min_peak_ratio * std::sqrt(std::log(ncell) / ncell) : -INFINITY;
     // patches per pass: two complex planes of P0 x P1 each, kept below a quarter of the free device memory
     size_t free_b = 0, total_b = 0;
     DXH_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -714,7 +724,8 @@ int phase_correlation_t(Dev& d, int H, int W, int C, const S* src, const S* dst,
     if (const char* e = std::getenv("DXH_PC_CHUNK")) chunk = std::max(1, std::min(npatch, std::atoi(e)));   // developer knob
     if ((rc = d.alloc(&dtw, sizeof(double) * tw.size())) || (rc = d.alloc(&drois, sizeof(PcRoi) * (size_t)npatch)) ||
         (rc = d.alloc(&dmeans, sizeof(double) * 2 * (size_t)npatch)) || (rc = d.alloc(&dshift, sizeof(double) * 2 * (size_t)npatch)) ||
-        (rc = d.alloc(&dok, sizeof(int) * (size_t)npatch)) || (rc = d.alloc(&FA, per_patch * chunk)) || (rc = d.alloc(&FB, per_patch * chunk)))
+        (rc = d.alloc(&dok, sizeof(int) * (size_t)npatch)) || (rc = d.alloc(&FA, per_patch * chunk)) || (rc = d.alloc(&FB, per_patch * chunk)) ||
+        (rc = d.alloc(&dpeak, sizeof(double) * (size_t)npatch)))
         return rc;
     DXH_HIP(hipMemcpyAsync(dtw, tw.data(), sizeof(double) * tw.size(), hipMemcpyDefault, d.st));
     DXH_HIP(hipMemcpyAsync(drois, rois_h, sizeof(PcRoi) * (size_t)npatch, hipMemcpyDefault, d.st));
@@ -743,12 +754,13 @@ int phase_correlation_t(Dev& d, int H, int W, int C, const S* src, const S* dst,
                            (const double*)dmeans + p0, npatch, P0, P1, l1, tw1, (double2*)FA, (double2*)FB);
         hipLaunchKernelGGL(k_pc_cols, dim3(P1 / CB, np), dim3(256), lds0, d.st, r, dec, P0, P1, l0, CB, tw0, (double2*)FA, (double2*)FB);
         hipLaunchKernelGGL(k_pc_rows_inv, dim3(P0, np), dim3(256), lds1, d.st, P0, P1, l1, tw1, (const double2*)FB, (double*)FA);
-        hipLaunchKernelGGL(k_pc_peak, dim3(np), dim3(1024), 0, d.st, r, dec, P0, P1, (const double*)FA, max_shift_fraction,
-                           (double*)dshift + 2 * p0, (int*)dok + p0);
+        hipLaunchKernelGGL(k_pc_peak, dim3(np), dim3(1024), 0, d.st, r, dec, P0, P1, (const double*)FA, max_shift_fraction, min_peak,
+                           (double*)dshift + 2 * p0, (int*)dok + p0, (double*)dpeak + p0);
         DXH_HIP(hipGetLastError());
     }
     DXH_HIP(hipMemcpyAsync(shifts, dshift, sizeof(double) * 2 * (size_t)npatch, hipMemcpyDefault, d.st));
     DXH_HIP(hipMemcpyAsync(ok, dok, sizeof(int) * (size_t)npatch, hipMemcpyDefault, d.st));
+    if (peaks) DXH_HIP(hipMemcpyAsync(peaks, dpeak, sizeof(double) * (size_t)npatch, hipMemcpyDefault, d.st));
     DXH_HIP(hipStreamSynchronize(d.st));
     return DXH_OK;
 }
@@ -853,7 +865,14 @@ int dxh_warp_patches(int device, int H, int W, int C, const float* base, const d
 
 int dxh_phase_correlation(int device, int H, int W, int C, int dtype, const void* src, const void* dst, int npatch,
                           const int32_t* rois, double max_shift_fraction, double* shifts, int32_t* ok) {
+    return dxh_phase_correlation_q(device, H, W, C, dtype, src, dst, npatch, rois, max_shift_fraction, 0.0, shifts, ok, nullptr);
+}
+
+int dxh_phase_correlation_q(int device, int H, int W, int C, int dtype, const void* src, const void* dst, int npatch,
+                            const int32_t* rois, double max_shift_fraction, double min_peak_ratio, double* shifts, int32_t* ok,
+                            double* peaks) {
     DXH_REQUIRE(src && dst && rois && shifts && ok, "null argument");
+    DXH_REQUIRE(min_peak_ratio >= 0.0, "min_peak_ratio must be >= 0");
     DXH_REQUIRE(H >= 1 && W >= 1 && (C == 1 || C == 3) && npatch >= 1, "shape (%d, %d, %d) with %d patches not supported", H, W, C, npatch);
     DXH_REQUIRE(dtype == DXH_F32 || dtype == DXH_F64 || dtype == DXH_U8 || dtype == DXH_U16,
                 "dtype %d not supported (float32, float64, uint8, uint16)", dtype);
@@ -878,10 +897,10 @@ int dxh_phase_correlation(int device, int H, int W, int C, int dtype, const void
     }
     int dec = 1;
     switch (dtype) {
-        case DXH_F32: rc = phase_correlation_t<float>(d, H, W, C, (const float*)dimg[0], (const float*)dimg[1], npatch, q, max_shift_fraction, shifts, ok, &dec); break;
-        case DXH_F64: rc = phase_correlation_t<double>(d, H, W, C, (const double*)dimg[0], (const double*)dimg[1], npatch, q, max_shift_fraction, shifts, ok, &dec); break;
-        case DXH_U8: rc = phase_correlation_t<unsigned char>(d, H, W, C, (const unsigned char*)dimg[0], (const unsigned char*)dimg[1], npatch, q, max_shift_fraction, shifts, ok, &dec); break;
-        default: rc = phase_correlation_t<unsigned short>(d, H, W, C, (const unsigned short*)dimg[0], (const unsigned short*)dimg[1], npatch, q, max_shift_fraction, shifts, ok, &dec); break;
+        case DXH_F32: rc = phase_correlation_t<float>(d, H, W, C, (const float*)dimg[0], (const float*)dimg[1], npatch, q, max_shift_fraction, min_peak_ratio, shifts, ok, peaks, &dec); break;
+        case DXH_F64: rc = phase_correlation_t<double>(d, H, W, C, (const double*)dimg[0], (const double*)dimg[1], npatch, q, max_shift_fraction, min_peak_ratio, shifts, ok, peaks, &dec); break;
+        case DXH_U8: rc = phase_correlation_t<unsigned char>(d, H, W, C, (const unsigned char*)dimg[0], (const unsigned char*)dimg[1], npatch, q, max_shift_fraction, min_peak_ratio, shifts, ok, peaks, &dec); break;
+        default: rc = phase_correlation_t<unsigned short>(d, H, W, C, (const unsigned short*)dimg[0], (const unsigned short*)dimg[1], npatch, q, max_shift_fraction, min_peak_ratio, shifts, ok, peaks, &dec); break;
     }
     if (rc) return rc;
     for (int k = 0; k < npatch; ++k)

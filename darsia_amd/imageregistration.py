@@ -45,8 +45,16 @@ class PhaseCorrelationEstimator:
     ``darsia.TranslationEstimator`` (ORB + RANSAC, OpenCV) with the same call signature; ``find_effective_translations`` takes
     all patches of an image pair in one call, which is what ``TranslationAnalysis`` uses when an estimator offers it."""
 
-    def __init__(self, max_shift_fraction: float = 0.25) -> None:
+    def __init__(self, max_shift_fraction: float = 0.25, min_peak_ratio: float = 4.0, min_active_fraction: float = 0.5) -> None:
+        """``min_peak_ratio``: an estimate is kept only if its correlation peak reaches this multiple of the level unrelated
+        patterns reach (``dxh_phase_correlation_q``): flat, noise-only and non-finite patches are reported as not intact, as
+        the reference's feature matcher does, and the spline interpolates over them.  ``min_active_fraction``: with masks, a
+        patch is estimated only if at least this fraction of its pixels is active in BOTH masks (the reference restricts
+        the matched pixels to the masks; here a mostly masked patch is left to the spline instead)."""
         self.max_shift_fraction = max_shift_fraction
+        self.min_peak_ratio = min_peak_ratio
+        self.min_active_fraction = min_active_fraction
+        self.last_peaks = None      # correlation peak per patch of the last call (diagnostics)
 
     def find_effective_translations(self, img_src, img_dst, rois, masks_src=None, masks_dst=None) -> list:
         """``[(translation, intact)]`` per patch; ``rois``: pairs of slices or rows (r0, r1, c0, c1) -- the same rectangle of both
@@ -78,13 +86,22 @@ class PhaseCorrelationEstimator:
         shifts = np.empty((n, 2), np.float64)
         ok = np.empty(n, np.int32)
         device = a.device if isinstance(a, DeviceArray) else (b.device if isinstance(b, DeviceArray) else _lib.default_device())
-        _lib.check(_lib.load().dxh_phase_correlation(device, a.shape[0], a.shape[1], 1 if a.ndim == 2 else 3,
-                                                      _PC_DTYPES[np.dtype(a.dtype)], _lib.ptr(a), _lib.ptr(b), n, _lib.ptr(boxes),
-                                                      float(self.max_shift_fraction), _lib.ptr(shifts), _lib.ptr(ok)))
+        peaks = np.empty(n, np.float64)
+        _lib.check(_lib.load().dxh_phase_correlation_q(device, a.shape[0], a.shape[1], 1 if a.ndim == 2 else 3,
+                                                        _PC_DTYPES[np.dtype(a.dtype)], _lib.ptr(a), _lib.ptr(b), n, _lib.ptr(boxes),
+                                                        float(self.max_shift_fraction), float(self.min_peak_ratio),
+                                                        _lib.ptr(shifts), _lib.ptr(ok), _lib.ptr(peaks)))
+        self.last_peaks = peaks
+
+        def enough(mask, r0, r1, c0, c1):
+            m = mask[r0:r1, c0:c1]
+            need = self.min_active_fraction * m.size
+            return np.count_nonzero(m) >= max(need, 1)
+
         out = []
         for k, (r0, r1, c0, c1) in enumerate(boxes):
-            active = ok[k] and (masks_src is None or masks_dst is None or
-                                (np.any(masks_src[r0:r1, c0:c1]) and np.any(masks_dst[r0:r1, c0:c1])))
+            active = ok[k] and bool(np.isfinite(shifts[k]).all()) and (
+                masks_src is None or masks_dst is None or (enough(masks_src, r0, r1, c0, c1) and enough(masks_dst, r0, r1, c0, c1)))
             out.append((np.array([[1.0, 0.0, shifts[k, 0]], [0.0, 1.0, shifts[k, 1]]]), True) if active else (None, False))
         return out
 
@@ -167,9 +184,14 @@ class TranslationAnalysis:
                 and isinstance(b, np.ndarray) and a.dtype == b.dtype and a.dtype in _PC_DTYPES and a.shape == b.shape
                 and a.ndim in (2, 3) and (a.ndim == 2 or a.shape[2] == 3))
 
+    def refresh(self) -> None:
+        """Drop the baseline's device copy (after an in-place edit of ``base.img``; ``update_base`` does it by itself)."""
+        self._drop_device_base()
+
     def _device_base(self):
-        """The baseline's pixels as a device array, uploaded once and kept while the host array looks unchanged (same object,
-        same fingerprint: shape, dtype and a strided sample of 4096 values)."""
+        """The baseline's pixels as a device array, uploaded once and kept while the host array is the same object with the
+        same fingerprint (``concentration._fingerprint``: a safety net -- in-place edits are outside the contract, see
+        ``refresh``).  ``self.base`` keeps the array alive, so its id() cannot be recycled under the mark."""
         from .concentration import _fingerprint
         from .device import DeviceArray
 

@@ -267,6 +267,25 @@ def numpy2_unsupported(img, mu, omega, ell, dim, x0, isotropic, solver, adaptive
     return None
 
 
+def choose_promotion(promotion: Optional[str], img_dtype, coefs, why_not: Optional[str]) -> str:
+    """The dtype flow a call runs in: an explicit ``promotion`` wins; else ``DXH_PROMOTION`` (``numpy2`` there means
+    "wherever that flow exists"); else ``numpy2`` exactly when a float32 image comes with a float64 coefficient array
+    and the flow exists for the configuration (``why_not`` is None), ``native`` otherwise."""
+    if promotion is None:
+        promotion = os.environ.get("DXH_PROMOTION") or None
+        if promotion is None:
+            mixed = np.dtype(img_dtype) == np.float32 and any(
+                isinstance(c, np.ndarray) and c.ndim > 0 and c.dtype == np.float64 for c in coefs)
+            promotion = "numpy2" if (mixed and why_not is None) else "native"
+            if mixed and why_not is not None:
+                logger.info("float32 image with float64 coefficients: native float32 flow (%s)", why_not)
+        elif promotion == "numpy2" and why_not is not None:
+            promotion = "native"
+    if promotion not in ("native", "numpy2"):
+        raise ValueError(f"promotion must be None, 'native' or 'numpy2', not {promotion!r}")
+    return promotion
+
+
 def split_bregman_tvd(
     img: np.ndarray,
     mu: Union[float, np.ndarray] = 1.0,
@@ -323,18 +342,7 @@ def split_bregman_tvd(
 
     quiet = not (verbose if isinstance(verbose, bool) else verbose > 0)
     why_not = numpy2_unsupported(img, mu, omega, ell, dim, x0, isotropic, solver, adaptive, quiet)
-    if promotion is None:
-        promotion = os.environ.get("DXH_PROMOTION") or None
-        if promotion is None:
-            mixed = img.dtype == np.float32 and any(isinstance(c, np.ndarray) and c.ndim > 0 and c.dtype == np.float64
-                                                    for c in (mu, omega, ell))
-            promotion = "numpy2" if (mixed and why_not is None) else "native"
-            if mixed and why_not is not None:
-                logger.info("float32 image with float64 coefficients: native float32 flow (%s)", why_not)
-        elif promotion == "numpy2" and why_not is not None:
-            promotion = "native"    # the environment variable asks for it wherever it exists
-    if promotion not in ("native", "numpy2"):
-        raise ValueError(f"promotion must be None, 'native' or 'numpy2', not {promotion!r}")
+    promotion = choose_promotion(promotion, img.dtype, (mu, omega, ell), why_not)
     if promotion == "numpy2":
         if why_not is not None:
             raise NotImplementedError(f"promotion='numpy2': {why_not}")

@@ -476,6 +476,17 @@ int dxh_warp_patches_typed(int device, int H, int W, int C, int dtype, const voi
 int dxh_phase_correlation(int device, int H, int W, int C, int dtype, const void* img_src, const void* img_dst, int npatch,
                           const int32_t* rois, double max_shift_fraction, double* shifts, int32_t* ok);
 /*
+ * The same with a peak-quality test: an estimate is accepted only if its shift is finite and the correlation peak reaches
+ * min_peak_ratio * sqrt(ln N / N), N = cells of the padded transform -- sqrt(ln N / N) is the level the maximum of the
+ * correlation surface of two UNRELATED patterns reaches (unit-modulus cross-power spectrum), a flat patch gives 0, two equal
+ * patterns 1.  min_peak_ratio = 0 switches the test off (NaN shifts are rejected in any case).  peaks (npatch doubles, or
+ * NULL): the peak value per patch.  (The reference's ORB + RANSAC estimator reports such patches as not intact and lets the
+ * spline interpolate over them: translationanalysis.py:262-283.)
+ */
+int dxh_phase_correlation_q(int device, int H, int W, int C, int dtype, const void* img_src, const void* img_dst, int npatch,
+                            const int32_t* rois, double max_shift_fraction, double min_peak_ratio, double* shifts, int32_t* ok,
+                            double* peaks);
+/*
  * Thin-plate-spline evaluation of a fitted scipy.interpolate.RBFInterpolator (kernel 'thin_plate_spline',
  * degree 1, epsilon 1) at n points -- TranslationAnalysis.translation / DiffeomorphicImageRegistration.
  * displacement (translationanalysis.py:285-301, imageregistration.py:265-306).  centers (p, 2), coeffs

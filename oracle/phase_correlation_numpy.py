@@ -15,7 +15,12 @@ Per patch pair (a = source patch, b = destination patch, same pixel rectangle of
     (patches longer than 8192 pixels are first reduced to cells of dec x dec pixels, see phase_correlation_patches)
   * cross = F(b) conj(F(a)), divided by max(|cross|, 1e-12); corr = real part of the inverse transform
   * the peak of corr (first maximum in row-major order) is refined by a parabola through its circular neighbours per axis,
-    unwrapped to [-P/2, P/2), and rejected when it exceeds ``max_shift_fraction`` of the patch size in either direction
+    unwrapped to [-P/2, P/2), and rejected when it exceeds ``max_shift_fraction`` of the patch size in either direction,
+    when it is not finite, or when the peak itself stays below ``min_peak_ratio * sqrt(ln N / N)``, N = P0 P1: that square root
+    is the level the maximum of the surface reaches for two UNRELATED patterns (each of the N values is the mean of N unit
+    phases, standard deviation 1 / sqrt(2 N)); a flat patch has a zero transform and a surface of zeros, two equal patterns a
+    peak of 1.  (The reference's ORB + RANSAC estimator reports such patches as not intact and the spline interpolates over
+    them, translationanalysis.py:262-283.)
 """
 import numpy as np
 
@@ -27,7 +32,7 @@ def next_pow2(n: int) -> int:
     return p
 
 
-def phase_correlation(a, b, padded_shape=None, max_shift_fraction: float = 0.25):
+def phase_correlation(a, b, padded_shape=None, max_shift_fraction: float = 0.25, min_peak_ratio: float = 4.0, return_peak=False):
     """(dx, dy) of patch ``b`` relative to patch ``a`` and whether the estimate is accepted; ``padded_shape`` = (P0, P1)."""
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
@@ -55,9 +60,11 @@ def phase_correlation(a, b, padded_shape=None, max_shift_fraction: float = 0.25)
         dy -= p0
     if dx > p1 / 2:
         dx -= p1
-    if abs(dy) > max_shift_fraction * ph or abs(dx) > max_shift_fraction * pw:
-        return (dx, dy), False
-    return (dx, dy), True
+    peak = float(corr[py, px])
+    n = float(p0) * float(p1)
+    min_peak = min_peak_ratio * np.sqrt(np.log(n) / n) if min_peak_ratio > 0 else -np.inf
+    ok = bool(abs(dy) <= max_shift_fraction * ph and abs(dx) <= max_shift_fraction * pw and np.isfinite(peak) and peak >= min_peak)
+    return ((dx, dy), ok, peak) if return_peak else ((dx, dy), ok)
 
 
 MAX_TRANSFORM = 8192   # longest transform of the device implementation (128 KB of LDS)
@@ -74,7 +81,7 @@ def cells(a, dec: int):
     return a[:ph * dec, :pw * dec].reshape(ph, dec, pw, dec).mean(axis=(1, 3))
 
 
-def phase_correlation_patches(img_src, img_dst, rois, max_shift_fraction: float = 0.25):
+def phase_correlation_patches(img_src, img_dst, rois, max_shift_fraction: float = 0.25, min_peak_ratio: float = 4.0):
     """All patches of a call: ``rois`` = (n, 4) rows r0, r1, c0, c1; one padded shape for the whole call.  When the largest patch is
     longer than MAX_TRANSFORM the patches are read in cells of dec x dec pixels (dec the smallest power of two that fits) and the
     shifts are scaled back to pixels."""
@@ -86,6 +93,7 @@ def phase_correlation_patches(img_src, img_dst, rois, max_shift_fraction: float 
     p0, p1 = next_pow2(maxh // dec), next_pow2(maxw // dec)
     out = []
     for r0, r1, c0, c1 in rois:
-        shift, ok = phase_correlation(cells(img_src[r0:r1, c0:c1], dec), cells(img_dst[r0:r1, c0:c1], dec), (p0, p1), max_shift_fraction)
+        shift, ok = phase_correlation(cells(img_src[r0:r1, c0:c1], dec), cells(img_dst[r0:r1, c0:c1], dec), (p0, p1), max_shift_fraction,
+                                      min_peak_ratio)
         out.append((None if shift is None else (shift[0] * dec, shift[1] * dec), ok))
     return out

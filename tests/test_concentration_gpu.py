@@ -222,7 +222,9 @@ def test_weight_map_stays_in_the_context_between_frames_and_edits_are_noticed():
     context, a map edited in place (or replaced) is uploaded again."""
     base, probe = _frames(64, 96, 60)
     rng = np.random.default_rng(61)
-    weight = 0.02 + 0.1 * rng.random((64, 96))
+    # (float32 like the signal: a float64 map next to float32 frames runs the operator's numpy2 flow instead of the
+    # context's own iterations, test_float32_signal_with_float64_weights_... below)
+    weight = (0.02 + 0.1 * rng.random((64, 96))).astype(np.float32)
     tvd = da.TVD(method="heterogeneous bregman", weight=weight, omega=1.0, regularization=0.3, max_num_iter=7, eps=None)
     ca = da.ConcentrationAnalysis(base, da.MonochromaticReduction(color="green"), None, tvd, None, **{"diff option": "positive"})
 
@@ -349,3 +351,53 @@ def test_random_sweep_of_frame_types_against_numpy_promotion():
         assert out.img.dtype == ref.dtype, (case, frame_dt, base_dt, with_filter, out.img.dtype, ref.dtype)
         assert np.array_equal(out.img, ref), (case, frame_dt, base_dt, with_filter, option, color)
         ca.close()
+
+
+def test_float32_signal_with_float64_weights_takes_the_reference_flow_and_paths_are_observable(caplog):
+    """The workflow's default (presets/workflows/restoration.py:117-148): float32 frames, float64 porosity weights.  The TVD
+    operator alone runs the reference's mixed dtype flow there (promotion "numpy2"); inside ConcentrationAnalysis the SAME
+    operator runs on the device-resident signal between the two elementwise stages, so the fused object and the operator
+    called by hand give the same bits -- which are the oracle's reference-flow bits.  ``last_path`` says which pipeline
+    served a frame; the host chain also logs why."""
+    import logging
+
+    from oracle import tvd_numpy as O
+
+    base, probe = _frames(48, 72, 11)
+    rng = np.random.default_rng(5)
+    weight = 0.08 * (0.3 + 0.7 * rng.random((48, 72)))          # float64
+    weight[10:20, 30:50] = 0.0
+    tvd = da.TVD(method="heterogeneous bregman", weight=weight, omega=1.0, regularization=1.0, max_num_iter=25, eps=None)
+    ca = da.ConcentrationAnalysis(base, da.MonochromaticReduction(color="red"), None, tvd, None, **{"diff option": "positive"})
+    out = ca(probe)
+    assert ca.last_path == "fused" and ca.last_path_reason is None and out.img.dtype == np.float32
+    signal = OC.concentration(probe.img, base.img, "positive", "red", None, [], None, False)
+    assert signal.dtype == np.float32
+    want = O.split_bregman_tvd(signal, mu=weight, omega=1.0, ell=1.0, max_num_iter=25)      # the reference's NumPy-2 flow
+    assert np.array_equal(out.img, want)
+    assert np.array_equal(tvd(signal), want)
+    # float32 weights: the context's own float32 iterations (bit-exact against the oracle's same-dtype flow)
+    tvd32 = da.TVD(method="heterogeneous bregman", weight=weight.astype(np.float32), omega=1.0, regularization=1.0, max_num_iter=25, eps=None)
+    ca32 = da.ConcentrationAnalysis(base, da.MonochromaticReduction(color="red"), None, tvd32, None, **{"diff option": "positive"})
+    got32 = ca32(probe).img
+    assert ca32.last_path == "fused"
+    assert np.array_equal(got32, O.split_bregman_tvd(signal, mu=weight.astype(np.float32), omega=1.0, ell=1.0, max_num_iter=25, promotion="strict"))
+    np.testing.assert_allclose(got32, want, rtol=1e-4, atol=1e-6)
+    # a stage the device pipeline does not have: the host chain serves the frame, says so, and gives the same answer
+    # as the stages applied by hand
+    ca_gen = da.ConcentrationAnalysis(base, da.MonochromaticReduction(color="red"), lambda x: x, tvd, None, **{"diff option": "positive"})
+    with caplog.at_level(logging.INFO, logger="darsia_amd.concentration"):
+        out_gen = ca_gen(probe)
+    assert ca_gen.last_path == "generic" and "balancing" in ca_gen.last_path_reason
+    assert any("stage-by-stage" in r.message for r in caplog.records)
+    assert np.array_equal(out_gen.img, want)
+    # refresh(): an in-place edit of the weight map is outside what the device caches can see; after refresh() it counts
+    weight32 = weight.astype(np.float32)
+    tvd_e = da.TVD(method="heterogeneous bregman", weight=weight32, omega=1.0, regularization=1.0, max_num_iter=8, eps=None)
+    ca_e = da.ConcentrationAnalysis(base, da.MonochromaticReduction(color="red"), None, tvd_e, None, **{"diff option": "positive"})
+    first = ca_e(probe).img.copy()
+    weight32[25, 37] *= 3.0                 # one pixel: no sample of the fingerprint sees it
+    ca_e.refresh()
+    second = ca_e(probe).img
+    assert not np.array_equal(first, second)
+    assert np.array_equal(second, O.split_bregman_tvd(signal, mu=weight32, omega=1.0, ell=1.0, max_num_iter=8, promotion="strict"))

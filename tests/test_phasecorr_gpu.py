@@ -88,3 +88,39 @@ def test_patches_in_several_passes_give_the_same_shifts(monkeypatch):
     chunked = est.find_effective_translations(a, b, rois)
     assert [ok for _, ok in whole] == [ok for _, ok in chunked] and all(ok for _, ok in whole)
     assert all(np.array_equal(t0, t1) for (t0, _), (t1, _) in zip(whole, chunked))
+
+
+def test_flat_noise_only_nan_and_mostly_masked_patches_are_not_intact():
+    """What the reference's ORB + RANSAC matcher reports as not intact (translationanalysis.py:262-283) must not become a
+    control point of the spline here either: a flat patch, two unrelated noise patches, a patch holding a NaN, a patch
+    most of which is masked out.  Flags equal the NumPy statement's; the peak values agree."""
+    rng = np.random.default_rng(12)
+    h, w = 128, 160
+    a, b = _pair(h, 4 * w, 9, shift=(2.5, -3.25))
+    a, b = a.copy(), b.copy()
+    a[:, w:2 * w] = b[:, w:2 * w] = 0.37                      # patch 1: flat in both frames
+    a[:, 2 * w:3 * w] = rng.random((h, w))                      # patch 2: unrelated noise
+    b[:, 2 * w:3 * w] = rng.random((h, w))
+    rois = [(0, h, k * w, (k + 1) * w) for k in range(4)]
+    est = PhaseCorrelationEstimator(0.25)
+    got = est.find_effective_translations(a, b, rois)
+    want = P.phase_correlation_patches(a, b, rois, 0.25)
+    assert [ok for _, ok in got] == [ok for _, ok in want] == [True, False, False, True]
+    peaks = [P.phase_correlation(a[r0:r1, c0:c1], b[r0:r1, c0:c1], (128, 256), return_peak=True)[2] for r0, r1, c0, c1 in rois]
+    np.testing.assert_allclose(est.last_peaks, peaks, rtol=0, atol=1e-9)
+    assert abs(est.last_peaks[1]) < 1e-12 and est.last_peaks[2] < 0.05 < est.last_peaks[0]
+    # the test can be switched off: then the noise patch is whatever its random peak says
+    assert PhaseCorrelationEstimator(0.5, min_peak_ratio=0.0).find_effective_translations(a, b, rois[:1])[0][1] is True
+    # a NaN anywhere in a patch poisons its transform: not intact (and the others are unaffected)
+    a_nan = a.copy()
+    a_nan[5, 3 * w + 7] = np.nan
+    flags = [ok for _, ok in est.find_effective_translations(a_nan, b, rois)]
+    assert flags == [True, False, False, False]
+    # masks: a patch counts only if at least min_active_fraction of it is active in both masks
+    m_src, m_dst = np.ones(a.shape, bool), np.ones(a.shape, bool)
+    m_src[:, :w][:, : int(0.7 * w)] = False                    # patch 0: 30 % active in the source mask
+    m_dst[: h // 4, 3 * w:] = False                             # patch 3: 75 % active in the destination mask
+    flags = [ok for _, ok in est.find_effective_translations(a, b, rois, m_src, m_dst)]
+    assert flags == [False, False, False, True]
+    assert [ok for _, ok in PhaseCorrelationEstimator(0.25, min_active_fraction=0.2).find_effective_translations(a, b, rois, m_src, m_dst)] == \
+        [True, False, False, True]
