@@ -199,12 +199,20 @@ class SocketTransport:
 
 
 # ---- communicators (dxh_comm_t) ------------------------------------------------------------------------------------
+_rccl_seq = 0   # communicators this process has created: every rank creates them in the same order
+
+
 def _rendezvous_path() -> str:
+    """One file per communicator: ranks of one launch share the launcher as parent and the rendezvous port, and the n-th
+    communicator of every rank gets the suffix n -- a second ``Comm.rccl`` in the same launch can never read the id of
+    the first."""
+    global _rccl_seq
+    seq = _rccl_seq
+    _rccl_seq += 1
     explicit = os.environ.get("DXH_RENDEZVOUS_FILE")
     if explicit:
-        return explicit
-    # ranks of one launch share the launcher as parent and the rendezvous port
-    tag = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}"
+        return f"{explicit}.{seq}" if seq else explicit
+    tag = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{seq}"
     return os.path.join(tempfile.gettempdir(), f"dxh_rccl_{tag}.id")
 
 
@@ -227,8 +235,17 @@ class Comm:
         buf = (C.c_char * _lib.COMM_ID_BYTES)()
         if rank == 0:
             _lib.check(lib.dxh_comm_unique_id(buf))
+            # written to a private temporary (O_EXCL, mode 0600) and renamed into place: a leftover of a crashed run is
+            # replaced atomically, never appended to or half read.  (A leftover can only be READ by a rank that gets here
+            # before rank 0 publishes AND shares launcher pid, port, run id and sequence number with the crashed run --
+            # i.e. with an explicit DXH_RENDEZVOUS_FILE; such a caller removes the file before launching.)
             tmp = f"{path}.{os.getpid()}.tmp"
-            with open(tmp, "wb") as f:
+            try:
+                os.unlink(tmp)
+            except OSError:
+                pass
+            fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+            with os.fdopen(fd, "wb") as f:
                 f.write(bytes(buf))
             os.replace(tmp, path)
         else:
@@ -248,14 +265,13 @@ class Comm:
         h = C.c_void_p()
         _lib.check(lib.dxh_comm_create_rccl(C.byref(h), device, buf, rank, world))
 
-        def cleanup():
-            if rank == 0:
-                try:
-                    os.unlink(path)
-                except OSError:
-                    pass
-        comm = cls(h, rank, world, device, cleanup=cleanup)
-        comm.barrier()   # every rank has read the id: rank 0 may remove the file when it is done
+        comm = cls(h, rank, world, device)
+        comm.barrier()   # every rank has read the id (ncclCommInitRank has returned everywhere)
+        if rank == 0:
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
         return comm
 
     @classmethod

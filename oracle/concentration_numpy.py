@@ -8,6 +8,10 @@ tests/test_concentration_golden_cpu.py): the four difference options, the red / 
 reductions, cleaning filters, Linear / Clip / Scaling / Combined models, TVD("heterogeneous bregman") before and after
 the model, float32 and float64.  The one exception is ``cv2.cvtColor(.., COLOR_RGB2GRAY)`` for the "gray" reduction
 (float32 weights 0.299 / 0.587 / 0.114), which stays UNPINNED (cv2 absent; that reduction is not in the vectors).
+Version label of that restatement: ``RGB2Gray<float>`` of OpenCV 2.4 .. 4.x (``modules/imgproc/src/color_rgb.simd.hpp``, before
+3.4.2 ``color.cpp``): ``src[0] * 0.299f + src[1] * 0.587f + src[2] * 0.114f`` in float32, left to right, for float input -- the
+only input type ``MonochromaticReduction`` hands it (signals/reduction/monochromatic.py:65-68: ``img.astype(np.float32)``); the
+8-bit integer path (15-bit fixed point since 3.4.2, 14-bit before) is not used.
 """
 from __future__ import annotations
 

@@ -6,7 +6,8 @@ configurations equal, bit for bit, what the reference's own CurvatureCorrection 
 by tests/golden/make_golden_curvature.py, which executes curvature.py / basecorrection.py; tests/test_curvature_golden_cpu.py).
 The "crop" step: how the reference assembles it (configuration normal form, corner conventions, target size, dtype handling) is
 pinned by tests/golden/make_golden_warp_assembly.py, which executes the reference's class and function with their two OpenCV
-calls answered by oracle/warp_numpy.py; the arithmetic of cv2.warpPerspective itself stays unpinned.
+calls answered by oracle/warp_numpy.py; the arithmetic of cv2.warpPerspective itself stays unpinned -- the restatement describes the
+classic fixed-point path of OpenCV 2.4 .. 4.10 (version label and upstream file / function names in oracle/warp_numpy.py's header).
 
 * ``map_coordinates``: ``scipy.ndimage.map_coordinates(input2d, grid, order=0|1)`` with the default mode
   "constant", cval 0 (call site curvature.py:943-945).  SciPy is a third-party, unpinned dependency of the

@@ -25,6 +25,14 @@ algorithm of OpenCV 4.x ``modules/imgproc/src/resize.cpp`` (generic, non-SIMD co
   INTER_AREA when enlarging falls back to the bilinear scheme with ``sx = floor(dx scale)``,
   ``f = (dx + 1) - (sx + 1) inv_scale`` clipped to [0, 1).
 * uint8 results: ``cvRound`` (half to even) and saturation.
+
+VERSION LABEL (from the builder's reading of the upstream sources; not checkable here -- no cv2, no network): OpenCV
+3.4.x .. 4.x (through 4.10; the file is unchanged in these respects in later 4.x as far as known) --
+``modules/imgproc/src/resize.cpp``: ``cv::resize`` size / scale rules, ``resizeNN`` (``resizeNNInvoker``),
+``resizeGeneric_<HResizeLinear, VResizeLinear>`` with ``INTER_RESIZE_COEF_BITS = 11`` for 8-bit images and float weights
+otherwise, ``resizeAreaFast_`` (integer scales; the 8-bit 2 x 2 SIMD form ``(s + 2) >> 2``) and ``resizeArea_`` with
+``computeResizeAreaTab``.  ``INTER_LINEAR_EXACT`` / ``INTER_NEAREST_EXACT`` (bit-exact integer paths added in 3.4 / 4.5) are
+different flags and not what DarSIA passes (restoration/resize.py:80-96).
 """
 from __future__ import annotations
 

@@ -23,6 +23,20 @@ WarpPerspectiveInvoker + remapBilinear):
   * value = S00*w00 + S01*w01 + S10*w10 + S11*w11 in float32, left to right, taps outside the source
     replaced by the constant border 0.
 
+VERSION LABEL (what this restatement describes; from the builder's reading of the upstream sources -- not checkable here,
+there is neither cv2 nor network): the classic path of OpenCV 2.4.x .. 4.10.x (opencv-python <= 4.10.0.84) --
+``modules/imgproc/src/imgwarp.cpp``: ``cv::getPerspectiveTransform`` (8 x 8 system, ``solve(..., DECOMP_SVD)`` in double),
+``cv::warpPerspective`` -> ``WarpPerspectiveInvoker::operator()`` (block sizes ``BLOCK_SZ = 32`` -> bh0 / bw0 as above, the
+``INTER_BITS = 5`` fixed-point coordinates with ``saturate_cast<int>`` of the rounded product, ``INTER_TAB_SIZE = 32``) ->
+``cv::remap`` -> ``remapBilinear<Cast<float, float>, RemapNoVec, float>`` with the float table ``BilinearTab_f``
+(``initInterTab2D``) and ``BORDER_CONSTANT``.  The SSE4.1 / AVX2 / NEON line kernels of those releases compute the same
+fixed-point coordinates.  OpenCV 4.11 (2025) and later route INTER_LINEAR warps of CV_8U / CV_16U / CV_32F images with 1, 3 or 4
+channels through new kernels (``modules/imgproc/src/warp_kernels.simd.hpp``, ``warpPerspectiveLinearInvoker_*``) that
+interpolate at the exact floating-point source position -- no 1/32-pixel quantisation --, so an installation with such a release
+differs from this restatement (and from the reference's own results under an older OpenCV) by up to ~1/64 pixel of sampling
+position.  The reference pins no OpenCV version (pyproject.toml:41), so WHICH of the two a DarSIA installation computes depends
+on the day it was installed; this repository reproduces the classic one.
+
 The thin-plate-spline evaluation is checked against SciPy itself (available here), see tests.
 """
 from __future__ import annotations
