@@ -185,6 +185,50 @@ __global__ void __launch_bounds__(256) k_jacobi_vol(Geom g, const T* __restrict_
     xout[off] = rs[off] + acc / dsc;
 }
 
+// The volume sweep again, 16 bytes per lane and XCD-aware.  k_jacobi_vol above deals the rows of the volume round-robin
+// over the eight XCDs, so the four neighbour rows of a row (axis 0 and axis 1) are fetched by other XCDs' L2s: every line of
+// x crosses the fabric five times per sweep.  Here XCD x (= block % 8) works through a CONTIGUOUS run of (plane, row) tiles in
+// order, so the neighbour rows and planes of what it computes are what it has just read -- or will read next -- through its own
+// L2 (three planes of 256 x 256 floats are 768 KB of its 4 MB); a thread owns N = 16 B / sizeof(T) consecutive elements of
+// axis 2 (n2 % N == 0, which keeps every row 16-byte aligned: the pitch is a multiple of 32 elements).  Same sums in the same
+// order as above.
+template <typename T>
+__global__ void __launch_bounds__(256) k_jacobi_vol_x(Geom g, const T* __restrict__ rs, const T* __restrict__ xin, Coef<T> c,
+                                                       CoefPlanes<T> cp, T* __restrict__ xout, int nbx, int64_t tiles, int64_t per_xcd) {
+    constexpr int N = VecOf<T>::N;
+    const int64_t t = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int64_t)(blockIdx.x >> 3) >= per_xcd || t >= tiles) return;
+    const int64_t row = t / nbx;
+    const int bx = (int)(t - row * nbx);
+    const int64_t i0 = row / g.n1, i1 = row - i0 * g.n1;
+    const int64_t i2 = ((int64_t)bx * 256 + threadIdx.x) * N;
+    if (i2 >= g.n2) return;
+    const int64_t off = i0 * g.pitch + i1 * g.n2 + i2;
+    T xc[N], xa[N], xb[N], xl[N], xr[N], r[N], o[N];
+    load_vec(xin + off, xc);
+    load_vec(xin + (i0 > 0 ? off - g.pitch : off), xa);
+    load_vec(xin + (i0 < g.n0 - 1 ? off + g.pitch : off), xb);
+    load_vec(xin + (i1 > 0 ? off - g.n2 : off), xl);
+    load_vec(xin + (i1 < g.n1 - 1 ? off + g.n2 : off), xr);
+    load_vec(rs + off, r);
+    const T left = i2 > 0 ? xin[off - 1] : xc[0];
+    const T right = i2 + N < g.n2 ? xin[off + N] : xc[N - 1];
+    T dscv[N];
+    if (cp.dsc) load_vec(cp.dsc + off, dscv);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        T acc = T(0);
+        acc = acc + xa[j];
+        acc = acc + xb[j];
+        acc = acc + xl[j];
+        acc = acc + xr[j];
+        acc = acc + (j == 0 ? left : xc[j - 1]);
+        acc = acc + (j == N - 1 ? right : xc[j + 1]);
+        o[j] = r[j] + acc / (cp.dsc ? dscv[j] : c.dsc);
+    }
+    store_vec(xout + off, o);
+}
+
 // q_j <- backward_diff(u_new, j) + b_j       split_bregman_tvd.py:136-146 (both branches)
 template <typename T, int DIM, bool ISO, bool FROM_DB>
 __global__ void __launch_bounds__(256) k_shrink(Geom g, const T* __restrict__ unew, QPlanes<T, DIM> q, DBPlanes<T> db,

@@ -728,6 +728,18 @@ static bool fused3d_supported(const Ctx* c) {
 
 template <typename T>
 static void launch_jacobi(Ctx* c, const void* xin, void* xout) {
+    constexpr int NV = VecOf<T>::N;
+    if (c->g.ndim == 3 && c->g.nsum_axes == 3 && c->g.n2 >= 64 && c->g.n2 % NV == 0 && !(c->tune & (16384 | 262144))) {
+        // volumes, 16 bytes per lane, XCD x sweeps a contiguous run of (plane, row) tiles (DXH_FUSED_TUNE bit 262144: the
+        // one-element-per-thread kernel below, A/B)
+        const int nbx = (int)((c->g.n2 / NV + 255) / 256);
+        const int64_t tiles = c->g.n0 * c->g.n1 * nbx, per_xcd = (tiles + 7) / 8;
+        if (per_xcd * 8 < (int64_t)INT32_MAX) {
+            hipLaunchKernelGGL((k_jacobi_vol_x<T>), dim3((unsigned)(per_xcd * 8)), dim3(256), 0, c->stream, c->g, (const T*)c->rs,
+                               (const T*)xin, make_coef<T>(c), make_planes<T>(c), (T*)xout, nbx, tiles, per_xcd);
+            return;
+        }
+    }
     if (c->g.ndim == 3 && c->g.nsum_axes == 3 && c->g.n2 >= 64 && c->g.n1 <= 65535 && c->g.n0 <= 65535 && !(c->tune & 16384)) {
         // volumes: 3-D grid, no per-element index divisions (DXH_FUSED_TUNE bit 16384: the generic kernel)
         const dim3 grid((unsigned)((c->g.n2 + 255) / 256), (unsigned)c->g.n1, (unsigned)c->g.n0);
