@@ -559,14 +559,58 @@ __device__ __forceinline__ void div_shared(const T (&x)[NQ], T d, T (&q)[NQ]) {
 // the sign of a zero result (which no later operation can tell apart: b = q - d, t = ell (b - d) and the
 // downloaded d compare equal) -- q > k: RN(q - k); q < -k: RN(q + k) = -RN(|q| - k); else q - q = 0.  One
 // v_med3_f32 and a (packable) subtraction instead of and / sub / max / bfi.  For k < 0 or NaN the forms differ.
+// ---- the isotropic shrink factor  max(s - k, 0) / (s + 1e-18),  s = sqrt(x)  (split_bregman_tvd.py:119-121) --------------
+// float: the square-root chain above starts from y = rsq(x) ~ 1 / s, so the reciprocal of the divisor is one Newton step
+// away:  rho = fma(fma(-s, y, 1), y, y).  For x in [2^-60, 2^60) the divisor s + 1e-18f IS s (1e-18 < ulp(s) / 2 from
+// s = 2^-30 on) and rho IS RN(1 / s) for every such x but the 120 whose root has an all-ones significand (screened out
+// below) -- decided by trying all of them on the device (k_isofac_rcp_check /
+// dxh_isofac_probe; the test suite runs it).  With an exact RN(1 / s) the five-operation refinement (div_by_const, the
+// same theorem and provisos as div_shared: numerator zero or not tiny, nothing under- or overflows -- the numerator
+// s - k is zero or at least ulp(s) / 2 >= 2^-54 here, the quotient lies in [0, 1]) yields RN(num / s): 2 + 5 operations
+// instead of the ~13 issue slots of the IEEE sequence (v_div_scale x 2, quarter-rate v_rcp, 4 fma, v_div_fmas,
+// v_div_fixup).  x == 0 (flat regions: common) goes the same way: the numerator is 0 and so is every term.
+// Anything else -- x outside the range, k < 0 or NaN -- takes the IEEE expressions on a rarely executed branch.
+// The whole routine is compared with the IEEE expressions on ~1e10 pseudo-random (x, k) pairs by the same probe.
+constexpr float kIsoLo = 0x1p-60f, kIsoHi = 0x1p+60f;
+__device__ __forceinline__ void iso_s_fac_fast(float x, float k, float& s, float& fac, bool& ok) {
+    const float y = __builtin_amdgcn_rsqf(fmaxf(x, kSqrtFastMin));
+    const float g = x * y, h = 0.5f * y;
+    s = fmaf(fmaf(-g, g, x), h, g);                      // t_sqrt_chain(x)
+    const float rho = fmaf(fmaf(-s, y, 1.0f), y, y);     // RN(1 / s) on [2^-60, 2^60) (exhaustive check)
+    const float num = (s - k) > 0.0f ? (s - k) : 0.0f;   // t_max0
+    fac = div_by_const<float>(num, s, rho);
+    // (the one s per binade whose significand is all ones is the classical exception of the Newton step: there rho is
+    // one ulp short of RN(1 / s) -- 120 of the 1.0e9 inputs, found by the exhaustive check; they take the IEEE branch)
+    // k >= 0 (what mu / ell is for any sensible input; false for NaN) keeps the numerator within [0, s]: nothing overflows
+    ok = k >= 0.0f && (((x >= kIsoLo && x < kIsoHi) && (__float_as_uint(s) & 0x7FFFFFu) != 0x7FFFFFu) || x == 0.0f);
+}
+template <typename T>
+__device__ __forceinline__ void iso_s_fac(T x, T k, T& s, T& fac) {
+#ifndef DXH_ISO_IEEE  // A/B builds: the IEEE expressions everywhere
+    if constexpr (std::is_same<T, float>::value) {
+        bool ok;
+        iso_s_fac_fast(x, k, s, fac, ok);
+        if (__builtin_expect(__any(!ok), 0)) {
+            if (!ok) {
+                s = t_sqrt(x);
+                fac = t_max0(s - k) / (s + 1e-18f);
+            }
+        }
+        return;
+    }
+#endif
+    s = t_sqrt(x);
+    fac = t_max0(s - k) / (s + T(1e-18));
+}
+
 template <typename T, int DIM, bool ISO, bool FASTSIGN = false>
 __device__ __forceinline__ void split_vars(const T (&q)[DIM], T k, T (&d)[DIM], T (&b)[DIM]) {
     if constexpr (ISO) {
         T s = T(0);
 #pragma unroll
         for (int j = 0; j < DIM; ++j) s = s + q[j] * q[j];
-        s = t_sqrt(s);
-        T fac = t_max0(s - k) / (s + T(1e-18));
+        T fac;
+        iso_s_fac<T>(s, k, s, fac);
 #pragma unroll
         for (int j = 0; j < DIM; ++j) {
             d[j] = q[j] * fac;

@@ -626,7 +626,8 @@ static DBPlanes<T> make_db(Ctx* c) {
 
 template <typename T, int DIM>
 static void launch_rhs(Ctx* c, bool iso, bool from_db) {
-    const dim3 grid = elem_grid(c->g), blk(256);
+    const Geom& gx = c->g;
+    const dim3 grid = elem_grid(gx), blk(256);
     auto q = make_q<T, DIM>(c, c->cur, c->cur);
     auto db = make_db<T>(c);
     auto co = make_coef<T>(c);
@@ -636,26 +637,27 @@ static void launch_rhs(Ctx* c, bool iso, bool from_db) {
         cp.diag = nullptr;
     }
     if (from_db)
-        hipLaunchKernelGGL((k_rhs<T, DIM, false, true>), grid, blk, 0, c->stream, c->g, (const T*)c->of, q, db, co, cp, (T*)c->rs);
+        hipLaunchKernelGGL((k_rhs<T, DIM, false, true>), grid, blk, 0, c->stream, gx, (const T*)c->of, q, db, co, cp, (T*)c->rs);
     else if (iso)
-        hipLaunchKernelGGL((k_rhs<T, DIM, true, false>), grid, blk, 0, c->stream, c->g, (const T*)c->of, q, db, co, cp, (T*)c->rs);
+        hipLaunchKernelGGL((k_rhs<T, DIM, true, false>), grid, blk, 0, c->stream, gx, (const T*)c->of, q, db, co, cp, (T*)c->rs);
     else
-        hipLaunchKernelGGL((k_rhs<T, DIM, false, false>), grid, blk, 0, c->stream, c->g, (const T*)c->of, q, db, co, cp, (T*)c->rs);
+        hipLaunchKernelGGL((k_rhs<T, DIM, false, false>), grid, blk, 0, c->stream, gx, (const T*)c->of, q, db, co, cp, (T*)c->rs);
 }
 
 template <typename T, int DIM>
 static void launch_shrink(Ctx* c, const void* unew, bool iso, bool from_db) {
-    const dim3 grid = elem_grid(c->g), blk(256);
+    const Geom& gx = c->g;
+    const dim3 grid = elem_grid(gx), blk(256);
     auto q = make_q<T, DIM>(c, c->cur, c->cur);  // in place: each thread touches only its own element
     auto db = make_db<T>(c);
     auto co = make_coef<T>(c);
     auto cp = make_planes<T>(c);
     if (from_db)
-        hipLaunchKernelGGL((k_shrink<T, DIM, false, true>), grid, blk, 0, c->stream, c->g, (const T*)unew, q, db, co, cp);
+        hipLaunchKernelGGL((k_shrink<T, DIM, false, true>), grid, blk, 0, c->stream, gx, (const T*)unew, q, db, co, cp);
     else if (iso)
-        hipLaunchKernelGGL((k_shrink<T, DIM, true, false>), grid, blk, 0, c->stream, c->g, (const T*)unew, q, db, co, cp);
+        hipLaunchKernelGGL((k_shrink<T, DIM, true, false>), grid, blk, 0, c->stream, gx, (const T*)unew, q, db, co, cp);
     else
-        hipLaunchKernelGGL((k_shrink<T, DIM, false, false>), grid, blk, 0, c->stream, c->g, (const T*)unew, q, db, co, cp);
+        hipLaunchKernelGGL((k_shrink<T, DIM, false, false>), grid, blk, 0, c->stream, gx, (const T*)unew, q, db, co, cp);
 }
 
 // dim = 3: the whole iteration in one pass (k_fused3d)
@@ -747,7 +749,8 @@ static void launch_jacobi(Ctx* c, const void* xin, void* xout) {
                            make_coef<T>(c), make_planes<T>(c), (T*)xout);
         return;
     }
-    hipLaunchKernelGGL((k_jacobi<T>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const T*)c->rs, (const T*)xin,
+    const Geom& gx = c->g;
+    hipLaunchKernelGGL((k_jacobi<T>), elem_grid(gx), dim3(256), 0, c->stream, gx, (const T*)c->rs, (const T*)xin,
                        make_coef<T>(c), make_planes<T>(c), (T*)xout);
 }
 
@@ -2667,6 +2670,64 @@ int dxh_rcp_probe(int device, unsigned long long* mismatches, unsigned long long
     unsigned long long bad2 = 0, n2 = 0;
     rc = run_probe(device, k_div_shared_check, &bad2, &n2);   // 8192 x 256 x 4096 operand sets
     *mismatches += bad2;
+    return rc;
+}
+
+// The isotropic shrink factor (iso_s_fac_fast, dxh_common.h).  (a) every float x in [2^-60, 2^60): the rsq-seeded reciprocal
+// against RN(1 / sqrt(x)), and s + 1e-18f == s;  (b) the whole routine against the IEEE expressions on pseudo-random (x, k):
+// raw bit patterns, image-like ranges, k just below / above s, zeros.
+__global__ void __launch_bounds__(256) k_isofac_rcp_check(unsigned long long* mismatches, unsigned long long* tested) {
+    unsigned long long bad = 0, n = 0;
+    const unsigned long long lo = __float_as_uint(kIsoLo), hi = __float_as_uint(kIsoHi);
+    for (unsigned long long b = lo + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; b < hi;
+         b += (unsigned long long)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float((unsigned)b);
+        const float y = __builtin_amdgcn_rsqf(fmaxf(x, kSqrtFastMin));
+        const float g = x * y, h = 0.5f * y;
+        const float s = fmaf(fmaf(-g, g, x), h, g);
+        const float rho = fmaf(fmaf(-s, y, 1.0f), y, y);
+        const bool excepted = (__float_as_uint(s) & 0x7FFFFFu) == 0x7FFFFFu;   // iso_s_fac_fast sends these to the IEEE branch
+        const bool same = (excepted || __float_as_uint(rho) == __float_as_uint(1.0f / s)) &&
+                          __float_as_uint(s + 1e-18f) == __float_as_uint(s) && __float_as_uint(s) == __float_as_uint(sqrtf(x));
+        bad += same ? 0 : 1;
+        ++n;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+    atomicAdd(tested, n);
+}
+__global__ void __launch_bounds__(256) k_isofac_check(unsigned long long* mismatches, unsigned long long* tested) {
+    unsigned long long bad = 0, n = 0;
+    const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (unsigned long long it = 0; it < 4096; ++it) {
+        const unsigned long long base = (tid * 4096 + it) * 4;
+        const unsigned mode = mix32(base + 3) % 4;
+        float x, k;
+        const unsigned r0 = mix32(base), r1 = mix32(base + 1);
+        if (mode == 0) { x = __uint_as_float(r0); k = __uint_as_float(r1); }                               // any bit patterns
+        else if (mode == 1) { x = ldexpf(1.0f + (r0 & 0x7FFFFF) * 0x1p-23f, (int)((r0 >> 23) % 40) - 30);   // image-like magnitudes
+                              k = ldexpf(1.0f + (r1 & 0x7FFFFF) * 0x1p-23f, (int)((r1 >> 23) % 24) - 20); }
+        else if (mode == 2) { x = ldexpf(1.0f + (r0 & 0x7FFFFF) * 0x1p-23f, (int)((r0 >> 23) % 30) - 20);   // k within a few ulps of s
+                              k = __uint_as_float(__float_as_uint(sqrtf(x)) + (int)(r1 % 9) - 4); }
+        else { x = (r0 & 1) ? 0.0f : __uint_as_float(r0 & 0x7FFFFFFFu); k = (r1 & 1) ? 0.0f : ldexpf(1.0f, (int)((r1 >> 1) % 200) - 100); }
+        float s, fac;
+        iso_s_fac<float>(x, k, s, fac);
+        const float s_ref = t_sqrt(x);
+        const float fac_ref = t_max0(s_ref - k) / (s_ref + 1e-18f);
+        auto eq = [](float a, float b) { return (a != a) ? (b != b) : (__float_as_uint(a) == __float_as_uint(b)); };
+        bad += (eq(s, s_ref) && eq(fac, fac_ref)) ? 0 : 1;
+        ++n;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+    atomicAdd(tested, n);
+}
+
+int dxh_isofac_probe(int device, unsigned long long* mismatches_rcp, unsigned long long* mismatches_fac, unsigned long long* tested) {
+    DXH_REQUIRE(mismatches_rcp && mismatches_fac && tested, "null argument");
+    unsigned long long n1 = 0, n2 = 0;
+    int rc = run_probe(device, k_isofac_rcp_check, mismatches_rcp, &n1);
+    if (rc) return rc;
+    rc = run_probe(device, k_isofac_check, mismatches_fac, &n2);
+    *tested = n1 + n2;
     return rc;
 }
 

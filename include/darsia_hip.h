@@ -348,6 +348,10 @@ int dxh_sqrt_probe(int device, unsigned long long* mismatches, unsigned long lon
  * floats, image-like magnitudes, values around the screen's thresholds): *mismatches must come back 0.
  */
 int dxh_rcp_probe(int device, unsigned long long* mismatches, unsigned long long* tested);
+/* The isotropic shrink factor max(s - k, 0) / (s + 1e-18) of the float kernels (dxh_common.h: iso_s_fac_fast): the
+ * rsq-seeded reciprocal against RN(1 / s) for EVERY float x = s^2 in [2^-60, 2^60) (mismatches_rcp), and the whole routine
+ * against the IEEE expressions on ~8.6e9 pseudo-random (x, k) pairs (mismatches_fac). */
+int dxh_isofac_probe(int device, unsigned long long* mismatches_rcp, unsigned long long* mismatches_fac, unsigned long long* tested);
 
 /*
  * One-shot Jacobi solve  mass * x - diffusion * laplace(x) = rhs  (jacobi.py:74-133),

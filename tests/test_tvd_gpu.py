@@ -365,6 +365,18 @@ def test_square_root_chain_is_the_correctly_rounded_square_root_for_every_float(
     assert bad.value == 0 and n.value == 0x71800000 - 0x0D800000 + 1
 
 
+def test_isotropic_shrink_factor_reciprocal_route_is_exact():
+    """The float kernels form max(s - k, 0) / (s + 1e-18) through a reciprocal seeded by the square root's own rsq
+    (dxh_common.h: iso_s_fac_fast): that reciprocal is RN(1 / s) for every float s^2 in [2^-60, 2^60) (exhaustive), and
+    the routine with its screens equals the IEEE expressions on 8.6e9 pseudo-random operand pairs."""
+    import ctypes as C
+
+    bad_r, bad_f, n = C.c_ulonglong(1), C.c_ulonglong(1), C.c_ulonglong(0)
+    _lib.check(_lib.load().dxh_isofac_probe(_lib.default_device(), C.byref(bad_r), C.byref(bad_f), C.byref(n)))
+    assert bad_r.value == 0 and bad_f.value == 0
+    assert n.value == (0x5D800000 - 0x21800000) + 8192 * 256 * 4096
+
+
 @pytest.mark.parametrize("shape", [(24, 24, 24), (9, 17, 70), (40, 33, 129), (3, 5, 2), (70, 26, 57), (1, 1, 9)])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("maxiter", [2, 3, 4, 5, 7, 20])
