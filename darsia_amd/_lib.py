@@ -35,7 +35,7 @@ EXPORTS = (
     "dxh_comm_unique_id", "dxh_comm_create_rccl", "dxh_comm_create_host", "dxh_comm_destroy", "dxh_comm_allreduce",
     "dxh_comm_barrier", "dxh_comm_info", "dxh_tvd_attach_comm", "dxh_tvd_exchange", "dxh_tvd_run_slab",
     "dxh_mem_alloc", "dxh_mem_free", "dxh_mem_copy", "dxh_sqrt_probe", "dxh_rcp_probe", "dxh_tvd_solve_banded", "dxh_mem_trim", "dxh_tps_eval_pair", "dxh_tvd_set_coeffs_typed", "dxh_tvd_slab_stats",
-    "dxh_phase_correlation_q", "dxh_isofac_probe", "dxh_tvd_set_promotion", "dxh_tvd_upload_typed", "dxh_tvd_download_typed",
+    "dxh_phase_correlation_q", "dxh_scale", "dxh_isofac_probe", "dxh_tvd_set_promotion", "dxh_tvd_upload_typed", "dxh_tvd_download_typed",
 )
 
 # host-staged transport callbacks (include/darsia_hip.h: dxh_comm_exchange_fn, dxh_comm_allreduce_fn)
@@ -167,6 +167,7 @@ def _declare(lib):
                                          C.POINTER(i)]
     lib.dxh_sqrt_probe.argtypes = [i, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     lib.dxh_rcp_probe.argtypes = [i, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
+    lib.dxh_scale.argtypes = [i, i, C.c_size_t, vp, dbl, vp]
     lib.dxh_isofac_probe.argtypes = [i, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     lib.dxh_mem_alloc.argtypes = [i, C.c_size_t, C.POINTER(vp)]
     lib.dxh_mem_free.argtypes = [i, vp]

@@ -1540,6 +1540,13 @@ __global__ void __launch_bounds__(256) k_convert_dense(const TS* __restrict__ sr
     if (i < n) dst[i] = (TD)src[i];
 }
 
+// dense array times a scalar rounded to the array's type first (what NumPy does for ``python_float * array``)
+template <typename T>
+__global__ void __launch_bounds__(256) k_scale_dense(const T* __restrict__ src, T s, T* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = s * src[i];
+}
+
 namespace {
 // k_signal<T, CH, S, B> for the types the arguments name
 template <typename T, int CH, typename S, typename B>
@@ -2469,6 +2476,22 @@ int dxh_tvd_adapt_ell(dxh_tvd_t h) {
     else     { if (c->desc.dim == 2) DXH_AD(double, 2); else DXH_AD(double, 3); }
 #undef DXH_AD
     DXH_HIP(hipGetLastError());
+    return DXH_OK;
+}
+
+int dxh_scale(int device, int dtype, size_t n, const void* src, double factor, void* dst) {
+    DXH_REQUIRE(src && dst, "null argument");
+    DXH_REQUIRE(dtype == DXH_F32 || dtype == DXH_F64, "dtype must be float32 or float64");
+    DXH_REQUIRE(is_device_ptr(src) && is_device_ptr(dst), "dxh_scale works on device arrays (dxh_mem_alloc)");
+    DXH_HIP(hipSetDevice(device));
+    hipStream_t st = nullptr;
+    DXH_HIP(cached_stream(device, &st));
+    if (n == 0) return DXH_OK;
+    const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
+    if (dtype == DXH_F32) hipLaunchKernelGGL((k_scale_dense<float>), grid, blk, 0, st, (const float*)src, (float)factor, (float*)dst, n);
+    else hipLaunchKernelGGL((k_scale_dense<double>), grid, blk, 0, st, (const double*)src, factor, (double*)dst, n);
+    DXH_HIP(hipGetLastError());
+    DXH_HIP(hipStreamSynchronize(st));
     return DXH_OK;
 }
 

@@ -10,15 +10,50 @@ from typing import Optional
 import numpy as np
 
 from .. import _lib
+from ..device import DeviceArray
 from ..image import with_array
 from ..utils.linear_solvers.jacobi import Jacobi
 from ..utils.linear_solvers.solver import Solver
+
+
+def _h1_device(img: DeviceArray, mu: float, omega: float, dim: int, solver: Solver) -> DeviceArray:
+    """Device-resident image in, device-resident result out (the reference chains in host memory,
+    h1_regularization.py:39-73): the Jacobi solve with rhs = omega * img formed on the device; MG / CG objects get the
+    right-hand side as a second device array.  Channel-wise (``img.ndim == dim + 1``) only in the one-launch form, i.e.
+    Jacobi without a tolerance."""
+    if type(omega) not in (float, int):
+        raise NotImplementedError("device-resident H1_regularization needs omega as a Python number")
+    if not isinstance(solver, Jacobi):
+        if img.ndim != dim:
+            raise NotImplementedError("device-resident H1_regularization with MG / CG: arrays of exactly dim axes")
+        rhs = DeviceArray(img.shape, img.dtype, img.device)
+        try:
+            _lib.check(_lib.load().dxh_scale(img.device, _lib.dtype_code(img.dtype), img.size, img.ptr, float(omega), rhs.ptr))
+            return solver(img, rhs)
+        finally:
+            rhs.close()
+    if img.ndim == dim + 1 and dim == 2 and solver.tol is None:
+        nsum = _lib.NSUM_SPATIAL
+    elif img.ndim == dim:
+        nsum = _lib.NSUM_ALL_AXES
+    else:
+        raise NotImplementedError("device-resident H1_regularization: (H, W[, C]) with Jacobi(tol=None), or arrays of dim axes")
+    ndim, n0, n1, n2 = _lib.shape3(img.shape, dim)
+    out = DeviceArray(img.shape, img.dtype, img.device)
+    done = C.c_int(0)
+    _lib.check(_lib.load().dxh_jacobi_solve(
+        img.device, _lib.dtype_code(img.dtype), ndim, dim, nsum, n0, n1, n2, img.ptr, None, out.ptr,
+        float(omega), None, float(mu), None, 1.0, int(solver.maxiter), -1.0 if solver.tol is None else float(solver.tol),
+        C.byref(done)))
+    return out
 
 
 def _h1_array(img: np.ndarray, mu: float, omega: float, dim: int, solver: Solver) -> np.ndarray:
     if img.dtype.kind != "f":
         raise TypeError("H1_regularization needs a float32/float64 image")
     solver.update_params(mass_coeff=omega, diffusion_coeff=mu, dim=dim)
+    if isinstance(img, DeviceArray):
+        return _h1_device(img, mu, omega, dim, solver)
     if not isinstance(solver, Jacobi):
         # MG / CG objects (device solvers themselves): the reference's generic flow, channel by channel
         # (h1_regularization.py:54-70)
@@ -66,7 +101,7 @@ def H1_regularization(img, mu: float, omega: float = 1.0, dim: int = 2, solver: 
     """Inline application of H1 regularisation to an array or an Image-like object."""
     if solver is None:
         solver = Jacobi()
-    if isinstance(img, np.ndarray):
+    if isinstance(img, (np.ndarray, DeviceArray)):
         return _h1_array(img, mu, omega, dim, solver)
     if hasattr(img, "img") and hasattr(img, "copy"):
         return with_array(img, _h1_array(img.img, mu, omega, dim, solver))

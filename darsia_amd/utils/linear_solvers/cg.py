@@ -13,16 +13,18 @@ from typing import Optional
 import numpy as np
 
 from ... import _lib
+from ...device import DeviceArray
 from .mg import _DeviceSolverHandle
 from .solver import Solver
 
 
 class CG(Solver):
     def __call__(self, x0: np.ndarray, rhs: np.ndarray, h: Optional[float] = None) -> np.ndarray:
-        x0 = np.asarray(x0)
+        if not isinstance(x0, DeviceArray):     # device-resident operands stay in HBM (DeviceArray in, DeviceArray out)
+            x0 = np.asarray(x0)
         if x0.dtype.kind != "f":
             raise TypeError("CG needs float32 / float64 arrays")
-        if np.shape(rhs) != x0.shape:
+        if tuple(rhs.shape if isinstance(rhs, DeviceArray) else np.shape(rhs)) != tuple(x0.shape):
             raise AssertionError("x0 and rhs must have the same shape")  # cg.py:33
         if self.tol is None:
             raise TypeError("CG needs a tolerance (scipy.sparse.linalg.cg(tol=None) fails in the reference as well)")

@@ -16,6 +16,7 @@ import ctypes as C
 import numpy as np
 
 from ... import _lib
+from ...device import DeviceArray
 from .solver import Solver
 
 
@@ -31,21 +32,29 @@ class Jacobi(Solver):
     def __call__(self, x0: np.ndarray, rhs: np.ndarray, h: float = 1.0) -> np.ndarray:
         if self.mass_coeff is None or self.diffusion_coeff is None:
             raise ValueError("mass_coeff and diffusion_coeff must be set (update_params)")
-        x0 = np.asarray(x0)
+        # device-resident operands stay in HBM: DeviceArray in (x0, and rhs of the same dtype), DeviceArray out
+        on_device = isinstance(x0, DeviceArray)
+        if not on_device:
+            x0 = np.asarray(x0)
         code = _lib.dtype_code(x0.dtype)
-        rhs = np.ascontiguousarray(rhs, dtype=x0.dtype)
-        if rhs.shape != x0.shape:
+        if isinstance(rhs, DeviceArray):
+            if rhs.dtype != x0.dtype:
+                raise TypeError("a device-resident rhs must have x0's dtype")
+        else:
+            rhs = np.ascontiguousarray(rhs, dtype=x0.dtype)
+        if tuple(rhs.shape) != tuple(x0.shape):
             raise ValueError("x0 and rhs must have the same shape")
         ndim, n0, n1, n2 = _lib.shape3(x0.shape, min(self.dim, x0.ndim))
         _lib.require_gpu()
-        m_s, m_a = _coef(self.mass_coeff, x0)
-        k_s, k_a = _coef(self.diffusion_coeff, x0)
-        src = np.ascontiguousarray(x0)
-        out = np.empty(src.shape, src.dtype)
+        like = np.empty((), x0.dtype) if on_device else x0
+        m_s, m_a = _coef(self.mass_coeff, np.broadcast_to(like, x0.shape) if on_device else x0)
+        k_s, k_a = _coef(self.diffusion_coeff, np.broadcast_to(like, x0.shape) if on_device else x0)
+        src = x0 if on_device else np.ascontiguousarray(x0)
+        out = DeviceArray(src.shape, src.dtype, src.device) if on_device else np.empty(src.shape, src.dtype)
         done = C.c_int(0)
         tol = -1.0 if self.tol is None else float(self.tol)
         _lib.check(_lib.load().dxh_jacobi_solve(
-            _lib.default_device(), code, ndim, self.dim, _lib.NSUM_ALL_AXES, n0, n1, n2,
+            src.device if on_device else _lib.default_device(), code, ndim, self.dim, _lib.NSUM_ALL_AXES, n0, n1, n2,
             _lib.ptr(src), _lib.ptr(rhs), _lib.ptr(out), m_s, _lib.ptr(m_a), k_s, _lib.ptr(k_a), float(h),
             int(self.maxiter), tol, C.byref(done)))
         if self.verbose:

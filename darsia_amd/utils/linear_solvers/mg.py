@@ -20,6 +20,7 @@ from typing import Optional, Union
 import numpy as np
 
 from ... import _lib
+from ...device import DeviceArray
 from .solver import Solver
 
 
@@ -70,9 +71,16 @@ class _DeviceSolverHandle:
         _lib.check(self.lib.dxh_solver_set_params(self._h, m_s, _lib.ptr(m_a), k_s, _lib.ptr(k_a)))
 
     def solve(self, x0, rhs):
-        x0 = np.ascontiguousarray(x0, dtype=self.dtype)
-        rhs = np.ascontiguousarray(rhs, dtype=self.dtype)
-        out = np.empty(x0.shape, x0.dtype)
+        # device-resident operands (DeviceArray x0 of the solver's dtype) stay in HBM and give a DeviceArray
+        on_device = isinstance(x0, DeviceArray)
+        for a in (x0, rhs):
+            if isinstance(a, DeviceArray) and a.dtype != self.dtype:
+                raise TypeError(f"device-resident operands must have the solver's dtype {self.dtype}")
+        if not on_device:
+            x0 = np.ascontiguousarray(x0, dtype=self.dtype)
+        if not isinstance(rhs, DeviceArray):
+            rhs = np.ascontiguousarray(rhs, dtype=self.dtype)
+        out = DeviceArray(x0.shape, x0.dtype, x0.device) if on_device else np.empty(x0.shape, x0.dtype)
         n = C.c_int32(0)
         _lib.check(self.lib.dxh_solver_solve(self._h, _lib.ptr(x0), _lib.ptr(rhs), _lib.ptr(out), C.byref(n)))
         return out, n.value
@@ -118,10 +126,11 @@ class MG(Solver):
         return self._dev
 
     def __call__(self, x0: np.ndarray, rhs: np.ndarray) -> np.ndarray:
-        x0 = np.asarray(x0)
+        if not isinstance(x0, DeviceArray):
+            x0 = np.asarray(x0)
         if x0.dtype.kind != "f":
             raise TypeError("MG needs float32 / float64 arrays")
-        if np.shape(rhs) != x0.shape:
+        if tuple(np.shape(rhs) if not isinstance(rhs, DeviceArray) else rhs.shape) != tuple(x0.shape):
             raise ValueError("x0 and rhs must have the same shape")
         dev = self._device(x0)
         out, cycles = dev.solve(x0, rhs)

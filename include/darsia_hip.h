@@ -74,6 +74,10 @@ int dxh_mem_alloc(int device, size_t bytes, void** ptr);
 int dxh_mem_free(int device, void* ptr);
 /* synchronous copy between any two of {host array, device array} */
 int dxh_mem_copy(int device, void* dst, const void* src, size_t bytes);
+/* dst = factor * src on dense DEVICE arrays of n elements, the factor rounded to the array's type first -- what NumPy does
+ * for ``python_float * array`` (H1_regularization's right-hand side omega * img, restoration/h1_regularization.py:73, for
+ * images that are in HBM already). */
+int dxh_scale(int device, int dtype, size_t n, const void* src, double factor, void* dst);
 /*
  * The TV contexts and dxh_mem_free keep the planes / arrays they release in a cache (exact-size re-use; at most 1/16 of the device memory,
  * DXH_POOL_MB overrides, 0 turns it off): hipFree costs 0.1 - 0.3 ms per plane and waits for the device, a whole call

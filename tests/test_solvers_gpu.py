@@ -173,3 +173,35 @@ def test_h1_regularization_with_cg_and_mg():
         ref = so.MG(depth=1, smoother_iterations=3, maxiter=2, dim=2, mass_coeff=1.0, diffusion_coeff=0.2)(
             np.ascontiguousarray(img[..., c]), 1.0 * np.ascontiguousarray(img[..., c]))
         np.testing.assert_array_equal(out[..., c], ref)
+
+
+def test_device_resident_chaining_through_jacobi_mg_cg_and_h1():
+    """The reference chains these in host memory (restoration/h1_regularization.py:39-73, utils/linear_solvers/*.py); an
+    image that is in HBM already (DeviceArray) goes through them without crossing PCIe and comes back as a DeviceArray
+    with the bits of the host-array call."""
+    import darsia_amd as da
+
+    rng = np.random.default_rng(3)
+    for dtype in (np.float32, np.float64):
+        x0 = rng.random((70, 90)).astype(dtype)
+        rhs = rng.random((70, 90)).astype(dtype)
+        d_x0, d_rhs = da.DeviceArray.from_host(x0), da.DeviceArray.from_host(rhs)
+        for solver in (da.Jacobi(maxiter=5, mass_coeff=0.7, diffusion_coeff=0.3), da.Jacobi(maxiter=30, tol=1e-4, mass_coeff=0.7, diffusion_coeff=0.3),
+                       da.MG(depth=2, smoother_iterations=3, maxiter=4, mass_coeff=0.7, diffusion_coeff=0.3),
+                       da.CG(maxiter=50, tol=1e-6, mass_coeff=0.7, diffusion_coeff=0.3)):
+            want = solver(x0, rhs)
+            got = solver(d_x0, d_rhs)
+            assert isinstance(got, da.DeviceArray) and got.dtype == want.dtype and np.array_equal(got.get(), want), type(solver).__name__
+            assert np.array_equal(solver(d_x0, rhs).get(), want)       # a host right-hand side next to a device iterate
+        # H1_regularization: gray and colour images, Jacobi / MG
+        col = rng.random((40, 60, 3)).astype(dtype)
+        for img, solver in ((x0, da.Jacobi(maxiter=7)), (col, da.Jacobi(maxiter=4)), (x0, da.MG(depth=2, smoother_iterations=2, maxiter=3)),
+                            (x0, da.CG(maxiter=40, tol=1e-6))):
+            want = da.H1_regularization(img, mu=0.4, omega=1.3, dim=2, solver=solver)
+            got = da.H1_regularization(da.DeviceArray.from_host(img), mu=0.4, omega=1.3, dim=2, solver=solver)
+            assert isinstance(got, da.DeviceArray) and np.array_equal(got.get(), want), type(solver).__name__
+        out = da.H1_regularization(da.ScalarImage(da.DeviceArray.from_host(x0)), mu=0.4, omega=1.3, solver=da.Jacobi(maxiter=3))
+        assert isinstance(out.img, da.DeviceArray)
+        assert np.array_equal(out.img.get(), da.H1_regularization(x0, mu=0.4, omega=1.3, solver=da.Jacobi(maxiter=3)))
+    with pytest.raises(NotImplementedError):
+        da.H1_regularization(da.DeviceArray.from_host(col), mu=0.4, omega=1.3, solver=da.Jacobi(maxiter=9, tol=1e-3))
