@@ -120,6 +120,12 @@ def extract_quadrilateral_ROI(img_src: np.ndarray, pts_src=None, indexing: str =
     rec.nx, rec.ny = int(width), int(height)
     rec.bw0 = _opencv_block_width(int(width), int(height))
     src = img_src
+    if isinstance(img_src, DeviceArray):
+        # an image that is in HBM already is warped into a new device array; the result has the source's shape there,
+        # so only a target of that shape (the default) stays device-resident
+        if (int(height), int(width)) != (h, w):
+            raise NotImplementedError("device-resident extract_quadrilateral_ROI: target shape = source shape")
+        return warp_patches(img_src, [rec])
     if height > h or width > w:
         # the kernel writes a canvas of the source's shape: a target larger than the source gets both embedded in their
         # common bounding shape, the source rectangle (sh, sw) still ends where the image ends

@@ -545,6 +545,248 @@ __global__ void __launch_bounds__(256) k_march3d(Geom g, const T* __restrict__ o
     }
 }
 
+// ============================================================================================
+// The 2.5-D march with FOUR ADJACENT columns per thread (float, n2 % 4 == 0).  k_march3d above gives a thread four columns
+// 256 apart: every column pays its own index arithmetic, predicates and 4-byte loads / stores / LDS accesses -- ~560 VALU
+// instructions per column and plane against ~36 per element in the 2-D pipelines, which is what bounds it (VALU issue 0.45,
+// waves waiting 70 %, one barrier per plane).  Here a thread owns columns l2 .. l2 + 3 of one patch row: 16-byte global and
+// LDS accesses, one set of predicates, and three of the four column neighbours (u, t_2, u_new) are the thread's own
+// registers; only the outer two come from LDS (or, on the rim, from global memory).  Patch: 256 / TPR rows x 4 TPR
+// columns; the last row and the last FOUR columns are the forward rim (u_new only), so patches tile with a stride of
+// (256 / TPR - 1, 4 TPR - 4) and every vector access stays 16-byte aligned.  Same expressions in the same order as k_march3d: same bits.
+// ============================================================================================
+template <bool ISO>
+__global__ void __launch_bounds__(256, (ISO ? 3 : 4)) k_march3d_v(Geom g, const float* __restrict__ of, QPlanes<float, 3> q,
+                                                    const float* __restrict__ u_in, float* __restrict__ u_out, Coef<float> c,
+                                                    CoefPlanes<float> cp, int nt1, int nt2, int nchunk, int ppc, int TPR) {
+    using T = float;
+    // TPR threads (= 4 TPR columns) per patch row, 256 / TPR rows: the host picks the TPR in 4 .. 64 whose patches waste the
+    // fewest rim and overhang columns on this volume (e.g. 17 for 256 columns: four patches of 64 owned + 4 rim columns)
+    constexpr int N = 4, COLS = 1024;
+    const int M2 = TPR * N, P1R = 256 / TPR, kM1 = P1R - 1, kM2 = M2 - N;
+    __shared__ __align__(16) T s_u[2][COLS], s_t1[2][COLS], s_t2[2][COLS], s_un[2][COLS];
+    const int total = nt1 * nt2 * nchunk;
+    const int per_xcd = (total + 7) >> 3;
+    const int bid = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (bid >= total) return;  // block-uniform
+    const int tt2 = bid % nt2, tt1 = (bid / nt2) % nt1, chunk = bid / (nt2 * nt1);
+    const int64_t P0 = (int64_t)chunk * ppc;
+    if (P0 >= g.n0) return;  // block-uniform
+    const int64_t P1 = (P0 + ppc < g.n0) ? P0 + ppc : g.n0;
+    const int64_t Pend = (P1 < g.n0) ? P1 : g.n0 - 1;  // last plane whose u_new is needed
+    const int l1 = (int)threadIdx.x / TPR, lq = (int)threadIdx.x % TPR, l2 = lq * N;
+    const int col = l1 * M2 + l2;                        // first of the thread's four LDS slots (< P1R * M2 <= 1024)
+    const int64_t i1 = (int64_t)tt1 * kM1 + l1, i2 = (int64_t)tt2 * kM2 + l2;
+    const bool in = l1 < P1R && i1 < g.n1 && i2 < g.n2;  // n2 % 4 == 0: the four columns are inside together
+    const bool owned = in && l1 < kM1 && lq < TPR - 1;
+    const bool e1m = i1 > 0, e1p = i1 < g.n1 - 1, e2m = i2 > 0, e2p = i2 + N < g.n2;   // e2m: column 0's left, e2p: column 3's right
+    int64_t off = P0 * g.pitch + i1 * g.n2 + i2;
+
+    auto ld4 = [](const T* p, T (&v)[N]) { load_vec(p, v); };
+    auto lds_ld4 = [](const T* p, T (&v)[N]) { load_vec(p, v); };
+    auto lds_st4 = [](T* p, const T (&v)[N]) { store_vec(p, v); };
+    auto coef4 = [&](const T* plane, T scalar, int64_t o, T (&v)[N]) {
+        if (plane) load_vec(plane + o, v);
+        else {
+#pragma unroll
+            for (int j = 0; j < N; ++j) v[j] = scalar;
+        }
+    };
+    // t = ell (b - d) and b of four columns from their q
+    auto split4 = [&](const T (&q0)[N], const T (&q1)[N], const T (&q2)[N], const T (&ell)[N], const T (&kq)[N], T (&t)[3][N], T (&b)[3][N]) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            T qq[3] = {q0[j], q1[j], q2[j]}, d[3], bb[3];
+            split_vars<T, 3, ISO>(qq, kq[j], d, bb);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { t[a][j] = ell[j] * (bb[a] - d[a]); b[a][j] = bb[a]; }
+        }
+    };
+    auto coef1 = [&](const T* plane, T scalar, int64_t o) -> T { return plane ? plane[o] : scalar; };
+
+    T um[N], uc[N], up[N], t0m[N], tcur[3][N], bcur[3][N], ofc[N], unm[N], bm[3][N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        um[j] = uc[j] = up[j] = t0m[j] = ofc[j] = unm[j] = T(0);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) tcur[a][j] = bcur[a][j] = bm[a][j] = T(0);
+    }
+    if (in) {
+        const int64_t o = off;
+        ld4(u_in + o, uc);
+        ld4(u_in + (P0 > 0 ? o - g.pitch : o), um);
+        ld4(u_in + (P0 < g.n0 - 1 ? o + g.pitch : o), up);
+        ld4(of + o, ofc);
+        T q0[N], q1[N], q2[N], ell[N], kq[N];
+        ld4(q.in[0] + o, q0); ld4(q.in[1] + o, q1); ld4(q.in[2] + o, q2);
+        coef4(cp.ell, c.ell, o, ell); coef4(cp.kq, c.kq, o, kq);
+        split4(q0, q1, q2, ell, kq, tcur, bcur);
+        if (P0 > 0) {
+            const int64_t ob = o - g.pitch;
+            T r0[N], r1[N], r2[N], el[N], kk[N], tt[3][N], bb[3][N];
+            ld4(q.in[0] + ob, r0);
+            if constexpr (ISO) { ld4(q.in[1] + ob, r1); ld4(q.in[2] + ob, r2); }
+            else {
+#pragma unroll
+                for (int j = 0; j < N; ++j) r1[j] = r2[j] = T(0);
+            }
+            coef4(cp.ell, c.ell, ob, el); coef4(cp.kq, c.kq, ob, kk);
+            if constexpr (ISO) {
+                split4(r0, r1, r2, el, kk, tt, bb);
+#pragma unroll
+                for (int j = 0; j < N; ++j) t0m[j] = tt[0][j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const T qq[1] = {r0[j]};
+                    T d[1], b1[1];
+                    split_vars<T, 1, false>(qq, kk[j], d, b1);
+                    t0m[j] = el[j] * (b1[0] - d[0]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < N; ++j) t0m[j] = tcur[0][j];  // the one-sided difference at the first plane is t - t
+        }
+        lds_st4(&s_u[P0 & 1][col], uc);
+        lds_st4(&s_t1[P0 & 1][col], tcur[1]);
+        lds_st4(&s_t2[P0 & 1][col], tcur[2]);
+    }
+    __syncthreads();
+
+    for (int64_t p = P0; p <= Pend; ++p) {
+        const int s = (int)(p & 1);
+        const bool have_next = p + 1 <= Pend;
+        if (in) {
+            const int64_t o = off;
+            T nq0[N], nq1[N], nq2[N], nof[N], nu2[N], nell[N], nkq[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) nq0[j] = nq1[j] = nq2[j] = nof[j] = nu2[j] = nell[j] = nkq[j] = T(0);
+            if (have_next) {
+                const int64_t on = o + g.pitch;
+                ld4(q.in[0] + on, nq0); ld4(q.in[1] + on, nq1); ld4(q.in[2] + on, nq2);
+                ld4(of + on, nof);
+                ld4(u_in + (p + 2 < g.n0 ? on + g.pitch : on), nu2);
+                coef4(cp.ell, c.ell, on, nell); coef4(cp.kq, c.kq, on, nkq);
+            }
+            // in-plane neighbours of u(p)
+            T u_rm[N], u_rp[N];
+            if (!e1m) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) u_rm[j] = uc[j];
+            } else if (l1 > 0) lds_ld4(&s_u[s][col - M2], u_rm);
+            else ld4(u_in + o - g.n2, u_rm);
+            if (!e1p) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) u_rp[j] = uc[j];
+            } else if (l1 < kM1) lds_ld4(&s_u[s][col + M2], u_rp);
+            else ld4(u_in + o + g.n2, u_rp);
+            const T u_left = !e2m ? uc[0] : (l2 > 0 ? s_u[s][col - 1] : u_in[o - 1]);
+            const T u_right = !e2p ? uc[N - 1] : (lq < TPR - 1 ? s_u[s][col + N] : u_in[o + N]);
+            // t_1 one row up, t_2 one column left
+            T t1n[N];
+            if (!e1m) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) t1n[j] = tcur[1][j];
+            } else if (l1 > 0) lds_ld4(&s_t1[s][col - M2], t1n);
+            else {
+#pragma unroll
+                for (int j = 0; j < N; ++j)
+                    t1n[j] = t_comp_at<T, ISO>(q, o - g.n2 + j, 1, coef1(cp.ell, c.ell, o - g.n2 + j), coef1(cp.kq, c.kq, o - g.n2 + j));
+            }
+            T t2_left;
+            if (!e2m) t2_left = tcur[2][0];
+            else if (l2 > 0) t2_left = s_t2[s][col - 1];
+            else t2_left = t_comp_at<T, ISO>(q, o - 1, 2, coef1(cp.ell, c.ell, o - 1), coef1(cp.kq, c.kq, o - 1));
+            T diag[N], dsc[N], unp[N];
+            coef4(cp.diag, c.diag, o, diag); coef4(cp.dsc, c.dsc, o, dsc);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                T rr = ofc[j];
+                rr = rr + (tcur[0][j] - t0m[j]);
+                rr = rr + (tcur[1][j] - t1n[j]);
+                rr = rr + (tcur[2][j] - (j == 0 ? t2_left : tcur[2][j - 1]));
+                const T rs = rr / diag[j];
+                T acc = T(0);
+                acc = acc + um[j];
+                acc = acc + up[j];
+                acc = acc + u_rm[j];
+                acc = acc + u_rp[j];
+                acc = acc + (j == 0 ? u_left : uc[j - 1]);
+                acc = acc + (j == N - 1 ? u_right : uc[j + 1]);
+                unp[j] = rs + acc / dsc[j];
+            }
+            lds_st4(&s_un[s][col], unp);
+            // plane p - 1 is complete now: u_new(p - 1) goes out, q_j <- D_j u_new + b_j
+            if (p > P0 && owned) {
+                const int sm = s ^ 1;
+                const int64_t ob = o - g.pitch;
+                T n1v[N];
+                if (e1p) lds_ld4(&s_un[sm][col + M2], n1v);
+                else {
+#pragma unroll
+                    for (int j = 0; j < N; ++j) n1v[j] = unm[j];
+                }
+                const T un_right = e2p ? s_un[sm][col + N] : unm[N - 1];
+                T o0[N], o1[N], o2[N];
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    o0[j] = (unp[j] - unm[j]) + bm[0][j];
+                    o1[j] = (n1v[j] - unm[j]) + bm[1][j];
+                    o2[j] = ((j == N - 1 ? un_right : unm[j + 1]) - unm[j]) + bm[2][j];
+                }
+                store_vec(u_out + ob, unm);
+                store_vec(q.out[0] + ob, o0);
+                store_vec(q.out[1] + ob, o1);
+                store_vec(q.out[2] + ob, o2);
+            }
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                unm[j] = unp[j];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) bm[a][j] = bcur[a][j];
+                t0m[j] = tcur[0][j];
+                um[j] = uc[j];
+                uc[j] = up[j];
+                up[j] = nu2[j];
+            }
+            off = o + g.pitch;
+            if (have_next) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) ofc[j] = nof[j];
+                split4(nq0, nq1, nq2, nell, nkq, tcur, bcur);
+                lds_st4(&s_u[s ^ 1][col], uc);
+                lds_st4(&s_t1[s ^ 1][col], tcur[1]);
+                lds_st4(&s_t2[s ^ 1][col], tcur[2]);
+            }
+        }
+        __syncthreads();
+    }
+    // the volume's last plane: no plane below, its axis-0 difference is zero
+    if (P1 == g.n0 && owned) {
+        const int sm = (int)((g.n0 - 1) & 1);
+        const int64_t ob = off - g.pitch;  // off has moved one plane past the last one computed
+        T n1v[N];
+        if (e1p) lds_ld4(&s_un[sm][col + M2], n1v);
+        else {
+#pragma unroll
+            for (int j = 0; j < N; ++j) n1v[j] = unm[j];
+        }
+        const T un_right = e2p ? s_un[sm][col + N] : unm[N - 1];
+        T o0[N], o1[N], o2[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            o0[j] = (unm[j] - unm[j]) + bm[0][j];
+            o1[j] = (n1v[j] - unm[j]) + bm[1][j];
+            o2[j] = ((j == N - 1 ? un_right : unm[j + 1]) - unm[j]) + bm[2][j];
+        }
+        store_vec(u_out + ob, unm);
+        store_vec(q.out[0] + ob, o0);
+        store_vec(q.out[1] + ob, o1);
+        store_vec(q.out[2] + ob, o2);
+    }
+}
+
 // explicit-(d, b) variant of the shrink step, used when the state cannot be kept compressed (adaptive ell:
 // the threshold changes between the iteration that produced d, b and the one that consumes them)
 template <typename T, int DIM, bool ISO>
@@ -1738,7 +1980,9 @@ struct Pipe {
         }
     }
 
-    template <int PH, int ROLE = 0>
+    // ACT: stages 0 .. ACT - 1 run, the others are skipped (the first steps of a chunk, fused_pipe_body: a stage has nothing
+    // valid to work on before its predecessors have produced two rows)
+    template <int PH, int ROLE = 0, int ACT = K>
     __device__ __forceinline__ void step(PipeState<T, K>& st, IncT<T> (&inc)[NORM ? K : 1][N], const int64_t r) const {
         constexpr int PFD = ROLE == 0 ? pipe_pfd<T, K, HET>() : 1;  // prefetch distance in steps
         constexpr bool INTRA_LDS = ROLE == 0;               // of / q1 hand-off between own stages through LDS
@@ -1787,7 +2031,7 @@ struct Pipe {
         }
         if constexpr (ROLE == 1) xput(12 + (PH & 3), st.of0);  // forward omega*f[row r] to the tail wave
         T q0h[N];  // Q0 of the next level at the next stage's row, handed from stage to stage
-        static_for<0, K>([&](auto sc) {
+        static_for<0, ACT>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             constexpr int c = (PH - s) & 3;          // ring slot of this stage's row
             constexpr int cm = (c + 3) & 3, cp = (c + 1) & 3;
@@ -2234,7 +2478,28 @@ __device__ __forceinline__ void fused_pipe_body(const FusedArgs<T>& a, const int
 #pragma unroll
         for (int i = 0; i < K; ++i) *(volatile T*)(linc_lane + i * kWave) = T(0);
     }
-    for (int64_t r = rs; r <= r_end; r += 4) {
+    // Start-up.  Stage s first matters at step 2 s - 1 of the chunk: its first VALID row is rs + s (step 2 s), and the
+    // step before builds the (t0, b0) it carries from the row above; earlier it would only turn zeros into garbage that
+    // nothing reads.  So the first groups of four steps run with act(t) = min(K, (t + 1) / 2 + 1) stages -- 2.25 of a K = 4
+    // chunk's row steps less (3 % of an 80-row chunk).  -DDXH_NO_STAGE_SKIP: all stages from the first step (A/B).
+    int64_t r = rs;
+#ifndef DXH_NO_STAGE_SKIP
+    // (not in the isotropic and array-coefficient instantiations: they sit at their register limit, and the extra code
+    // paths cost them scratch -- isotropic RGB K = 4: 20 bytes per lane and +6.5 % time, profiles/r03_stage_skip_ab.txt)
+    if constexpr (!ISO && !HET) {
+        constexpr int NG = (2 * K - 4) / 4 + 1;   // groups that contain a step with fewer than K active stages
+        static_for<0, NG>([&](auto gc) {
+            constexpr int t0 = 4 * decltype(gc)::value;
+            constexpr auto act = [](int t) { return (t + 1) / 2 + 1 < K ? (t + 1) / 2 + 1 : K; };
+            pp.template step<0, 0, act(t0)>(st, inc, r);
+            pp.template step<1, 0, act(t0 + 1)>(st, inc, r + 1);
+            pp.template step<2, 0, act(t0 + 2)>(st, inc, r + 2);
+            pp.template step<3, 0, act(t0 + 3)>(st, inc, r + 3);
+            r += 4;
+        });
+    }
+#endif
+    for (; r <= r_end; r += 4) {
         pp.template step<0>(st, inc, r);
         pp.template step<1>(st, inc, r + 1);
         pp.template step<2>(st, inc, r + 2);

@@ -489,7 +489,7 @@ int dxh_phase_correlation(int device, int H, int W, int C, int dtype, const void
  * correlation surface of two UNRELATED patterns reaches (unit-modulus cross-power spectrum), a flat patch gives 0, two equal
  * patterns 1.  min_peak_ratio = 0 switches the test off (NaN shifts are rejected in any case).  peaks (npatch doubles, or
  * NULL): the peak value per patch.  (The reference's ORB + RANSAC estimator reports such patches as not intact and lets the
- * spline interpolate over them: translationanalysis.py:262-283.)
+ * spline interpolate over them: translationanalysis.py:225-275.)
  */
 int dxh_phase_correlation_q(int device, int H, int W, int C, int dtype, const void* img_src, const void* img_dst, int npatch,
                             const int32_t* rois, double max_shift_fraction, double min_peak_ratio, double* shifts, int32_t* ok,

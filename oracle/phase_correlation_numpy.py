@@ -20,7 +20,7 @@ Per patch pair (a = source patch, b = destination patch, same pixel rectangle of
     is the level the maximum of the surface reaches for two UNRELATED patterns (each of the N values is the mean of N unit
     phases, standard deviation 1 / sqrt(2 N)); a flat patch has a zero transform and a surface of zeros, two equal patterns a
     peak of 1.  (The reference's ORB + RANSAC estimator reports such patches as not intact and the spline interpolates over
-    them, translationanalysis.py:262-283.)
+    them, translationanalysis.py:225-275.)
 """
 import numpy as np
 

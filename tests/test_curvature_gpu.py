@@ -197,6 +197,12 @@ def test_extract_quadrilateral_roi_against_the_reference_function():
         assert np.array_equal(da.extract_quadrilateral_ROI(src32, pts_src=quad, interpolation="inter_area"), g["roi/list_reverse"])
         with pytest.raises(NotImplementedError):
             da.extract_quadrilateral_ROI(src32, pts_src=quad, interpolation="bicubic")
+        # an image that is in HBM already stays there (target shape = source shape, the default)
+        for name, kw in (("default", {}), ("list_reverse", dict(pts_src=quad))):
+            d = da.extract_quadrilateral_ROI(da.DeviceArray.from_host(src32), **kw)
+            assert isinstance(d, da.DeviceArray) and np.array_equal(d.get(), g[f"roi/{name}"]), name
+        with pytest.raises(NotImplementedError):
+            da.extract_quadrilateral_ROI(da.DeviceArray.from_host(src32), pts_src=quad, shape=(55, 75))
 
 
 def test_extract_quadrilateral_roi_target_larger_than_the_source():

@@ -91,7 +91,7 @@ def test_patches_in_several_passes_give_the_same_shifts(monkeypatch):
 
 
 def test_flat_noise_only_nan_and_mostly_masked_patches_are_not_intact():
-    """What the reference's ORB + RANSAC matcher reports as not intact (translationanalysis.py:262-283) must not become a
+    """What the reference's ORB + RANSAC matcher reports as not intact (translationanalysis.py:225-275) must not become a
     control point of the spline here either: a flat patch, two unrelated noise patches, a patch holding a NaN, a patch
     most of which is masked out.  Flags equal the NumPy statement's; the peak values agree."""
     rng = np.random.default_rng(12)

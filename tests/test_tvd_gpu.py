@@ -301,7 +301,35 @@ def test_early_stop_with_temporal_blocking(golden, monkeypatch, name, eps, fuse_
     assert_bits(out2, O.split_bregman_tvd(img, mu=0.1, max_num_iter=7, promotion="strict"))
 
 
-@pytest.mark.parametrize("shape", [(24, 24, 24), (9, 17, 70), (1, 5, 3), (33, 8, 129), (8, 9, 64), (17, 1, 1)])
+@pytest.mark.parametrize("m2", ["64", "68", "128", "184", "256", "16"])
+@pytest.mark.parametrize("kind", ["aniso", "iso", "het"])
+def test_vectorised_volume_march_every_patch_shape(monkeypatch, m2, kind):
+    """k_march3d_v (float volumes with n2 % 4 == 0: four adjacent columns per thread) with each of its patch shapes forced
+    (patch widths from 16 to 256 columns, incl. 68 and 184 whose thread rows do not divide 256), on volumes that span several patches along both in-plane axes with ragged ends, against the
+    three kernels and the oracle; and with several plane chunks (DXH_NCHUNKS)."""
+    monkeypatch.setenv("DXH_MARCH_M2", m2)
+    rng = np.random.default_rng(int(m2))
+    for shape, chunks in (((11, 21, 268), None), ((26, 37, 132), "5"), ((2, 3, 4), None)):
+        if chunks:
+            monkeypatch.setenv("DXH_NCHUNKS", chunks)
+        else:
+            monkeypatch.delenv("DXH_NCHUNKS", raising=False)
+        vol = rng.random(shape).astype(np.float32)
+        mu = (0.03 + 0.2 * rng.random(shape)).astype(np.float32) if kind == "het" else 0.1
+        outs = {}
+        for name, flags in (("march", 0), ("three_kernel", _lib.FLAG_NO_FUSED)):
+            with da.DeviceTVD(vol.shape, vol.dtype, dim=3) as st:
+                st.set_coeffs(mu, 0.7, None, vol)
+                st.upload(vol)
+                st.run(4, isotropic=kind == "iso", flags=flags)
+                outs[name] = st.download(want_split=True)
+        for a, b in zip(outs["march"], outs["three_kernel"]):
+            assert_bits(a, b)
+        assert_bits(outs["march"][0], O.split_bregman_tvd(vol, mu=mu, omega=0.7, dim=3, max_num_iter=4, isotropic=kind == "iso",
+                                                          promotion="strict"))
+
+
+@pytest.mark.parametrize("shape", [(24, 24, 24), (9, 17, 70), (1, 5, 3), (33, 8, 129), (8, 9, 64), (17, 1, 1), (19, 37, 132)])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("kind", ["aniso", "iso", "het"])
 def test_fused_volume_sweep_equals_three_kernels_and_oracle(shape, dtype, kind):

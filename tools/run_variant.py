@@ -1,5 +1,5 @@
 """A few launches of one pipeline at the BASELINE size, for profiling (tools/sq_any.sh).
-usage: run_variant.py aniso|iso|het|chambolle|warp|vol3d|gray|f64"""
+usage: run_variant.py aniso|iso|het|chambolle|warp|vol3d|gray|f64|np2|np2arr|jacobi3d"""
 import sys
 sys.path.insert(0, ".")
 import numpy as np
@@ -31,3 +31,12 @@ elif v == "warp":
 elif v == "vol3d":
     vol = np.random.default_rng(0).random((256, 256, 256)).astype(np.float32)
     st = da.DeviceTVD(vol.shape, vol.dtype, dim=3); st.set_coeffs(0.1, 1.0, None, vol); st.upload(vol); st.run(8); st.close()
+elif v in ("np2", "np2arr"):
+    img = synthetic_image(H, W, 3)
+    mu = 0.1 if v == "np2" else 0.1 * (0.3 + 0.7 * np.random.default_rng(1).random(img.shape))
+    st = da.DeviceTVD(img.shape, img.dtype, promotion="numpy2"); st.set_coeffs(mu, 1.0, 0.2, img); st.upload(img)
+    r = st.run(12); print(v, "ms/iter", r.loop_ms / 12, "launches", r.launches); st.close()
+elif v == "jacobi3d":
+    vol = np.random.default_rng(0).random((256, 256, 256)).astype(np.float32)
+    st = da.DeviceTVD(vol.shape, vol.dtype, dim=3); st.set_coeffs(0.1, 1.0, None, vol); st.upload(vol)
+    r = st.run(3, jacobi_maxiter=20); print(v, "ms/outer iteration", r.loop_ms / 3, "launches", r.launches); st.close()
