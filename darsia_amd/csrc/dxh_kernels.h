@@ -546,23 +546,22 @@ __global__ void __launch_bounds__(256) k_march3d(Geom g, const T* __restrict__ o
 }
 
 // ============================================================================================
-// The 2.5-D march with FOUR ADJACENT columns per thread (float, n2 % 4 == 0).  k_march3d above gives a thread four columns
+// The 2.5-D march with N = 16 B / sizeof(T) ADJACENT columns per thread (four floats, two doubles; n2 % N == 0).  k_march3d above gives a thread four columns
 // 256 apart: every column pays its own index arithmetic, predicates and 4-byte loads / stores / LDS accesses -- ~560 VALU
 // instructions per column and plane against ~36 per element in the 2-D pipelines, which is what bounds it (VALU issue 0.45,
 // waves waiting 70 %, one barrier per plane).  Here a thread owns columns l2 .. l2 + 3 of one patch row: 16-byte global and
-// LDS accesses, one set of predicates, and three of the four column neighbours (u, t_2, u_new) are the thread's own
+// LDS accesses, one set of predicates, and the inner column neighbours (u, t_2, u_new) are the thread's own
 // registers; only the outer two come from LDS (or, on the rim, from global memory).  Patch: 256 / TPR rows x 4 TPR
 // columns; the last row and the last FOUR columns are the forward rim (u_new only), so patches tile with a stride of
-// (256 / TPR - 1, 4 TPR - 4) and every vector access stays 16-byte aligned.  Same expressions in the same order as k_march3d: same bits.
+// (256 / TPR - 1, N TPR - N) and every vector access stays 16-byte aligned (written for N = 4 below: "four" = N).  Same expressions in the same order as k_march3d: same bits.
 // ============================================================================================
-template <bool ISO>
-__global__ void __launch_bounds__(256, (ISO ? 3 : 4)) k_march3d_v(Geom g, const float* __restrict__ of, QPlanes<float, 3> q,
-                                                    const float* __restrict__ u_in, float* __restrict__ u_out, Coef<float> c,
-                                                    CoefPlanes<float> cp, int nt1, int nt2, int nchunk, int ppc, int TPR) {
-    using T = float;
+template <typename T, bool ISO>
+__global__ void __launch_bounds__(256, (sizeof(T) == 8 ? 2 : (ISO ? 3 : 4))) k_march3d_v(Geom g, const T* __restrict__ of, QPlanes<T, 3> q,
+                                                    const T* __restrict__ u_in, T* __restrict__ u_out, Coef<T> c,
+                                                    CoefPlanes<T> cp, int nt1, int nt2, int nchunk, int ppc, int TPR) {
     // TPR threads (= 4 TPR columns) per patch row, 256 / TPR rows: the host picks the TPR in 4 .. 64 whose patches waste the
     // fewest rim and overhang columns on this volume (e.g. 17 for 256 columns: four patches of 64 owned + 4 rim columns)
-    constexpr int N = 4, COLS = 1024;
+    constexpr int N = VecOf<T>::N, COLS = 256 * N;   // 16 bytes per thread: four floats / two doubles
     const int M2 = TPR * N, P1R = 256 / TPR, kM1 = P1R - 1, kM2 = M2 - N;
     __shared__ __align__(16) T s_u[2][COLS], s_t1[2][COLS], s_t2[2][COLS], s_un[2][COLS];
     const int total = nt1 * nt2 * nchunk;

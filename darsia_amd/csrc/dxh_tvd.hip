@@ -670,17 +670,18 @@ static void launch_fused3d(Ctx* c, int in, int out, bool iso) {
     }
     // float: the 2.5-D march; double: the brick kernel (the march needs 255 registers there and loses, 0.42 vs 0.39 ms on
     // 256^3); DXH_FUSED_TUNE bit 4096 forces the bricks, 8192 the march
-    if constexpr (std::is_same<T, float>::value) {
-        if (c->g.n2 % 4 == 0 && !(c->tune & (4096 | 8192 | 1048576))) {
-            // float volumes whose rows are 16-byte multiples: the march with four adjacent columns per thread
-            // (k_march3d_v; DXH_FUSED_TUNE bit 1048576: the one-column-at-a-time march below, A/B)
-            // Threads per patch row (TPR; patch = 256 / TPR rows x 4 TPR columns).  What a width costs depends on more than
+    {
+        constexpr int NV = VecOf<T>::N;
+        if (c->g.n2 % NV == 0 && !(c->tune & (4096 | 8192 | 1048576))) {
+            // volumes whose rows are 16-byte multiples: the march with NV = 16 B / sizeof(T) adjacent columns per thread
+            // (k_march3d_v; DXH_FUSED_TUNE bit 1048576: the one-column-at-a-time march / the bricks below, A/B)
+            // Threads per patch row (TPR; patch = 256 / TPR rows x NV TPR columns).  What a width costs depends on more than
             // the wasted rim and overhang columns (rim columns recompute t_2 from global memory, wide rows coalesce better, the
             // plane chunks must fill the resident-block slots), so for volumes of a million voxels and more the candidates
             // are TIMED once per (shape, variant) on the first launch -- the launch is idempotent (in and out planes differ) --
             // and the choice is remembered; small volumes take the width with the least waste.  Results never depend on it.
             auto launch_with = [&](int tpr) {
-                const int o1 = 256 / tpr - 1, o2 = 4 * tpr - 4;
+                const int o1 = 256 / tpr - 1, o2 = NV * tpr - NV;
                 const int nt1 = (int)((c->g.n1 + o1 - 1) / o1), nt2 = (int)((c->g.n2 + o2 - 1) / o2);
                 auto launch = [&](auto kernel) {
                     int bpc = 0;
@@ -692,21 +693,21 @@ static void launch_fused3d(Ctx* c, int in, int out, bool iso) {
                     if (c->force_chunks > 0) ppc = std::max<int64_t>(1, (c->g.n0 + c->force_chunks - 1) / c->force_chunks);
                     nchunk = (c->g.n0 + ppc - 1) / ppc;
                     const int64_t total = nchunk * tiles;
-                    if (c->tune & 512) fprintf(stderr, "[dxh] march3d_v patch %dx%d tiles %lld chunks %lld (%lld planes) blocks/CU %d\n", o1 + 1, o2 + 4, (long long)tiles, (long long)nchunk, (long long)ppc, bpc);
-                    hipLaunchKernelGGL(kernel, dim3((unsigned)((total + 7) / 8 * 8)), dim3(256), 0, c->stream, c->g, (const float*)c->of, q,
-                                       (const float*)c->u[in], (float*)c->u[out], make_coef<float>(c), make_planes<float>(c), nt1, nt2,
+                    if (c->tune & 512) fprintf(stderr, "[dxh] march3d_v patch %dx%d tiles %lld chunks %lld (%lld planes) blocks/CU %d\n", o1 + 1, o2 + NV, (long long)tiles, (long long)nchunk, (long long)ppc, bpc);
+                    hipLaunchKernelGGL(kernel, dim3((unsigned)((total + 7) / 8 * 8)), dim3(256), 0, c->stream, c->g, (const T*)c->of, q,
+                                       (const T*)c->u[in], (T*)c->u[out], make_coef<T>(c), make_planes<T>(c), nt1, nt2,
                                        (int)nchunk, (int)ppc, tpr);
                 };
-                if (iso) launch(k_march3d_v<true>); else launch(k_march3d_v<false>);
+                if (iso) launch(k_march3d_v<T, true>); else launch(k_march3d_v<T, false>);
             };
             auto least_waste = [&]() {
                 int tpr = 16;
                 double best = -1.0;
                 for (int t = 4; t <= 64; ++t) {
-                    const int o1 = 256 / t - 1, o2 = 4 * t - 4;
+                    const int o1 = 256 / t - 1, o2 = NV * t - NV;
                     if (o1 < 1) continue;
                     const double tiles = (double)((c->g.n1 + o1 - 1) / o1) * (double)((c->g.n2 + o2 - 1) / o2);
-                    const double eff = (double)c->g.n1 * (double)c->g.n2 / (tiles * 1024.0);   // useful columns per thread slot
+                    const double eff = (double)c->g.n1 * (double)c->g.n2 / (tiles * 256.0 * NV);   // useful columns per thread slot
                     if (eff > best * 1.001) { best = eff; tpr = t; }
                 }
                 return tpr;
@@ -714,13 +715,13 @@ static void launch_fused3d(Ctx* c, int in, int out, bool iso) {
             int tpr = 0;
             if (const char* e = getenv("DXH_MARCH_M2")) {  // developer knob: patch width in columns
                 const int v = atoi(e);
-                if (v >= 16 && v <= 256 && v % 4 == 0) tpr = v / 4;
+                if (v >= 4 * NV && v <= 64 * NV && v % NV == 0) tpr = v / NV;
             }
             static const bool tune_on = [] { const char* e = getenv("DXH_MARCH_TUNE"); return !(e && atoi(e) == 0); }();
             if (!tpr && tune_on && c->g.n0 * c->g.n1 * c->g.n2 >= (int64_t(1) << 20) && !c->force_chunks && !c->waves_per_cu) {
                 static std::mutex mtx;
                 static std::map<std::array<int64_t, 5>, int> chosen;
-                const std::array<int64_t, 5> key = {c->g.n0, c->g.n1, c->g.n2, (int64_t)iso, (int64_t)c->het};
+                const std::array<int64_t, 5> key = {c->g.n0, c->g.n1, c->g.n2, (int64_t)iso + 2 * (int64_t)sizeof(T), (int64_t)c->het};
                 {
                     std::lock_guard<std::mutex> lk(mtx);
                     auto it = chosen.find(key);
@@ -729,7 +730,7 @@ static void launch_fused3d(Ctx* c, int in, int out, bool iso) {
                 if (!tpr) {
                     std::vector<int> cand = {16, least_waste()};
                     for (int k = 1; k <= 4; ++k) {   // k patches exactly across axis 2
-                        const int t = (int)((c->g.n2 + 4 * k - 1) / (4 * k)) + 1;
+                        const int t = (int)((c->g.n2 + NV * k - 1) / (NV * k)) + 1;
                         if (t >= 8 && t <= 64) cand.push_back(t);
                     }
                     std::sort(cand.begin(), cand.end());
@@ -746,7 +747,7 @@ static void launch_fused3d(Ctx* c, int in, int out, bool iso) {
                                 float m = 1e30f;
                                 if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&m, e0, e1) == hipSuccess) ms = std::min(ms, m);
                             }
-                            if (c->tune & 512) fprintf(stderr, "[dxh] march3d_v tuning: %d columns per patch row: %.4f ms\n", 4 * t, ms);
+                            if (c->tune & 512) fprintf(stderr, "[dxh] march3d_v tuning: %d columns per patch row: %.4f ms\n", NV * t, ms);
                             if (ms < best_ms) { best_ms = ms; tpr = t; }
                         }
                     }

@@ -303,8 +303,9 @@ def test_early_stop_with_temporal_blocking(golden, monkeypatch, name, eps, fuse_
 
 @pytest.mark.parametrize("m2", ["64", "68", "128", "184", "256", "16"])
 @pytest.mark.parametrize("kind", ["aniso", "iso", "het"])
-def test_vectorised_volume_march_every_patch_shape(monkeypatch, m2, kind):
-    """k_march3d_v (float volumes with n2 % 4 == 0: four adjacent columns per thread) with each of its patch shapes forced
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_vectorised_volume_march_every_patch_shape(monkeypatch, m2, kind, dtype):
+    """k_march3d_v (volumes whose rows are 16-byte multiples: four adjacent float / two adjacent double columns per thread) with each of its patch shapes forced
     (patch widths from 16 to 256 columns, incl. 68 and 184 whose thread rows do not divide 256), on volumes that span several patches along both in-plane axes with ragged ends, against the
     three kernels and the oracle; and with several plane chunks (DXH_NCHUNKS)."""
     monkeypatch.setenv("DXH_MARCH_M2", m2)
@@ -314,8 +315,8 @@ def test_vectorised_volume_march_every_patch_shape(monkeypatch, m2, kind):
             monkeypatch.setenv("DXH_NCHUNKS", chunks)
         else:
             monkeypatch.delenv("DXH_NCHUNKS", raising=False)
-        vol = rng.random(shape).astype(np.float32)
-        mu = (0.03 + 0.2 * rng.random(shape)).astype(np.float32) if kind == "het" else 0.1
+        vol = rng.random(shape).astype(dtype)
+        mu = (0.03 + 0.2 * rng.random(shape)).astype(dtype) if kind == "het" else 0.1
         outs = {}
         for name, flags in (("march", 0), ("three_kernel", _lib.FLAG_NO_FUSED)):
             with da.DeviceTVD(vol.shape, vol.dtype, dim=3) as st:
