@@ -254,6 +254,141 @@ __global__ void __launch_bounds__(256) k_shrink(Geom g, const T* __restrict__ un
     }
 }
 
+// k_rhs and k_shrink for volumes (dim = 3, compressed state) in the form of k_jacobi_vol_x: N = 16 B / sizeof(T) adjacent
+// columns per thread, XCD x works a contiguous run of (plane, row) tiles, no per-element index divisions -- and the
+// neighbours' t = ell (b - d) are formed for the ONE component the difference needs (the generic k_rhs splits all three
+// at each of its three neighbours).  These two frame the Jacobi sweeps of a multi-sweep or solver iteration
+// (examples/regularization.py:8-47: Jacobi(maxiter=20)).  Same expressions, same order: same bits.
+template <typename T, bool ISO>
+__global__ void __launch_bounds__(256) k_rhs_vol(Geom g, const T* __restrict__ of, QPlanes<T, 3> q, Coef<T> c, CoefPlanes<T> cp,
+                                                  T* __restrict__ rs, int nbx, int64_t tiles, int64_t per_xcd) {
+    constexpr int N = VecOf<T>::N;
+    const int64_t t = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int64_t)(blockIdx.x >> 3) >= per_xcd || t >= tiles) return;
+    const int64_t row = t / nbx;
+    const int bx = (int)(t - row * nbx);
+    const int64_t i0 = row / g.n1, i1 = row - i0 * g.n1;
+    const int64_t i2 = ((int64_t)bx * 256 + threadIdx.x) * N;
+    if (i2 >= g.n2) return;
+    const int64_t off = i0 * g.pitch + i1 * g.n2 + i2;
+    auto coef4 = [&](const T* plane, T scalar, int64_t o, T (&v)[N]) {
+        if (plane) load_vec(plane + o, v);
+        else {
+#pragma unroll
+            for (int j = 0; j < N; ++j) v[j] = scalar;
+        }
+    };
+    // component `a` of t at N consecutive elements starting at o
+    auto t_comp4 = [&](int64_t o, int a, T (&tv)[N]) {
+        T ell[N], kq[N];
+        coef4(cp.ell, c.ell, o, ell); coef4(cp.kq, c.kq, o, kq);
+        if constexpr (ISO) {
+            T q0[N], q1[N], q2[N];
+            load_vec(q.in[0] + o, q0); load_vec(q.in[1] + o, q1); load_vec(q.in[2] + o, q2);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                T qq[3] = {q0[j], q1[j], q2[j]}, d[3], b[3];
+                split_vars<T, 3, true>(qq, kq[j], d, b);
+                tv[j] = ell[j] * (b[a] - d[a]);
+            }
+        } else {
+            T qa[N];
+            load_vec(q.in[a] + o, qa);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const T qq[1] = {qa[j]};
+                T d[1], b[1];
+                split_vars<T, 1, false>(qq, kq[j], d, b);
+                tv[j] = ell[j] * (b[0] - d[0]);
+            }
+        }
+    };
+    T q0[N], q1[N], q2[N], ofv[N], ell[N], kq[N], diag[N], tc[3][N];
+    load_vec(q.in[0] + off, q0); load_vec(q.in[1] + off, q1); load_vec(q.in[2] + off, q2);
+    load_vec(of + off, ofv);
+    coef4(cp.ell, c.ell, off, ell); coef4(cp.kq, c.kq, off, kq); coef4(cp.diag, c.diag, off, diag);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        T qq[3] = {q0[j], q1[j], q2[j]}, d[3], b[3];
+        split_vars<T, 3, ISO>(qq, kq[j], d, b);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) tc[a][j] = ell[j] * (b[a] - d[a]);
+    }
+    T tn0[N], tn1[N];
+    if (i0 > 0) t_comp4(off - g.pitch, 0, tn0);
+    else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) tn0[j] = tc[0][j];
+    }
+    if (i1 > 0) t_comp4(off - g.n2, 1, tn1);
+    else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) tn1[j] = tc[1][j];
+    }
+    T t2_left = tc[2][0];
+    if (i2 > 0) {
+        const int64_t o = off - 1;
+        const T ell_n = cp.ell ? cp.ell[o] : c.ell, kq_n = cp.kq ? cp.kq[o] : c.kq;
+        if constexpr (ISO) {
+            T qq[3] = {q.in[0][o], q.in[1][o], q.in[2][o]}, d[3], b[3];
+            split_vars<T, 3, true>(qq, kq_n, d, b);
+            t2_left = ell_n * (b[2] - d[2]);
+        } else {
+            const T qq[1] = {q.in[2][o]};
+            T d[1], b[1];
+            split_vars<T, 1, false>(qq, kq_n, d, b);
+            t2_left = ell_n * (b[0] - d[0]);
+        }
+    }
+    T out[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        T r = ofv[j];
+        r = r + (tc[0][j] - tn0[j]);
+        r = r + (tc[1][j] - tn1[j]);
+        r = r + (tc[2][j] - (j == 0 ? t2_left : tc[2][j - 1]));
+        out[j] = r / diag[j];
+    }
+    store_vec(rs + off, out);
+}
+
+template <typename T, bool ISO>
+__global__ void __launch_bounds__(256) k_shrink_vol(Geom g, const T* __restrict__ unew, QPlanes<T, 3> q, Coef<T> c,
+                                                     CoefPlanes<T> cp, int nbx, int64_t tiles, int64_t per_xcd) {
+    constexpr int N = VecOf<T>::N;
+    const int64_t t = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if ((int64_t)(blockIdx.x >> 3) >= per_xcd || t >= tiles) return;
+    const int64_t row = t / nbx;
+    const int bx = (int)(t - row * nbx);
+    const int64_t i0 = row / g.n1, i1 = row - i0 * g.n1;
+    const int64_t i2 = ((int64_t)bx * 256 + threadIdx.x) * N;
+    if (i2 >= g.n2) return;
+    const int64_t off = i0 * g.pitch + i1 * g.n2 + i2;
+    T q0[N], q1[N], q2[N], kq[N], uc[N], ua[N], ub[N];
+    load_vec(q.in[0] + off, q0); load_vec(q.in[1] + off, q1); load_vec(q.in[2] + off, q2);
+    if (cp.kq) load_vec(cp.kq + off, kq);
+    else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) kq[j] = c.kq;
+    }
+    load_vec(unew + off, uc);
+    load_vec(unew + (i0 < g.n0 - 1 ? off + g.pitch : off), ua);
+    load_vec(unew + (i1 < g.n1 - 1 ? off + g.n2 : off), ub);
+    const T right = i2 + N < g.n2 ? unew[off + N] : uc[N - 1];
+    T o0[N], o1[N], o2[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        T qq[3] = {q0[j], q1[j], q2[j]}, d[3], b[3];
+        split_vars<T, 3, ISO>(qq, kq[j], d, b);
+        o0[j] = (ua[j] - uc[j]) + b[0];
+        o1[j] = (ub[j] - uc[j]) + b[1];
+        o2[j] = ((j == N - 1 ? right : uc[j + 1]) - uc[j]) + b[2];
+    }
+    store_vec(q.out[0] + off, o0);
+    store_vec(q.out[1] + off, o1);
+    store_vec(q.out[2] + off, o2);
+}
+
 // ============================================================================================
 // One outer iteration of a dim = 3 problem in ONE pass (examples/regularization.py:8-47 and the PET volumes of
 // examples/paper/pet_simulations_comparison_block_b.py:680-713 are the reference's 3-D use): right-hand side, Jacobi

@@ -605,6 +605,20 @@ static void launch_fused(Ctx* c, int in, int out, bool iso, bool dpp) {
 }
 
 // ---- the three-kernel path ----------------------------------------------------------------------
+// grid of the vectorised volume kernels (k_jacobi_vol_x, k_rhs_vol, k_shrink_vol): tiles = (plane, row, 256-vector block)
+struct VolTiles { int nbx; int64_t tiles, per_xcd; unsigned grid; };
+template <typename T>
+static bool vol_tiles(const Ctx* c, VolTiles* v) {
+    constexpr int NV = VecOf<T>::N;
+    if (!(c->g.ndim == 3 && c->desc.dim == 3 && c->g.n2 >= 64 && c->g.n2 % NV == 0) || (c->tune & (16384 | 262144))) return false;
+    v->nbx = (int)((c->g.n2 / NV + 255) / 256);
+    v->tiles = c->g.n0 * c->g.n1 * v->nbx;
+    v->per_xcd = (v->tiles + 7) / 8;
+    if (v->per_xcd * 8 >= (int64_t)INT32_MAX) return false;
+    v->grid = (unsigned)(v->per_xcd * 8);
+    return true;
+}
+
 template <typename T, int DIM>
 static QPlanes<T, DIM> make_q(Ctx* c, int in, int out) {
     QPlanes<T, DIM> q;
@@ -636,6 +650,14 @@ static void launch_rhs(Ctx* c, bool iso, bool from_db) {
         co.diag = T(1);
         cp.diag = nullptr;
     }
+    if constexpr (DIM == 3) {
+        VolTiles vt;
+        if (!from_db && vol_tiles<T>(c, &vt)) {  // volumes: 16 bytes per lane, XCD-contiguous tiles (k_rhs_vol)
+            if (iso) hipLaunchKernelGGL((k_rhs_vol<T, true>), dim3(vt.grid), blk, 0, c->stream, c->g, (const T*)c->of, q, co, cp, (T*)c->rs, vt.nbx, vt.tiles, vt.per_xcd);
+            else hipLaunchKernelGGL((k_rhs_vol<T, false>), dim3(vt.grid), blk, 0, c->stream, c->g, (const T*)c->of, q, co, cp, (T*)c->rs, vt.nbx, vt.tiles, vt.per_xcd);
+            return;
+        }
+    }
     if (from_db)
         hipLaunchKernelGGL((k_rhs<T, DIM, false, true>), grid, blk, 0, c->stream, gx, (const T*)c->of, q, db, co, cp, (T*)c->rs);
     else if (iso)
@@ -652,6 +674,14 @@ static void launch_shrink(Ctx* c, const void* unew, bool iso, bool from_db) {
     auto db = make_db<T>(c);
     auto co = make_coef<T>(c);
     auto cp = make_planes<T>(c);
+    if constexpr (DIM == 3) {
+        VolTiles vt;
+        if (!from_db && vol_tiles<T>(c, &vt)) {  // volumes: k_shrink_vol
+            if (iso) hipLaunchKernelGGL((k_shrink_vol<T, true>), dim3(vt.grid), blk, 0, c->stream, c->g, (const T*)unew, q, co, cp, vt.nbx, vt.tiles, vt.per_xcd);
+            else hipLaunchKernelGGL((k_shrink_vol<T, false>), dim3(vt.grid), blk, 0, c->stream, c->g, (const T*)unew, q, co, cp, vt.nbx, vt.tiles, vt.per_xcd);
+            return;
+        }
+    }
     if (from_db)
         hipLaunchKernelGGL((k_shrink<T, DIM, false, true>), grid, blk, 0, c->stream, gx, (const T*)unew, q, db, co, cp);
     else if (iso)

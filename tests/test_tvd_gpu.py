@@ -406,7 +406,7 @@ def test_isotropic_shrink_factor_reciprocal_route_is_exact():
     assert n.value == (0x5D800000 - 0x21800000) + 8192 * 256 * 4096
 
 
-@pytest.mark.parametrize("shape", [(24, 24, 24), (9, 17, 70), (40, 33, 129), (3, 5, 2), (70, 26, 57), (1, 1, 9)])
+@pytest.mark.parametrize("shape", [(24, 24, 24), (9, 17, 70), (40, 33, 129), (3, 5, 2), (70, 26, 57), (1, 1, 9), (6, 9, 64), (13, 7, 132)])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("maxiter", [2, 3, 4, 5, 7, 20])
 def test_multi_sweep_jacobi_on_volumes(shape, dtype, maxiter):
