@@ -1,0 +1,76 @@
+"""Developer fuzz for round 3's kernels against the NumPy oracle, bit for bit:
+  (a) the numpy2 promotion flow (k_fused_np2): random 2-D / colour float32 images, scalar or array mu (float32 / float64),
+      scalar omega / ell, eps, special magnitudes -- against the oracle's reference ("numpy2") flow;
+  (b) dim = 3 volumes (k_march3d_v, k_march3d, k_fused3d, k_jacobi_vol_x, k_rhs_vol, k_shrink_vol): random shapes whose rows
+      are / are not 16-byte multiples, float32 / float64, anisotropic / isotropic / array mu, one or several Jacobi sweeps.
+usage: python tests/fuzz/fuzz_r3.py [seed] [cases]"""
+import sys, time
+sys.path.insert(0, ".")
+import numpy as np
+import darsia_amd as da
+from oracle import tvd_numpy as O
+
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+bad = 0
+t0 = time.time()
+
+
+def report(tag, shape, dt, kw, out, ref):
+    global bad
+    bad += 1
+    print("MISMATCH", tag, shape, np.dtype(dt).name, {k: (v if np.ndim(v) == 0 else f"array({v.dtype})") for k, v in kw.items()},
+          "max abs", float(np.abs(out.astype(np.float64) - ref.astype(np.float64)).max()), flush=True)
+
+
+for case in range(n_cases):
+    if case % 2 == 0:
+        # ---- (a) numpy2 flow
+        h, w = int(rng.integers(1, 120)), int(rng.integers(1, 900))
+        c = int(rng.choice([0, 0, 1, 2, 3, 4]))
+        shape = (h, w) if c == 0 else (h, w, c)
+        scale = float(rng.choice([1.0, 1.0, 1.0, 1e-6, 1e4, 255.0]))
+        img = (rng.random(shape) * scale).astype(np.float32)
+        if rng.random() < 0.2:
+            img[rng.random(shape) < 0.3] = 0.0
+        kw = dict(max_num_iter=int(rng.integers(1, 16)), ell=float(rng.choice([0.2, 0.5, 1.0, 3.0])), omega=float(rng.choice([0.5, 1.0, 2.0])))
+        kind = rng.choice(["scalar", "f64", "f32"])
+        if kind == "scalar":
+            kw["mu"] = float(rng.choice([0.0, 0.05, 0.1, 0.3]))
+            if rng.random() < 0.3:
+                del kw["ell"]            # ell = 2 mu as a Python float
+                if kw["mu"] == 0.0:
+                    kw["mu"] = 0.1
+        else:
+            mu = 0.02 + 0.2 * rng.random(shape)
+            if rng.random() < 0.5:
+                mu[rng.random(shape) < 0.2] = 0.0
+            kw["mu"] = mu if kind == "f64" else mu.astype(np.float32)
+        if rng.random() < 0.3:
+            kw["eps"] = float(rng.choice([1e-2, 3e-3]))
+        ref = O.split_bregman_tvd(img, **kw)                                   # the reference's NumPy-2 dtype flow
+        out = da.split_bregman_tvd(img, promotion="numpy2", **kw)
+        if out.dtype != ref.dtype or not np.array_equal(out, ref):
+            report("numpy2", shape, np.float32, kw, out, ref)
+    else:
+        # ---- (b) volumes
+        n0, n1 = int(rng.integers(1, 40)), int(rng.integers(1, 60))
+        n2 = int(rng.choice([rng.integers(1, 300), 4 * rng.integers(1, 80), 64, 68, 128]))
+        shape = (n0, n1, n2)
+        dt = rng.choice([np.float32, np.float64])
+        vol = rng.random(shape).astype(dt)
+        kw = dict(max_num_iter=int(rng.integers(1, 7)), dim=3)
+        het = rng.random() < 0.3
+        kw["mu"] = (0.02 + 0.2 * rng.random(shape)).astype(dt) if het else float(rng.choice([0.05, 0.1, 0.3]))
+        if rng.random() < 0.3:
+            kw["omega"] = float(rng.choice([0.5, 2.0]))
+        if rng.random() < 0.3:
+            kw["ell"] = float(rng.choice([0.3, 1.0]))
+        iso = rng.random() < 0.3
+        jm = int(rng.choice([1, 1, 2, 3, 20]))
+        ref = O.split_bregman_tvd(vol, isotropic=iso, jacobi_maxiter=jm, promotion="strict", **kw)
+        out = da.split_bregman_tvd(vol, isotropic=iso, solver=da.Jacobi(maxiter=jm), **kw)
+        if not np.array_equal(out, ref):
+            report(f"dim3 iso={iso} jm={jm}", shape, dt, kw, out, ref)
+print(f"{n_cases} cases, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
+sys.exit(1 if bad else 0)

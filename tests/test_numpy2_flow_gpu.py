@@ -176,3 +176,15 @@ def test_unsupported_configurations_say_so():
         da.split_bregman_tvd(img.astype(np.float64), mu=0.1, promotion="numpy2")
     with pytest.raises(ValueError):
         da.split_bregman_tvd(img, mu=0.1, promotion="float16")
+
+
+def test_small_random_sweep_of_the_numpy2_flow_and_the_volume_kernels():
+    """A short run of tests/fuzz/fuzz_r3.py inside the suite (80 cases: the numpy2 flow on random 2-D / colour float32 images
+    with scalar, float32-array and float64-array mu, special magnitudes, eps; dim = 3 volumes through the vectorised and
+    the scalar march / sweeps) -- bit for bit against the oracle."""
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_r3.py"), "7", "80"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "80 cases, 0 mismatches" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
