@@ -1431,6 +1431,11 @@ static int exchange_now(Ctx* c) { return start_exchange(c, false); }
 
 template <typename T>
 static void launch_any(Ctx* c, int in, int out, bool iso, bool dpp, int K) {
+    if (c->np2) {
+        if constexpr (std::is_same<T, double>::value) (void)launch_np2(c, in, out);
+        c->np2_first = false;
+        return;
+    }
     if (K >= 2) launch_fused_multi<T>(c, in, out, iso, K);
     else launch_fused<T>(c, in, out, iso, dpp);
 }
@@ -1446,7 +1451,11 @@ static int run_slab_t(Ctx* c, int n_iter, int m, double eps, uint32_t flags, dxh
                           !c->solver && !c->explicit_db && !c->from_db;
     const bool overlap = dist && fused_ok && !(flags & DXH_FLAG_NO_OVERLAP);
     const bool async = (flags & DXH_FLAG_ASYNC) && !use_eps;
-    DXH_REQUIRE(!c->np2, "numpy2 promotion is not available on row slabs");
+    if (c->np2) {   // the reference's float32 dtype flow on slabs: one iteration per launch (k_fused_np2), same exchanges
+        constexpr bool is_double = std::is_same<T, double>::value;
+        DXH_REQUIRE(fused_ok && m == 1 && !iso && is_double && (!c->het || (c->het_cdiag && c->cp_kq)),
+                    "numpy2 promotion on slabs: dim = 2, one Jacobi sweep, anisotropic, scalar omega and ell");
+    }
     if (dist) DXH_REQUIRE(c->halo_top >= m, "halos of %lld rows cannot carry an iteration of %d Jacobi sweeps",
                           (long long)c->halo_top, m);
     if (dist && c->from_db) { set_error("a warm start with explicit split variables is not supported on row slabs"); return DXH_ESTATE; }
@@ -1483,7 +1492,7 @@ static int run_slab_t(Ctx* c, int n_iter, int m, double eps, uint32_t flags, dxh
         const int cap = dist ? (int)std::min<int64_t>(left, c->halo_valid / m) : left;
         int K;
         if (fused_ok) {
-            K = use_eps ? 1 : std::min(pick_k(c, left), cap);
+            K = (use_eps || c->np2) ? 1 : std::min(pick_k(c, left), cap);
             if (K >= 2 && !(dpp && multi_supported(c))) K = 1;
             if (K >= 2 && c->het && K != kHetFuseK) K = 1;
             const int in = c->cur, out = c->cur ^ 1;

@@ -366,11 +366,11 @@ class HipSlabEngine:
     (launches, exchanges, overlap) runs inside ``dxh_tvd_run_slab``."""
 
     def __init__(self, slab_img: np.ndarray, dim: int, mu, omega, ell, boundary, device: int, comm: Comm,
-                 plan: SlabPlan):
+                 plan: SlabPlan, promotion: str = "native"):
         from .restoration.split_bregman_tvd import DeviceTVD
 
         self.comm = comm
-        self.st = DeviceTVD(slab_img.shape, slab_img.dtype, dim=dim, device=device, row_slab=boundary)
+        self.st = DeviceTVD(slab_img.shape, slab_img.dtype, dim=dim, device=device, row_slab=boundary, promotion=promotion)
         self.st.set_coeffs(mu, omega, ell, slab_img)
         self.st.upload(slab_img)
         _lib.check(self.st.lib.dxh_tvd_attach_comm(self.st._h, comm._h, plan.halo_top_rows, plan.halo_bot_rows))
@@ -416,7 +416,8 @@ class SlabTVD:
 
     def __init__(self, plan: SlabPlan, slab_img: np.ndarray, mu=1.0, omega=1.0, ell=None, dim: int = 2,
                  halo_iters: int = 1, jacobi_maxiter: int = 1, isotropic: bool = False, engine_factory=None,
-                 comm: Optional[Comm] = None, transport=None, device: Optional[int] = None, flags: int = 0):
+                 comm: Optional[Comm] = None, transport=None, device: Optional[int] = None, flags: int = 0,
+                 promotion: str = "native"):
         self.plan = plan
         self.k = int(halo_iters)
         self.m = int(jacobi_maxiter)
@@ -443,7 +444,8 @@ class SlabTVD:
                 raise ValueError("communicator and plan disagree on rank / world")
             if device is None:
                 device = comm.device
-            self.engine = HipSlabEngine(slab_img, dim, mu, omega, ell, boundary, device, comm, plan)
+            # promotion="numpy2": the reference's own float32 dtype flow (restoration/split_bregman_tvd.py) on every slab
+            self.engine = HipSlabEngine(slab_img, dim, mu, omega, ell, boundary, device, comm, plan, promotion)
         else:
             if plan.world > 1 and transport is None:
                 raise ValueError("an injected engine needs a host transport")

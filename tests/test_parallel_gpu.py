@@ -45,7 +45,7 @@ def _worker(rank, world, port, case, out_dir):
             mu = np.ascontiguousarray(np.load(os.path.join(out_dir, "mu.npy"))[plan.slab0:plan.slab1])
         flags = _lib.FLAG_NO_OVERLAP if case.get("no_overlap") else 0
         s = SlabTVD(plan, slab, mu=mu, ell=case.get("ell"), dim=case.get("dim", 2), halo_iters=case["halo_iters"], jacobi_maxiter=jm,
-                    isotropic=case.get("iso", False), comm=comm, flags=flags)
+                    isotropic=case.get("iso", False), comm=comm, flags=flags, promotion=case.get("promotion", "native"))
         done = 0
         for part in case.get("parts", [case["n_iter"]]):
             # several calls continue one iteration sequence; all but the last prefetch the halos for the next
@@ -75,7 +75,7 @@ def _spawn(world, case, tmp_path):
 def _reference(img, mu, case):
     import darsia_amd as da
 
-    with da.DeviceTVD(img.shape, img.dtype, dim=case.get("dim", 2)) as st:
+    with da.DeviceTVD(img.shape, img.dtype, dim=case.get("dim", 2), promotion=case.get("promotion", "native")) as st:
         st.set_coeffs(mu, 1.0, case.get("ell"), img)
         st.upload(img)
         res = st.run(case["n_iter"], jacobi_maxiter=case.get("jm", 1), eps=case.get("eps"),
@@ -101,6 +101,10 @@ CASES = {
     "het_mu_array_scalar_ell_eps": dict(shape=(260, 300, 3), world=2, halo_iters=3, n_iter=60, het=True, ell=0.3, eps=4e-3),
     "jacobi_maxiter2": dict(shape=(160, 200, 3), world=2, halo_iters=3, n_iter=7, jm=2),
     "f64": dict(shape=(600, 200, 3), world=2, halo_iters=4, n_iter=12, dtype="float64"),
+    # the reference's float32 dtype flow (k_fused_np2) on slabs: scalar and float64-array mu, three ranks, eps
+    "numpy2_rgb": dict(shape=(330, 300, 3), world=2, halo_iters=5, n_iter=17, promotion="numpy2", ell=1.0),
+    "numpy2_gray_mu64_3ranks": dict(shape=(500, 420), world=3, halo_iters=4, n_iter=13, promotion="numpy2", het=True, mu64=True, ell=0.5),
+    "numpy2_eps": dict(shape=(150, 300, 3), world=2, halo_iters=3, n_iter=60, promotion="numpy2", ell=0.2, eps=4e-3),
 }
 
 
@@ -110,7 +114,7 @@ def test_ranks_on_one_gpu(tmp_path, name):
     rng = np.random.default_rng(3)
     img = rng.random(case["shape"]).astype(case.get("dtype", "float32"))
     np.save(tmp_path / "img.npy", img)
-    mu = (0.03 + 0.1 * rng.random(case["shape"])).astype(np.float32) if case.get("het") else 0.1
+    mu = (0.03 + 0.1 * rng.random(case["shape"])).astype(np.float64 if case.get("mu64") else np.float32) if case.get("het") else 0.1
     if case.get("het"):
         np.save(tmp_path / "mu.npy", mu)
     world = case["world"]
