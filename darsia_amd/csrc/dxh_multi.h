@@ -22,6 +22,12 @@ template <typename T, int K>
 void launch_multi_kernel_c24(int C, bool coupled, bool iso, bool want_inc, bool pair, const FusedArgs<T>& a, unsigned grid,
                              hipStream_t stream);
 
+// the reference's float32 dtype flow (NP2 pipelines, double storage): K = 4 scalar threshold, K = kHetFuseK threshold plane
+template <int K>
+void launch_multi_kernel_np2(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
+extern template void launch_multi_kernel_np2<3>(int, bool, bool, const FusedArgs<double>&, unsigned, hipStream_t);
+extern template void launch_multi_kernel_np2<4>(int, bool, bool, const FusedArgs<double>&, unsigned, hipStream_t);
+
 extern template void launch_multi_kernel<float, 2>(int, bool, bool, bool, bool, const FusedArgs<float>&, unsigned, hipStream_t);
 extern template void launch_multi_kernel<float, 3>(int, bool, bool, bool, bool, const FusedArgs<float>&, unsigned, hipStream_t);
 extern template void launch_multi_kernel<float, 4>(int, bool, bool, bool, bool, const FusedArgs<float>&, unsigned, hipStream_t);

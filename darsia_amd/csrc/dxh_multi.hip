@@ -18,6 +18,26 @@
 #define DXH_HET_K 3  // the K for which the heterogeneous-coefficient pipeline is instantiated (dxh_multi.h)
 #endif
 
+#ifdef DXH_MULTI_NP2
+// ---- the reference's float32 dtype flow (Pipe<..., NP2>): double storage, C in {1, 3}; K = 4 with a scalar threshold,
+// K = kHetFuseK with the per-element threshold plane (array-valued mu) -- one object per K (build.sh: np2_k3, np2_k4)
+namespace dxh {
+template <int K>
+void launch_multi_kernel_np2(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream) {
+    constexpr bool KQV = (K == DXH_HET_K);
+#define DXH_NP2_K(C_, CP_)                                                                                                          \
+    do {                                                                                                                            \
+        if (want_inc) hipLaunchKernelGGL((k_fused_multi<double, C_, CP_, false, K, true, true, false, KQV, true>), dim3(grid), dim3(256), 0, stream, a);  \
+        else hipLaunchKernelGGL((k_fused_multi<double, C_, CP_, false, K, false, true, false, KQV, true>), dim3(grid), dim3(256), 0, stream, a);          \
+    } while (0)
+    if (C == 1) { if (coupled) DXH_NP2_K(1, true); else DXH_NP2_K(1, false); }
+    else        { if (coupled) DXH_NP2_K(3, true); else DXH_NP2_K(3, false); }
+#undef DXH_NP2_K
+}
+template void launch_multi_kernel_np2<DXH_MULTI_K>(int, bool, bool, const FusedArgs<double>&, unsigned, hipStream_t);
+}  // namespace dxh
+#else
+
 namespace dxh {
 
 namespace {
@@ -101,3 +121,4 @@ template void launch_multi_kernel_c24<DXH_MULTI_T, DXH_MULTI_K>(int, bool, bool,
 #endif
 
 }  // namespace dxh
+#endif  // DXH_MULTI_NP2

@@ -519,6 +519,15 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
     // read from cp_kq (DXH_FUSED_TUNE bit 65536: the general array pipeline instead, A/B)
     a.kqv = ((C == 1 || C == 3) && c->het && c->het_cdiag && c->cp_kq && a.c.const_diag && !(c->tune & 65536)) ? 1 : 0;
     a.derive = (c->het && !a.kqv) ? 1 : 0;  // array coefficients (multi_supported: only with the given planes at hand, K = kHetFuseK)
+    a.np2_first = (c->np2 && c->np2_first) ? 1 : 0;
+    if (c->np2) {
+        // the reference's float32 dtype flow: Pipe<..., NP2> (dxh_multi.hip, objects np2_k3 / np2_k4); pick_k only asks for
+        // the combinations that exist
+        if constexpr (std::is_same<T, double>::value && !ISO && (C == 1 || C == 3) && (K == 4 || K == kHetFuseK)) {
+            if ((K == kHetFuseK) == (a.kqv != 0)) launch_multi_kernel_np2<K>(C, COUPLED, want_inc, a, grid, c->stream);
+        }
+        return;
+    }
     // the kernels are instantiated in dxh_multi.hip (one object per element type and K, built in parallel)
     if constexpr (C == 1 || C == 3) launch_multi_kernel<T, K>(C, COUPLED, ISO, want_inc, pair, a, grid, c->stream);
     else launch_multi_kernel_c24<T, K>(C, COUPLED, ISO, want_inc, pair, a, grid, c->stream);
@@ -537,6 +546,13 @@ static bool multi_supported(const Ctx* c) {
 // iterations of the next launch when `left` iterations remain (array coefficients: their pipeline exists for one K
 // only, shorter remainders run as single-iteration sweeps)
 static int pick_k(const Ctx* c, int left) {
+    if (c->np2) {
+        // the reference's float32 dtype flow: K = 4 (scalar threshold) / K = kHetFuseK (threshold plane) pipelines for 1 and
+        // 3 channels, remainders and other channel counts one iteration per launch (k_fused_np2)
+        if (!(c->g.n2 == 1 || c->g.n2 == 3)) return 1;
+        if (c->het) return (c->fuse_k >= kHetFuseK && left >= kHetFuseK) ? kHetFuseK : 1;
+        return (c->fuse_k >= 4 && left >= 4) ? 4 : 1;
+    }
     if (c->het) return (c->fuse_k >= kHetFuseK && left >= kHetFuseK) ? kHetFuseK : 1;
     return std::max(1, std::min(c->fuse_k, left));
 }
@@ -1041,6 +1057,18 @@ static int launch_np2(Ctx* c, int in, int out) {
 }
 
 template <typename T>
+static void launch_any(Ctx* c, int in, int out, bool iso, bool dpp, int K) {
+    if (c->np2) {
+        if (K >= 2) launch_fused_multi<T>(c, in, out, iso, K);
+        else if constexpr (std::is_same<T, double>::value) (void)launch_np2(c, in, out);
+        c->np2_first = false;
+        return;
+    }
+    if (K >= 2) launch_fused_multi<T>(c, in, out, iso, K);
+    else launch_fused<T>(c, in, out, iso, dpp);
+}
+
+template <typename T>
 static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, double eps, double norm_scale,
                  uint32_t flags, dxh_tvd_result* res) {
     const bool iso = flags & DXH_FLAG_ISOTROPIC;
@@ -1059,6 +1087,7 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
         DXH_REQUIRE(!iso, "numpy2 promotion: anisotropic shrinkage only (the reference's isotropic branch is float64-only)");
         DXH_REQUIRE(!c->from_db && !c->explicit_db && !(flags & DXH_FLAG_EXPLICIT), "numpy2 promotion: no explicit split variables");
         DXH_REQUIRE(!c->het || (c->het_cdiag && c->cp_kq), "numpy2 promotion: omega and ell must be scalars");
+        DXH_REQUIRE(fused_ok, "numpy2 promotion: the coefficients are outside the fused sweep's range (mu / ell must be >= 0)");
     }
     if (c->solver) {
         // Solver.update_params(mass_coeff=omega, diffusion_coeff=ell) (split_bregman_tvd.py:63-67, 154-158)
@@ -1121,12 +1150,14 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
     if (!async) DXH_HIP(hipEventRecord(c->ev0, c->stream));
     for (int it = 0; it < n_iter; ++it) {
         const int in = c->cur, out = c->cur ^ 1;
-        if (!c->np2 && fused_ok && !c->from_db && use_eps && dpp && multi_supported(c) && pick_k(c, n_iter - it) >= 2) {
+        if (fused_ok && !c->from_db && use_eps && dpp && multi_supported(c) && pick_k(c, n_iter - it) >= 2) {
             // eps with temporal blocking: one launch does K iterations and also reduces every iteration's
             // squared increment; if the test fires at an inner iteration j, the K-iteration result is
             // discarded (the input buffers still hold iteration `it`) and exactly j+1 iterations are redone
             const int K = pick_k(c, n_iter - it);
+            const bool first0 = c->np2_first;   // numpy2 flow: the redo starts from the same (float32-valued) iterate
             launch_fused_multi<T>(c, in, out, iso, K, true);
+            c->np2_first = false;
             ++launches;
             if (!c->inc_partial) { set_error("out of device memory for the increment partials"); return DXH_ENOMEM; }
             hipLaunchKernelGGL(k_sum_partials, dim3(K), dim3(256), 0, c->stream, c->inc_partial, K * c->inc_nwaves,
@@ -1152,10 +1183,10 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
             } else {
                 // redo exactly hit+1 iterations from the untouched input state
                 int left = hit + 1, a_in = in, a_out = out;
+                c->np2_first = first0;
                 while (left > 0) {
                     const int k2 = pick_k(c, left);
-                    if (k2 >= 2) launch_fused_multi<T>(c, a_in, a_out, iso, k2, false);
-                    else launch_fused<T>(c, a_in, a_out, iso, dpp);
+                    launch_any<T>(c, a_in, a_out, iso, dpp, k2);
                     ++launches;
                     left -= k2;
                     std::swap(a_in, a_out);
@@ -1163,24 +1194,12 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
                 c->cur = a_in;  // the buffer written last
             }
             break;
-        } else if (c->np2) {
-            if constexpr (std::is_same<T, double>::value) {
-                int rc = launch_np2(c, in, out);
-                if (rc) return rc;
-            }
-            c->np2_first = false;
-            ++launches;
-            c->cur = out;
         } else if (fused_ok && !c->from_db) {
             // temporal blocking: fuse_k iterations per launch while enough iterations remain and no
             // per-iteration host test is requested
             const int K = (!use_eps && dpp && multi_supported(c)) ? pick_k(c, n_iter - it) : 1;
-            if (K >= 2) {
-                launch_fused_multi<T>(c, in, out, iso, K);
-                it += K - 1;
-            } else {
-                launch_fused<T>(c, in, out, iso, dpp);
-            }
+            launch_any<T>(c, in, out, iso, dpp, K);
+            it += K - 1;
             ++launches;
             c->cur = out;
         } else if (fused3d_ok && !c->from_db) {
@@ -1429,16 +1448,6 @@ static int start_exchange(Ctx* c, bool after_signal) {
 // exchange in stream order behind everything in flight (no overlap)
 static int exchange_now(Ctx* c) { return start_exchange(c, false); }
 
-template <typename T>
-static void launch_any(Ctx* c, int in, int out, bool iso, bool dpp, int K) {
-    if (c->np2) {
-        if constexpr (std::is_same<T, double>::value) (void)launch_np2(c, in, out);
-        c->np2_first = false;
-        return;
-    }
-    if (K >= 2) launch_fused_multi<T>(c, in, out, iso, K);
-    else launch_fused<T>(c, in, out, iso, dpp);
-}
 
 template <typename T>
 static int run_slab_t(Ctx* c, int n_iter, int m, double eps, uint32_t flags, dxh_tvd_result* res) {
@@ -1492,9 +1501,10 @@ static int run_slab_t(Ctx* c, int n_iter, int m, double eps, uint32_t flags, dxh
         const int cap = dist ? (int)std::min<int64_t>(left, c->halo_valid / m) : left;
         int K;
         if (fused_ok) {
-            K = (use_eps || c->np2) ? 1 : std::min(pick_k(c, left), cap);
+            K = use_eps ? 1 : std::min(pick_k(c, left), cap);
             if (K >= 2 && !(dpp && multi_supported(c))) K = 1;
             if (K >= 2 && c->het && K != kHetFuseK) K = 1;
+            if (K >= 2 && c->np2 && !c->het && K != 4) K = 1;   // numpy2 flow: the scalar pipeline exists for K = 4 only
             const int in = c->cur, out = c->cur ^ 1;
             const bool xchg_after = dist && (c->halo_valid - (int64_t)K * m < m) &&
                                     (done + K < n_iter || (flags & DXH_FLAG_CONTINUE)) && !use_eps;
