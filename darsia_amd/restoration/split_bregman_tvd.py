@@ -300,6 +300,7 @@ def split_bregman_tvd(
     solver: Optional[Solver] = None,
     adaptive=None,
     promotion: Optional[str] = None,
+    _context_cache: Optional[dict] = None,
 ) -> np.ndarray:
     """Split Bregman algorithm for TV denoising (split_bregman_tvd.py:14-177).
 
@@ -346,11 +347,39 @@ def split_bregman_tvd(
     if promotion == "numpy2":
         if why_not is not None:
             raise NotImplementedError(f"promotion='numpy2': {why_not}")
-        with DeviceTVD(img.shape, img.dtype, dim=dim, device=img.device if on_device else None, promotion="numpy2") as st:
-            st.set_coeffs(mu, omega, ell, img)
+        # ``_context_cache`` (a dict an operator object owns, restoration/tvd.py): the device context and its coefficient
+        # planes -- a 256 MB float64 weight map at 4000 x 8000 -- stay from call to call while shape, device and the
+        # coefficients' fingerprints are the same (in-place edits of a weight array: outside the contract, clear the dict)
+        from ..concentration import _fingerprint
+
+        device = img.device if on_device else _lib.default_device()
+        key = (tuple(img.shape), device)
+        mark = tuple(_fingerprint(v) for v in (mu, omega, ell))
+        held = None if _context_cache is None else _context_cache.get("numpy2")
+        if held is not None and held[0] != key:
+            held[2].close()
+            held = None
+        if held is None:
+            st = DeviceTVD(img.shape, img.dtype, dim=dim, device=device, promotion="numpy2")
+            st_mark = None
+        else:
+            _, st_mark, st, _refs = held
+        try:
+            if st_mark != mark:
+                st.set_coeffs(mu, omega, ell, img)
             st.upload(img)
             st.run(max_num_iter, 1, None, eps=eps)
-            return st.download(out=DeviceArray(img.shape, img.dtype, img.device) if on_device else None)
+            out = st.download(out=DeviceArray(img.shape, img.dtype, img.device) if on_device else None)
+        except BaseException:
+            st.close()
+            if _context_cache is not None:
+                _context_cache.pop("numpy2", None)
+            raise
+        if _context_cache is None:
+            st.close()
+        else:
+            _context_cache["numpy2"] = (key, mark, st, (mu, omega, ell))
+        return out
     if (not on_device and x0 is None and eps is None and adaptive is None and quiet and dim == 2 and img.ndim in (2, 3)
             and isinstance(solver, Jacobi) and solver.tol is None and solver.maxiter >= 1 and max_num_iter >= 1
             and img.nbytes >= (32 << 20)):

@@ -40,6 +40,7 @@ class TVD:
         self.max_num_iter = kwargs.pop(key + "max_num_iter", 200)
         self.eps = kwargs.pop(key + "eps", 2e-4)
         self.kwargs = kwargs
+        self._contexts = {}    # device contexts kept between calls (numpy2 flow: coefficient planes stay in HBM)
 
     def __call__(self, img):
         if isinstance(img, (np.ndarray, DeviceArray)):  # a DeviceArray stays in HBM (darsia_amd.device)
@@ -58,6 +59,7 @@ class TVD:
                 ell=self.regularization,
                 max_num_iter=self.max_num_iter,
                 eps=self.eps,
+                _context_cache=self._contexts,
                 **self.kwargs,
             )
         elif self.method == "chambolle":
@@ -69,6 +71,20 @@ class TVD:
                                       isotropic=self.method == "isotropic bregman")
         else:
             raise ValueError(f"Method {self.method} not supported.")
+
+    def release(self) -> None:
+        """Free the device contexts the operator keeps between calls (they come back on demand)."""
+        for held in self._contexts.values():
+            held[2].close()
+        self._contexts.clear()
+
+    def __deepcopy__(self, memo):
+        import copy
+
+        new = copy.copy(self)
+        new.kwargs = copy.deepcopy(self.kwargs, memo)
+        new._contexts = {}          # device contexts are not shared between copies
+        return new
 
     def _tvd_image(self, img):
         # tvd.py:127-129: a copy of the image with the denoised array

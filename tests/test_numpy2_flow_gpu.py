@@ -188,3 +188,28 @@ def test_small_random_sweep_of_the_numpy2_flow_and_the_volume_kernels():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_r3.py"), "7", "80"], cwd=ROOT,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "80 cases, 0 mismatches" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_operator_keeps_its_numpy2_context_between_calls(mixed):
+    """A TVD operator object is long-lived in the reference's workflows (presets/workflows/restoration.py returns one per run);
+    in the numpy2 flow it keeps its device context -- the float64 weight map's planes -- from frame to frame.  Same bits as
+    fresh calls; a new weight array, another shape or release() start afresh."""
+    img, mu, ref = mixed["m8_tvd_operator/img"], mixed["m8_tvd_operator/mu"], mixed["m8_tvd_operator/out"]
+    op = da.TVD(method="heterogeneous bregman", weight=mu, max_num_iter=20, eps=None)
+    bits(op(img), ref)
+    held = op._contexts["numpy2"][2]
+    img2 = np.ascontiguousarray(img[::-1])
+    want2 = da.split_bregman_tvd(img2, mu=mu, ell=1.0, max_num_iter=20)
+    bits(op(img2), want2)
+    assert op._contexts["numpy2"][2] is held                       # the same context served the second frame
+    bits(op(img), ref)                                             # ... and leaves no trace of it
+    op.weight = mu * 0.5                                           # another weight map: coefficients are set again
+    bits(op(img), da.split_bregman_tvd(img, mu=mu * 0.5, ell=1.0, max_num_iter=20))
+    small = np.ascontiguousarray(img[:40, :50])
+    op.weight = np.ascontiguousarray(mu[:40, :50])
+    bits(op(small), da.split_bregman_tvd(small, mu=op.weight, ell=1.0, max_num_iter=20))
+    assert op._contexts["numpy2"][2] is not held                   # another shape: another context, the old one closed
+    import copy
+    assert copy.deepcopy(op)._contexts == {}
+    op.release()
+    assert op._contexts == {}
