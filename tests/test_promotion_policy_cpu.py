@@ -1,0 +1,114 @@
+"""Host logic of round 3 that needs no GPU: which dtype flow a split_bregman_tvd call takes (choose_promotion /
+numpy2_unsupported), what keeps a ConcentrationAnalysis frame off the fused device pipeline (and that it says so), the
+estimator's acceptance rule in its NumPy statement, the per-communicator rendezvous file names."""
+import numpy as np
+import pytest
+
+import darsia_amd as da
+from darsia_amd.restoration.split_bregman_tvd import choose_promotion, numpy2_unsupported
+
+
+def _why(img, mu=0.1, omega=1.0, ell=1.0, dim=2, x0=None, iso=False, solver=None, adaptive=None, quiet=True):
+    return numpy2_unsupported(img, mu, omega, ell, dim, x0, iso, solver or da.Jacobi(), adaptive, quiet)
+
+
+def test_numpy2_flow_exists_for_the_default_solve_only():
+    f32 = np.zeros((8, 9), np.float32)
+    assert _why(f32) is None
+    assert _why(np.zeros((8, 9, 3), np.float32), mu=np.ones((8, 9, 3))) is None
+    assert "float32" in _why(np.zeros((8, 9)))                                   # float64 images run natively (and exactly)
+    assert "scalars" in _why(f32, omega=np.ones((8, 9)))
+    assert "scalars" in _why(f32, ell=np.ones((8, 9)))
+    assert "scalar ell" in _why(f32, mu=np.ones((8, 9)), ell=None)               # ell = 2 mu would be an array
+    assert "anisotropic" in _why(f32, iso=True)
+    assert "Jacobi" in _why(f32, solver=da.Jacobi(maxiter=3))
+    assert "Jacobi" in _why(f32, solver=da.Jacobi(tol=1e-3))
+    assert "warm start" in _why(f32, x0=(f32, None, None))
+    assert "dim = 2" in _why(np.zeros((4, 5, 6), np.float32), dim=3)
+    assert "dim = 2" in _why(np.zeros((4, 5, 6), np.float32))                    # six "channels"
+
+
+def test_choice_of_the_dtype_flow(monkeypatch):
+    monkeypatch.delenv("DXH_PROMOTION", raising=False)
+    mu64, mu32 = np.ones((4, 4)), np.ones((4, 4), np.float32)
+    # default: the reference's flow exactly where a float32 image meets a float64 coefficient array and the flow exists
+    assert choose_promotion(None, np.float32, (mu64, 1.0, 1.0), None) == "numpy2"
+    assert choose_promotion(None, np.float32, (mu32, 1.0, 1.0), None) == "native"
+    assert choose_promotion(None, np.float32, (0.1, 1.0, None), None) == "native"
+    assert choose_promotion(None, np.float64, (mu64, 1.0, 1.0), "the image is not float32") == "native"
+    assert choose_promotion(None, np.float32, (mu64, 1.0, None), "an array-valued mu needs a scalar ell") == "native"
+    # explicit wins; an explicit numpy2 where the flow does not exist is the caller's error (raised by split_bregman_tvd)
+    assert choose_promotion("native", np.float32, (mu64, 1.0, 1.0), None) == "native"
+    assert choose_promotion("numpy2", np.float32, (0.1, 1.0, None), None) == "numpy2"
+    with pytest.raises(ValueError):
+        choose_promotion("float16", np.float32, (0.1, 1.0, None), None)
+    # the environment variable: numpy2 wherever it exists, native otherwise
+    monkeypatch.setenv("DXH_PROMOTION", "numpy2")
+    assert choose_promotion(None, np.float32, (0.1, 1.0, None), None) == "numpy2"
+    assert choose_promotion(None, np.float32, (0.1, 1.0, None), "anisotropic only") == "native"
+    monkeypatch.setenv("DXH_PROMOTION", "native")
+    assert choose_promotion(None, np.float32, (mu64, 1.0, 1.0), None) == "native"
+
+
+def test_concentration_analysis_says_why_a_frame_leaves_the_fused_pipeline():
+    rng = np.random.default_rng(0)
+    base = da.OpticalImage(rng.random((12, 14, 3)).astype(np.float32))
+    probe = rng.random((12, 14, 3)).astype(np.float32)
+    red = da.MonochromaticReduction(color="red")
+    plan, why = da.ConcentrationAnalysis(base, red, None, None, None)._fusable_why(probe)
+    assert plan is not None and why is None
+    for kwargs, word in ((dict(balancing=lambda x: x), "balancing"),
+                         (dict(restoration=lambda x: x), "not a TVD operator"),
+                         (dict(restoration=da.TVD(method="heterogeneous bregman", dim=3)), "keyword arguments"),
+                         (dict(restoration=da.TVD(method="heterogeneous bregman", weight=np.ones((3, 3)))), "another shape"),
+                         (dict(model=lambda x: x), "no device stage")):
+        args = dict(signal_reduction=red, balancing=None, restoration=None, model=None)
+        args.update(kwargs)
+        ca = da.ConcentrationAnalysis(base, args["signal_reduction"], args["balancing"], args["restoration"], args["model"])
+        plan, why = ca._fusable_why(probe)
+        assert plan is None and word in why, (word, why)
+    # float32 signal with float64 weights: stays on the device, but as the operator's own numpy2 flow ("op" mode)
+    tvd = da.TVD(method="heterogeneous bregman", weight=np.full((12, 14), 0.1), max_num_iter=3, eps=None)
+    plan, why = da.ConcentrationAnalysis(base, red, None, tvd, None)._fusable_why(probe)
+    assert why is None and plan[-1] == "op"
+    tvd32 = da.TVD(method="heterogeneous bregman", weight=np.full((12, 14), 0.1, np.float32), max_num_iter=3, eps=None)
+    plan, why = da.ConcentrationAnalysis(base, red, None, tvd32, None)._fusable_why(probe)
+    assert why is None and plan[-1] == "hb"
+    # the host chain itself needs no device when nothing in it does: path and reason are recorded
+    ca = da.ConcentrationAnalysis(base, red, lambda x: x, None, None, **{"diff option": "positive"})
+    out = ca(da.OpticalImage(probe))
+    assert ca.last_path == "generic" and "balancing" in ca.last_path_reason
+    assert np.array_equal(out.img, np.maximum(probe - base.img, 0)[..., 0])
+
+
+def test_estimator_acceptance_rule_in_its_numpy_statement():
+    from oracle import phase_correlation_numpy as P
+
+    rng = np.random.default_rng(3)
+    a = rng.random((64, 96))
+    shifted = np.roll(a, (2, -3), axis=(0, 1))
+    (dx, dy), ok, peak = P.phase_correlation(a, shifted, return_peak=True)
+    assert ok and abs(dx + 3) < 0.5 and abs(dy - 2) < 0.5 and peak > 0.3
+    flat = np.full((64, 96), 0.4)
+    _, ok, peak = P.phase_correlation(flat, flat, return_peak=True)
+    assert not ok and abs(peak) < 1e-12
+    (_, ok, peak) = P.phase_correlation(a, rng.random((64, 96)), return_peak=True)
+    n = 64 * 128
+    assert not ok and peak < 4 * np.sqrt(np.log(n) / n)
+    assert P.phase_correlation(a, rng.random((64, 96)), min_peak_ratio=0.0, max_shift_fraction=1.0)[1] is True
+    nan = a.copy()
+    nan[3, 4] = np.nan
+    assert P.phase_correlation(nan, shifted)[1] is False
+
+
+def test_rendezvous_file_per_communicator(monkeypatch):
+    from darsia_amd import parallel
+
+    monkeypatch.setenv("MASTER_PORT", "29999")
+    monkeypatch.delenv("DXH_RENDEZVOUS_FILE", raising=False)
+    monkeypatch.setattr(parallel, "_rccl_seq", 0)
+    first, second = parallel._rendezvous_path(), parallel._rendezvous_path()
+    assert first != second and first.endswith("_0.id") and second.endswith("_1.id")
+    monkeypatch.setenv("DXH_RENDEZVOUS_FILE", "/tmp/x.id")
+    monkeypatch.setattr(parallel, "_rccl_seq", 0)
+    assert parallel._rendezvous_path() == "/tmp/x.id" and parallel._rendezvous_path() == "/tmp/x.id.1"
