@@ -322,6 +322,18 @@ static CoefPlanes<T> make_planes(const Ctx* c) {
     return p;
 }
 
+// The coefficient planes a one-thread-per-element or volume kernel really needs: with an array-valued mu only (scalar omega
+// and ell -- what the TVD operator passes, e.g. examples/regularization.py:14-29: weight = mu array, regularization = 1.0)
+// ell, diag and diag_scaled are the wave-invariant scalars of make_coef (set_coeffs_t fills them with derive_coefs' own
+// values, so the bits are the planes' bits); only the threshold mu / ell varies.  The kernels read a scalar where the
+// pointer is null: 4 - 12 bytes per element less per pass (DXH_FUSED_TUNE bit 2097152: all four planes, A/B).
+template <typename T>
+static CoefPlanes<T> make_planes_min(const Ctx* c) {
+    CoefPlanes<T> p = make_planes<T>(c);
+    if (c->het && c->het_cdiag && !(c->tune & 2097152)) p.ell = p.diag = p.dsc = nullptr;
+    return p;
+}
+
 template <typename T>
 static CoefIn<T> make_coefin(const Ctx* c) {
     CoefIn<T> in{};
@@ -661,7 +673,7 @@ static void launch_rhs(Ctx* c, bool iso, bool from_db) {
     auto q = make_q<T, DIM>(c, c->cur, c->cur);
     auto db = make_db<T>(c);
     auto co = make_coef<T>(c);
-    auto cp = make_planes<T>(c);
+    auto cp = make_planes_min<T>(c);
     if (c->solver) {  // MG / CG take the right-hand side itself, not rhs / diag: divide by exactly 1
         co.diag = T(1);
         cp.diag = nullptr;
@@ -689,7 +701,7 @@ static void launch_shrink(Ctx* c, const void* unew, bool iso, bool from_db) {
     auto q = make_q<T, DIM>(c, c->cur, c->cur);  // in place: each thread touches only its own element
     auto db = make_db<T>(c);
     auto co = make_coef<T>(c);
-    auto cp = make_planes<T>(c);
+    auto cp = make_planes_min<T>(c);
     if constexpr (DIM == 3) {
         VolTiles vt;
         if (!from_db && vol_tiles<T>(c, &vt)) {  // volumes: k_shrink_vol
@@ -741,7 +753,7 @@ static void launch_fused3d(Ctx* c, int in, int out, bool iso) {
                     const int64_t total = nchunk * tiles;
                     if (c->tune & 512) fprintf(stderr, "[dxh] march3d_v patch %dx%d tiles %lld chunks %lld (%lld planes) blocks/CU %d\n", o1 + 1, o2 + NV, (long long)tiles, (long long)nchunk, (long long)ppc, bpc);
                     hipLaunchKernelGGL(kernel, dim3((unsigned)((total + 7) / 8 * 8)), dim3(256), 0, c->stream, c->g, (const T*)c->of, q,
-                                       (const T*)c->u[in], (T*)c->u[out], make_coef<T>(c), make_planes<T>(c), nt1, nt2,
+                                       (const T*)c->u[in], (T*)c->u[out], make_coef<T>(c), make_planes_min<T>(c), nt1, nt2,
                                        (int)nchunk, (int)ppc, tpr);
                 };
                 if (iso) launch(k_march3d_v<T, true>); else launch(k_march3d_v<T, false>);
@@ -878,7 +890,7 @@ static void launch_jacobi(Ctx* c, const void* xin, void* xout) {
         const int64_t tiles = c->g.n0 * c->g.n1 * nbx, per_xcd = (tiles + 7) / 8;
         if (per_xcd * 8 < (int64_t)INT32_MAX) {
             hipLaunchKernelGGL((k_jacobi_vol_x<T>), dim3((unsigned)(per_xcd * 8)), dim3(256), 0, c->stream, c->g, (const T*)c->rs,
-                               (const T*)xin, make_coef<T>(c), make_planes<T>(c), (T*)xout, nbx, tiles, per_xcd);
+                               (const T*)xin, make_coef<T>(c), make_planes_min<T>(c), (T*)xout, nbx, tiles, per_xcd);
             return;
         }
     }
@@ -886,16 +898,17 @@ static void launch_jacobi(Ctx* c, const void* xin, void* xout) {
         // volumes: 3-D grid, no per-element index divisions (DXH_FUSED_TUNE bit 16384: the generic kernel)
         const dim3 grid((unsigned)((c->g.n2 + 255) / 256), (unsigned)c->g.n1, (unsigned)c->g.n0);
         hipLaunchKernelGGL((k_jacobi_vol<T>), grid, dim3(256), 0, c->stream, c->g, (const T*)c->rs, (const T*)xin,
-                           make_coef<T>(c), make_planes<T>(c), (T*)xout);
+                           make_coef<T>(c), make_planes_min<T>(c), (T*)xout);
         return;
     }
     const Geom& gx = c->g;
     hipLaunchKernelGGL((k_jacobi<T>), elem_grid(gx), dim3(256), 0, c->stream, gx, (const T*)c->rs, (const T*)xin,
-                       make_coef<T>(c), make_planes<T>(c), (T*)xout);
+                       make_coef<T>(c), make_planes_min<T>(c), (T*)xout);
 }
 
 static bool jacobi_multi_supported(const Ctx* c) {
-    return c->desc.dim == 2 && !c->het && (c->g.n2 == 1 || c->g.n2 == 3) && !(c->tune & 64);
+    // (an array-valued mu alone leaves the sweep's only coefficient, diag_scaled, the scalar of make_coef: het_cdiag)
+    return c->desc.dim == 2 && (!c->het || c->het_cdiag) && (c->g.n2 == 1 || c->g.n2 == 3) && !(c->tune & 64);
 }
 
 template <typename T, int C, bool COUPLED, int K>

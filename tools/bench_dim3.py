@@ -14,3 +14,14 @@ for shape, dt in (((256, 256, 256), np.float32), ((256, 256, 256), np.float64), 
         n = vol.size
         print(f"{shape} {np.dtype(dt).name} Jacobi(maxiter={jm}): {ms:.3f} ms/iter  {n/ms/1e6:.1f} GVox/s  launches/iter {ts[0].launches/20:.0f}", flush=True)
         st.close()
+    if dt == np.float32:
+        # the reference example's coefficients (examples/regularization.py:14-29): mu an array, omega = 0.1, ell = 1.0
+        mu = np.ones(shape, dt); mu[:, : shape[1] // 3, :] = 0.5
+        st = da.DeviceTVD(vol.shape, vol.dtype, dim=3); st.set_coeffs(mu, 0.1, 1.0, vol); st.upload(vol)
+        st.run(3, jacobi_maxiter=20)
+        ms = min(st.run(10, jacobi_maxiter=20).loop_ms for _ in range(2)) / 10
+        print(f"{shape} {np.dtype(dt).name} array-valued mu, Jacobi(maxiter=20): {ms:.3f} ms/iter", flush=True)
+        st.run(3)
+        ms = min(st.run(20).loop_ms for _ in range(2)) / 20
+        print(f"{shape} {np.dtype(dt).name} array-valued mu, Jacobi(maxiter=1): {ms:.3f} ms/iter", flush=True)
+        st.close()
