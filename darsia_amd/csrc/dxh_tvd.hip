@@ -2625,6 +2625,7 @@ int dxh_tvd_adapt_ell(dxh_tvd_t h) {
         c->het = true;
     }
     c->in_valid = false;  // the coefficient planes no longer follow from the given arrays
+    c->het_cdiag = false; // ell varies per element from here on: nobody may take it for the scalar it was (make_planes_min)
     const void* u = c->u[c->cur];
 #define DXH_AD(T, DIM) hipLaunchKernelGGL((k_adapt_ell<T, DIM>), grid, blk, 0, c->stream, c->g, (const T*)u, (T)c->mu_s, \
                                           (const T*)c->mu_plane, (T*)c->cp_ell, (T*)c->cp_kq)

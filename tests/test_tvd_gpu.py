@@ -519,6 +519,19 @@ def test_adaptive_regularisation(golden, name, kw, sched):
         assert np.median(rel) < 1e-4 and np.mean(rel < 1e-2) > 0.98
 
 
+def test_adaptive_regularisation_with_an_array_valued_mu():
+    """adaptive ell on top of an array-valued mu with scalar omega / ell: until the first update ell is a scalar next to
+    the threshold plane (the kernels then read it as one), afterwards it varies per element -- 2-D and a volume, against
+    the oracle (split_bregman_tvd.py:149-158)."""
+    rng = np.random.default_rng(77)
+    for shape, dim in (((40, 68), 2), ((9, 12, 64), 3)):
+        img = rng.random(shape)
+        mu = 0.05 + 0.2 * rng.random(shape)
+        sched = lambda it: it in (1, 3)   # noqa: E731
+        kw = dict(mu=mu, omega=0.8, ell=0.6, dim=dim, max_num_iter=6)
+        assert_bits(da.split_bregman_tvd(img, adaptive=sched, **kw), O.split_bregman_tvd(img, adaptive=sched, promotion="strict", **kw))
+
+
 @pytest.mark.parametrize("iso", [False, True])
 @pytest.mark.parametrize("n_iter", [3, 7, 8])
 def test_heterogeneous_temporal_blocking_bit_exact(iso, n_iter, monkeypatch):
