@@ -170,6 +170,21 @@ def main():
             if not self_check["bit_identical_to_k1_replay"]:
                 raise SystemExit("bench self-check failed: timed state differs from the one-iteration-per-launch replay")
         st.close()
+        # Outside the timed region, for the record: the same workload in the product's DEFAULT dtype flow for float32
+        # images (promotion "numpy2": the reference's own mixed float32 / float64 arithmetic, bit for bit -- DESIGN.md
+        # section 3).  `value` above is the native float32 flow, the arithmetic BASELINE.json's metric names (float32), whose
+        # result at this configuration lies within rtol 1e-4 of the reference's (tests/test_tvd_gpu.py, full size).
+        ref_flow = None
+        if not a.no_self_check:
+            st = DeviceTVD(img.shape, img.dtype, dim=2, device=local_rank, promotion="numpy2")
+            st.set_coeffs(mu, 1.0, None, img)
+            st.upload(img)
+            st.run(8)
+            r2 = st.run(a.iters)
+            st.close()
+            ref_flow = {"promotion": "numpy2", "ms_per_step": round(r2.loop_ms, 4),
+                        "value": round(float(H) * W * a.iters / (r2.loop_ms * 1e-3) / 1e6, 1), "unit": "MPix/s",
+                        "launches": int(r2.launches)}
     else:
         from darsia_amd.parallel import SlabTVD, init_from_env, make_plan
 
@@ -325,6 +340,8 @@ def main():
                 out["roofline"]["traffic_source"] = traffic.get("source")
             if self_check:
                 out["self_check"] = self_check
+            if ref_flow:
+                out["reference_dtype_flow"] = ref_flow
             if not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(C, a.cpu_sample)
         elif self_check:

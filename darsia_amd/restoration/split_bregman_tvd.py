@@ -10,15 +10,18 @@ Divergences from the reference, all deliberate:
 
 * ``solver=None`` creates a fresh ``Jacobi()`` per call instead of sharing one
   def-time instance whose cached diagonal never updates (quirks Q1, Q3);
-* by default arithmetic stays in the image dtype; the reference's float32 run promotes the
-  Jacobi iterate to float64 under NumPy >= 2 (jacobi.py:101-114).  For ``ell = 2 mu`` (this
-  function's default) the two agree to ~2e-7 after 100 iterations; for ``ell >= 0.5`` the float32
-  flow drifts to ~3e-5 after 100 iterations, past rtol 1e-4 on small values.  ``promotion="numpy2"``
-  (an extra keyword; also ``DXH_PROMOTION=numpy2``) reproduces the reference's mixed float32 /
-  float64 flow BIT FOR BIT (``k_fused_np2``), at ~1 ms instead of ~0.15 ms per iteration on
-  4000 x 8000 x 3.  It is chosen automatically when a float32 image meets a float64 weight array --
-  the workflow's default (presets/workflows/restoration.py:117-148) -- because there the caller
-  handed over float64 data and the reference computes the threshold in it;
+* two dtype flows for float32 images (``promotion``, an extra keyword; ``DXH_PROMOTION`` sets the
+  default).  ``"numpy2"`` -- THE DEFAULT wherever it exists (dim = 2, ``Jacobi(maxiter=1)`` without
+  tolerance, anisotropic, scalar omega / ell) -- is the reference's own flow under NumPy >= 2: the
+  Jacobi iterate is float64 (jacobi.py:101-114), ``d``, ``b`` and the right-hand side float32, a
+  float64 weight map the threshold; reproduced BIT FOR BIT (``Pipe<..., NP2>``, ``k_fused_np2``),
+  0.39 ms per iteration at 4000 x 8000 x 3.  ``"native"`` keeps every quantity float32 (0.15 ms):
+  the oracle's same-dtype flow bit for bit, but only CLOSE to the reference -- 2e-7 while the
+  shrinkage is inactive (``mu / ell`` above the image's gradients: ``mu = 0.1``, ``ell = 2 mu`` on a
+  [0, 1] image, the benchmark's setting), 1e-4 absolute = 10 - 80 x the rtol-1e-4 tolerance once it is
+  active (``mu = 1``, or ``ell >= 0.3`` at ``mu = 0.1``: a near-threshold element that shrinks in one
+  flow and not in the other; tests/test_oracle_mixed_golden.py).  float64 images have one flow,
+  which is the reference's, bit for bit;
 * the isotropic variant also accepts float32 and colour images (the reference's
   numba kernel is float64 / 2-D only);
 * float images only (integer images silently break the reference, quirk Q5).
@@ -268,19 +271,16 @@ def numpy2_unsupported(img, mu, omega, ell, dim, x0, isotropic, solver, adaptive
 
 
 def choose_promotion(promotion: Optional[str], img_dtype, coefs, why_not: Optional[str]) -> str:
-    """The dtype flow a call runs in: an explicit ``promotion`` wins; else ``DXH_PROMOTION`` (``numpy2`` there means
-    "wherever that flow exists"); else ``numpy2`` exactly when a float32 image comes with a float64 coefficient array
-    and the flow exists for the configuration (``why_not`` is None), ``native`` otherwise."""
+    """The dtype flow a call runs in: an explicit ``promotion`` wins; else ``DXH_PROMOTION``; else -- the default -- the
+    reference's own flow (``"numpy2"``) for every float32 image whose configuration has it (``why_not`` is None), the
+    native flow otherwise (float64 images: native IS the reference's flow).  ``coefs`` is kept for the log message."""
     if promotion is None:
         promotion = os.environ.get("DXH_PROMOTION") or None
-        if promotion is None:
-            mixed = np.dtype(img_dtype) == np.float32 and any(
-                isinstance(c, np.ndarray) and c.ndim > 0 and c.dtype == np.float64 for c in coefs)
-            promotion = "numpy2" if (mixed and why_not is None) else "native"
-            if mixed and why_not is not None:
-                logger.info("float32 image with float64 coefficients: native float32 flow (%s)", why_not)
-        elif promotion == "numpy2" and why_not is not None:
-            promotion = "native"
+        if promotion is None or promotion == "numpy2":
+            f32 = np.dtype(img_dtype) == np.float32
+            if f32 and why_not is not None:
+                logger.info("float32 image: native float32 flow, not the reference's mixed float32 / float64 one (%s)", why_not)
+            promotion = "numpy2" if (f32 and why_not is None) else "native"
     if promotion not in ("native", "numpy2"):
         raise ValueError(f"promotion must be None, 'native' or 'numpy2', not {promotion!r}")
     return promotion
@@ -308,10 +308,10 @@ def split_bregman_tvd(
     with ``d0``/``b0`` of shape ``(*img.shape, dim)``; as in the reference they are
     updated in place with the final split variables.
 
-    ``promotion`` (extension, see the module docstring): ``"native"`` -- arithmetic in the image dtype;
-    ``"numpy2"`` -- the reference's own mixed flow for float32 images, bit for bit; ``None`` -- ``DXH_PROMOTION`` if
-    set, else ``"numpy2"`` exactly when a float32 image comes with a float64 coefficient array and the configuration
-    has that flow (``numpy2_supported``), ``"native"`` otherwise.
+    ``promotion`` (extension, see the module docstring): ``"numpy2"`` -- the reference's own mixed flow for float32
+    images, bit for bit; ``"native"`` -- arithmetic in the image dtype (2.5 x faster, close to the reference only while
+    the shrinkage is inactive); ``None`` -- ``DXH_PROMOTION`` if set, else ``"numpy2"`` for every float32 image whose
+    configuration has that flow (``numpy2_unsupported``), ``"native"`` otherwise.
 
     Returns:
         array: denoised image, same dtype as ``img``.

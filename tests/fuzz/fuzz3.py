@@ -1,5 +1,6 @@
 """Developer fuzz, part 3: piecewise perspective warp, CurvatureCorrection, heterogeneous MG, CG."""
-import sys, time
+import os, sys, time
+os.environ.setdefault("DXH_PROMOTION", "native")   # these sweeps pin the native float32 kernels (oracle flow "strict")
 sys.path.insert(0, ".")
 import numpy as np
 import darsia_amd as da

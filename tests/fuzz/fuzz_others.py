@@ -1,5 +1,6 @@
 """Developer fuzz: Chambolle, Gauss-Seidel Bregman, Jacobi, MG, map_coordinates, resize against their oracles."""
-import sys, time
+import os, sys, time
+os.environ.setdefault("DXH_PROMOTION", "native")   # these sweeps pin the native float32 kernels (oracle flow "strict")
 sys.path.insert(0, ".")
 import numpy as np
 from scipy.ndimage import map_coordinates as sp_map

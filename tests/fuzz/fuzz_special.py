@@ -1,6 +1,7 @@
 """Developer fuzz: special values -- exact zeros, constants, tiny and huge magnitudes, negative values -- through the
 K-iteration pipelines (reciprocal division with its IEEE fallback) against the oracle, bit for bit."""
-import sys, warnings
+import os, sys, warnings
+os.environ.setdefault("DXH_PROMOTION", "native")   # these sweeps pin the native float32 kernels (oracle flow "strict")
 sys.path.insert(0, ".")
 import numpy as np
 import darsia_amd as da

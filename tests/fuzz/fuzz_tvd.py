@@ -1,6 +1,7 @@
 """Developer fuzz: random shapes / dtypes / parameters of split_bregman_tvd against the NumPy oracle, bit for bit
 (anisotropic) or to 1e-6 / 1e-13 (isotropic: sqrt and division order, cf. golden G4)."""
-import sys, time
+import os, sys, time
+os.environ.setdefault("DXH_PROMOTION", "native")   # these sweeps pin the native float32 kernels (oracle flow "strict")
 sys.path.insert(0, ".")
 import numpy as np
 import darsia_amd as da

@@ -1,4 +1,5 @@
-import sys
+import os, sys
+os.environ.setdefault("DXH_PROMOTION", "native")   # these sweeps pin the native float32 kernels (oracle flow "strict")
 sys.path.insert(0, ".")
 import numpy as np
 import darsia_amd as da

@@ -37,6 +37,9 @@ def test_single_gpu_line_has_contract_fields():
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1.5
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1
     assert "workload" in d["config"]
+    # for the record next to `value` (the native float32 flow): the same workload in the default dtype flow of float32 images
+    assert d["reference_dtype_flow"]["promotion"] == "numpy2" and 0 < d["reference_dtype_flow"]["value"] < d["value"]
+    assert d["self_check"]["bit_identical_to_k1_replay"] is True
 
 
 def test_two_rank_rehearsal_runs_the_slab_path():
@@ -51,6 +54,11 @@ def test_two_rank_rehearsal_runs_the_slab_path():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["rows_per_gpu"] == 128
     assert "REHEARSAL" in d["data"] and d["value"] > 0
     assert d["comm"]["transport"] == "host" and d["comm"]["exchanges"] >= 2
+    # per-rank diagnostics: loop time min / max over the ranks, exchange timings, launch and exchange counts of rank 0
+    pr = d["per_rank"]
+    assert 0 < pr["loop_ms_per_step"]["min"] <= pr["loop_ms_per_step"]["max"]
+    assert pr["rank0"]["exchanges"] >= 2 and pr["rank0"]["exchanges_timed"] == pr["rank0"]["exchanges"] and pr["rank0"]["wait_timeouts"] == 0
+    assert pr["ms_per_exchange_signal_to_scatter_end"]["max"] > 0
     # every rank compared its rows with a single-GPU replay of all iterations on the whole image
     assert d["self_check"] == {"iterations": 48, "ranks_bit_identical_to_single_gpu_replay": 2, "ranks": 2,
                                "max_abs_difference": 0.0}

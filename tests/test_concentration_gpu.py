@@ -353,8 +353,9 @@ def test_random_sweep_of_frame_types_against_numpy_promotion():
         ca.close()
 
 
-def test_float32_signal_with_float64_weights_takes_the_reference_flow_and_paths_are_observable(caplog):
-    """The workflow's default (presets/workflows/restoration.py:117-148): float32 frames, float64 porosity weights.  The TVD
+def test_float32_signal_with_float64_weights_takes_the_reference_flow_and_paths_are_observable(caplog, monkeypatch):
+    """(Runs in the product's DEFAULT dtype flow: this module otherwise pins the native float32 kernels, conftest.py.)
+    The workflow's default (presets/workflows/restoration.py:117-148): float32 frames, float64 porosity weights.  The TVD
     operator alone runs the reference's mixed dtype flow there (promotion "numpy2"); inside ConcentrationAnalysis the SAME
     operator runs on the device-resident signal between the two elementwise stages, so the fused object and the operator
     called by hand give the same bits -- which are the oracle's reference-flow bits.  ``last_path`` says which pipeline
@@ -363,6 +364,7 @@ def test_float32_signal_with_float64_weights_takes_the_reference_flow_and_paths_
 
     from oracle import tvd_numpy as O
 
+    monkeypatch.delenv("DXH_PROMOTION", raising=False)
     base, probe = _frames(48, 72, 11)
     rng = np.random.default_rng(5)
     weight = 0.08 * (0.3 + 0.7 * rng.random((48, 72)))          # float64
@@ -376,8 +378,9 @@ def test_float32_signal_with_float64_weights_takes_the_reference_flow_and_paths_
     want = O.split_bregman_tvd(signal, mu=weight, omega=1.0, ell=1.0, max_num_iter=25)      # the reference's NumPy-2 flow
     assert np.array_equal(out.img, want)
     assert np.array_equal(tvd(signal), want)
-    # float32 weights: the context's own float32 iterations (bit-exact against the oracle's same-dtype flow)
-    tvd32 = da.TVD(method="heterogeneous bregman", weight=weight.astype(np.float32), omega=1.0, regularization=1.0, max_num_iter=25, eps=None)
+    # promotion="native": the context's own float32 iterations (bit-exact against the oracle's same-dtype flow)
+    tvd32 = da.TVD(method="heterogeneous bregman", weight=weight.astype(np.float32), omega=1.0, regularization=1.0, max_num_iter=25, eps=None,
+                   promotion="native")
     ca32 = da.ConcentrationAnalysis(base, da.MonochromaticReduction(color="red"), None, tvd32, None, **{"diff option": "positive"})
     got32 = ca32(probe).img
     assert ca32.last_path == "fused"
@@ -393,7 +396,8 @@ def test_float32_signal_with_float64_weights_takes_the_reference_flow_and_paths_
     assert np.array_equal(out_gen.img, want)
     # refresh(): an in-place edit of the weight map is outside what the device caches can see; after refresh() it counts
     weight32 = weight.astype(np.float32)
-    tvd_e = da.TVD(method="heterogeneous bregman", weight=weight32, omega=1.0, regularization=1.0, max_num_iter=8, eps=None)
+    tvd_e = da.TVD(method="heterogeneous bregman", weight=weight32, omega=1.0, regularization=1.0, max_num_iter=8, eps=None,
+                   promotion="native")
     ca_e = da.ConcentrationAnalysis(base, da.MonochromaticReduction(color="red"), None, tvd_e, None, **{"diff option": "positive"})
     first = ca_e(probe).img.copy()
     weight32[25, 37] *= 3.0                 # one pixel: no sample of the fingerprint sees it

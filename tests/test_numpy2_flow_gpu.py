@@ -15,6 +15,7 @@ import darsia_amd as da
 from oracle import tvd_numpy as O
 
 pytestmark = pytest.mark.gpu
+DEFAULT_DTYPE_FLOW = True   # conftest.py: this module runs the product's default dtype flow
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RTOL, ATOL = 1e-4, 1e-6
@@ -49,6 +50,11 @@ def test_float32_goldens_of_the_reference_bit_for_bit(golden, name, kw, n):
     img = golden[name + "/img"]
     assert img.dtype == np.float32
     bits(da.split_bregman_tvd(img, max_num_iter=n, promotion="numpy2", **kw), golden[name + "/out"])
+    bits(da.split_bregman_tvd(img, max_num_iter=n, **kw), golden[name + "/out"])            # ... which is the DEFAULT call
+    # the native flow on the same input: the oracle's same-dtype flow bit for bit, the reference within the tolerance here
+    nat = da.split_bregman_tvd(img, max_num_iter=n, promotion="native", **kw)
+    bits(nat, O.split_bregman_tvd(img, max_num_iter=n, promotion="strict", **kw))
+    np.testing.assert_allclose(nat, golden[name + "/out"], rtol=RTOL, atol=ATOL)
 
 
 def test_stop_iteration_and_operator_call(golden):

@@ -7,6 +7,8 @@ import pytest
 import darsia_amd as da
 from darsia_amd.restoration.split_bregman_tvd import choose_promotion, numpy2_unsupported
 
+DEFAULT_DTYPE_FLOW = True   # conftest.py: this module runs the product's default dtype flow
+
 
 def _why(img, mu=0.1, omega=1.0, ell=1.0, dim=2, x0=None, iso=False, solver=None, adaptive=None, quiet=True):
     return numpy2_unsupported(img, mu, omega, ell, dim, x0, iso, solver or da.Jacobi(), adaptive, quiet)
@@ -31,23 +33,23 @@ def test_numpy2_flow_exists_for_the_default_solve_only():
 def test_choice_of_the_dtype_flow(monkeypatch):
     monkeypatch.delenv("DXH_PROMOTION", raising=False)
     mu64, mu32 = np.ones((4, 4)), np.ones((4, 4), np.float32)
-    # default: the reference's flow exactly where a float32 image meets a float64 coefficient array and the flow exists
+    # default: the reference's own flow for every float32 image whose configuration has it
     assert choose_promotion(None, np.float32, (mu64, 1.0, 1.0), None) == "numpy2"
-    assert choose_promotion(None, np.float32, (mu32, 1.0, 1.0), None) == "native"
-    assert choose_promotion(None, np.float32, (0.1, 1.0, None), None) == "native"
+    assert choose_promotion(None, np.float32, (mu32, 1.0, 1.0), None) == "numpy2"
+    assert choose_promotion(None, np.float32, (0.1, 1.0, None), None) == "numpy2"
     assert choose_promotion(None, np.float64, (mu64, 1.0, 1.0), "the image is not float32") == "native"
     assert choose_promotion(None, np.float32, (mu64, 1.0, None), "an array-valued mu needs a scalar ell") == "native"
     # explicit wins; an explicit numpy2 where the flow does not exist is the caller's error (raised by split_bregman_tvd)
     assert choose_promotion("native", np.float32, (mu64, 1.0, 1.0), None) == "native"
-    assert choose_promotion("numpy2", np.float32, (0.1, 1.0, None), None) == "numpy2"
+    assert choose_promotion("numpy2", np.float32, (0.1, 1.0, None), "anisotropic only") == "numpy2"
     with pytest.raises(ValueError):
         choose_promotion("float16", np.float32, (0.1, 1.0, None), None)
-    # the environment variable: numpy2 wherever it exists, native otherwise
+    # the environment variable sets the default: native everywhere, or numpy2 wherever it exists
+    monkeypatch.setenv("DXH_PROMOTION", "native")
+    assert choose_promotion(None, np.float32, (mu64, 1.0, 1.0), None) == "native"
     monkeypatch.setenv("DXH_PROMOTION", "numpy2")
     assert choose_promotion(None, np.float32, (0.1, 1.0, None), None) == "numpy2"
     assert choose_promotion(None, np.float32, (0.1, 1.0, None), "anisotropic only") == "native"
-    monkeypatch.setenv("DXH_PROMOTION", "native")
-    assert choose_promotion(None, np.float32, (mu64, 1.0, 1.0), None) == "native"
 
 
 def test_concentration_analysis_says_why_a_frame_leaves_the_fused_pipeline():
@@ -73,7 +75,13 @@ def test_concentration_analysis_says_why_a_frame_leaves_the_fused_pipeline():
     assert why is None and plan[-1] == "op"
     tvd32 = da.TVD(method="heterogeneous bregman", weight=np.full((12, 14), 0.1, np.float32), max_num_iter=3, eps=None)
     plan, why = da.ConcentrationAnalysis(base, red, None, tvd32, None)._fusable_why(probe)
-    assert why is None and plan[-1] == "hb"
+    assert why is None and plan[-1] == "op"                     # float32 signal: the reference's flow whatever the weights' type
+    tvd_native = da.TVD(method="heterogeneous bregman", weight=0.1, max_num_iter=3, eps=None, promotion="native")
+    plan, why = da.ConcentrationAnalysis(base, red, None, tvd_native, None)._fusable_why(probe)
+    assert why is None and plan[-1] == "hb"                     # asked for: the context's own float32 iterations
+    base64 = da.OpticalImage(base.img.astype(np.float64))
+    plan, why = da.ConcentrationAnalysis(base64, red, None, tvd32, None)._fusable_why(probe.astype(np.float64))
+    assert why is None and plan[-1] == "hb"                     # float64 signal: one flow, the reference's
     # the host chain itself needs no device when nothing in it does: path and reason are recorded
     ca = da.ConcentrationAnalysis(base, red, lambda x: x, None, None, **{"diff option": "positive"})
     out = ca(da.OpticalImage(probe))
