@@ -1703,6 +1703,20 @@ __global__ void __launch_bounds__(256) k_scale_dense(const T* __restrict__ src, 
     if (i < n) dst[i] = s * src[i];
 }
 
+// dense (n0, L) array of one float type <-> pitched plane of the other (round to nearest, as ndarray.astype)
+template <typename TS, typename TD>
+__global__ void __launch_bounds__(256) k_dense_to_plane(Geom g, const TS* __restrict__ src, TD* __restrict__ plane) {
+    ElemIdx e;
+    if (!elem_index(g, e)) return;
+    plane[e.off] = (TD)src[e.row * g.L + e.x];
+}
+template <typename TS, typename TD>
+__global__ void __launch_bounds__(256) k_plane_to_dense(Geom g, const TS* __restrict__ plane, TD* __restrict__ dst) {
+    ElemIdx e;
+    if (!elem_index(g, e)) return;
+    dst[e.row * g.L + e.x] = (TD)plane[e.off];
+}
+
 namespace {
 // k_signal<T, CH, S, B> for the types the arguments name
 template <typename T, int CH, typename S, typename B>
@@ -2674,23 +2688,26 @@ int dxh_tvd_upload_typed(dxh_tvd_t h, const void* img, int img_dtype) {
     DXH_REQUIRE(c && img, "null argument");
     DXH_REQUIRE(img_dtype == DXH_F32 || img_dtype == DXH_F64, "image dtype must be float32 or float64");
     if (img_dtype == c->desc.dtype) return dxh_tvd_upload(h, img, nullptr, nullptr, nullptr);
+    if (!c->have_coefs) { set_error("dxh_tvd_set_coeffs must be called before dxh_tvd_upload"); return DXH_ESTATE; }
     int rc = set_device(c);
     if (rc) return rc;
     const size_t n = (size_t)c->g.n0 * (size_t)c->g.L, ssz = img_dtype == DXH_F32 ? 4 : 8;
-    DevTmp raw, conv;
+    void* raw = nullptr;   // the image as stored, in HBM (a cached block: exact-size re-use from call to call)
     const void* src = img;
     if (!is_device_ptr(src)) {
-        DXH_HIP(hipMalloc(&raw.p, n * ssz));
-        DXH_HIP(hipMemcpyAsync(raw.p, src, n * ssz, hipMemcpyDefault, c->stream));
-        src = raw.p;
+        DXH_HIP(pool_malloc(&raw, n * ssz));
+        hipError_t e = hipMemcpyAsync(raw, src, n * ssz, hipMemcpyDefault, c->stream);
+        if (e != hipSuccess) { pool_free(raw); set_error("upload failed: %s", hipGetErrorString(e)); return DXH_EHIP; }
+        src = raw;
     }
-    DXH_HIP(hipMalloc(&conv.p, n * c->esz));
-    const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
-    if (img_dtype == DXH_F64) hipLaunchKernelGGL((k_convert_dense<double, float>), grid, blk, 0, c->stream, (const double*)src, (float*)conv.p, n);
-    else hipLaunchKernelGGL((k_convert_dense<float, double>), grid, blk, 0, c->stream, (const float*)src, (double*)conv.p, n);
-    DXH_HIP(hipGetLastError());
-    rc = dxh_tvd_upload(h, conv.p, nullptr, nullptr, nullptr);
-    (void)hipStreamSynchronize(c->stream);
+    // converted straight into the context's (pitched) image plane
+    if (img_dtype == DXH_F64) hipLaunchKernelGGL((k_dense_to_plane<double, float>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const double*)src, (float*)c->u[0]);
+    else hipLaunchKernelGGL((k_dense_to_plane<float, double>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const float*)src, (double*)c->u[0]);
+    rc = hipGetLastError() == hipSuccess ? finish_upload(c, nullptr, nullptr, nullptr) : DXH_EHIP;
+    if (raw) {
+        (void)hipStreamSynchronize(c->stream);
+        pool_free(raw);
+    }
     return rc;
 }
 
@@ -2703,16 +2720,23 @@ int dxh_tvd_download_typed(dxh_tvd_t h, void* u, int out_dtype) {
     int rc = set_device(c);
     if (rc) return rc;
     const size_t n = (size_t)c->g.n0 * (size_t)c->g.L, osz = out_dtype == DXH_F32 ? 4 : 8;
-    DevTmp dense, conv;
-    DXH_HIP(hipMalloc(&dense.p, n * c->esz));
-    DXH_HIP(hipMalloc(&conv.p, n * osz));
-    if ((rc = dxh_tvd_download(h, dense.p, nullptr, nullptr))) return rc;   // pitched plane -> dense, inside HBM
-    const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
-    if (out_dtype == DXH_F32) hipLaunchKernelGGL((k_convert_dense<double, float>), grid, blk, 0, c->stream, (const double*)dense.p, (float*)conv.p, n);
-    else hipLaunchKernelGGL((k_convert_dense<float, double>), grid, blk, 0, c->stream, (const float*)dense.p, (double*)conv.p, n);
-    DXH_HIP(hipGetLastError());
-    DXH_HIP(hipMemcpyAsync(u, conv.p, n * osz, hipMemcpyDefault, c->stream));
-    DXH_HIP(hipStreamSynchronize(c->stream));
+    HostPrefault pf;   // map the output pages while the device converts (and, after an asynchronous run, still iterates)
+    pf.start(u, n * osz);
+    if (c->signal) {   // a slab: a timed-out halo wait makes the state invalid (slab_check_fault)
+        DXH_HIP(hipStreamSynchronize(c->stream));
+        if ((rc = slab_check_fault(c))) return rc;
+    }
+    const bool to_device = is_device_ptr(u);
+    void* conv = to_device ? u : nullptr;   // a device-resident result is written where it goes
+    if (!conv) DXH_HIP(pool_malloc(&conv, n * osz));
+    if (out_dtype == DXH_F32) hipLaunchKernelGGL((k_plane_to_dense<double, float>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const double*)c->u[c->cur], (float*)conv);
+    else hipLaunchKernelGGL((k_plane_to_dense<float, double>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const float*)c->u[c->cur], (double*)conv);
+    hipError_t e = hipGetLastError();
+    pf.join();
+    if (e == hipSuccess && !to_device) e = hipMemcpyAsync(u, conv, n * osz, hipMemcpyDefault, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (!to_device) pool_free(conv);
+    if (e != hipSuccess) { set_error("download failed: %s", hipGetErrorString(e)); return DXH_EHIP; }
     return DXH_OK;
 }
 
