@@ -1721,8 +1721,13 @@ struct Np2Coef {
     int first;       // u still holds the float32 image: neighbour sums in float32 (first iteration of a call)
 };
 
+// FAST (callers guarantee k >= 0: the scalar threshold of a fused launch): q - clamp(q, -k, k), which is
+// max(|q| - k, 0) sign(q) bit for bit up to the sign of a zero that no later operation can tell apart (split_vars).
+template <bool FAST = false>
 __device__ __forceinline__ void np2_split(double q, double kq, float& d, float& b) {
-    const double d64 = t_max0(fabs(q) - kq) * sgn(q);   // np.maximum(np.abs(x) - k, 0) * np.sign(x), float64
+    double d64;
+    if constexpr (FAST) d64 = q - t_clamp_sym(q, kq);
+    else d64 = t_max0(fabs(q) - kq) * sgn(q);           // np.maximum(np.abs(x) - k, 0) * np.sign(x), float64
     d = (float)d64;                                       // d[..., j] = ...   (float32 array)
     b = (float)(q - (double)d);                           // b[..., j] = dub - d[..., j]
 }
@@ -1789,7 +1794,7 @@ __global__ void __launch_bounds__(256) k_fused_np2(FusedArgs<double> a, Np2Coef 
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             float d, b;
-            np2_split(q0v[j], KQARR ? kqm[j] : kq[j], d, b);
+            np2_split<!KQARR>(q0v[j], KQARR ? kqm[j] : kq[j], d, b);
             t0m[j] = k.ell * (b - d);
             upm[j] = T(0);
             b0m[j] = 0.f;
@@ -1820,8 +1825,8 @@ __global__ void __launch_bounds__(256) k_fused_np2(FusedArgs<double> a, Np2Coef 
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 float d0, b0, d1, b1;
-                np2_split(q0r[j], kq[j], d0, b0);
-                np2_split(q1r[j], kq[j], d1, b1);
+                np2_split<!KQARR>(q0r[j], kq[j], d0, b0);
+                np2_split<!KQARR>(q1r[j], kq[j], d1, b1);
                 b0c[j] = b0;
                 b1c[j] = b1;
                 t0c[j] = k.ell * (b0 - d0);
@@ -2245,8 +2250,8 @@ struct Pipe {
                     t1c[j] = st.coef[s][0][j] * (b[1] - d[1]);
                 } else if constexpr (NP2) {
                     float df[2], bf[2];
-                    np2_split((double)qq[0], (double)(KQV ? st.kqv[s][j] : kq), df[0], bf[0]);
-                    np2_split((double)qq[1], (double)(KQV ? st.kqv[s][j] : kq), df[1], bf[1]);
+                    np2_split<!KQV>((double)qq[0], (double)(KQV ? st.kqv[s][j] : kq), df[0], bf[0]);
+                    np2_split<!KQV>((double)qq[1], (double)(KQV ? st.kqv[s][j] : kq), df[1], bf[1]);
                     b[0] = (T)bf[0];
                     b[1] = (T)bf[1];
                     t0c[j] = (T)(ell_f * (bf[0] - df[0]));
@@ -2626,7 +2631,7 @@ __device__ __forceinline__ void pipe_prologue(const PipeT& pp, PipeState<T, K>& 
             st.t0[0][1][j] = cfm[0][j] * (b[0] - d[0]);
         } else if constexpr (PipeT::kNP2) {
             float df, bf;
-            np2_split((double)qq[0], (double)(KQV ? kqm[j] : pp.kq), df, bf);
+            np2_split<!KQV>((double)qq[0], (double)(KQV ? kqm[j] : pp.kq), df, bf);
             b[0] = (T)bf;
             st.t0[0][1][j] = (T)(pp.ell_f * (bf - df));
         } else if constexpr (KQV) {
