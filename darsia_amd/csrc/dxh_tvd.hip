@@ -2212,9 +2212,12 @@ static double banded_time(const std::vector<int64_t>& cuts, int64_t H, int64_t h
     return td;
 }
 
-int dxh_tvd_solve_banded(const dxh_tvd_desc* desc, const void* img, void* out, double mu, const void* mu_arr, double omega,
-                         const void* omega_arr, int has_ell, double ell, const void* ell_arr, int n_iter,
-                         int jacobi_maxiter, uint32_t flags, int nbands, int* nbands_used) {
+// host_dtype: element type of img / out (the coefficient arrays have the context's); promotion: DXH_PROMOTION_* of the
+// band contexts (numpy2: a float32 host image through float64 contexts, scalar coefficients)
+static int solve_banded_impl(const dxh_tvd_desc* desc, const void* img, void* out, int host_dtype, int promotion, double mu,
+                             const void* mu_arr, double omega, const void* omega_arr, int has_ell, double ell,
+                             const void* ell_arr, int n_iter, int jacobi_maxiter, uint32_t flags, int nbands,
+                             int* nbands_used) {
     DXH_REQUIRE(desc && img && out, "null argument");
     DXH_REQUIRE(desc->struct_size == (int32_t)sizeof(dxh_tvd_desc), "dxh_tvd_desc size mismatch");
     DXH_REQUIRE(desc->dim == 2, "row bands need dim == 2 (axis 0 is the band axis; a volume's planes are coupled along it "
@@ -2224,7 +2227,9 @@ int dxh_tvd_solve_banded(const dxh_tvd_desc* desc, const void* img, void* out, d
     DXH_REQUIRE(nbands >= 0 && nbands <= 64, "nbands must be 0 (choose) .. 64");
     DXH_REQUIRE(!is_device_ptr(img) && !is_device_ptr(out), "host arrays expected (device arrays: dxh_tvd_run)");
     const int64_t H = desc->n0, L = desc->n1 * desc->n2;
-    const size_t esz = desc->dtype == DXH_F32 ? 4 : 8;
+    const size_t esz = host_dtype == DXH_F32 ? 4 : 8, csz = desc->dtype == DXH_F32 ? 4 : 8;
+    const bool typed = host_dtype != desc->dtype;
+    const bool np2 = (promotion & DXH_PROMOTION_NUMPY2) != 0;
     const int64_t ht = (int64_t)n_iter * jacobi_maxiter, hb = ht + 1;
     int S = nbands;
     double edge = 1.0;
@@ -2235,6 +2240,7 @@ int dxh_tvd_solve_banded(const dxh_tvd_desc* desc, const void* img, void* out, d
         // bands iterate ~20 % slower than their share of the whole image (fewer row chunks, the copies alongside)
         const double sec_copy = (double)L * esz / 50e9;
         double per = desc->dtype == DXH_F32 ? 1.6e-12 : 3.6e-12;
+        if (np2) per = 3.9e-12;
         if ((flags & DXH_FLAG_ISOTROPIC) || mu_arr || omega_arr || ell_arr) per *= 1.5;
         const double sec_comp = (double)L * per * n_iter * jacobi_maxiter;
         band_cuts(H, 1, 1.0, &cuts);
@@ -2245,7 +2251,8 @@ int dxh_tvd_solve_banded(const dxh_tvd_desc* desc, const void* img, void* out, d
             for (double e : {1.0, 0.7, 0.45}) {
                 if (k < 3 && e != 1.0) continue;
                 band_cuts(H, k, e, &cuts);
-                const double t = banded_time(cuts, H, ht, hb, sec_copy, 1.2 * sec_comp, sec_copy, 0.3e-3);
+                // (the numpy2 pipelines are arithmetic-bound: the copies alongside cost them less -- 1.1, measured)
+                const double t = banded_time(cuts, H, ht, hb, sec_copy, (np2 ? 1.1 : 1.2) * sec_comp, sec_copy, 0.3e-3);
                 if (t < 0.97 * best) { best = t; S = k; edge = e; }
             }
         }
@@ -2261,7 +2268,8 @@ int dxh_tvd_solve_banded(const dxh_tvd_desc* desc, const void* img, void* out, d
     HostPrefault pf;  // map the result's pages while the first band goes up
     pf.start(out, (size_t)H * L * esz, {{img, (size_t)H * L * esz}});
 
-    struct Band { int64_t own0, own1, lo, hi; dxh_tvd_t ctx = nullptr; hipEvent_t up = nullptr, done = nullptr; std::atomic<int> state{0}; };
+    struct Band { int64_t own0, own1, lo, hi; dxh_tvd_t ctx = nullptr; hipEvent_t up = nullptr, done = nullptr; std::atomic<int> state{0};
+                  void* raw = nullptr; };   // raw: the band's rows as the host stores them (typed), converted on the device
     std::atomic<int> downloaded{0};   // bands whose rows are back on the host (or given up)
     std::vector<Band> bands(S);
     for (int b = 0; b < S; ++b) {
@@ -2279,6 +2287,9 @@ int dxh_tvd_solve_banded(const dxh_tvd_desc* desc, const void* img, void* out, d
     auto at = [&](const void* base, int64_t row) -> const void* {
         return base ? static_cast<const char*>(base) + (size_t)row * L * esz : nullptr;
     };
+    auto coef_at = [&](const void* base, int64_t row) -> const void* {
+        return base ? static_cast<const char*>(base) + (size_t)row * L * csz : nullptr;
+    };
     // the uploader: creates band b's context, sends its rows up and enqueues its iterations
     std::thread uploader([&]() {
         for (int b = 0; b < S; ++b) {
@@ -2293,7 +2304,8 @@ int dxh_tvd_solve_banded(const dxh_tvd_desc* desc, const void* img, void* out, d
             while (downloaded.load(std::memory_order_acquire) < b - 2) std::this_thread::yield();
             tr[b][0] = now_ms();
             int r = dxh_tvd_create(&bd.ctx, &d);
-            if (!r) r = dxh_tvd_set_coeffs(bd.ctx, mu, at(mu_arr, bd.lo), omega, at(omega_arr, bd.lo), has_ell, ell, at(ell_arr, bd.lo));
+            if (!r && promotion) r = dxh_tvd_set_promotion(bd.ctx, promotion);
+            if (!r) r = dxh_tvd_set_coeffs(bd.ctx, mu, coef_at(mu_arr, bd.lo), omega, coef_at(omega_arr, bd.lo), has_ell, ell, coef_at(ell_arr, bd.lo));
             tr[b][1] = now_ms();
             if (!r) {
                 Ctx* c = reinterpret_cast<Ctx*>(bd.ctx);
@@ -2301,8 +2313,19 @@ int dxh_tvd_solve_banded(const dxh_tvd_desc* desc, const void* img, void* out, d
                 hipError_t e = hipEventCreateWithFlags(&bd.up, hipEventDisableTiming);
                 if (e == hipSuccess && b > 0) e = hipStreamWaitEvent(c->stream, bands[b - 1].up, 0);
                 if (e != hipSuccess) { set_error("band event failed: %s", hipGetErrorString(e)); r = DXH_EHIP; }
-                if (!r) r = h2d_plane(c, c->u[0], at(img, bd.lo));
+                if (!r && !typed) r = h2d_plane(c, c->u[0], at(img, bd.lo));
+                if (!r && typed) {   // the rows as stored, then converted straight into the pitched image plane
+                    const size_t nb = (size_t)(bd.hi - bd.lo) * L * esz;
+                    e = pool_malloc(&bd.raw, nb);
+                    if (e == hipSuccess) e = hipMemcpyAsync(bd.raw, at(img, bd.lo), nb, hipMemcpyDefault, c->stream);
+                    if (e != hipSuccess) { set_error("band upload failed: %s", hipGetErrorString(e)); r = DXH_EHIP; }
+                }
                 if (!r && hipEventRecord(bd.up, c->stream) != hipSuccess) { set_error("hipEventRecord failed"); r = DXH_EHIP; }
+                if (!r && typed) {
+                    if (host_dtype == DXH_F32) hipLaunchKernelGGL((k_dense_to_plane<float, double>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const float*)bd.raw, (double*)c->u[0]);
+                    else hipLaunchKernelGGL((k_dense_to_plane<double, float>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const double*)bd.raw, (float*)c->u[0]);
+                    if (hipGetLastError() != hipSuccess) { set_error("band conversion failed"); r = DXH_EHIP; }
+                }
                 if (!r) r = finish_upload(c, nullptr, nullptr, nullptr, /*lean=*/true);
             }
             tr[b][2] = now_ms();
@@ -2335,9 +2358,25 @@ int dxh_tvd_solve_banded(const dxh_tvd_desc* desc, const void* img, void* out, d
         Ctx* c = reinterpret_cast<Ctx*>(bd.ctx);
         tr[b][4] = now_ms();
         const char* src = static_cast<const char*>(c->u[c->cur]) + (size_t)(bd.own0 - bd.lo) * c->g.pitch * c->esz;
-        hipError_t e = hipMemcpy2DAsync(static_cast<char*>(out) + (size_t)bd.own0 * L * esz, L * esz, src, c->g.pitch * c->esz,
-                                        L * esz, bd.own1 - bd.own0, hipMemcpyDefault, c->stream);
+        hipError_t e = hipSuccess;
+        void* conv = nullptr;
+        if (!typed) {
+            e = hipMemcpy2DAsync(static_cast<char*>(out) + (size_t)bd.own0 * L * esz, L * esz, src, c->g.pitch * c->esz,
+                                 L * esz, bd.own1 - bd.own0, hipMemcpyDefault, c->stream);
+        } else {   // the owned rows, rounded to the host's type (ndarray.astype) into a dense block, then down in one copy
+            Geom g2 = c->g;
+            g2.n0 = bd.own1 - bd.own0;
+            const size_t nb = (size_t)g2.n0 * L * esz;
+            e = pool_malloc(&conv, nb);
+            if (e == hipSuccess) {
+                if (host_dtype == DXH_F32) hipLaunchKernelGGL((k_plane_to_dense<double, float>), elem_grid(g2), dim3(256), 0, c->stream, g2, (const double*)src, (float*)conv);
+                else hipLaunchKernelGGL((k_plane_to_dense<float, double>), elem_grid(g2), dim3(256), 0, c->stream, g2, (const float*)src, (double*)conv);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(static_cast<char*>(out) + (size_t)bd.own0 * L * esz, conv, nb, hipMemcpyDefault, c->stream);
+        }
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (conv) pool_free(conv);
         if (e != hipSuccess) { set_error("band download failed: %s", hipGetErrorString(e)); rc = DXH_EHIP; }
         tr[b][5] = now_ms();
         downloaded.store(b + 1, std::memory_order_release);
@@ -2352,6 +2391,7 @@ int dxh_tvd_solve_banded(const dxh_tvd_desc* desc, const void* img, void* out, d
             dxh_tvd_destroy(bd.ctx);
         }
     for (auto& bd : bands) {
+        if (bd.raw) pool_free(bd.raw);
         if (bd.up) (void)hipEventDestroy(bd.up);
         if (bd.done) (void)hipEventDestroy(bd.done);
     }
@@ -2363,6 +2403,27 @@ int dxh_tvd_solve_banded(const dxh_tvd_desc* desc, const void* img, void* out, d
         fprintf(stderr, "[dxh bands] joined %.2f, contexts destroyed %.2f ms\n", t_joined, now_ms());
     }
     return rc;
+}
+
+int dxh_tvd_solve_banded(const dxh_tvd_desc* desc, const void* img, void* out, double mu, const void* mu_arr, double omega,
+                         const void* omega_arr, int has_ell, double ell, const void* ell_arr, int n_iter,
+                         int jacobi_maxiter, uint32_t flags, int nbands, int* nbands_used) {
+    DXH_REQUIRE(desc, "null argument");
+    return solve_banded_impl(desc, img, out, desc->dtype, DXH_PROMOTION_NATIVE, mu, mu_arr, omega, omega_arr, has_ell, ell, ell_arr,
+                             n_iter, jacobi_maxiter, flags, nbands, nbands_used);
+}
+
+int dxh_tvd_solve_banded_typed(const dxh_tvd_desc* desc, const void* img, void* out, int host_dtype, int promotion, double mu,
+                               double omega, int has_ell, double ell, int n_iter, uint32_t flags, int nbands,
+                               int* nbands_used) {
+    DXH_REQUIRE(desc, "null argument");
+    DXH_REQUIRE(host_dtype == DXH_F32 || host_dtype == DXH_F64, "host dtype must be float32 or float64");
+    DXH_REQUIRE(promotion == DXH_PROMOTION_NATIVE || promotion == DXH_PROMOTION_NUMPY2, "promotion must be native or numpy2");
+    if (promotion == DXH_PROMOTION_NUMPY2)
+        DXH_REQUIRE(host_dtype == DXH_F32 && desc->dtype == DXH_F64 && !(flags & DXH_FLAG_ISOTROPIC),
+                    "numpy2 promotion: a float32 host image through float64 contexts, anisotropic");
+    return solve_banded_impl(desc, img, out, host_dtype, promotion, mu, nullptr, omega, nullptr, has_ell, ell, nullptr, n_iter, 1,
+                             flags, nbands, nbands_used);
 }
 
 int dxh_tvd_download(dxh_tvd_t h, void* u, void* d, void* b) {

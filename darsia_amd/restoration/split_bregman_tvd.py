@@ -249,6 +249,30 @@ def solve_banded(img: np.ndarray, mu, omega, ell, n_iter: int, jacobi_maxiter: i
     return (out, used.value) if return_bands else out
 
 
+def solve_banded_numpy2(img: np.ndarray, mu: float, omega: float, ell: Optional[float], n_iter: int, nbands: int = 0,
+                        device: Optional[int] = None, return_bands: bool = False):
+    """The row-band whole call for the reference's float32 dtype flow (``dxh_tvd_solve_banded_typed``): a float32 host
+    image through float64 band contexts with promotion "numpy2", scalar coefficients, Jacobi(maxiter=1)."""
+    lib = _lib.load()
+    _lib.require_gpu()
+    src = np.ascontiguousarray(img, dtype=np.float32)
+    ndim, n0, n1, n2 = _lib.shape3(src.shape, 2)
+    d = _lib.TvdDesc()
+    d.struct_size = C.sizeof(_lib.TvdDesc)
+    d.device = _lib.default_device() if device is None else device
+    d.dtype = _lib.dtype_code(np.dtype(np.float64))
+    d.ndim, d.dim, d.nsum = ndim, 2, _lib.NSUM_ALL_AXES
+    d.n0, d.n1, d.n2 = n0, n1, n2
+    d.top_is_boundary = d.bottom_is_boundary = 1
+    out = np.empty(src.shape, np.float32)
+    used = C.c_int(0)
+    has_ell, ell_s = (0, 0.0) if ell is None else (1, float(ell))
+    _lib.check(lib.dxh_tvd_solve_banded_typed(C.byref(d), _lib.ptr(src), _lib.ptr(out), _lib.dtype_code(np.dtype(np.float32)),
+                                              _lib.PROMOTION_NUMPY2, float(mu), float(omega), has_ell, ell_s, int(n_iter),
+                                              0, int(nbands), C.byref(used)))
+    return (out, used.value) if return_bands else out
+
+
 def numpy2_unsupported(img, mu, omega, ell, dim, x0, isotropic, solver, adaptive, quiet) -> Optional[str]:
     """None when the reference's NumPy >= 2 flow for a float32 image exists on the device for this call, else why not."""
     if img.dtype != np.float32:
@@ -352,6 +376,11 @@ def split_bregman_tvd(
         # coefficients' fingerprints are the same (in-place edits of a weight array: outside the contract, clear the dict)
         from ..concentration import _fingerprint
 
+        if (not on_device and eps is None and np.ndim(mu) == 0 and max_num_iter >= 1 and img.nbytes >= (32 << 20)):
+            # fixed iteration count on a large host image with scalar coefficients: row bands through the device, the
+            # transfers overlapped with the iterations (bit-identical to the one-piece run below; an array-valued mu stays
+            # with the kept context, whose weight planes need not cross PCIe again)
+            return solve_banded_numpy2(img, mu, omega, ell, max_num_iter)
         device = img.device if on_device else _lib.default_device()
         key = (tuple(img.shape), device)
         mark = tuple(_fingerprint(v) for v in (mu, omega, ell))

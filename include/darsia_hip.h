@@ -169,6 +169,15 @@ int dxh_tvd_solve_banded(const dxh_tvd_desc* desc, const void* img, void* out, d
                          int jacobi_maxiter, uint32_t flags, int nbands, int* nbands_used);
 
 /*
+ * The same for a host image of another float type than the band contexts' (converted on the device, band by band), with
+ * scalar coefficients and one Jacobi sweep.  promotion = DXH_PROMOTION_NUMPY2: host_dtype DXH_F32, desc->dtype DXH_F64 --
+ * the reference's NumPy >= 2 dtype flow for a float32 image (dxh_tvd_set_promotion), bit-identical to the one-piece run.
+ */
+int dxh_tvd_solve_banded_typed(const dxh_tvd_desc* desc, const void* img, void* out, int host_dtype, int promotion, double mu,
+                               double omega, int has_ell, double ell, int n_iter, uint32_t flags, int nbands,
+                               int* nbands_used);
+
+/*
  * ConcentrationAnalysis fusion (multi_image_analysis/concentrationanalysis.py:230-310): the elementwise stages
  * either side of the restoration run on the device, so that a frame goes up once (colour) and the
  * concentration comes down once (scalar).  The context is the scalar (H, W) TVD problem.

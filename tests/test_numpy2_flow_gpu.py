@@ -219,3 +219,37 @@ def test_operator_keeps_its_numpy2_context_between_calls(mixed):
     assert copy.deepcopy(op)._contexts == {}
     op.release()
     assert op._contexts == {}
+
+
+@pytest.mark.parametrize("shape,n,nbands", [((300, 200, 3), 7, 3), ((257, 129), 5, 4), ((96, 64, 2), 6, 2), ((40, 33, 3), 9, 0)],
+                         ids=["rgb", "gray-odd", "2ch", "auto"])
+def test_row_bands_of_the_numpy2_flow_equal_the_one_piece_run_and_the_oracle(shape, n, nbands):
+    """dxh_tvd_solve_banded_typed: float32 host rows through float64 band contexts (promotion numpy2), each band with the
+    dependence cone of n iterations as halo -- the whole-image result bit for bit."""
+    from darsia_amd.restoration.split_bregman_tvd import solve_banded_numpy2
+
+    rng = np.random.default_rng(17)
+    img = rng.random(shape, dtype=np.float32)
+    for kw in (dict(mu=0.1, omega=1.0, ell=None), dict(mu=1.0, omega=0.7, ell=0.45)):
+        out, used = solve_banded_numpy2(img, kw["mu"], kw["omega"], kw["ell"], n, nbands=nbands, return_bands=True)
+        assert out.dtype == np.float32 and (nbands == 0 or used == nbands)
+        bits(out, O.split_bregman_tvd(img, max_num_iter=n, promotion="numpy2", **kw))
+        with da.DeviceTVD(img.shape, img.dtype, promotion="numpy2") as st:
+            st.set_coeffs(kw["mu"], kw["omega"], kw["ell"], img)
+            st.upload(img)
+            st.run(n)
+            bits(out, st.download())
+
+
+def test_large_host_image_takes_the_row_bands_by_default():
+    """>= 32 MB float32 host image, scalar coefficients, fixed iteration count: the default call goes through the bands
+    (a size the oracle cannot check in seconds: against the one-piece device run, bit for bit)."""
+    rng = np.random.default_rng(3)
+    img = rng.random((1500, 2000, 3), dtype=np.float32)
+    assert img.nbytes >= (32 << 20)
+    out = da.split_bregman_tvd(img, mu=0.1, max_num_iter=12)
+    with da.DeviceTVD(img.shape, img.dtype, promotion="numpy2") as st:
+        st.set_coeffs(0.1, 1.0, None, img)
+        st.upload(img)
+        st.run(12)
+        bits(out, st.download())
