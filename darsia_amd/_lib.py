@@ -34,7 +34,7 @@ EXPORTS = (
     "dxh_tvd_energy", "dxh_tvd_adapt_ell", "dxh_tvd_set_base", "dxh_tvd_set_cleaning_filter", "dxh_tvd_upload_signal", "dxh_tvd_download_model", "dxh_tvd_set_base_typed", "dxh_tvd_upload_signal_typed", "dxh_warp_patches_typed", "dxh_phase_correlation",
     "dxh_comm_unique_id", "dxh_comm_create_rccl", "dxh_comm_create_host", "dxh_comm_destroy", "dxh_comm_allreduce",
     "dxh_comm_barrier", "dxh_comm_info", "dxh_tvd_attach_comm", "dxh_tvd_exchange", "dxh_tvd_run_slab",
-    "dxh_mem_alloc", "dxh_mem_free", "dxh_mem_copy", "dxh_sqrt_probe", "dxh_rcp_probe", "dxh_tvd_solve_banded", "dxh_tvd_solve_banded_typed", "dxh_mem_trim", "dxh_tps_eval_pair", "dxh_tvd_set_coeffs_typed", "dxh_tvd_slab_stats",
+    "dxh_mem_alloc", "dxh_mem_free", "dxh_mem_copy", "dxh_sqrt_probe", "dxh_rcp_probe", "dxh_tvd_solve_banded", "dxh_tvd_solve_banded_typed", "dxh_warp_div_probe", "dxh_mem_trim", "dxh_tps_eval_pair", "dxh_tvd_set_coeffs_typed", "dxh_tvd_slab_stats",
     "dxh_phase_correlation_q", "dxh_scale", "dxh_isofac_probe", "dxh_tvd_set_promotion", "dxh_tvd_upload_typed", "dxh_tvd_download_typed",
 )
 
@@ -166,6 +166,7 @@ def _declare(lib):
     lib.dxh_tvd_solve_banded.argtypes = [C.POINTER(TvdDesc), vp, vp, dbl, vp, dbl, vp, i, dbl, vp, i, i, C.c_uint32, i,
                                          C.POINTER(i)]
     lib.dxh_tvd_solve_banded_typed.argtypes = [C.POINTER(TvdDesc), vp, vp, i, i, dbl, dbl, i, dbl, i, C.c_uint32, i, C.POINTER(i)]
+    lib.dxh_warp_div_probe.argtypes = [i, C.c_ulonglong, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     lib.dxh_sqrt_probe.argtypes = [i, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     lib.dxh_rcp_probe.argtypes = [i, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     lib.dxh_scale.argtypes = [i, i, C.c_size_t, vp, dbl, vp]

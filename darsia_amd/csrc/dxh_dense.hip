@@ -34,12 +34,65 @@ struct WarpPatch {
     int pad;                     // set by dxh_warp_patches: ceil(2^32 / bw0) for the division by bw0, 0 = divide
 };
 
-// saturate_cast<int>(max(INT_MIN, min(INT_MAX, v))) with cvRound's round-half-to-even: the clamped value is an int
+// saturate_cast<int>(max(INT_MIN, min(INT_MAX, v))) with cvRound's round-half-to-even: the clamped value is an int.
+// fmax / fmin return the other operand for a NaN (so NaN -> INT_MIN like the comparison chain of the host code), and the
+// clamped v plus 1.5 * 2^52 is rounded to an integer by the addition itself (ulp = 1, ties to even), whose two's complement
+// sits in the low word: three full-rate operations instead of compares, selects, v_rndne_f64 and v_cvt_i32_f64.
 __device__ __forceinline__ int round_half_even_clamped(double v) {
-    const double lo = -2147483648.0, hi = 2147483647.0;
-    v = v < lo ? lo : (v > hi ? hi : v);  // NaN falls through to lo below
-    if (!(v == v)) v = lo;
-    return __double2int_rn(v);            // v_cvt_i32_f64: round to nearest even
+    v = fmin(fmax(v, -2147483648.0), 2147483647.0);
+    return __double2loint(v + 6755399441055744.0);
+}
+
+// W != 0 ? 32.0 / W : 0.0  (OpenCV's perspective scale).  The compiler's correctly rounded division is
+// v_div_scale x 2, v_rcp_f64, two Newton steps, q0 = n r, e = n - d q0, v_div_fmas, v_div_fixup; for a denominator whose
+// exponent is far from both ends nothing is scaled, v_div_fmas is a plain FMA and v_div_fixup passes the quotient through,
+// so the same operations without the three quarter-rate helpers give the same bits (dxh_warp_div_probe compares the two
+// on the device over random and edge denominators).  Everything else -- zero, denormals, huge values, NaN -- divides.
+__device__ __forceinline__ double warp_scale_ieee(double W) { return W != 0.0 ? 32.0 / W : 0.0; }
+__device__ __forceinline__ double warp_scale(double W) {
+#ifdef DXH_WARP_IEEE
+    return warp_scale_ieee(W);
+#else
+    const unsigned ex = ((unsigned)__double2hiint(W) >> 20) & 0x7ffu;
+    if (ex - 523u < 1001u) {   // 2^-500 <= |W| < 2^501
+        double r = __builtin_amdgcn_rcp(W);
+        double e = fma(-W, r, 1.0);
+        r = fma(r, e, r);
+        e = fma(-W, r, 1.0);
+        r = fma(r, e, r);
+        const double q0 = 32.0 * r;
+        return fma(fma(-W, q0, 32.0), r, q0);
+    }
+    return warp_scale_ieee(W);
+#endif
+}
+
+// Device test of warp_scale against the compiler's division: every thread walks `per_thread` pseudo-random denominators
+// (splitmix64 of a global counter) -- any sign, mantissa and exponent in round 0, exponents within 2^+-16 of 1 (the
+// values a homography produces) in round 1, and the boundary exponents of the screen in round 2.
+__global__ void __launch_bounds__(256) k_warp_div_check(unsigned long long seed, int per_thread, int round,
+                                                         unsigned long long* __restrict__ bad) {
+    unsigned long long n = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) * (unsigned long long)per_thread;
+    unsigned mism = 0;
+    for (int i = 0; i < per_thread; ++i, ++n) {
+        unsigned long long z = seed + (n + 1) * 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        unsigned long long bits = z;
+        if (round == 1) {
+            const unsigned long long ex = 1023ull - 16ull + ((z >> 52) & 31ull);
+            bits = (z & 0x800FFFFFFFFFFFFFull) | (ex << 52);
+        } else if (round == 2) {
+            const unsigned long long edges[8] = {522, 523, 524, 1522, 1523, 1524, 0, 2047};
+            bits = (z & 0x800FFFFFFFFFFFFFull) | (edges[(z >> 52) & 7ull] << 52);
+        }
+        const double W = __longlong_as_double((long long)bits);
+        const double a = warp_scale(W), b = warp_scale_ieee(W);
+        const bool same = __double_as_longlong(a) == __double_as_longlong(b) || (a != a && b != b);
+        mism += same ? 0u : 1u;
+    }
+    if (mism) atomicAdd(bad, (unsigned long long)mism);
 }
 
 constexpr int kWarpBW = 256, kWarpBH = 16;
@@ -66,17 +119,18 @@ __global__ void __launch_bounds__(256) k_warp(const S* __restrict__ base, int H,
     const int k0 = bin_off[bin], k1 = bin_off[bin + 1];
     for (int kk = k0; kk < k1; ++kk) {
         const WarpPatch& p = pt[bin_idx[kk]];
-        const int tx = x - p.ox, ty = y - p.oy;
-        if (tx < 0 || ty < 0 || tx >= p.nx || ty >= p.ny) continue;
-        // tx < 2^16 and bw0 < 2^16: the high word of tx * ceil(2^32 / bw0) is the exact quotient
+        // (one batch of scalar loads for the integers of the record, no short-circuit in between)
+        const int nx = p.nx, ny = p.ny, bw0 = p.bw0;
         const unsigned magic = (unsigned)p.pad;
-        const int bx = (magic ? (int)__umulhi((unsigned)tx, magic) : tx / p.bw0) * p.bw0;
+        const int tx = x - p.ox, ty = y - p.oy;
+        if (((tx | ty) < 0) | (tx >= nx) | (ty >= ny)) continue;
+        // tx < 2^16 and bw0 < 2^16: the high word of tx * ceil(2^32 / bw0) is the exact quotient
+        const int bx = (magic ? (int)__umulhi((unsigned)tx, magic) : tx / bw0) * bw0;
         const double x1 = (double)(tx - bx), fbx = (double)bx, fy_ = (double)ty;
         const double X0 = p.minv[0] * fbx + p.minv[1] * fy_ + p.minv[2];
         const double Y0 = p.minv[3] * fbx + p.minv[4] * fy_ + p.minv[5];
         const double W0 = p.minv[6] * fbx + p.minv[7] * fy_ + p.minv[8];
-        double Wd = W0 + p.minv[6] * x1;
-        Wd = Wd != 0.0 ? 32.0 / Wd : 0.0;
+        const double Wd = warp_scale(W0 + p.minv[6] * x1);
         const int X = round_half_even_clamped((X0 + p.minv[0] * x1) * Wd);
         const int Y = round_half_even_clamped((Y0 + p.minv[3] * x1) * Wd);
         int sx = X >> 5, sy = Y >> 5;   // arithmetic shifts; saturate_cast<short> below
@@ -84,6 +138,22 @@ __global__ void __launch_bounds__(256) k_warp(const S* __restrict__ base, int H,
         sy = sy < -32768 ? -32768 : (sy > 32767 ? 32767 : sy);
         const float fx = (float)(X & 31) * (1.0f / 32.0f), fy = (float)(Y & 31) * (1.0f / 32.0f);
         const float wx[2] = {1.0f - fx, fx}, wy[2] = {1.0f - fy, fy};
+        // the four taps, loaded unconditionally from clamped positions (no divergent branches around the loads; the
+        // patch size stays in scalar registers) and zeroed by a select where the tap lies outside the patch
+        const int sh = p.sh, sw = p.sw;
+        const bool oky[2] = {(unsigned)sy < (unsigned)sh, (unsigned)(sy + 1) < (unsigned)sh};
+        const bool okx[2] = {(unsigned)sx < (unsigned)sw, (unsigned)(sx + 1) < (unsigned)sw};
+        const S* row[2];
+#pragma unroll
+        for (int ky = 0; ky < 2; ++ky) row[ky] = base + ((size_t)(p.sr0 + (oky[ky] ? sy + ky : 0)) * W + p.sc0) * C;
+        const int col[2] = {okx[0] ? sx : 0, okx[1] ? sx + 1 : 0};
+        S raw[2][2][C];
+#pragma unroll
+        for (int ky = 0; ky < 2; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 2; ++kx)
+#pragma unroll
+                for (int c = 0; c < C; ++c) raw[ky][kx][c] = row[ky][(size_t)col[kx] * C + c];
         float v[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) v[c] = 0.f;
@@ -92,13 +162,11 @@ __global__ void __launch_bounds__(256) k_warp(const S* __restrict__ base, int H,
         for (int ky = 0; ky < 2; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 2; ++kx) {
-                const int yy = sy + ky, xx = sx + kx;
-                const bool ok = yy >= 0 && yy < p.sh && xx >= 0 && xx < p.sw;
+                const bool ok = oky[ky] && okx[kx];
                 const float wgt = wy[ky] * wx[kx];
-                const S* s = base + ((size_t)(p.sr0 + (ok ? yy : 0)) * W + (p.sc0 + (ok ? xx : 0))) * C;
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
-                    const float term = (ok ? (float)s[c] : 0.f) * wgt;
+                    const float term = (ok ? (float)raw[ky][kx][c] : 0.f) * wgt;
                     v[c] = first ? term : v[c] + term;
                 }
                 first = false;
@@ -855,6 +923,26 @@ int dxh_warp_patches_typed(int device, int H, int W, int C, int dtype, const voi
     pf.join();
     if (!canvas_on_device) DXH_HIP(hipMemcpyAsync(canvas, dcanvas, bytes, hipMemcpyDefault, d.st));
     DXH_HIP(hipStreamSynchronize(d.st));  // also keeps the host-side tables alive until their copies are done
+    return DXH_OK;
+}
+
+int dxh_warp_div_probe(int device, unsigned long long seed, unsigned long long* mismatches, unsigned long long* tested) {
+    DXH_REQUIRE(mismatches && tested, "null argument");
+    int rc = check_device(device);
+    if (rc) return rc;
+    Dev d;
+    DXH_HIP(cached_stream(device, &d.st));
+    void* dbad = nullptr;
+    if ((rc = d.alloc(&dbad, sizeof(unsigned long long)))) return rc;
+    DXH_HIP(hipMemsetAsync(dbad, 0, sizeof(unsigned long long), d.st));
+    constexpr int kBlocks = 4096, kPer = 512;   // 2^29 denominators per round
+    for (int round = 0; round < 3; ++round)
+        hipLaunchKernelGGL(k_warp_div_check, dim3(kBlocks), dim3(256), 0, d.st, seed + 0x1234567ull * (unsigned)round, kPer, round,
+                           (unsigned long long*)dbad);
+    DXH_HIP(hipGetLastError());
+    DXH_HIP(hipMemcpyAsync(mismatches, dbad, sizeof(unsigned long long), hipMemcpyDefault, d.st));
+    DXH_HIP(hipStreamSynchronize(d.st));
+    *tested = 3ull * kBlocks * 256ull * kPer;
     return DXH_OK;
 }
 

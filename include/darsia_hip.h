@@ -482,6 +482,15 @@ int dxh_warp_patches_typed(int device, int H, int W, int C, int dtype, const voi
                            int npatch, void* canvas);
 
 /*
+ * Diagnostic: the projective scale 32 / W of dxh_warp_patches (cv2.warpPerspective's double-precision division,
+ * piecewiseperspective.py:121-131) is computed without the scaling helpers of the compiler's division when the exponent of W
+ * is far from both ends; this runs that code and the plain division side by side on the device over 3 x 2^29 pseudo-random
+ * denominators (all exponents; the range a homography produces; the boundaries of the screen) and counts results that
+ * differ in any bit.  Expected: 0.
+ */
+int dxh_warp_div_probe(int device, unsigned long long seed, unsigned long long* mismatches, unsigned long long* tested);
+
+/*
  * Translation of every patch of img_dst relative to the same patch of img_src by phase correlation -- the patch estimator
  * darsia_amd's registration ships where the reference calls OpenCV (ORB features + RANSAC, translationestimator.py, out of reach:
  * SURVEY.md section 2; the registration takes any estimator with that signature).  Algorithm: oracle/phase_correlation_numpy.py.

@@ -94,9 +94,14 @@ def source_coordinates(minv: np.ndarray, w: int, h: int):
 
 def warp_perspective(src: np.ndarray, m: np.ndarray, w: int, h: int) -> np.ndarray:
     """cv2.warpPerspective(src, m, (w, h), flags=INTER_LINEAR) for float32 images, constant border 0."""
+    return warp_with_inverse(src, np.linalg.inv(np.asarray(m, dtype=np.float64)), w, h)
+
+
+def warp_with_inverse(src: np.ndarray, minv: np.ndarray, w: int, h: int) -> np.ndarray:
+    """The same with the inverted matrix given (what warpPerspective works with after its own inversion): lets the tests
+    feed degenerate maps -- W = 0, denormal or huge denominators -- that no invertible homography produces."""
     src = np.asarray(src, dtype=np.float32)
     sh, sw = src.shape[:2]
-    minv = np.linalg.inv(np.asarray(m, dtype=np.float64))
     X, Y = source_coordinates(minv, w, h)
     sx = np.clip(X >> INTER_BITS, -32768, 32767)
     sy = np.clip(Y >> INTER_BITS, -32768, 32767)

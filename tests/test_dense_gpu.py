@@ -328,3 +328,50 @@ def test_find_and_warp_against_the_reference_loop(tag):
     assert res.img.dtype == want.dtype and np.array_equal(res.img, want)
     assert [type(res).__name__, str(res.name), str(list(res.dimensions))] == list(g[f"{tag}/meta"])
     assert res.scalar == (img.ndim == 2)
+
+
+def test_projective_scale_without_the_division_helpers_is_the_division():
+    """k_warp computes 32 / W as v_rcp_f64 + two Newton steps + one residual correction -- the compiler's own division
+    sequence minus v_div_scale / v_div_fmas / v_div_fixup -- wherever the exponent of W is far from both ends; the device
+    compares the two over 3 x 2^29 denominators (dxh_warp_div_probe)."""
+    import ctypes as C
+    from darsia_amd import _lib
+
+    bad, tested = C.c_ulonglong(1), C.c_ulonglong(0)
+    _lib.check(_lib.load().dxh_warp_div_probe(_lib.default_device(), 2024, C.byref(bad), C.byref(tested)))
+    assert tested.value == 3 * (1 << 29) and bad.value == 0, f"{bad.value} of {tested.value} quotients differ"
+
+
+def test_degenerate_homographies_take_the_same_path_as_the_oracle():
+    """W = 0 (scale 0), denormal and huge denominators, coordinates far outside the int range, ties of the fixed-point
+    rounding: the kernel's screen + division fallback and its clamp / round (fmax, fmin, magic-number rounding) against
+    the oracle's saturate_cast chain, bit for bit."""
+    from darsia_amd import _lib
+    from darsia_amd.registration import warp_patches
+
+    rng = np.random.default_rng(8)
+    H, Wd = 40, 70
+    img = rng.random((H, Wd)).astype(np.float32)
+    cases = [
+        [[1, 0, 0], [0, 1, 0], [0, 0, 0.0]],                   # W == 0 everywhere: scale 0 -> source (0, 0)
+        [[1, 0, 0], [0, 1, 0], [-1.0 / 16, 0, 1.0]],           # W crosses zero inside the tile (x = 16)
+        [[1e300, 0, 0], [0, 1e300, 0], [0, 0, 1e-300]],        # overflow: inf, and the int clamp
+        [[1, 0, 0], [0, 1, 0], [0, 0, 1e-310]],                # denormal W: the division path
+        [[1, 0, 0], [0, 1, 0], [0, 0, 2.0 ** -500]],           # first exponent of the fast path
+        [[1, 0, 0], [0, 1, 0], [0, 0, 2.0 ** -501]],           # last one below it
+        [[1e-200, 0, 0], [0, 1e-200, 0], [0, 0, 2.0 ** 500]],  # top of the fast path
+        [[1e12, 0, -3e11], [0, -1e12, 5e11], [0, 0, 1.0]],     # far outside int32 after the * 32
+        [[1, 0, 0.015625], [0, 1, 0.046875], [0, 0, 1.0]],     # exact ties of the 1/32 rounding
+        [[0.9, 0.05, 1.3], [-0.04, 1.1, -0.7], [1e-4, -2e-4, 1.0]],
+        [[float("nan"), 0, 0], [0, 1, 0], [0, 0, 1.0]],        # NaN coordinate -> INT_MIN
+    ]
+    for rows in cases:
+        minv = np.array(rows, dtype=np.float64)
+        table = np.zeros(1, dtype=np.dtype(_lib.WarpPatch))
+        table["minv"] = minv.reshape(1, 9)
+        table["sh"], table["sw"], table["w_eff"], table["h_eff"], table["nx"], table["ny"] = H, Wd, Wd, H, Wd, H
+        table["bw0"] = min(1024 // min(16, H), Wd)
+        with np.errstate(all="ignore"):
+            ref = W.warp_with_inverse(img, minv, Wd, H)
+        out = warp_patches(img, table)
+        assert np.array_equal(out, ref, equal_nan=True), rows
