@@ -20,7 +20,7 @@ namespace dxh {
 // the pixel, evaluates OpenCV's float32 bilinear perspective sample (see oracle/warp_numpy.py for the
 // restated algorithm) and adds it to the pixel in float32 -- the same order of additions as the
 // reference's  canvas[roi] += tmp , hence deterministic and free of atomics.
-// A block covers kWarpBW x 1 pixels and looks only at the patches whose rectangle meets its
+// A block covers kWarpBW x kWarpRows pixels and looks only at the patches whose rectangle meets its
 // kWarpBW x kWarpBH bin of the canvas (CSR lists built on the host, table order kept): one to four
 // candidates instead of the whole table (200 records for 10 x 20 patches), and the list is block-uniform,
 // so the records come in through scalar loads.
@@ -105,78 +105,104 @@ template <> __device__ __forceinline__ unsigned short warp_store<unsigned short>
 
 // S: stored type of image and canvas; the patch is read as ``patch.astype(float32)`` (piecewiseperspective.py:121) and the
 // sum over the patches is a float32 canvas, whatever S.
+// A thread produces kWarpRows vertically adjacent pixels (same bin, hence the same candidate records): the chain of scalar
+// loads that fetches a record is paid once for them, the products with the column are shared and the independent
+// per-row chains interleave.
+constexpr int kWarpRows = 4;
+static_assert(kWarpBH % kWarpRows == 0, "the rows of a thread must lie in one bin");
+
 template <int C, typename S>
 __global__ void __launch_bounds__(256) k_warp(const S* __restrict__ base, int H, int W, const WarpPatch* __restrict__ pt,
                                                const int* __restrict__ bin_off, const int* __restrict__ bin_idx,
                                                S* __restrict__ canvas) {
+    constexpr int R = kWarpRows;
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    if (x >= W || y >= H) return;
-    float acc[C];
+    const int y0 = blockIdx.y * R;
+    if (x >= W || y0 >= H) return;
+    float acc[R][C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) acc[c] = 0.f;
-    const int bin = (y / kWarpBH) * gridDim.x + blockIdx.x;
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[r][c] = 0.f;
+    const int bin = (y0 / kWarpBH) * gridDim.x + blockIdx.x;
     const int k0 = bin_off[bin], k1 = bin_off[bin + 1];
     for (int kk = k0; kk < k1; ++kk) {
         const WarpPatch& p = pt[bin_idx[kk]];
         // (one batch of scalar loads for the integers of the record, no short-circuit in between)
         const int nx = p.nx, ny = p.ny, bw0 = p.bw0;
         const unsigned magic = (unsigned)p.pad;
-        const int tx = x - p.ox, ty = y - p.oy;
-        if (((tx | ty) < 0) | (tx >= nx) | (ty >= ny)) continue;
+        const int tx = x - p.ox, ty0 = y0 - p.oy;
+        bool in[R];
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            in[r] = !(((tx | (ty0 + r)) < 0) | (tx >= nx) | (ty0 + r >= ny) | (y0 + r >= H));
+            any |= in[r];
+        }
+        if (!any) continue;
         // tx < 2^16 and bw0 < 2^16: the high word of tx * ceil(2^32 / bw0) is the exact quotient
         const int bx = (magic ? (int)__umulhi((unsigned)tx, magic) : tx / bw0) * bw0;
-        const double x1 = (double)(tx - bx), fbx = (double)bx, fy_ = (double)ty;
-        const double X0 = p.minv[0] * fbx + p.minv[1] * fy_ + p.minv[2];
-        const double Y0 = p.minv[3] * fbx + p.minv[4] * fy_ + p.minv[5];
-        const double W0 = p.minv[6] * fbx + p.minv[7] * fy_ + p.minv[8];
-        const double Wd = warp_scale(W0 + p.minv[6] * x1);
-        const int X = round_half_even_clamped((X0 + p.minv[0] * x1) * Wd);
-        const int Y = round_half_even_clamped((Y0 + p.minv[3] * x1) * Wd);
-        int sx = X >> 5, sy = Y >> 5;   // arithmetic shifts; saturate_cast<short> below
-        sx = sx < -32768 ? -32768 : (sx > 32767 ? 32767 : sx);
-        sy = sy < -32768 ? -32768 : (sy > 32767 ? 32767 : sy);
-        const float fx = (float)(X & 31) * (1.0f / 32.0f), fy = (float)(Y & 31) * (1.0f / 32.0f);
-        const float wx[2] = {1.0f - fx, fx}, wy[2] = {1.0f - fy, fy};
-        // the four taps, loaded unconditionally from clamped positions (no divergent branches around the loads; the
-        // patch size stays in scalar registers) and zeroed by a select where the tap lies outside the patch
+        const double x1 = (double)(tx - bx), fbx = (double)bx;
         const int sh = p.sh, sw = p.sw;
-        const bool oky[2] = {(unsigned)sy < (unsigned)sh, (unsigned)(sy + 1) < (unsigned)sh};
-        const bool okx[2] = {(unsigned)sx < (unsigned)sw, (unsigned)(sx + 1) < (unsigned)sw};
-        const S* row[2];
 #pragma unroll
-        for (int ky = 0; ky < 2; ++ky) row[ky] = base + ((size_t)(p.sr0 + (oky[ky] ? sy + ky : 0)) * W + p.sc0) * C;
-        const int col[2] = {okx[0] ? sx : 0, okx[1] ? sx + 1 : 0};
-        S raw[2][2][C];
+        for (int r = 0; r < R; ++r) {
+            // a row outside the tile runs along on whatever its coordinates give (the taps are clamped into the patch) and
+            // is dropped by the select at the end
+            const double fy_ = (double)(ty0 + r);
+            const double X0 = p.minv[0] * fbx + p.minv[1] * fy_ + p.minv[2];
+            const double Y0 = p.minv[3] * fbx + p.minv[4] * fy_ + p.minv[5];
+            const double W0 = p.minv[6] * fbx + p.minv[7] * fy_ + p.minv[8];
+            const double Wd = warp_scale(W0 + p.minv[6] * x1);
+            const int X = round_half_even_clamped((X0 + p.minv[0] * x1) * Wd);
+            const int Y = round_half_even_clamped((Y0 + p.minv[3] * x1) * Wd);
+            int sx = X >> 5, sy = Y >> 5;   // arithmetic shifts; saturate_cast<short> below
+            sx = sx < -32768 ? -32768 : (sx > 32767 ? 32767 : sx);
+            sy = sy < -32768 ? -32768 : (sy > 32767 ? 32767 : sy);
+            const float fx = (float)(X & 31) * (1.0f / 32.0f), fy = (float)(Y & 31) * (1.0f / 32.0f);
+            const float wx[2] = {1.0f - fx, fx}, wy[2] = {1.0f - fy, fy};
+            // the four taps, loaded unconditionally from clamped positions (no divergent branches around the loads; the
+            // patch size stays in scalar registers) and zeroed by a select where the tap lies outside the patch
+            const bool oky[2] = {(unsigned)sy < (unsigned)sh, (unsigned)(sy + 1) < (unsigned)sh};
+            const bool okx[2] = {(unsigned)sx < (unsigned)sw, (unsigned)(sx + 1) < (unsigned)sw};
+            const S* row[2];
 #pragma unroll
-        for (int ky = 0; ky < 2; ++ky)
+            for (int ky = 0; ky < 2; ++ky) row[ky] = base + ((size_t)(p.sr0 + (oky[ky] ? sy + ky : 0)) * W + p.sc0) * C;
+            const int col[2] = {okx[0] ? sx : 0, okx[1] ? sx + 1 : 0};
+            S raw[2][2][C];
 #pragma unroll
-            for (int kx = 0; kx < 2; ++kx)
+            for (int ky = 0; ky < 2; ++ky)
 #pragma unroll
-                for (int c = 0; c < C; ++c) raw[ky][kx][c] = row[ky][(size_t)col[kx] * C + c];
-        float v[C];
+                for (int kx = 0; kx < 2; ++kx)
 #pragma unroll
-        for (int c = 0; c < C; ++c) v[c] = 0.f;
-        bool first = true;
+                    for (int c = 0; c < C; ++c) raw[ky][kx][c] = row[ky][(size_t)col[kx] * C + c];
+            float v[C];
 #pragma unroll
-        for (int ky = 0; ky < 2; ++ky)
+            for (int c = 0; c < C; ++c) v[c] = 0.f;
+            bool first = true;
 #pragma unroll
-            for (int kx = 0; kx < 2; ++kx) {
-                const bool ok = oky[ky] && okx[kx];
-                const float wgt = wy[ky] * wx[kx];
+            for (int ky = 0; ky < 2; ++ky)
 #pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    const float term = (ok ? (float)raw[ky][kx][c] : 0.f) * wgt;
-                    v[c] = first ? term : v[c] + term;
+                for (int kx = 0; kx < 2; ++kx) {
+                    const bool ok = oky[ky] && okx[kx];
+                    const float wgt = wy[ky] * wx[kx];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        const float term = (ok ? (float)raw[ky][kx][c] : 0.f) * wgt;
+                        v[c] = first ? term : v[c] + term;
+                    }
+                    first = false;
                 }
-                first = false;
-            }
 #pragma unroll
-        for (int c = 0; c < C; ++c) acc[c] = acc[c] + v[c];
+            for (int c = 0; c < C; ++c) acc[r][c] = in[r] ? acc[r][c] + v[c] : acc[r][c];
+        }
     }
-    S* o = canvas + ((size_t)y * W + x) * C;
 #pragma unroll
-    for (int c = 0; c < C; ++c) o[c] = warp_store<S>(acc[c]);
+    for (int r = 0; r < R; ++r) {
+        if (y0 + r >= H) break;
+        S* o = canvas + ((size_t)(y0 + r) * W + x) * C;
+#pragma unroll
+        for (int c = 0; c < C; ++c) o[c] = warp_store<S>(acc[r][c]);
+    }
 }
 
 // ---- thin-plate-spline field ------------------------------------------------------------------------
@@ -907,7 +933,7 @@ int dxh_warp_patches_typed(int device, int H, int W, int C, int dtype, const voi
     if (npatch) DXH_HIP(hipMemcpyAsync(dpt, table.data(), sizeof(WarpPatch) * (size_t)npatch, hipMemcpyDefault, d.st));
     DXH_HIP(hipMemcpyAsync(doff, off.data(), sizeof(int) * off.size(), hipMemcpyDefault, d.st));
     DXH_HIP(hipMemcpyAsync(didx, idx.data(), sizeof(int) * idx.size(), hipMemcpyDefault, d.st));
-    const dim3 grid(nbx, H), blk(kWarpBW);
+    const dim3 grid(nbx, (H + kWarpRows - 1) / kWarpRows), blk(kWarpBW);
 #define DXH_WARP(CH, S) hipLaunchKernelGGL((k_warp<CH, S>), grid, blk, 0, d.st, (const S*)dbase, H, W, (const WarpPatch*)dpt, \
                                            (const int*)doff, (const int*)didx, (S*)dcanvas)
 #define DXH_WARP_C(S) do { if (C == 1) DXH_WARP(1, S); else DXH_WARP(3, S); } while (0)
