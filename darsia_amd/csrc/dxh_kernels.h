@@ -1732,6 +1732,60 @@ __device__ __forceinline__ void np2_split(double q, double kq, float& d, float& 
     b = (float)(q - (double)d);                           // b[..., j] = dub - d[..., j]
 }
 
+// ---- the same flow as three kernels (any dim, any shape, several Jacobi sweeps): the generic path of a numpy2 context ----
+// One thread per element like k_rhs / k_jacobi / k_shrink; the expressions and their order are those of k_fused_np2.
+//   k_rhs_np2:          rs = float32( float32(omega img + sum_j fd_j(ell (b_j - d_j))) / diag ), stored in the double plane
+//   k_jacobi_np2_first: the FIRST sweep of a call, whose iterate still is the float32 image: N(u) is summed in float32
+//                       (jacobi.py:25-55 on a float32 array), then / np.float64(diag_scaled) -> float64.  Every later sweep
+//                       is the double context's own sweep (float64 N(u); rs holds float32 values, which float64 + float32
+//                       -> float64 adds exactly as stored).
+//   k_shrink_np2:       q_j <- D_j u_new + float64(b_j)  with b_j the float32 value re-derived from the stored q_j
+template <int DIM, bool KQARR>
+__global__ void __launch_bounds__(256) k_rhs_np2(Geom g, const double* __restrict__ of, QPlanes<double, DIM> q, Np2Coef k,
+                                                  double* __restrict__ rs) {
+    ElemIdx e;
+    if (!elem_index(g, e)) return;
+    const double kq_c = KQARR ? k.kq_plane[e.off] : k.kq;
+    float r = (float)of[e.off];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+        float d, b;
+        np2_split(q.in[j][e.off], kq_c, d, b);
+        const float tc = k.ell * (b - d);
+        const int64_t o = nb_off(g, e, j, -1);
+        np2_split(q.in[j][o], KQARR ? k.kq_plane[o] : k.kq, d, b);
+        const float tn = k.ell * (b - d);
+        r = r + (tc - tn);
+    }
+    rs[e.off] = (double)(r / k.diag);
+}
+
+static __global__ void __launch_bounds__(256) k_jacobi_np2_first(Geom g, const double* __restrict__ rs, const double* __restrict__ xin,
+                                                                 double dsc, double* __restrict__ xout) {
+    ElemIdx e;
+    if (!elem_index(g, e)) return;
+    float acc = 0.f;
+    for (int ax = 0; ax < g.nsum_axes; ++ax) {
+        acc = acc + (float)xin[nb_off(g, e, ax, -1)];
+        acc = acc + (float)xin[nb_off(g, e, ax, +1)];
+    }
+    xout[e.off] = rs[e.off] + (double)acc / dsc;
+}
+
+template <int DIM, bool KQARR>
+__global__ void __launch_bounds__(256) k_shrink_np2(Geom g, const double* __restrict__ unew, QPlanes<double, DIM> q, Np2Coef k) {
+    ElemIdx e;
+    if (!elem_index(g, e)) return;
+    const double kq = KQARR ? k.kq_plane[e.off] : k.kq;
+    const double uc = unew[e.off];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+        float d, b;
+        np2_split(q.in[j][e.off], kq, d, b);
+        q.out[j][e.off] = (unew[nb_off(g, e, j, +1)] - uc) + (double)b;
+    }
+}
+
 template <int C, bool COUPLED, bool KQARR>
 __global__ void __launch_bounds__(256) k_fused_np2(FusedArgs<double> a, Np2Coef k) {
     using T = double;

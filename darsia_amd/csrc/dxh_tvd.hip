@@ -1017,6 +1017,17 @@ static int solve_u(Ctx* c, int jacobi_maxiter, double jacobi_tol, void* tmp, int
     return rc;
 }
 
+static Np2Coef np2_coef(const Ctx* c) {
+    Np2Coef k{};
+    k.dsc = c->c_dsc;
+    k.kq = c->c_kq;
+    k.ell = (float)c->c_ell;
+    k.diag = (float)c->c_diag;
+    k.kq_plane = c->het ? (const double*)c->cp_kq : nullptr;
+    k.first = c->np2_first ? 1 : 0;
+    return k;
+}
+
 // numpy2 flow (double context): one outer iteration by k_fused_np2
 static int launch_np2(Ctx* c, int in, int out) {
     FusedArgs<double> a{};
@@ -1044,13 +1055,7 @@ static int launch_np2(Ctx* c, int in, int out) {
     const ChunkLayout lay = make_layout(c, nbx, 1, choose);
     const unsigned grid = apply_layout(c, a, lay, nbx);
     a.remap = 1;
-    Np2Coef k{};
-    k.dsc = c->c_dsc;
-    k.kq = c->c_kq;
-    k.ell = (float)c->c_ell;
-    k.diag = (float)c->c_diag;
-    k.kq_plane = c->het ? (const double*)c->cp_kq : nullptr;
-    k.first = c->np2_first ? 1 : 0;
+    const Np2Coef k = np2_coef(c);
     const bool coupled = c->desc.ndim == 3 && c->desc.nsum == DXH_NSUM_ALL_AXES;
     const bool arr = k.kq_plane != nullptr;
 #define DXH_NP2(C_)                                                                                          \
@@ -1066,6 +1071,51 @@ static int launch_np2(Ctx* c, int in, int out) {
     }
 #undef DXH_NP2
     DXH_HIP(hipGetLastError());
+    return DXH_OK;
+}
+
+// numpy2 flow outside the fused sweeps (dim = 3, more than four channels, several Jacobi sweeps): right-hand side, sweeps,
+// shrinkage as three kinds of launches on the double context; u[cur] -> u[cur ^ 1], q updated in place
+template <int DIM>
+static int np2_generic_iteration(Ctx* c, int maxiter, void* tmp, int64_t* launches) {
+    const int in = c->cur, out = c->cur ^ 1;
+    const dim3 grid = elem_grid(c->g), blk(256);
+    const Np2Coef k = np2_coef(c);
+    auto q = make_q<double, DIM>(c, in, in);
+    if (k.kq_plane) hipLaunchKernelGGL((k_rhs_np2<DIM, true>), grid, blk, 0, c->stream, c->g, (const double*)c->of, q, k, (double*)c->rs);
+    else hipLaunchKernelGGL((k_rhs_np2<DIM, false>), grid, blk, 0, c->stream, c->g, (const double*)c->of, q, k, (double*)c->rs);
+    ++*launches;
+    // x lives alternately in u[out] and tmp; the first sweep reads u[in]
+    const void* x = c->u[in];
+    void* bufs[2] = {c->u[out], tmp};
+    int w = 0, left = maxiter;
+    if (left > 0 && c->np2_first) {   // the iterate still is the float32 image: float32 neighbour sums
+        hipLaunchKernelGGL(k_jacobi_np2_first, grid, blk, 0, c->stream, c->g, (const double*)c->rs, (const double*)x, k.dsc, (double*)bufs[w]);
+        x = bufs[w];
+        w ^= 1;
+        --left;
+        ++*launches;
+    }
+    while (left >= 2 && jacobi_multi_supported(c)) {   // float64 sweeps: the double context's own kernels
+        const int kk = left == 5 ? 3 : std::min(4, left);
+        launch_jacobi_multi<double>(c, x, bufs[w], kk);
+        x = bufs[w];
+        w ^= 1;
+        left -= kk;
+        ++*launches;
+    }
+    for (; left > 0; --left) {
+        launch_jacobi<double>(c, x, bufs[w]);
+        x = bufs[w];
+        w ^= 1;
+        ++*launches;
+    }
+    if (x != c->u[out]) DXH_HIP(hipMemcpyAsync(c->u[out], x, c->plane_bytes, hipMemcpyDeviceToDevice, c->stream));
+    if (k.kq_plane) hipLaunchKernelGGL((k_shrink_np2<DIM, true>), grid, blk, 0, c->stream, c->g, (const double*)c->u[out], q, k);
+    else hipLaunchKernelGGL((k_shrink_np2<DIM, false>), grid, blk, 0, c->stream, c->g, (const double*)c->u[out], q, k);
+    ++*launches;
+    DXH_HIP(hipGetLastError());
+    c->np2_first = false;
     return DXH_OK;
 }
 
@@ -1092,15 +1142,18 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
     const bool dpp = !(flags & DXH_FLAG_NO_DPP);
     bool fused_ok = fused_supported(c) && jacobi_maxiter == 1 && !use_tol && !(flags & DXH_FLAG_NO_FUSED) && !c->solver;
     const int dim = c->desc.dim;
+    bool np2_generic = false;
     if (c->np2) {
-        // the reference's float32-image flow exists for the default solve only: dim = 2, one Jacobi sweep without a
-        // tolerance, anisotropic shrinkage, scalar omega and ell (mu: scalar or array), state as uploaded
-        DXH_REQUIRE(dim == 2 && c->g.n2 >= 1 && c->g.n2 <= 4, "numpy2 promotion: dim = 2 with 1..4 channels only");
-        DXH_REQUIRE(jacobi_maxiter == 1 && !use_tol && !c->solver, "numpy2 promotion: Jacobi(maxiter=1) without tolerance only");
+        // the reference's float32-image flow: Jacobi sweeps without a tolerance, anisotropic shrinkage, scalar omega and
+        // ell (mu: scalar or array), state as uploaded.  One sweep on a 2-D image of up to four channels runs in the fused
+        // pipelines; everything else (dim = 3, more channels, several sweeps) as three kinds of launches
+        DXH_REQUIRE(jacobi_maxiter >= 1 && !use_tol && !c->solver, "numpy2 promotion: Jacobi sweeps without tolerance only");
         DXH_REQUIRE(!iso, "numpy2 promotion: anisotropic shrinkage only (the reference's isotropic branch is float64-only)");
         DXH_REQUIRE(!c->from_db && !c->explicit_db && !(flags & DXH_FLAG_EXPLICIT), "numpy2 promotion: no explicit split variables");
         DXH_REQUIRE(!c->het || (c->het_cdiag && c->cp_kq), "numpy2 promotion: omega and ell must be scalars");
-        DXH_REQUIRE(fused_ok, "numpy2 promotion: the coefficients are outside the fused sweep's range (mu / ell must be >= 0)");
+        if constexpr (!std::is_same<T, double>::value) { set_error("numpy2 promotion needs a float64 context"); return DXH_ESTATE; }
+        np2_generic = !(fused_ok && dim == 2 && c->g.n2 >= 1 && c->g.n2 <= 4);
+        if (np2_generic) fused_ok = false;
     }
     if (c->solver) {
         // Solver.update_params(mass_coeff=omega, diffusion_coeff=ell) (split_bregman_tvd.py:63-67, 154-158)
@@ -1117,7 +1170,7 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
     void*& tmp = tmp_guard.p;
     const bool explicit_mode = (flags & DXH_FLAG_EXPLICIT) || c->explicit_db;
     const bool fused3d_ok = fused3d_supported(c) && jacobi_maxiter == 1 && !use_tol && !(flags & DXH_FLAG_NO_FUSED) &&
-                            !c->solver && !explicit_mode;
+                            !c->solver && !explicit_mode && !c->np2;
     const bool need_generic = (!fused_ok && !fused3d_ok) || c->from_db;
     if (need_generic) {
         int rc = alloc_plane(c, &c->rs);
@@ -1236,6 +1289,12 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
 #undef DXH_SDB
             }
             ++launches;
+            c->cur = out;
+        } else if (np2_generic) {
+            int rc = dim == 2 ? np2_generic_iteration<2>(c, jacobi_maxiter, tmp, &launches)
+                              : np2_generic_iteration<3>(c, jacobi_maxiter, tmp, &launches);
+            if (rc) return rc;
+            for (int j = 0; j < dim; ++j) std::swap(c->q[j][in], c->q[j][out]);
             c->cur = out;
         } else {
             const bool fdb = c->from_db;
@@ -2733,8 +2792,8 @@ int dxh_tvd_set_promotion(dxh_tvd_t h, int mode) {
     DXH_REQUIRE(mode == DXH_PROMOTION_NATIVE || mode == DXH_PROMOTION_NUMPY2 || mode == (DXH_PROMOTION_NUMPY2 | DXH_PROMOTION_MU_IS_THRESHOLD),
                 "unknown promotion mode %d", mode);
     if (mode != DXH_PROMOTION_NATIVE)
-        DXH_REQUIRE(c->desc.dtype == DXH_F64 && c->desc.dim == 2, "numpy2 promotion needs a float64 context with dim = 2 (it holds the "
-                    "reference's float64 iterate of a float32 image)");
+        DXH_REQUIRE(c->desc.dtype == DXH_F64, "numpy2 promotion needs a float64 context (it holds the reference's float64 iterate "
+                    "of a float32 image)");
     c->np2 = (mode & DXH_PROMOTION_NUMPY2) != 0;
     c->np2_mu_is_kq = (mode & DXH_PROMOTION_MU_IS_THRESHOLD) != 0;
     c->uploaded = false;

@@ -68,9 +68,19 @@ for case in range(n_cases):
             kw["ell"] = float(rng.choice([0.3, 1.0]))
         iso = rng.random() < 0.3
         jm = int(rng.choice([1, 1, 2, 3, 20]))
+        # the native kernels (vector march, sweeps) against the oracle's same-dtype flow ...
         ref = O.split_bregman_tvd(vol, isotropic=iso, jacobi_maxiter=jm, promotion="strict", **kw)
-        out = da.split_bregman_tvd(vol, isotropic=iso, solver=da.Jacobi(maxiter=jm), **kw)
+        out = da.split_bregman_tvd(vol, isotropic=iso, solver=da.Jacobi(maxiter=jm), promotion="native", **kw)
         if not np.array_equal(out, ref):
             report(f"dim3 iso={iso} jm={jm}", shape, dt, kw, out, ref)
+        # ... and, where the reference's own float32 flow exists (anisotropic, scalar ell), the DEFAULT call against it
+        if dt == np.float32 and not iso and (not het or "ell" in kw):
+            kw2 = dict(kw)
+            if het:
+                kw2["mu"] = kw["mu"].astype(np.float64) if rng.random() < 0.5 else kw["mu"]
+            ref = O.split_bregman_tvd(vol, jacobi_maxiter=jm, promotion="numpy2", **kw2)
+            out = da.split_bregman_tvd(vol, solver=da.Jacobi(maxiter=jm), **kw2)
+            if not np.array_equal(out, ref):
+                report(f"dim3 numpy2 jm={jm}", shape, dt, kw2, out, ref)
 print(f"{n_cases} cases, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
 sys.exit(1 if bad else 0)

@@ -1,0 +1,86 @@
+"""Golden vectors for float32 images OUTSIDE the default solve: several Jacobi sweeps per iteration, volumes (dim = 3),
+more than four channels -- the configurations the device runs as three kinds of launches in the reference's own dtype flow
+(promotion "numpy2": k_rhs_np2, k_jacobi_np2_first + the float64 sweeps, k_shrink_np2).
+
+TEST INFRASTRUCTURE.  Run in the build container only (``/root/reference`` is not on the GPU box):
+
+    python tests/golden/make_golden_np2_generic.py
+
+What NumPy >= 2 does in the reference here (restoration/split_bregman_tvd.py:84-101,129-146; utils/linear_solvers/
+jacobi.py:74-133): rhs and rhs / diag stay float32; the FIRST sweep of a call sums the neighbours of the float32 image in
+float32 and divides by the np.float64 ``const_diag_scaled`` -> float64; every later sweep and iteration sums in float64;
+d and b are float32 arrays.  The reference's modules are loaded exactly as in ``make_golden.py`` (same shim, a FRESH
+``Jacobi`` per call).  The output holds inputs and expected outputs only.
+"""
+from __future__ import annotations
+
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from make_golden import _shim, noisy_blocks  # noqa: E402
+from make_golden_mixed import weight_map  # noqa: E402
+
+
+def main():
+    da = _shim()
+    out = {}
+    meta = {"numpy": np.__version__}
+
+    gray = noisy_blocks((64, 96), 41, np.float32)
+    rgb = noisy_blocks((48, 64, 3), 42, np.float32)
+    vol = noisy_blocks((20, 24, 28), 43, np.float32)
+    six = noisy_blocks((40, 36, 6), 45, np.float32)           # 2-D image with six channels
+
+    def run(name, img, maxiter, **kw):
+        res = da.split_bregman_tvd(img.copy(), solver=da.Jacobi(maxiter=maxiter), **kw)
+        out[name + "/img"] = img
+        out[name + "/out"] = res
+        out[name + "/maxiter"] = np.int64(maxiter)
+        meta[name + "_dtype"] = str(res.dtype)
+        return res
+
+    # several sweeps, 2-D: 2 (first sweep float32 + one float64), 3, 5 (the 2-D multi-sweep passes), 6
+    run("n1_gray_m2", gray, 2, mu=0.1, max_num_iter=12)
+    run("n2_gray_m3_mu1", gray, 3, mu=1.0, omega=0.7, ell=0.45, max_num_iter=15)
+    run("n3_rgb_m5", rgb, 5, mu=0.1, max_num_iter=10)
+    run("n4_rgb_m6_ell", rgb, 6, mu=0.2, ell=0.3, max_num_iter=8)
+    mu_g = 0.1 * weight_map(gray.shape, 46)
+    out["n5_gray_m4_muarr/mu"] = mu_g
+    run("n5_gray_m4_muarr", gray, 4, mu=mu_g, ell=0.5, max_num_iter=10)
+    # volumes
+    run("n6_vol_m1", vol, 1, mu=0.1, dim=3, max_num_iter=10)
+    run("n7_vol_m4", vol, 4, mu=0.3, omega=0.5, ell=0.4, dim=3, max_num_iter=8)
+    mu_v = 0.2 * (0.3 + 0.7 * np.random.default_rng(47).random(vol.shape))
+    out["n8_vol_m2_muarr/mu"] = mu_v
+    run("n8_vol_m2_muarr", vol, 2, mu=mu_v, ell=0.6, dim=3, max_num_iter=8)
+    run("n9_vol_m7", vol, 7, mu=0.1, dim=3, max_num_iter=5)
+    # six channels, one sweep (outside the fused pipelines' channel counts)
+    run("n10_six_m1", six, 1, mu=0.1, max_num_iter=9)
+    run("n11_six_m3", six, 3, mu=0.15, ell=0.5, max_num_iter=7)
+    # early stop through eps with several sweeps
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        res = da.split_bregman_tvd(gray.copy(), solver=da.Jacobi(maxiter=3), mu=0.1, max_num_iter=200, eps=2e-3, verbose=True)
+    out["n12_gray_m3_eps/img"] = gray
+    out["n12_gray_m3_eps/out"] = res
+    out["n12_gray_m3_eps/maxiter"] = np.int64(3)
+    out["n12_gray_m3_eps/iters"] = np.int64(sum(1 for ln in buf.getvalue().splitlines() if ln.startswith("Split Bregman iteration")))
+
+    for k, v in meta.items():
+        out["meta/" + k] = np.array(v)
+    path = os.path.join(HERE, "tvd_np2_generic_golden.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB,", len(out), "arrays")
+    for k, v in meta.items():
+        print(" ", k, "=", v)
+
+
+if __name__ == "__main__":
+    main()

@@ -177,7 +177,9 @@ def test_unsupported_configurations_say_so():
     with pytest.raises(NotImplementedError, match="numpy2"):
         da.split_bregman_tvd(img, mu=0.1, isotropic=True, promotion="numpy2")
     with pytest.raises(NotImplementedError, match="numpy2"):
-        da.split_bregman_tvd(img, mu=0.1, solver=da.Jacobi(maxiter=3), promotion="numpy2")
+        da.split_bregman_tvd(img, mu=0.1, solver=da.Jacobi(maxiter=3, tol=1e-3), promotion="numpy2")
+    with pytest.raises(NotImplementedError, match="numpy2"):
+        da.split_bregman_tvd(img, mu=0.1, solver=da.MG(2), promotion="numpy2")
     with pytest.raises(NotImplementedError, match="numpy2"):
         da.split_bregman_tvd(img.astype(np.float64), mu=0.1, promotion="numpy2")
     with pytest.raises(ValueError):
@@ -253,3 +255,58 @@ def test_large_host_image_takes_the_row_bands_by_default():
         st.upload(img)
         st.run(12)
         bits(out, st.download())
+
+
+# ---- float32 images outside the default solve: several Jacobi sweeps, volumes, six channels (three kinds of launches) ----
+from test_oracle_np2_generic_golden import CASES as GENERIC_CASES, case_kwargs  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def generic():
+    return np.load(os.path.join(ROOT, "tests", "golden", "tvd_np2_generic_golden.npz"), allow_pickle=False)
+
+
+@pytest.mark.parametrize("name", sorted(GENERIC_CASES))
+def test_several_sweeps_volumes_and_six_channels_bit_for_bit_against_the_reference(generic, name):
+    """k_rhs_np2 / k_jacobi_np2_first + the float64 sweeps / k_shrink_np2: vectors produced by executing the reference
+    (tests/golden/make_golden_np2_generic.py).  The DEFAULT call takes this flow."""
+    kw, m = case_kwargs(generic, name)
+    img = generic[name + "/img"]
+    out = da.split_bregman_tvd(img, solver=da.Jacobi(maxiter=m), **kw)
+    bits(out, generic[name + "/out"])
+    bits(da.split_bregman_tvd(img, solver=da.Jacobi(maxiter=m), promotion="numpy2", **kw), generic[name + "/out"])
+    # device in, device out
+    dev = da.split_bregman_tvd(da.DeviceArray.from_host(img), solver=da.Jacobi(maxiter=m), **kw)
+    bits(dev.get(), generic[name + "/out"])
+
+
+def test_stop_iteration_with_several_sweeps(generic):
+    img = generic["n12_gray_m3_eps/img"]
+    out = da.split_bregman_tvd(img, mu=0.1, max_num_iter=200, eps=2e-3, solver=da.Jacobi(maxiter=3))
+    bits(out, generic["n12_gray_m3_eps/out"])
+    with da.DeviceTVD(img.shape, img.dtype, promotion="numpy2") as st:
+        st.set_coeffs(0.1, 1.0, None, img)
+        st.upload(img)
+        r = st.run(200, 3, None, eps=2e-3)
+        assert r.converged and r.iters_done == int(generic["n12_gray_m3_eps/iters"])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_shapes_of_the_generic_numpy2_flow_against_the_oracle(seed):
+    rng = np.random.default_rng(100 + seed)
+    for _ in range(6):
+        dim = int(rng.choice([2, 3]))
+        if dim == 3:
+            shape = tuple(int(v) for v in rng.integers(3, 40, size=3))
+        else:
+            shape = (int(rng.integers(2, 70)), int(rng.integers(2, 90))) + ((int(rng.choice([1, 2, 3, 4, 5, 7])),) if rng.random() < 0.6 else ())
+        img = rng.random(shape, dtype=np.float32) * np.float32(rng.choice([1.0, 255.0, 1e-3]))
+        m = int(rng.choice([1, 2, 3, 4, 5, 6, 9]))
+        mu = float(rng.choice([0.05, 0.3, 1.0])) * float(img.max())
+        kw = dict(mu=mu, omega=float(rng.choice([1.0, 0.6])), ell=None if rng.random() < 0.5 else float(rng.choice([0.4, 1.0])) * float(img.max()))
+        if kw["ell"] is not None and rng.random() < 0.4:
+            kw["mu"] = mu * (0.2 + 0.8 * rng.random(shape))           # float64 array
+        n = int(rng.integers(1, 7))
+        out = da.split_bregman_tvd(img, dim=dim, max_num_iter=n, solver=da.Jacobi(maxiter=m), **kw)
+        ref = O.split_bregman_tvd(img, dim=dim, max_num_iter=n, jacobi_maxiter=m, promotion="numpy2", **kw)
+        bits(out, ref)

@@ -1,0 +1,55 @@
+"""The oracle's numpy2 flow against vectors produced by executing the reference on float32 images outside the default
+solve: several Jacobi sweeps, volumes (dim = 3), six channels (tests/golden/make_golden_np2_generic.py).  Bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import tvd_numpy as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CASES = {
+    "n1_gray_m2": dict(mu=0.1, max_num_iter=12),
+    "n2_gray_m3_mu1": dict(mu=1.0, omega=0.7, ell=0.45, max_num_iter=15),
+    "n3_rgb_m5": dict(mu=0.1, max_num_iter=10),
+    "n4_rgb_m6_ell": dict(mu=0.2, ell=0.3, max_num_iter=8),
+    "n5_gray_m4_muarr": dict(mu="arr", ell=0.5, max_num_iter=10),
+    "n6_vol_m1": dict(mu=0.1, dim=3, max_num_iter=10),
+    "n7_vol_m4": dict(mu=0.3, omega=0.5, ell=0.4, dim=3, max_num_iter=8),
+    "n8_vol_m2_muarr": dict(mu="arr", ell=0.6, dim=3, max_num_iter=8),
+    "n9_vol_m7": dict(mu=0.1, dim=3, max_num_iter=5),
+    "n10_six_m1": dict(mu=0.1, max_num_iter=9),
+    "n11_six_m3": dict(mu=0.15, ell=0.5, max_num_iter=7),
+}
+
+
+@pytest.fixture(scope="module")
+def generic():
+    return np.load(os.path.join(ROOT, "tests", "golden", "tvd_np2_generic_golden.npz"), allow_pickle=False)
+
+
+def case_kwargs(generic, name):
+    kw = dict(CASES[name])
+    if isinstance(kw.get("mu"), str):
+        kw["mu"] = generic[name + "/mu"]
+    return kw, int(generic[name + "/maxiter"])
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_reproduces_the_reference_bit_for_bit(generic, name):
+    kw, m = case_kwargs(generic, name)
+    img = generic[name + "/img"]
+    assert img.dtype == np.float32
+    out = O.split_bregman_tvd(img, jacobi_maxiter=m, promotion="numpy2", **kw)
+    ref = generic[name + "/out"]
+    assert out.dtype == ref.dtype == np.float32
+    assert np.array_equal(out, ref)
+
+
+def test_oracle_stop_iteration_with_several_sweeps(generic):
+    img = generic["n12_gray_m3_eps/img"]
+    out, _, _, done = O.split_bregman_tvd(img, mu=0.1, max_num_iter=200, eps=2e-3, jacobi_maxiter=3, promotion="numpy2",
+                                          return_state=True)
+    assert done == int(generic["n12_gray_m3_eps/iters"])
+    assert np.array_equal(out, generic["n12_gray_m3_eps/out"])

@@ -14,7 +14,7 @@ def _why(img, mu=0.1, omega=1.0, ell=1.0, dim=2, x0=None, iso=False, solver=None
     return numpy2_unsupported(img, mu, omega, ell, dim, x0, iso, solver or da.Jacobi(), adaptive, quiet)
 
 
-def test_numpy2_flow_exists_for_the_default_solve_only():
+def test_where_the_numpy2_flow_exists():
     f32 = np.zeros((8, 9), np.float32)
     assert _why(f32) is None
     assert _why(np.zeros((8, 9, 3), np.float32), mu=np.ones((8, 9, 3))) is None
@@ -23,11 +23,14 @@ def test_numpy2_flow_exists_for_the_default_solve_only():
     assert "scalars" in _why(f32, ell=np.ones((8, 9)))
     assert "scalar ell" in _why(f32, mu=np.ones((8, 9)), ell=None)               # ell = 2 mu would be an array
     assert "anisotropic" in _why(f32, iso=True)
-    assert "Jacobi" in _why(f32, solver=da.Jacobi(maxiter=3))
+    assert _why(f32, solver=da.Jacobi(maxiter=3)) is None                         # several sweeps: three kinds of launches
     assert "Jacobi" in _why(f32, solver=da.Jacobi(tol=1e-3))
+    assert "Jacobi" in _why(f32, solver=da.MG(2))
     assert "warm start" in _why(f32, x0=(f32, None, None))
-    assert "dim = 2" in _why(np.zeros((4, 5, 6), np.float32), dim=3)
-    assert "dim = 2" in _why(np.zeros((4, 5, 6), np.float32))                    # six "channels"
+    assert _why(np.zeros((4, 5, 6), np.float32), dim=3) is None                  # volumes
+    assert _why(np.zeros((4, 5, 6), np.float32)) is None                         # six "channels"
+    assert "2 or 3 axes" in _why(np.zeros((4, 5, 6, 2), np.float32), dim=3)
+    assert "2 or 3 axes" in _why(f32, dim=3)
 
 
 def test_choice_of_the_dtype_flow(monkeypatch):

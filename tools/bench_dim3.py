@@ -25,3 +25,10 @@ for shape, dt in (((256, 256, 256), np.float32), ((256, 256, 256), np.float64), 
         ms = min(st.run(20).loop_ms for _ in range(2)) / 20
         print(f"{shape} {np.dtype(dt).name} array-valued mu, Jacobi(maxiter=1): {ms:.3f} ms/iter", flush=True)
         st.close()
+        # the reference's own float32 dtype flow (promotion "numpy2": float64 context, three kinds of launches)
+        for jm in (1, 20):
+            st = da.DeviceTVD(vol.shape, vol.dtype, dim=3, promotion="numpy2"); st.set_coeffs(0.1, 1.0, None, vol); st.upload(vol)
+            st.run(3, jacobi_maxiter=jm)
+            ms = min(st.run(10, jacobi_maxiter=jm).loop_ms for _ in range(2)) / 10
+            print(f"{shape} float32 numpy2 flow, Jacobi(maxiter={jm}): {ms:.3f} ms/iter", flush=True)
+            st.close()

@@ -18,3 +18,11 @@ for shape in ((4000, 8000, 3), (4000, 8000)):
             st.run(8)
             r = min((st.run(40) for _ in range(3)), key=lambda r: r.loop_ms)
             print(f"{shape} {label:28s} {r.loop_ms / 40:.4f} ms/iteration  ({r.launches} launches)", flush=True)
+    # several Jacobi sweeps in the numpy2 flow (three kinds of launches) next to the native float32 multi-sweep passes
+    for label, kw in (("native f32 Jacobi(maxiter=5)", dict()), ("numpy2 Jacobi(maxiter=5)", dict(promotion="numpy2"))):
+        with da.DeviceTVD(img.shape, img.dtype, **kw) as st:
+            st.set_coeffs(0.1, 1.0, 0.2, img)
+            st.upload(img)
+            st.run(2, jacobi_maxiter=5)
+            r = min((st.run(10, jacobi_maxiter=5) for _ in range(3)), key=lambda r: r.loop_ms)
+            print(f"{shape} {label:28s} {r.loop_ms / 10:.4f} ms/iteration  ({r.launches} launches)", flush=True)
