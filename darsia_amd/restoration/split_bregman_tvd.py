@@ -285,8 +285,8 @@ def numpy2_unsupported(img, mu, omega, ell, dim, x0, isotropic, solver, adaptive
         return "an array-valued mu needs a scalar ell"
     if isinstance(mu, DeviceArray):
         return "device-resident coefficient arrays"
-    if x0 is not None or adaptive is not None or not quiet:
-        return "no warm start, adaptive schedule or verbose mode"
+    if x0 is not None or adaptive is not None:
+        return "no warm start or adaptive schedule"
     if isotropic:
         return "anisotropic only (the reference's isotropic branch is float64-only)"
     if not isinstance(solver, Jacobi) or solver.maxiter < 1 or solver.tol is not None:
@@ -376,6 +376,22 @@ def split_bregman_tvd(
         # coefficients' fingerprints are the same (in-place edits of a weight array: outside the contract, clear the dict)
         from ..concentration import _fingerprint
 
+        if not quiet:
+            # verbose: one iteration per call so that increment and energy can be printed (debug path, same messages as
+            # split_bregman_tvd.py:103-104,161-167; the energy is evaluated in double from the device planes)
+            show = (lambda it: verbose) if isinstance(verbose, bool) else (lambda it: verbose > 0 and it % verbose == 0)
+            with DeviceTVD(img.shape, img.dtype, dim=dim, device=img.device if on_device else None, promotion="numpy2") as st:
+                st.set_coeffs(mu, omega, ell, img)
+                st.upload(img)
+                print(f"The energy functional starts at {st.energy()}")
+                for it in range(max_num_iter):
+                    r = st.run(1, solver.maxiter, None, eps=0.0 if eps is None else eps)
+                    if show(it):
+                        print(f"Split Bregman iteration {it} - relative increment: {r.rel_increment}, "
+                              f"energy functional: {st.energy(previous=True)}")
+                    if eps is not None and r.converged:
+                        break
+                return st.download(out=DeviceArray(img.shape, img.dtype, img.device) if on_device else None)
         if (not on_device and eps is None and np.ndim(mu) == 0 and max_num_iter >= 1 and img.nbytes >= (32 << 20)
                 and dim == 2 and solver.maxiter == 1 and (img.ndim == 2 or img.shape[2] <= 4)):
             # fixed iteration count on a large host image with scalar coefficients: row bands through the device, the

@@ -310,3 +310,19 @@ def test_random_shapes_of_the_generic_numpy2_flow_against_the_oracle(seed):
         out = da.split_bregman_tvd(img, dim=dim, max_num_iter=n, solver=da.Jacobi(maxiter=m), **kw)
         ref = O.split_bregman_tvd(img, dim=dim, max_num_iter=n, jacobi_maxiter=m, promotion="numpy2", **kw)
         bits(out, ref)
+
+
+def test_verbose_run_is_the_same_flow_and_prints_the_reference_messages(mixed, generic, capsys):
+    """verbose=True (the reference's debug path: one iteration per call, increment and energy printed) stays in the
+    reference's dtype flow: the vectors m7 / n12 were recorded from verbose runs of the reference with eps."""
+    img, mu = mixed["m7_gray_eps/img"], mixed["m7_gray_eps/mu"]
+    out = da.split_bregman_tvd(img, mu=mu, ell=0.2, omega=0.8, max_num_iter=200, eps=2e-3, verbose=True)
+    printed = capsys.readouterr().out
+    bits(out, mixed["m7_gray_eps/out"])
+    lines = [ln for ln in printed.splitlines() if ln.startswith("Split Bregman iteration")]
+    assert len(lines) == int(mixed["m7_gray_eps/iters"]) and printed.startswith("The energy functional starts at ")
+    img = generic["n12_gray_m3_eps/img"]
+    out = da.split_bregman_tvd(img, mu=0.1, max_num_iter=200, eps=2e-3, solver=da.Jacobi(maxiter=3), verbose=5)
+    printed = capsys.readouterr().out
+    bits(out, generic["n12_gray_m3_eps/out"])
+    assert sum(ln.startswith("Split Bregman iteration") for ln in printed.splitlines()) == (int(generic["n12_gray_m3_eps/iters"]) + 4) // 5
