@@ -326,3 +326,10 @@ def test_verbose_run_is_the_same_flow_and_prints_the_reference_messages(mixed, g
     printed = capsys.readouterr().out
     bits(out, generic["n12_gray_m3_eps/out"])
     assert sum(ln.startswith("Split Bregman iteration") for ln in printed.splitlines()) == (int(generic["n12_gray_m3_eps/iters"]) + 4) // 5
+
+
+def test_the_round_one_float32_vector_with_three_sweeps_is_bit_exact_now(golden):
+    """g6_jacobi3_rgb_f32 (tests/golden/make_golden.py: RGB float32, Jacobi(maxiter=3)) was within the tolerance through the
+    native kernels since round 1; through the default flow it is the reference's result bit for bit."""
+    img = golden["g6_jacobi3_rgb_f32/img"]
+    bits(da.split_bregman_tvd(img, mu=0.1, max_num_iter=5, solver=da.Jacobi(maxiter=3)), golden["g6_jacobi3_rgb_f32/out"])
