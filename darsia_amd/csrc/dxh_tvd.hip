@@ -959,8 +959,10 @@ static void launch_jacobi_multi(Ctx* c, const void* xin, void* xout, int K) {
 // Jacobi.__call__ on device buffers: x0 in u[cur], rs ready; leaves the result in u[cur ^ 1]... or, when
 // the reference returns x0 itself (tol met on the first sweep, or maxiter == 0), copies it there.
 // Needs a third buffer for sweeps > 1: `tmp`.
+// first_f32 (numpy2 flow, double context): x0 still is the float32 image, whose neighbours the reference sums in float32
+// in the first sweep (k_jacobi_np2_first); every later sweep is the context's own.
 template <typename T>
-static int jacobi_sweeps(Ctx* c, int maxiter, double tol, void* tmp, int64_t* launches, int* sweeps_done) {
+static int jacobi_sweeps(Ctx* c, int maxiter, double tol, void* tmp, int64_t* launches, int* sweeps_done, bool first_f32 = false) {
     const int in = c->cur, out = c->cur ^ 1;
     const bool use_tol = tol >= 0.0 && !std::isnan(tol);
     double nrm0 = 0.0;
@@ -973,7 +975,34 @@ static int jacobi_sweeps(Ctx* c, int maxiter, double tol, void* tmp, int64_t* la
     const void* x = c->u[in];
     void* bufs[2] = {c->u[out], tmp};
     int w = 0, done = 0;
-    if (!use_tol && maxiter >= 2 && jacobi_multi_supported(c)) {
+    bool stop = false;
+    auto single = [&](bool f32) -> int {
+        void* xn = bufs[w];
+        if (f32) {
+            if constexpr (std::is_same<T, double>::value)
+                hipLaunchKernelGGL(k_jacobi_np2_first, elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const double*)c->rs,
+                                   (const double*)x, c->c_dsc, (double*)xn);
+        } else {
+            launch_jacobi<T>(c, x, xn);
+        }
+        ++*launches;
+        if (use_tol) {
+            double inc = 0.0;
+            int rc = sq_diff<T>(c, xn, x, 0, c->g.n0, &inc, 0);
+            if (rc) return rc;
+            if (std::sqrt(inc) / nrm0 < tol) { stop = true; return DXH_OK; }  // reference keeps the PREVIOUS iterate (jacobi.py:123-126)
+        }
+        x = xn;
+        w ^= 1;
+        ++done;
+        return DXH_OK;
+    };
+    if (first_f32 && maxiter >= 1) {
+        int rc = single(true);
+        if (rc) return rc;
+        --maxiter;
+    }
+    if (!stop && !use_tol && maxiter >= 2 && jacobi_multi_supported(c)) {
         // several sweeps per pass; a remainder of one sweep goes through the single-sweep kernel below
         int left = maxiter;
         while (left >= 2) {
@@ -988,19 +1017,9 @@ static int jacobi_sweeps(Ctx* c, int maxiter, double tol, void* tmp, int64_t* la
         }
         maxiter = left;  // 0 or 1
     }
-    for (int s = 0; s < maxiter; ++s) {
-        void* xn = bufs[w];
-        launch_jacobi<T>(c, x, xn);
-        ++*launches;
-        if (use_tol) {
-            double inc = 0.0;
-            int rc = sq_diff<T>(c, xn, x, 0, c->g.n0, &inc, 0);
-            if (rc) return rc;
-            if (std::sqrt(inc) / nrm0 < tol) break;  // reference keeps the PREVIOUS iterate (jacobi.py:123-126)
-        }
-        x = xn;
-        w ^= 1;
-        ++done;
+    for (int s = 0; s < maxiter && !stop; ++s) {
+        int rc = single(false);
+        if (rc) return rc;
     }
     if (x != c->u[out]) DXH_HIP(hipMemcpyAsync(c->u[out], x, c->plane_bytes, hipMemcpyDeviceToDevice, c->stream));
     if (sweeps_done) *sweeps_done = done;
@@ -1077,7 +1096,7 @@ static int launch_np2(Ctx* c, int in, int out) {
 // numpy2 flow outside the fused sweeps (dim = 3, more than four channels, several Jacobi sweeps): right-hand side, sweeps,
 // shrinkage as three kinds of launches on the double context; u[cur] -> u[cur ^ 1], q updated in place
 template <int DIM>
-static int np2_generic_iteration(Ctx* c, int maxiter, void* tmp, int64_t* launches) {
+static int np2_generic_iteration(Ctx* c, int maxiter, double tol, void* tmp, int64_t* launches) {
     const int in = c->cur, out = c->cur ^ 1;
     const dim3 grid = elem_grid(c->g), blk(256);
     const Np2Coef k = np2_coef(c);
@@ -1085,37 +1104,14 @@ static int np2_generic_iteration(Ctx* c, int maxiter, void* tmp, int64_t* launch
     if (k.kq_plane) hipLaunchKernelGGL((k_rhs_np2<DIM, true>), grid, blk, 0, c->stream, c->g, (const double*)c->of, q, k, (double*)c->rs);
     else hipLaunchKernelGGL((k_rhs_np2<DIM, false>), grid, blk, 0, c->stream, c->g, (const double*)c->of, q, k, (double*)c->rs);
     ++*launches;
-    // x lives alternately in u[out] and tmp; the first sweep reads u[in]
-    const void* x = c->u[in];
-    void* bufs[2] = {c->u[out], tmp};
-    int w = 0, left = maxiter;
-    if (left > 0 && c->np2_first) {   // the iterate still is the float32 image: float32 neighbour sums
-        hipLaunchKernelGGL(k_jacobi_np2_first, grid, blk, 0, c->stream, c->g, (const double*)c->rs, (const double*)x, k.dsc, (double*)bufs[w]);
-        x = bufs[w];
-        w ^= 1;
-        --left;
-        ++*launches;
-    }
-    while (left >= 2 && jacobi_multi_supported(c)) {   // float64 sweeps: the double context's own kernels
-        const int kk = left == 5 ? 3 : std::min(4, left);
-        launch_jacobi_multi<double>(c, x, bufs[w], kk);
-        x = bufs[w];
-        w ^= 1;
-        left -= kk;
-        ++*launches;
-    }
-    for (; left > 0; --left) {
-        launch_jacobi<double>(c, x, bufs[w]);
-        x = bufs[w];
-        w ^= 1;
-        ++*launches;
-    }
-    if (x != c->u[out]) DXH_HIP(hipMemcpyAsync(c->u[out], x, c->plane_bytes, hipMemcpyDeviceToDevice, c->stream));
+    int swept = 0;
+    int rc = jacobi_sweeps<double>(c, maxiter, tol, tmp, launches, &swept, c->np2_first);
+    if (rc) return rc;
     if (k.kq_plane) hipLaunchKernelGGL((k_shrink_np2<DIM, true>), grid, blk, 0, c->stream, c->g, (const double*)c->u[out], q, k);
     else hipLaunchKernelGGL((k_shrink_np2<DIM, false>), grid, blk, 0, c->stream, c->g, (const double*)c->u[out], q, k);
     ++*launches;
     DXH_HIP(hipGetLastError());
-    c->np2_first = false;
+    if (swept > 0) c->np2_first = false;   // (a tolerance met by the very first sweep hands back the float32 iterate itself)
     return DXH_OK;
 }
 
@@ -1144,10 +1140,10 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
     const int dim = c->desc.dim;
     bool np2_generic = false;
     if (c->np2) {
-        // the reference's float32-image flow: Jacobi sweeps without a tolerance, anisotropic shrinkage, scalar omega and
+        // the reference's float32-image flow: Jacobi sweeps, anisotropic shrinkage, scalar omega and
         // ell (mu: scalar or array), state as uploaded.  One sweep on a 2-D image of up to four channels runs in the fused
         // pipelines; everything else (dim = 3, more channels, several sweeps) as three kinds of launches
-        DXH_REQUIRE(jacobi_maxiter >= 1 && !use_tol && !c->solver, "numpy2 promotion: Jacobi sweeps without tolerance only");
+        DXH_REQUIRE(jacobi_maxiter >= 1 && !c->solver, "numpy2 promotion: Jacobi sweeps only");
         DXH_REQUIRE(!iso, "numpy2 promotion: anisotropic shrinkage only (the reference's isotropic branch is float64-only)");
         DXH_REQUIRE(!c->from_db && !c->explicit_db && !(flags & DXH_FLAG_EXPLICIT), "numpy2 promotion: no explicit split variables");
         DXH_REQUIRE(!c->het || (c->het_cdiag && c->cp_kq), "numpy2 promotion: omega and ell must be scalars");
@@ -1291,8 +1287,8 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
             ++launches;
             c->cur = out;
         } else if (np2_generic) {
-            int rc = dim == 2 ? np2_generic_iteration<2>(c, jacobi_maxiter, tmp, &launches)
-                              : np2_generic_iteration<3>(c, jacobi_maxiter, tmp, &launches);
+            int rc = dim == 2 ? np2_generic_iteration<2>(c, jacobi_maxiter, jacobi_tol, tmp, &launches)
+                              : np2_generic_iteration<3>(c, jacobi_maxiter, jacobi_tol, tmp, &launches);
             if (rc) return rc;
             for (int j = 0; j < dim; ++j) std::swap(c->q[j][in], c->q[j][out]);
             c->cur = out;
@@ -3134,6 +3130,93 @@ int dxh_jacobi_solve(int device, int dtype, int ndim, int dim, int nsum, int64_t
         return r;
     };
     rc = body();
+    dxh_tvd_destroy(hctx);
+    return rc;
+}
+
+// float32 rhs -> rs = float32(rhs / diag) in the double plane (jacobi.py:107 on a float32 array with a Python-float diagonal)
+static __global__ void __launch_bounds__(256) k_divide_np2(Geom g, const double* __restrict__ a, float diag, double* __restrict__ out) {
+    ElemIdx e;
+    if (!elem_index(g, e)) return;
+    out[e.off] = (double)((float)a[e.off] / diag);
+}
+
+int dxh_jacobi_solve_np2(int device, int ndim, int dim, int nsum, int64_t n0, int64_t n1, int64_t n2, const void* x0,
+                         const void* rhs, void* out, int out_dtype, double mass, double diffusion, double h, int maxiter,
+                         double tol, int* sweeps_done) {
+    DXH_REQUIRE(x0 && out, "null argument");
+    DXH_REQUIRE(maxiter >= 0, "maxiter must be >= 0");
+    DXH_REQUIRE(h > 0.0, "h must be positive");
+    DXH_REQUIRE(out_dtype == DXH_F32 || out_dtype == DXH_F64, "output dtype must be float32 or float64");
+    dxh_tvd_desc d{};
+    d.struct_size = sizeof d;
+    d.device = device;
+    d.dtype = DXH_F64;
+    d.ndim = ndim;
+    d.dim = dim;
+    d.nsum = nsum;
+    d.n0 = n0; d.n1 = n1; d.n2 = n2;
+    d.top_is_boundary = d.bottom_is_boundary = 1;
+    dxh_tvd_t hctx = nullptr;
+    int rc = dxh_tvd_create(&hctx, &d);
+    if (rc) return rc;
+    Ctx* c = reinterpret_cast<Ctx*>(hctx);
+    const size_t n = (size_t)n0 * (size_t)n1 * (size_t)n2;
+    HostPrefault pf;  // map the output pages while the device works
+    pf.start(out, n * (out_dtype == DXH_F32 ? 4 : 8), {{x0, n * 4}, {rhs, rhs ? n * 4 : 0}});
+    void *raw0 = nullptr, *raw1 = nullptr, *conv = nullptr, *tmp = nullptr;
+    auto body = [&]() -> int {
+        int r = set_coeffs_t<double>(c, 0.0, nullptr, mass, nullptr, 1, diffusion, nullptr, h, false);
+        if (r) return r;
+        if ((r = alloc_plane(c, &c->rs))) return r;
+        const dim3 grid = elem_grid(c->g), blk(256);
+        // float32 operands into the double planes (exact)
+        auto up = [&](const void* src, void** raw, void* plane) -> int {
+            if (!is_device_ptr(src)) {
+                DXH_HIP(pool_malloc(raw, n * 4));
+                DXH_HIP(hipMemcpyAsync(*raw, src, n * 4, hipMemcpyDefault, c->stream));
+                src = *raw;
+            }
+            hipLaunchKernelGGL((k_dense_to_plane<float, double>), grid, blk, 0, c->stream, c->g, (const float*)src, (double*)plane);
+            DXH_HIP(hipGetLastError());
+            return DXH_OK;
+        };
+        if ((r = up(x0, &raw0, c->u[0]))) return r;
+        if (rhs) {
+            if ((r = up(rhs, &raw1, c->u[1]))) return r;
+        } else {
+            // H1 regularisation: rhs = omega * img (h1_regularization.py:73), a float32 product
+            hipLaunchKernelGGL(k_scale_np2, grid, blk, 0, c->stream, c->g, (const double*)c->u[0], (float)mass, (double*)c->u[1]);
+        }
+        hipLaunchKernelGGL(k_divide_np2, grid, blk, 0, c->stream, c->g, (const double*)c->u[1], (float)c->c_diag, (double*)c->rs);
+        DXH_HIP(hipGetLastError());
+        if (maxiter > 1) DXH_HIP(hipMalloc(&tmp, c->plane_bytes));
+        c->cur = 0;
+        int64_t launches = 0;
+        r = jacobi_sweeps<double>(c, maxiter, tol, tmp, &launches, sweeps_done, /*first_f32=*/true);
+        pf.join();
+        if (r) return r;
+        if (out_dtype == DXH_F64) {
+            r = d2h_plane(c, out, c->u[1]);
+        } else {   // convert_dtype(out, float32) (h1_regularization.py:76): rounded on the device
+            void* dst = out;
+            if (!is_device_ptr(out)) {
+                DXH_HIP(pool_malloc(&conv, n * 4));
+                dst = conv;
+            }
+            hipLaunchKernelGGL((k_plane_to_dense<double, float>), grid, blk, 0, c->stream, c->g, (const double*)c->u[1], (float*)dst);
+            DXH_HIP(hipGetLastError());
+            if (conv) DXH_HIP(hipMemcpyAsync(out, conv, n * 4, hipMemcpyDefault, c->stream));
+        }
+        if (!r && hipStreamSynchronize(c->stream) != hipSuccess) { set_error("stream sync failed"); r = DXH_EHIP; }
+        return r;
+    };
+    rc = body();
+    (void)hipStreamSynchronize(c->stream);
+    if (raw0) pool_free(raw0);
+    if (raw1) pool_free(raw1);
+    if (conv) pool_free(conv);
+    if (tmp) (void)hipFree(tmp);
     dxh_tvd_destroy(hctx);
     return rc;
 }

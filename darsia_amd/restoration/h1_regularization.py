@@ -12,11 +12,11 @@ import numpy as np
 from .. import _lib
 from ..device import DeviceArray
 from ..image import with_array
-from ..utils.linear_solvers.jacobi import Jacobi
+from ..utils.linear_solvers.jacobi import Jacobi, float32_flow
 from ..utils.linear_solvers.solver import Solver
 
 
-def _h1_device(img: DeviceArray, mu: float, omega: float, dim: int, solver: Solver) -> DeviceArray:
+def _h1_device(img: DeviceArray, mu: float, omega: float, dim: int, solver: Solver, promotion=None) -> DeviceArray:
     """Device-resident image in, device-resident result out (the reference chains in host memory,
     h1_regularization.py:39-73): the Jacobi solve with rhs = omega * img formed on the device; MG / CG objects get the
     right-hand side as a second device array.  Channel-wise (``img.ndim == dim + 1``) only in the one-launch form, i.e.
@@ -38,6 +38,9 @@ def _h1_device(img: DeviceArray, mu: float, omega: float, dim: int, solver: Solv
         nsum = _lib.NSUM_ALL_AXES
     else:
         raise NotImplementedError("device-resident H1_regularization: (H, W[, C]) with Jacobi(tol=None), or arrays of dim axes")
+    if img.dtype == np.float32 and float32_flow(promotion, omega, mu) == "numpy2":
+        # the reference's own float32 flow; convert_dtype(out, float32) on the way out (h1_regularization.py:76)
+        return solver._call_numpy2(img, None, 1.0, out_dtype=np.float32, nsum=nsum)
     ndim, n0, n1, n2 = _lib.shape3(img.shape, dim)
     out = DeviceArray(img.shape, img.dtype, img.device)
     done = C.c_int(0)
@@ -48,12 +51,12 @@ def _h1_device(img: DeviceArray, mu: float, omega: float, dim: int, solver: Solv
     return out
 
 
-def _h1_array(img: np.ndarray, mu: float, omega: float, dim: int, solver: Solver) -> np.ndarray:
+def _h1_array(img: np.ndarray, mu: float, omega: float, dim: int, solver: Solver, promotion=None) -> np.ndarray:
     if img.dtype.kind != "f":
         raise TypeError("H1_regularization needs a float32/float64 image")
     solver.update_params(mass_coeff=omega, diffusion_coeff=mu, dim=dim)
     if isinstance(img, DeviceArray):
-        return _h1_device(img, mu, omega, dim, solver)
+        return _h1_device(img, mu, omega, dim, solver, promotion)
     if not isinstance(solver, Jacobi):
         # MG / CG objects (device solvers themselves): the reference's generic flow, channel by channel
         # (h1_regularization.py:54-70)
@@ -74,7 +77,7 @@ def _h1_array(img: np.ndarray, mu: float, omega: float, dim: int, solver: Solver
         # with a tolerance every channel stops at its own sweep and returns its own iterate (the reference solves channel
         # by channel, h1_regularization.py:54-67; Jacobi's stop test is a norm over the array it is given, jacobi.py:116-126)
         moved = np.moveaxis(src, -1, 0)
-        res = np.stack([_h1_array(np.ascontiguousarray(ch), mu, omega, dim, solver) for ch in moved], axis=0)
+        res = np.stack([_h1_array(np.ascontiguousarray(ch), mu, omega, dim, solver, promotion) for ch in moved], axis=0)
         return np.ascontiguousarray(np.moveaxis(res, 0, -1))
     if img.ndim == dim + 1 and dim == 2:
         # all channels in one launch: neighbour sum restricted to the spatial axes
@@ -85,6 +88,10 @@ def _h1_array(img: np.ndarray, mu: float, omega: float, dim: int, solver: Solver
         nsum = _lib.NSUM_ALL_AXES
     else:
         raise ValueError(f"image with {img.ndim} axes and dim={dim} not supported")
+    if img.dtype == np.float32 and type(omega) in (float, int) and float32_flow(promotion, omega, mu) == "numpy2":
+        # the reference's own float32 flow (float64 iterate from the first sweep's division on); the result rounded to
+        # float32 as convert_dtype(out_img, float32) does (h1_regularization.py:76)
+        return solver._call_numpy2(src, None, 1.0, out_dtype=np.float32, nsum=nsum)
     # omega * img: on the device when omega is a Python number (NumPy rounds it to the image dtype and multiplies there:
     # the kernel does the same); any other scalar type goes through NumPy's own promotion on the host
     rhs = None if type(omega) in (float, int) else np.ascontiguousarray(omega * src, dtype=img.dtype)
@@ -97,12 +104,14 @@ def _h1_array(img: np.ndarray, mu: float, omega: float, dim: int, solver: Solver
     return out
 
 
-def H1_regularization(img, mu: float, omega: float = 1.0, dim: int = 2, solver: Optional[Solver] = None):
-    """Inline application of H1 regularisation to an array or an Image-like object."""
+def H1_regularization(img, mu: float, omega: float = 1.0, dim: int = 2, solver: Optional[Solver] = None, promotion=None):
+    """Inline application of H1 regularisation to an array or an Image-like object.  ``promotion`` (extension): the dtype
+    flow of a float32 image with the Jacobi solver -- ``None``: ``DXH_PROMOTION``, else the reference's own ("numpy2":
+    float64 iterate, float32 result, utils/linear_solvers/jacobi.py); ``"native"``: float32 throughout."""
     if solver is None:
         solver = Jacobi()
     if isinstance(img, (np.ndarray, DeviceArray)):
-        return _h1_array(img, mu, omega, dim, solver)
+        return _h1_array(img, mu, omega, dim, solver, promotion)
     if hasattr(img, "img") and hasattr(img, "copy"):
-        return with_array(img, _h1_array(img.img, mu, omega, dim, solver))
+        return with_array(img, _h1_array(img.img, mu, omega, dim, solver, promotion))
     raise TypeError(f"Type {type(img)} not supported.")

@@ -11,8 +11,8 @@ Divergences from the reference, all deliberate:
 * ``solver=None`` creates a fresh ``Jacobi()`` per call instead of sharing one
   def-time instance whose cached diagonal never updates (quirks Q1, Q3);
 * two dtype flows for float32 images (``promotion``, an extra keyword; ``DXH_PROMOTION`` sets the
-  default).  ``"numpy2"`` -- THE DEFAULT wherever it exists (``Jacobi`` sweeps without tolerance,
-  anisotropic, scalar omega / ell, no warm start) -- is the reference's own flow under NumPy >= 2: the
+  default).  ``"numpy2"`` -- THE DEFAULT wherever it exists (the ``Jacobi`` solver, anisotropic,
+  scalar omega / ell, no warm start) -- is the reference's own flow under NumPy >= 2: the
   Jacobi iterate is float64 (jacobi.py:101-114), ``d``, ``b`` and the right-hand side float32, a
   float64 weight map the threshold; reproduced BIT FOR BIT (``Pipe<..., NP2>``, ``k_fused_np2``),
   0.39 ms per iteration at 4000 x 8000 x 3.  ``"native"`` keeps every quantity float32 (0.15 ms):
@@ -289,8 +289,8 @@ def numpy2_unsupported(img, mu, omega, ell, dim, x0, isotropic, solver, adaptive
         return "no warm start or adaptive schedule"
     if isotropic:
         return "anisotropic only (the reference's isotropic branch is float64-only)"
-    if not isinstance(solver, Jacobi) or solver.maxiter < 1 or solver.tol is not None:
-        return "Jacobi sweeps without tolerance only"
+    if not isinstance(solver, Jacobi) or solver.maxiter < 1:
+        return "the Jacobi solver only"
     return None
 
 
@@ -385,7 +385,7 @@ def split_bregman_tvd(
                 st.upload(img)
                 print(f"The energy functional starts at {st.energy()}")
                 for it in range(max_num_iter):
-                    r = st.run(1, solver.maxiter, None, eps=0.0 if eps is None else eps)
+                    r = st.run(1, solver.maxiter, solver.tol, eps=0.0 if eps is None else eps)
                     if show(it):
                         print(f"Split Bregman iteration {it} - relative increment: {r.rel_increment}, "
                               f"energy functional: {st.energy(previous=True)}")
@@ -393,7 +393,7 @@ def split_bregman_tvd(
                         break
                 return st.download(out=DeviceArray(img.shape, img.dtype, img.device) if on_device else None)
         if (not on_device and eps is None and np.ndim(mu) == 0 and max_num_iter >= 1 and img.nbytes >= (32 << 20)
-                and dim == 2 and solver.maxiter == 1 and (img.ndim == 2 or img.shape[2] <= 4)):
+                and dim == 2 and solver.maxiter == 1 and solver.tol is None and (img.ndim == 2 or img.shape[2] <= 4)):
             # fixed iteration count on a large host image with scalar coefficients: row bands through the device, the
             # transfers overlapped with the iterations (bit-identical to the one-piece run below; an array-valued mu stays
             # with the kept context, whose weight planes need not cross PCIe again)
@@ -415,7 +415,7 @@ def split_bregman_tvd(
                 st.set_coeffs(mu, omega, ell, img)
             st.upload(img)
             if on_device:
-                st.run(max_num_iter, solver.maxiter, None, eps=eps)
+                st.run(max_num_iter, solver.maxiter, solver.tol, eps=eps)
                 out = st.download(out=DeviceArray(img.shape, img.dtype, img.device))
             else:
                 # the result array's pages are mapped on this thread WHILE the device iterates (the blocking C call runs
@@ -425,7 +425,7 @@ def split_bregman_tvd(
 
                 def work():
                     try:
-                        st.run(max_num_iter, solver.maxiter, None, eps=eps)
+                        st.run(max_num_iter, solver.maxiter, solver.tol, eps=eps)
                     except BaseException as e:  # noqa: BLE001 -- re-raised on the calling thread
                         box["e"] = e
 

@@ -3,8 +3,12 @@
 Differences from the reference, both deliberate:
 
 * no hidden ``const_diag`` cache: the diagonal follows ``update_params`` (Q3);
-* arithmetic stays in the array's dtype (the reference promotes a float32
-  iterate to float64 under NumPy >= 2 through a strongly typed scalar).
+* two dtype flows for float32 operands, as in the TV loop (``promotion``, ``DXH_PROMOTION``): by default the
+  reference's own under NumPy >= 2 -- with Python-float coefficients its ``const_diag_scaled`` is an
+  ``np.float64``, so ``rhs / diag`` stays float32, the first sweep sums the neighbours of the float32 ``x0`` in
+  float32, and from its division on the iterate is float64: ``Jacobi.__call__`` RETURNS A FLOAT64 ARRAY for
+  float32 input there, and so does this one (``dxh_jacobi_solve_np2``); ``"native"`` keeps everything float32.
+  Array-valued coefficients always take the native flow.
 
 Kept: the neighbour sum runs over EVERY array axis (Q2), and with ``tol`` the
 iterate BEFORE the one that met the tolerance is returned (Q7).
@@ -28,10 +32,27 @@ def _coef(value, like: np.ndarray):
     return float(value), None
 
 
+def float32_flow(promotion, *coefficients) -> str:
+    """The dtype flow of a float32 solve: ``promotion`` if given, else ``DXH_PROMOTION``, else the reference's own
+    ("numpy2") -- which exists for scalar coefficients only."""
+    import os
+
+    if promotion is None:
+        promotion = os.environ.get("DXH_PROMOTION") or "numpy2"
+    if promotion not in ("native", "numpy2"):
+        raise ValueError(f"promotion must be None, 'native' or 'numpy2', not {promotion!r}")
+    if any(np.ndim(c) != 0 for c in coefficients):
+        return "native"
+    return promotion
+
+
 class Jacobi(Solver):
-    def __call__(self, x0: np.ndarray, rhs: np.ndarray, h: float = 1.0) -> np.ndarray:
+    def __call__(self, x0: np.ndarray, rhs: np.ndarray, h: float = 1.0, promotion=None) -> np.ndarray:
         if self.mass_coeff is None or self.diffusion_coeff is None:
             raise ValueError("mass_coeff and diffusion_coeff must be set (update_params)")
+        if (x0.dtype == np.float32 and getattr(rhs, "dtype", None) == np.float32
+                and float32_flow(promotion, self.mass_coeff, self.diffusion_coeff) == "numpy2"):
+            return self._call_numpy2(x0, rhs, h)
         # device-resident operands stay in HBM: DeviceArray in (x0, and rhs of the same dtype), DeviceArray out
         on_device = isinstance(x0, DeviceArray)
         if not on_device:
@@ -57,6 +78,28 @@ class Jacobi(Solver):
             src.device if on_device else _lib.default_device(), code, ndim, self.dim, _lib.NSUM_ALL_AXES, n0, n1, n2,
             _lib.ptr(src), _lib.ptr(rhs), _lib.ptr(out), m_s, _lib.ptr(m_a), k_s, _lib.ptr(k_a), float(h),
             int(self.maxiter), tol, C.byref(done)))
+        if self.verbose:
+            print(f"Jacobi: {done.value} of {self.maxiter} sweeps completed.")
+        return out
+
+    def _call_numpy2(self, x0, rhs, h: float, out_dtype=np.float64, nsum=_lib.NSUM_ALL_AXES):
+        """float32 operands in the reference's dtype flow (``dxh_jacobi_solve_np2``); ``rhs = None``: ``mass * x0``."""
+        on_device = isinstance(x0, DeviceArray)
+        src = x0 if on_device else np.ascontiguousarray(x0)
+        if rhs is not None:
+            if tuple(rhs.shape) != tuple(x0.shape):
+                raise ValueError("x0 and rhs must have the same shape")
+            if not isinstance(rhs, DeviceArray):
+                rhs = np.ascontiguousarray(rhs, dtype=np.float32)
+        ndim, n0, n1, n2 = _lib.shape3(src.shape, min(self.dim, src.ndim))
+        _lib.require_gpu()
+        out_dtype = np.dtype(out_dtype)
+        out = DeviceArray(src.shape, out_dtype, src.device) if on_device else np.empty(src.shape, out_dtype)
+        done = C.c_int(0)
+        _lib.check(_lib.load().dxh_jacobi_solve_np2(
+            src.device if on_device else _lib.default_device(), ndim, self.dim, nsum, n0, n1, n2, _lib.ptr(src), _lib.ptr(rhs),
+            _lib.ptr(out), _lib.dtype_code(out_dtype), float(self.mass_coeff), float(self.diffusion_coeff), float(h),
+            int(self.maxiter), -1.0 if self.tol is None else float(self.tol), C.byref(done)))
         if self.verbose:
             print(f"Jacobi: {done.value} of {self.maxiter} sweeps completed.")
         return out

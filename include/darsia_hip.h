@@ -380,6 +380,17 @@ int dxh_jacobi_solve(int device, int dtype, int ndim, int dim, int nsum, int64_t
                      int* sweeps_done);
 
 /*
+ * The same solve in the reference's dtype flow for FLOAT32 operands under NumPy >= 2 (scalar coefficients): rhs / diag stays
+ * float32, the first sweep sums the neighbours of the float32 x0 in float32 and divides by the np.float64 const_diag_scaled
+ * (jacobi.py:101-114), every later sweep runs in float64.  x0, rhs (or NULL = mass * x0): float32 arrays, host or device;
+ * out: out_dtype DXH_F64 (what Jacobi.__call__ returns in the reference) or DXH_F32 (convert_dtype(out, float32),
+ * h1_regularization.py:76).
+ */
+int dxh_jacobi_solve_np2(int device, int ndim, int dim, int nsum, int64_t n0, int64_t n1, int64_t n2, const void* x0,
+                         const void* rhs, void* out, int out_dtype, double mass, double diffusion, double h, int maxiter,
+                         double tol, int* sweeps_done);
+
+/*
  * Multigrid and conjugate-gradient solvers for  mass * x - diffusion * laplace(x) = rhs
  * (utils/linear_solvers/mg.py:13-270, cg.py:16-59; plug-in contract utils/linear_solvers/solver.py:12-72).
  * Arrays have exactly `dim` axes, shape (n0, n1[, n2]), dense host memory.  The object is stateful like the

@@ -73,6 +73,39 @@ def main():
     out["n12_gray_m3_eps/maxiter"] = np.int64(3)
     out["n12_gray_m3_eps/iters"] = np.int64(sum(1 for ln in buf.getvalue().splitlines() if ln.startswith("Split Bregman iteration")))
 
+    # a tolerance in the inner solver (Q7: the iterate before the one that met it is returned)
+    run_tol = lambda name, img, **kw: (out.__setitem__(name + "/img", img),                                     # noqa: E731
+                                       out.__setitem__(name + "/out", da.split_bregman_tvd(img.copy(), **kw)))
+    run_tol("t1_gray_tol", gray, solver=da.Jacobi(maxiter=20, tol=1e-3), mu=0.1, max_num_iter=6)
+    run_tol("t2_rgb_tol", rgb, solver=da.Jacobi(maxiter=15, tol=3e-3), mu=0.2, ell=0.5, max_num_iter=5)
+    run_tol("t3_vol_tol", vol, solver=da.Jacobi(maxiter=12, tol=2e-3), mu=0.1, dim=3, max_num_iter=4)
+    run_tol("t4_gray_tol_loose", gray, solver=da.Jacobi(maxiter=5, tol=0.5), mu=0.1, max_num_iter=3)   # met at once: x0 comes back
+
+    # Jacobi.__call__ on float32 operands (returns float64 under NumPy >= 2) and H1_regularization (float32 out)
+    def jac(name, x0, rhs, solver, **params):
+        solver.update_params(**params)
+        res = solver(x0=x0.copy(), rhs=rhs.copy())
+        out[name + "/x0"], out[name + "/rhs"], out[name + "/out"] = x0, rhs, res
+        meta[name + "_dtype"] = str(res.dtype)
+
+    rhs_g = noisy_blocks(gray.shape, 51, np.float32)
+    jac("j1_gray_m1", gray, rhs_g, da.Jacobi(maxiter=1), mass_coeff=1.0, diffusion_coeff=0.2, dim=2)
+    jac("j2_gray_m7", gray, rhs_g, da.Jacobi(maxiter=7), mass_coeff=0.7, diffusion_coeff=0.35, dim=2)
+    jac("j3_rgb_m4", rgb, noisy_blocks(rgb.shape, 52, np.float32), da.Jacobi(maxiter=4), mass_coeff=1.0, diffusion_coeff=0.2, dim=2)
+    jac("j4_vol_m3", vol, noisy_blocks(vol.shape, 53, np.float32), da.Jacobi(maxiter=3), mass_coeff=1.3, diffusion_coeff=0.4, dim=3)
+    jac("j5_gray_tol", gray, rhs_g, da.Jacobi(maxiter=30, tol=1e-3), mass_coeff=1.0, diffusion_coeff=0.2, dim=2)
+
+    def h1(name, img, solver, **kw):
+        res = da.H1_regularization(img.copy(), solver=solver, **kw)
+        out[name + "/img"], out[name + "/out"] = img, res
+        meta[name + "_dtype"] = str(res.dtype)
+
+    h1("h1_gray_m4", gray, da.Jacobi(maxiter=4), mu=0.4, omega=1.3, dim=2)
+    h1("h2_rgb_m4", rgb, da.Jacobi(maxiter=4), mu=0.4, omega=1.3, dim=2)
+    h1("h3_rgb_tol", rgb, da.Jacobi(maxiter=30, tol=1e-3), mu=1.0, omega=1.0, dim=2)
+    h1("h4_vol_m6", vol, da.Jacobi(maxiter=6), mu=0.5, omega=0.8, dim=3)
+    h1("h5_gray_m1", gray, da.Jacobi(), mu=1.0, omega=1.0, dim=2)
+
     for k, v in meta.items():
         out["meta/" + k] = np.array(v)
     path = os.path.join(HERE, "tvd_np2_generic_golden.npz")

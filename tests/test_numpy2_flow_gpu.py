@@ -177,8 +177,6 @@ def test_unsupported_configurations_say_so():
     with pytest.raises(NotImplementedError, match="numpy2"):
         da.split_bregman_tvd(img, mu=0.1, isotropic=True, promotion="numpy2")
     with pytest.raises(NotImplementedError, match="numpy2"):
-        da.split_bregman_tvd(img, mu=0.1, solver=da.Jacobi(maxiter=3, tol=1e-3), promotion="numpy2")
-    with pytest.raises(NotImplementedError, match="numpy2"):
         da.split_bregman_tvd(img, mu=0.1, solver=da.MG(2), promotion="numpy2")
     with pytest.raises(NotImplementedError, match="numpy2"):
         da.split_bregman_tvd(img.astype(np.float64), mu=0.1, promotion="numpy2")
@@ -258,7 +256,7 @@ def test_large_host_image_takes_the_row_bands_by_default():
 
 
 # ---- float32 images outside the default solve: several Jacobi sweeps, volumes, six channels (three kinds of launches) ----
-from test_oracle_np2_generic_golden import CASES as GENERIC_CASES, case_kwargs  # noqa: E402
+from test_oracle_np2_generic_golden import CASES as GENERIC_CASES, H1_CASES, JACOBI_CASES, TOL_CASES, case_kwargs  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -333,3 +331,41 @@ def test_the_round_one_float32_vector_with_three_sweeps_is_bit_exact_now(golden)
     native kernels since round 1; through the default flow it is the reference's result bit for bit."""
     img = golden["g6_jacobi3_rgb_f32/img"]
     bits(da.split_bregman_tvd(img, mu=0.1, max_num_iter=5, solver=da.Jacobi(maxiter=3)), golden["g6_jacobi3_rgb_f32/out"])
+
+
+@pytest.mark.parametrize("name", sorted(TOL_CASES))
+def test_tolerance_in_the_jacobi_solver_bit_for_bit_against_the_reference(generic, name):
+    c = TOL_CASES[name]
+    out = da.split_bregman_tvd(generic[name + "/img"], solver=da.Jacobi(maxiter=c["m"], tol=c["tol"]), **c["kw"])
+    bits(out, generic[name + "/out"])
+
+
+@pytest.mark.parametrize("name", sorted(JACOBI_CASES))
+def test_jacobi_on_float32_operands_returns_the_references_float64_iterate(generic, name):
+    """Jacobi.__call__ (jacobi.py:74-133) on float32 arrays under NumPy >= 2: float64 out -- dxh_jacobi_solve_np2."""
+    c = JACOBI_CASES[name]
+    solver = da.Jacobi(maxiter=c["m"], tol=c["tol"])
+    solver.update_params(mass_coeff=c["mass"], diffusion_coeff=c["diff"], dim=c["dim"])
+    x0, rhs = generic[name + "/x0"], generic[name + "/rhs"]
+    out = solver(x0, rhs)
+    assert out.dtype == np.float64
+    bits(out, generic[name + "/out"])
+    dev = solver(da.DeviceArray.from_host(x0), da.DeviceArray.from_host(rhs))
+    assert dev.dtype == np.float64
+    bits(dev.get(), generic[name + "/out"])
+    # the float32 kernels on request: the oracle's same-dtype flow
+    nat = solver(x0, rhs, promotion="native")
+    assert nat.dtype == np.float32
+    bits(nat, O.jacobi(x0, rhs, c["mass"], c["diff"], dim=c["dim"], maxiter=c["m"], tol=c["tol"], promotion="strict").astype(np.float32))
+
+
+@pytest.mark.parametrize("name", sorted(H1_CASES))
+def test_h1_regularization_of_float32_images_bit_for_bit_against_the_reference(generic, name):
+    c = H1_CASES[name]
+    img = generic[name + "/img"]
+    out = da.H1_regularization(img, solver=da.Jacobi(maxiter=c["m"], tol=c["tol"]), **c["kw"])
+    assert out.dtype == np.float32
+    bits(out, generic[name + "/out"])
+    if c["tol"] is None or img.ndim == c["kw"]["dim"]:
+        dev = da.H1_regularization(da.DeviceArray.from_host(img), solver=da.Jacobi(maxiter=c["m"], tol=c["tol"]), **c["kw"])
+        bits(dev.get(), generic[name + "/out"])

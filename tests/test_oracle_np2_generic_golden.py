@@ -53,3 +53,49 @@ def test_oracle_stop_iteration_with_several_sweeps(generic):
                                           return_state=True)
     assert done == int(generic["n12_gray_m3_eps/iters"])
     assert np.array_equal(out, generic["n12_gray_m3_eps/out"])
+
+
+TOL_CASES = {
+    "t1_gray_tol": dict(m=20, tol=1e-3, kw=dict(mu=0.1, max_num_iter=6)),
+    "t2_rgb_tol": dict(m=15, tol=3e-3, kw=dict(mu=0.2, ell=0.5, max_num_iter=5)),
+    "t3_vol_tol": dict(m=12, tol=2e-3, kw=dict(mu=0.1, dim=3, max_num_iter=4)),
+    "t4_gray_tol_loose": dict(m=5, tol=0.5, kw=dict(mu=0.1, max_num_iter=3)),
+}
+JACOBI_CASES = {
+    "j1_gray_m1": dict(m=1, tol=None, mass=1.0, diff=0.2, dim=2),
+    "j2_gray_m7": dict(m=7, tol=None, mass=0.7, diff=0.35, dim=2),
+    "j3_rgb_m4": dict(m=4, tol=None, mass=1.0, diff=0.2, dim=2),
+    "j4_vol_m3": dict(m=3, tol=None, mass=1.3, diff=0.4, dim=3),
+    "j5_gray_tol": dict(m=30, tol=1e-3, mass=1.0, diff=0.2, dim=2),
+}
+H1_CASES = {
+    "h1_gray_m4": dict(m=4, tol=None, kw=dict(mu=0.4, omega=1.3, dim=2)),
+    "h2_rgb_m4": dict(m=4, tol=None, kw=dict(mu=0.4, omega=1.3, dim=2)),
+    "h3_rgb_tol": dict(m=30, tol=1e-3, kw=dict(mu=1.0, omega=1.0, dim=2)),
+    "h4_vol_m6": dict(m=6, tol=None, kw=dict(mu=0.5, omega=0.8, dim=3)),
+    "h5_gray_m1": dict(m=1, tol=None, kw=dict(mu=1.0, omega=1.0, dim=2)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(TOL_CASES))
+def test_oracle_with_a_tolerance_in_the_jacobi_solver(generic, name):
+    c = TOL_CASES[name]
+    out = O.split_bregman_tvd(generic[name + "/img"], jacobi_maxiter=c["m"], jacobi_tol=c["tol"], promotion="numpy2", **c["kw"])
+    assert out.dtype == np.float32 and np.array_equal(out, generic[name + "/out"])
+
+
+@pytest.mark.parametrize("name", sorted(JACOBI_CASES))
+def test_oracle_jacobi_on_float32_operands_returns_float64_like_the_reference(generic, name):
+    c = JACOBI_CASES[name]
+    out = O.jacobi(generic[name + "/x0"], generic[name + "/rhs"], c["mass"], c["diff"], dim=c["dim"], maxiter=c["m"], tol=c["tol"],
+                   promotion="numpy2")
+    ref = generic[name + "/out"]
+    assert ref.dtype == np.float64 and out.dtype == np.float64 and np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("name", sorted(H1_CASES))
+def test_oracle_h1_regularization_of_float32_images(generic, name):
+    c = H1_CASES[name]
+    out = O.h1_regularization(generic[name + "/img"], jacobi_maxiter=c["m"], jacobi_tol=c["tol"], promotion="numpy2", **c["kw"])
+    ref = generic[name + "/out"]
+    assert ref.dtype == np.float32 and out.dtype == np.float32 and np.array_equal(out, ref)
