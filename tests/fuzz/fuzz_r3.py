@@ -48,10 +48,31 @@ for case in range(n_cases):
             kw["mu"] = mu if kind == "f64" else mu.astype(np.float32)
         if rng.random() < 0.3:
             kw["eps"] = float(rng.choice([1e-2, 3e-3]))
-        ref = O.split_bregman_tvd(img, **kw)                                   # the reference's NumPy-2 dtype flow
-        out = da.split_bregman_tvd(img, promotion="numpy2", **kw)
+        # one sweep (the fused pipelines), several, or sweeps with a tolerance (three kinds of launches); now and then six channels
+        jm = int(rng.choice([1, 1, 1, 2, 3, 5, 8]))
+        tol = float(rng.choice([1e-2, 1e-3])) if (jm > 1 and rng.random() < 0.3) else None
+        if rng.random() < 0.1 and c == 0:
+            img = np.repeat(img[..., None], 6, axis=2) * rng.random((h, w, 6)).astype(np.float32)
+            shape = img.shape
+            if np.ndim(kw["mu"]) != 0:
+                kw["mu"] = np.repeat(kw["mu"][..., None], 6, axis=2)
+        ref = O.split_bregman_tvd(img, jacobi_maxiter=jm, jacobi_tol=tol, **kw)   # the reference's NumPy-2 dtype flow
+        out = da.split_bregman_tvd(img, promotion="numpy2", solver=da.Jacobi(maxiter=jm, tol=tol), **kw)
         if out.dtype != ref.dtype or not np.array_equal(out, ref):
-            report("numpy2", shape, np.float32, kw, out, ref)
+            report(f"numpy2 jm={jm} tol={tol}", shape, np.float32, kw, out, ref)
+        if case % 10 == 0:
+            # Jacobi.__call__ (float64 out) and H1_regularization (float32 out) on the same image
+            sol = da.Jacobi(maxiter=jm, tol=tol)
+            sol.update_params(mass_coeff=kw["omega"], diffusion_coeff=kw["ell"] if "ell" in kw else 0.3, dim=2)
+            rhs = (rng.random(img.shape) * scale).astype(np.float32)
+            ref = O.jacobi(img, rhs, sol.mass_coeff, sol.diffusion_coeff, dim=2, maxiter=jm, tol=tol)
+            out = sol(img, rhs)
+            if out.dtype != ref.dtype or not np.array_equal(out, ref):
+                report(f"jacobi numpy2 jm={jm} tol={tol}", shape, np.float32, {}, out, ref)
+            ref = O.h1_regularization(img, 0.4, 1.3, dim=2, jacobi_maxiter=jm, jacobi_tol=tol)
+            out = da.H1_regularization(img, 0.4, 1.3, dim=2, solver=da.Jacobi(maxiter=jm, tol=tol))
+            if out.dtype != ref.dtype or not np.array_equal(out, ref):
+                report(f"h1 numpy2 jm={jm} tol={tol}", shape, np.float32, {}, out, ref)
     else:
         # ---- (b) volumes
         n0, n1 = int(rng.integers(1, 40)), int(rng.integers(1, 60))
