@@ -8,12 +8,12 @@
 import csv, glob, os, re, shutil, collections
 os.makedirs("profiles", exist_ok=True)
 rows = []
-for v in ("aniso", "iso", "gray", "np2", "np2arr", "jacobi3d"):
+for v in ("aniso", "iso", "gray", "np2", "np2arr", "jacobi3d", "warp"):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(f"gpurun_out/sq_r03_{v}/p*/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if not any(s in k for s in ("k_fused", "k_jacobi_vol")):
+            if not any(s in k for s in ("k_fused", "k_jacobi_vol", "k_warp")):
                 continue
             acc[k.split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, d in acc.items():
