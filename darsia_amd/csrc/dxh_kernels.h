@@ -1761,7 +1761,8 @@ __global__ void __launch_bounds__(256) k_rhs_np2(Geom g, const double* __restric
 }
 
 static __global__ void __launch_bounds__(256) k_jacobi_np2_first(Geom g, const double* __restrict__ rs, const double* __restrict__ xin,
-                                                                 double dsc, double* __restrict__ xout) {
+                                                                 double dsc, const double* __restrict__ dsc_p,
+                                                                 double* __restrict__ xout) {
     ElemIdx e;
     if (!elem_index(g, e)) return;
     float acc = 0.f;
@@ -1769,7 +1770,45 @@ static __global__ void __launch_bounds__(256) k_jacobi_np2_first(Geom g, const d
         acc = acc + (float)xin[nb_off(g, e, ax, -1)];
         acc = acc + (float)xin[nb_off(g, e, ax, +1)];
     }
-    xout[e.off] = rs[e.off] + (double)acc / dsc;
+    xout[e.off] = rs[e.off] + (double)acc / (dsc_p ? dsc_p[e.off] : dsc);
+}
+
+// Array-valued omega and / or ell (float64 arrays, or ell = 2 mu of a float64 mu) next to the float32 image: what NumPy's
+// promotion makes of split_bregman_tvd.py:84-89 and jacobi.py:107 then --
+//   ell an array:   t = ell (b - d) is float64 (b - d is formed in float32 first); rhs += fd_j(t) adds in float64 and
+//                   stores float32 (in-place ufunc, same-kind cast) unless the right-hand side itself is float64
+//   omega an array: rhs = omega img is float64 and stays so
+//   diag an array (either of the two): rhs / diag is float64 whatever rhs is
+struct Np2Het {
+    const double *ell_p, *diag_p, *kq_p;  // planes or nullptr (ell_p only when ell is an array)
+    double kq, diag_d;
+    float ell_f, diag_f;
+    int rhs64;
+};
+template <int DIM>
+__global__ void __launch_bounds__(256) k_rhs_np2_het(Geom g, const double* __restrict__ of, QPlanes<double, DIM> q, Np2Het k,
+                                                      double* __restrict__ rs) {
+    ElemIdx e;
+    if (!elem_index(g, e)) return;
+    const double kq_c = k.kq_p ? k.kq_p[e.off] : k.kq;
+    double r = of[e.off];   // a float32 value unless rhs64
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+        float d, b;
+        np2_split(q.in[j][e.off], kq_c, d, b);
+        const float bd_c = b - d;
+        const int64_t o = nb_off(g, e, j, -1);
+        np2_split(q.in[j][o], k.kq_p ? k.kq_p[o] : k.kq, d, b);
+        const float bd_n = b - d;
+        if (k.ell_p) {
+            const double fd = k.ell_p[e.off] * (double)bd_c - k.ell_p[o] * (double)bd_n;
+            r = k.rhs64 ? r + fd : (double)(float)(r + fd);
+        } else {
+            const float fd = k.ell_f * bd_c - k.ell_f * bd_n;
+            r = k.rhs64 ? r + (double)fd : (double)((float)r + fd);
+        }
+    }
+    rs[e.off] = k.diag_p ? r / k.diag_p[e.off] : (k.rhs64 ? r / k.diag_d : (double)((float)r / k.diag_f));
 }
 
 template <int DIM, bool KQARR>

@@ -111,6 +111,7 @@ struct Ctx {
     bool np2 = false;            // double context whose planes hold the reference's mixed float32 / float64 state
     bool np2_first = true;       // u still is the float32 image (first iteration after an upload)
     bool np2_mu_is_kq = false;   // the given mu array already is the threshold mu / ell (float32 quotient, widened)
+    bool ell_is_arr = false, om_is_arr = false;   // set_coeffs: ell (given, or 2 mu) / omega is an array
 
     // ---- row slab of a distributed problem (dxh_tvd_attach_comm) ----
     Comm* comm = nullptr;
@@ -981,7 +982,8 @@ static int jacobi_sweeps(Ctx* c, int maxiter, double tol, void* tmp, int64_t* la
         if (f32) {
             if constexpr (std::is_same<T, double>::value)
                 hipLaunchKernelGGL(k_jacobi_np2_first, elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const double*)c->rs,
-                                   (const double*)x, c->c_dsc, (double*)xn);
+                                   (const double*)x, c->c_dsc, (c->het && !c->het_cdiag) ? (const double*)c->cp_dsc : nullptr,
+                                   (double*)xn);
         } else {
             launch_jacobi<T>(c, x, xn);
         }
@@ -1101,7 +1103,19 @@ static int np2_generic_iteration(Ctx* c, int maxiter, double tol, void* tmp, int
     const dim3 grid = elem_grid(c->g), blk(256);
     const Np2Coef k = np2_coef(c);
     auto q = make_q<double, DIM>(c, in, in);
-    if (k.kq_plane) hipLaunchKernelGGL((k_rhs_np2<DIM, true>), grid, blk, 0, c->stream, c->g, (const double*)c->of, q, k, (double*)c->rs);
+    if (c->het && !c->het_cdiag) {   // array-valued omega and / or ell: float64 enters the right-hand side (k_rhs_np2_het)
+        Np2Het hk{};
+        hk.ell_p = c->ell_is_arr ? (const double*)c->cp_ell : nullptr;
+        hk.diag_p = (const double*)c->cp_diag;
+        hk.kq_p = (const double*)c->cp_kq;
+        hk.kq = c->c_kq;
+        hk.diag_d = c->c_diag;
+        hk.ell_f = (float)c->ell_s;
+        hk.diag_f = (float)c->c_diag;
+        hk.rhs64 = c->om_is_arr ? 1 : 0;
+        hipLaunchKernelGGL((k_rhs_np2_het<DIM>), grid, blk, 0, c->stream, c->g, (const double*)c->of, q, hk, (double*)c->rs);
+    }
+    else if (k.kq_plane) hipLaunchKernelGGL((k_rhs_np2<DIM, true>), grid, blk, 0, c->stream, c->g, (const double*)c->of, q, k, (double*)c->rs);
     else hipLaunchKernelGGL((k_rhs_np2<DIM, false>), grid, blk, 0, c->stream, c->g, (const double*)c->of, q, k, (double*)c->rs);
     ++*launches;
     int swept = 0;
@@ -1146,9 +1160,9 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
         DXH_REQUIRE(jacobi_maxiter >= 1 && !c->solver, "numpy2 promotion: Jacobi sweeps only");
         DXH_REQUIRE(!iso, "numpy2 promotion: anisotropic shrinkage only (the reference's isotropic branch is float64-only)");
         DXH_REQUIRE(!c->from_db && !c->explicit_db && !(flags & DXH_FLAG_EXPLICIT), "numpy2 promotion: no explicit split variables");
-        DXH_REQUIRE(!c->het || (c->het_cdiag && c->cp_kq), "numpy2 promotion: omega and ell must be scalars");
+        DXH_REQUIRE(!c->het || c->cp_kq, "numpy2 promotion: the coefficient planes are missing");
         if constexpr (!std::is_same<T, double>::value) { set_error("numpy2 promotion needs a float64 context"); return DXH_ESTATE; }
-        np2_generic = !(fused_ok && dim == 2 && c->g.n2 >= 1 && c->g.n2 <= 4);
+        np2_generic = !(fused_ok && dim == 2 && c->g.n2 >= 1 && c->g.n2 <= 4) || (c->het && !c->het_cdiag);
         if (np2_generic) fused_ok = false;
     }
     if (c->solver) {
@@ -1654,6 +1668,7 @@ static int set_coeffs_t(Ctx* c, double mu, const void* mu_arr, double omega, con
     const int dim = c->desc.dim;
     const double h2 = h * h;
     c->het = mu_arr || omega_arr || ell_arr;
+    c->ell_is_arr = c->om_is_arr = false;
     c->mu_s = mu;
     c->omega_s = omega;
     for (void** p : {&c->in_mu, &c->in_om, &c->in_ell}) {
@@ -1726,6 +1741,8 @@ static int set_coeffs_t(Ctx* c, double mu, const void* mu_arr, double omega, con
     // only mu varies (the TVD operator always passes a scalar ell): the Jacobi divisors are the Python floats of
     // derive_coefs' diag_s / dsc_s, and the fused sweep divides by them through reciprocals like the scalar pipeline
     const bool ell_is_arr = ell_arr || (!has_ell && mu_arr);
+    c->ell_is_arr = ell_is_arr;
+    c->om_is_arr = omega_arr != nullptr;
     if (!ell_is_arr && !omega_arr) {
         c->c_diag = omega + ell_d * 2 * dim / h2;
         c->c_dsc = c->c_diag / (ell_d / h2);
@@ -2025,7 +2042,7 @@ static int finish_upload(Ctx* c, const void* u0, const void* d0, const void* b0,
     if (f32)
         hipLaunchKernelGGL((k_scale<float>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const float*)c->u[0],
                            (float)c->omega_s, om_arr ? (const float*)c->om_plane : nullptr, (float*)c->of);
-    else if (c->np2)   // np.multiply(omega, img) on the float32 image: a float32 product, kept in the float64 plane
+    else if (c->np2 && !om_arr)   // np.multiply(omega, img) on the float32 image: a float32 product, kept in the float64 plane
         hipLaunchKernelGGL(k_scale_np2, elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const double*)c->u[0],
                            (float)c->omega_s, (double*)c->of);
     else
@@ -2033,7 +2050,7 @@ static int finish_upload(Ctx* c, const void* u0, const void* d0, const void* b0,
                            c->omega_s, om_arr ? (const double*)c->om_plane : nullptr, (double*)c->of);
     DXH_HIP(hipGetLastError());
     c->np2_first = true;
-    if (c->np2) DXH_REQUIRE(!u0 && !d0 && !om_arr, "numpy2 promotion: no warm start, scalar omega");
+    if (c->np2) DXH_REQUIRE(!u0 && !d0, "numpy2 promotion: no warm start");   // (a float64 omega array: a float64 product, the branch above)
     if (u0 && (rc = h2d_plane(c, c->u[0], u0))) return rc;
     if (!c->pristine) {   // a fresh context's planes were cleared when they were allocated
         for (int j = 0; j < dim; ++j) {

@@ -131,13 +131,26 @@ class DeviceTVD:
         """Scalar omega and ell; mu a scalar or an array.  A float64 mu array is divided by ell on the device in float64
         (``mu / ell``, split_bregman_tvd.py:144: float64 array / Python float); a float32 one the way NumPy does it -- the
         quotient in float32 -- here, and handed over as the threshold itself."""
-        if np.ndim(omega) != 0 or (ell is not None and np.ndim(ell) != 0):
-            raise NotImplementedError("promotion='numpy2': omega and ell must be scalars")
-        mu_s, mu_a = _coef(mu, like, "mu", True)
-        if mu_a is not None and ell is None:
-            raise NotImplementedError("promotion='numpy2': an array-valued mu needs a scalar ell (ell = 2 mu would be an array)")
-        if isinstance(mu_a, DeviceArray):
+        if any(isinstance(c, DeviceArray) for c in (mu, omega, ell)):
             raise NotImplementedError("promotion='numpy2': device-resident coefficient arrays are not supported")
+        if np.ndim(omega) != 0 or (ell is not None and np.ndim(ell) != 0) or (ell is None and np.ndim(mu) != 0):
+            # array-valued omega / ell (or ell = 2 mu): float64 arrays, the coefficient planes of the double context
+            # (split_bregman_tvd.py:62-68, jacobi.py:57-72,101-106 in float64, as for a float64 image)
+            arrs = [np.asarray(c) for c in (mu, omega, ell) if c is not None and np.ndim(c) != 0]
+            if any(a.dtype != np.float64 for a in arrs):
+                raise NotImplementedError("promotion='numpy2': array-valued omega / ell need float64 arrays")
+            f64 = _lib.dtype_code(np.dtype(np.float64))
+            shaped = lambda c: None if (c is None or np.ndim(c) == 0) else np.ascontiguousarray(  # noqa: E731
+                np.broadcast_to(c, like.shape), dtype=np.float64)
+            sc = lambda c: 0.0 if (c is None or np.ndim(c) != 0) else float(c)   # noqa: E731
+            mu_a, om_a, ell_a = shaped(mu), shaped(omega), shaped(ell)
+            if self._promotion_mode != _lib.PROMOTION_NUMPY2:
+                _lib.check(self.lib.dxh_tvd_set_promotion(self._h, _lib.PROMOTION_NUMPY2))
+                self._promotion_mode = _lib.PROMOTION_NUMPY2
+            _lib.check(self.lib.dxh_tvd_set_coeffs_typed(self._h, sc(mu), _lib.ptr(mu_a), f64, sc(omega) if om_a is None else float("nan"),
+                                                          _lib.ptr(om_a), f64, 0 if ell is None else 1, sc(ell), _lib.ptr(ell_a), f64))
+            return
+        mu_s, mu_a = _coef(mu, like, "mu", True)
         mode = _lib.PROMOTION_NUMPY2
         if mu_a is not None and mu_a.dtype == np.float32:
             mu_a = (mu_a / float(ell)).astype(np.float64)      # float32 array / Python float -> float32 quotient, widened
@@ -279,12 +292,15 @@ def numpy2_unsupported(img, mu, omega, ell, dim, x0, isotropic, solver, adaptive
         return "the image is not float32"
     if dim not in (2, 3) or img.ndim not in (2, 3) or dim > img.ndim:
         return "dim = 2 or 3 on an array of 2 or 3 axes only"
-    if np.ndim(omega) != 0 or (ell is not None and np.ndim(ell) != 0):
-        return "omega and ell must be scalars"
-    if np.ndim(mu) != 0 and ell is None:
-        return "an array-valued mu needs a scalar ell"
-    if isinstance(mu, DeviceArray):
+    if any(isinstance(c, DeviceArray) for c in (mu, omega, ell)):
         return "device-resident coefficient arrays"
+    if np.ndim(omega) != 0 or (ell is not None and np.ndim(ell) != 0) or (ell is None and np.ndim(mu) != 0):
+        # omega and / or ell (given, or 2 mu) an array: float64 arrays pull parts of the right-hand side into float64
+        # (k_rhs_np2_het); with float32 arrays only, every quantity of the reference stays float32 -- the native flow IS
+        # the reference's (native_is_the_reference_flow); a mixture of the two is not reproduced
+        kinds = {np.asarray(c).dtype for c in (mu, omega, ell) if c is not None and np.ndim(c) != 0}
+        if kinds != {np.dtype(np.float64)}:
+            return "array-valued omega / ell: float64 arrays only"
     if x0 is not None or adaptive is not None:
         return "no warm start or adaptive schedule"
     if isotropic:
@@ -292,6 +308,17 @@ def numpy2_unsupported(img, mu, omega, ell, dim, x0, isotropic, solver, adaptive
     if not isinstance(solver, Jacobi) or solver.maxiter < 1:
         return "the Jacobi solver only"
     return None
+
+
+def native_is_the_reference_flow(img, mu, omega, ell) -> bool:
+    """float32 image with an array-valued omega or ell (given, or 2 mu) and float32 arrays only: the Jacobi diagonals are
+    float32 arrays then (jacobi.py:57-72,101-106), no np.float64 scalar meets the iterate, and every quantity of the
+    reference stays float32 -- its flow is the native one, bit for bit."""
+    if img.dtype != np.float32 or any(isinstance(c, DeviceArray) for c in (mu, omega, ell)):
+        return False
+    if not (np.ndim(omega) != 0 or (ell is not None and np.ndim(ell) != 0) or (ell is None and np.ndim(mu) != 0)):
+        return False
+    return {np.asarray(c).dtype for c in (mu, omega, ell) if c is not None and np.ndim(c) != 0} == {np.dtype(np.float32)}
 
 
 def choose_promotion(promotion: Optional[str], img_dtype, coefs, why_not: Optional[str]) -> str:
@@ -367,6 +394,8 @@ def split_bregman_tvd(
 
     quiet = not (verbose if isinstance(verbose, bool) else verbose > 0)
     why_not = numpy2_unsupported(img, mu, omega, ell, dim, x0, isotropic, solver, adaptive, quiet)
+    if promotion in (None, "numpy2") and native_is_the_reference_flow(img, mu, omega, ell):
+        promotion = "native"   # all-float32 arrays: the reference's own flow is float32 throughout
     promotion = choose_promotion(promotion, img.dtype, (mu, omega, ell), why_not)
     if promotion == "numpy2":
         if why_not is not None:

@@ -106,6 +106,33 @@ def main():
     h1("h4_vol_m6", vol, da.Jacobi(maxiter=6), mu=0.5, omega=0.8, dim=3)
     h1("h5_gray_m1", gray, da.Jacobi(), mu=1.0, omega=1.0, dim=2)
 
+    # array-valued omega / ell (or ell = 2 mu) next to the float32 image.  a*: float64 arrays (parts of the right-hand side
+    # turn float64); f*: float32 arrays only (every quantity stays float32)
+    rng = np.random.default_rng(61)
+
+    def arr(shape, lo, hi, dt=np.float64):
+        return (lo + (hi - lo) * rng.random(shape)).astype(dt)
+
+    def run_arr(name, img, maxiter=1, **kw):
+        for k, v in kw.items():
+            if isinstance(v, np.ndarray):
+                out[f"{name}/{k}"] = v
+        res = da.split_bregman_tvd(img.copy(), solver=da.Jacobi(maxiter=maxiter), **{k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in kw.items()})
+        out[name + "/img"], out[name + "/out"], out[name + "/maxiter"] = img, res, np.int64(maxiter)
+        meta[name + "_dtype"] = str(res.dtype)
+
+    run_arr("a1_gray_omega", gray, mu=0.1, omega=arr(gray.shape, 0.5, 1.5), max_num_iter=10)
+    run_arr("a2_gray_omega_ell", gray, mu=0.1, omega=arr(gray.shape, 0.5, 1.5), ell=0.4, max_num_iter=10)
+    run_arr("a3_gray_ellarr", gray, mu=0.1, ell=arr(gray.shape, 0.15, 0.6), max_num_iter=10)
+    run_arr("a4_rgb_all", rgb, mu=arr(rgb.shape, 0.02, 0.2), omega=arr(rgb.shape, 0.6, 1.2), ell=arr(rgb.shape, 0.2, 0.5), max_num_iter=8)
+    run_arr("a5_vol_munone", vol, mu=arr(vol.shape, 0.03, 0.2), dim=3, max_num_iter=6)
+    run_arr("a6_gray_omega_m3", gray, maxiter=3, mu=arr(gray.shape, 0.03, 0.2), omega=arr(gray.shape, 0.5, 1.5), ell=0.5, max_num_iter=7)
+    run_arr("a7_vol_ellarr_m2", vol, maxiter=2, mu=0.2, ell=arr(vol.shape, 0.3, 0.8), omega=0.7, dim=3, max_num_iter=5)
+    run_arr("f1_gray_munone_f32", gray, mu=arr(gray.shape, 0.03, 0.2, np.float32), max_num_iter=10)
+    run_arr("f2_rgb_omega_f32", rgb, mu=0.1, omega=arr(rgb.shape, 0.5, 1.5, np.float32), max_num_iter=8)
+    run_arr("f3_gray_all_f32_m2", gray, maxiter=2, mu=arr(gray.shape, 0.02, 0.2, np.float32), omega=arr(gray.shape, 0.6, 1.2, np.float32),
+            ell=arr(gray.shape, 0.2, 0.5, np.float32), max_num_iter=6)
+
     for k, v in meta.items():
         out["meta/" + k] = np.array(v)
     path = os.path.join(HERE, "tvd_np2_generic_golden.npz")

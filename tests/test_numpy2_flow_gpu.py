@@ -104,10 +104,11 @@ def test_native_flow_on_the_same_vectors_at_the_north_star_tolerance(mixed):
         np.testing.assert_allclose(got, ref, rtol=RTOL, atol=ATOL)
         # ... and it is the oracle's float32 ("strict") flow bit for bit, with the weights rounded to float32 first
         bits(got, O.split_bregman_tvd(img, mu=mu, promotion="strict", **MIXED[name]))
-    # ell = None makes ell = 2 mu a float64 ARRAY: no numpy2 pipeline for that, the default call runs natively -- and
-    # agrees with the reference to 2e-7 (ell = 2 mu is the benign regime)
+    # ell = None makes ell = 2 mu a float64 ARRAY: float64 enters the right-hand side (k_rhs_np2_het) -- the default call
+    # is the reference's result bit for bit; the native flow agrees to 2e-7 (ell = 2 mu is the benign regime)
     for name in ("m3_gray_ellnone", "m5_rgb_ellnone"):
-        got = da.split_bregman_tvd(mixed[name + "/img"], mu=mixed[name + "/mu"], max_num_iter=20)
+        bits(da.split_bregman_tvd(mixed[name + "/img"], mu=mixed[name + "/mu"], max_num_iter=20), mixed[name + "/out"])
+        got = da.split_bregman_tvd(mixed[name + "/img"], mu=mixed[name + "/mu"], max_num_iter=20, promotion="native")
         np.testing.assert_allclose(got, mixed[name + "/out"], rtol=RTOL, atol=ATOL)
         assert np.abs(got - mixed[name + "/out"]).max() < 1e-6
 
@@ -256,7 +257,8 @@ def test_large_host_image_takes_the_row_bands_by_default():
 
 
 # ---- float32 images outside the default solve: several Jacobi sweeps, volumes, six channels (three kinds of launches) ----
-from test_oracle_np2_generic_golden import CASES as GENERIC_CASES, H1_CASES, JACOBI_CASES, TOL_CASES, case_kwargs  # noqa: E402
+from test_oracle_np2_generic_golden import (ARRAY_CASES, CASES as GENERIC_CASES, H1_CASES, JACOBI_CASES, TOL_CASES,  # noqa: E402
+                                            array_kwargs, case_kwargs)
 
 
 @pytest.fixture(scope="module")
@@ -369,3 +371,28 @@ def test_h1_regularization_of_float32_images_bit_for_bit_against_the_reference(g
     if c["tol"] is None or img.ndim == c["kw"]["dim"]:
         dev = da.H1_regularization(da.DeviceArray.from_host(img), solver=da.Jacobi(maxiter=c["m"], tol=c["tol"]), **c["kw"])
         bits(dev.get(), generic[name + "/out"])
+
+
+@pytest.mark.parametrize("name", sorted(ARRAY_CASES))
+def test_array_valued_omega_and_ell_bit_for_bit_against_the_reference(generic, name):
+    """float64 arrays (a*): parts of the right-hand side turn float64 (k_rhs_np2_het, the double context's coefficient
+    planes); float32 arrays only (f*): the reference stays float32 throughout and the DEFAULT call takes the native kernels,
+    which are that flow."""
+    kw, m = array_kwargs(generic, name)
+    img = generic[name + "/img"]
+    bits(da.split_bregman_tvd(img, solver=da.Jacobi(maxiter=m), **kw), generic[name + "/out"])
+    bits(da.split_bregman_tvd(img, solver=da.Jacobi(maxiter=m), promotion="numpy2", **kw), generic[name + "/out"])
+    bits(da.split_bregman_tvd(da.DeviceArray.from_host(img), solver=da.Jacobi(maxiter=m), **kw).get(), generic[name + "/out"])
+
+
+def test_mixed_float32_and_float64_coefficient_arrays_take_the_native_flow_and_say_so(caplog):
+    rng = np.random.default_rng(5)
+    img = rng.random((24, 30), dtype=np.float32)
+    mu, ell = 0.05 + 0.1 * rng.random((24, 30)), (0.3 + 0.3 * rng.random((24, 30))).astype(np.float32)
+    with pytest.raises(NotImplementedError, match="numpy2"):
+        da.split_bregman_tvd(img, mu=mu, ell=ell, max_num_iter=3, promotion="numpy2")
+    import logging
+    with caplog.at_level(logging.INFO):
+        out = da.split_bregman_tvd(img, mu=mu, ell=ell, max_num_iter=3)
+    assert "float64 arrays only" in caplog.text
+    np.testing.assert_allclose(out, O.split_bregman_tvd(img, mu=mu, ell=ell, max_num_iter=3, promotion="numpy2"), rtol=RTOL, atol=ATOL)

@@ -99,3 +99,34 @@ def test_oracle_h1_regularization_of_float32_images(generic, name):
     out = O.h1_regularization(generic[name + "/img"], jacobi_maxiter=c["m"], jacobi_tol=c["tol"], promotion="numpy2", **c["kw"])
     ref = generic[name + "/out"]
     assert ref.dtype == np.float32 and out.dtype == np.float32 and np.array_equal(out, ref)
+
+
+ARRAY_CASES = {   # name -> scalar keyword arguments (arrays come from the file)
+    "a1_gray_omega": dict(mu=0.1, max_num_iter=10),
+    "a2_gray_omega_ell": dict(mu=0.1, ell=0.4, max_num_iter=10),
+    "a3_gray_ellarr": dict(mu=0.1, max_num_iter=10),
+    "a4_rgb_all": dict(max_num_iter=8),
+    "a5_vol_munone": dict(dim=3, max_num_iter=6),
+    "a6_gray_omega_m3": dict(ell=0.5, max_num_iter=7),
+    "a7_vol_ellarr_m2": dict(mu=0.2, omega=0.7, dim=3, max_num_iter=5),
+    "f1_gray_munone_f32": dict(max_num_iter=10),
+    "f2_rgb_omega_f32": dict(mu=0.1, max_num_iter=8),
+    "f3_gray_all_f32_m2": dict(max_num_iter=6),
+}
+
+
+def array_kwargs(generic, name):
+    kw = dict(ARRAY_CASES[name])
+    for k in ("mu", "omega", "ell"):
+        if f"{name}/{k}" in generic.files:
+            kw[k] = generic[f"{name}/{k}"]
+    return kw, int(generic[name + "/maxiter"])
+
+
+@pytest.mark.parametrize("name", sorted(ARRAY_CASES))
+def test_oracle_with_array_valued_omega_and_ell(generic, name):
+    kw, m = array_kwargs(generic, name)
+    out = O.split_bregman_tvd(generic[name + "/img"], jacobi_maxiter=m, promotion="numpy2", **kw)
+    assert out.dtype == np.float32 and np.array_equal(out, generic[name + "/out"])
+    if name.startswith("f"):   # float32 arrays only: the reference's flow is float32 throughout -- the same-dtype flow
+        assert np.array_equal(O.split_bregman_tvd(generic[name + "/img"], jacobi_maxiter=m, promotion="strict", **kw), generic[name + "/out"])

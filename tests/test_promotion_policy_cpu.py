@@ -19,9 +19,14 @@ def test_where_the_numpy2_flow_exists():
     assert _why(f32) is None
     assert _why(np.zeros((8, 9, 3), np.float32), mu=np.ones((8, 9, 3))) is None
     assert "float32" in _why(np.zeros((8, 9)))                                   # float64 images run natively (and exactly)
-    assert "scalars" in _why(f32, omega=np.ones((8, 9)))
-    assert "scalars" in _why(f32, ell=np.ones((8, 9)))
-    assert "scalar ell" in _why(f32, mu=np.ones((8, 9)), ell=None)               # ell = 2 mu would be an array
+    assert _why(f32, omega=np.ones((8, 9))) is None                              # float64 arrays: k_rhs_np2_het
+    assert _why(f32, ell=np.ones((8, 9))) is None
+    assert _why(f32, mu=np.ones((8, 9)), ell=None) is None                       # ell = 2 mu is a float64 array
+    assert "float64 arrays only" in _why(f32, mu=np.ones((8, 9)), ell=np.ones((8, 9), np.float32))
+    from darsia_amd.restoration.split_bregman_tvd import native_is_the_reference_flow as nat
+    assert nat(f32, np.ones((8, 9), np.float32), 1.0, None) and nat(f32, 0.1, np.ones((8, 9), np.float32), 1.0)
+    assert not nat(f32, np.ones((8, 9), np.float32), 1.0, 1.0)                   # scalar ell: np.float64 diag_scaled
+    assert not nat(f32, np.ones((8, 9)), 1.0, None) and not nat(np.zeros((8, 9)), np.ones((8, 9), np.float32), 1.0, None)
     assert "anisotropic" in _why(f32, iso=True)
     assert _why(f32, solver=da.Jacobi(maxiter=3)) is None                         # several sweeps: three kinds of launches
     assert _why(f32, solver=da.Jacobi(maxiter=9, tol=1e-3)) is None
