@@ -48,14 +48,28 @@ for case in range(n_cases):
             kw["mu"] = mu if kind == "f64" else mu.astype(np.float32)
         if rng.random() < 0.3:
             kw["eps"] = float(rng.choice([1e-2, 3e-3]))
+        if rng.random() < 0.25:
+            # array-valued omega and / or ell (or ell = 2 mu of an array mu): float64 arrays throughout (k_rhs_np2_het)
+            if np.ndim(kw["mu"]) != 0:
+                kw["mu"] = np.maximum(kw["mu"].astype(np.float64), 0.01)
+            which = rng.choice(["omega", "ell", "both", "ellnone"])
+            if which in ("omega", "both"):
+                kw["omega"] = 0.5 + rng.random(shape)
+            if which in ("ell", "both"):
+                kw["ell"] = 0.2 + 0.8 * rng.random(shape)
+            if which == "ellnone":
+                kw.pop("ell", None)
+                if np.ndim(kw["mu"]) == 0:
+                    kw["mu"] = 0.02 + 0.2 * rng.random(shape)
         # one sweep (the fused pipelines), several, or sweeps with a tolerance (three kinds of launches); now and then six channels
         jm = int(rng.choice([1, 1, 1, 2, 3, 5, 8]))
         tol = float(rng.choice([1e-2, 1e-3])) if (jm > 1 and rng.random() < 0.3) else None
         if rng.random() < 0.1 and c == 0:
             img = np.repeat(img[..., None], 6, axis=2) * rng.random((h, w, 6)).astype(np.float32)
             shape = img.shape
-            if np.ndim(kw["mu"]) != 0:
-                kw["mu"] = np.repeat(kw["mu"][..., None], 6, axis=2)
+            for key in ("mu", "omega", "ell"):
+                if key in kw and np.ndim(kw[key]) != 0:
+                    kw[key] = np.repeat(kw[key][..., None], 6, axis=2)
         ref = O.split_bregman_tvd(img, jacobi_maxiter=jm, jacobi_tol=tol, **kw)   # the reference's NumPy-2 dtype flow
         out = da.split_bregman_tvd(img, promotion="numpy2", solver=da.Jacobi(maxiter=jm, tol=tol), **kw)
         if out.dtype != ref.dtype or not np.array_equal(out, ref):
@@ -63,7 +77,8 @@ for case in range(n_cases):
         if case % 10 == 0:
             # Jacobi.__call__ (float64 out) and H1_regularization (float32 out) on the same image
             sol = da.Jacobi(maxiter=jm, tol=tol)
-            sol.update_params(mass_coeff=kw["omega"], diffusion_coeff=kw["ell"] if "ell" in kw else 0.3, dim=2)
+            sol.update_params(mass_coeff=kw["omega"] if np.ndim(kw["omega"]) == 0 else 0.8,
+                              diffusion_coeff=kw["ell"] if ("ell" in kw and np.ndim(kw["ell"]) == 0) else 0.3, dim=2)
             rhs = (rng.random(img.shape) * scale).astype(np.float32)
             ref = O.jacobi(img, rhs, sol.mass_coeff, sol.diffusion_coeff, dim=2, maxiter=jm, tol=tol)
             out = sol(img, rhs)
