@@ -34,7 +34,7 @@ EXPORTS = (
     "dxh_tvd_energy", "dxh_tvd_adapt_ell", "dxh_tvd_set_base", "dxh_tvd_set_cleaning_filter", "dxh_tvd_upload_signal", "dxh_tvd_download_model", "dxh_tvd_set_base_typed", "dxh_tvd_upload_signal_typed", "dxh_warp_patches_typed", "dxh_phase_correlation",
     "dxh_comm_unique_id", "dxh_comm_create_rccl", "dxh_comm_create_host", "dxh_comm_destroy", "dxh_comm_allreduce",
     "dxh_comm_barrier", "dxh_comm_info", "dxh_tvd_attach_comm", "dxh_tvd_exchange", "dxh_tvd_run_slab",
-    "dxh_mem_alloc", "dxh_mem_free", "dxh_mem_copy", "dxh_sqrt_probe", "dxh_rcp_probe", "dxh_tvd_solve_banded", "dxh_tvd_solve_banded_typed", "dxh_warp_div_probe", "dxh_jacobi_solve_np2", "dxh_mem_trim", "dxh_tps_eval_pair", "dxh_tvd_set_coeffs_typed", "dxh_tvd_slab_stats",
+    "dxh_mem_alloc", "dxh_mem_free", "dxh_mem_copy", "dxh_sqrt_probe", "dxh_rcp_probe", "dxh_tvd_solve_banded", "dxh_tvd_solve_banded_typed", "dxh_warp_div_probe", "dxh_jacobi_solve_np2", "dxh_tvd_upload_warm_np2", "dxh_tvd_download_split_np2", "dxh_mem_trim", "dxh_tps_eval_pair", "dxh_tvd_set_coeffs_typed", "dxh_tvd_slab_stats",
     "dxh_phase_correlation_q", "dxh_scale", "dxh_isofac_probe", "dxh_tvd_set_promotion", "dxh_tvd_upload_typed", "dxh_tvd_download_typed",
 )
 
@@ -148,6 +148,8 @@ def _declare(lib):
     lib.dxh_tvd_adapt_ell.argtypes = [vp]
     lib.dxh_jacobi_solve.argtypes = [i, i, i, i, i, i64, i64, i64, vp, vp, vp, dbl, vp, dbl, vp, dbl, i, dbl,
                                      C.POINTER(i)]
+    lib.dxh_tvd_upload_warm_np2.argtypes = [vp, vp, vp, i, vp, vp]
+    lib.dxh_tvd_download_split_np2.argtypes = [vp, vp, vp]
     lib.dxh_jacobi_solve_np2.argtypes = [i, i, i, i, i64, i64, i64, vp, vp, vp, i, dbl, dbl, dbl, i, dbl, C.POINTER(i)]
     lib.dxh_diff.argtypes = [i, i, i64, i64, i64, i, i, dbl, vp, vp]
     lib.dxh_chambolle.argtypes = [i, i, i, i64, i64, i64, vp, vp, dbl, dbl, i, C.POINTER(i)]

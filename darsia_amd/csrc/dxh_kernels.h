@@ -1740,9 +1740,10 @@ __device__ __forceinline__ void np2_split(double q, double kq, float& d, float& 
 //                       is the double context's own sweep (float64 N(u); rs holds float32 values, which float64 + float32
 //                       -> float64 adds exactly as stored).
 //   k_shrink_np2:       q_j <- D_j u_new + float64(b_j)  with b_j the float32 value re-derived from the stored q_j
-template <int DIM, bool KQARR>
-__global__ void __launch_bounds__(256) k_rhs_np2(Geom g, const double* __restrict__ of, QPlanes<double, DIM> q, Np2Coef k,
-                                                  double* __restrict__ rs) {
+// FROM_DB: the first iteration of a warm start -- d and b are the caller's float32 arrays, held as explicit planes
+template <int DIM, bool KQARR, bool FROM_DB = false>
+__global__ void __launch_bounds__(256) k_rhs_np2(Geom g, const double* __restrict__ of, QPlanes<double, DIM> q, DBPlanes<double> db,
+                                                  Np2Coef k, double* __restrict__ rs) {
     ElemIdx e;
     if (!elem_index(g, e)) return;
     const double kq_c = KQARR ? k.kq_plane[e.off] : k.kq;
@@ -1750,10 +1751,12 @@ __global__ void __launch_bounds__(256) k_rhs_np2(Geom g, const double* __restric
 #pragma unroll
     for (int j = 0; j < DIM; ++j) {
         float d, b;
-        np2_split(q.in[j][e.off], kq_c, d, b);
-        const float tc = k.ell * (b - d);
         const int64_t o = nb_off(g, e, j, -1);
-        np2_split(q.in[j][o], KQARR ? k.kq_plane[o] : k.kq, d, b);
+        if constexpr (FROM_DB) { d = (float)db.d[j][e.off]; b = (float)db.b[j][e.off]; }
+        else np2_split(q.in[j][e.off], kq_c, d, b);
+        const float tc = k.ell * (b - d);
+        if constexpr (FROM_DB) { d = (float)db.d[j][o]; b = (float)db.b[j][o]; }
+        else np2_split(q.in[j][o], KQARR ? k.kq_plane[o] : k.kq, d, b);
         const float tn = k.ell * (b - d);
         r = r + (tc - tn);
     }
@@ -1811,8 +1814,9 @@ __global__ void __launch_bounds__(256) k_rhs_np2_het(Geom g, const double* __res
     rs[e.off] = k.diag_p ? r / k.diag_p[e.off] : (k.rhs64 ? r / k.diag_d : (double)((float)r / k.diag_f));
 }
 
-template <int DIM, bool KQARR>
-__global__ void __launch_bounds__(256) k_shrink_np2(Geom g, const double* __restrict__ unew, QPlanes<double, DIM> q, Np2Coef k) {
+template <int DIM, bool KQARR, bool FROM_DB = false>
+__global__ void __launch_bounds__(256) k_shrink_np2(Geom g, const double* __restrict__ unew, QPlanes<double, DIM> q, DBPlanes<double> db,
+                                                     Np2Coef k) {
     ElemIdx e;
     if (!elem_index(g, e)) return;
     const double kq = KQARR ? k.kq_plane[e.off] : k.kq;
@@ -1820,9 +1824,47 @@ __global__ void __launch_bounds__(256) k_shrink_np2(Geom g, const double* __rest
 #pragma unroll
     for (int j = 0; j < DIM; ++j) {
         float d, b;
-        np2_split(q.in[j][e.off], kq, d, b);
+        if constexpr (FROM_DB) b = (float)db.b[j][e.off];
+        else np2_split(q.in[j][e.off], kq, d, b);
         q.out[j][e.off] = (unew[nb_off(g, e, j, +1)] - uc) + (double)b;
     }
+}
+
+// d, b of a numpy2 context as the reference holds them (float32, (..., dim) interleaved): re-derived from the stored q
+template <int DIM, bool KQARR>
+__global__ void __launch_bounds__(256) k_expand_np2(Geom g, QPlanes<double, DIM> q, Np2Coef k, float* __restrict__ dout,
+                                                     float* __restrict__ bout) {
+    ElemIdx e;
+    if (!elem_index(g, e)) return;
+    const double kq = KQARR ? k.kq_plane[e.off] : k.kq;
+    const int64_t o = (e.row * g.L + e.x) * DIM;  // dense (no pitch)
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+        float d, b;
+        np2_split(q.in[j][e.off], kq, d, b);
+        if (dout) dout[o + j] = d;
+        if (bout) bout[o + j] = b;
+    }
+}
+
+// (..., dim) interleaved arrays of one float type <-> explicit planes of the other
+template <typename TS, typename TD, int DIM>
+__global__ void __launch_bounds__(256) k_deinterleave_cvt(Geom g, const TS* __restrict__ src, TD* p0, TD* p1, TD* p2) {
+    ElemIdx e;
+    if (!elem_index(g, e)) return;
+    const int64_t o = (e.row * g.L + e.x) * DIM;
+    TD* pl[3] = {p0, p1, p2};
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) pl[j][e.off] = (TD)src[o + j];
+}
+template <typename TS, typename TD, int DIM>
+__global__ void __launch_bounds__(256) k_interleave_cvt(Geom g, const TS* p0, const TS* p1, const TS* p2, TD* __restrict__ dst) {
+    ElemIdx e;
+    if (!elem_index(g, e)) return;
+    const int64_t o = (e.row * g.L + e.x) * DIM;
+    const TS* pl[3] = {p0, p1, p2};
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) dst[o + j] = (TD)pl[j][e.off];
 }
 
 template <int C, bool COUPLED, bool KQARR>

@@ -1103,6 +1103,9 @@ static int np2_generic_iteration(Ctx* c, int maxiter, double tol, void* tmp, int
     const dim3 grid = elem_grid(c->g), blk(256);
     const Np2Coef k = np2_coef(c);
     auto q = make_q<double, DIM>(c, in, in);
+    const bool fdb = c->from_db;   // first iteration of a warm start: d, b are explicit planes (float32 values)
+    auto db = make_db<double>(c);
+    if (fdb) DXH_REQUIRE(!c->het || c->het_cdiag, "numpy2 promotion: a warm start needs scalar omega and ell");
     if (c->het && !c->het_cdiag) {   // array-valued omega and / or ell: float64 enters the right-hand side (k_rhs_np2_het)
         Np2Het hk{};
         hk.ell_p = c->ell_is_arr ? (const double*)c->cp_ell : nullptr;
@@ -1115,14 +1118,23 @@ static int np2_generic_iteration(Ctx* c, int maxiter, double tol, void* tmp, int
         hk.rhs64 = c->om_is_arr ? 1 : 0;
         hipLaunchKernelGGL((k_rhs_np2_het<DIM>), grid, blk, 0, c->stream, c->g, (const double*)c->of, q, hk, (double*)c->rs);
     }
-    else if (k.kq_plane) hipLaunchKernelGGL((k_rhs_np2<DIM, true>), grid, blk, 0, c->stream, c->g, (const double*)c->of, q, k, (double*)c->rs);
-    else hipLaunchKernelGGL((k_rhs_np2<DIM, false>), grid, blk, 0, c->stream, c->g, (const double*)c->of, q, k, (double*)c->rs);
+    else if (fdb) {
+        if (k.kq_plane) hipLaunchKernelGGL((k_rhs_np2<DIM, true, true>), grid, blk, 0, c->stream, c->g, (const double*)c->of, q, db, k, (double*)c->rs);
+        else hipLaunchKernelGGL((k_rhs_np2<DIM, false, true>), grid, blk, 0, c->stream, c->g, (const double*)c->of, q, db, k, (double*)c->rs);
+    }
+    else if (k.kq_plane) hipLaunchKernelGGL((k_rhs_np2<DIM, true>), grid, blk, 0, c->stream, c->g, (const double*)c->of, q, db, k, (double*)c->rs);
+    else hipLaunchKernelGGL((k_rhs_np2<DIM, false>), grid, blk, 0, c->stream, c->g, (const double*)c->of, q, db, k, (double*)c->rs);
     ++*launches;
     int swept = 0;
     int rc = jacobi_sweeps<double>(c, maxiter, tol, tmp, launches, &swept, c->np2_first);
     if (rc) return rc;
-    if (k.kq_plane) hipLaunchKernelGGL((k_shrink_np2<DIM, true>), grid, blk, 0, c->stream, c->g, (const double*)c->u[out], q, k);
-    else hipLaunchKernelGGL((k_shrink_np2<DIM, false>), grid, blk, 0, c->stream, c->g, (const double*)c->u[out], q, k);
+    if (fdb) {
+        if (k.kq_plane) hipLaunchKernelGGL((k_shrink_np2<DIM, true, true>), grid, blk, 0, c->stream, c->g, (const double*)c->u[out], q, db, k);
+        else hipLaunchKernelGGL((k_shrink_np2<DIM, false, true>), grid, blk, 0, c->stream, c->g, (const double*)c->u[out], q, db, k);
+    }
+    else if (k.kq_plane) hipLaunchKernelGGL((k_shrink_np2<DIM, true>), grid, blk, 0, c->stream, c->g, (const double*)c->u[out], q, db, k);
+    else hipLaunchKernelGGL((k_shrink_np2<DIM, false>), grid, blk, 0, c->stream, c->g, (const double*)c->u[out], q, db, k);
+    c->from_db = false;
     ++*launches;
     DXH_HIP(hipGetLastError());
     if (swept > 0) c->np2_first = false;   // (a tolerance met by the very first sweep hands back the float32 iterate itself)
@@ -1159,7 +1171,7 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
         // pipelines; everything else (dim = 3, more channels, several sweeps) as three kinds of launches
         DXH_REQUIRE(jacobi_maxiter >= 1 && !c->solver, "numpy2 promotion: Jacobi sweeps only");
         DXH_REQUIRE(!iso, "numpy2 promotion: anisotropic shrinkage only (the reference's isotropic branch is float64-only)");
-        DXH_REQUIRE(!c->from_db && !c->explicit_db && !(flags & DXH_FLAG_EXPLICIT), "numpy2 promotion: no explicit split variables");
+        DXH_REQUIRE(!c->explicit_db && !(flags & DXH_FLAG_EXPLICIT), "numpy2 promotion: no explicit split variables");
         DXH_REQUIRE(!c->het || c->cp_kq, "numpy2 promotion: the coefficient planes are missing");
         if constexpr (!std::is_same<T, double>::value) { set_error("numpy2 promotion needs a float64 context"); return DXH_ESTATE; }
         np2_generic = !(fused_ok && dim == 2 && c->g.n2 >= 1 && c->g.n2 <= 4) || (c->het && !c->het_cdiag);
@@ -1300,7 +1312,7 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
             }
             ++launches;
             c->cur = out;
-        } else if (np2_generic) {
+        } else if (c->np2) {   // np2_generic, or the first iteration of a warm start
             int rc = dim == 2 ? np2_generic_iteration<2>(c, jacobi_maxiter, jacobi_tol, tmp, &launches)
                               : np2_generic_iteration<3>(c, jacobi_maxiter, jacobi_tol, tmp, &launches);
             if (rc) return rc;
@@ -2842,6 +2854,87 @@ int dxh_tvd_upload_typed(dxh_tvd_t h, const void* img, int img_dtype) {
         pool_free(raw);
     }
     return rc;
+}
+
+// Warm start of a numpy2 context (split_bregman_tvd.py:92-96 with float32 arrays): img float32; u0 float32 (the first sweep
+// sums its neighbours in float32, like the image's) or float64, or NULL (= img); d0, b0 float32 (..., dim) arrays, kept as
+// explicit planes for the first iteration.  Host pointers.
+int dxh_tvd_upload_warm_np2(dxh_tvd_t h, const void* img, const void* u0, int u0_dtype, const void* d0, const void* b0) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    DXH_REQUIRE(c && img && d0 && b0, "null argument");
+    DXH_REQUIRE(c->np2, "the context is not in numpy2 promotion");
+    DXH_REQUIRE(!u0 || u0_dtype == DXH_F32 || u0_dtype == DXH_F64, "u0 must be float32 or float64");
+    DXH_REQUIRE(!is_device_ptr(img) && !is_device_ptr(u0) && !is_device_ptr(d0) && !is_device_ptr(b0), "host arrays expected");
+    int rc = dxh_tvd_upload_typed(h, img, DXH_F32);   // of = omega img (float32 product), u = img, planes cleared
+    if (rc) return rc;
+    const int dim = c->desc.dim;
+    const size_t n = (size_t)c->g.n0 * (size_t)c->g.L;
+    const dim3 grid = elem_grid(c->g), blk(256);
+    void* raw = nullptr;
+    DXH_HIP(pool_malloc(&raw, n * (size_t)dim * 4 > n * 8 ? n * (size_t)dim * 4 : n * 8));
+    auto fail = [&](int r) { (void)hipStreamSynchronize(c->stream); pool_free(raw); return r; };
+    if (u0) {
+        if (u0_dtype == DXH_F64) {
+            if ((rc = h2d_plane(c, c->u[0], u0))) return fail(rc);
+            c->np2_first = false;   // a float64 iterate: float64 neighbour sums from the first sweep on
+        } else {
+            if (hipMemcpyAsync(raw, u0, n * 4, hipMemcpyDefault, c->stream) != hipSuccess) { set_error("upload failed"); return fail(DXH_EHIP); }
+            hipLaunchKernelGGL((k_dense_to_plane<float, double>), grid, blk, 0, c->stream, c->g, (const float*)raw, (double*)c->u[0]);
+        }
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+        void** pl = pass == 0 ? c->dpl : c->bpl;
+        for (int j = 0; j < dim; ++j)
+            if ((rc = alloc_plane(c, &pl[j]))) return fail(rc);
+        if (hipMemcpyAsync(raw, pass == 0 ? d0 : b0, n * (size_t)dim * 4, hipMemcpyDefault, c->stream) != hipSuccess) { set_error("upload failed"); return fail(DXH_EHIP); }
+        if (dim == 2) hipLaunchKernelGGL((k_deinterleave_cvt<float, double, 2>), grid, blk, 0, c->stream, c->g, (const float*)raw, (double*)pl[0], (double*)pl[1], (double*)pl[2]);
+        else hipLaunchKernelGGL((k_deinterleave_cvt<float, double, 3>), grid, blk, 0, c->stream, c->g, (const float*)raw, (double*)pl[0], (double*)pl[1], (double*)pl[2]);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { set_error("warm-start upload failed"); return fail(DXH_EHIP); }
+    }
+    c->from_db = true;
+    return fail(DXH_OK);
+}
+
+// d, b of a numpy2 context as float32 (..., dim) host arrays (either may be NULL)
+int dxh_tvd_download_split_np2(dxh_tvd_t h, void* d, void* b) {
+    Ctx* c = reinterpret_cast<Ctx*>(h);
+    DXH_REQUIRE(c, "null context");
+    DXH_REQUIRE(c->np2, "the context is not in numpy2 promotion");
+    if (!c->uploaded) { set_error("nothing to download"); return DXH_ESTATE; }
+    DXH_REQUIRE(!c->het || c->het_cdiag, "numpy2 promotion: split variables are available with scalar omega and ell only");
+    int rc = set_device(c);
+    if (rc) return rc;
+    const int dim = c->desc.dim;
+    const size_t dense = (size_t)c->g.n0 * (size_t)c->g.L * (size_t)dim * 4;
+    const dim3 grid = elem_grid(c->g), blk(256);
+    void *dd = nullptr, *bb = nullptr;
+    if (d) DXH_HIP(pool_malloc(&dd, dense));
+    if (b && pool_malloc(&bb, dense) != hipSuccess) { if (dd) pool_free(dd); set_error("out of device memory"); return DXH_ENOMEM; }
+    if (c->from_db) {   // no iteration has run: the planes as uploaded
+        for (int pass = 0; pass < 2; ++pass) {
+            void* dst = pass == 0 ? dd : bb;
+            if (!dst) continue;
+            void** pl = pass == 0 ? c->dpl : c->bpl;
+            if (dim == 2) hipLaunchKernelGGL((k_interleave_cvt<double, float, 2>), grid, blk, 0, c->stream, c->g, (const double*)pl[0], (const double*)pl[1], (const double*)pl[2], (float*)dst);
+            else hipLaunchKernelGGL((k_interleave_cvt<double, float, 3>), grid, blk, 0, c->stream, c->g, (const double*)pl[0], (const double*)pl[1], (const double*)pl[2], (float*)dst);
+        }
+    } else {
+        const Np2Coef k = np2_coef(c);
+#define DXH_XNP2(DIM_) do { auto q = make_q<double, DIM_>(c, c->cur, c->cur);                                                        \
+        if (k.kq_plane) hipLaunchKernelGGL((k_expand_np2<DIM_, true>), grid, blk, 0, c->stream, c->g, q, k, (float*)dd, (float*)bb);  \
+        else hipLaunchKernelGGL((k_expand_np2<DIM_, false>), grid, blk, 0, c->stream, c->g, q, k, (float*)dd, (float*)bb); } while (0)
+        if (dim == 2) DXH_XNP2(2); else DXH_XNP2(3);
+#undef DXH_XNP2
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && d) e = hipMemcpyAsync(d, dd, dense, hipMemcpyDefault, c->stream);
+    if (e == hipSuccess && b) e = hipMemcpyAsync(b, bb, dense, hipMemcpyDefault, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    else (void)hipStreamSynchronize(c->stream);
+    if (dd) pool_free(dd);
+    if (bb) pool_free(bb);
+    if (e != hipSuccess) { set_error("download failed: %s", hipGetErrorString(e)); return DXH_EHIP; }
+    return DXH_OK;
 }
 
 int dxh_tvd_download_typed(dxh_tvd_t h, void* u, int out_dtype) {

@@ -165,11 +165,26 @@ class DeviceTVD:
 
     def upload(self, img, u0=None, d0=None, b0=None):
         if self.numpy2:
-            if u0 is not None or d0 is not None or b0 is not None:
-                raise NotImplementedError("promotion='numpy2': no warm start")
             if not isinstance(img, DeviceArray):
                 img = np.ascontiguousarray(img, dtype=self.dtype)
             assert tuple(img.shape) == self.shape and img.dtype == self.dtype
+            if u0 is not None or d0 is not None or b0 is not None:
+                # warm start (split_bregman_tvd.py:92-96): float32 d0 / b0 as the function leaves them, u0 float32 / float64
+                if d0 is None or b0 is None or isinstance(img, DeviceArray):
+                    raise NotImplementedError("promotion='numpy2': a warm start needs host arrays img, d0, b0")
+                if np.asarray(d0).dtype != np.float32 or np.asarray(b0).dtype != np.float32:
+                    raise NotImplementedError("promotion='numpy2': a warm start needs float32 d0 / b0")
+                d0c, b0c = np.ascontiguousarray(d0), np.ascontiguousarray(b0)
+                assert d0c.shape == b0c.shape == self.shape + (self.dim,)
+                u0c = None
+                if u0 is not None:
+                    u0c = np.ascontiguousarray(u0)
+                    if u0c.dtype not in (np.float32, np.float64) or u0c.shape != self.shape:
+                        raise NotImplementedError("promotion='numpy2': u0 must be a float32 or float64 array of the image's shape")
+                _lib.check(self.lib.dxh_tvd_upload_warm_np2(self._h, _lib.ptr(img), _lib.ptr(u0c),
+                                                             _lib.dtype_code(u0c.dtype) if u0c is not None else 0,
+                                                             _lib.ptr(d0c), _lib.ptr(b0c)))
+                return
             _lib.check(self.lib.dxh_tvd_upload_typed(self._h, _lib.ptr(img), _lib.dtype_code(self.dtype)))
             return
 
@@ -222,11 +237,14 @@ class DeviceTVD:
         assert tuple(u.shape) == self.shape and u.dtype == self.dtype
         assert isinstance(u, DeviceArray) or u.flags.c_contiguous
         if self.numpy2:
-            if want_split:
-                raise NotImplementedError("promotion='numpy2': the split variables are not downloadable")
             # convert_dtype(img_iter, float32) (split_bregman_tvd.py:177): the float64 iterate rounded to float32
             _lib.check(self.lib.dxh_tvd_download_typed(self._h, _lib.ptr(u), _lib.dtype_code(self.dtype)))
-            return u
+            if not want_split:
+                return u
+            d = np.empty(self.shape + (self.dim,), np.float32)   # the reference's float32 d, b
+            b = np.empty(self.shape + (self.dim,), np.float32)
+            _lib.check(self.lib.dxh_tvd_download_split_np2(self._h, _lib.ptr(d), _lib.ptr(b)))
+            return u, d, b
         if not want_split:
             _lib.check(self.lib.dxh_tvd_download(self._h, _lib.ptr(u), None, None))
             return u
@@ -301,8 +319,18 @@ def numpy2_unsupported(img, mu, omega, ell, dim, x0, isotropic, solver, adaptive
         kinds = {np.asarray(c).dtype for c in (mu, omega, ell) if c is not None and np.ndim(c) != 0}
         if kinds != {np.dtype(np.float64)}:
             return "array-valued omega / ell: float64 arrays only"
-    if x0 is not None or adaptive is not None:
-        return "no warm start or adaptive schedule"
+    if adaptive is not None:
+        return "no adaptive schedule"
+    if x0 is not None:
+        # a warm start in the reference's flow: float32 d0 / b0 (what the function itself leaves in them for a float32
+        # image), u0 float32 or float64, host arrays, scalar omega and ell
+        u0, d0, b0 = x0
+        if isinstance(img, DeviceArray) or any(not isinstance(a, np.ndarray) for a in (u0, d0, b0)):
+            return "a warm start needs host arrays"
+        if d0.dtype != np.float32 or b0.dtype != np.float32 or u0.dtype not in (np.float32, np.float64):
+            return "a warm start needs float32 d0 / b0 and a float32 or float64 u0"
+        if np.ndim(omega) != 0 or (ell is not None and np.ndim(ell) != 0) or (ell is None and np.ndim(mu) != 0):
+            return "a warm start needs scalar omega and ell"
     if isotropic:
         return "anisotropic only (the reference's isotropic branch is float64-only)"
     if not isinstance(solver, Jacobi) or solver.maxiter < 1:
@@ -405,22 +433,31 @@ def split_bregman_tvd(
         # coefficients' fingerprints are the same (in-place edits of a weight array: outside the contract, clear the dict)
         from ..concentration import _fingerprint
 
-        if not quiet:
-            # verbose: one iteration per call so that increment and energy can be printed (debug path, same messages as
-            # split_bregman_tvd.py:103-104,161-167; the energy is evaluated in double from the device planes)
+        if not quiet or x0 is not None:
+            # verbose (one iteration per call so that increment and energy can be printed: the debug path, same messages as
+            # split_bregman_tvd.py:103-104,161-167; the energy is evaluated in double from the device planes) and / or a
+            # warm start (float32 d0 / b0 in, and back into the caller's arrays as the reference leaves them)
             show = (lambda it: verbose) if isinstance(verbose, bool) else (lambda it: verbose > 0 and it % verbose == 0)
             with DeviceTVD(img.shape, img.dtype, dim=dim, device=img.device if on_device else None, promotion="numpy2") as st:
                 st.set_coeffs(mu, omega, ell, img)
-                st.upload(img)
-                print(f"The energy functional starts at {st.energy()}")
-                for it in range(max_num_iter):
-                    r = st.run(1, solver.maxiter, solver.tol, eps=0.0 if eps is None else eps)
-                    if show(it):
-                        print(f"Split Bregman iteration {it} - relative increment: {r.rel_increment}, "
-                              f"energy functional: {st.energy(previous=True)}")
-                    if eps is not None and r.converged:
-                        break
-                return st.download(out=DeviceArray(img.shape, img.dtype, img.device) if on_device else None)
+                st.upload(img, u0, d0, b0)
+                if quiet:
+                    st.run(max_num_iter, solver.maxiter, solver.tol, eps=eps)
+                else:
+                    print(f"The energy functional starts at {st.energy()}")
+                    for it in range(max_num_iter):
+                        r = st.run(1, solver.maxiter, solver.tol, eps=0.0 if eps is None else eps)
+                        if show(it):
+                            print(f"Split Bregman iteration {it} - relative increment: {r.rel_increment}, "
+                                  f"energy functional: {st.energy(previous=True)}")
+                        if eps is not None and r.converged:
+                            break
+                if x0 is None:
+                    return st.download(out=DeviceArray(img.shape, img.dtype, img.device) if on_device else None)
+                u, d, b = st.download(want_split=True)
+                d0[...] = d
+                b0[...] = b
+                return u
         if (not on_device and eps is None and np.ndim(mu) == 0 and max_num_iter >= 1 and img.nbytes >= (32 << 20)
                 and dim == 2 and solver.maxiter == 1 and solver.tol is None and (img.ndim == 2 or img.shape[2] <= 4)):
             # fixed iteration count on a large host image with scalar coefficients: row bands through the device, the

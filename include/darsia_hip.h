@@ -307,6 +307,15 @@ int dxh_tvd_upload_typed(dxh_tvd_t ctx, const void* img, int img_dtype);
 int dxh_tvd_download_typed(dxh_tvd_t ctx, void* u, int out_dtype);
 
 /*
+ * Warm start x0 = (img0, d0, b0) of a numpy2 context (split_bregman_tvd.py:92-96 with float32 arrays): img float32; u0
+ * float32 or float64 (u0_dtype), or NULL for img itself; d0, b0 float32 arrays of shape (*img.shape, dim).  Host pointers.
+ * dxh_tvd_download_split_np2 hands d and b back as the reference leaves them in the caller's arrays (float32; either
+ * pointer may be NULL).  Scalar omega and ell.
+ */
+int dxh_tvd_upload_warm_np2(dxh_tvd_t ctx, const void* img, const void* u0, int u0_dtype, const void* d0, const void* b0);
+int dxh_tvd_download_split_np2(dxh_tvd_t ctx, void* d, void* b);
+
+/*
  * Where the time of a slab context went (diagnostics; no reference counterpart).  Every exchange is bracketed by three
  * events on the stream it runs on: wait_signal_ms sums the time that stream idled until the interface waves of the
  * signalling launch had released their rows (0 for exchanges in plain stream order), exchange_ms the time from there to

@@ -133,6 +133,29 @@ def main():
     run_arr("f3_gray_all_f32_m2", gray, maxiter=2, mu=arr(gray.shape, 0.02, 0.2, np.float32), omega=arr(gray.shape, 0.6, 1.2, np.float32),
             ell=arr(gray.shape, 0.2, 0.5, np.float32), max_num_iter=6)
 
+    # warm starts x0 = (u0, d0, b0): float32 d0 / b0 as a previous call left them (mutated in place by the reference), u0 the
+    # previous float32 result -- or a float64 array (w3); recorded: the inputs of the SECOND call and what it returns / leaves
+    def warm(name, img, first_iters, second_iters, maxiter=1, u0_as=None, **kw):
+        dim = kw.get("dim", 2)
+        d0 = np.zeros(img.shape + (dim,), np.float32)
+        b0 = np.zeros(img.shape + (dim,), np.float32)
+        cp = lambda k: {a: (v.copy() if isinstance(v, np.ndarray) else v) for a, v in k.items()}   # noqa: E731
+        u1 = da.split_bregman_tvd(img.copy(), x0=(img.copy(), d0, b0), solver=da.Jacobi(maxiter=maxiter), max_num_iter=first_iters, **cp(kw))
+        u0 = u1 if u0_as is None else (u1.astype(u0_as) * 1.0009765625).astype(u0_as)
+        for k, v in kw.items():
+            if isinstance(v, np.ndarray):
+                out[f"{name}/{k}"] = v
+        out[name + "/img"], out[name + "/u0"], out[name + "/d0"], out[name + "/b0"] = img, u0.copy(), d0.copy(), b0.copy()
+        res = da.split_bregman_tvd(img.copy(), x0=(u0.copy(), d0, b0), solver=da.Jacobi(maxiter=maxiter), max_num_iter=second_iters, **cp(kw))
+        out[name + "/out"], out[name + "/d"], out[name + "/b"] = res, d0.copy(), b0.copy()
+        out[name + "/maxiter"], out[name + "/iters"] = np.int64(maxiter), np.int64(second_iters)
+        meta[name + "_dtypes"] = f"{res.dtype} {d0.dtype} {u0.dtype}"
+
+    warm("w1_gray", gray, 4, 5, mu=0.1)
+    warm("w2_rgb_muarr_m2", rgb, 3, 4, maxiter=2, mu=arr(rgb.shape, 0.03, 0.2), ell=0.5)
+    warm("w3_vol_u0_f64", vol, 3, 3, u0_as=np.float64, mu=0.2, omega=0.7, ell=0.4, dim=3)
+    warm("w4_gray_one", gray, 2, 1, mu=1.0, ell=0.45)
+
     for k, v in meta.items():
         out["meta/" + k] = np.array(v)
     path = os.path.join(HERE, "tvd_np2_generic_golden.npz")

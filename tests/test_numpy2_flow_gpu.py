@@ -258,7 +258,7 @@ def test_large_host_image_takes_the_row_bands_by_default():
 
 # ---- float32 images outside the default solve: several Jacobi sweeps, volumes, six channels (three kinds of launches) ----
 from test_oracle_np2_generic_golden import (ARRAY_CASES, CASES as GENERIC_CASES, H1_CASES, JACOBI_CASES, TOL_CASES,  # noqa: E402
-                                            array_kwargs, case_kwargs)
+                                            WARM_CASES, array_kwargs, case_kwargs, warm_inputs)
 
 
 @pytest.fixture(scope="module")
@@ -396,3 +396,30 @@ def test_mixed_float32_and_float64_coefficient_arrays_take_the_native_flow_and_s
         out = da.split_bregman_tvd(img, mu=mu, ell=ell, max_num_iter=3)
     assert "float64 arrays only" in caplog.text
     np.testing.assert_allclose(out, O.split_bregman_tvd(img, mu=mu, ell=ell, max_num_iter=3, promotion="numpy2"), rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("name", sorted(WARM_CASES))
+def test_warm_start_bit_for_bit_against_the_reference(generic, name):
+    """x0 = (u0, d0, b0) with the float32 d0 / b0 a previous call left behind: the result AND what the call leaves in the
+    caller's d0 / b0 (the reference updates them in place, split_bregman_tvd.py:92-96,143-146)."""
+    kw, m, n = warm_inputs(generic, name)
+    d0, b0 = generic[name + "/d0"].copy(), generic[name + "/b0"].copy()
+    out = da.split_bregman_tvd(generic[name + "/img"], x0=(generic[name + "/u0"], d0, b0), solver=da.Jacobi(maxiter=m),
+                               max_num_iter=n, **kw)
+    bits(out, generic[name + "/out"])
+    bits(d0, generic[name + "/d"])
+    bits(b0, generic[name + "/b"])
+
+
+def test_two_warm_started_halves_equal_the_reference_chain_and_zero_iterations_change_nothing(generic):
+    img = generic["w1_gray/img"]
+    d0, b0 = np.zeros(img.shape + (2,), np.float32), np.zeros(img.shape + (2,), np.float32)
+    u1 = da.split_bregman_tvd(img, mu=0.1, x0=(img.copy(), d0, b0), max_num_iter=4)
+    bits(u1, generic["w1_gray/u0"])
+    bits(d0, generic["w1_gray/d0"])
+    bits(b0, generic["w1_gray/b0"])
+    d1, b1 = d0.copy(), b0.copy()
+    u2 = da.split_bregman_tvd(img, mu=0.1, x0=(u1, d1, b1), max_num_iter=0)
+    bits(u2, u1)
+    bits(d1, d0)
+    bits(b1, b0)

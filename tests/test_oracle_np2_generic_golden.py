@@ -130,3 +130,30 @@ def test_oracle_with_array_valued_omega_and_ell(generic, name):
     assert out.dtype == np.float32 and np.array_equal(out, generic[name + "/out"])
     if name.startswith("f"):   # float32 arrays only: the reference's flow is float32 throughout -- the same-dtype flow
         assert np.array_equal(O.split_bregman_tvd(generic[name + "/img"], jacobi_maxiter=m, promotion="strict", **kw), generic[name + "/out"])
+
+
+WARM_CASES = {
+    "w1_gray": dict(mu=0.1),
+    "w2_rgb_muarr_m2": dict(ell=0.5),
+    "w3_vol_u0_f64": dict(mu=0.2, omega=0.7, ell=0.4, dim=3),
+    "w4_gray_one": dict(mu=1.0, ell=0.45),
+}
+
+
+def warm_inputs(generic, name):
+    kw = dict(WARM_CASES[name])
+    if f"{name}/mu" in generic.files:
+        kw["mu"] = generic[f"{name}/mu"]
+    return kw, int(generic[name + "/maxiter"]), int(generic[name + "/iters"])
+
+
+@pytest.mark.parametrize("name", sorted(WARM_CASES))
+def test_oracle_warm_start_of_a_float32_image(generic, name):
+    kw, m, n = warm_inputs(generic, name)
+    dim = kw.get("dim", 2)
+    d0, b0 = generic[name + "/d0"], generic[name + "/b0"]
+    x0 = (generic[name + "/u0"], [d0[..., j].copy() for j in range(dim)], [b0[..., j].copy() for j in range(dim)])
+    out, d, b, _ = O.split_bregman_tvd(generic[name + "/img"], x0=x0, jacobi_maxiter=m, max_num_iter=n, promotion="numpy2",
+                                       return_state=True, **kw)
+    assert np.array_equal(out, generic[name + "/out"])
+    assert np.array_equal(np.stack(d, axis=-1), generic[name + "/d"]) and np.array_equal(np.stack(b, axis=-1), generic[name + "/b"])
