@@ -233,6 +233,23 @@ __device__ __forceinline__ double tps_log(double v, const double2* __restrict__ 
     return fma(e, 0.6931471805599453094, t.y + q);
 }
 
+// The same for arguments known to be positive, normal and finite (k_tps_pair clamps r^2 from below; pixel coordinates are
+// finite): no special-case branch, and the exponent becomes a double by assembling 2^52 + ex from its bits and subtracting
+// (one full-rate addition instead of v_cvt_f64_i32).
+__device__ __forceinline__ double tps_log_pos(double v, const double2* __restrict__ tab) {
+    const int hi = __double2hiint(v);
+    const double2 t = tab[(hi >> 13) & (kLogTab - 1)];
+    const double m = __hiloint2double((hi & 0x000fffff) | 0x3ff00000, __double2loint(v));
+    const double r = fma(m, t.x, -1.0);            // |r| <= 2^-8: the series up to r^6 (next term r^7 / 7 < 4e-18)
+    double q = fma(r, -1.0 / 6.0, 1.0 / 5.0);
+    q = fma(q, r, -1.0 / 4.0);
+    q = fma(q, r, 1.0 / 3.0);
+    q = fma(q, r, -0.5);
+    q = fma(q * r, r, r);
+    const double e = __hiloint2double(0x43300000, (int)((unsigned)hi >> 20)) - (4503599627370496.0 + 1023.0);
+    return fma(e, 0.6931471805599453094, t.y + q);
+}
+
 static const double* tps_log_table() {
     static const std::array<double, 2 * kLogTab> tab = [] {
         std::array<double, 2 * kLogTab> t{};
@@ -324,6 +341,9 @@ struct TpsPairArgs {
     double* out;              // (n, 2)
 };
 
+// kTpsPts pixels of one row per thread (n, n + 1, ...: adjacent in x): the centre record comes out of LDS once for all of
+// them and their chains are independent (the loop is bound by dependent double-precision operations)
+constexpr int kTpsPts = 4;
 __global__ void __launch_bounds__(256) k_tps_pair(TpsPairArgs a) {
     extern __shared__ __align__(16) double sm_all[];  // log table, then the centre table
     const double2* ltab = reinterpret_cast<const double2*>(sm_all);
@@ -331,35 +351,49 @@ __global__ void __launch_bounds__(256) k_tps_pair(TpsPairArgs a) {
     for (int i = threadIdx.x; i < 2 * kLogTab; i += blockDim.x) sm_all[i] = a.logtab[i];
     for (int i = threadIdx.x; i < 4 * a.pu; i += blockDim.x) sm[i] = a.table[i];
     __syncthreads();
-    const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= a.n) return;
-    const double x = a.gx0 + a.gsx * (double)(n % a.grid_w);
-    const double y = a.gy0 + a.gsy * (double)(n / a.grid_w);
-    double acc0 = 0.0, acc1 = 0.0;
+    constexpr int P = kTpsPts;
+    const long long n0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * P;
+    if (n0 >= a.n) return;
+    double x[P], y[P], acc0[P], acc1[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        const long long n = n0 + k < a.n ? n0 + k : a.n - 1;
+        x[k] = a.gx0 + a.gsx * (double)(n % a.grid_w);
+        y[k] = a.gy0 + a.gsy * (double)(n / a.grid_w);
+        acc0[k] = acc1[k] = 0.0;
+    }
     const double2* tb = reinterpret_cast<const double2*>(sm);
     {
         // compared with SciPy to a tolerance, not bit for bit: fused multiply-adds are welcome here (the library is built with
-        // -ffp-contract=off for the NumPy-exact kernels), and two centres per trip give the scheduler two independent chains
+        // -ffp-contract=off for the NumPy-exact kernels)
 #pragma clang fp contract(fast)
-#pragma unroll 2
         for (int i = 0; i < a.pu; ++i) {
             const double2 c = tb[2 * i], w = tb[2 * i + 1];
-            const double dx = x - c.x, dy = y - c.y;
-            const double r2 = dx * dx + dy * dy;
-            const double phi = r2 == 0.0 ? 0.0 : 0.5 * r2 * tps_log(r2, ltab);
-            acc0 += phi * w.x;
-            acc1 += phi * w.y;
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                const double dx = x[k] - c.x, dy = y[k] - c.y;
+                const double r2 = dx * dx + dy * dy;
+                // r^2 log r = 0.5 r^2 log r^2, the 0.5 folded into the weights on the host; at a centre (r^2 = 0) the
+                // clamped argument keeps the logarithm finite and the product an exact 0
+                const double phi = r2 * tps_log_pos(fmax(r2, 1e-300), ltab);
+                acc0[k] += phi * w.x;
+                acc1[k] += phi * w.y;
+            }
         }
     }
-    double acc[2] = {acc0, acc1};
 #pragma unroll
-    for (int o = 0; o < 2; ++o) {
-        const double xh = (x - a.shift[o][0]) / a.scale[o][0], yh = (y - a.shift[o][1]) / a.scale[o][1];
-        for (int j = 0; j < 3; ++j)
-            acc[o] += pow(xh, (double)a.powers[o][j][0]) * pow(yh, (double)a.powers[o][j][1]) * a.poly[o][j];
+    for (int k = 0; k < P; ++k) {
+        if (n0 + k >= a.n) break;
+        double acc[2] = {acc0[k], acc1[k]};
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const double xh = (x[k] - a.shift[o][0]) / a.scale[o][0], yh = (y[k] - a.shift[o][1]) / a.scale[o][1];
+            for (int j = 0; j < 3; ++j)
+                acc[o] += pow(xh, (double)a.powers[o][j][0]) * pow(yh, (double)a.powers[o][j][1]) * a.poly[o][j];
+        }
+        a.out[2 * (n0 + k)] = a.out_scale[0] * acc[0];
+        a.out[2 * (n0 + k) + 1] = a.out_scale[1] * acc[1];
     }
-    a.out[2 * n] = a.out_scale[0] * acc[0];
-    a.out[2 * n + 1] = a.out_scale[1] * acc[1];
 }
 
 // ---- affine colour balance -----------------------------------------------------------------------------
@@ -1099,6 +1133,8 @@ int dxh_tps_eval_pair(int device, int p0, const double* centers0, const double* 
         }
     }
     const int pu = (int)(table.size() / 4);
+    // r^2 log r = 0.5 r^2 log r^2: the factor goes into the weights (a power of two: the same bits as multiplying afterwards)
+    for (int i = 0; i < pu; ++i) { table[4 * (size_t)i + 2] *= 0.5; table[4 * (size_t)i + 3] *= 0.5; }
     const size_t smem = sizeof(double) * (2 * (size_t)kLogTab + 4 * (size_t)pu);
     DXH_REQUIRE(smem <= 64 * 1024, "too many centres (%d) for the LDS-resident table", pu);
     HostPrefault pf;  // map the output pages while the device works
@@ -1132,7 +1168,7 @@ int dxh_tps_eval_pair(int device, int p0, const double* centers0, const double* 
     a.gx0 = gx0; a.gy0 = gy0; a.gsx = gsx; a.gsy = gsy;
     a.out_scale[0] = out_scale0; a.out_scale[1] = out_scale1;
     a.out = (double*)dout_;
-    hipLaunchKernelGGL(k_tps_pair, dim3((unsigned)((n + 255) / 256)), dim3(256), smem, d.st, a);
+    hipLaunchKernelGGL(k_tps_pair, dim3((unsigned)(((n + kTpsPts - 1) / kTpsPts + 255) / 256)), dim3(256), smem, d.st, a);
     DXH_HIP(hipGetLastError());
     pf.join();
     if (!out_on_device) DXH_HIP(hipMemcpyAsync(out, dout_, sizeof(double) * 2 * (size_t)n, hipMemcpyDefault, d.st));
