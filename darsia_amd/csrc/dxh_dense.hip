@@ -307,11 +307,15 @@ __global__ void __launch_bounds__(256) k_tps(TpsArgs a) {
             // thin-plate spline r^2 log r = 0.5 r^2 log(r^2): no square root (SciPy evaluates r^2 log r; the two forms
             // differ in the last bits only, tests compare to 1e-10)
             const double r2 = dx * dx + dy * dy;
-            const double phi = r2 == 0.0 ? 0.0 : 0.5 * r2 * tps_log(r2, ltab);
+            // (branch-free logarithm on the clamped argument as in k_tps_pair: exact 0 at a centre, NaN / inf coordinates
+            // still give NaN / inf; the factor 0.5 once at the end -- a power of two, the same bits)
+            const double phi = r2 * tps_log_pos(fmax(r2, 1e-300), ltab);
             acc0 += phi * cf[i * a.dout];
             if (a.dout > 1) acc1 += phi * cf[i * a.dout + 1];
         }
     }
+    acc0 *= 0.5;
+    acc1 *= 0.5;
     const double xh = (x - a.shift[0]) / a.scale[0], yh = (y - a.shift[1]) / a.scale[1];
     for (int j = 0; j < 3; ++j) {
         const double mono = pow(xh, (double)a.powers[j][0]) * pow(yh, (double)a.powers[j][1]);
