@@ -36,9 +36,22 @@ ops = {
     "concentration chambolle": lambda: ca_ch(frames[1]),
     "tps pair / displacement": lambda: reg.displacement(),
     "registration": lambda: reg(frames_gray[1]),
+    # round 3 entry points (the default dtype flow of float32 images and what came with it)
+    "tvd native f32": lambda: da.split_bregman_tvd(img, mu=0.1, max_num_iter=8, promotion="native"),
+    "tvd numpy2 sweeps tol": lambda: da.split_bregman_tvd(img, mu=0.1, max_num_iter=4, solver=da.Jacobi(maxiter=5, tol=1e-3)),
+    "tvd numpy2 volume": lambda: da.split_bregman_tvd(vol, mu=0.1, dim=3, max_num_iter=3, solver=da.Jacobi(maxiter=2)),
+    "tvd numpy2 arrays": lambda: da.split_bregman_tvd(g, mu=mu64, omega=mu64 * 8, max_num_iter=4),
+    "tvd numpy2 warm start": lambda: da.split_bregman_tvd(g, mu=0.1, max_num_iter=3, x0=(g, np.zeros(g.shape + (2,), np.float32), np.zeros(g.shape + (2,), np.float32))),
+    "tvd numpy2 banded": lambda: solve_banded_numpy2(img, 0.1, 1.0, None, 9, nbands=3),
+    "jacobi numpy2": lambda: jac(g, g),
+    "warp patches": lambda: da.PiecewisePerspectiveTransform().find_and_warp(da.Patches(g, [3, 4]), lambda p: np.ones((2, len(p)))),
     "roi extraction": lambda: da.extract_quadrilateral_ROI(img, pts_src=[[5, 4], [4, 590], [880, 592], [890, 3]], shape=(500, 700)),
 }
-from darsia_amd.restoration.split_bregman_tvd import solve_banded
+from darsia_amd.restoration.split_bregman_tvd import solve_banded, solve_banded_numpy2
+vol = synthetic_image(40, 60, 3)[..., 0][:, :, None].repeat(32, axis=2).copy()
+mu64 = np.full(g.shape, 0.1)
+jac = da.Jacobi(maxiter=4)
+jac.update_params(mass_coeff=1.0, diffusion_coeff=0.3, dim=2)
 base = da.OpticalImage(img)
 frames = [da.OpticalImage(np.clip(img + 0.05 * k, 0, 1).astype(np.float32)) for k in range(1, 4)]
 model = da.CombinedModel([da.LinearModel(scaling=2.0, offset=0.0), da.ClipModel(min_value=0.0, max_value=1.0)])
