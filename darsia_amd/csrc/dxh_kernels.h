@@ -1719,6 +1719,7 @@ struct Np2Coef {
     float ell, diag; // weak Python floats meeting float32 arrays
     const double* kq_plane;  // mu / ell per element (float64 array-valued mu), or nullptr
     int first;       // u still holds the float32 image: neighbour sums in float32 (first iteration of a call)
+    const double* ell_plane = nullptr;  // adaptive schedule (explicit d, b): ell per element, float32 values (k_adapt_ell_np2)
 };
 
 // FAST (callers guarantee k >= 0: the scalar threshold of a fused launch): q - clamp(q, -k, k), which is
@@ -1754,10 +1755,10 @@ __global__ void __launch_bounds__(256) k_rhs_np2(Geom g, const double* __restric
         const int64_t o = nb_off(g, e, j, -1);
         if constexpr (FROM_DB) { d = (float)db.d[j][e.off]; b = (float)db.b[j][e.off]; }
         else np2_split(q.in[j][e.off], kq_c, d, b);
-        const float tc = k.ell * (b - d);
+        const float tc = (FROM_DB && k.ell_plane ? (float)k.ell_plane[e.off] : k.ell) * (b - d);
         if constexpr (FROM_DB) { d = (float)db.d[j][o]; b = (float)db.b[j][o]; }
         else np2_split(q.in[j][o], KQARR ? k.kq_plane[o] : k.kq, d, b);
-        const float tn = k.ell * (b - d);
+        const float tn = (FROM_DB && k.ell_plane ? (float)k.ell_plane[o] : k.ell) * (b - d);
         r = r + (tc - tn);
     }
     rs[e.off] = (double)(r / k.diag);
@@ -1828,6 +1829,61 @@ __global__ void __launch_bounds__(256) k_shrink_np2(Geom g, const double* __rest
         else np2_split(q.in[j][e.off], kq, d, b);
         q.out[j][e.off] = (unew[nb_off(g, e, j, +1)] - uc) + (double)b;
     }
+}
+
+// ---- explicit split variables in the numpy2 flow (the adaptive schedule, split_bregman_tvd.py:149-158): d and b are planes
+// of float32 values, the shrinkage writes them, the right-hand side reads them (k_rhs_np2<.., FROM_DB>) ----
+template <int DIM, bool KQARR>
+__global__ void __launch_bounds__(256) k_expand_planes_np2(Geom g, QPlanes<double, DIM> q, Np2Coef k, double* d0, double* d1, double* d2,
+                                                            double* b0, double* b1, double* b2) {
+    ElemIdx e;
+    if (!elem_index(g, e)) return;
+    double* dp[3] = {d0, d1, d2};
+    double* bp[3] = {b0, b1, b2};
+    const double kq = KQARR ? k.kq_plane[e.off] : k.kq;
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+        float d, b;
+        np2_split(q.in[j][e.off], kq, d, b);
+        dp[j][e.off] = (double)d;
+        bp[j][e.off] = (double)b;
+    }
+}
+
+template <int DIM, bool KQARR>
+__global__ void __launch_bounds__(256) k_shrink_db_np2(Geom g, const double* __restrict__ unew, double* d0, double* d1, double* d2,
+                                                        double* b0, double* b1, double* b2, Np2Coef k) {
+    ElemIdx e;
+    if (!elem_index(g, e)) return;
+    double* dp[3] = {d0, d1, d2};
+    double* bp[3] = {b0, b1, b2};
+    const double kq = KQARR ? k.kq_plane[e.off] : k.kq;
+    const double uc = unew[e.off];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+        const double dub = (unew[nb_off(g, e, j, +1)] - uc) + bp[j][e.off];   // float64 + float32
+        float d, b;
+        np2_split(dub, kq, d, b);
+        dp[j][e.off] = (double)d;
+        bp[j][e.off] = (double)b;
+    }
+}
+
+// ell <- 1 / max(|grad u|_1, 1e-12) with grad a float32 array (the float64 differences rounded on assignment), hence ell
+// float32; the threshold mu / ell: Python float / float32 array -> float32, float64 array / float32 array -> float64
+template <int DIM>
+__global__ void __launch_bounds__(256) k_adapt_ell_np2(Geom g, const double* __restrict__ u, double mu_s, const double* __restrict__ mu_p,
+                                                        double* __restrict__ ell_o, double* __restrict__ kq_o) {
+    ElemIdx e;
+    if (!elem_index(g, e)) return;
+    const double uc = u[e.off];
+    float l1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) l1 = l1 + fabsf((float)(u[nb_off(g, e, j, +1)] - uc));
+    const float lo = (float)1e-12;
+    const float ell = 1.0f / (l1 > lo ? l1 : lo);
+    ell_o[e.off] = (double)ell;
+    kq_o[e.off] = mu_p ? mu_p[e.off] / (double)ell : (double)((float)mu_s / ell);
 }
 
 // d, b of a numpy2 context as the reference holds them (float32, (..., dim) interleaved): re-derived from the stored q

@@ -112,6 +112,7 @@ struct Ctx {
     bool np2_first = true;       // u still is the float32 image (first iteration after an upload)
     bool np2_mu_is_kq = false;   // the given mu array already is the threshold mu / ell (float32 quotient, widened)
     bool ell_is_arr = false, om_is_arr = false;   // set_coeffs: ell (given, or 2 mu) / omega is an array
+    bool np2_adapted = false;    // dxh_tvd_adapt_ell on a numpy2 context: cp_ell / cp_kq hold the adapted float32 ell and threshold
 
     // ---- row slab of a distributed problem (dxh_tvd_attach_comm) ----
     Comm* comm = nullptr;
@@ -1046,6 +1047,7 @@ static Np2Coef np2_coef(const Ctx* c) {
     k.diag = (float)c->c_diag;
     k.kq_plane = c->het ? (const double*)c->cp_kq : nullptr;
     k.first = c->np2_first ? 1 : 0;
+    k.ell_plane = c->np2_adapted ? (const double*)c->cp_ell : nullptr;
     return k;
 }
 
@@ -1141,6 +1143,29 @@ static int np2_generic_iteration(Ctx* c, int maxiter, double tol, void* tmp, int
     return DXH_OK;
 }
 
+// numpy2 flow with explicit d, b planes (the adaptive schedule): right-hand side from the planes, sweeps, shrinkage into the planes
+template <int DIM>
+static int np2_explicit_iteration(Ctx* c, int maxiter, double tol, void* tmp, int64_t* launches) {
+    const int in = c->cur, out = c->cur ^ 1;
+    const dim3 grid = elem_grid(c->g), blk(256);
+    const Np2Coef k = np2_coef(c);
+    DXH_REQUIRE(!c->het || c->het_cdiag || c->np2_adapted, "numpy2 promotion: explicit split variables need scalar omega and ell");
+    auto q = make_q<double, DIM>(c, in, in);
+    auto db = make_db<double>(c);
+    if (k.kq_plane) hipLaunchKernelGGL((k_rhs_np2<DIM, true, true>), grid, blk, 0, c->stream, c->g, (const double*)c->of, q, db, k, (double*)c->rs);
+    else hipLaunchKernelGGL((k_rhs_np2<DIM, false, true>), grid, blk, 0, c->stream, c->g, (const double*)c->of, q, db, k, (double*)c->rs);
+    ++*launches;
+    int swept = 0;
+    int rc = jacobi_sweeps<double>(c, maxiter, tol, tmp, launches, &swept, c->np2_first);
+    if (rc) return rc;
+    if (k.kq_plane) hipLaunchKernelGGL((k_shrink_db_np2<DIM, true>), grid, blk, 0, c->stream, c->g, (const double*)c->u[out], (double*)c->dpl[0], (double*)c->dpl[1], (double*)c->dpl[2], (double*)c->bpl[0], (double*)c->bpl[1], (double*)c->bpl[2], k);
+    else hipLaunchKernelGGL((k_shrink_db_np2<DIM, false>), grid, blk, 0, c->stream, c->g, (const double*)c->u[out], (double*)c->dpl[0], (double*)c->dpl[1], (double*)c->dpl[2], (double*)c->bpl[0], (double*)c->bpl[1], (double*)c->bpl[2], k);
+    ++*launches;
+    DXH_HIP(hipGetLastError());
+    if (swept > 0) c->np2_first = false;
+    return DXH_OK;
+}
+
 template <typename T>
 static void launch_any(Ctx* c, int in, int out, bool iso, bool dpp, int K) {
     if (c->np2) {
@@ -1171,7 +1196,6 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
         // pipelines; everything else (dim = 3, more channels, several sweeps) as three kinds of launches
         DXH_REQUIRE(jacobi_maxiter >= 1 && !c->solver, "numpy2 promotion: Jacobi sweeps only");
         DXH_REQUIRE(!iso, "numpy2 promotion: anisotropic shrinkage only (the reference's isotropic branch is float64-only)");
-        DXH_REQUIRE(!c->explicit_db && !(flags & DXH_FLAG_EXPLICIT), "numpy2 promotion: no explicit split variables");
         DXH_REQUIRE(!c->het || c->cp_kq, "numpy2 promotion: the coefficient planes are missing");
         if constexpr (!std::is_same<T, double>::value) { set_error("numpy2 promotion needs a float64 context"); return DXH_ESTATE; }
         np2_generic = !(fused_ok && dim == 2 && c->g.n2 >= 1 && c->g.n2 <= 4) || (c->het && !c->het_cdiag);
@@ -1214,7 +1238,15 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
                 const dim3 grid = elem_grid(c->g), blk(256);
 #define DXH_XP(DIM_, ISO_) hipLaunchKernelGGL((k_expand_planes<T, DIM_, ISO_>), grid, blk, 0, c->stream, c->g, make_q<T, DIM_>(c, c->cur, c->cur), \
         make_coef<T>(c), make_planes<T>(c), (T*)c->dpl[0], (T*)c->dpl[1], (T*)c->dpl[2], (T*)c->bpl[0], (T*)c->bpl[1], (T*)c->bpl[2])
-                if (dim == 2) { if (c->last_iso_prev) DXH_XP(2, true); else DXH_XP(2, false); }
+                if (c->np2) {   // float32 d, b re-derived from the stored q with the reference's operations
+                    const Np2Coef k = np2_coef(c);
+#define DXH_XPN(DIM_) do { auto qq = make_q<double, DIM_>(c, c->cur, c->cur);                                                              \
+        if (k.kq_plane) hipLaunchKernelGGL((k_expand_planes_np2<DIM_, true>), grid, blk, 0, c->stream, c->g, qq, k, (double*)c->dpl[0], (double*)c->dpl[1], (double*)c->dpl[2], (double*)c->bpl[0], (double*)c->bpl[1], (double*)c->bpl[2]);  \
+        else hipLaunchKernelGGL((k_expand_planes_np2<DIM_, false>), grid, blk, 0, c->stream, c->g, qq, k, (double*)c->dpl[0], (double*)c->dpl[1], (double*)c->dpl[2], (double*)c->bpl[0], (double*)c->bpl[1], (double*)c->bpl[2]); } while (0)
+                    if (dim == 2) DXH_XPN(2); else DXH_XPN(3);
+#undef DXH_XPN
+                }
+                else if (dim == 2) { if (c->last_iso_prev) DXH_XP(2, true); else DXH_XP(2, false); }
                 else          { if (c->last_iso_prev) DXH_XP(3, true); else DXH_XP(3, false); }
 #undef DXH_XP
                 DXH_HIP(hipGetLastError());
@@ -1293,6 +1325,11 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
         } else if (fused3d_ok && !c->from_db) {
             launch_fused3d<T>(c, in, out, iso);
             ++launches;
+            c->cur = out;
+        } else if (explicit_mode && c->np2) {
+            int rc = dim == 2 ? np2_explicit_iteration<2>(c, jacobi_maxiter, jacobi_tol, tmp, &launches)
+                              : np2_explicit_iteration<3>(c, jacobi_maxiter, jacobi_tol, tmp, &launches);
+            if (rc) return rc;
             c->cur = out;
         } else if (explicit_mode) {
             // rhs from explicit planes, Jacobi, shrink back into the planes
@@ -1681,6 +1718,7 @@ static int set_coeffs_t(Ctx* c, double mu, const void* mu_arr, double omega, con
     const double h2 = h * h;
     c->het = mu_arr || omega_arr || ell_arr;
     c->ell_is_arr = c->om_is_arr = false;
+    c->np2_adapted = false;
     c->mu_s = mu;
     c->omega_s = omega;
     for (void** p : {&c->in_mu, &c->in_om, &c->in_ell}) {
@@ -2773,6 +2811,28 @@ int dxh_tvd_adapt_ell(dxh_tvd_t h) {
     if (rc) return rc;
     const dim3 grid = elem_grid(c->g), blk(256);
     const bool f32 = c->desc.dtype == DXH_F32;
+    if (c->np2) {
+        // the reference's float32 flow: ell becomes a float32 array, the threshold mu / ell float32 (scalar mu) or float64
+        // (float64 mu array); the Jacobi diagonals keep their cached scalar values (quirk Q3)
+        DXH_REQUIRE(!c->het || c->het_cdiag || c->np2_adapted, "numpy2 promotion: the adaptive schedule needs scalar omega and ell");
+        DXH_REQUIRE(!c->np2_mu_is_kq, "numpy2 promotion: the adaptive schedule needs mu as a scalar or a float64 array");
+        const bool mu_arr = c->het && c->mu_plane;
+        if ((rc = alloc_plane(c, &c->cp_ell)) || (rc = alloc_plane(c, &c->cp_kq))) return rc;
+        if (!c->het) {   // scalar coefficients so far: planes of the same scalars for the kernels that want planes
+            if ((rc = alloc_plane(c, &c->cp_diag)) || (rc = alloc_plane(c, &c->cp_dsc))) return rc;
+            hipLaunchKernelGGL((k_fill_coef<double>), grid, blk, 0, c->stream, c->g, make_coef<double>(c), (double*)c->cp_ell, (double*)c->cp_diag, (double*)c->cp_dsc, (double*)c->cp_kq);
+            DXH_HIP(hipGetLastError());
+        }
+        const void* un = c->u[c->cur];
+        if (c->desc.dim == 2) hipLaunchKernelGGL((k_adapt_ell_np2<2>), grid, blk, 0, c->stream, c->g, (const double*)un, c->mu_s, mu_arr ? (const double*)c->mu_plane : nullptr, (double*)c->cp_ell, (double*)c->cp_kq);
+        else hipLaunchKernelGGL((k_adapt_ell_np2<3>), grid, blk, 0, c->stream, c->g, (const double*)un, c->mu_s, mu_arr ? (const double*)c->mu_plane : nullptr, (double*)c->cp_ell, (double*)c->cp_kq);
+        DXH_HIP(hipGetLastError());
+        c->het = true;
+        c->het_cdiag = false;
+        c->np2_adapted = true;
+        c->in_valid = false;
+        return DXH_OK;
+    }
     if (!c->het) {
         // materialise the four coefficient planes with exactly the scalar path's values
         if ((rc = alloc_plane(c, &c->cp_ell)) || (rc = alloc_plane(c, &c->cp_diag)) || (rc = alloc_plane(c, &c->cp_dsc)) ||
@@ -2901,7 +2961,7 @@ int dxh_tvd_download_split_np2(dxh_tvd_t h, void* d, void* b) {
     DXH_REQUIRE(c, "null context");
     DXH_REQUIRE(c->np2, "the context is not in numpy2 promotion");
     if (!c->uploaded) { set_error("nothing to download"); return DXH_ESTATE; }
-    DXH_REQUIRE(!c->het || c->het_cdiag, "numpy2 promotion: split variables are available with scalar omega and ell only");
+    DXH_REQUIRE(!c->het || c->het_cdiag || c->np2_adapted, "numpy2 promotion: split variables are available with scalar omega and ell only");
     int rc = set_device(c);
     if (rc) return rc;
     const int dim = c->desc.dim;
@@ -2910,7 +2970,7 @@ int dxh_tvd_download_split_np2(dxh_tvd_t h, void* d, void* b) {
     void *dd = nullptr, *bb = nullptr;
     if (d) DXH_HIP(pool_malloc(&dd, dense));
     if (b && pool_malloc(&bb, dense) != hipSuccess) { if (dd) pool_free(dd); set_error("out of device memory"); return DXH_ENOMEM; }
-    if (c->from_db) {   // no iteration has run: the planes as uploaded
+    if (c->from_db || c->explicit_db) {   // explicit planes (a warm start before its first iteration; the adaptive schedule)
         for (int pass = 0; pass < 2; ++pass) {
             void* dst = pass == 0 ? dd : bb;
             if (!dst) continue;

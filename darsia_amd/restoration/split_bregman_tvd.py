@@ -320,7 +320,11 @@ def numpy2_unsupported(img, mu, omega, ell, dim, x0, isotropic, solver, adaptive
         if kinds != {np.dtype(np.float64)}:
             return "array-valued omega / ell: float64 arrays only"
     if adaptive is not None:
-        return "no adaptive schedule"
+        # ell becomes a float32 array (split_bregman_tvd.py:149-158 on a float32 image): explicit float32 d, b on the device
+        if np.ndim(omega) != 0 or (ell is not None and np.ndim(ell) != 0) or (ell is None and np.ndim(mu) != 0):
+            return "the adaptive schedule needs scalar omega and ell"
+        if np.ndim(mu) != 0 and np.asarray(mu).dtype != np.float64:
+            return "the adaptive schedule needs mu as a scalar or a float64 array"
     if x0 is not None:
         # a warm start in the reference's flow: float32 d0 / b0 (what the function itself leaves in them for a float32
         # image), u0 float32 or float64, host arrays, scalar omega and ell
@@ -433,7 +437,7 @@ def split_bregman_tvd(
         # coefficients' fingerprints are the same (in-place edits of a weight array: outside the contract, clear the dict)
         from ..concentration import _fingerprint
 
-        if not quiet or x0 is not None:
+        if not quiet or x0 is not None or adaptive is not None:
             # verbose (one iteration per call so that increment and energy can be printed: the debug path, same messages as
             # split_bregman_tvd.py:103-104,161-167; the energy is evaluated in double from the device planes) and / or a
             # warm start (float32 d0 / b0 in, and back into the caller's arrays as the reference leaves them)
@@ -441,7 +445,21 @@ def split_bregman_tvd(
             with DeviceTVD(img.shape, img.dtype, dim=dim, device=img.device if on_device else None, promotion="numpy2") as st:
                 st.set_coeffs(mu, omega, ell, img)
                 st.upload(img, u0, d0, b0)
-                if quiet:
+                if adaptive is not None:
+                    # the schedule is a host callable: one iteration per call, split variables explicit because the
+                    # threshold changes between the iteration that writes d, b and the one that reads them
+                    if not quiet:
+                        print(f"The energy functional starts at {st.energy()}")
+                    for it in range(max_num_iter):
+                        r = st.run(1, solver.maxiter, solver.tol, eps=0.0 if eps is None else eps, flags=_lib.FLAG_EXPLICIT)
+                        if adaptive(it):
+                            st.adapt_ell()
+                        if not quiet and show(it):
+                            print(f"Split Bregman iteration {it} - relative increment: {r.rel_increment}, "
+                                  f"energy functional: {st.energy(previous=True)}")
+                        if eps is not None and r.converged:
+                            break
+                elif quiet:
                     st.run(max_num_iter, solver.maxiter, solver.tol, eps=eps)
                 else:
                     print(f"The energy functional starts at {st.energy()}")

@@ -156,6 +156,23 @@ def main():
     warm("w3_vol_u0_f64", vol, 3, 3, u0_as=np.float64, mu=0.2, omega=0.7, ell=0.4, dim=3)
     warm("w4_gray_one", gray, 2, 1, mu=1.0, ell=0.45)
 
+    # adaptive regularisation (split_bregman_tvd.py:149-158) on float32 images: ell becomes a float32 array, the Jacobi
+    # diagonals keep their cached values (quirk Q3).  Schedules are recorded as the list of iterations that adapt.
+    def adapt(name, img, when, maxiter=1, **kw):
+        for k, v in kw.items():
+            if isinstance(v, np.ndarray):
+                out[f"{name}/{k}"] = v
+        res = da.split_bregman_tvd(img.copy(), solver=da.Jacobi(maxiter=maxiter), adaptive=lambda it: it in when,
+                                   **{k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in kw.items()})
+        out[name + "/img"], out[name + "/out"] = img, res
+        out[name + "/when"], out[name + "/maxiter"] = np.array(sorted(when), dtype=np.int64), np.int64(maxiter)
+        meta[name + "_dtype"] = str(res.dtype)
+
+    adapt("d1_gray", gray, {1, 3}, mu=0.1, max_num_iter=6)
+    adapt("d2_rgb_muarr", rgb, {0, 2, 3}, mu=arr(rgb.shape, 0.03, 0.2), omega=0.8, ell=0.6, max_num_iter=5)
+    adapt("d3_vol_m2", vol, {1, 2}, maxiter=2, mu=0.2, omega=0.7, ell=0.4, dim=3, max_num_iter=4)
+    adapt("d4_gray_late", gray, {4}, mu=1.0, ell=0.45, max_num_iter=6)
+
     for k, v in meta.items():
         out["meta/" + k] = np.array(v)
     path = os.path.join(HERE, "tvd_np2_generic_golden.npz")

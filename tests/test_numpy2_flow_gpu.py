@@ -258,7 +258,7 @@ def test_large_host_image_takes_the_row_bands_by_default():
 
 # ---- float32 images outside the default solve: several Jacobi sweeps, volumes, six channels (three kinds of launches) ----
 from test_oracle_np2_generic_golden import (ARRAY_CASES, CASES as GENERIC_CASES, H1_CASES, JACOBI_CASES, TOL_CASES,  # noqa: E402
-                                            WARM_CASES, array_kwargs, case_kwargs, warm_inputs)
+                                            WARM_CASES, ADAPT_CASES, adapt_inputs, array_kwargs, case_kwargs, warm_inputs)
 
 
 @pytest.fixture(scope="module")
@@ -423,3 +423,19 @@ def test_two_warm_started_halves_equal_the_reference_chain_and_zero_iterations_c
     bits(u2, u1)
     bits(d1, d0)
     bits(b1, b0)
+
+
+@pytest.mark.parametrize("name", sorted(ADAPT_CASES))
+def test_adaptive_regularisation_bit_for_bit_against_the_reference(generic, name):
+    """adaptive ell on a float32 image (split_bregman_tvd.py:149-158): ell a float32 array, explicit float32 d / b planes on
+    the device (k_rhs_np2<.., FROM_DB>, k_shrink_db_np2, k_adapt_ell_np2)."""
+    kw, m, sched = adapt_inputs(generic, name)
+    bits(da.split_bregman_tvd(generic[name + "/img"], solver=da.Jacobi(maxiter=m), adaptive=sched, **kw), generic[name + "/out"])
+
+
+def test_the_round_one_adaptive_float32_vectors_are_bit_exact_now(golden):
+    """g14_adaptive_f32 / g14_adaptive_rgb_f32: ell = 1 / |grad u| makes the iteration expansive (values reach 1e7), the
+    native float32 flow decorrelates from the reference in a few elements -- the default flow reproduces it bit for bit."""
+    for name, kw, sched in (("g14_adaptive_f32", dict(mu=0.1, max_num_iter=9), lambda it: it % 3 == 1),
+                            ("g14_adaptive_rgb_f32", dict(mu=0.1, omega=0.9, max_num_iter=6), lambda it: it >= 2)):
+        bits(da.split_bregman_tvd(golden[name + "/img"], adaptive=sched, **kw), golden[name + "/out"])

@@ -157,3 +157,26 @@ def test_oracle_warm_start_of_a_float32_image(generic, name):
                                        return_state=True, **kw)
     assert np.array_equal(out, generic[name + "/out"])
     assert np.array_equal(np.stack(d, axis=-1), generic[name + "/d"]) and np.array_equal(np.stack(b, axis=-1), generic[name + "/b"])
+
+
+ADAPT_CASES = {
+    "d1_gray": dict(mu=0.1, max_num_iter=6),
+    "d2_rgb_muarr": dict(omega=0.8, ell=0.6, max_num_iter=5),
+    "d3_vol_m2": dict(mu=0.2, omega=0.7, ell=0.4, dim=3, max_num_iter=4),
+    "d4_gray_late": dict(mu=1.0, ell=0.45, max_num_iter=6),
+}
+
+
+def adapt_inputs(generic, name):
+    kw = dict(ADAPT_CASES[name])
+    if f"{name}/mu" in generic.files:
+        kw["mu"] = generic[f"{name}/mu"]
+    when = set(int(v) for v in generic[name + "/when"])
+    return kw, int(generic[name + "/maxiter"]), (lambda it: it in when)
+
+
+@pytest.mark.parametrize("name", sorted(ADAPT_CASES))
+def test_oracle_adaptive_regularisation_of_float32_images(generic, name):
+    kw, m, sched = adapt_inputs(generic, name)
+    out = O.split_bregman_tvd(generic[name + "/img"], jacobi_maxiter=m, adaptive=sched, promotion="numpy2", **kw)
+    assert out.dtype == np.float32 and np.array_equal(out, generic[name + "/out"])
