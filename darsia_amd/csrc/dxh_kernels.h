@@ -1720,6 +1720,8 @@ struct Np2Coef {
     const double* kq_plane;  // mu / ell per element (float64 array-valued mu), or nullptr
     int first;       // u still holds the float32 image: neighbour sums in float32 (first iteration of a call)
     const double* ell_plane = nullptr;  // adaptive schedule (explicit d, b): ell per element, float32 values (k_adapt_ell_np2)
+    int q32 = 0;     // the stored q was formed in float32 (np2_dub with u32): a scalar threshold then met a float32 array in the
+                     // reference, i.e. its shrinkage ran in float32 arithmetic
 };
 
 // FAST (callers guarantee k >= 0: the scalar threshold of a fused launch): q - clamp(q, -k, k), which is
@@ -1731,6 +1733,18 @@ __device__ __forceinline__ void np2_split(double q, double kq, float& d, float& 
     else d64 = t_max0(fabs(q) - kq) * sgn(q);           // np.maximum(np.abs(x) - k, 0) * np.sign(x), float64
     d = (float)d64;                                       // d[..., j] = ...   (float32 array)
     b = (float)(q - (double)d);                           // b[..., j] = dub - d[..., j]
+}
+
+// d, b from a stored q in the generic kernels: as np2_split, or -- q32 with a scalar threshold -- in float32 arithmetic
+template <bool KQARR>
+__device__ __forceinline__ void np2_split_q(double q, double kq, int q32, float& d, float& b) {
+    if (!KQARR && q32) {
+        const float x = (float)q, kf = (float)kq;
+        d = t_max0(fabsf(x) - kf) * sgn(x);
+        b = x - d;
+    } else {
+        np2_split(q, kq, d, b);
+    }
 }
 
 // ---- the same flow as three kernels (any dim, any shape, several Jacobi sweeps): the generic path of a numpy2 context ----
@@ -1754,10 +1768,10 @@ __global__ void __launch_bounds__(256) k_rhs_np2(Geom g, const double* __restric
         float d, b;
         const int64_t o = nb_off(g, e, j, -1);
         if constexpr (FROM_DB) { d = (float)db.d[j][e.off]; b = (float)db.b[j][e.off]; }
-        else np2_split(q.in[j][e.off], kq_c, d, b);
+        else np2_split_q<KQARR>(q.in[j][e.off], kq_c, k.q32, d, b);
         const float tc = (FROM_DB && k.ell_plane ? (float)k.ell_plane[e.off] : k.ell) * (b - d);
         if constexpr (FROM_DB) { d = (float)db.d[j][o]; b = (float)db.b[j][o]; }
-        else np2_split(q.in[j][o], KQARR ? k.kq_plane[o] : k.kq, d, b);
+        else np2_split_q<KQARR>(q.in[j][o], KQARR ? k.kq_plane[o] : k.kq, k.q32, d, b);
         const float tn = (FROM_DB && k.ell_plane ? (float)k.ell_plane[o] : k.ell) * (b - d);
         r = r + (tc - tn);
     }
@@ -1815,9 +1829,15 @@ __global__ void __launch_bounds__(256) k_rhs_np2_het(Geom g, const double* __res
     rs[e.off] = k.diag_p ? r / k.diag_p[e.off] : (k.rhs64 ? r / k.diag_d : (double)((float)r / k.diag_f));
 }
 
+// u32: the solver handed the float32 iterate itself back (a tolerance met by the very first sweep of a call, jacobi.py:
+// 123-126): the reference's D u + b is a float32 sum then
+__device__ __forceinline__ double np2_dub(double un, double uc, float b, int u32) {
+    return u32 ? (double)(((float)un - (float)uc) + b) : (un - uc) + (double)b;
+}
+
 template <int DIM, bool KQARR, bool FROM_DB = false>
 __global__ void __launch_bounds__(256) k_shrink_np2(Geom g, const double* __restrict__ unew, QPlanes<double, DIM> q, DBPlanes<double> db,
-                                                     Np2Coef k) {
+                                                     Np2Coef k, int u32) {
     ElemIdx e;
     if (!elem_index(g, e)) return;
     const double kq = KQARR ? k.kq_plane[e.off] : k.kq;
@@ -1826,8 +1846,8 @@ __global__ void __launch_bounds__(256) k_shrink_np2(Geom g, const double* __rest
     for (int j = 0; j < DIM; ++j) {
         float d, b;
         if constexpr (FROM_DB) b = (float)db.b[j][e.off];
-        else np2_split(q.in[j][e.off], kq, d, b);
-        q.out[j][e.off] = (unew[nb_off(g, e, j, +1)] - uc) + (double)b;
+        else np2_split_q<KQARR>(q.in[j][e.off], kq, k.q32, d, b);
+        q.out[j][e.off] = np2_dub(unew[nb_off(g, e, j, +1)], uc, b, u32);
     }
 }
 
@@ -1844,7 +1864,7 @@ __global__ void __launch_bounds__(256) k_expand_planes_np2(Geom g, QPlanes<doubl
 #pragma unroll
     for (int j = 0; j < DIM; ++j) {
         float d, b;
-        np2_split(q.in[j][e.off], kq, d, b);
+        np2_split_q<KQARR>(q.in[j][e.off], kq, k.q32, d, b);
         dp[j][e.off] = (double)d;
         bp[j][e.off] = (double)b;
     }
@@ -1852,7 +1872,7 @@ __global__ void __launch_bounds__(256) k_expand_planes_np2(Geom g, QPlanes<doubl
 
 template <int DIM, bool KQARR>
 __global__ void __launch_bounds__(256) k_shrink_db_np2(Geom g, const double* __restrict__ unew, double* d0, double* d1, double* d2,
-                                                        double* b0, double* b1, double* b2, Np2Coef k) {
+                                                        double* b0, double* b1, double* b2, Np2Coef k, int u32) {
     ElemIdx e;
     if (!elem_index(g, e)) return;
     double* dp[3] = {d0, d1, d2};
@@ -1861,9 +1881,15 @@ __global__ void __launch_bounds__(256) k_shrink_db_np2(Geom g, const double* __r
     const double uc = unew[e.off];
 #pragma unroll
     for (int j = 0; j < DIM; ++j) {
-        const double dub = (unew[nb_off(g, e, j, +1)] - uc) + bp[j][e.off];   // float64 + float32
+        const double dub = np2_dub(unew[nb_off(g, e, j, +1)], uc, (float)bp[j][e.off], u32);   // float64 + float32
         float d, b;
-        np2_split(dub, kq, d, b);
+        if (u32 && !KQARR) {   // a float32 dub meets the Python-float threshold: the shrinkage itself is float32 arithmetic
+            const float x = (float)dub, kf = (float)kq;
+            d = t_max0(fabsf(x) - kf) * sgn(x);
+            b = x - d;
+        } else {
+            np2_split(dub, kq, d, b);
+        }
         dp[j][e.off] = (double)d;
         bp[j][e.off] = (double)b;
     }
@@ -1897,7 +1923,7 @@ __global__ void __launch_bounds__(256) k_expand_np2(Geom g, QPlanes<double, DIM>
 #pragma unroll
     for (int j = 0; j < DIM; ++j) {
         float d, b;
-        np2_split(q.in[j][e.off], kq, d, b);
+        np2_split_q<KQARR>(q.in[j][e.off], kq, k.q32, d, b);
         if (dout) dout[o + j] = d;
         if (bout) bout[o + j] = b;
     }

@@ -112,6 +112,7 @@ struct Ctx {
     bool np2_first = true;       // u still is the float32 image (first iteration after an upload)
     bool np2_mu_is_kq = false;   // the given mu array already is the threshold mu / ell (float32 quotient, widened)
     bool ell_is_arr = false, om_is_arr = false;   // set_coeffs: ell (given, or 2 mu) / omega is an array
+    bool np2_q32 = false;        // the stored q was formed in float32 (the solver handed the float32 iterate back): Np2Coef::q32
     bool np2_adapted = false;    // dxh_tvd_adapt_ell on a numpy2 context: cp_ell / cp_kq hold the adapted float32 ell and threshold
 
     // ---- row slab of a distributed problem (dxh_tvd_attach_comm) ----
@@ -1048,6 +1049,7 @@ static Np2Coef np2_coef(const Ctx* c) {
     k.kq_plane = c->het ? (const double*)c->cp_kq : nullptr;
     k.first = c->np2_first ? 1 : 0;
     k.ell_plane = c->np2_adapted ? (const double*)c->cp_ell : nullptr;
+    k.q32 = c->np2_q32 ? 1 : 0;
     return k;
 }
 
@@ -1130,13 +1132,16 @@ static int np2_generic_iteration(Ctx* c, int maxiter, double tol, void* tmp, int
     int swept = 0;
     int rc = jacobi_sweeps<double>(c, maxiter, tol, tmp, launches, &swept, c->np2_first);
     if (rc) return rc;
+    // the solver handed the float32 iterate itself back (tolerance met by the first sweep of a call): float32 D u + b
+    const int u32 = (c->np2_first && swept == 0) ? 1 : 0;
     if (fdb) {
-        if (k.kq_plane) hipLaunchKernelGGL((k_shrink_np2<DIM, true, true>), grid, blk, 0, c->stream, c->g, (const double*)c->u[out], q, db, k);
-        else hipLaunchKernelGGL((k_shrink_np2<DIM, false, true>), grid, blk, 0, c->stream, c->g, (const double*)c->u[out], q, db, k);
+        if (k.kq_plane) hipLaunchKernelGGL((k_shrink_np2<DIM, true, true>), grid, blk, 0, c->stream, c->g, (const double*)c->u[out], q, db, k, u32);
+        else hipLaunchKernelGGL((k_shrink_np2<DIM, false, true>), grid, blk, 0, c->stream, c->g, (const double*)c->u[out], q, db, k, u32);
     }
-    else if (k.kq_plane) hipLaunchKernelGGL((k_shrink_np2<DIM, true>), grid, blk, 0, c->stream, c->g, (const double*)c->u[out], q, db, k);
-    else hipLaunchKernelGGL((k_shrink_np2<DIM, false>), grid, blk, 0, c->stream, c->g, (const double*)c->u[out], q, db, k);
+    else if (k.kq_plane) hipLaunchKernelGGL((k_shrink_np2<DIM, true>), grid, blk, 0, c->stream, c->g, (const double*)c->u[out], q, db, k, u32);
+    else hipLaunchKernelGGL((k_shrink_np2<DIM, false>), grid, blk, 0, c->stream, c->g, (const double*)c->u[out], q, db, k, u32);
     c->from_db = false;
+    c->np2_q32 = u32 != 0;
     ++*launches;
     DXH_HIP(hipGetLastError());
     if (swept > 0) c->np2_first = false;   // (a tolerance met by the very first sweep hands back the float32 iterate itself)
@@ -1158,8 +1163,9 @@ static int np2_explicit_iteration(Ctx* c, int maxiter, double tol, void* tmp, in
     int swept = 0;
     int rc = jacobi_sweeps<double>(c, maxiter, tol, tmp, launches, &swept, c->np2_first);
     if (rc) return rc;
-    if (k.kq_plane) hipLaunchKernelGGL((k_shrink_db_np2<DIM, true>), grid, blk, 0, c->stream, c->g, (const double*)c->u[out], (double*)c->dpl[0], (double*)c->dpl[1], (double*)c->dpl[2], (double*)c->bpl[0], (double*)c->bpl[1], (double*)c->bpl[2], k);
-    else hipLaunchKernelGGL((k_shrink_db_np2<DIM, false>), grid, blk, 0, c->stream, c->g, (const double*)c->u[out], (double*)c->dpl[0], (double*)c->dpl[1], (double*)c->dpl[2], (double*)c->bpl[0], (double*)c->bpl[1], (double*)c->bpl[2], k);
+    const int u32 = (c->np2_first && swept == 0) ? 1 : 0;
+    if (k.kq_plane) hipLaunchKernelGGL((k_shrink_db_np2<DIM, true>), grid, blk, 0, c->stream, c->g, (const double*)c->u[out], (double*)c->dpl[0], (double*)c->dpl[1], (double*)c->dpl[2], (double*)c->bpl[0], (double*)c->bpl[1], (double*)c->bpl[2], k, u32);
+    else hipLaunchKernelGGL((k_shrink_db_np2<DIM, false>), grid, blk, 0, c->stream, c->g, (const double*)c->u[out], (double*)c->dpl[0], (double*)c->dpl[1], (double*)c->dpl[2], (double*)c->bpl[0], (double*)c->bpl[1], (double*)c->bpl[2], k, u32);
     ++*launches;
     DXH_HIP(hipGetLastError());
     if (swept > 0) c->np2_first = false;
@@ -1217,7 +1223,7 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
     const bool explicit_mode = (flags & DXH_FLAG_EXPLICIT) || c->explicit_db;
     const bool fused3d_ok = fused3d_supported(c) && jacobi_maxiter == 1 && !use_tol && !(flags & DXH_FLAG_NO_FUSED) &&
                             !c->solver && !explicit_mode && !c->np2;
-    const bool need_generic = (!fused_ok && !fused3d_ok) || c->from_db;
+    const bool need_generic = (!fused_ok && !fused3d_ok) || c->from_db || c->np2_q32;
     if (need_generic) {
         int rc = alloc_plane(c, &c->rs);
         if (rc) return rc;
@@ -1270,7 +1276,7 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
     if (!async) DXH_HIP(hipEventRecord(c->ev0, c->stream));
     for (int it = 0; it < n_iter; ++it) {
         const int in = c->cur, out = c->cur ^ 1;
-        if (fused_ok && !c->from_db && use_eps && dpp && multi_supported(c) && pick_k(c, n_iter - it) >= 2) {
+        if (fused_ok && !c->from_db && !c->np2_q32 && use_eps && dpp && multi_supported(c) && pick_k(c, n_iter - it) >= 2) {
             // eps with temporal blocking: one launch does K iterations and also reduces every iteration's
             // squared increment; if the test fires at an inner iteration j, the K-iteration result is
             // discarded (the input buffers still hold iteration `it`) and exactly j+1 iterations are redone
@@ -1314,7 +1320,7 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
                 c->cur = a_in;  // the buffer written last
             }
             break;
-        } else if (fused_ok && !c->from_db) {
+        } else if (fused_ok && !c->from_db && !c->np2_q32) {
             // temporal blocking: fuse_k iterations per launch while enough iterations remain and no
             // per-iteration host test is requested
             const int K = (!use_eps && dpp && multi_supported(c)) ? pick_k(c, n_iter - it) : 1;
@@ -2100,6 +2106,7 @@ static int finish_upload(Ctx* c, const void* u0, const void* d0, const void* b0,
                            c->omega_s, om_arr ? (const double*)c->om_plane : nullptr, (double*)c->of);
     DXH_HIP(hipGetLastError());
     c->np2_first = true;
+    c->np2_q32 = false;
     if (c->np2) DXH_REQUIRE(!u0 && !d0, "numpy2 promotion: no warm start");   // (a float64 omega array: a float64 product, the branch above)
     if (u0 && (rc = h2d_plane(c, c->u[0], u0))) return rc;
     if (!c->pristine) {   // a fresh context's planes were cleared when they were allocated

@@ -102,4 +102,11 @@ class Jacobi(Solver):
             int(self.maxiter), -1.0 if self.tol is None else float(self.tol), C.byref(done)))
         if self.verbose:
             print(f"Jacobi: {done.value} of {self.maxiter} sweeps completed.")
+        if done.value == 0 and out_dtype != np.float32:
+            # no sweep was accepted (a tolerance met by the very first one, jacobi.py:123-126): the reference returns x0
+            # itself, a float32 array
+            if on_device:
+                out.close()
+                return src
+            return np.array(src, dtype=np.float32)
         return out

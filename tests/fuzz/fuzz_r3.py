@@ -70,10 +70,30 @@ for case in range(n_cases):
             for key in ("mu", "omega", "ell"):
                 if key in kw and np.ndim(kw[key]) != 0:
                     kw[key] = np.repeat(kw[key][..., None], 6, axis=2)
-        ref = O.split_bregman_tvd(img, jacobi_maxiter=jm, jacobi_tol=tol, **kw)   # the reference's NumPy-2 dtype flow
-        out = da.split_bregman_tvd(img, promotion="numpy2", solver=da.Jacobi(maxiter=jm, tol=tol), **kw)
-        if out.dtype != ref.dtype or not np.array_equal(out, ref):
-            report(f"numpy2 jm={jm} tol={tol}", shape, np.float32, kw, out, ref)
+        # now and then the adaptive schedule (scalar omega / ell, mu a scalar or a float64 array) or a warm start
+        extra = {}
+        scalars = np.ndim(kw["omega"]) == 0 and "ell" in kw and np.ndim(kw["ell"]) == 0
+        if scalars and (np.ndim(kw["mu"]) == 0 or kw["mu"].dtype == np.float64) and rng.random() < 0.15:
+            when = set(int(v) for v in rng.integers(0, kw["max_num_iter"], size=2))
+            extra["adaptive"] = lambda it, when=when: it in when
+        ref = O.split_bregman_tvd(img, jacobi_maxiter=jm, jacobi_tol=tol, **kw, **extra)   # the reference's NumPy-2 dtype flow
+        out = da.split_bregman_tvd(img, promotion="numpy2", solver=da.Jacobi(maxiter=jm, tol=tol), **kw, **extra)
+        if out.dtype != ref.dtype or not np.array_equal(out, ref, equal_nan=True):
+            report(f"numpy2 jm={jm} tol={tol} adaptive={'adaptive' in extra}", shape, np.float32, kw, out, ref)
+        if scalars and not extra and "eps" not in kw and rng.random() < 0.15:
+            # warm start: continue from the state the oracle holds after the run above
+            dim = 2
+            _, dl, bl, _ = O.split_bregman_tvd(img, jacobi_maxiter=jm, jacobi_tol=tol, return_state=True, **kw)
+            kw2 = dict(kw, max_num_iter=int(rng.integers(0, 4)))
+            ref2, dl2, bl2, _ = O.split_bregman_tvd(img, jacobi_maxiter=jm, jacobi_tol=tol, return_state=True,
+                                                    x0=(ref, [a.copy() for a in dl], [a.copy() for a in bl]), **kw2)
+            d0, b0 = np.stack(dl, axis=-1), np.stack(bl, axis=-1)
+            out2 = da.split_bregman_tvd(img, promotion="numpy2", solver=da.Jacobi(maxiter=jm, tol=tol), x0=(ref, d0, b0), **kw2)
+            if not (np.array_equal(out2, ref2) and np.array_equal(d0, np.stack(dl2, axis=-1)) and np.array_equal(b0, np.stack(bl2, axis=-1))):
+                dd = float(np.abs(d0.astype(np.float64) - np.stack(dl2, axis=-1)).max())
+                bb = float(np.abs(b0.astype(np.float64) - np.stack(bl2, axis=-1)).max())
+                report(f"numpy2 warm start jm={jm} tol={tol} scale={scale} |dd|={dd:.3e} |db|={bb:.3e} dtypes {d0.dtype} {dl2[0].dtype}",
+                       shape, np.float32, kw2, out2, ref2)
         if case % 10 == 0:
             # Jacobi.__call__ (float64 out) and H1_regularization (float32 out) on the same image
             sol = da.Jacobi(maxiter=jm, tol=tol)

@@ -439,3 +439,31 @@ def test_the_round_one_adaptive_float32_vectors_are_bit_exact_now(golden):
     for name, kw, sched in (("g14_adaptive_f32", dict(mu=0.1, max_num_iter=9), lambda it: it % 3 == 1),
                             ("g14_adaptive_rgb_f32", dict(mu=0.1, omega=0.9, max_num_iter=6), lambda it: it >= 2)):
         bits(da.split_bregman_tvd(golden[name + "/img"], adaptive=sched, **kw), golden[name + "/out"])
+
+
+def test_a_tolerance_met_by_the_first_sweep_hands_the_float32_iterate_back():
+    """jacobi.py:123-126: the reference returns x0 ITSELF then -- a float32 array -- and the TV loop's D u + b, shrinkage
+    included, runs in float32 for that iteration (the stored q is marked float32-formed: Np2Coef::q32).  Found by the fuzzer."""
+    rng = np.random.default_rng(12)
+    img = rng.random((37, 53, 3), dtype=np.float32)
+    for kw in (dict(mu=0.1, ell=0.3), dict(mu=0.1, ell=0.2, omega=0.7), dict(mu=0.1 + 0.1 * rng.random(img.shape), ell=0.3)):
+        for n in (1, 2, 4):
+            ref = O.split_bregman_tvd(img, max_num_iter=n, jacobi_maxiter=3, jacobi_tol=0.5, promotion="numpy2", **kw)
+            bits(da.split_bregman_tvd(img, max_num_iter=n, solver=da.Jacobi(maxiter=3, tol=0.5), **kw), ref)
+    # warm-started chain through that state, d / b included
+    kw = dict(mu=0.1, ell=0.3)
+    _, dl, bl, _ = O.split_bregman_tvd(img, max_num_iter=2, jacobi_maxiter=3, jacobi_tol=0.5, promotion="numpy2", return_state=True, **kw)
+    u1 = O.split_bregman_tvd(img, max_num_iter=2, jacobi_maxiter=3, jacobi_tol=0.5, promotion="numpy2", **kw)
+    ref2, dl2, bl2, _ = O.split_bregman_tvd(img, max_num_iter=1, jacobi_maxiter=3, jacobi_tol=0.5, promotion="numpy2", return_state=True,
+                                            x0=(u1, [a.copy() for a in dl], [a.copy() for a in bl]), **kw)
+    d0, b0 = np.stack(dl, axis=-1), np.stack(bl, axis=-1)
+    out2 = da.split_bregman_tvd(img, max_num_iter=1, solver=da.Jacobi(maxiter=3, tol=0.5), x0=(u1, d0, b0), **kw)
+    bits(out2, ref2)
+    bits(d0, np.stack(dl2, axis=-1))
+    bits(b0, np.stack(bl2, axis=-1))
+    # the solver alone
+    sol = da.Jacobi(maxiter=5, tol=10.0)
+    sol.update_params(mass_coeff=1.0, diffusion_coeff=0.3, dim=2)
+    x0 = img[..., 0].copy()
+    out = sol(x0, x0)
+    assert out.dtype == np.float32 and np.array_equal(out, x0)
