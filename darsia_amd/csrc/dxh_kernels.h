@@ -2195,10 +2195,13 @@ using IncT = T;
 // coefficients: 3 waves (<= 168 VGPRs; the kernel is VALU-issue bound and a third wave fills issue slots);
 // that budget has no room for the staging registers of a two-step prefetch, and with three waves one step
 // of distance is enough.  double and the array-coefficient pipelines keep 2 waves (they would spill).
-template <typename T, int K, bool HET>
-constexpr int pipe_waves() { return HET ? 2 : (K >= 3 ? (sizeof(T) == 4 ? DXH_LB4 : 2) : 3); }
-template <typename T, int K, bool HET>
-constexpr int pipe_pfd() { return (K >= 4 && pipe_waves<T, K, HET>() <= 2) ? 2 : 1; }
+#ifndef DXH_ISO_WAVES
+#define DXH_ISO_WAVES DXH_LB4   // developer A/B: waves per SIMD of the isotropic float pipelines (K >= 3)
+#endif
+template <typename T, int K, bool HET, bool ISO = false>
+constexpr int pipe_waves() { return HET ? 2 : (K >= 3 ? (sizeof(T) == 4 ? (ISO ? DXH_ISO_WAVES : DXH_LB4) : 2) : 3); }
+template <typename T, int K, bool HET, bool ISO = false>
+constexpr int pipe_pfd() { return (K >= 4 && pipe_waves<T, K, HET, ISO>() <= 2) ? 2 : 1; }
 template <typename T, int K>
 struct PipeState {
     static constexpr int N = VecOf<T>::N;
@@ -2367,7 +2370,7 @@ struct Pipe {
 
     template <int PH, int ROLE = 0, int ACT = K>
     __device__ __forceinline__ void step(PipeState<T, K>& st, IncT<T> (&inc)[NORM ? K : 1][N], const int64_t r) const {
-        constexpr int PFD = ROLE == 0 ? pipe_pfd<T, K, HET>() : 1;  // prefetch distance in steps
+        constexpr int PFD = ROLE == 0 ? pipe_pfd<T, K, HET, ISO>() : 1;  // prefetch distance in steps
         constexpr bool INTRA_LDS = ROLE == 0;               // of / q1 hand-off between own stages through LDS
         // prefetch the level-0 rows of a later step: distance 1 straight into their ring slots, distance 2
         // (K >= 4: a step is long, the registers are there at 2 waves/SIMD; +2.6 % measured) into staging
@@ -2902,7 +2905,7 @@ __device__ __forceinline__ void fused_pipe_body(const FusedArgs<T>& a, const int
         for (int i = 0; i < PipeLds<K>::SLOTS; ++i) pp.lds_put(i, z);
     }
     const int64_t rs = pp.R0 - (K - 1);
-    pipe_prologue<pipe_pfd<T, K, HET>(), ISO, HET, KQV>(pp, st, rs);
+    pipe_prologue<pipe_pfd<T, K, HET, ISO>(), ISO, HET, KQV>(pp, st, rs);
     // the last stage must reach row R1: steps rs .. R1 + K - 1, rounded up to whole groups of 4
     // (extra steps touch clamped rows only and store nothing)
     const int64_t r_end = pp.R1 + (K - 1);
@@ -3066,7 +3069,7 @@ __global__ void __launch_bounds__(256, DXH_PAIR_LB) k_fused_pair(FusedArgs<T> a)
 
 template <typename T, int C, bool COUPLED, bool ISO, int K, bool NORM = false, bool NTS = true, bool HET = false, bool KQV = false,
           bool NP2 = false>
-__global__ void __launch_bounds__(256, (pipe_waves<T, K, HET>())) k_fused_multi(FusedArgs<T> a) {
+__global__ void __launch_bounds__(256, (pipe_waves<T, K, HET, ISO>())) k_fused_multi(FusedArgs<T> a) {
     constexpr int N = VecOf<T>::N;
     using SG = StripGeomK<T, C, K>;
     const int lane = threadIdx.x & (kWave - 1);
