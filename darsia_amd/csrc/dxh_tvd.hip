@@ -979,6 +979,16 @@ static int jacobi_sweeps(Ctx* c, int maxiter, double tol, void* tmp, int64_t* la
     void* bufs[2] = {c->u[out], tmp};
     int w = 0, done = 0;
     bool stop = false;
+    if (!use_tol && tmp) {
+        // without a tolerance the number of passes is known: start in the buffer that makes the last one land in u[out]
+        // (no plane copy at the end; with a tolerance the stop is not known in advance)
+        int left = maxiter, passes = 0;
+        if (first_f32 && left >= 1) { ++passes; --left; }
+        if (left >= 2 && jacobi_multi_supported(c))
+            while (left >= 2) { left -= (left == 5 ? 3 : std::min(4, left)); ++passes; }
+        passes += left;
+        if (passes >= 2 && passes % 2 == 0) w = 1;
+    }
     auto single = [&](bool f32) -> int {
         void* xn = bufs[w];
         if (f32) {
