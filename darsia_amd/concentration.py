@@ -339,16 +339,19 @@ class ConcentrationAnalysis:
             for coef in (rest.weight, rest.omega, rest.regularization):
                 if isinstance(coef, np.ndarray) and coef.ndim > 0 and coef.shape != probe.shape[:2]:
                     return None, "coefficient array of another shape than the frame"
-            # a float32 signal with float64 weights (the workflow's porosity maps): the operator itself would run the
-            # reference's mixed dtype flow (promotion "numpy2", restoration/split_bregman_tvd.py) -- so it runs, as an
-            # operator on the device-resident signal between the two elementwise stages, instead of the context's own
-            # float32 iterations
-            from .restoration.split_bregman_tvd import choose_promotion, numpy2_unsupported
+            # a float32 signal: the operator itself would run the reference's own dtype flow (promotion "numpy2",
+            # restoration/split_bregman_tvd.py) -- the scalar context of the pipeline then IS a numpy2 context (mode "hb2":
+            # the signal is formed in float32 and written into its float64 planes, k_signal<float, .., double>; the model
+            # reads the float64 iterate rounded to float32, k_model<float, double>), the iterations run where the signal lies
+            from .restoration.split_bregman_tvd import choose_promotion, native_is_the_reference_flow, numpy2_unsupported
             sig = np.empty((1, 1), self._signal_dtype(probe, reduction))
             jac = solver if solver is not None else Jacobi()
             why = numpy2_unsupported(sig, rest.weight, rest.omega, rest.regularization, 2, None, iso, jac, None, True)
-            if choose_promotion(rest.kwargs.get("promotion"), sig.dtype, (rest.weight, rest.omega, rest.regularization), why) == "numpy2":
-                mode = "op"
+            want = rest.kwargs.get("promotion")
+            if want in (None, "numpy2") and native_is_the_reference_flow(sig, rest.weight, rest.omega, rest.regularization):
+                want = "native"
+            if choose_promotion(want, sig.dtype, (rest.weight, rest.omega, rest.regularization), why) == "numpy2":
+                mode = "hb2"
         else:
             solver, iso = None, False
         ops = _model_ops(self.model)
@@ -373,9 +376,9 @@ class ConcentrationAnalysis:
             if self._ctxs[slot] is not None:
                 self._ctxs[slot].close()
                 self._ctxs[slot] = None
-            h, w, dts = key
+            h, w, dts = key[:3]
             dt = np.dtype(dts)
-            st = DeviceTVD((h, w), dt, dim=2)
+            st = DeviceTVD((h, w), dt, dim=2, promotion="numpy2" if (len(key) > 3 and key[3] == "numpy2") else "native")
             # the baseline stays in its own float type (probe - baseline is evaluated in NumPy's promotion of the two on the
             # device): a float32 baseline under a float64 cleaning filter is half the bytes, and no host conversion
             base = None
@@ -411,7 +414,7 @@ class ConcentrationAnalysis:
         reduction, channels, ops, solver, iso, mode = plan
         rest = self.restoration
         like = np.empty(st.shape, st.dtype)
-        coefs = (rest.weight, rest.omega, rest.regularization) if mode == "hb" else (1.0, 1.0, None)
+        coefs = (rest.weight, rest.omega, rest.regularization) if mode in ("hb", "hb2") else (1.0, 1.0, None)
         # the coefficients stay in the context from frame to frame: a weight map (porosity) is 128 - 256 MB of upload and
         # three derived planes per frame otherwise.  "Unchanged" = the same objects with the same fingerprint (_fingerprint:
         # in-place edits are outside the contract, refresh() drops the copies)
@@ -443,7 +446,7 @@ class ConcentrationAnalysis:
             signal.close()
             st.upload(restored)
             restored.close()
-        elif mode == "hb":
+        elif mode in ("hb", "hb2"):
             maxiter, tol = (1, None) if solver is None else (solver.maxiter, solver.tol)
             # nothing to read back without stopping criteria: enqueue only, the download below maps the pages of the
             # result array meanwhile
@@ -456,7 +459,7 @@ class ConcentrationAnalysis:
 
     def _device_call(self, probe: np.ndarray, plan) -> np.ndarray:
         dt = self._signal_dtype(probe, plan[0])
-        st = self._ctx_for(0, (probe.shape[0], probe.shape[1], dt.str), plan[1])
+        st = self._ctx_for(0, (probe.shape[0], probe.shape[1], dt.str, "numpy2" if plan[5] == "hb2" else "native"), plan[1])
         self._upload_frame(st, probe, plan)
         return self._finish_frame(st, plan, isinstance(probe, DeviceArray))   # device frame in, device concentration out
 
@@ -501,7 +504,7 @@ class ConcentrationAnalysis:
             return
         dt = self._signal_dtype(cur.img, plan[0])
         shape, channels = cur.img.shape, plan[1]
-        key = (shape[0], shape[1], dt.str)
+        key = (shape[0], shape[1], dt.str, "numpy2" if plan[5] == "hb2" else "native")
         if self._uploader is None:
             self._uploader = ThreadPoolExecutor(max_workers=1, thread_name_prefix="dxh-upload")
         pool = self._uploader

@@ -1187,10 +1187,12 @@ template <> struct SigLoad<unsigned short> {
 // S: stored type of the probe frame, B: of the baseline, T: of the scalar signal (the context).  Difference and reduction run
 // in NumPy's promotion D of probe and baseline; the signal is widened to T where the cleaning filter promotes it
 // (concentrationanalysis.py:328-395).
-template <typename T, int C, typename S, typename B>
+// O: element type of the plane the signal goes into -- T, or double for a float32 signal in a numpy2 context (the reference's
+// float32 flow keeps its iterate in float64 planes; the signal itself is formed in float32 as NumPy does)
+template <typename T, int C, typename S, typename B, typename O = T>
 __global__ void __launch_bounds__(256) k_signal(Geom g, const S* __restrict__ probe, const B* __restrict__ base,
                                                  const T* __restrict__ filt, int option, int reduction, ModelOps pre,
-                                                 T* __restrict__ out) {
+                                                 O* __restrict__ out) {
     using F = typename SigLoad<S>::F;
     using D = std::conditional_t<(sizeof(F) > sizeof(B)), F, B>;
     static_assert(sizeof(T) >= sizeof(D), "the signal cannot be narrower than probe - baseline");
@@ -1225,14 +1227,16 @@ __global__ void __launch_bounds__(256) k_signal(Geom g, const S* __restrict__ pr
     }
     T s = (T)sig;
     if (filt) s = t_max0(s - filt[pix]);  // np.clip(img - filter, 0, None)
-    out[e.off] = apply_model_ops<T>(s, pre);
+    out[e.off] = (O)apply_model_ops<T>(s, pre);
 }
 
-template <typename T>
-__global__ void __launch_bounds__(256) k_model(Geom g, const T* __restrict__ in, ModelOps post, T* __restrict__ out_dense) {
+// I: element type of the plane -- T, or double in a numpy2 context: convert_dtype(img_iter, float32) (split_bregman_tvd.py:177)
+// rounds the float64 iterate first, the model runs on the float32 array
+template <typename T, typename I = T>
+__global__ void __launch_bounds__(256) k_model(Geom g, const I* __restrict__ in, ModelOps post, T* __restrict__ out_dense) {
     ElemIdx e;
     if (!elem_index(g, e)) return;
-    out_dense[e.row * g.L + e.x] = apply_model_ops<T>(in[e.off], post);
+    out_dense[e.row * g.L + e.x] = apply_model_ops<T>((T)in[e.off], post);
 }
 
 // energy functional 0.5 ||omega (x - img)||^2 + sum_j sum |mu D+_j x|  (split_bregman_tvd.py:71-77, verbose only).

@@ -1857,33 +1857,33 @@ __global__ void __launch_bounds__(256) k_plane_to_dense(Geom g, const TS* __rest
 
 namespace {
 // k_signal<T, CH, S, B> for the types the arguments name
-template <typename T, int CH, typename S, typename B>
+template <typename T, int CH, typename S, typename B, typename O = T>
 void launch_signal(Ctx* c, int diff_option, int reduction, const ModelOps& pre) {
-    hipLaunchKernelGGL((k_signal<T, CH, S, B>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const S*)c->probe_buf,
-                       (const B*)c->base_img, (const T*)c->clean_filter, diff_option, reduction, pre, (T*)c->u[0]);
+    hipLaunchKernelGGL((k_signal<T, CH, S, B, O>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const S*)c->probe_buf,
+                       (const B*)c->base_img, (const T*)c->clean_filter, diff_option, reduction, pre, (O*)c->u[0]);
 }
 
-template <typename T, int CH, typename S>
+template <typename T, int CH, typename S, typename O = T>
 int signal_by_base(Ctx* c, int diff_option, int reduction, const ModelOps& pre) {
     using F = typename SigLoad<S>::F;
     // without a baseline B only sizes the difference type: take the probe's own float type
     const int bdt = c->base_img ? c->base_dtype : (sizeof(F) == 4 ? DXH_F32 : DXH_F64);
     if (bdt == DXH_F32) {
-        if constexpr (sizeof(T) >= sizeof(F)) { launch_signal<T, CH, S, float>(c, diff_option, reduction, pre); return DXH_OK; }
+        if constexpr (sizeof(T) >= sizeof(F)) { launch_signal<T, CH, S, float, O>(c, diff_option, reduction, pre); return DXH_OK; }
     } else {
-        if constexpr (sizeof(T) == 8) { launch_signal<T, CH, S, double>(c, diff_option, reduction, pre); return DXH_OK; }
+        if constexpr (sizeof(T) == 8) { launch_signal<T, CH, S, double, O>(c, diff_option, reduction, pre); return DXH_OK; }
     }
     set_error("the context's dtype is narrower than probe - baseline (NumPy would promote to float64)");
     return DXH_EINVAL;
 }
 
-template <typename T, int CH>
+template <typename T, int CH, typename O = T>
 int signal_by_probe(Ctx* c, int probe_dtype, int diff_option, int reduction, const ModelOps& pre) {
     switch (probe_dtype) {
-        case DXH_F32: return signal_by_base<T, CH, float>(c, diff_option, reduction, pre);
-        case DXH_F64: return signal_by_base<T, CH, double>(c, diff_option, reduction, pre);
-        case DXH_U8: return signal_by_base<T, CH, unsigned char>(c, diff_option, reduction, pre);
-        default: return signal_by_base<T, CH, unsigned short>(c, diff_option, reduction, pre);
+        case DXH_F32: return signal_by_base<T, CH, float, O>(c, diff_option, reduction, pre);
+        case DXH_F64: return signal_by_base<T, CH, double, O>(c, diff_option, reduction, pre);
+        case DXH_U8: return signal_by_base<T, CH, unsigned char, O>(c, diff_option, reduction, pre);
+        default: return signal_by_base<T, CH, unsigned short, O>(c, diff_option, reduction, pre);
     }
 }
 }  // namespace
@@ -2220,7 +2220,8 @@ int dxh_tvd_set_cleaning_filter(dxh_tvd_t h, const void* filter) {
     DXH_REQUIRE(c->desc.ndim == 2, "the signal pipeline needs a scalar (H, W) context");
     int rc = set_device(c);
     if (rc) return rc;
-    return set_dense(c, &c->clean_filter, filter, (size_t)c->g.n0 * c->g.L * c->esz);
+    // (numpy2 context: the signal is a float32 array, and so is a filter that leaves it one)
+    return set_dense(c, &c->clean_filter, filter, (size_t)c->g.n0 * c->g.L * (c->np2 ? 4 : c->esz));
 }
 
 int dxh_tvd_upload_signal_typed(dxh_tvd_t h, const void* probe, int probe_dtype, int channels, int diff_option, int reduction,
@@ -2249,7 +2250,10 @@ int dxh_tvd_upload_signal_typed(dxh_tvd_t h, const void* probe, int probe_dtype,
         c->probe_bytes = bytes;
     }
     DXH_HIP(hipMemcpyAsync(c->probe_buf, probe, bytes, hipMemcpyDefault, c->stream));
-    if (c->desc.dtype == DXH_F32)
+    if (c->np2)   // a float32 signal (formed in float32, as NumPy forms it) into the float64 planes of the reference's float32 flow
+        rc = channels == 1 ? signal_by_probe<float, 1, double>(c, probe_dtype, diff_option, reduction, pre)
+                           : signal_by_probe<float, 3, double>(c, probe_dtype, diff_option, reduction, pre);
+    else if (c->desc.dtype == DXH_F32)
         rc = channels == 1 ? signal_by_probe<float, 1>(c, probe_dtype, diff_option, reduction, pre)
                            : signal_by_probe<float, 3>(c, probe_dtype, diff_option, reduction, pre);
     else
@@ -2275,14 +2279,16 @@ int dxh_tvd_download_model(dxh_tvd_t h, void* out, const dxh_model_op* post_ops,
     int rc = to_ops(post_ops, n_post, &post);
     if (rc) return rc;
     if ((rc = set_device(c))) return rc;
-    const size_t dense = (size_t)c->g.n0 * c->g.L * c->esz;
+    const size_t dense = (size_t)c->g.n0 * c->g.L * (c->np2 ? 4 : c->esz);   // numpy2: the float32 array the reference returns
     HostPrefault pf;  // map the output pages while the device works (the iterations may still be running: DXH_FLAG_ASYNC)
     pf.start(out, dense);
     if (!c->stage || dense > (size_t)c->g.n0 * c->g.L * c->desc.dim * c->esz) {
         if (c->stage) { DXH_HIP(hipFree(c->stage)); c->stage = nullptr; }
         DXH_HIP(hipMalloc(&c->stage, (size_t)c->g.n0 * c->g.L * c->desc.dim * c->esz));
     }
-    if (c->desc.dtype == DXH_F32)
+    if (c->np2)
+        hipLaunchKernelGGL((k_model<float, double>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const double*)c->u[c->cur], post, (float*)c->stage);
+    else if (c->desc.dtype == DXH_F32)
         hipLaunchKernelGGL((k_model<float>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const float*)c->u[c->cur], post, (float*)c->stage);
     else
         hipLaunchKernelGGL((k_model<double>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const double*)c->u[c->cur], post, (double*)c->stage);

@@ -77,13 +77,13 @@ def test_concentration_analysis_says_why_a_frame_leaves_the_fused_pipeline():
         ca = da.ConcentrationAnalysis(base, args["signal_reduction"], args["balancing"], args["restoration"], args["model"])
         plan, why = ca._fusable_why(probe)
         assert plan is None and word in why, (word, why)
-    # float32 signal with float64 weights: stays on the device, but as the operator's own numpy2 flow ("op" mode)
+    # float32 signal with float64 weights: the pipeline's scalar context is a numpy2 context then (mode "hb2")
     tvd = da.TVD(method="heterogeneous bregman", weight=np.full((12, 14), 0.1), max_num_iter=3, eps=None)
     plan, why = da.ConcentrationAnalysis(base, red, None, tvd, None)._fusable_why(probe)
-    assert why is None and plan[-1] == "op"
+    assert why is None and plan[-1] == "hb2"
     tvd32 = da.TVD(method="heterogeneous bregman", weight=np.full((12, 14), 0.1, np.float32), max_num_iter=3, eps=None)
     plan, why = da.ConcentrationAnalysis(base, red, None, tvd32, None)._fusable_why(probe)
-    assert why is None and plan[-1] == "op"                     # float32 signal: the reference's flow whatever the weights' type
+    assert why is None and plan[-1] == "hb2"                    # float32 signal: the reference's flow whatever the weights' type
     tvd_native = da.TVD(method="heterogeneous bregman", weight=0.1, max_num_iter=3, eps=None, promotion="native")
     plan, why = da.ConcentrationAnalysis(base, red, None, tvd_native, None)._fusable_why(probe)
     assert why is None and plan[-1] == "hb"                     # asked for: the context's own float32 iterations
