@@ -437,6 +437,12 @@ class ConcentrationAnalysis:
                                                        C.cast(_ops_array(pre), C.c_void_p), len(pre)))
 
     def _finish_frame(self, st: DeviceTVD, plan, on_device: bool = False):
+        self._start_frame(st, plan)
+        return self._fetch_frame(st, plan, on_device)
+
+    def _start_frame(self, st: DeviceTVD, plan) -> None:
+        """The restoration of the frame that is in ``st``: enqueued only where nothing has to be read back (no stopping
+        criteria), so that the caller can fetch the previous frame / send the next one meanwhile (``map``)."""
         reduction, channels, ops, solver, iso, mode = plan
         rest = self.restoration
         if mode == "op":
@@ -452,6 +458,10 @@ class ConcentrationAnalysis:
             # result array meanwhile
             flags = _lib.FLAG_ASYNC if rest.eps is None and tol is None else 0
             st.run(rest.max_num_iter, maxiter, tol, eps=rest.eps, isotropic=iso, flags=flags)
+
+    def _fetch_frame(self, st: DeviceTVD, plan, on_device: bool = False):
+        """The model stage and the way back of the frame whose restoration ``_start_frame`` started."""
+        ops = plan[2]
         post = ops if self.first_restoration_then_model else []
         out = DeviceArray(st.shape, st.dtype, st.device) if on_device else np.empty(st.shape, st.dtype)
         _lib.check(st.lib.dxh_tvd_download_model(st._h, _lib.ptr(out), C.cast(_ops_array(post), C.c_void_p), len(post)))
@@ -515,25 +525,52 @@ class ConcentrationAnalysis:
 
         fut = submit(0, cur)
         try:
+            # Two slots, two schedules (measured on 4000 x 8000 frames, 100 TV iterations; three slots with everything side
+            # by side were slower than either):
+            #  * upload-bound (float32 / float64 colour frames in the native flow: 7 - 15 ms of PCIe per frame): frame k + 1
+            #    goes up while frame k iterates, runs its model stage and comes back;
+            #  * compute-bound (the reference's float32 flow, whose TV stage is 2.3 x longer; frames of few bytes per
+            #    pixel): frame k iterates (enqueued) while frame k - 1 comes back, then frame k + 1 goes up into the slot that
+            #    became free -- results are yielded one frame behind the iterations.
+            bytes_per_pixel = cur.img.dtype.itemsize * (1 if cur.img.ndim == 2 else cur.img.shape[2])
+            late_upload = plan[5] == "hb2" or bytes_per_pixel <= 6
             k = 0
+            pending = None   # (slot, image) of the frame whose iterations have been started but whose result is still on the device
             while cur is not None:
                 fut.result()                                      # frame k is on the device (slot k % 2)
                 fut = None
                 nxt = next(it, None)
                 same = nxt is not None and nxt.img.shape == shape and fusable(nxt) == plan and \
                     self._signal_dtype(nxt.img, plan[0]) == dt
-                if same:
+                if same and not late_upload:
                     fut = submit((k + 1) % 2, nxt)   # overlaps the work on frame k below
-                out = self._finish_frame(self._ctxs[k % 2], plan, isinstance(cur.img, DeviceArray))
-                yield self._wrap(cur, out)
+                self._start_frame(self._ctxs[k % 2], plan)
+                if pending is not None:
+                    out = self._fetch_frame(self._ctxs[pending[0]], plan, isinstance(pending[1].img, DeviceArray))
+                    yield self._wrap(pending[1], out)
+                    pending = None
+                if late_upload:
+                    if same:
+                        fut = submit((k + 1) % 2, nxt)   # into the slot just fetched; overlaps the iterations of frame k
+                    pending = (k % 2, cur)
+                else:
+                    out = self._fetch_frame(self._ctxs[k % 2], plan, isinstance(cur.img, DeviceArray))
+                    yield self._wrap(cur, out)
                 if nxt is not None and not same:
                     # a frame of another kind ends the pipelined stretch
+                    if pending is not None:
+                        out = self._fetch_frame(self._ctxs[pending[0]], plan, isinstance(pending[1].img, DeviceArray))
+                        yield self._wrap(pending[1], out)
+                        pending = None
                     yield self(nxt)
                     for img in it:
                         yield self(img)
                     return
                 cur = nxt
                 k += 1
+            if pending is not None:
+                out = self._fetch_frame(self._ctxs[pending[0]], plan, isinstance(pending[1].img, DeviceArray))
+                yield self._wrap(pending[1], out)
         finally:
             if fut is not None:   # generator abandoned or failed: join the upload in flight
                 try:
