@@ -1734,7 +1734,12 @@ template <bool FAST = false>
 __device__ __forceinline__ void np2_split(double q, double kq, float& d, float& b) {
     double d64;
     if constexpr (FAST) d64 = q - t_clamp_sym(q, kq);
-    else d64 = t_max0(fabs(q) - kq) * sgn(q);           // np.maximum(np.abs(x) - k, 0) * np.sign(x), float64
+    else {
+        // np.maximum(np.abs(x) - k, 0) * np.sign(x), float64 -- NaN included (np.maximum and np.sign hand a NaN on; a
+        // diverged adaptive run reaches inf - inf)
+        const double m = fabs(q) - kq;
+        d64 = (m != m || q != q) ? (m + q) : t_max0(m) * sgn(q);
+    }
     d = (float)d64;                                       // d[..., j] = ...   (float32 array)
     b = (float)(q - (double)d);                           // b[..., j] = dub - d[..., j]
 }
@@ -1744,7 +1749,8 @@ template <bool KQARR>
 __device__ __forceinline__ void np2_split_q(double q, double kq, int q32, float& d, float& b) {
     if (!KQARR && q32) {
         const float x = (float)q, kf = (float)kq;
-        d = t_max0(fabsf(x) - kf) * sgn(x);
+        const float m = fabsf(x) - kf;
+        d = (m != m || x != x) ? (m + x) : t_max0(m) * sgn(x);
         b = x - d;
     } else {
         np2_split(q, kq, d, b);
@@ -1889,7 +1895,8 @@ __global__ void __launch_bounds__(256) k_shrink_db_np2(Geom g, const double* __r
         float d, b;
         if (u32 && !KQARR) {   // a float32 dub meets the Python-float threshold: the shrinkage itself is float32 arithmetic
             const float x = (float)dub, kf = (float)kq;
-            d = t_max0(fabsf(x) - kf) * sgn(x);
+            const float m = fabsf(x) - kf;
+            d = (m != m || x != x) ? (m + x) : t_max0(m) * sgn(x);
             b = x - d;
         } else {
             np2_split(dub, kq, d, b);
@@ -1911,7 +1918,7 @@ __global__ void __launch_bounds__(256) k_adapt_ell_np2(Geom g, const double* __r
 #pragma unroll
     for (int j = 0; j < DIM; ++j) l1 = l1 + fabsf((float)(u[nb_off(g, e, j, +1)] - uc));
     const float lo = (float)1e-12;
-    const float ell = 1.0f / (l1 > lo ? l1 : lo);
+    const float ell = 1.0f / ((l1 > lo || l1 != l1) ? l1 : lo);   // np.maximum hands a NaN on
     ell_o[e.off] = (double)ell;
     kq_o[e.off] = mu_p ? mu_p[e.off] / (double)ell : (double)((float)mu_s / ell);
 }

@@ -19,8 +19,11 @@ t0 = time.time()
 def report(tag, shape, dt, kw, out, ref):
     global bad
     bad += 1
+    o64, r64 = out.astype(np.float64), ref.astype(np.float64)
+    both = np.isfinite(o64) & np.isfinite(r64)
     print("MISMATCH", tag, shape, np.dtype(dt).name, {k: (v if np.ndim(v) == 0 else f"array({v.dtype})") for k, v in kw.items()},
-          "max abs", float(np.abs(out.astype(np.float64) - ref.astype(np.float64)).max()), flush=True)
+          "max abs", float(np.abs(o64 - r64).max()), "| non-finite: device", int((~np.isfinite(o64)).sum()), "oracle", int((~np.isfinite(r64)).sum()),
+          "| max abs where both finite", float(np.abs(o64 - r64)[both].max()) if both.any() else 0.0, flush=True)
 
 
 for case in range(n_cases):
