@@ -360,6 +360,27 @@ def init_from_env(device: Optional[int] = None, rehearsal_base_port: Optional[in
     return Comm.rccl(rank, world, dev), rank, world, dev
 
 
+def slab_promotion(promotion: Optional[str], dtype, mu, omega, ell, dim: int, jacobi_maxiter: int, isotropic: bool) -> str:
+    """The dtype flow a slab run takes -- ``split_bregman_tvd``'s policy (``choose_promotion``) with what the slab path of
+    the numpy2 flow covers (``dxh_tvd_run_slab``: dim = 2, one Jacobi sweep, anisotropic, scalar omega and ell; mu a
+    scalar or a float64 array)."""
+    from .restoration.split_bregman_tvd import choose_promotion
+
+    why_not = None
+    if np.dtype(dtype) != np.float32:
+        why_not = "the image is not float32"
+    elif dim != 2 or jacobi_maxiter != 1 or isotropic:
+        why_not = "row slabs: dim = 2, one Jacobi sweep, anisotropic only"
+    elif np.ndim(omega) != 0 or (ell is not None and np.ndim(ell) != 0) or (ell is None and np.ndim(mu) != 0):
+        why_not = "row slabs: scalar omega and ell only"
+    elif np.ndim(mu) != 0 and np.asarray(mu).dtype != np.float64:
+        why_not = "row slabs: mu a scalar or a float64 array"
+    chosen = choose_promotion(promotion, dtype, (mu, omega, ell), why_not)
+    if chosen == "numpy2" and why_not is not None:
+        raise NotImplementedError(f"promotion='numpy2' on row slabs: {why_not}")
+    return chosen
+
+
 # ---- engines ---------------------------------------------------------------------------------------------------------
 class HipSlabEngine:
     """The product engine: one ``DeviceTVD`` context per rank with a communicator attached; the whole round loop
@@ -417,7 +438,7 @@ class SlabTVD:
     def __init__(self, plan: SlabPlan, slab_img: np.ndarray, mu=1.0, omega=1.0, ell=None, dim: int = 2,
                  halo_iters: int = 1, jacobi_maxiter: int = 1, isotropic: bool = False, engine_factory=None,
                  comm: Optional[Comm] = None, transport=None, device: Optional[int] = None, flags: int = 0,
-                 promotion: str = "native"):
+                 promotion: Optional[str] = None):
         self.plan = plan
         self.k = int(halo_iters)
         self.m = int(jacobi_maxiter)
@@ -444,8 +465,11 @@ class SlabTVD:
                 raise ValueError("communicator and plan disagree on rank / world")
             if device is None:
                 device = comm.device
-            # promotion="numpy2": the reference's own float32 dtype flow (restoration/split_bregman_tvd.py) on every slab
-            self.engine = HipSlabEngine(slab_img, dim, mu, omega, ell, boundary, device, comm, plan, promotion)
+            # the dtype flow of a float32 image follows split_bregman_tvd's policy: an explicit ``promotion`` wins, then
+            # DXH_PROMOTION, then the reference's own flow ("numpy2", restoration/split_bregman_tvd.py under NumPy >= 2)
+            # wherever the slab path has it, the native float32 flow otherwise (the log says why)
+            self.promotion = slab_promotion(promotion, slab_img.dtype, mu, omega, ell, dim, self.m, isotropic)
+            self.engine = HipSlabEngine(slab_img, dim, mu, omega, ell, boundary, device, comm, plan, self.promotion)
         else:
             if plan.world > 1 and transport is None:
                 raise ValueError("an injected engine needs a host transport")

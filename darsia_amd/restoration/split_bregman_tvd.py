@@ -476,11 +476,12 @@ def split_bregman_tvd(
                 d0[...] = d
                 b0[...] = b
                 return u
-        if (not on_device and eps is None and np.ndim(mu) == 0 and max_num_iter >= 1 and img.nbytes >= (32 << 20)
+        if (not on_device and eps is None and np.ndim(mu) == 0 and np.ndim(omega) == 0 and (ell is None or np.ndim(ell) == 0)
+                and max_num_iter >= 1 and img.nbytes >= (32 << 20)
                 and dim == 2 and solver.maxiter == 1 and solver.tol is None and (img.ndim == 2 or img.shape[2] <= 4)):
             # fixed iteration count on a large host image with scalar coefficients: row bands through the device, the
-            # transfers overlapped with the iterations (bit-identical to the one-piece run below; an array-valued mu stays
-            # with the kept context, whose weight planes need not cross PCIe again)
+            # transfers overlapped with the iterations (bit-identical to the one-piece run below; array-valued mu / omega /
+            # ell stay with the kept context, whose coefficient planes need not cross PCIe again)
             return solve_banded_numpy2(img, mu, omega, ell, max_num_iter)
         device = img.device if on_device else _lib.default_device()
         key = (tuple(img.shape), device, dim)

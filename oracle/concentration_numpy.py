@@ -45,8 +45,10 @@ def reduce(img, color):
     raise ValueError(color)
 
 
-def concentration(img, base, option, color, cleaning_filter, model, tvd_kwargs, restoration_first):
-    """model: list of callables applied in order; tvd_kwargs: None or kwargs of tvd_numpy.split_bregman_tvd."""
+def concentration(img, base, option, color, cleaning_filter, model, tvd_kwargs, restoration_first, promotion="strict"):
+    """model: list of callables applied in order; tvd_kwargs: None or kwargs of tvd_numpy.split_bregman_tvd.
+    ``promotion``: the dtype flow of the TV stage on a float32 signal -- "strict" is the reference under NumPy < 2 (what the
+    class's golden vectors were made with), "numpy2" the reference under NumPy >= 2 (tvd_numpy's docstring)."""
     signal = reduce(diff(img, base, option), color)
     if cleaning_filter is not None:
         signal = np.clip(signal - cleaning_filter, 0, None)
@@ -57,6 +59,6 @@ def concentration(img, base, option, color, cleaning_filter, model, tvd_kwargs, 
         return x
 
     def restore(x):
-        return x if tvd_kwargs is None else tvd_numpy.split_bregman_tvd(np.ascontiguousarray(x), promotion="strict", **tvd_kwargs)
+        return x if tvd_kwargs is None else tvd_numpy.split_bregman_tvd(np.ascontiguousarray(x), promotion=promotion, **tvd_kwargs)
 
     return apply_model(restore(signal)) if restoration_first else restore(apply_model(signal))

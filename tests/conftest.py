@@ -15,13 +15,15 @@ def pytest_configure(config):
 
 @pytest.fixture(autouse=True)
 def _dtype_flow_of_the_module(request, monkeypatch):
-    """Most modules of this suite pin the NATIVE float32 kernels against the oracle's same-dtype ("strict") flow, bit for bit:
-    they run with DXH_PROMOTION=native, the documented switch for that flow.  Modules that pin the product's DEFAULT --
-    the reference's own float32 dtype flow, promotion "numpy2" -- say ``DEFAULT_DTYPE_FLOW = True`` and run without it."""
-    if getattr(request.module, "DEFAULT_DTYPE_FLOW", False):
-        monkeypatch.delenv("DXH_PROMOTION", raising=False)
-    else:
+    """The suite runs in the flow a user of the drop-in API gets: the product's DEFAULT (the reference's own float32 dtype
+    flow under NumPy >= 2, promotion "numpy2", wherever it exists) -- no DXH_PROMOTION in the environment.  Modules that pin
+    the NATIVE float32 kernels (the reference's arithmetic under NumPy < 2, what bench.py's headline times) against the
+    oracle's same-dtype ("strict") flow or the NumPy-1.26 goldens say ``NATIVE_DTYPE_FLOW = True`` and run with
+    DXH_PROMOTION=native, the documented switch for that flow."""
+    if getattr(request.module, "NATIVE_DTYPE_FLOW", False):
         monkeypatch.setenv("DXH_PROMOTION", "native")
+    else:
+        monkeypatch.delenv("DXH_PROMOTION", raising=False)
 
 
 @pytest.fixture(scope="session")

@@ -37,9 +37,26 @@ def test_single_gpu_line_has_contract_fields():
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1.5
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1
     assert "workload" in d["config"]
-    # for the record next to `value` (the native float32 flow): the same workload in the default dtype flow of float32 images
-    # (at this launch-bound test size the two flows take about the same time; at the benchmark size native is 2.5 x faster)
-    assert d["reference_dtype_flow"]["promotion"] == "numpy2" and 0 < d["reference_dtype_flow"]["value"] < 2 * d["value"]
+    assert d["config"]["dtype_flow"] == "native" and "native float32 flow" in d["config"]["workload"]
+    assert "NumPy" in d["cpu_baseline"]["sample"]
+    # next to `value` (the native float32 flow): the same workload in the default dtype flow of float32 images, timed over the
+    # same steps, with its own roofline block and the same K = 1 replay self-check
+    # (at this launch-bound test size the two flows take about the same time; at the benchmark size native is ~2 x faster)
+    o = d["other_flow"]
+    assert o["promotion"] == "numpy2" and 0 < o["value"] < 2 * d["value"] and o["steps"] == 2
+    assert o["roofline"]["bound"] == "hbm" and 0 < o["roofline"]["frac"] < 1.5 and "NP2" in o["roofline"]["kernel"]
+    assert o["roofline"]["algorithmic_bytes_per_launch"] > d["roofline"]["algorithmic_bytes_per_launch"]
+    assert d["self_check"]["bit_identical_to_k1_replay"] is True and o["self_check"]["bit_identical_to_k1_replay"] is True
+    assert d["self_check"]["sha256_of_result"] != o["self_check"]["sha256_of_result"]
+
+
+def test_single_gpu_line_in_the_default_flow():
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "1", "--height", "256", "--width", "512",
+                        "--iters", "12", "--promotion", "numpy2", "--one-flow", "--no-cpu-baseline"], cwd=ROOT,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _last_json(r.stdout)
+    assert d["config"]["dtype_flow"] == "numpy2" and "other_flow" not in d and d["dtype"].startswith("f32/f64")
     assert d["self_check"]["bit_identical_to_k1_replay"] is True
 
 
@@ -63,6 +80,11 @@ def test_two_rank_rehearsal_runs_the_slab_path():
     # every rank compared its rows with a single-GPU replay of all iterations on the whole image
     assert d["self_check"] == {"iterations": 48, "ranks_bit_identical_to_single_gpu_replay": 2, "ranks": 2,
                                "max_abs_difference": 0.0}
+    # the slab alone (no exchange) on each rank, and the same run in the product's default flow with its own diagnostics
+    assert pr["no_exchange_ms_per_step_same_slab_alone"]["max"] > 0 and pr["exchange_efficiency_slab_alone_over_loop"] > 0
+    o = d["other_flow"]
+    assert o["promotion"] == "numpy2" and o["value"] > 0 and o["self_check"] == d["self_check"]
+    assert o["per_rank"]["rank0"]["exchanges"] == pr["rank0"]["exchanges"]
     # weak scaling stays available
     cmd2 = list(cmd)
     cmd2[cmd2.index("--master-port") + 1] = str(_free_port())

@@ -119,7 +119,13 @@ def test_typed_signal_upload_rejects_what_numpy_would_widen():
         assert lib.dxh_tvd_upload_signal_typed(st._h, _lib.ptr(probe32), _lib.DXH_F32, 3, 0, 2, None, 0) == 0
 
 
-def test_scalar_frames_and_generic_fallback_chain():
+@pytest.mark.parametrize("flow", ["default", "native"])
+def test_scalar_frames_and_generic_fallback_chain(flow, monkeypatch):
+    """float32 frames with a TV stage, in the flow a caller gets by default (the reference under NumPy >= 2: oracle flow
+    "numpy2") and in the native float32 flow (DXH_PROMOTION=native, the reference under NumPy < 2: oracle flow "strict")."""
+    if flow == "native":
+        monkeypatch.setenv("DXH_PROMOTION", "native")
+    oflow = "strict" if flow == "native" else "numpy2"
     rng = np.random.default_rng(5)
     base = da.ScalarImage(rng.random((40, 50)).astype(np.float32))
     probe = da.ScalarImage((base.img + 0.2 * rng.random((40, 50))).astype(np.float32))
@@ -127,7 +133,7 @@ def test_scalar_frames_and_generic_fallback_chain():
     ca = da.ConcentrationAnalysis(base, None, None, tvd, da.ClipModel(min_value=0.05), **{"diff option": "plain"})
     out = ca(probe)
     ref = OC.concentration(probe.img, base.img, "plain", None, None, [lambda x: np.clip(x, 0.05, None)],
-                           dict(mu=0.1, omega=1, ell=1.0, max_num_iter=8), False)
+                           dict(mu=0.1, omega=1, ell=1.0, max_num_iter=8), False, promotion=oflow)
     assert np.array_equal(out.img, ref)
     # a callable reduction cannot be fused: the stages run one by one through the objects' __call__
     base3, probe3 = _frames(30, 44, 6)
@@ -137,7 +143,7 @@ def test_scalar_frames_and_generic_fallback_chain():
     sig = np.abs(probe3.img - base3.img)
     sig = sig[:, :, 0] - sig[:, :, 2]
     from oracle import tvd_numpy as O
-    assert np.array_equal(out2.img, O.split_bregman_tvd(sig, mu=0.1, ell=1.0, max_num_iter=5, promotion="strict"))
+    assert np.array_equal(out2.img, O.split_bregman_tvd(sig, mu=0.1, ell=1.0, max_num_iter=5, promotion=oflow))
 
 
 @pytest.mark.parametrize("n_frames", [0, 1, 2, 5])
@@ -263,12 +269,17 @@ def _golden_cases():
 
 
 @pytest.mark.parametrize("tag", _golden_cases()[1])
-def test_product_against_outputs_of_the_reference_class(tag):
+def test_product_against_outputs_of_the_reference_class(tag, monkeypatch):
     """The fused device pipeline against what the reference's own ConcentrationAnalysis returned for the same inputs
-    (tests/golden/make_golden_concentration.py): float64 bit for bit; float32 with TVD bit for bit as well (the vectors
-    were made under NumPy 1.26, whose value-based casting keeps the reference's iteration in float32)."""
+    (tests/golden/make_golden_concentration.py): float64 bit for bit; float32 with TVD bit for bit as well -- the vectors
+    were made under NumPy 1.26 (the only NumPy next to a real scikit-image here), whose value-based casting keeps the
+    reference's iteration in float32: that vector is the NATIVE flow's (DXH_PROMOTION=native); the default flow of the same
+    configuration is checked against the oracle's NumPy-2 flow below."""
     g, _, ast = _golden_cases()
     spec = ast.literal_eval(str(g[f"{tag}/spec"]))
+    float32_tv = spec["rest"] is not None and g[f"{tag}/probe"].dtype == np.float32
+    if float32_tv:
+        monkeypatch.setenv("DXH_PROMOTION", "native")
     base, probe = g[f"{tag}/base"], g[f"{tag}/probe"]
     extras = [g[f"{tag}/extra{i}"] for i in range(spec["nclean"])]
     model = {"linear_clip": lambda: da.CombinedModel([da.LinearModel(scaling=2.5, offset=-0.05), da.ClipModel(min_value=0.0, max_value=1.0)]),
@@ -284,6 +295,20 @@ def test_product_against_outputs_of_the_reference_class(tag):
     want = g[f"{tag}/out"]
     assert isinstance(out, da.ScalarImage) and out.name == "frame" and out.img.dtype == want.dtype
     assert np.array_equal(out.img, want), np.abs(out.img - want).max()
+    if float32_tv:
+        # the same configuration in the product's default flow: the reference's arithmetic under NumPy >= 2
+        assert extras == [] and spec["model"] == "scaling" and not spec["rest_first"]
+        monkeypatch.delenv("DXH_PROMOTION")
+        ca = da.ConcentrationAnalysis(bases[0], da.MonochromaticReduction(color=spec["color"]), None,
+                                      da.TVD(method="heterogeneous bregman", eps=None, **spec["rest"]), model,
+                                      **{"diff option": spec["diff"], "restoration -> model": spec["rest_first"]})
+        out = ca(da.OpticalImage(probe, name="frame"))
+        r = spec["rest"]
+        ref = OC.concentration(probe, base, spec["diff"], spec["color"], None, [lambda x: 3.0 * x],
+                               dict(mu=r["weight"], omega=r.get("omega", 1.0), ell=r.get("regularization", 1.0),
+                                    max_num_iter=r["max_num_iter"]), False, promotion="numpy2")
+        assert out.img.dtype == ref.dtype and np.array_equal(out.img, ref)
+        assert not np.array_equal(ref, want)    # the two NumPy generations of the reference do differ on this input
 
 
 def test_device_resident_frames_stay_on_the_device():

@@ -38,21 +38,26 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_whole(img, n_iter):
-    with da.DeviceTVD(img.shape, img.dtype, dim=2) as st:
+FLOWS = ["native", "numpy2"]   # the headline's float32 flow and the product's default (the reference under NumPy >= 2)
+ORACLE_FLOW = {"native": "strict", "numpy2": "numpy2"}
+
+
+def _run_whole(img, n_iter, promotion="native"):
+    with da.DeviceTVD(img.shape, img.dtype, dim=2, promotion=promotion) as st:
         st.set_coeffs(MU, 1.0, None, img)
         st.upload(img)
         res = st.run(n_iter)
         return st.download(), res
 
 
-def test_config5_whole_image_on_one_gpu_windows_against_the_oracle(monkeypatch):
+@pytest.mark.parametrize("flow", FLOWS)
+def test_config5_whole_image_on_one_gpu_windows_against_the_oracle(monkeypatch, flow):
     img = synthetic_image(H5, W5, C5)
     n = 20
-    out, res = _run_whole(img, n)
+    out, res = _run_whole(img, n, flow)
     assert res.iters_done == n and res.launches == n // 4
     monkeypatch.setenv("DXH_FUSE_K", "1")
-    out1, res1 = _run_whole(img, n)
+    out1, res1 = _run_whole(img, n, flow)
     monkeypatch.delenv("DXH_FUSE_K")
     assert res1.launches == n
     assert np.array_equal(out, out1)
@@ -65,13 +70,14 @@ def test_config5_whole_image_on_one_gpu_windows_against_the_oracle(monkeypatch):
         ra, rb = (0 if r0 == 0 else m), (S if r0 + S == H5 else S - m)
         ca, cb = (0 if c0 == 0 else m), (S if c0 + S == W5 else S - m)
         got = out[r0 + ra:r0 + rb, c0 + ca:c0 + cb]
-        want = O.split_bregman_tvd(crop, mu=MU, max_num_iter=n, promotion="strict")[ra:rb, ca:cb]
+        want = O.split_bregman_tvd(crop, mu=MU, max_num_iter=n, promotion=ORACLE_FLOW[flow])[ra:rb, ca:cb]
         assert np.array_equal(got, want), f"window ({r0},{c0}): max abs {np.abs(got - want).max():.3e}"
         want2 = O.split_bregman_tvd(crop, mu=MU, max_num_iter=n)[ra:rb, ca:cb]      # the reference's NumPy-2 dtype flow
         np.testing.assert_allclose(got, want2, rtol=1e-4, atol=1e-6)
 
 
-def test_config5_slab_of_one_rank_at_n8_over_rccl():
+@pytest.mark.parametrize("flow", FLOWS)
+def test_config5_slab_of_one_rank_at_n8_over_rccl(flow):
     """1000 owned rows x 16000 x 3 with 20 + 21 halo rows: what rank r of 8 holds; neighbour = itself (periodic)."""
     from darsia_amd.parallel import Comm, SlabTVD, make_plan, periodic_slab
 
@@ -82,7 +88,7 @@ def test_config5_slab_of_one_rank_at_n8_over_rccl():
     try:
         plan = make_plan(rows, 1, 0, k, periodic=True)
         assert plan.rows == rows + 2 * k + 1
-        s = SlabTVD(plan, periodic_slab(img, plan), mu=MU, halo_iters=k, comm=comm)
+        s = SlabTVD(plan, periodic_slab(img, plan), mu=MU, halo_iters=k, comm=comm, promotion=flow)
         done = 0
         for part in (60, 40):       # two calls continue one sequence, the first prefetches the halos for the second
             done += s.run(part, more_to_come=done + part < n, asynchronous=True)
@@ -96,12 +102,12 @@ def test_config5_slab_of_one_rank_at_n8_over_rccl():
     # every exchange was started by the device counter behind a signalling launch, none timed out
     assert stats["signalling_launches"] == info["exchanges"] and stats["wait_timeouts"] == 0
     tiled = np.ascontiguousarray(np.concatenate([img, img, img], axis=0))
-    ref, _ = _run_whole(tiled, n)
+    ref, _ = _run_whole(tiled, n, flow)
     ref = ref[rows:2 * rows]
     assert np.array_equal(got, ref), f"max abs {np.abs(got - ref).max():.3e}"
 
 
-def _rank_worker(rank, world, port, n_iter, halo_iters, out_dir):
+def _rank_worker(rank, world, port, n_iter, halo_iters, out_dir, flow):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["RANK"], os.environ["WORLD_SIZE"], os.environ["LOCAL_RANK"] = str(rank), str(world), str(rank)
@@ -111,7 +117,7 @@ def _rank_worker(rank, world, port, n_iter, halo_iters, out_dir):
     try:
         plan = make_plan(H5, world, rank, halo_iters)
         slab = synthetic_image(plan.rows, W5, C5, row0=plan.slab0)
-        s = SlabTVD(plan, slab, mu=MU, halo_iters=halo_iters, comm=comm)
+        s = SlabTVD(plan, slab, mu=MU, halo_iters=halo_iters, comm=comm, promotion=flow)
         del slab
         done = s.run(n_iter)
         mine = s.owned_result()
@@ -123,17 +129,18 @@ def _rank_worker(rank, world, port, n_iter, halo_iters, out_dir):
         comm.close()
 
 
-def test_config5_two_host_staged_ranks_equal_one_context(tmp_path):
+@pytest.mark.parametrize("flow", FLOWS)
+def test_config5_two_host_staged_ranks_equal_one_context(tmp_path, flow):
     import multiprocessing as mp
 
     n, k, world = 44, 20, 2     # two exchanges, the last round shorter than the halo budget
     ctx = mp.get_context("spawn")
     port = _free_port()
-    procs = [ctx.Process(target=_rank_worker, args=(r, world, port, n, k, str(tmp_path))) for r in range(world)]
+    procs = [ctx.Process(target=_rank_worker, args=(r, world, port, n, k, str(tmp_path), flow)) for r in range(world)]
     for p in procs:
         p.start()
     whole = synthetic_image(H5, W5, C5)
-    ref, _ = _run_whole(whole, n)
+    ref, _ = _run_whole(whole, n, flow)
     del whole
     for p in procs:
         p.join(900)

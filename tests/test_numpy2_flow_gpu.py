@@ -15,7 +15,7 @@ import darsia_amd as da
 from oracle import tvd_numpy as O
 
 pytestmark = pytest.mark.gpu
-DEFAULT_DTYPE_FLOW = True   # conftest.py: this module runs the product's default dtype flow
+
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RTOL, ATOL = 1e-4, 1e-6

@@ -7,7 +7,7 @@ import pytest
 import darsia_amd as da
 from darsia_amd.restoration.split_bregman_tvd import choose_promotion, numpy2_unsupported
 
-DEFAULT_DTYPE_FLOW = True   # conftest.py: this module runs the product's default dtype flow
+
 
 
 def _why(img, mu=0.1, omega=1.0, ell=1.0, dim=2, x0=None, iso=False, solver=None, adaptive=None, quiet=True):

@@ -17,6 +17,7 @@ from oracle import tvd_numpy as O
 from conftest import split_last_axis
 
 pytestmark = pytest.mark.gpu
+NATIVE_DTYPE_FLOW = True   # conftest.py: this module pins the native float32 kernels (DXH_PROMOTION=native)
 
 RTOL, ATOL = 1e-4, 1e-6
 
