@@ -1391,6 +1391,7 @@ struct FusedArgs {
     int nwaves_total;
     int np2_first;     // NP2 pipelines (the reference's float32 dtype flow): u still holds the float32 image, so the neighbour
                        // sums of the launch's first iteration (stage 0) are float32 sums
+    int np2_div3;      // NP2 pipelines: the three-operation float32 division rhs / diag is exact for this diag (k_div3_check)
 };
 
 // ALIGN: the lanes that store cover whole 128-byte lines (strip stride rounded down to a multiple of

@@ -1,0 +1,606 @@
+// K outer iterations per pass in the reference's OWN dtype flow for a float32 image under NumPy >= 2 ("numpy2" promotion;
+// restoration/split_bregman_tvd.py:84-101,129-146, utils/linear_solvers/jacobi.py:101-114) -- the product's DEFAULT flow.
+//
+// Same decomposition as k_fused_multi (dxh_kernels.h: a wave owns a column strip of 64 lanes x 16 B and a chunk of rows and
+// marches down the rows with a K-stage register pipeline; column / channel neighbours by DPP wave shifts, no barriers), but
+// every quantity lives in the type the reference gives it, so that nothing is converted back and forth:
+//
+//   float64 (registers: double rings; HBM: double planes)   u, q_j = dub_j, the neighbour sum N(u), N(u) / diag_scaled
+//   float32 (registers: FLOAT rings; LDS: float rows)       d_j, b_j, t_j = ell (b_j - d_j), omega*img, the right-hand side,
+//                                                           rhs / diag
+//
+// Per element and stage: the two float64 shrinkages (clamp form) with their roundings to float32 (d, then b = q - d), the
+// float32 right-hand side (the column difference of t_1 with the lane shift folded into the subtraction on interior
+// strips), rhs / diag as a float32 division by a wave-invariant divisor through the host-rounded reciprocal (three
+// operations where an exhaustive device check of all 2^23 mantissas says that is exact for this diag, five otherwise;
+// dxh_common.h: div_by_const), N(u) / diag_scaled as a float64 division through the reciprocal with two residual
+// corrections, and the new q_j in float64.  Stage 0 of the first launch after an upload sums N(u) in float32 (u still is
+// the float32 image, exactly held by the doubles).
+//
+// The first version of this flow (round 3) ran inside the generic Pipe<double, ...>: the float32-valued state sat in double
+// rings and was converted on every use (8 v_cvt per element and stage), rhs / diag was the compiler's IEEE division
+// sequence, and the kernel needed 176 VGPRs (2 waves per SIMD): 1.47 - 1.55 ms per K = 4 launch at 4000 x 8000 x 3
+// (profiles/r03_sq_counters.csv: SQ_INSTS_VALU 7.64e8).
+#pragma once
+
+#include "dxh_kernels.h"
+
+#ifndef DXH_NP2_WAVES
+#define DXH_NP2_WAVES 3   // waves per SIMD the pipeline is compiled for (register cap 168 / 256)
+#endif
+#ifndef DXH_NP2_PFD
+#define DXH_NP2_PFD 1     // prefetch distance in row steps (2: staging registers, needs DXH_NP2_WAVES = 2)
+#endif
+
+namespace dxh {
+
+template <int K>
+struct Np2State {
+    static constexpr int N = 2;
+    double U[K + 1][4][N];   // rows of level l, slot = (row - rs) & 3 (level K: parity)
+    float t0[K][2][N];       // ell (b_0 - d_0) of each stage's current / previous row
+    float b0[K][2][N];
+    double q0l[2][N], q1l[2][N];  // loaded level-0 q rows (current / prefetched)
+    float of0[N];            // omega*img of stage 0's row
+    double pf[2][4][N];      // prefetch distance 2: rows in flight two steps ahead (u, omega*img, q0, q1)
+    double kqv[K][N];        // KQV: the float64 threshold mu / ell of each stage's current row
+    double kqn[N];
+};
+
+// LDS of one wave.  Rows of the levels 1 .. K - 1 go from their producer (stage l - 1) to their consumer (stage l, one step
+// later) through LDS, and the consumer reads its column (+-C) and channel (+-1) neighbours straight out of the row at
+// per-lane addresses -- no v_mov_b32_dpp pairs per double and, because the image-border / channel-border replicate rules are
+// folded into the (loop-invariant) addresses, no v_bfi selects either: 14 of the 71 VALU instructions per element and stage of
+// the first version.  A wave's LDS operations execute in order, so no barrier is involved.
+//   U rows     2 (K - 1) slots of 64 lanes x 16 B, 32 B of zeros in front of each and behind the last (lanes that look past
+//              the wave's ends read zeros, as bound_ctrl DPP gives them); slot = (level - 1) * 2 + parity of the step it is READ in
+//   b_1 rows   2 (K - 1) slots of 64 lanes x 8 B   float32 b_1 of the same rows (the consumer forms q_1 = D_1 u + b_1 itself)
+//   omega*img  4 slots of 64 lanes x 8 B          rows r .. r - 3 as float32, written by stage 0
+template <int K>
+struct Np2Lds {
+    static constexpr int PAD = 32;
+    static constexpr int USLOT = PAD + kWave * 16;          // the next slot's pad follows
+    static constexpr int NU = 2 * (K - 1);
+    static constexpr int U_BYTES = NU * USLOT + PAD;
+    static constexpr int B1_OFF = U_BYTES;
+    static constexpr int FSLOT = kWave * 8;
+    static constexpr int OF_OFF = B1_OFF + NU * FSLOT;
+    static constexpr int BYTES = OF_OFF + 4 * FSLOT;        // K = 4: 6368 + 3072 + 2048 = 11488 per wave
+    static_assert(U_BYTES % 16 == 0 && USLOT % 16 == 0, "16-byte rows");
+};
+
+template <int DELTA>
+__device__ __forceinline__ void shifted2f(const float (&v)[2], float (&w)[2]) {
+    w[0] = shifted_elem<DELTA, 0, true>(v);
+    w[1] = shifted_elem<DELTA, 1, true>(v);
+}
+
+// x - clamp(x, -k, k) pieces as single instructions: fmax / fmin of the compiler canonicalise (v_max_f64 x, x, x) every
+// operand they cannot prove quiet -- one more double-rate instruction per value that comes out of memory or LDS.  The
+// hardware instructions themselves return the other operand for a NaN, which is what fmax / fmin do.
+__device__ __forceinline__ double np2_clamp(double x, double negk, double k) {
+    double t, r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(t) : "v"(x), "v"(negk));
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(t), "v"(k));
+    return r;
+}
+__device__ __forceinline__ float np2_absmin(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double np2_absmin(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// d = float32(shrink(q, k)), b = float32(q - d) with the clamp form (scalar threshold k >= 0, np2_split<true>)
+__device__ __forceinline__ void np2_split_fast(double q, double negk, double k, float& d, float& b) {
+    d = (float)(q - np2_clamp(q, negk, k));
+    b = (float)(q - (double)d);
+}
+
+template <int C, bool COUPLED, int K, bool NTS, bool EDGE, bool NORM, bool KQV>
+struct PipeNp2 {
+    static constexpr int N = 2;
+    static constexpr int PFD = KQV ? 1 : DXH_NP2_PFD;   // the per-element threshold is prefetched at distance 1
+    using L = Np2Lds<K>;
+    const double* of_p;
+    const double* u_in;
+    const double* q0_in;
+    const double* q1_in;
+    const double* kq_p;
+    double* u_out;
+    double* q0_out;
+    double* q1_out;
+    int64_t P, nrow, R0, R1;
+    int nrow32, R0_32, R1_32;
+    double dsc, rdsc, kq, negkq;
+    float ell_f, diag_f, rdiag_f;
+    bool div3f;         // rhs / diag: one residual correction is exact for every numerator (k_div3_check on this diag)
+    bool np2_first;
+    bool store_lane;
+    uint32_t edgeL[N], edgeR[N], ch0[N], chLast[N];
+    bool inL[N];
+    uint32_t voff;
+    char* lw;           // this lane's own 16 bytes in U slot 0 of the wave's LDS region
+    char* aL[N];        // where element j's left / right column neighbour and left / right channel neighbour live in U slot 0
+    char* aR[N];        // (the element itself where the reference replicates: image border, first / last channel)
+    char* aCL[N];
+    char* aCR[N];
+    float* lb1;         // this lane's pair in b_1 slot 0
+    float* lof;         // this lane's pair in omega*img slot 0
+    double* linc;       // eps instantiation: running sums of squared increments, [stage][lane] in LDS
+
+    __device__ __forceinline__ void u_put(int slot, const double (&v)[N]) const {
+        store_vec(reinterpret_cast<double*>(lw + slot * L::USLOT), v);
+    }
+    __device__ __forceinline__ double u_get(const char* a, int slot) const {
+        return *reinterpret_cast<const double*>(a + slot * L::USLOT);
+    }
+    __device__ __forceinline__ void f_put(float* base, int slot, const float (&v)[N]) const {
+        *reinterpret_cast<float2*>(base + slot * (kWave * N)) = make_float2(v[0], v[1]);
+    }
+    __device__ __forceinline__ void f_get(const float* base, int slot, float (&v)[N]) const {
+        const float2 t = *reinterpret_cast<const float2*>(base + slot * (kWave * N));
+        v[0] = t.x;
+        v[1] = t.y;
+    }
+    __device__ __forceinline__ int64_t clampr(int64_t r) const { return r < 0 ? 0 : (r > nrow - 1 ? nrow - 1 : r); }
+    __device__ __forceinline__ const double* at(const double* plane, int64_t row) const {
+        return reinterpret_cast<const double*>(reinterpret_cast<const char*>(plane + row * P) + voff);
+    }
+    __device__ __forceinline__ double* at(double* plane, int64_t row) const {
+        return reinterpret_cast<double*>(reinterpret_cast<char*>(plane + row * P) + voff);
+    }
+    __device__ __forceinline__ void split(double q, double kqj, float& d, float& b) const {
+        if constexpr (KQV) np2_split<false>(q, kqj, d, b);
+        else np2_split_fast(q, negkq, kq, d, b);
+    }
+
+    // un = float64( float32(rhs) / float32(diag) ) + N(u) / diag_scaled        (jacobi.py:107,110-114)
+    __device__ __forceinline__ void divide(const float (&rhs)[N], const double (&acc)[N], double (&un)[N]) const {
+        float rs[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) rs[j] = div_by_const3(rhs[j], diag_f, rdiag_f);
+        if (!div3f) {
+            DXH_UNIFORM_BRANCH();
+#pragma unroll
+            for (int j = 0; j < N; ++j) rs[j] = div_refine(rs[j], rhs[j], diag_f, rdiag_f);
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) un[j] = (double)rs[j] + div_by_const<double>(acc[j], dsc, rdsc);
+        // numerators outside the reciprocal chains' proven range (non-zero and tiny): the IEEE divisions.  One cheap
+        // screen per lane first (exact zeros trip it and are sorted out by the precise test)
+        const float lo_f = np2_absmin(rhs[0], rhs[1]);
+        const double lo_d = np2_absmin(acc[0], acc[1]);
+        if (__builtin_expect(__any(lo_f < DivSafe<float>::tiny || lo_d < DivSafe<double>::tiny), 0)) {
+            bool unsafe = false;
+#pragma unroll
+            for (int j = 0; j < N; ++j) unsafe = unsafe || div_unsafe(rhs[j]) || div_unsafe(acc[j]);
+            if (__any(unsafe)) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) un[j] = (double)(rhs[j] / diag_f) + acc[j] / dsc;
+            }
+        }
+    }
+
+    // ACT: stages 0 .. ACT - 1 run (the first steps of a chunk, fused_np2_body)
+    template <int PH, int ACT = K>
+    __device__ __forceinline__ void step(Np2State<K>& st, const int64_t r) const {
+        double frn[N];
+        if constexpr (PFD == 1) {
+            const int64_t rn = clampr(r + 1);
+            load_vec(at(u_in, clampr(r + 2)), st.U[0][(PH + 2) & 3]);
+            load_vec(at(of_p, rn), frn);
+            load_vec(at(q0_in, rn), st.q0l[(PH + 1) & 1]);
+            load_vec(at(q1_in, rn), st.q1l[(PH + 1) & 1]);
+            if constexpr (KQV) load_vec(at(kq_p, rn), st.kqn);
+        } else {
+            const int64_t rn = clampr(r + 2);
+            load_vec(at(u_in, clampr(r + 3)), st.pf[PH & 1][0]);
+            load_vec(at(of_p, rn), st.pf[PH & 1][1]);
+            load_vec(at(q0_in, rn), st.pf[PH & 1][2]);
+            load_vec(at(q1_in, rn), st.pf[PH & 1][3]);
+        }
+        if constexpr (K > 1) f_put(lof, PH & 3, st.of0);   // omega*img of row r for the later stages
+        double q0h[N];   // Q0 of the next level at the next stage's row, handed from stage to stage
+        static_for<0, ACT>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            constexpr int c = (PH - s) & 3;
+            constexpr int cm = (c + 3) & 3, cp = (c + 1) & 3;
+            constexpr int cur = PH & 1, prv = cur ^ 1;
+            constexpr bool last = (s == K - 1);
+            const int64_t p = r - s;
+            const int p32 = (int)p;
+            double(&um)[N] = st.U[s][cm];
+            double(&uc)[N] = st.U[s][c];
+            double(&up)[N] = st.U[s][cp];
+            float(&t0m)[N] = st.t0[s][prv];
+            float(&t0c)[N] = st.t0[s][cur];
+            float(&b0m)[N] = st.b0[s][prv];
+            float(&b0c)[N] = st.b0[s][cur];
+            double(&un)[N] = last ? st.U[K][cur] : st.U[s + 1][c];
+            const double(&unm)[N] = last ? st.U[K][prv] : st.U[s + 1][cm];
+
+            // neighbours of this stage's row: nl / nr (column -+C), cl / cr (channel -+1), replicate rules applied
+            double nl[N], nr[N], cl[N], cr[N], q1c[N];
+            float ofv[N];
+            if constexpr (s == 0) {
+                // level 0 comes from HBM into registers: lane shifts by DPP, selects for the replicate rules
+                double ul[N], ur[N], ucl[N], ucr[N];
+                shifted<-C, true>(uc, ul);
+                shifted<+C, true>(uc, ur);
+                if constexpr (COUPLED) {
+                    shifted<-1, true>(uc, ucl);
+                    shifted<+1, true>(uc, ucr);
+                }
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    nl[j] = EDGE ? sel_bits(edgeL[j], uc[j], ul[j]) : ul[j];
+                    nr[j] = EDGE ? sel_bits(edgeR[j], uc[j], ur[j]) : ur[j];
+                    if constexpr (COUPLED) {
+                        cl[j] = sel_bits(ch0[j], uc[j], ucl[j]);
+                        cr[j] = sel_bits(chLast[j], uc[j], ucr[j]);
+                    }
+                    q1c[j] = st.q1l[cur][j];
+                    ofv[j] = st.of0[j];
+                }
+            } else {
+                // levels >= 1: out of the row stage s - 1 put into LDS one step ago; q_1 = D_1 u + b_1 is formed here
+                constexpr int slot = (s - 1) * 2 + cur;
+                float b1p[N];
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    nl[j] = u_get(aL[j], slot);
+                    nr[j] = u_get(aR[j], slot);
+                    if constexpr (COUPLED) {
+                        cl[j] = u_get(aCL[j], slot);
+                        cr[j] = u_get(aCR[j], slot);
+                    }
+                }
+                f_get(lb1, slot, b1p);
+                f_get(lof, c, ofv);
+#pragma unroll
+                for (int j = 0; j < N; ++j) q1c[j] = (nr[j] - uc[j]) + (double)b1p[j];
+            }
+
+            // d_j = float32(shrink(q_j)), b_j = float32(q_j - d_j), t_j = ell (b_j - d_j) in float32   (:84-89,143-146)
+            float b1c[N], t1c[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const double kqj = KQV ? st.kqv[s][j] : kq;
+                float d0f, b0f, d1f, b1f;
+                split((s == 0) ? st.q0l[cur][j] : q0h[j], kqj, d0f, b0f);
+                split(q1c[j], kqj, d1f, b1f);
+                t0c[j] = ell_f * (b0f - d0f);
+                t1c[j] = ell_f * (b1f - d1f);
+                b0c[j] = b0f;
+                b1c[j] = b1f;
+            }
+            if (p == 0) {  // replicate the row above the image
+                DXH_UNIFORM_BRANCH();
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    um[j] = uc[j];
+                    t0m[j] = t0c[j];
+                }
+            }
+            float rhs[N];
+            double acc[N];
+            if constexpr (EDGE) {
+                float t1l[N];
+                shifted2f<-C>(t1c, t1l);
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const float rf = ofv[j] + (t0c[j] - t0m[j]);
+                    rhs[j] = rf + (t1c[j] - sel_bits(edgeL[j], t1c[j], t1l[j]));
+                }
+            } else {
+                // interior strips: the lane shift rides on the subtraction where the neighbour is one lane away
+                static_for<0, N>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    const float rf = ofv[j] + (t0c[j] - t0m[j]);
+                    rhs[j] = rf + add_shifted_elem<-C, j, true>(t1c[j], t1c);
+                });
+            }
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                double a = um[j] + up[j];
+                a = a + nl[j];
+                a = a + nr[j];
+                if constexpr (COUPLED) {
+                    a = a + cl[j];
+                    a = a + cr[j];
+                }
+                acc[j] = a;
+            }
+            if constexpr (s == 0) {
+                if (np2_first) {  // u is the float32 image: the reference's accumulator is float32 too (wave-uniform)
+                    DXH_UNIFORM_BRANCH();
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {
+                        float af = (float)um[j] + (float)up[j];
+                        af = af + (float)nl[j];
+                        af = af + (float)nr[j];
+                        if constexpr (COUPLED) {
+                            af = af + (float)cl[j];
+                            af = af + (float)cr[j];
+                        }
+                        acc[j] = (double)af;
+                    }
+                }
+            }
+            divide(rhs, acc, un);
+            if (p32 >= nrow32) {  // below the image: replicate the new iterate
+                DXH_UNIFORM_BRANCH();
+#pragma unroll
+                for (int j = 0; j < N; ++j) un[j] = unm[j];
+            }
+            if (NORM && p32 >= R0_32 && p32 < R1_32) {  // wave-uniform; rows of this chunk only (each element once)
+                // one running sum per lane and stage, kept in LDS through volatile accesses; the lane mask (strip halo) is
+                // applied when the sums are read back (fused_np2_body)
+                double t = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const double dlt = un[j] - uc[j];
+                    const double sq = inL[j] ? dlt * dlt : 0.0;
+                    t = j == 0 ? sq : t + sq;
+                }
+                volatile double* slot = linc + s * kWave;
+                *slot = *slot + t;
+            }
+            double q0o[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) q0o[j] = (un[j] - unm[j]) + (double)b0m[j];
+            if constexpr (last) {
+                double unr[N], q1o[N];
+                shifted<+C, true>(un, unr);
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    if constexpr (EDGE)
+                        q1o[j] = (sel_bits(edgeR[j], un[j], unr[j]) - un[j]) + (double)b1c[j];
+                    else
+                        q1o[j] = (unr[j] - un[j]) + (double)b1c[j];
+                }
+                if (store_lane) {
+                    if (p32 >= R0_32 && p32 < R1_32) {
+                        if constexpr (NTS) {
+                            store_vec_nt(at(q1_out, p), q1o);
+                            store_vec_nt(at(u_out, p), un);
+                        } else {
+                            store_vec(at(q1_out, p), q1o);
+                            store_vec(at(u_out, p), un);
+                        }
+                    }
+                    if (p32 - 1 >= R0_32 && p32 - 1 < R1_32) {
+                        if constexpr (NTS)
+                            store_vec_nt(at(q0_out, p - 1), q0o);
+                        else
+                            store_vec(at(q0_out, p - 1), q0o);
+                    }
+                }
+            } else {
+                // the new row and its b_1 for stage s + 1, which reads them at the next step (its parity "cur")
+                u_put(s * 2 + prv, un);
+                f_put(lb1, s * 2 + prv, b1c);
+#pragma unroll
+                for (int j = 0; j < N; ++j) q0h[j] = q0o[j];
+            }
+        });
+        if constexpr (KQV) {
+#pragma unroll
+            for (int s2 = K - 1; s2 >= 1; --s2)
+#pragma unroll
+                for (int j = 0; j < N; ++j) st.kqv[s2][j] = st.kqv[s2 - 1][j];
+#pragma unroll
+            for (int j = 0; j < N; ++j) st.kqv[0][j] = st.kqn[j];
+        }
+        if constexpr (PFD == 2) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                st.U[0][(PH + 2) & 3][j] = st.pf[(PH + 1) & 1][0][j];
+                frn[j] = st.pf[(PH + 1) & 1][1][j];
+                st.q0l[(PH + 1) & 1][j] = st.pf[(PH + 1) & 1][2][j];
+                st.q1l[(PH + 1) & 1][j] = st.pf[(PH + 1) & 1][3][j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) st.of0[j] = (float)frn[j];   // the plane holds float32 values: exact
+    }
+};
+
+template <int C, bool COUPLED, int K, bool NTS, bool EDGE, bool NORM, bool KQV>
+__device__ __forceinline__ void fused_np2_body(const FusedArgs<double>& a, const int strip, const int chunk, const int lane,
+                                               char* lds_wave, double* linc_lane) {
+    constexpr int N = 2;
+    using SG = StripGeomK<double, C, K>;
+    using PipeT = PipeNp2<C, COUPLED, K, NTS, EDGE, NORM, KQV>;
+    using L = Np2Lds<K>;
+    PipeT pp;
+    pp.linc = linc_lane;
+    chunk_rows(a, chunk, pp.R0, pp.R1);
+    if (pp.R0 >= a.n0) return;
+    const int64_t x0 = (int64_t)strip * SG::STRIDE + (int64_t)(lane - SG::LH) * N;
+    int64_t xl = x0;
+    if (xl < 0) xl = 0;
+    if (xl > a.pitch - N) xl = a.pitch - N;
+    pp.store_lane = lane >= SG::LH && lane < SG::LH + SG::VALID && x0 < a.L;
+    pp.lw = lds_wave + L::PAD + lane * 16;
+    pp.lb1 = reinterpret_cast<float*>(lds_wave + L::B1_OFF) + lane * N;
+    pp.lof = reinterpret_cast<float*>(lds_wave + L::OF_OFF) + lane * N;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const int64_t x = x0 + j;
+        const bool eL = x < C, eR = x >= a.L - C;
+        const int cc = (int)(((x % C) + C) % C);
+        pp.edgeL[j] = lane_mask_bits(eL);
+        pp.edgeR[j] = lane_mask_bits(eR);
+        pp.ch0[j] = lane_mask_bits(cc == 0);
+        pp.chLast[j] = lane_mask_bits(cc == C - 1);
+        pp.inL[j] = x >= 0 && x < a.L;
+        // LDS addresses of the neighbours (relative to the lane's own element j: +-C / +-1 elements of 8 bytes); the element
+        // itself where the reference replicates
+        char* own = pp.lw + j * 8;
+        pp.aL[j] = own - (eL ? 0 : C * 8);
+        pp.aR[j] = own + (eR ? 0 : C * 8);
+        pp.aCL[j] = own - (cc == 0 ? 0 : 8);
+        pp.aCR[j] = own + (cc == C - 1 ? 0 : 8);
+    }
+    pp.of_p = a.of;
+    pp.u_in = a.u_in;
+    pp.q0_in = a.q0_in;
+    pp.q1_in = a.q1_in;
+    pp.u_out = a.u_out;
+    pp.q0_out = a.q0_out;
+    pp.q1_out = a.q1_out;
+    pp.kq_p = a.cp.kq;
+    pp.voff = (uint32_t)(xl * (int64_t)sizeof(double));
+    pp.P = a.pitch;
+    pp.nrow = a.n0;
+    pp.nrow32 = (int)a.n0;  // the host keeps n0 below 2^31 - 64 for these kernels (multi_supported)
+    pp.R0_32 = (int)pp.R0;
+    pp.R1_32 = (int)pp.R1;
+    pp.dsc = a.c.dsc;
+    pp.rdsc = a.c.rdsc;
+    pp.kq = a.c.kq;
+    pp.negkq = -a.c.kq;
+    pp.ell_f = (float)a.c.ell;
+    pp.diag_f = (float)a.c.diag;
+    pp.rdiag_f = 1.0f / pp.diag_f;     // RN(1 / diag): IEEE division, once per wave
+    pp.div3f = a.np2_div3 != 0;
+    pp.np2_first = a.np2_first != 0;
+
+    Np2State<K> st;
+#pragma unroll
+    for (int l = 0; l <= K; ++l)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) st.U[l][i][j] = 0.0;
+#pragma unroll
+    for (int l = 0; l < K; ++l)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) st.t0[l][i][j] = st.b0[l][i][j] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) st.q0l[i][j] = st.q1l[i][j] = 0.0;
+#pragma unroll
+    for (int l = 0; l < K; ++l)
+#pragma unroll
+        for (int j = 0; j < N; ++j) st.kqv[l][j] = 0.0;   // thresholds of the not yet started stages: shrink by nothing
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        st.of0[j] = 0.0f;
+        st.kqn[j] = 0.0;
+    }
+    {
+        // the wave's LDS region starts zeroed (pads included): the leading (discarded) rows must not see NaN bit patterns,
+        // and lanes that look past the wave's ends read zeros
+        static_assert(L::BYTES % 16 == 0, "whole 16-byte words");
+        for (int off = lane * 16; off < L::BYTES; off += kWave * 16)
+            *reinterpret_cast<float4*>(lds_wave + off) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    // prologue: phase 0 at row rs; rows rs - 1, rs, rs + 1 of u in ring slots 3, 0, 1, the carried (t0, b0) of row rs - 1
+    // recomputed from the stored q0
+    const int64_t rs = pp.R0 - (K - 1);
+    {
+        double ofd[N];
+        load_vec(pp.at(pp.u_in, pp.clampr(rs - 1)), st.U[0][3]);
+        load_vec(pp.at(pp.u_in, pp.clampr(rs)), st.U[0][0]);
+        load_vec(pp.at(pp.u_in, pp.clampr(rs + 1)), st.U[0][1]);
+        load_vec(pp.at(pp.of_p, pp.clampr(rs)), ofd);
+        load_vec(pp.at(pp.q0_in, pp.clampr(rs)), st.q0l[0]);
+        load_vec(pp.at(pp.q1_in, pp.clampr(rs)), st.q1l[0]);
+        if constexpr (PipeT::PFD == 2) {
+            load_vec(pp.at(pp.u_in, pp.clampr(rs + 2)), st.pf[1][0]);
+            load_vec(pp.at(pp.of_p, pp.clampr(rs + 1)), st.pf[1][1]);
+            load_vec(pp.at(pp.q0_in, pp.clampr(rs + 1)), st.pf[1][2]);
+            load_vec(pp.at(pp.q1_in, pp.clampr(rs + 1)), st.pf[1][3]);
+        }
+        const int64_t rm = pp.clampr(rs - 1);
+        double q0v[N], kqm[N];
+        load_vec(pp.at(pp.q0_in, rm), q0v);
+        if constexpr (KQV) {
+            load_vec(pp.at(pp.kq_p, rm), kqm);
+            load_vec(pp.at(pp.kq_p, pp.clampr(rs)), st.kqv[0]);
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            float df, bf;
+            pp.split(q0v[j], KQV ? kqm[j] : pp.kq, df, bf);
+            st.t0[0][1][j] = pp.ell_f * (bf - df);   // parity "prv" of phase 0
+            st.b0[0][1][j] = bf;
+            st.of0[j] = (float)ofd[j];
+        }
+    }
+    const int64_t r_end = pp.R1 + (K - 1);
+    if constexpr (NORM) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) *(volatile double*)(linc_lane + i * kWave) = 0.0;
+    }
+    // Start-up: stage s first matters at step 2 s - 1 of the chunk (fused_pipe_body states the argument)
+    int64_t r = rs;
+#ifndef DXH_NO_STAGE_SKIP
+    {
+        constexpr int NG = (2 * K - 4) / 4 + 1;
+        static_for<0, NG>([&](auto gc) {
+            constexpr int t0 = 4 * decltype(gc)::value;
+            constexpr auto act = [](int t) { return (t + 1) / 2 + 1 < K ? (t + 1) / 2 + 1 : K; };
+            pp.template step<0, act(t0)>(st, r);
+            pp.template step<1, act(t0 + 1)>(st, r + 1);
+            pp.template step<2, act(t0 + 2)>(st, r + 2);
+            pp.template step<3, act(t0 + 3)>(st, r + 3);
+            r += 4;
+        });
+    }
+#endif
+    for (; r <= r_end; r += 4) {
+        pp.template step<0>(st, r);
+        pp.template step<1>(st, r + 1);
+        pp.template step<2>(st, r + 2);
+        pp.template step<3>(st, r + 3);
+    }
+    if constexpr (NORM) {
+        // a wave's LDS operations complete in order: the sums are final here.  Lanes outside the strip's stored part drop out
+        double inc[K][N];
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            const double v = *(volatile double*)(linc_lane + s * kWave);
+            inc[s][0] = pp.store_lane ? v : 0.0;
+            inc[s][1] = 0.0;
+        }
+        pipe_write_partials<K, 0>(a, inc, chunk * a.nstrips + strip, lane);
+    }
+}
+
+template <int C, bool COUPLED, int K, bool NORM, bool KQV, bool NTS = true>
+__global__ void __launch_bounds__(256, DXH_NP2_WAVES) k_fused_multi_np2(FusedArgs<double> a) {
+    constexpr int N = 2;
+    using SG = StripGeomK<double, C, K>;
+    using L = Np2Lds<K>;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    constexpr int WPB = 4;
+    const int nbx = (a.nstrips + WPB - 1) / WPB;
+    int bx, chunk;
+    if (!block_to_tile_sub((int)blockIdx.x, nbx, a, bx, chunk)) return;  // block-uniform
+    const int strip = bx * WPB + wave;
+    if (strip >= a.nstrips || chunk >= a.nchunks) return;  // wave-uniform
+    const int64_t w0 = (int64_t)strip * SG::STRIDE - SG::LH * N;  // first element of the wave's window
+    const bool edge = (w0 < C) || (w0 + kWave * N > a.L - C);     // wave-uniform
+    __shared__ __attribute__((aligned(16))) char lds_all[WPB * L::BYTES];
+    __shared__ double lds_inc[NORM ? WPB * K * kWave : 1];
+    char* lds_wave = lds_all + (size_t)wave * L::BYTES;
+    double* linc_lane = NORM ? lds_inc + (size_t)wave * (K * kWave) + lane : lds_inc;
+    if (edge)
+        fused_np2_body<C, COUPLED, K, NTS, true, NORM, KQV>(a, strip, chunk, lane, lds_wave, linc_lane);
+    else
+        fused_np2_body<C, COUPLED, K, NTS, false, NORM, KQV>(a, strip, chunk, lane, lds_wave, linc_lane);
+    signal_chunk_done(a, chunk, lane);
+}
+
+}  // namespace dxh

@@ -142,6 +142,7 @@ struct Ctx {
     unsigned wait_timeout_ms = 10000;    // polling kernel: give up after this long (DXH_SLAB_WAIT_TIMEOUT_MS)
     bool test_lost_signal = false;       // DXH_SLAB_TEST_LOST_SIGNAL=1: wait for one wave more than will ever signal (tests)
     bool slab_fault = false;             // a time-out has been seen (sticky until upload)
+    bool no_kernel = false;              // a launcher found no instantiated pipeline for what it was asked (checked after the launch)
     int64_t slab_launches = 0, slab_exchanges = 0, slab_timed = 0, slab_timeouts = 0;
     double slab_wait_ms = 0.0, slab_xchg_ms = 0.0;
     struct XEv { hipEvent_t a = nullptr, b = nullptr, c = nullptr; bool busy = false; };
@@ -535,12 +536,22 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
     a.kqv = ((C == 1 || C == 3) && c->het && c->het_cdiag && c->cp_kq && a.c.const_diag && !(c->tune & 65536)) ? 1 : 0;
     a.derive = (c->het && !a.kqv) ? 1 : 0;  // array coefficients (multi_supported: only with the given planes at hand, K = kHetFuseK)
     a.np2_first = (c->np2 && c->np2_first) ? 1 : 0;
+    a.np2_div3 = 0;
     if (c->np2) {
+        // rhs / diag is a float32 division by the float32-rounded Python float: three operations through the reciprocal
+        // where the exhaustive check says so for this divisor (remembered per divisor), five otherwise
+        const float fd = (float)c->c_diag;
+        if (std::isfinite(fd) && std::fabs(fd) >= 0x1p-20f && std::fabs(fd) <= 0x1p+20f && !(c->tune & 128))
+            a.np2_div3 = div3_verified(c, fd, fd);
         // the reference's float32 dtype flow: Pipe<..., NP2> (dxh_multi.hip, objects np2_k3 / np2_k4); pick_k only asks for
         // the combinations that exist
         if constexpr (std::is_same<T, double>::value && !ISO && (C == 1 || C == 3) && (K == 4 || K == kHetFuseK)) {
-            if ((K == kHetFuseK) == (a.kqv != 0)) launch_multi_kernel_np2<K>(C, COUPLED, want_inc, a, grid, c->stream);
+            if ((K == kHetFuseK) == (a.kqv != 0)) {
+                launch_multi_kernel_np2<K>(C, COUPLED, want_inc, a, grid, c->stream);
+                return;
+            }
         }
+        c->no_kernel = true;   // never a silent no-op: the callers turn this into DXH_ESTATE (launched_or_fail)
         return;
     }
     // the kernels are instantiated in dxh_multi.hip (one object per element type and K, built in parallel)
@@ -1182,6 +1193,15 @@ static int np2_explicit_iteration(Ctx* c, int maxiter, double tol, void* tmp, in
     return DXH_OK;
 }
 
+// after a launcher: a (K, coefficient kind) combination without an instantiated pipeline is an error, not a skipped launch
+static int launched_or_fail(Ctx* c, int K) {
+    if (!c->no_kernel) return DXH_OK;
+    c->no_kernel = false;
+    set_error("no fused pipeline is instantiated for K = %d with these coefficients in this dtype flow (DXH_FUSED_TUNE / "
+              "DXH_FUSE_K developer knobs can ask for one that does not exist); nothing was launched", K);
+    return DXH_ESTATE;
+}
+
 template <typename T>
 static void launch_any(Ctx* c, int in, int out, bool iso, bool dpp, int K) {
     if (c->np2) {
@@ -1293,6 +1313,7 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
             const int K = pick_k(c, n_iter - it);
             const bool first0 = c->np2_first;   // numpy2 flow: the redo starts from the same (float32-valued) iterate
             launch_fused_multi<T>(c, in, out, iso, K, true);
+            if (int rc = launched_or_fail(c, K)) return rc;
             c->np2_first = false;
             ++launches;
             if (!c->inc_partial) { set_error("out of device memory for the increment partials"); return DXH_ENOMEM; }
@@ -1323,6 +1344,7 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
                 while (left > 0) {
                     const int k2 = pick_k(c, left);
                     launch_any<T>(c, a_in, a_out, iso, dpp, k2);
+                    if (int rc = launched_or_fail(c, k2)) return rc;
                     ++launches;
                     left -= k2;
                     std::swap(a_in, a_out);
@@ -1335,6 +1357,7 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
             // per-iteration host test is requested
             const int K = (!use_eps && dpp && multi_supported(c)) ? pick_k(c, n_iter - it) : 1;
             launch_any<T>(c, in, out, iso, dpp, K);
+            if (int rc = launched_or_fail(c, K)) return rc;
             it += K - 1;
             ++launches;
             c->cur = out;
@@ -1677,6 +1700,7 @@ static int run_slab_t(Ctx* c, int n_iter, int m, double eps, uint32_t flags, dxh
             }
             launch_any<T>(c, in, out, iso, dpp, K);
             c->row_lo = c->row_hi = 0;
+            if ((rc = launched_or_fail(c, K))) return rc;
             if (c->signalling) {
                 c->signal_target += c->signal_pending;
                 ++c->split_launches;

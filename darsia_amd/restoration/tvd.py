@@ -12,6 +12,8 @@ raises ``TypeError`` inside ``split_bregman_tvd``.  Here it is popped, so
 """
 from __future__ import annotations
 
+import threading
+
 import numpy as np
 
 from ..device import DeviceArray
@@ -40,15 +42,22 @@ class TVD:
         self.max_num_iter = kwargs.pop(key + "max_num_iter", 200)
         self.eps = kwargs.pop(key + "eps", 2e-4)
         self.kwargs = kwargs
-        self._contexts = {}    # device contexts kept between calls (numpy2 flow: coefficient planes stay in HBM)
+        # Device contexts kept between calls (numpy2 flow: the coefficient planes -- a 256 MB float64 weight map at
+        # 4000 x 8000 -- stay in HBM).  CONTRACT: ``weight`` / ``omega`` / ``regularization`` arrays are not edited in place
+        # between calls; the planes are refreshed when the array OBJECT or a strided sample of its values changes
+        # (concentration._fingerprint), which a localized in-place edit can miss -- after such an edit call ``refresh()``
+        # (or assign a new array).  One call at a time per operator: the lock serialises concurrent callers.
+        self._contexts = {}
+        self._lock = threading.RLock()
 
     def __call__(self, img):
-        if isinstance(img, (np.ndarray, DeviceArray)):  # a DeviceArray stays in HBM (darsia_amd.device)
-            return self._tvd_array(img)
-        elif _is_image(img):
-            return self._tvd_image(img)
-        else:
-            raise TypeError(f"Input type {type(img)} not supported.")
+        with self._lock:
+            if isinstance(img, (np.ndarray, DeviceArray)):  # a DeviceArray stays in HBM (darsia_amd.device)
+                return self._tvd_array(img)
+            elif _is_image(img):
+                return self._tvd_image(img)
+            else:
+                raise TypeError(f"Input type {type(img)} not supported.")
 
     def _tvd_array(self, img: np.ndarray) -> np.ndarray:
         if self.method == "heterogeneous bregman":
@@ -74,17 +83,37 @@ class TVD:
 
     def release(self) -> None:
         """Free the device contexts the operator keeps between calls (they come back on demand)."""
-        for held in self._contexts.values():
-            held[2].close()
-        self._contexts.clear()
+        with self._lock:
+            for held in self._contexts.values():
+                held[2].close()
+            self._contexts.clear()
+
+    def refresh(self) -> None:
+        """Forget the coefficient planes held on the device: the next call uploads ``weight`` / ``omega`` /
+        ``regularization`` afresh.  Call it after editing one of those arrays IN PLACE (see ``_contexts`` above)."""
+        self.release()
 
     def __deepcopy__(self, memo):
         import copy
 
         new = copy.copy(self)
+        # arrays are duplicated as the default deepcopy would (a copy must not see later edits of the original's weight map)
+        for name in ("weight", "omega", "regularization"):
+            setattr(new, name, copy.deepcopy(getattr(self, name), memo))
         new.kwargs = copy.deepcopy(self.kwargs, memo)
         new._contexts = {}          # device contexts are not shared between copies
+        new._lock = threading.RLock()
         return new
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state["_contexts"] = {}     # device handles and the lock do not travel (pickle, multiprocessing)
+        state.pop("_lock", None)
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._lock = threading.RLock()
 
     def _tvd_image(self, img):
         # tvd.py:127-129: a copy of the image with the denoised array

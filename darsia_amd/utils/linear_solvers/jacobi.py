@@ -50,13 +50,19 @@ class Jacobi(Solver):
     def __call__(self, x0: np.ndarray, rhs: np.ndarray, h: float = 1.0, promotion=None) -> np.ndarray:
         if self.mass_coeff is None or self.diffusion_coeff is None:
             raise ValueError("mass_coeff and diffusion_coeff must be set (update_params)")
-        if (x0.dtype == np.float32 and getattr(rhs, "dtype", None) == np.float32
-                and float32_flow(promotion, self.mass_coeff, self.diffusion_coeff) == "numpy2"):
-            return self._call_numpy2(x0, rhs, h)
         # device-resident operands stay in HBM: DeviceArray in (x0, and rhs of the same dtype), DeviceArray out
         on_device = isinstance(x0, DeviceArray)
         if not on_device:
-            x0 = np.asarray(x0)
+            x0 = np.asarray(x0)         # lists and other array-likes, as the reference's NumPy expressions take them
+        if not isinstance(rhs, DeviceArray):
+            rhs = np.asarray(rhs)
+        # the reference's flow under NumPy >= 2 as reproduced here hinges on PYTHON-number coefficients (weak scalars; only
+        # their quotient const_diag_scaled is an np.float64); NumPy scalars (np.float32(..), np.float64(..)) are strongly
+        # typed and promote differently at other places -- they stay with the native flow
+        weak = all(type(c) in (float, int) for c in (self.mass_coeff, self.diffusion_coeff))
+        if (x0.dtype == np.float32 and rhs.dtype == np.float32 and weak
+                and float32_flow(promotion, self.mass_coeff, self.diffusion_coeff) == "numpy2"):
+            return self._call_numpy2(x0, rhs, h)
         code = _lib.dtype_code(x0.dtype)
         if isinstance(rhs, DeviceArray):
             if rhs.dtype != x0.dtype:

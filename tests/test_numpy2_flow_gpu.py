@@ -256,6 +256,65 @@ def test_large_host_image_takes_the_row_bands_by_default():
         bits(out, st.download())
 
 
+# ---- BASELINE.json full size (4000 x 8000 x 3 float32) in the flow a caller of the drop-in API gets -------------------------
+def test_full_size_config2_default_call_windows_against_the_oracle(monkeypatch):
+    """configs[1] at its real size through the DEFAULT call ``da.split_bregman_tvd(img32, mu=0.1, max_num_iter=100)`` -- the
+    numpy2 flow, row bands for a host image of this size: (a) four 512 x 512 windows (three corners and the centre) BIT FOR BIT
+    against the oracle's reference flow on the crop (dependence cone, restoration/split_bregman_tvd.py:84-101,129-146,
+    utils/linear_solvers/jacobi.py:41-54,101-114: after n iterations a pixel knows nothing beyond n + 1 pixels;
+    tests/test_tvd_gpu.py states the argument); (b) the one-context K = 4 pipeline run == the one-iteration-per-launch run ==
+    the banded default call, bit for bit over the whole image; (c) 3 iterations over the WHOLE image against the oracle."""
+    from darsia_amd.synthetic import synthetic_image
+
+    H, W, n, m, S = 4000, 8000, 100, 102, 512
+    img = synthetic_image(H, W, 3)
+    out = da.split_bregman_tvd(img, mu=0.1, max_num_iter=n)          # the default call (banded at this size)
+    assert out.dtype == np.float32 and np.isfinite(out).all()
+
+    def one_context(iters):
+        with da.DeviceTVD(img.shape, img.dtype, promotion="numpy2") as st:
+            st.set_coeffs(0.1, 1.0, None, img)
+            st.upload(img)
+            res = st.run(iters)
+            return st.download(), res
+
+    out_k4, res = one_context(n)
+    assert res.iters_done == n and res.launches == n // 4               # the K = 4 NP2 pipeline served every launch
+    bits(out, out_k4)
+    monkeypatch.setenv("DXH_FUSE_K", "1")
+    out_k1, res1 = one_context(n)
+    monkeypatch.delenv("DXH_FUSE_K")
+    assert res1.launches == n
+    bits(out_k4, out_k1)
+    del out_k1, out_k4
+    for (r0, c0) in ((0, 0), ((H - S) // 2, (W - S) // 2), (H - S, W - S), (0, W - S)):
+        crop = np.ascontiguousarray(img[r0:r0 + S, c0:c0 + S])
+        ra, rb = (0 if r0 == 0 else m), (S if r0 + S == H else S - m)
+        ca, cb = (0 if c0 == 0 else m), (S if c0 + S == W else S - m)
+        want = O.split_bregman_tvd(crop, mu=0.1, max_num_iter=n)[ra:rb, ca:cb]      # the reference's NumPy-2 dtype flow
+        bits(out[r0 + ra:r0 + rb, c0 + ca:c0 + cb], want)
+    out3, _ = one_context(3)
+    bits(out3, O.split_bregman_tvd(img, mu=0.1, max_num_iter=3))
+
+
+def test_large_host_image_with_array_valued_omega_or_ell():
+    """>= 32 MB float32 host image, scalar mu next to a float64 ARRAY omega (or ell): not a row-band case (the bands take
+    scalar coefficients) -- the kept-context path serves it, same bits as the explicit device run.  (Regression: the band
+    shortcut once looked at mu only and failed on ``float(omega)``.)"""
+    rng = np.random.default_rng(5)
+    img = rng.random((1500, 2000, 3), dtype=np.float32)
+    assert img.nbytes >= (32 << 20)
+    om = 0.5 + rng.random(img.shape)
+    out = da.split_bregman_tvd(img, mu=0.1, omega=om, ell=0.3, max_num_iter=3)
+    S = 96
+    bits(out[:S, :S], O.split_bregman_tvd(np.ascontiguousarray(img[:S + 8, :S + 8]), mu=0.1, omega=np.ascontiguousarray(om[:S + 8, :S + 8]),
+                                          ell=0.3, max_num_iter=3)[:S, :S])
+    ell = 0.2 + 0.5 * rng.random(img.shape)
+    out = da.split_bregman_tvd(img, mu=0.1, ell=ell, max_num_iter=3)
+    bits(out[-S:, -S:], O.split_bregman_tvd(np.ascontiguousarray(img[-S - 8:, -S - 8:]), mu=0.1, ell=np.ascontiguousarray(ell[-S - 8:, -S - 8:]),
+                                            max_num_iter=3)[-S:, -S:])
+
+
 # ---- float32 images outside the default solve: several Jacobi sweeps, volumes, six channels (three kinds of launches) ----
 from test_oracle_np2_generic_golden import (ARRAY_CASES, CASES as GENERIC_CASES, H1_CASES, JACOBI_CASES, TOL_CASES,  # noqa: E402
                                             WARM_CASES, ADAPT_CASES, adapt_inputs, array_kwargs, case_kwargs, warm_inputs)
