@@ -22,6 +22,11 @@ template <typename T, int K>
 void launch_multi_kernel_c24(int C, bool coupled, bool iso, bool want_inc, bool pair, const FusedArgs<T>& a, unsigned grid,
                              hipStream_t stream);
 
+// waves per SIMD the numpy2 pipelines (dxh_np2_pipe.h) are compiled for; the host's chunk-count model uses the same number
+#ifndef DXH_NP2_WAVES
+#define DXH_NP2_WAVES 3
+#endif
+
 // the reference's float32 dtype flow (NP2 pipelines, double storage): K = 4 scalar threshold, K = kHetFuseK threshold plane
 template <int K>
 void launch_multi_kernel_np2(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);

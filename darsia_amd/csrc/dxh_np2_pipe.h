@@ -25,9 +25,7 @@
 
 #include "dxh_kernels.h"
 
-#ifndef DXH_NP2_WAVES
-#define DXH_NP2_WAVES 3   // waves per SIMD the pipeline is compiled for (register cap 168 / 256)
-#endif
+// DXH_NP2_WAVES (dxh_multi.h): waves per SIMD the pipeline is compiled for (register cap 168 / 256)
 #ifndef DXH_NP2_PFD
 #define DXH_NP2_PFD 1     // prefetch distance in row steps (2: staging registers, needs DXH_NP2_WAVES = 2)
 #endif
@@ -45,6 +43,8 @@ struct Np2State {
     double pf[2][4][N];      // prefetch distance 2: rows in flight two steps ahead (u, omega*img, q0, q1)
     double kqv[K][N];        // KQV: the float64 threshold mu / ell of each stage's current row
     double kqn[N];
+    bool kbad[K];            // KQV, wave-uniform: that row holds a threshold that is negative or NaN somewhere in the wave (the
+                             // clamp form of the shrinkage needs k >= 0; such rows take the general expression)
 };
 
 // LDS of one wave.  Rows of the levels 1 .. K - 1 go from their producer (stage l - 1) to their consumer (stage l, one step
@@ -52,21 +52,31 @@ struct Np2State {
 // per-lane addresses -- no v_mov_b32_dpp pairs per double and, because the image-border / channel-border replicate rules are
 // folded into the (loop-invariant) addresses, no v_bfi selects either: 14 of the 71 VALU instructions per element and stage of
 // the first version.  A wave's LDS operations execute in order, so no barrier is involved.
-//   U rows     2 (K - 1) slots of 64 lanes x 16 B, 32 B of zeros in front of each and behind the last (lanes that look past
-//              the wave's ends read zeros, as bound_ctrl DPP gives them); slot = (level - 1) * 2 + parity of the step it is READ in
+//   U rows     2 (K - 1) slots, each the row's EVEN elements (element 0 of every lane: 64 x 8 B) followed by its ODD elements,
+//              16 B of zeros in front of each half and behind the last (lanes that look past the wave's ends read zeros, as
+//              bound_ctrl DPP gives them).  De-interleaved so that a wave's 8-byte reads at consecutive lanes are consecutive
+//              in LDS: conflict-free (a 16-byte lane stride is a 2-way bank conflict for ds_read_b64: measured, 5.4e7
+//              conflict cycles per launch).  slot = (level - 1) * 2 + parity of the step it is READ in
 //   b_1 rows   2 (K - 1) slots of 64 lanes x 8 B   float32 b_1 of the same rows (the consumer forms q_1 = D_1 u + b_1 itself)
 //   omega*img  4 slots of 64 lanes x 8 B          rows r .. r - 3 as float32, written by stage 0
 template <int K>
 struct Np2Lds {
-    static constexpr int PAD = 32;
-    static constexpr int USLOT = PAD + kWave * 16;          // the next slot's pad follows
+    static constexpr int PAD = 16;
+    static constexpr int UHALF = PAD + kWave * 8;           // one parity of a row: pad + 64 x 8 B (the next half's pad follows)
+    static constexpr int USLOT = 2 * UHALF;
     static constexpr int NU = 2 * (K - 1);
     static constexpr int U_BYTES = NU * USLOT + PAD;
     static constexpr int B1_OFF = U_BYTES;
     static constexpr int FSLOT = kWave * 8;
     static constexpr int OF_OFF = B1_OFF + NU * FSLOT;
-    static constexpr int BYTES = OF_OFF + 4 * FSLOT;        // K = 4: 6368 + 3072 + 2048 = 11488 per wave
+    static constexpr int BYTES = OF_OFF + 4 * FSLOT;        // K = 4: 6352 + 3072 + 2048 = 11472 per wave
+    // byte offset, within U slot 0, of element e of the wave's window (e = 2 lane + j; e in [-4, 132) stays inside the pads)
+    static __device__ __forceinline__ int elem_off(int e) {
+        const int par = e & 1;
+        return PAD + par * UHALF + ((e - par) >> 1) * 8;
+    }
     static_assert(U_BYTES % 16 == 0 && USLOT % 16 == 0, "16-byte rows");
+    static_assert(PAD >= 16, "C <= 4: a lane looks at most 4 elements (2 lanes x 8 B per half) past the wave's ends");
 };
 
 template <int DELTA>
@@ -123,7 +133,7 @@ struct PipeNp2 {
     uint32_t edgeL[N], edgeR[N], ch0[N], chLast[N];
     bool inL[N];
     uint32_t voff;
-    char* lw;           // this lane's own 16 bytes in U slot 0 of the wave's LDS region
+    char* lw[N];        // this lane's own elements in U slot 0 of the wave's LDS region
     char* aL[N];        // where element j's left / right column neighbour and left / right channel neighbour live in U slot 0
     char* aR[N];        // (the element itself where the reference replicates: image border, first / last channel)
     char* aCL[N];
@@ -133,7 +143,8 @@ struct PipeNp2 {
     double* linc;       // eps instantiation: running sums of squared increments, [stage][lane] in LDS
 
     __device__ __forceinline__ void u_put(int slot, const double (&v)[N]) const {
-        store_vec(reinterpret_cast<double*>(lw + slot * L::USLOT), v);
+#pragma unroll
+        for (int j = 0; j < N; ++j) *reinterpret_cast<double*>(lw[j] + slot * L::USLOT) = v[j];
     }
     __device__ __forceinline__ double u_get(const char* a, int slot) const {
         return *reinterpret_cast<const double*>(a + slot * L::USLOT);
@@ -154,7 +165,7 @@ struct PipeNp2 {
         return reinterpret_cast<double*>(reinterpret_cast<char*>(plane + row * P) + voff);
     }
     __device__ __forceinline__ void split(double q, double kqj, float& d, float& b) const {
-        if constexpr (KQV) np2_split<false>(q, kqj, d, b);
+        if constexpr (KQV) np2_split_fast(q, -kqj, kqj, d, b);
         else np2_split_fast(q, negkq, kq, d, b);
     }
 
@@ -278,6 +289,21 @@ struct PipeNp2 {
                 b0c[j] = b0f;
                 b1c[j] = b1f;
             }
+            if constexpr (KQV) {
+                if (st.kbad[s]) {  // a negative or NaN threshold in this row: np.maximum(|x| - k, 0) * np.sign(x) as written
+                    DXH_UNIFORM_BRANCH();
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {
+                        float d0f, b0f, d1f, b1f;
+                        np2_split<false>((s == 0) ? st.q0l[cur][j] : q0h[j], st.kqv[s][j], d0f, b0f);
+                        np2_split<false>(q1c[j], st.kqv[s][j], d1f, b1f);
+                        t0c[j] = ell_f * (b0f - d0f);
+                        t1c[j] = ell_f * (b1f - d1f);
+                        b0c[j] = b0f;
+                        b1c[j] = b1f;
+                    }
+                }
+            }
             if (p == 0) {  // replicate the row above the image
                 DXH_UNIFORM_BRANCH();
 #pragma unroll
@@ -395,6 +421,9 @@ struct PipeNp2 {
                 for (int j = 0; j < N; ++j) st.kqv[s2][j] = st.kqv[s2 - 1][j];
 #pragma unroll
             for (int j = 0; j < N; ++j) st.kqv[0][j] = st.kqn[j];
+#pragma unroll
+            for (int s2 = K - 1; s2 >= 1; --s2) st.kbad[s2] = st.kbad[s2 - 1];
+            st.kbad[0] = __any(!(st.kqn[0] >= 0.0) || !(st.kqn[1] >= 0.0)) != 0;
         }
         if constexpr (PFD == 2) {
 #pragma unroll
@@ -426,7 +455,6 @@ __device__ __forceinline__ void fused_np2_body(const FusedArgs<double>& a, const
     if (xl < 0) xl = 0;
     if (xl > a.pitch - N) xl = a.pitch - N;
     pp.store_lane = lane >= SG::LH && lane < SG::LH + SG::VALID && x0 < a.L;
-    pp.lw = lds_wave + L::PAD + lane * 16;
     pp.lb1 = reinterpret_cast<float*>(lds_wave + L::B1_OFF) + lane * N;
     pp.lof = reinterpret_cast<float*>(lds_wave + L::OF_OFF) + lane * N;
 #pragma unroll
@@ -439,13 +467,14 @@ __device__ __forceinline__ void fused_np2_body(const FusedArgs<double>& a, const
         pp.ch0[j] = lane_mask_bits(cc == 0);
         pp.chLast[j] = lane_mask_bits(cc == C - 1);
         pp.inL[j] = x >= 0 && x < a.L;
-        // LDS addresses of the neighbours (relative to the lane's own element j: +-C / +-1 elements of 8 bytes); the element
-        // itself where the reference replicates
-        char* own = pp.lw + j * 8;
-        pp.aL[j] = own - (eL ? 0 : C * 8);
-        pp.aR[j] = own + (eR ? 0 : C * 8);
-        pp.aCL[j] = own - (cc == 0 ? 0 : 8);
-        pp.aCR[j] = own + (cc == C - 1 ? 0 : 8);
+        // LDS addresses of the element and of its neighbours (+-C / +-1 elements along the row); the element itself where the
+        // reference replicates
+        const int e = 2 * lane + j;
+        pp.lw[j] = lds_wave + L::elem_off(e);
+        pp.aL[j] = lds_wave + L::elem_off(eL ? e : e - C);
+        pp.aR[j] = lds_wave + L::elem_off(eR ? e : e + C);
+        pp.aCL[j] = lds_wave + L::elem_off(cc == 0 ? e : e - 1);
+        pp.aCR[j] = lds_wave + L::elem_off(cc == C - 1 ? e : e + 1);
     }
     pp.of_p = a.of;
     pp.u_in = a.u_in;
@@ -493,6 +522,8 @@ __device__ __forceinline__ void fused_np2_body(const FusedArgs<double>& a, const
 #pragma unroll
         for (int j = 0; j < N; ++j) st.kqv[l][j] = 0.0;   // thresholds of the not yet started stages: shrink by nothing
 #pragma unroll
+    for (int l = 0; l < K; ++l) st.kbad[l] = false;
+#pragma unroll
     for (int j = 0; j < N; ++j) {
         st.of0[j] = 0.0f;
         st.kqn[j] = 0.0;
@@ -528,10 +559,12 @@ __device__ __forceinline__ void fused_np2_body(const FusedArgs<double>& a, const
             load_vec(pp.at(pp.kq_p, rm), kqm);
             load_vec(pp.at(pp.kq_p, pp.clampr(rs)), st.kqv[0]);
         }
+        if constexpr (KQV) st.kbad[0] = __any(!(st.kqv[0][0] >= 0.0) || !(st.kqv[0][1] >= 0.0)) != 0;
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             float df, bf;
-            pp.split(q0v[j], KQV ? kqm[j] : pp.kq, df, bf);
+            if constexpr (KQV) np2_split<false>(q0v[j], kqm[j], df, bf);   // (once per chunk: the general expression)
+            else pp.split(q0v[j], pp.kq, df, bf);
             st.t0[0][1][j] = pp.ell_f * (bf - df);   // parity "prv" of phase 0
             st.b0[0][1][j] = bf;
             st.of0[j] = (float)ofd[j];

@@ -482,7 +482,8 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
             const int64_t target_blocks = (int64_t)c->num_cu * (c->waves_per_cu ? c->waves_per_cu : 24) / 4 - 8 * extra_per_xcd;
             nchunks = std::max<int64_t>(1, target_blocks / nbx);
         } else {
-            constexpr int W = pipe_waves<T, K, false>();  // blocks resident per CU (one wave of each per SIMD)
+            // blocks resident per CU (one wave of each per SIMD); the numpy2 pipelines have their own register budget
+            const int W = c->np2 ? DXH_NP2_WAVES : pipe_waves<T, K, false>();
             // issue cost of one VALU instruction per SIMD with 1 / 2 / 3 / 4 waves taking turns (tools/valubench.hip)
             static const double cpi[5] = {0.0, 6.6, 3.7, 3.5, 3.2};  // 3: fitted to chunk sweeps of this kernel (a third wave adds ~8 %)
             const int64_t cu_per_xcd = std::max(1, c->num_cu / 8);

@@ -173,6 +173,22 @@ def test_float32_mu_array_and_windows_at_100_iterations():
     print(f"native float32 flow after {n} iterations at ell = 1.0: worst error / tolerance = {worst_native:.2f}")
 
 
+def test_negative_thresholds_take_the_general_shrinkage():
+    """A float64 weight map with negative entries (np.maximum(|x| - k, 0) with k < 0 GROWS x) and a -0.0: the K-stage
+    pipeline's clamp form of the shrinkage needs k >= 0, rows that hold anything else fall back to the expression as written
+    (wave-uniform per row, PipeNp2::step) -- bit for bit like the oracle.  (A NaN weight is outside what is reproduced: the
+    compressed state re-derives d = shrink(0, NaN) = NaN at the first iteration where the reference still holds d = 0, so
+    the NaN reaches the iterate one iteration early -- DESIGN.md, known deviations.)"""
+    rng = np.random.default_rng(23)
+    for shape, n in (((70, 150), 9), ((40, 90, 3), 9), ((300, 700, 3), 13)):
+        img = rng.random(shape).astype(np.float32)
+        mu = 0.1 * rng.random(shape)
+        mu[10:14, 20:60] *= -1.0
+        mu[30, 5] = -0.0
+        got = da.split_bregman_tvd(img, mu=mu, ell=0.5, max_num_iter=n)
+        bits(got, O.split_bregman_tvd(img, mu=mu, ell=0.5, max_num_iter=n))
+
+
 def test_unsupported_configurations_say_so():
     img = np.random.default_rng(1).random((20, 30)).astype(np.float32)
     with pytest.raises(NotImplementedError, match="numpy2"):
