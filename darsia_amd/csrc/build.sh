@@ -45,8 +45,8 @@ for k in 3 4 2; do
         run "multi_f64_k${k}_c${cs}" dxh_multi.hip -DDXH_MULTI_T=double -DDXH_MULTI_K=${k} -DDXH_MULTI_CSET=${cs}
     done
 done
-run np2_k4 dxh_multi.hip -DDXH_MULTI_T=double -DDXH_MULTI_K=4 -DDXH_MULTI_NP2=1
-run np2_k3 dxh_multi.hip -DDXH_MULTI_T=double -DDXH_MULTI_K=3 -DDXH_MULTI_NP2=1
+run np2_s dxh_multi.hip -DDXH_MULTI_T=double -DDXH_MULTI_K=4 -DDXH_MULTI_NP2=1
+run np2_q dxh_multi.hip -DDXH_MULTI_T=double -DDXH_MULTI_K=4 -DDXH_MULTI_NP2=2
 run tvd dxh_tvd.hip
 run chambolle dxh_chambolle.hip
 run dense dxh_dense.hip

@@ -2252,18 +2252,10 @@ struct PipeLds {
 // division), only the shrink threshold kq = mu / ell is per element: one more plane read per launch (cp.kq, filled by
 // k_coef_planes with derive_coefs' expression) and K x N registers, instead of the 4 x K x N coefficient registers and
 // the per-row derivation of the general array pipeline -- three waves per SIMD instead of two.
-// NP2 (double storage, scalar pipelines and KQV): the reference's own dtype flow for a float32 image under NumPy >= 2, as in
-// k_fused_np2 above -- u and the compressed split state q = dub are float64; d, b, t = ell (b - d) and the right-hand side are
-// float32 values (held in the double rings: every float is a double); rhs / diag is a float32 division, N(u) / diag_scaled a
-// float64 one.  Stage 0 of the first launch after an upload sums N(u) in float32 (u still is the float32 image).
-template <typename T, int C, bool COUPLED, bool ISO, int K, bool NTS, bool EDGE, bool NORM, bool HET = false, bool KQV = false,
-          bool NP2 = false>
+// (The reference's mixed float32 / float64 flow for float32 images -- "numpy2" -- has its own pipeline: dxh_np2_pipe.h.)
+template <typename T, int C, bool COUPLED, bool ISO, int K, bool NTS, bool EDGE, bool NORM, bool HET = false, bool KQV = false>
 struct Pipe {
     static_assert(!(HET && KQV), "KQV is a variant of the scalar pipeline");
-    static_assert(!NP2 || (std::is_same<T, double>::value && !ISO && !HET), "NP2: double storage, anisotropic, scalar omega / ell");
-    static constexpr bool kNP2 = NP2;
-    bool np2_first;
-    float ell_f, diag_f;
     const T* kq_p;
     static constexpr int N = VecOf<T>::N;
     static constexpr bool DPP = true;
@@ -2364,22 +2356,6 @@ struct Pipe {
 
     // ACT: stages 0 .. ACT - 1 run, the others are skipped (the first steps of a chunk, fused_pipe_body: a stage has nothing
     // valid to work on before its predecessors have produced two rows)
-    // NP2: un = float32(rhs) / float32(diag) [a float32 quotient] + N(u) / diag_scaled [float64, through the reciprocal
-    // with two residual corrections; tiny non-zero numerators take the IEEE division]
-    __device__ __forceinline__ void np2_div(const T (&rhs)[N], const T (&acc)[N], T (&un)[N]) const {
-        bool unsafe = false;
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            const float rs = (float)rhs[j] / diag_f;
-            un[j] = (T)rs + div_by_const<T>(acc[j], dsc, rdsc);
-            unsafe = unsafe || div_unsafe(acc[j]);
-        }
-        if (__builtin_expect(__any(unsafe), 0)) {
-#pragma unroll
-            for (int j = 0; j < N; ++j) un[j] = (T)((float)rhs[j] / diag_f) + acc[j] / dsc;
-        }
-    }
-
     template <int PH, int ROLE = 0, int ACT = K>
     __device__ __forceinline__ void step(PipeState<T, K>& st, IncT<T> (&inc)[NORM ? K : 1][N], const int64_t r) const {
         constexpr int PFD = ROLE == 0 ? pipe_pfd<T, K, HET, ISO>() : 1;  // prefetch distance in steps
@@ -2480,14 +2456,6 @@ struct Pipe {
                     split_vars<T, 2, ISO, false>(qq, st.coef[s][3][j], d, b);
                     t0c[j] = st.coef[s][0][j] * (b[0] - d[0]);
                     t1c[j] = st.coef[s][0][j] * (b[1] - d[1]);
-                } else if constexpr (NP2) {
-                    float df[2], bf[2];
-                    np2_split<!KQV>((double)qq[0], (double)(KQV ? st.kqv[s][j] : kq), df[0], bf[0]);
-                    np2_split<!KQV>((double)qq[1], (double)(KQV ? st.kqv[s][j] : kq), df[1], bf[1]);
-                    b[0] = (T)bf[0];
-                    b[1] = (T)bf[1];
-                    t0c[j] = (T)(ell_f * (bf[0] - df[0]));
-                    t1c[j] = (T)(ell_f * (bf[1] - df[1]));
                 } else if constexpr (KQV) {
                     split_vars<T, 2, ISO, false>(qq, st.kqv[s][j], d, b);
                     t0c[j] = ell * (b[0] - d[0]);
@@ -2517,42 +2485,7 @@ struct Pipe {
                 shifted<+1, DPP>(uc, ucr);
             }
             T rhs[N], acc[N];
-            if constexpr (NP2) {
-#pragma unroll
-                for (int j = 0; j < N; ++j) {
-                    // float32: rhs = omega img; rhs += fd_0; rhs += fd_1 (split_bregman_tvd.py:84-89)
-                    const float t1left = (float)(EDGE ? sel_bits(edgeL[j], t1c[j], t1l[j]) : t1l[j]);
-                    float rf = (float)ofv[j] + ((float)t0c[j] - (float)t0m[j]);
-                    rf = rf + ((float)t1c[j] - t1left);
-                    rhs[j] = (T)rf;
-                    const T nl = EDGE ? sel_bits(edgeL[j], uc[j], ul[j]) : ul[j], nr = EDGE ? sel_bits(edgeR[j], uc[j], ur[j]) : ur[j];
-                    T a = um[j] + up[j];
-                    a = a + nl;
-                    a = a + nr;
-                    if constexpr (COUPLED) {
-                        a = a + sel_bits(ch0[j], uc[j], ucl[j]);
-                        a = a + sel_bits(chLast[j], uc[j], ucr[j]);
-                    }
-                    acc[j] = a;
-                }
-                if constexpr (s == 0) {
-                    if (np2_first) {  // u is the float32 image: the reference's accumulator is float32 too (wave-uniform)
-                        DXH_UNIFORM_BRANCH();
-#pragma unroll
-                        for (int j = 0; j < N; ++j) {
-                            const T nl = EDGE ? sel_bits(edgeL[j], uc[j], ul[j]) : ul[j], nr = EDGE ? sel_bits(edgeR[j], uc[j], ur[j]) : ur[j];
-                            float af = (float)um[j] + (float)up[j];
-                            af = af + (float)nl;
-                            af = af + (float)nr;
-                            if constexpr (COUPLED) {
-                                af = af + (float)sel_bits(ch0[j], uc[j], ucl[j]);
-                                af = af + (float)sel_bits(chLast[j], uc[j], ucr[j]);
-                            }
-                            acc[j] = (T)af;
-                        }
-                    }
-                }
-            } else if constexpr (!EDGE && DXH_FUSE_DPP_ADDS) {
+            if constexpr (!EDGE && DXH_FUSE_DPP_ADDS) {
                 // interior strips: the lane shifts ride on the adds themselves (add_shifted_elem); neighbour elements
                 // that the channel selects need as values anyway keep their shared v_mov_dpp
                 static_for<0, N>([&](auto jc) {
@@ -2611,8 +2544,6 @@ struct Pipe {
 #pragma unroll
                     for (int j = 0; j < N; ++j) un[j] = rhs[j] / st.coef[s][1][j] + acc[j] / st.coef[s][2][j];
                 }
-            } else if constexpr (NP2) {
-                np2_div(rhs, acc, un);
             } else {
                 div_const(rhs, acc, un);
             }
@@ -2768,9 +2699,6 @@ __device__ __forceinline__ bool pipe_setup(PipeT& pp, const FusedArgs<T>& a, con
     pp.cdiag = a.c.const_diag != 0;
     pp.ci = a.ci;
     pp.kq_p = a.cp.kq;
-    pp.np2_first = a.np2_first != 0;
-    pp.ell_f = (float)a.c.ell;
-    pp.diag_f = (float)a.c.diag;
     return true;
 }
 
@@ -2861,11 +2789,6 @@ __device__ __forceinline__ void pipe_prologue(const PipeT& pp, PipeState<T, K>& 
         if constexpr (HET) {
             split_vars<T, 2, ISO, false>(qq, cfm[3][j], d, b);
             st.t0[0][1][j] = cfm[0][j] * (b[0] - d[0]);
-        } else if constexpr (PipeT::kNP2) {
-            float df, bf;
-            np2_split<!KQV>((double)qq[0], (double)(KQV ? kqm[j] : pp.kq), df, bf);
-            b[0] = (T)bf;
-            st.t0[0][1][j] = (T)(pp.ell_f * (bf - df));
         } else if constexpr (KQV) {
             split_vars<T, 2, ISO, false>(qq, kqm[j], d, b);
             st.t0[0][1][j] = pp.ell * (b[0] - d[0]);
@@ -2892,13 +2815,12 @@ __device__ __forceinline__ void pipe_write_partials(const FusedArgs<T>& a, IncT<
     }
 }
 
-template <typename T, int C, bool COUPLED, bool ISO, int K, bool NTS, bool EDGE, bool NORM, bool HET = false, bool KQV = false,
-          bool NP2 = false>
+template <typename T, int C, bool COUPLED, bool ISO, int K, bool NTS, bool EDGE, bool NORM, bool HET = false, bool KQV = false>
 __device__ __forceinline__ void fused_pipe_body(const FusedArgs<T>& a, const int strip, const int chunk, const int lane,
                                                 T* lds_lane, T* linc_lane) {
     constexpr int N = VecOf<T>::N;
     static_assert(!HET || K <= 3, "heterogeneous pipelines prefetch at distance 1 (K <= 3)");
-    using PipeT = Pipe<T, C, COUPLED, ISO, K, NTS, EDGE, NORM, HET, KQV, NP2>;
+    using PipeT = Pipe<T, C, COUPLED, ISO, K, NTS, EDGE, NORM, HET, KQV>;
     PipeT pp;
     pp.lds = lds_lane;
     pp.xlds = lds_lane;
@@ -3079,8 +3001,7 @@ __global__ void __launch_bounds__(256, DXH_PAIR_LB) k_fused_pair(FusedArgs<T> a)
 }
 #endif  // DXH_ENABLE_PAIR
 
-template <typename T, int C, bool COUPLED, bool ISO, int K, bool NORM = false, bool NTS = true, bool HET = false, bool KQV = false,
-          bool NP2 = false>
+template <typename T, int C, bool COUPLED, bool ISO, int K, bool NORM = false, bool NTS = true, bool HET = false, bool KQV = false>
 __global__ void __launch_bounds__(256, (pipe_waves<T, K, HET, ISO>())) k_fused_multi(FusedArgs<T> a) {
     constexpr int N = VecOf<T>::N;
     using SG = StripGeomK<T, C, K>;
@@ -3100,9 +3021,9 @@ __global__ void __launch_bounds__(256, (pipe_waves<T, K, HET, ISO>())) k_fused_m
     __shared__ T lds_inc[NORM ? WPB * K * kWave : 1];
     T* linc_lane = NORM ? lds_inc + (size_t)wave * (K * kWave) + lane : lds_inc;
     if (edge)
-        fused_pipe_body<T, C, COUPLED, ISO, K, NTS, true, NORM, HET, KQV, NP2>(a, strip, chunk, lane, lds_lane, linc_lane);
+        fused_pipe_body<T, C, COUPLED, ISO, K, NTS, true, NORM, HET, KQV>(a, strip, chunk, lane, lds_lane, linc_lane);
     else
-        fused_pipe_body<T, C, COUPLED, ISO, K, NTS, false, NORM, HET, KQV, NP2>(a, strip, chunk, lane, lds_lane, linc_lane);
+        fused_pipe_body<T, C, COUPLED, ISO, K, NTS, false, NORM, HET, KQV>(a, strip, chunk, lane, lds_lane, linc_lane);
     signal_chunk_done(a, chunk, lane);
 }
 

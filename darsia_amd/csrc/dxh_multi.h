@@ -26,24 +26,14 @@ void launch_multi_kernel_c24(int C, bool coupled, bool iso, bool want_inc, bool 
 #ifndef DXH_NP2_WAVES
 #define DXH_NP2_WAVES 3
 #endif
+#ifndef DXH_NP2_WAVES_KQV   // threshold-plane variant: K more threshold rows in registers (168 VGPRs spill 24 - 108 bytes per lane)
+#define DXH_NP2_WAVES_KQV 2
+#endif
 
-// the reference's float32 dtype flow (NP2 pipelines, double storage): K = 4 scalar threshold, K = kHetFuseK threshold plane
-template <int K>
-void launch_multi_kernel_np2(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
-extern template void launch_multi_kernel_np2<3>(int, bool, bool, const FusedArgs<double>&, unsigned, hipStream_t);
-extern template void launch_multi_kernel_np2<4>(int, bool, bool, const FusedArgs<double>&, unsigned, hipStream_t);
-
-extern template void launch_multi_kernel<float, 2>(int, bool, bool, bool, bool, const FusedArgs<float>&, unsigned, hipStream_t);
-extern template void launch_multi_kernel<float, 3>(int, bool, bool, bool, bool, const FusedArgs<float>&, unsigned, hipStream_t);
-extern template void launch_multi_kernel<float, 4>(int, bool, bool, bool, bool, const FusedArgs<float>&, unsigned, hipStream_t);
-extern template void launch_multi_kernel<double, 2>(int, bool, bool, bool, bool, const FusedArgs<double>&, unsigned, hipStream_t);
-extern template void launch_multi_kernel<double, 3>(int, bool, bool, bool, bool, const FusedArgs<double>&, unsigned, hipStream_t);
-extern template void launch_multi_kernel<double, 4>(int, bool, bool, bool, bool, const FusedArgs<double>&, unsigned, hipStream_t);
-extern template void launch_multi_kernel_c24<float, 2>(int, bool, bool, bool, bool, const FusedArgs<float>&, unsigned, hipStream_t);
-extern template void launch_multi_kernel_c24<float, 3>(int, bool, bool, bool, bool, const FusedArgs<float>&, unsigned, hipStream_t);
-extern template void launch_multi_kernel_c24<float, 4>(int, bool, bool, bool, bool, const FusedArgs<float>&, unsigned, hipStream_t);
-extern template void launch_multi_kernel_c24<double, 2>(int, bool, bool, bool, bool, const FusedArgs<double>&, unsigned, hipStream_t);
-extern template void launch_multi_kernel_c24<double, 3>(int, bool, bool, bool, bool, const FusedArgs<double>&, unsigned, hipStream_t);
-extern template void launch_multi_kernel_c24<double, 4>(int, bool, bool, bool, bool, const FusedArgs<double>&, unsigned, hipStream_t);
+// the reference's float32 dtype flow (numpy2 pipelines, dxh_np2_pipe.h; double planes): K = kNp2K for both the scalar-threshold
+// and the threshold-plane (kqv: array-valued mu) variant, C in {1, 3}.  Two objects (build.sh: np2_s, np2_q).
+constexpr int kNp2K = 4;
+void launch_multi_kernel_np2_scalar(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
+void launch_multi_kernel_np2_kqv(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
 
 }  // namespace dxh

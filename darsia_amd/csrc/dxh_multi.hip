@@ -20,31 +20,27 @@
 
 #ifdef DXH_MULTI_NP2
 // ---- the reference's float32 dtype flow (PipeNp2, dxh_np2_pipe.h): double planes, float32-valued state in float rings;
-// C in {1, 3}; K = 4 with a scalar threshold, K = kHetFuseK with the per-element threshold plane (array-valued mu) -- one
-// object per K (build.sh: np2_k3, np2_k4).  -DDXH_NP2_LEGACY: round 3's form inside the generic Pipe<double, ..., NP2> (A/B)
+// C in {1, 3}, K = kNp2K; -DDXH_MULTI_NP2=1: scalar threshold, -DDXH_MULTI_NP2=2: per-element threshold plane (array-valued
+// mu) -- one object each (build.sh: np2_s, np2_q)
 #include "dxh_np2_pipe.h"
 namespace dxh {
-template <int K>
-void launch_multi_kernel_np2(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream) {
-    constexpr bool KQV = (K == DXH_HET_K);
-#ifndef DXH_NP2_LEGACY
-#define DXH_NP2_K(C_, CP_)                                                                                                          \
-    do {                                                                                                                            \
-        if (want_inc) hipLaunchKernelGGL((k_fused_multi_np2<C_, CP_, K, true, KQV>), dim3(grid), dim3(256), 0, stream, a);          \
-        else hipLaunchKernelGGL((k_fused_multi_np2<C_, CP_, K, false, KQV>), dim3(grid), dim3(256), 0, stream, a);                  \
-    } while (0)
+#if DXH_MULTI_NP2 == 2
+#define DXH_NP2_KQV true
+void launch_multi_kernel_np2_kqv(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream) {
 #else
+#define DXH_NP2_KQV false
+void launch_multi_kernel_np2_scalar(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream) {
+#endif
+    constexpr int K = kNp2K;
 #define DXH_NP2_K(C_, CP_)                                                                                                          \
     do {                                                                                                                            \
-        if (want_inc) hipLaunchKernelGGL((k_fused_multi<double, C_, CP_, false, K, true, true, false, KQV, true>), dim3(grid), dim3(256), 0, stream, a);  \
-        else hipLaunchKernelGGL((k_fused_multi<double, C_, CP_, false, K, false, true, false, KQV, true>), dim3(grid), dim3(256), 0, stream, a);          \
+        if (want_inc) hipLaunchKernelGGL((k_fused_multi_np2<C_, CP_, K, true, DXH_NP2_KQV>), dim3(grid), dim3(256), 0, stream, a);  \
+        else hipLaunchKernelGGL((k_fused_multi_np2<C_, CP_, K, false, DXH_NP2_KQV>), dim3(grid), dim3(256), 0, stream, a);          \
     } while (0)
-#endif
     if (C == 1) { if (coupled) DXH_NP2_K(1, true); else DXH_NP2_K(1, false); }
     else        { if (coupled) DXH_NP2_K(3, true); else DXH_NP2_K(3, false); }
 #undef DXH_NP2_K
 }
-template void launch_multi_kernel_np2<DXH_MULTI_K>(int, bool, bool, const FusedArgs<double>&, unsigned, hipStream_t);
 }  // namespace dxh
 #else
 

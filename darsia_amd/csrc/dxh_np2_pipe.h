@@ -611,7 +611,7 @@ __device__ __forceinline__ void fused_np2_body(const FusedArgs<double>& a, const
 }
 
 template <int C, bool COUPLED, int K, bool NORM, bool KQV, bool NTS = true>
-__global__ void __launch_bounds__(256, DXH_NP2_WAVES) k_fused_multi_np2(FusedArgs<double> a) {
+__global__ void __launch_bounds__(256, (KQV ? DXH_NP2_WAVES_KQV : DXH_NP2_WAVES)) k_fused_multi_np2(FusedArgs<double> a) {
     constexpr int N = 2;
     using SG = StripGeomK<double, C, K>;
     using L = Np2Lds<K>;

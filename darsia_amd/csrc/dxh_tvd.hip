@@ -483,7 +483,7 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
             nchunks = std::max<int64_t>(1, target_blocks / nbx);
         } else {
             // blocks resident per CU (one wave of each per SIMD); the numpy2 pipelines have their own register budget
-            const int W = c->np2 ? DXH_NP2_WAVES : pipe_waves<T, K, false>();
+            const int W = c->np2 ? (kqv_pipe ? DXH_NP2_WAVES_KQV : DXH_NP2_WAVES) : pipe_waves<T, K, false>();
             // issue cost of one VALU instruction per SIMD with 1 / 2 / 3 / 4 waves taking turns (tools/valubench.hip)
             static const double cpi[5] = {0.0, 6.6, 3.7, 3.5, 3.2};  // 3: fitted to chunk sweeps of this kernel (a third wave adds ~8 %)
             const int64_t cu_per_xcd = std::max(1, c->num_cu / 8);
@@ -544,13 +544,12 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
         const float fd = (float)c->c_diag;
         if (std::isfinite(fd) && std::fabs(fd) >= 0x1p-20f && std::fabs(fd) <= 0x1p+20f && !(c->tune & 128))
             a.np2_div3 = div3_verified(c, fd, fd);
-        // the reference's float32 dtype flow: Pipe<..., NP2> (dxh_multi.hip, objects np2_k3 / np2_k4); pick_k only asks for
+        // the reference's float32 dtype flow: PipeNp2 (dxh_np2_pipe.h; dxh_multi.hip objects np2_s / np2_q); pick_k only asks for
         // the combinations that exist
-        if constexpr (std::is_same<T, double>::value && !ISO && (C == 1 || C == 3) && (K == 4 || K == kHetFuseK)) {
-            if ((K == kHetFuseK) == (a.kqv != 0)) {
-                launch_multi_kernel_np2<K>(C, COUPLED, want_inc, a, grid, c->stream);
-                return;
-            }
+        if constexpr (std::is_same<T, double>::value && !ISO && (C == 1 || C == 3) && K == kNp2K) {
+            if (a.kqv) launch_multi_kernel_np2_kqv(C, COUPLED, want_inc, a, grid, c->stream);
+            else launch_multi_kernel_np2_scalar(C, COUPLED, want_inc, a, grid, c->stream);
+            return;
         }
         c->no_kernel = true;   // never a silent no-op: the callers turn this into DXH_ESTATE (launched_or_fail)
         return;
@@ -574,11 +573,10 @@ static bool multi_supported(const Ctx* c) {
 // only, shorter remainders run as single-iteration sweeps)
 static int pick_k(const Ctx* c, int left) {
     if (c->np2) {
-        // the reference's float32 dtype flow: K = 4 (scalar threshold) / K = kHetFuseK (threshold plane) pipelines for 1 and
-        // 3 channels, remainders and other channel counts one iteration per launch (k_fused_np2)
+        // the reference's float32 dtype flow: K = kNp2K pipelines (scalar threshold or threshold plane) for 1 and 3 channels,
+        // remainders and other channel counts one iteration per launch (k_fused_np2)
         if (!(c->g.n2 == 1 || c->g.n2 == 3)) return 1;
-        if (c->het) return (c->fuse_k >= kHetFuseK && left >= kHetFuseK) ? kHetFuseK : 1;
-        return (c->fuse_k >= 4 && left >= 4) ? 4 : 1;
+        return (c->fuse_k >= kNp2K && left >= kNp2K) ? kNp2K : 1;
     }
     if (c->het) return (c->fuse_k >= kHetFuseK && left >= kHetFuseK) ? kHetFuseK : 1;
     return std::max(1, std::min(c->fuse_k, left));
@@ -1674,8 +1672,8 @@ static int run_slab_t(Ctx* c, int n_iter, int m, double eps, uint32_t flags, dxh
         if (fused_ok) {
             K = use_eps ? 1 : std::min(pick_k(c, left), cap);
             if (K >= 2 && !(dpp && multi_supported(c))) K = 1;
-            if (K >= 2 && c->het && K != kHetFuseK) K = 1;
-            if (K >= 2 && c->np2 && !c->het && K != 4) K = 1;   // numpy2 flow: the scalar pipeline exists for K = 4 only
+            if (K >= 2 && c->het && !c->np2 && K != kHetFuseK) K = 1;
+            if (K >= 2 && c->np2 && K != kNp2K) K = 1;   // numpy2 flow: the pipelines exist for K = kNp2K only
             const int in = c->cur, out = c->cur ^ 1;
             const bool xchg_after = dist && (c->halo_valid - (int64_t)K * m < m) &&
                                     (done + K < n_iter || (flags & DXH_FLAG_CONTINUE)) && !use_eps;

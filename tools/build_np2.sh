@@ -1,11 +1,11 @@
 #!/bin/bash
-# Developer: rebuild only the two numpy2 pipeline objects (np2_k3, np2_k4) and relink libdarsia_hip.so.  Extra args -> hipcc.
+# Developer: rebuild only the two numpy2 pipeline objects (np2_s, np2_q) and relink libdarsia_hip.so.  Extra args -> hipcc.
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")/../darsia_amd/csrc" && pwd)"
 F=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function "$@")
-/opt/rocm/bin/hipcc "${F[@]}" -DDXH_MULTI_T=double -DDXH_MULTI_K=4 -DDXH_MULTI_NP2=1 -c "${HERE}/dxh_multi.hip" -o "${HERE}/_build/np2_k4.o" &
+/opt/rocm/bin/hipcc "${F[@]}" -DDXH_MULTI_T=double -DDXH_MULTI_K=4 -DDXH_MULTI_NP2=1 -c "${HERE}/dxh_multi.hip" -o "${HERE}/_build/np2_s.o" &
 p1=$!
-/opt/rocm/bin/hipcc "${F[@]}" -DDXH_MULTI_T=double -DDXH_MULTI_K=3 -DDXH_MULTI_NP2=1 -c "${HERE}/dxh_multi.hip" -o "${HERE}/_build/np2_k3.o" &
+/opt/rocm/bin/hipcc "${F[@]}" -DDXH_MULTI_T=double -DDXH_MULTI_K=4 -DDXH_MULTI_NP2=2 -c "${HERE}/dxh_multi.hip" -o "${HERE}/_build/np2_q.o" &
 p2=$!
 wait $p1
 wait $p2
