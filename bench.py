@@ -56,9 +56,10 @@ FLOW = {
     "native": {"bytes_per_elem": 7 * 4, "dtype": "f32", "storage": "7 float32 planes",
                "kernel": "k_fused_multi<float,C=%d,coupled,aniso,K=%d>", "kernel1": "k_fused<float,C=%d,coupled,aniso,scalar>"},
     # the reference's flow under NumPy >= 2 (the product's DEFAULT for float32 images): u, q float64; d, b, rhs float32 values
-    "numpy2": {"bytes_per_elem": 7 * 8, "dtype": "f32 image, f64 iterate (mixed, as the reference under NumPy >= 2)",
-               "storage": "7 float64 planes",
-               "kernel": "k_fused_multi<double,C=%d,coupled,aniso,K=%d,NP2>", "kernel1": "k_fused_np2<C=%d,coupled,scalar>"},
+    # omega*img is read as a float32 plane (4 B), u / q0 / q1 are float64 planes read and written (6 x 8 B): 52 B
+    "numpy2": {"bytes_per_elem": 6 * 8 + 4, "dtype": "f32 image, f64 iterate (mixed, as the reference under NumPy >= 2)",
+               "storage": "6 float64 planes + omega*img as a float32 plane",
+               "kernel": "k_fused_multi_np2<C=%d,coupled,K=%d>", "kernel1": "k_fused_np2<C=%d,coupled,scalar>"},
 }
 
 
@@ -144,7 +145,7 @@ def roofline_block(flow: str, elems: float, channels: int, kernel_ms: float, lau
         "algorithmic_bytes_per_launch": per_launch,
         "ms_per_launch": round(ms_launch, 5),
         "launches_timed": launches,
-        "note": f"algorithmic bytes of ONE LAUNCH: {f['storage']} (read omega*f,u,q0,q1; write u,q0,q1) = "
+        "note": f"algorithmic bytes of ONE LAUNCH of the K-stage kernel: {f['storage']} (read omega*f,u,q0,q1; write u,q0,q1) = "
                 f"{f['bytes_per_elem']} B per pixel-channel, whatever the number K of outer iterations the launch fuses in "
                 "registers. SURVEY.md 8(d) prices the reference's own float32 state at 11 values = 44 B per pixel-channel per "
                 "ITERATION; against that accounting see survey_44B_per_iteration",

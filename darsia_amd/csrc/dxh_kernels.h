@@ -1042,10 +1042,15 @@ __global__ void __launch_bounds__(256) k_scale(Geom g, const T* __restrict__ a, 
 }
 
 // numpy2 flow: omega * img of a float32 image (held exactly in a float64 plane) is a float32 product
-static __global__ void __launch_bounds__(256) k_scale_np2(Geom g, const double* __restrict__ a, float s, double* __restrict__ out) {
+// out32 (optional): the same float32 products as a float32 plane of the same pitch -- what the K-stage numpy2 pipelines read
+// (4 instead of 8 bytes per element and launch)
+static __global__ void __launch_bounds__(256) k_scale_np2(Geom g, const double* __restrict__ a, float s, double* __restrict__ out,
+                                                          float* __restrict__ out32 = nullptr) {
     ElemIdx e;
     if (!elem_index(g, e)) return;
-    out[e.off] = (double)(s * (float)a[e.off]);
+    const float v = s * (float)a[e.off];
+    out[e.off] = (double)v;
+    if (out32) out32[e.off] = v;
 }
 
 template <typename T>
@@ -1392,6 +1397,7 @@ struct FusedArgs {
     int np2_first;     // NP2 pipelines (the reference's float32 dtype flow): u still holds the float32 image, so the neighbour
                        // sums of the launch's first iteration (stage 0) are float32 sums
     int np2_div3;      // NP2 pipelines: the three-operation float32 division rhs / diag is exact for this diag (k_div3_check)
+    const float* of32; // NP2 pipelines: omega * img as a float32 plane (same pitch in elements as `of`, whose values it holds)
 };
 
 // ALIGN: the lanes that store cover whole 128-byte lines (strip stride rounded down to a multiple of

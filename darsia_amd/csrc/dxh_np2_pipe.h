@@ -40,7 +40,8 @@ struct Np2State {
     float b0[K][2][N];
     double q0l[2][N], q1l[2][N];  // loaded level-0 q rows (current / prefetched)
     float of0[N];            // omega*img of stage 0's row
-    double pf[2][4][N];      // prefetch distance 2: rows in flight two steps ahead (u, omega*img, q0, q1)
+    double pf[2][4][N];      // prefetch distance 2: rows in flight two steps ahead (u, -, q0, q1)
+    float pff[2][N];         // ... and omega*img
     double kqv[K][N];        // KQV: the float64 threshold mu / ell of each stage's current row
     double kqn[N];
     bool kbad[K];            // KQV, wave-uniform: that row holds a threshold that is negative or NaN somewhere in the wave (the
@@ -115,7 +116,7 @@ struct PipeNp2 {
     static constexpr int N = 2;
     static constexpr int PFD = KQV ? 1 : DXH_NP2_PFD;   // the per-element threshold is prefetched at distance 1
     using L = Np2Lds<K>;
-    const double* of_p;
+    const float* of_p;   // omega * img, float32 plane (FusedArgs::of32)
     const double* u_in;
     const double* q0_in;
     const double* q1_in;
@@ -164,6 +165,12 @@ struct PipeNp2 {
     __device__ __forceinline__ double* at(double* plane, int64_t row) const {
         return reinterpret_cast<double*>(reinterpret_cast<char*>(plane + row * P) + voff);
     }
+    // the lane's two float32 values of a row of the omega * img plane (same pitch in elements, half the bytes)
+    __device__ __forceinline__ void load_of(int64_t row, float (&v)[N]) const {
+        const float2 t = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(of_p + row * P) + (voff >> 1));
+        v[0] = t.x;
+        v[1] = t.y;
+    }
     __device__ __forceinline__ void split(double q, double kqj, float& d, float& b) const {
         if constexpr (KQV) np2_split_fast(q, -kqj, kqj, d, b);
         else np2_split_fast(q, negkq, kq, d, b);
@@ -199,18 +206,18 @@ struct PipeNp2 {
     // ACT: stages 0 .. ACT - 1 run (the first steps of a chunk, fused_np2_body)
     template <int PH, int ACT = K>
     __device__ __forceinline__ void step(Np2State<K>& st, const int64_t r) const {
-        double frn[N];
+        float frn[N];
         if constexpr (PFD == 1) {
             const int64_t rn = clampr(r + 1);
             load_vec(at(u_in, clampr(r + 2)), st.U[0][(PH + 2) & 3]);
-            load_vec(at(of_p, rn), frn);
+            load_of(rn, frn);
             load_vec(at(q0_in, rn), st.q0l[(PH + 1) & 1]);
             load_vec(at(q1_in, rn), st.q1l[(PH + 1) & 1]);
             if constexpr (KQV) load_vec(at(kq_p, rn), st.kqn);
         } else {
             const int64_t rn = clampr(r + 2);
             load_vec(at(u_in, clampr(r + 3)), st.pf[PH & 1][0]);
-            load_vec(at(of_p, rn), st.pf[PH & 1][1]);
+            load_of(rn, st.pff[PH & 1]);
             load_vec(at(q0_in, rn), st.pf[PH & 1][2]);
             load_vec(at(q1_in, rn), st.pf[PH & 1][3]);
         }
@@ -429,13 +436,13 @@ struct PipeNp2 {
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 st.U[0][(PH + 2) & 3][j] = st.pf[(PH + 1) & 1][0][j];
-                frn[j] = st.pf[(PH + 1) & 1][1][j];
+                frn[j] = st.pff[(PH + 1) & 1][j];
                 st.q0l[(PH + 1) & 1][j] = st.pf[(PH + 1) & 1][2][j];
                 st.q1l[(PH + 1) & 1][j] = st.pf[(PH + 1) & 1][3][j];
             }
         }
 #pragma unroll
-        for (int j = 0; j < N; ++j) st.of0[j] = (float)frn[j];   // the plane holds float32 values: exact
+        for (int j = 0; j < N; ++j) st.of0[j] = frn[j];
     }
 };
 
@@ -476,7 +483,7 @@ __device__ __forceinline__ void fused_np2_body(const FusedArgs<double>& a, const
         pp.aCL[j] = lds_wave + L::elem_off(cc == 0 ? e : e - 1);
         pp.aCR[j] = lds_wave + L::elem_off(cc == C - 1 ? e : e + 1);
     }
-    pp.of_p = a.of;
+    pp.of_p = a.of32;
     pp.u_in = a.u_in;
     pp.q0_in = a.q0_in;
     pp.q1_in = a.q1_in;
@@ -539,16 +546,15 @@ __device__ __forceinline__ void fused_np2_body(const FusedArgs<double>& a, const
     // recomputed from the stored q0
     const int64_t rs = pp.R0 - (K - 1);
     {
-        double ofd[N];
         load_vec(pp.at(pp.u_in, pp.clampr(rs - 1)), st.U[0][3]);
         load_vec(pp.at(pp.u_in, pp.clampr(rs)), st.U[0][0]);
         load_vec(pp.at(pp.u_in, pp.clampr(rs + 1)), st.U[0][1]);
-        load_vec(pp.at(pp.of_p, pp.clampr(rs)), ofd);
+        pp.load_of(pp.clampr(rs), st.of0);
         load_vec(pp.at(pp.q0_in, pp.clampr(rs)), st.q0l[0]);
         load_vec(pp.at(pp.q1_in, pp.clampr(rs)), st.q1l[0]);
         if constexpr (PipeT::PFD == 2) {
             load_vec(pp.at(pp.u_in, pp.clampr(rs + 2)), st.pf[1][0]);
-            load_vec(pp.at(pp.of_p, pp.clampr(rs + 1)), st.pf[1][1]);
+            pp.load_of(pp.clampr(rs + 1), st.pff[1]);
             load_vec(pp.at(pp.q0_in, pp.clampr(rs + 1)), st.pf[1][2]);
             load_vec(pp.at(pp.q1_in, pp.clampr(rs + 1)), st.pf[1][3]);
         }
@@ -567,7 +573,6 @@ __device__ __forceinline__ void fused_np2_body(const FusedArgs<double>& a, const
             else pp.split(q0v[j], pp.kq, df, bf);
             st.t0[0][1][j] = pp.ell_f * (bf - df);   // parity "prv" of phase 0
             st.b0[0][1][j] = bf;
-            st.of0[j] = (float)ofd[j];
         }
     }
     const int64_t r_end = pp.R1 + (K - 1);

@@ -109,6 +109,8 @@ struct Ctx {
 
     // ---- the reference's NumPy >= 2 dtype flow for a float32 image (dxh_tvd_set_promotion; k_fused_np2) ----
     bool np2 = false;            // double context whose planes hold the reference's mixed float32 / float64 state
+    void* of32 = nullptr;        // numpy2, scalar omega: omega * img once more as a float32 plane (read by the K-stage pipelines)
+    bool of32_valid = false;
     bool np2_first = true;       // u still is the float32 image (first iteration after an upload)
     bool np2_mu_is_kq = false;   // the given mu array already is the threshold mu / ell (float32 quotient, widened)
     bool ell_is_arr = false, om_is_arr = false;   // set_coeffs: ell (given, or 2 mu) / omega is an array
@@ -538,7 +540,10 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
     a.derive = (c->het && !a.kqv) ? 1 : 0;  // array coefficients (multi_supported: only with the given planes at hand, K = kHetFuseK)
     a.np2_first = (c->np2 && c->np2_first) ? 1 : 0;
     a.np2_div3 = 0;
+    a.of32 = nullptr;
     if (c->np2) {
+        if (!c->of32_valid) { c->no_kernel = true; return; }   // (cannot happen: every upload of a scalar-omega numpy2 context fills it)
+        a.of32 = (const float*)c->of32;
         // rhs / diag is a float32 division by the float32-rounded Python float: three operations through the reciprocal
         // where the exhaustive check says so for this divisor (remembered per divisor), five otherwise
         const float fd = (float)c->c_diag;
@@ -2008,7 +2013,7 @@ int dxh_tvd_destroy(dxh_tvd_t h) {
     comm_release(c->comm);
     delete c->solver;
     auto fr = [](void* p) { pool_free(p); };   // planes go back to the cache, anything else to the runtime
-    fr(c->of); fr(c->u[0]); fr(c->u[1]); fr(c->rs);
+    fr(c->of); fr(c->u[0]); fr(c->u[1]); fr(c->rs); fr(c->of32);
     for (int j = 0; j < 3; ++j) { fr(c->q[j][0]); fr(c->q[j][1]); fr(c->dpl[j]); fr(c->bpl[j]); }
     fr(c->in_mu); fr(c->in_om); fr(c->in_ell);
     fr(c->cp_ell); fr(c->cp_diag); fr(c->cp_dsc); fr(c->cp_kq); fr(c->om_plane); fr(c->mu_plane); fr(c->base_img); fr(c->clean_filter); fr(c->probe_buf); fr(c->stage); fr(c->partial); fr(c->red_out); fr(c->inc_partial);
@@ -2131,13 +2136,20 @@ static int finish_upload(Ctx* c, const void* u0, const void* d0, const void* b0,
     if (f32)
         hipLaunchKernelGGL((k_scale<float>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const float*)c->u[0],
                            (float)c->omega_s, om_arr ? (const float*)c->om_plane : nullptr, (float*)c->of);
-    else if (c->np2 && !om_arr)   // np.multiply(omega, img) on the float32 image: a float32 product, kept in the float64 plane
+    else if (c->np2 && !om_arr) {  // np.multiply(omega, img) on the float32 image: a float32 product, kept in the float64 plane
+        if (!c->of32) {             // ... and as a float32 plane for the K-stage pipelines
+            DXH_HIP(pool_malloc(&c->of32, c->plane_bytes / 2));
+            DXH_HIP(hipMemsetAsync(c->of32, 0, c->plane_bytes / 2, c->stream));
+        }
         hipLaunchKernelGGL(k_scale_np2, elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const double*)c->u[0],
-                           (float)c->omega_s, (double*)c->of);
+                           (float)c->omega_s, (double*)c->of, (float*)c->of32);
+        c->of32_valid = true;
+    }
     else
         hipLaunchKernelGGL((k_scale<double>), elem_grid(c->g), dim3(256), 0, c->stream, c->g, (const double*)c->u[0],
                            c->omega_s, om_arr ? (const double*)c->om_plane : nullptr, (double*)c->of);
     DXH_HIP(hipGetLastError());
+    if (!(c->np2 && !om_arr)) c->of32_valid = false;
     c->np2_first = true;
     c->np2_q32 = false;
     if (c->np2) DXH_REQUIRE(!u0 && !d0, "numpy2 promotion: no warm start");   // (a float64 omega array: a float64 product, the branch above)

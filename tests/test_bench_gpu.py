@@ -44,7 +44,7 @@ def test_single_gpu_line_has_contract_fields():
     # (at this launch-bound test size the two flows take about the same time; at the benchmark size native is ~2 x faster)
     o = d["other_flow"]
     assert o["promotion"] == "numpy2" and 0 < o["value"] < 2 * d["value"] and o["steps"] == 2
-    assert o["roofline"]["bound"] == "hbm" and 0 < o["roofline"]["frac"] < 1.5 and "NP2" in o["roofline"]["kernel"]
+    assert o["roofline"]["bound"] == "hbm" and 0 < o["roofline"]["frac"] < 1.5 and "np2" in o["roofline"]["kernel"]
     assert o["roofline"]["algorithmic_bytes_per_launch"] > d["roofline"]["algorithmic_bytes_per_launch"]
     assert d["self_check"]["bit_identical_to_k1_replay"] is True and o["self_check"]["bit_identical_to_k1_replay"] is True
     assert d["self_check"]["sha256_of_result"] != o["self_check"]["sha256_of_result"]
