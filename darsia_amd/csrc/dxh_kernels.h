@@ -1733,6 +1733,8 @@ struct Np2Coef {
     const double* ell_plane = nullptr;  // adaptive schedule (explicit d, b): ell per element, float32 values (k_adapt_ell_np2)
     int q32 = 0;     // the stored q was formed in float32 (np2_dub with u32): a scalar threshold then met a float32 array in the
                      // reference, i.e. its shrinkage ran in float32 arithmetic
+    double rdsc = 0.0;   // k_shrink_rhs_np2: RN(1 / dsc) and RN(1 / diag) for the reciprocal divisions (0: IEEE divisions)
+    float rdiag = 0.0f;
 };
 
 // FAST (callers guarantee k >= 0: the scalar threshold of a fused launch): q - clamp(q, -k, k), which is
@@ -1866,6 +1868,68 @@ __global__ void __launch_bounds__(256) k_shrink_np2(Geom g, const double* __rest
         else np2_split_q<KQARR>(q.in[j][e.off], kq, k.q32, d, b);
         q.out[j][e.off] = np2_dub(unew[nb_off(g, e, j, +1)], uc, b, u32);
     }
+}
+
+// ---- shrinkage of iteration n, right-hand side of iteration n + 1 and its first Jacobi sweep in ONE pass ---------------------
+// The three-launch flow streams ~19 values of 8 B per element and iteration; most of them are q and u read twice: by the
+// shrinkage (q_j <- D_j u_new + b_j) and again by the next right-hand side (t_j = ell (b_j - d_j) of that q_j at the element
+// and at its lower neighbour along j), whose first sweep x_1 = rs + N(u_new) / diag_scaled then reads u_new a third time.
+// Here a thread forms the new q_j at its element AND at the lower neighbour along each axis (the same expression, so the
+// value the neighbour's thread stores is the value used here), the float32 right-hand side, rs = rhs / diag, and x_1 --
+// k_shrink_np2, k_rhs_np2 and the first sweep with the operations and their order unchanged.  q is read from the `in`
+// buffers and written to the `out` buffers (other threads still read the old values of this thread's element).
+// Scalar omega and ell (mu: scalar or the threshold plane), float64 iterate (not the first iteration of a call), no warm
+// start planes: what every iteration of a numpy2 context after the first looks like.  rs is written only when more sweeps
+// follow (WRITE_RS); with Jacobi(maxiter=1) x_1 already is the next iterate.
+//   bytes per element, dim = 2: u 8 + q 16 + omega*img 4 read, q 16 + x_1 8 (+ rs 8) written = 52 (60); the three launches
+//   it replaces: 32 (rhs) + 24 (sweep) + 40 (shrinkage) = 96
+// FASTK: a scalar threshold k >= 0 (checked on the host): the clamp form of the shrinkage (np2_split<true>)
+template <int DIM, bool KQARR, bool WRITE_RS, bool FASTK>
+__global__ void __launch_bounds__(256) k_shrink_rhs_np2(Geom g, const double* __restrict__ unew, QPlanes<double, DIM> q,
+                                                         const float* __restrict__ of32, Np2Coef k, double* __restrict__ rs,
+                                                         double* __restrict__ x1) {
+    ElemIdx e;
+    if (!elem_index(g, e)) return;
+    const double kq_c = KQARR ? k.kq_plane[e.off] : k.kq;
+    const double uc = unew[e.off];
+    float r = of32[e.off];
+#pragma unroll
+    for (int j = 0; j < DIM; ++j) {
+        float d, b;
+        np2_split<FASTK>(q.in[j][e.off], kq_c, d, b);                                // the old b_j here (k_shrink_np2)
+        const double qe = np2_dub(unew[nb_off(g, e, j, +1)], uc, b, 0);
+        q.out[j][e.off] = qe;
+        np2_split<FASTK>(qe, kq_c, d, b);                                            // k_rhs_np2 on the new state
+        const float tc = k.ell * (b - d);
+        const int64_t o = nb_off(g, e, j, -1);
+        float tn = tc;
+        if (o != e.off) {   // the lower neighbour's new q_j: its upper neighbour along j is this element
+            const double kq_o = KQARR ? k.kq_plane[o] : k.kq;
+            np2_split<FASTK>(q.in[j][o], kq_o, d, b);
+            const double qo = np2_dub(uc, unew[o], b, 0);
+            np2_split<FASTK>(qo, kq_o, d, b);
+            tn = k.ell * (b - d);
+        }
+        r = r + (tc - tn);
+    }
+    double acc = 0.0;   // k_jacobi<double> on the float64 iterate
+    for (int ax = 0; ax < g.nsum_axes; ++ax) {
+        acc = acc + unew[nb_off(g, e, ax, -1)];
+        acc = acc + unew[nb_off(g, e, ax, +1)];
+    }
+    // both quotients are correctly rounded either way: through the host-rounded reciprocals with two residual corrections
+    // (dxh_common.h, div_by_const) unless a numerator is non-zero and tiny, or the divisor was outside the comfortable range
+    float rsv;
+    double qa;
+    if (k.rdsc != 0.0 && !div_unsafe(r) && !div_unsafe(acc)) {
+        rsv = div_by_const<float>(r, k.diag, k.rdiag);
+        qa = div_by_const<double>(acc, k.dsc, k.rdsc);
+    } else {
+        rsv = r / k.diag;
+        qa = acc / k.dsc;
+    }
+    if constexpr (WRITE_RS) rs[e.off] = (double)rsv;
+    x1[e.off] = (double)rsv + qa;
 }
 
 // ---- explicit split variables in the numpy2 flow (the adaptive schedule, split_bregman_tvd.py:149-158): d and b are planes

@@ -111,6 +111,10 @@ struct Ctx {
     bool np2 = false;            // double context whose planes hold the reference's mixed float32 / float64 state
     void* of32 = nullptr;        // numpy2, scalar omega: omega * img once more as a float32 plane (read by the K-stage pipelines)
     bool of32_valid = false;
+    // numpy2, three-launch flow: the previous iteration's fused pass (k_shrink_rhs_np2) has already formed this iteration's rs
+    // and its first sweep; np2_pre_x = where that first sweep's result lives (u[cur ^ 1] or the sweep scratch plane)
+    bool np2_pre = false;
+    void* np2_pre_x = nullptr;
     bool np2_first = true;       // u still is the float32 image (first iteration after an upload)
     bool np2_mu_is_kq = false;   // the given mu array already is the threshold mu / ell (float32 quotient, widened)
     bool ell_is_arr = false, om_is_arr = false;   // set_coeffs: ell (given, or 2 mu) / omega is an array
@@ -979,8 +983,14 @@ static void launch_jacobi_multi(Ctx* c, const void* xin, void* xout, int K) {
 // Needs a third buffer for sweeps > 1: `tmp`.
 // first_f32 (numpy2 flow, double context): x0 still is the float32 image, whose neighbours the reference sums in float32
 // in the first sweep (k_jacobi_np2_first); every later sweep is the context's own.
+// passes jacobi_sweeps needs for `sweeps` sweeps without a tolerance (its grouping rule: 5 = 3 + 2, else fours, a last single)
+static int jacobi_passes(const Ctx* c, int sweeps, bool first_f32);
+
+// started: the first sweep has been done already (by k_shrink_rhs_np2) and its result lives in `started` -- u[cur ^ 1] when the
+// remaining passes are even in number, `tmp` when they are odd (np2_pre_target), so that the last pass lands in u[cur ^ 1]
 template <typename T>
-static int jacobi_sweeps(Ctx* c, int maxiter, double tol, void* tmp, int64_t* launches, int* sweeps_done, bool first_f32 = false) {
+static int jacobi_sweeps(Ctx* c, int maxiter, double tol, void* tmp, int64_t* launches, int* sweeps_done, bool first_f32 = false,
+                         const void* started = nullptr) {
     const int in = c->cur, out = c->cur ^ 1;
     const bool use_tol = tol >= 0.0 && !std::isnan(tol);
     double nrm0 = 0.0;
@@ -994,7 +1004,12 @@ static int jacobi_sweeps(Ctx* c, int maxiter, double tol, void* tmp, int64_t* la
     void* bufs[2] = {c->u[out], tmp};
     int w = 0, done = 0;
     bool stop = false;
-    if (!use_tol && tmp) {
+    if (started) {
+        x = started;
+        w = started == c->u[out] ? 1 : 0;   // the next pass writes the other buffer
+        done = 1;
+        --maxiter;
+    } else if (!use_tol && tmp) {
         // without a tolerance the number of passes is known: start in the buffer that makes the last one land in u[out]
         // (no plane copy at the end; with a tolerance the stop is not known in advance)
         int left = maxiter, passes = 0;
@@ -1053,6 +1068,14 @@ static int jacobi_sweeps(Ctx* c, int maxiter, double tol, void* tmp, int64_t* la
     if (x != c->u[out]) DXH_HIP(hipMemcpyAsync(c->u[out], x, c->plane_bytes, hipMemcpyDeviceToDevice, c->stream));
     if (sweeps_done) *sweeps_done = done;
     return DXH_OK;
+}
+
+static int jacobi_passes(const Ctx* c, int sweeps, bool first_f32) {
+    int left = sweeps, passes = 0;
+    if (first_f32 && left >= 1) { ++passes; --left; }
+    if (left >= 2 && jacobi_multi_supported(c))
+        while (left >= 2) { left -= (left == 5 ? 3 : std::min(4, left)); ++passes; }
+    return passes + left;
 }
 
 // the u-update of one outer iteration: Jacobi sweeps, or the plugged-in solver on (u[cur], rhs) -> u[cur ^ 1]
@@ -1127,7 +1150,7 @@ static int launch_np2(Ctx* c, int in, int out) {
 // numpy2 flow outside the fused sweeps (dim = 3, more than four channels, several Jacobi sweeps): right-hand side, sweeps,
 // shrinkage as three kinds of launches on the double context; u[cur] -> u[cur ^ 1], q updated in place
 template <int DIM>
-static int np2_generic_iteration(Ctx* c, int maxiter, double tol, void* tmp, int64_t* launches) {
+static int np2_generic_iteration(Ctx* c, int maxiter, double tol, void* tmp, int64_t* launches, bool more) {
     const int in = c->cur, out = c->cur ^ 1;
     const dim3 grid = elem_grid(c->g), blk(256);
     const Np2Coef k = np2_coef(c);
@@ -1135,6 +1158,13 @@ static int np2_generic_iteration(Ctx* c, int maxiter, double tol, void* tmp, int
     const bool fdb = c->from_db;   // first iteration of a warm start: d, b are explicit planes (float32 values)
     auto db = make_db<double>(c);
     if (fdb) DXH_REQUIRE(!c->het || c->het_cdiag, "numpy2 promotion: a warm start needs scalar omega and ell");
+    int swept = 0;
+    if (c->np2_pre) {
+        // rs and the first sweep of this iteration came out of the previous iteration's fused pass
+        c->np2_pre = false;
+        int rc = jacobi_sweeps<double>(c, maxiter, tol, tmp, launches, &swept, false, c->np2_pre_x);
+        if (rc) return rc;
+    } else {
     if (c->het && !c->het_cdiag) {   // array-valued omega and / or ell: float64 enters the right-hand side (k_rhs_np2_het)
         Np2Het hk{};
         hk.ell_p = c->ell_is_arr ? (const double*)c->cp_ell : nullptr;
@@ -1154,12 +1184,47 @@ static int np2_generic_iteration(Ctx* c, int maxiter, double tol, void* tmp, int
     else if (k.kq_plane) hipLaunchKernelGGL((k_rhs_np2<DIM, true>), grid, blk, 0, c->stream, c->g, (const double*)c->of, q, db, k, (double*)c->rs);
     else hipLaunchKernelGGL((k_rhs_np2<DIM, false>), grid, blk, 0, c->stream, c->g, (const double*)c->of, q, db, k, (double*)c->rs);
     ++*launches;
-    int swept = 0;
     int rc = jacobi_sweeps<double>(c, maxiter, tol, tmp, launches, &swept, c->np2_first);
     if (rc) return rc;
+    }
     // the solver handed the float32 iterate itself back (tolerance met by the first sweep of a call): float32 D u + b
     const int u32 = (c->np2_first && swept == 0) ? 1 : 0;
-    if (fdb) {
+    // Another iteration follows in this call and it is an ordinary one (scalar omega / ell, float64 iterate, no tolerance):
+    // shrinkage, the next right-hand side and its first sweep in one pass (k_shrink_rhs_np2); q goes to the `out` buffers.
+    // (DXH_FUSED_TUNE bit 524288: the three launches, A/B)
+    const bool use_tol = tol >= 0.0 && !std::isnan(tol);
+    // Measured (profiles/r04_np2_generic.txt): volumes gain at every sweep count (256^3, one sweep: 0.47 -> 0.34 ms per
+    // iteration, 12 launches instead of 30); 2-D gains little (five sweeps 2.50 -> 2.43 ms: the K-sweep pass behind it is what
+    // costs) and loses at exactly two sweeps, where the fused first sweep breaks up the two-sweep pass -- left unfused
+    const bool fuse = more && !fdb && !u32 && !k.q32 && !use_tol && (!c->het || c->het_cdiag) && c->of32_valid && !(c->tune & 524288) &&
+                      (maxiter == 1 || tmp) && (DIM == 3 || maxiter != 2);
+    if (fuse) {
+        // where the first sweep of the next iteration goes: its u[cur ^ 1] is this iteration's u[in]; the remaining sweeps
+        // alternate between that plane and tmp and must end in it
+        const int rest = jacobi_passes(c, maxiter - 1, false);
+        void* x1 = (rest % 2 == 0) ? c->u[in] : tmp;
+        auto q2 = make_q<double, DIM>(c, in, out);
+        Np2Coef kf = k;
+        auto okd = [](double d) { return std::isfinite(d) && std::fabs(d) >= 0x1p-20 && std::fabs(d) <= 0x1p+20; };
+        if (okd(k.dsc) && okd((double)k.diag)) { kf.rdsc = 1.0 / k.dsc; kf.rdiag = 1.0f / k.diag; }
+        const bool fastk = !k.kq_plane && k.kq >= 0.0;
+#define DXH_SR(KQ_, WR_, FK_) hipLaunchKernelGGL((k_shrink_rhs_np2<DIM, KQ_, WR_, FK_>), grid, blk, 0, c->stream, c->g, (const double*)c->u[out], q2, (const float*)c->of32, kf, (double*)c->rs, (double*)x1)
+        if (maxiter > 1) {
+            if (k.kq_plane) DXH_SR(true, true, false);
+            else if (fastk) DXH_SR(false, true, true);
+            else DXH_SR(false, true, false);
+        } else {
+            if (k.kq_plane) DXH_SR(true, false, false);
+            else if (fastk) DXH_SR(false, false, true);
+            else DXH_SR(false, false, false);
+        }
+#undef DXH_SR
+        c->np2_pre = true;
+        c->np2_pre_x = x1;
+        // the caller swaps q[.][in] and q[.][out] (in-place convention of the three launches): undo by swapping here
+        for (int j = 0; j < DIM; ++j) std::swap(c->q[j][in], c->q[j][out]);
+    }
+    else if (fdb) {
         if (k.kq_plane) hipLaunchKernelGGL((k_shrink_np2<DIM, true, true>), grid, blk, 0, c->stream, c->g, (const double*)c->u[out], q, db, k, u32);
         else hipLaunchKernelGGL((k_shrink_np2<DIM, false, true>), grid, blk, 0, c->stream, c->g, (const double*)c->u[out], q, db, k, u32);
     }
@@ -1226,6 +1291,7 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
     const bool use_tol = jacobi_tol >= 0.0 && !std::isnan(jacobi_tol);
     c->signalling = false;  // only dxh_tvd_run_slab builds signalling launches
     c->row_lo = c->row_hi = 0;
+    c->np2_pre = false;     // nothing prepared by an earlier call survives (halo exchanges, new coefficients, downloads between calls)
     const bool dpp = !(flags & DXH_FLAG_NO_DPP);
     bool fused_ok = fused_supported(c) && jacobi_maxiter == 1 && !use_tol && !(flags & DXH_FLAG_NO_FUSED) && !c->solver;
     const int dim = c->desc.dim;
@@ -1393,8 +1459,11 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
             ++launches;
             c->cur = out;
         } else if (c->np2) {   // np2_generic, or the first iteration of a warm start
-            int rc = dim == 2 ? np2_generic_iteration<2>(c, jacobi_maxiter, jacobi_tol, tmp, &launches)
-                              : np2_generic_iteration<3>(c, jacobi_maxiter, jacobi_tol, tmp, &launches);
+            // (with an eps test the previous iterate must survive the iteration: its plane is where the fused pass would put
+            // the next first sweep)
+            const bool more = it + 1 < n_iter && !use_eps;
+            int rc = dim == 2 ? np2_generic_iteration<2>(c, jacobi_maxiter, jacobi_tol, tmp, &launches, more)
+                              : np2_generic_iteration<3>(c, jacobi_maxiter, jacobi_tol, tmp, &launches, more);
             if (rc) return rc;
             for (int j = 0; j < dim; ++j) std::swap(c->q[j][in], c->q[j][out]);
             c->cur = out;
