@@ -205,6 +205,9 @@ def _fingerprint(value):
         flat = value.reshape(-1) if value.flags.c_contiguous else value.ravel()
         step = max(1, flat.size // 4096)
         return ("array", id(value), value.shape, value.dtype.str, float(np.sum(flat[::step], dtype=np.float64)))
+    if isinstance(value, DeviceArray):
+        # a device-resident array: identity only (its contents cannot be sampled without a download; same contract)
+        return ("device", id(value), value.shape, value.dtype.str, value.ptr)
     return ("scalar", None if value is None else float(value))
 
 

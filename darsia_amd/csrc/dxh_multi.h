@@ -31,9 +31,12 @@ void launch_multi_kernel_c24(int C, bool coupled, bool iso, bool want_inc, bool 
 #endif
 
 // the reference's float32 dtype flow (numpy2 pipelines, dxh_np2_pipe.h; double planes): K = kNp2K for both the scalar-threshold
-// and the threshold-plane (kqv: array-valued mu) variant, C in {1, 3}.  Two objects (build.sh: np2_s, np2_q).
+// and the threshold-plane (kqv: array-valued mu) variant, C in {1, 3}; scalar threshold also for C in {2, 4}.  Three objects
+// (build.sh: np2_s, np2_q, np2_s24).
 constexpr int kNp2K = 4;
 void launch_multi_kernel_np2_scalar(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
+// ... C in {2, 4}, scalar threshold (object np2_s24)
+void launch_multi_kernel_np2_scalar_c24(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
 void launch_multi_kernel_np2_kqv(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
 
 }  // namespace dxh

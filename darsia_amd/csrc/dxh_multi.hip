@@ -27,6 +27,9 @@ namespace dxh {
 #if DXH_MULTI_NP2 == 2
 #define DXH_NP2_KQV true
 void launch_multi_kernel_np2_kqv(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream) {
+#elif DXH_MULTI_CSET == 1
+#define DXH_NP2_KQV false
+void launch_multi_kernel_np2_scalar_c24(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream) {
 #else
 #define DXH_NP2_KQV false
 void launch_multi_kernel_np2_scalar(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream) {
@@ -37,8 +40,13 @@ void launch_multi_kernel_np2_scalar(int C, bool coupled, bool want_inc, const Fu
         if (want_inc) hipLaunchKernelGGL((k_fused_multi_np2<C_, CP_, K, true, DXH_NP2_KQV>), dim3(grid), dim3(256), 0, stream, a);  \
         else hipLaunchKernelGGL((k_fused_multi_np2<C_, CP_, K, false, DXH_NP2_KQV>), dim3(grid), dim3(256), 0, stream, a);          \
     } while (0)
+#if DXH_MULTI_CSET == 1
+    if (C == 2) { if (coupled) DXH_NP2_K(2, true); else DXH_NP2_K(2, false); }
+    else        { if (coupled) DXH_NP2_K(4, true); else DXH_NP2_K(4, false); }
+#else
     if (C == 1) { if (coupled) DXH_NP2_K(1, true); else DXH_NP2_K(1, false); }
     else        { if (coupled) DXH_NP2_K(3, true); else DXH_NP2_K(3, false); }
+#endif
 #undef DXH_NP2_K
 }
 }  // namespace dxh

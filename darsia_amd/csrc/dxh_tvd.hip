@@ -117,6 +117,7 @@ struct Ctx {
     void* np2_pre_x = nullptr;
     bool np2_first = true;       // u still is the float32 image (first iteration after an upload)
     bool np2_mu_is_kq = false;   // the given mu array already is the threshold mu / ell (float32 quotient, widened)
+    bool np2_mu_auto = false;    // ... because dxh_tvd_set_coeffs_typed formed that quotient itself from a float32 mu array
     bool ell_is_arr = false, om_is_arr = false;   // set_coeffs: ell (given, or 2 mu) / omega is an array
     bool np2_q32 = false;        // the stored q was formed in float32 (the solver handed the float32 iterate back): Np2Coef::q32
     bool np2_adapted = false;    // dxh_tvd_adapt_ell on a numpy2 context: cp_ell / cp_kq hold the adapted float32 ell and threshold
@@ -560,6 +561,12 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
             else launch_multi_kernel_np2_scalar(C, COUPLED, want_inc, a, grid, c->stream);
             return;
         }
+        if constexpr (std::is_same<T, double>::value && !ISO && (C == 2 || C == 4) && K == kNp2K) {
+            if (!c->het) {   // two / four channels: the scalar-threshold pipeline (a threshold plane: one iteration per launch)
+                launch_multi_kernel_np2_scalar_c24(C, COUPLED, want_inc, a, grid, c->stream);
+                return;
+            }
+        }
         c->no_kernel = true;   // never a silent no-op: the callers turn this into DXH_ESTATE (launched_or_fail)
         return;
     }
@@ -582,9 +589,9 @@ static bool multi_supported(const Ctx* c) {
 // only, shorter remainders run as single-iteration sweeps)
 static int pick_k(const Ctx* c, int left) {
     if (c->np2) {
-        // the reference's float32 dtype flow: K = kNp2K pipelines (scalar threshold or threshold plane) for 1 and 3 channels,
-        // remainders and other channel counts one iteration per launch (k_fused_np2)
-        if (!(c->g.n2 == 1 || c->g.n2 == 3)) return 1;
+        // the reference's float32 dtype flow: K = kNp2K pipelines -- scalar threshold for 1 - 4 channels, threshold plane for 1
+        // and 3 --, remainders one iteration per launch (k_fused_np2)
+        if (!(c->g.n2 == 1 || c->g.n2 == 3) && c->het) return 1;
         return (c->fuse_k >= kNp2K && left >= kNp2K) ? kNp2K : 1;
     }
     if (c->het) return (c->fuse_k >= kHetFuseK && left >= kHetFuseK) ? kHetFuseK : 1;
@@ -2155,6 +2162,12 @@ int dxh_tvd_set_coeffs(dxh_tvd_t h, double mu, const void* mu_arr, double omega,
     return DXH_OK;
 }
 
+// float32 mu array / float32(ell), widened: what NumPy makes of  float32_array / python_float  (the quotient is float32)
+__global__ void __launch_bounds__(256) k_convert_div_dense(const float* __restrict__ src, float ell, double* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = (double)(src[i] / ell);
+}
+
 int dxh_tvd_set_coeffs_typed(dxh_tvd_t h, double mu, const void* mu_arr, int mu_dtype, double omega, const void* omega_arr,
                              int omega_dtype, int has_ell, double ell, const void* ell_arr, int ell_dtype) {
     Ctx* c = reinterpret_cast<Ctx*>(h);
@@ -2165,7 +2178,29 @@ int dxh_tvd_set_coeffs_typed(dxh_tvd_t h, double mu, const void* mu_arr, int mu_
     DevTmp raw[3], conv[3];
     const void* arrs[3] = {mu_arr, omega_arr, ell_arr};
     const int dts[3] = {mu_dtype, omega_dtype, ell_dtype};
+    // numpy2 context, float32 mu array (host or device) next to scalar omega and ell: the reference's threshold mu / ell is a
+    // float32 quotient (split_bregman_tvd.py:144 with a float32 array and a Python float) -- formed here, on the device, and
+    // handed on as the threshold itself (DXH_PROMOTION_MU_IS_THRESHOLD's meaning, set for this coefficient set only)
+    const bool mu_div = c->np2 && mu_arr && mu_dtype == DXH_F32 && !omega_arr && !ell_arr && has_ell &&
+                        !(c->np2_mu_is_kq && !c->np2_mu_auto);   // (not when the caller said the array already is the threshold)
+    if (!mu_div && c->np2_mu_auto) { c->np2_mu_is_kq = false; c->np2_mu_auto = false; }
     for (int k = 0; k < 3; ++k) {
+        if (k == 0 && mu_div) {
+            const void* src = arrs[0];
+            if (!is_device_ptr(src)) {
+                DXH_HIP(hipMalloc(&raw[0].p, n * 4));
+                DXH_HIP(hipMemcpyAsync(raw[0].p, src, n * 4, hipMemcpyDefault, c->stream));
+                src = raw[0].p;
+            }
+            DXH_HIP(hipMalloc(&conv[0].p, n * 8));
+            hipLaunchKernelGGL(k_convert_div_dense, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const float*)src, (float)ell,
+                               (double*)conv[0].p, n);
+            DXH_HIP(hipGetLastError());
+            arrs[0] = conv[0].p;
+            c->np2_mu_is_kq = true;
+            c->np2_mu_auto = true;
+            continue;
+        }
         if (!arrs[k] || dts[k] == c->desc.dtype) continue;
         DXH_REQUIRE(dts[k] == DXH_F32 || dts[k] == DXH_F64, "coefficient arrays must be float32 or float64");
         const size_t ssz = dts[k] == DXH_F32 ? 4 : 8;
@@ -3008,6 +3043,7 @@ int dxh_tvd_set_promotion(dxh_tvd_t h, int mode) {
                     "of a float32 image)");
     c->np2 = (mode & DXH_PROMOTION_NUMPY2) != 0;
     c->np2_mu_is_kq = (mode & DXH_PROMOTION_MU_IS_THRESHOLD) != 0;
+    c->np2_mu_auto = false;
     c->uploaded = false;
     c->have_coefs = false;
     return DXH_OK;
@@ -3051,7 +3087,7 @@ int dxh_tvd_upload_warm_np2(dxh_tvd_t h, const void* img, const void* u0, int u0
     DXH_REQUIRE(c && img && d0 && b0, "null argument");
     DXH_REQUIRE(c->np2, "the context is not in numpy2 promotion");
     DXH_REQUIRE(!u0 || u0_dtype == DXH_F32 || u0_dtype == DXH_F64, "u0 must be float32 or float64");
-    DXH_REQUIRE(!is_device_ptr(img) && !is_device_ptr(u0) && !is_device_ptr(d0) && !is_device_ptr(b0), "host arrays expected");
+    // (host or device pointers: every copy below resolves its direction from the pointers)
     int rc = dxh_tvd_upload_typed(h, img, DXH_F32);   // of = omega img (float32 product), u = img, planes cleared
     if (rc) return rc;
     const int dim = c->desc.dim;

@@ -63,6 +63,14 @@ class DeviceArray:
             _lib.check(self.lib.dxh_mem_copy(self.device, _lib.ptr(out), self.ptr, self.nbytes))
         return out
 
+    def set(self, arr: np.ndarray) -> "DeviceArray":
+        """Overwrite with a host array of the same shape and dtype."""
+        arr = np.ascontiguousarray(arr, dtype=self.dtype)
+        assert tuple(arr.shape) == self.shape
+        if self.nbytes:
+            _lib.check(self.lib.dxh_mem_copy(self.device, self.ptr, _lib.ptr(arr), self.nbytes))
+        return self
+
     def copy(self) -> "DeviceArray":
         """A device-to-device copy (what ``CombinedModel`` starts from, signals/models/combinedmodel.py:39)."""
         d = DeviceArray(self.shape, self.dtype, self.device)

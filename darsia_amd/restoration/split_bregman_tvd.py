@@ -50,8 +50,10 @@ def _coef(value, img, name: str, keep_float_type: bool = False):
     """(scalar, array or None).  ``keep_float_type``: a float32 / float64 array stays in its own type -- the library
     converts it on the device (``dxh_tvd_set_coeffs_typed``) instead of a host pass over it."""
     if isinstance(value, DeviceArray):
-        if value.shape != tuple(img.shape) or value.dtype != img.dtype:
-            raise ValueError(f"a device-resident {name} must have the image's shape and dtype")
+        ok_type = value.dtype in (np.float32, np.float64) if keep_float_type else value.dtype == img.dtype
+        if value.shape != tuple(img.shape) or not ok_type:
+            raise ValueError(f"a device-resident {name} must have the image's shape and " +
+                             ("a float dtype" if keep_float_type else "dtype"))
         return 0.0, value
     if isinstance(value, np.ndarray) and value.ndim > 0:
         try:
@@ -128,40 +130,40 @@ class DeviceTVD:
                                                       code(om_a), has_ell, ell_s, _lib.ptr(ell_a), code(ell_a)))
 
     def _set_coeffs_numpy2(self, mu, omega, ell, like):
-        """Scalar omega and ell; mu a scalar or an array.  A float64 mu array is divided by ell on the device in float64
-        (``mu / ell``, split_bregman_tvd.py:144: float64 array / Python float); a float32 one the way NumPy does it -- the
-        quotient in float32 -- here, and handed over as the threshold itself."""
-        if any(isinstance(c, DeviceArray) for c in (mu, omega, ell)):
-            raise NotImplementedError("promotion='numpy2': device-resident coefficient arrays are not supported")
-        if np.ndim(omega) != 0 or (ell is not None and np.ndim(ell) != 0) or (ell is None and np.ndim(mu) != 0):
+        """Scalar omega and ell with mu a scalar or an array, or float64 arrays for omega / ell; arrays on the host or on the
+        device (``DeviceArray``).  A float64 mu array is divided by ell on the device in float64 (``mu / ell``,
+        split_bregman_tvd.py:144: float64 array / Python float); a float32 one the way NumPy does it -- the quotient in
+        float32 (``dxh_tvd_set_coeffs_typed`` forms it on the device and hands it on as the threshold itself)."""
+        is_arr = lambda c: c is not None and (isinstance(c, DeviceArray) or np.ndim(c) != 0)   # noqa: E731
+        dt_of = lambda c: c.dtype if isinstance(c, DeviceArray) else np.asarray(c).dtype        # noqa: E731
+        f64 = _lib.dtype_code(np.dtype(np.float64))
+        if self._promotion_mode != _lib.PROMOTION_NUMPY2:
+            _lib.check(self.lib.dxh_tvd_set_promotion(self._h, _lib.PROMOTION_NUMPY2))
+            self._promotion_mode = _lib.PROMOTION_NUMPY2
+        if is_arr(omega) or is_arr(ell) or (ell is None and is_arr(mu)):
             # array-valued omega / ell (or ell = 2 mu): float64 arrays, the coefficient planes of the double context
             # (split_bregman_tvd.py:62-68, jacobi.py:57-72,101-106 in float64, as for a float64 image)
-            arrs = [np.asarray(c) for c in (mu, omega, ell) if c is not None and np.ndim(c) != 0]
-            if any(a.dtype != np.float64 for a in arrs):
+            if any(dt_of(a) != np.float64 for a in (mu, omega, ell) if is_arr(a)):
                 raise NotImplementedError("promotion='numpy2': array-valued omega / ell need float64 arrays")
-            f64 = _lib.dtype_code(np.dtype(np.float64))
-            shaped = lambda c: None if (c is None or np.ndim(c) == 0) else np.ascontiguousarray(  # noqa: E731
-                np.broadcast_to(c, like.shape), dtype=np.float64)
-            sc = lambda c: 0.0 if (c is None or np.ndim(c) != 0) else float(c)   # noqa: E731
+
+            def shaped(c):
+                if not is_arr(c):
+                    return None
+                if isinstance(c, DeviceArray):
+                    if c.shape != tuple(like.shape):
+                        raise ValueError("a device-resident coefficient array must have the image's shape")
+                    return c
+                return np.ascontiguousarray(np.broadcast_to(c, like.shape), dtype=np.float64)
+
+            sc = lambda c: 0.0 if (c is None or is_arr(c)) else float(c)   # noqa: E731
             mu_a, om_a, ell_a = shaped(mu), shaped(omega), shaped(ell)
-            if self._promotion_mode != _lib.PROMOTION_NUMPY2:
-                _lib.check(self.lib.dxh_tvd_set_promotion(self._h, _lib.PROMOTION_NUMPY2))
-                self._promotion_mode = _lib.PROMOTION_NUMPY2
             _lib.check(self.lib.dxh_tvd_set_coeffs_typed(self._h, sc(mu), _lib.ptr(mu_a), f64, sc(omega) if om_a is None else float("nan"),
                                                           _lib.ptr(om_a), f64, 0 if ell is None else 1, sc(ell), _lib.ptr(ell_a), f64))
             return
         mu_s, mu_a = _coef(mu, like, "mu", True)
-        mode = _lib.PROMOTION_NUMPY2
-        if mu_a is not None and mu_a.dtype == np.float32:
-            mu_a = (mu_a / float(ell)).astype(np.float64)      # float32 array / Python float -> float32 quotient, widened
-            mode |= _lib.PROMOTION_MU_IS_THRESHOLD
-        if mode != self._promotion_mode:
-            _lib.check(self.lib.dxh_tvd_set_promotion(self._h, mode))
-            self._promotion_mode = mode
         has_ell, ell_s = (0, 0.0) if ell is None else (1, float(ell))
-        f64 = _lib.dtype_code(np.dtype(np.float64))
-        _lib.check(self.lib.dxh_tvd_set_coeffs_typed(self._h, mu_s, _lib.ptr(mu_a), f64, float(omega), None, f64, has_ell,
-                                                      ell_s, None, f64))
+        _lib.check(self.lib.dxh_tvd_set_coeffs_typed(self._h, mu_s, _lib.ptr(mu_a), _lib.dtype_code(np.dtype(np.float64) if mu_a is None else mu_a.dtype),
+                                                      float(omega), None, f64, has_ell, ell_s, None, f64))
 
     def upload(self, img, u0=None, d0=None, b0=None):
         if self.numpy2:
@@ -169,17 +171,19 @@ class DeviceTVD:
                 img = np.ascontiguousarray(img, dtype=self.dtype)
             assert tuple(img.shape) == self.shape and img.dtype == self.dtype
             if u0 is not None or d0 is not None or b0 is not None:
-                # warm start (split_bregman_tvd.py:92-96): float32 d0 / b0 as the function leaves them, u0 float32 / float64
-                if d0 is None or b0 is None or isinstance(img, DeviceArray):
-                    raise NotImplementedError("promotion='numpy2': a warm start needs host arrays img, d0, b0")
-                if np.asarray(d0).dtype != np.float32 or np.asarray(b0).dtype != np.float32:
+                # warm start (split_bregman_tvd.py:92-96): float32 d0 / b0 as the function leaves them, u0 float32 / float64;
+                # host arrays or DeviceArrays (a chain of calls whose state stays in HBM)
+                if d0 is None or b0 is None:
+                    raise NotImplementedError("promotion='numpy2': a warm start needs d0 and b0")
+                dense = lambda a: a if isinstance(a, DeviceArray) else np.ascontiguousarray(a)   # noqa: E731
+                d0c, b0c = dense(d0), dense(b0)
+                if d0c.dtype != np.float32 or b0c.dtype != np.float32:
                     raise NotImplementedError("promotion='numpy2': a warm start needs float32 d0 / b0")
-                d0c, b0c = np.ascontiguousarray(d0), np.ascontiguousarray(b0)
-                assert d0c.shape == b0c.shape == self.shape + (self.dim,)
+                assert tuple(d0c.shape) == tuple(b0c.shape) == self.shape + (self.dim,)
                 u0c = None
                 if u0 is not None:
-                    u0c = np.ascontiguousarray(u0)
-                    if u0c.dtype not in (np.float32, np.float64) or u0c.shape != self.shape:
+                    u0c = dense(u0)
+                    if u0c.dtype not in (np.float32, np.float64) or tuple(u0c.shape) != self.shape:
                         raise NotImplementedError("promotion='numpy2': u0 must be a float32 or float64 array of the image's shape")
                 _lib.check(self.lib.dxh_tvd_upload_warm_np2(self._h, _lib.ptr(img), _lib.ptr(u0c),
                                                              _lib.dtype_code(u0c.dtype) if u0c is not None else 0,
@@ -231,8 +235,10 @@ class DeviceTVD:
         _lib.check(self.lib.dxh_tvd_energy(self._h, 1 if previous else 0, C.byref(v)))
         return v.value
 
-    def download(self, want_split=False, out=None):
-        """The iterate (and the split variables) as host arrays, or into ``out`` (ndarray or DeviceArray)."""
+    def download(self, want_split=False, out=None, split_out=None):
+        """The iterate (and the split variables) as host arrays, or into ``out`` (ndarray or DeviceArray); numpy2 contexts
+        write the split variables into ``split_out = (d, b)`` when given (float32 ``(..., dim)`` DeviceArrays or contiguous
+        ndarrays)."""
         u = np.empty(self.shape, self.dtype) if out is None else out
         assert tuple(u.shape) == self.shape and u.dtype == self.dtype
         assert isinstance(u, DeviceArray) or u.flags.c_contiguous
@@ -241,8 +247,14 @@ class DeviceTVD:
             _lib.check(self.lib.dxh_tvd_download_typed(self._h, _lib.ptr(u), _lib.dtype_code(self.dtype)))
             if not want_split:
                 return u
-            d = np.empty(self.shape + (self.dim,), np.float32)   # the reference's float32 d, b
-            b = np.empty(self.shape + (self.dim,), np.float32)
+            if split_out is not None:
+                d, b = split_out
+                for a in (d, b):
+                    assert tuple(a.shape) == self.shape + (self.dim,) and a.dtype == np.float32
+                    assert isinstance(a, DeviceArray) or a.flags.c_contiguous
+            else:
+                d = np.empty(self.shape + (self.dim,), np.float32)   # the reference's float32 d, b
+                b = np.empty(self.shape + (self.dim,), np.float32)
             _lib.check(self.lib.dxh_tvd_download_split_np2(self._h, _lib.ptr(d), _lib.ptr(b)))
             return u, d, b
         if not want_split:
@@ -310,30 +322,34 @@ def numpy2_unsupported(img, mu, omega, ell, dim, x0, isotropic, solver, adaptive
         return "the image is not float32"
     if dim not in (2, 3) or img.ndim not in (2, 3) or dim > img.ndim:
         return "dim = 2 or 3 on an array of 2 or 3 axes only"
-    if any(isinstance(c, DeviceArray) for c in (mu, omega, ell)):
-        return "device-resident coefficient arrays"
-    if np.ndim(omega) != 0 or (ell is not None and np.ndim(ell) != 0) or (ell is None and np.ndim(mu) != 0):
+    is_arr = lambda c: c is not None and (isinstance(c, DeviceArray) or np.ndim(c) != 0)   # noqa: E731
+    dt_of = lambda c: c.dtype if isinstance(c, DeviceArray) else np.asarray(c).dtype        # noqa: E731
+    for name, c in (("mu", mu), ("omega", omega), ("ell", ell)):
+        if isinstance(c, DeviceArray) and (c.shape != tuple(img.shape) or c.dtype not in (np.float32, np.float64)):
+            return f"a device-resident {name} must be a float32 / float64 array of the image's shape"
+    arr_ell = is_arr(omega) or is_arr(ell) or (ell is None and is_arr(mu))
+    if arr_ell:
         # omega and / or ell (given, or 2 mu) an array: float64 arrays pull parts of the right-hand side into float64
         # (k_rhs_np2_het); with float32 arrays only, every quantity of the reference stays float32 -- the native flow IS
         # the reference's (native_is_the_reference_flow); a mixture of the two is not reproduced
-        kinds = {np.asarray(c).dtype for c in (mu, omega, ell) if c is not None and np.ndim(c) != 0}
+        kinds = {np.dtype(dt_of(c)) for c in (mu, omega, ell) if is_arr(c)}
         if kinds != {np.dtype(np.float64)}:
             return "array-valued omega / ell: float64 arrays only"
     if adaptive is not None:
         # ell becomes a float32 array (split_bregman_tvd.py:149-158 on a float32 image): explicit float32 d, b on the device
-        if np.ndim(omega) != 0 or (ell is not None and np.ndim(ell) != 0) or (ell is None and np.ndim(mu) != 0):
+        if arr_ell:
             return "the adaptive schedule needs scalar omega and ell"
-        if np.ndim(mu) != 0 and np.asarray(mu).dtype != np.float64:
+        if is_arr(mu) and dt_of(mu) != np.float64:
             return "the adaptive schedule needs mu as a scalar or a float64 array"
     if x0 is not None:
         # a warm start in the reference's flow: float32 d0 / b0 (what the function itself leaves in them for a float32
-        # image), u0 float32 or float64, host arrays, scalar omega and ell
+        # image), u0 float32 or float64, on the host or on the device, scalar omega and ell
         u0, d0, b0 = x0
-        if isinstance(img, DeviceArray) or any(not isinstance(a, np.ndarray) for a in (u0, d0, b0)):
-            return "a warm start needs host arrays"
+        if any(not isinstance(a, (np.ndarray, DeviceArray)) for a in (u0, d0, b0)):
+            return "a warm start needs arrays (ndarray or DeviceArray)"
         if d0.dtype != np.float32 or b0.dtype != np.float32 or u0.dtype not in (np.float32, np.float64):
             return "a warm start needs float32 d0 / b0 and a float32 or float64 u0"
-        if np.ndim(omega) != 0 or (ell is not None and np.ndim(ell) != 0) or (ell is None and np.ndim(mu) != 0):
+        if arr_ell:
             return "a warm start needs scalar omega and ell"
     if isotropic:
         return "anisotropic only (the reference's isotropic branch is float64-only)"
@@ -415,14 +431,16 @@ def split_bregman_tvd(
         raise ValueError("an MG solver constructed with coefficient arrays cannot be re-parametrised by the TV loop "
                          "(the reference's broadcasting fails on its coarse levels as well)")
     # the reference feeds the solver (split_bregman_tvd.py:62-68); kept for callers that inspect it
-    solver.update_params(mass_coeff=omega, diffusion_coeff=(2 * mu if ell is None else ell), dim=dim)
+    # (ell = 2 mu of a device-resident mu is formed on the device; the solver object keeps its previous diffusion_coeff then)
+    solver.update_params(mass_coeff=omega, dim=dim,
+                         diffusion_coeff=ell if ell is not None else (None if isinstance(mu, DeviceArray) else 2 * mu))
 
     u0 = d0 = b0 = None
     if x0 is not None:
         u0, d0, b0 = x0
         for name, a in (("d0", d0), ("b0", b0)):
-            if not isinstance(a, np.ndarray) or a.shape != tuple(img.shape) + (dim,):
-                raise ValueError(f"{name} must have shape (*img.shape, dim) = {img.shape + (dim,)}")
+            if not isinstance(a, (np.ndarray, DeviceArray)) or tuple(a.shape) != tuple(img.shape) + (dim,):
+                raise ValueError(f"{name} must have shape (*img.shape, dim) = {tuple(img.shape) + (dim,)}")
 
     quiet = not (verbose if isinstance(verbose, bool) else verbose > 0)
     why_not = numpy2_unsupported(img, mu, omega, ell, dim, x0, isotropic, solver, adaptive, quiet)
@@ -472,9 +490,16 @@ def split_bregman_tvd(
                             break
                 if x0 is None:
                     return st.download(out=DeviceArray(img.shape, img.dtype, img.device) if on_device else None)
-                u, d, b = st.download(want_split=True)
-                d0[...] = d
-                b0[...] = b
+                out_u = DeviceArray(img.shape, img.dtype, img.device) if on_device else None
+                if isinstance(d0, DeviceArray) and isinstance(b0, DeviceArray):
+                    u, _, _ = st.download(want_split=True, out=out_u, split_out=(d0, b0))   # the state stays in HBM
+                    return u
+                u, d, b = st.download(want_split=True, out=out_u)
+                for dst, src in ((d0, d), (b0, b)):
+                    if isinstance(dst, DeviceArray):
+                        dst.set(src)
+                    else:
+                        dst[...] = src
                 return u
         if (not on_device and eps is None and np.ndim(mu) == 0 and np.ndim(omega) == 0 and (ell is None or np.ndim(ell) == 0)
                 and max_num_iter >= 1 and img.nbytes >= (32 << 20)
