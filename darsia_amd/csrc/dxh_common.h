@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -200,6 +201,46 @@ struct HostPrefault {
             if (t.joinable()) t.join();
     }
     ~HostPrefault() { join(); }
+};
+
+// ---- roctx ranges for rocprofv3 --marker-trace timelines --------------------------------------------------------
+// Named host-side ranges around the TV loop, the halo exchange and the band copies.  Off unless DXH_ROCTX is set (the marker
+// library is then resolved with dlopen once: librocprofiler-sdk-roctx, else the older libroctx64); without it a range is two
+// predictable branches.
+struct RoctxApi {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    static const RoctxApi& get() {
+        static const RoctxApi api = [] {
+            RoctxApi a;
+            if (!getenv("DXH_ROCTX")) return a;
+            for (const char* n : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+                void* h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+                if (!h) continue;
+                *(void**)(&a.push) = dlsym(h, "roctxRangePushA");
+                *(void**)(&a.pop) = dlsym(h, "roctxRangePop");
+                if (a.push && a.pop) break;
+                a.push = nullptr;
+                a.pop = nullptr;
+            }
+            return a;
+        }();
+        return api;
+    }
+};
+struct RoctxRange {
+    bool on;
+    explicit RoctxRange(const char* name) : on(RoctxApi::get().push != nullptr) { if (on) RoctxApi::get().push(name); }
+    RoctxRange(const char* fmt, long long a, long long b = 0) : on(RoctxApi::get().push != nullptr) {
+        if (on) {
+            char buf[96];
+            snprintf(buf, sizeof buf, fmt, a, b);
+            RoctxApi::get().push(buf);
+        }
+    }
+    ~RoctxRange() { if (on) RoctxApi::get().pop(); }
+    RoctxRange(const RoctxRange&) = delete;
+    RoctxRange& operator=(const RoctxRange&) = delete;
 };
 
 constexpr int kWave = 64;

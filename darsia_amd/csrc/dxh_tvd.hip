@@ -1296,6 +1296,7 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
     const bool iso = flags & DXH_FLAG_ISOTROPIC;
     const bool use_eps = eps >= 0.0 && !std::isnan(eps);
     const bool use_tol = jacobi_tol >= 0.0 && !std::isnan(jacobi_tol);
+    RoctxRange range("dxh_tvd_run: %lld TV iterations (%lld Jacobi sweeps each)", n_iter, jacobi_maxiter);
     c->signalling = false;  // only dxh_tvd_run_slab builds signalling launches
     c->row_lo = c->row_hi = 0;
     c->np2_pre = false;     // nothing prepared by an earlier call survives (halo exchanges, new coefficients, downloads between calls)
@@ -1622,6 +1623,7 @@ static Ctx::XEv* slab_take_events(Ctx* c) {
 }
 
 static int start_exchange(Ctx* c, bool after_signal) {
+    RoctxRange range(after_signal ? "halo exchange: enqueue (starts on the interface rows' signal)" : "halo exchange: enqueue (stream order)");
     Comm* cm = c->comm;
     if (c->from_db) { set_error("halo exchange before the first iteration of a warm start is not supported"); return DXH_ESTATE; }
     // Overlapped exchange: it -- and every launch after it -- goes to the context's OTHER stream (a different hardware
@@ -1701,6 +1703,7 @@ static int exchange_now(Ctx* c) { return start_exchange(c, false); }
 
 template <typename T>
 static int run_slab_t(Ctx* c, int n_iter, int m, double eps, uint32_t flags, dxh_tvd_result* res) {
+    RoctxRange range("dxh_tvd_run_slab: %lld TV iterations on a row slab (halos valid for %lld)", n_iter, (long long)c->halo_valid);
     Comm* cm = c->comm;
     const bool dist = cm && (c->top > 0 || c->bot > 0);
     const bool iso = flags & DXH_FLAG_ISOTROPIC;
@@ -2586,6 +2589,7 @@ static int solve_banded_impl(const dxh_tvd_desc* desc, const void* img, void* ou
             // three streams in turn: band b re-uses the stream of band b - 3, whose download must have been issued
             // before anything of band b is enqueued behind it
             while (downloaded.load(std::memory_order_acquire) < b - 2) std::this_thread::yield();
+            RoctxRange range("row band %lld: create, upload, enqueue %lld iterations", b, n_iter);
             tr[b][0] = now_ms();
             int r = dxh_tvd_create(&bd.ctx, &d);
             if (!r && promotion) r = dxh_tvd_set_promotion(bd.ctx, promotion);
@@ -2640,6 +2644,7 @@ static int solve_banded_impl(const dxh_tvd_desc* desc, const void* img, void* ou
         while ((st = bd.state.load(std::memory_order_acquire)) == 0) std::this_thread::yield();
         if (st < 0) { rc = st; break; }
         Ctx* c = reinterpret_cast<Ctx*>(bd.ctx);
+        RoctxRange range("row band %lld: download of %lld owned rows", b, (long long)(bd.own1 - bd.own0));
         tr[b][4] = now_ms();
         const char* src = static_cast<const char*>(c->u[c->cur]) + (size_t)(bd.own0 - bd.lo) * c->g.pitch * c->esz;
         hipError_t e = hipSuccess;

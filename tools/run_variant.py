@@ -36,6 +36,14 @@ elif v in ("np2", "np2arr"):
     mu = 0.1 if v == "np2" else 0.1 * (0.3 + 0.7 * np.random.default_rng(1).random(img.shape))
     st = da.DeviceTVD(img.shape, img.dtype, promotion="numpy2"); st.set_coeffs(mu, 1.0, 0.2, img); st.upload(img)
     r = st.run(12); print(v, "ms/iter", r.loop_ms / 12, "launches", r.launches); st.close()
+elif v == "np2gray":
+    img = synthetic_image(H, W, 1)
+    st = da.DeviceTVD(img.shape, img.dtype, promotion="numpy2"); st.set_coeffs(0.1, 1.0, 0.2, img); st.upload(img)
+    r = st.run(12); print(v, "ms/iter", r.loop_ms / 12, "launches", r.launches); st.close()
+elif v == "banded":
+    img = synthetic_image(H, W, 3)
+    out = da.split_bregman_tvd(img, mu=0.1, max_num_iter=40)     # the default call on a host image: row bands, numpy2 flow
+    print("banded default call done", out.dtype, float(out[0, 0, 0]))
 elif v == "jacobi3d":
     vol = np.random.default_rng(0).random((256, 256, 256)).astype(np.float32)
     st = da.DeviceTVD(vol.shape, vol.dtype, dim=3); st.set_coeffs(0.1, 1.0, None, vol); st.upload(vol)
