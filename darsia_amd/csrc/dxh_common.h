@@ -644,6 +644,68 @@ __device__ __forceinline__ void iso_s_fac(T x, T k, T& s, T& fac) {
     fac = t_max0(s - k) / (s + T(1e-18));
 }
 
+// The isotropic (d, b) of the N elements a lane holds, scalar threshold k (the K-stage float pipelines): the fast chain of
+// iso_s_fac_fast for all of them, ONE wave-level test for the rarely taken IEEE branch instead of one per element, and two
+// wave-uniform relaxations that the host grants per threshold after trying every float x in [2^-60, 2^60) on the device
+// (k_isolean_check, dxh_tvd.hip: the whole expression max(s - k, 0) / (s + 1e-18f) against its IEEE evaluation):
+//   lean   the 120 square roots with an all-ones significand need no IEEE detour for THIS k (their reciprocal is one ulp
+//          short, which the quotient's rounding absorbs unless s - k lands badly) -- no per-element significand test
+//   div3   the quotient is correctly rounded after ONE residual correction for every x -- three operations instead of five
+// Same operations on the same values as split_vars<float, 2, true> otherwise, so the results are bit-identical to it.
+template <int N>
+__device__ __forceinline__ void iso_split_vec(const float (&q0)[N], const float (&q1)[N], float k, bool lean, bool div3,
+                                              float (&d0)[N], float (&b0)[N], float (&d1)[N], float (&b1)[N]) {
+    float fac[N];
+    bool okv[N];
+    bool bad = !(k >= 0.0f);   // (false for NaN too) keeps the numerator within [0, s]: wave-uniform
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        float xx = 0.0f;
+        xx = xx + q0[j] * q0[j];
+        xx = xx + q1[j] * q1[j];
+        const float y = __builtin_amdgcn_rsqf(fmaxf(xx, kSqrtFastMin));
+        const float g = xx * y, h = 0.5f * y;
+        const float s = fmaf(fmaf(-g, g, xx), h, g);               // t_sqrt_chain(x)
+        const float rho = fmaf(fmaf(-s, y, 1.0f), y, y);           // RN(1 / s) on [2^-60, 2^60) but for the all-ones significands
+        const float num = (s - k) > 0.0f ? (s - k) : 0.0f;         // t_max0
+        float f = div_by_const3(num, s, rho);
+        if (!div3) {
+            DXH_UNIFORM_BRANCH();
+            f = div_refine(f, num, s, rho);
+        }
+        fac[j] = f;
+        // x in [2^-60, 2^60) as one unsigned comparison of the bit patterns (x >= 0 or NaN: a sum of squares), or x == 0
+        const unsigned ub = __float_as_uint(xx);
+        bool ok = (ub - __float_as_uint(kIsoLo)) < (__float_as_uint(kIsoHi) - __float_as_uint(kIsoLo)) || ub == 0u;
+        if (!lean) {
+            DXH_UNIFORM_BRANCH();
+            ok = ok && (__float_as_uint(s) & 0x7FFFFFu) != 0x7FFFFFu;
+        }
+        okv[j] = ok;
+        bad = bad || !ok;
+    }
+    if (__builtin_expect(__any(bad), 0)) {
+        const bool kbad = !(k >= 0.0f);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            if (kbad || !okv[j]) {
+                float xx = 0.0f;
+                xx = xx + q0[j] * q0[j];
+                xx = xx + q1[j] * q1[j];
+                const float s = t_sqrt(xx);
+                fac[j] = t_max0(s - k) / (s + 1e-18f);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        d0[j] = q0[j] * fac[j];
+        b0[j] = q0[j] * (1.0f - fac[j]);
+        d1[j] = q1[j] * fac[j];
+        b1[j] = q1[j] * (1.0f - fac[j]);
+    }
+}
+
 template <typename T, int DIM, bool ISO, bool FASTSIGN = false>
 __device__ __forceinline__ void split_vars(const T (&q)[DIM], T k, T (&d)[DIM], T (&b)[DIM]) {
     if constexpr (ISO) {

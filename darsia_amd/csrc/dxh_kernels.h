@@ -1398,6 +1398,7 @@ struct FusedArgs {
                        // sums of the launch's first iteration (stage 0) are float32 sums
     int np2_div3;      // NP2 pipelines: the three-operation float32 division rhs / diag is exact for this diag (k_div3_check)
     const float* of32; // NP2 pipelines: omega * img as a float32 plane (same pitch in elements as `of`, whose values it holds)
+    int iso_lean, iso_div3;   // isotropic float pipelines, scalar threshold: relaxations verified for this threshold (iso_split_vec)
 };
 
 // ALIGN: the lanes that store cover whole 128-byte lines (strip stride rounded down to a multiple of
@@ -2345,6 +2346,7 @@ struct Pipe {
                                // s_cmp_lt_i64, 64-bit tests become v_mov_b64 + v_cmp_*_i64 on the VALU); n0 < 2^31 - 64
     T ell, diag, dsc, kq, rdiag, rdsc;
     bool div3;          // Coef::div3
+    bool iso_lean, iso_div3;  // FusedArgs::iso_lean / iso_div3
     bool cdiag;         // Coef::const_diag
     bool store_lane;
     uint32_t edgeL[N], edgeR[N], ch0[N], chLast[N];  // lane patterns as 0 / ~0 words (sel_bits)
@@ -2519,6 +2521,18 @@ struct Pipe {
             if constexpr (ring_out) xget(0 + cm, unm_tmp);  // written by this wave one step ago
 
             T b1c[N], t1c[N];
+            if constexpr (ISO && !HET && !KQV && std::is_same<T, float>::value) {
+                // scalar threshold, float: the lane's N elements at once (one wave-level test, verified relaxations)
+                T q0v[N], d0v[N], d1v[N];
+#pragma unroll
+                for (int j = 0; j < N; ++j) q0v[j] = (s == 0) ? st.q0l[lcur][j] : q0h[j];
+                iso_split_vec<N>(q0v, q1c, kq, iso_lean, iso_div3, d0v, b0c, d1v, b1c);
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    t0c[j] = ell * (b0c[j] - d0v[j]);
+                    t1c[j] = ell * (b1c[j] - d1v[j]);
+                }
+            } else {
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 T qq[2] = {(s == 0) ? st.q0l[lcur][j] : q0h[j], q1c[j]}, d[2], b[2];
@@ -2537,6 +2551,7 @@ struct Pipe {
                 }
                 b0c[j] = b[0];
                 b1c[j] = b[1];
+            }
             }
             if (p == 0) {  // replicate the row above the image
                 DXH_UNIFORM_BRANCH();
@@ -2766,6 +2781,8 @@ __device__ __forceinline__ bool pipe_setup(PipeT& pp, const FusedArgs<T>& a, con
     pp.rdiag = a.c.rdiag;
     pp.rdsc = a.c.rdsc;
     pp.div3 = a.c.div3 != 0;
+    pp.iso_lean = a.iso_lean != 0;
+    pp.iso_div3 = a.iso_div3 != 0;
     pp.cdiag = a.c.const_diag != 0;
     pp.ci = a.ci;
     pp.kq_p = a.cp.kq;

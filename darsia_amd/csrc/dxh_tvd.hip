@@ -303,6 +303,63 @@ static int div3_verified(Ctx* c, float diag, float dsc) {
     return ok;
 }
 
+// Exhaustive test of iso_split_vec's relaxations for ONE scalar threshold k >= 0: every float x in [2^-60, 2^60) through the
+// fast chain WITHOUT the significand screen, the quotient after one (bit 1 of *bad) and after two (bit 0) residual
+// corrections, against the IEEE evaluation of max(sqrt(x) - k, 0) / (sqrt(x) + 1e-18f).  ~1e9 values, a few milliseconds.
+__global__ void __launch_bounds__(256) k_isolean_check(float k, unsigned* bad) {
+    unsigned b = 0;
+    const unsigned long long lo = __float_as_uint(kIsoLo), hi = __float_as_uint(kIsoHi);
+    for (unsigned long long u = lo + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; u < hi;
+         u += (unsigned long long)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float((unsigned)u);
+        const float y = __builtin_amdgcn_rsqf(fmaxf(x, kSqrtFastMin));
+        const float g = x * y, h = 0.5f * y;
+        const float s = fmaf(fmaf(-g, g, x), h, g);
+        const float rho = fmaf(fmaf(-s, y, 1.0f), y, y);
+        const float num = (s - k) > 0.0f ? (s - k) : 0.0f;
+        const float f3 = div_by_const3(num, s, rho);
+        const float f5 = div_refine(f3, num, s, rho);
+        const float sr = sqrtf(x);
+        const float want = t_max0(sr - k) / (sr + 1e-18f);
+        if (__float_as_uint(s) != __float_as_uint(sr)) b |= 3u;
+        if (__float_as_uint(f5) != __float_as_uint(want)) b |= 1u;
+        if (__float_as_uint(f3) != __float_as_uint(want)) b |= 2u;
+    }
+    if (b) atomicOr(bad, b);
+}
+
+// bit 0: lean (no significand screen) with the five-operation quotient is exact for this k; bit 1: also with three operations.
+// Remembered per threshold; the first call for a threshold costs one launch and a 4-byte read-back.
+static unsigned iso_relaxations_verified(Ctx* c, float k) {
+    if (!(k >= 0.0f) || !std::isfinite(k)) return 0;
+    static std::mutex mtx;
+    static std::map<uint32_t, unsigned> known;
+    uint32_t key;
+    std::memcpy(&key, &k, 4);
+    {
+        std::lock_guard<std::mutex> g(mtx);
+        auto it = known.find(key);
+        if (it != known.end()) return it->second;
+    }
+    unsigned* flag = nullptr;
+    unsigned bad = 3u;
+    if (hipMalloc(&flag, sizeof(unsigned)) == hipSuccess) {
+        hipError_t e = hipMemsetAsync(flag, 0, sizeof(unsigned), c->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_isolean_check, dim3(8192), dim3(256), 0, c->stream, k, flag);
+            e = hipMemcpyAsync(&bad, flag, sizeof(unsigned), hipMemcpyDefault, c->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) bad = 3u;
+        (void)hipFree(flag);
+    }
+    const unsigned ok = ((bad & 1u) ? 0u : 1u) | ((bad & 3u) ? 0u : 2u);   // three operations count only when five are exact too
+    std::lock_guard<std::mutex> g(mtx);
+    if (known.size() > 4096) known.clear();
+    known[key] = ok;
+    return ok;
+}
+
 template <typename T>
 static Coef<T> make_coef(const Ctx* c) {
     Coef<T> k;
@@ -546,6 +603,15 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
     a.np2_first = (c->np2 && c->np2_first) ? 1 : 0;
     a.np2_div3 = 0;
     a.of32 = nullptr;
+    a.iso_lean = a.iso_div3 = 0;
+    if constexpr (ISO && std::is_same<T, float>::value) {
+        if (!c->het && !(c->tune & 2097152)) {   // (DXH_FUSED_TUNE bit 2097152: the screened five-operation form, A/B)
+            const unsigned r = iso_relaxations_verified(c, (float)c->c_kq);
+            a.iso_lean = (r & 1u) ? 1 : 0;
+            a.iso_div3 = (r & 2u) ? 1 : 0;
+            if (c->tune & 512) fprintf(stderr, "[dxh] isotropic shrink factor, k = %g: lean %d, three-operation quotient %d\n", c->c_kq, a.iso_lean, a.iso_div3);
+        }
+    }
     if (c->np2) {
         if (!c->of32_valid) { c->no_kernel = true; return; }   // (cannot happen: every upload of a scalar-omega numpy2 context fills it)
         a.of32 = (const float*)c->of32;
