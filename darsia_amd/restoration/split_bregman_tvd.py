@@ -11,17 +11,17 @@ Divergences from the reference, all deliberate:
 * ``solver=None`` creates a fresh ``Jacobi()`` per call instead of sharing one
   def-time instance whose cached diagonal never updates (quirks Q1, Q3);
 * two dtype flows for float32 images (``promotion``, an extra keyword; ``DXH_PROMOTION`` sets the
-  default).  ``"numpy2"`` -- THE DEFAULT wherever it exists (the ``Jacobi`` solver, anisotropic,
-  scalar omega / ell, no warm start) -- is the reference's own flow under NumPy >= 2: the
-  Jacobi iterate is float64 (jacobi.py:101-114), ``d``, ``b`` and the right-hand side float32, a
-  float64 weight map the threshold; reproduced BIT FOR BIT (``Pipe<..., NP2>``, ``k_fused_np2``),
-  0.39 ms per iteration at 4000 x 8000 x 3.  ``"native"`` keeps every quantity float32 (0.15 ms):
-  the oracle's same-dtype flow bit for bit, but only CLOSE to the reference -- 2e-7 while the
-  shrinkage is inactive (``mu / ell`` above the image's gradients: ``mu = 0.1``, ``ell = 2 mu`` on a
-  [0, 1] image, the benchmark's setting), 1e-4 absolute = 10 - 80 x the rtol-1e-4 tolerance once it is
-  active (``mu = 1``, or ``ell >= 0.3`` at ``mu = 0.1``: a near-threshold element that shrinks in one
-  flow and not in the other; tests/test_oracle_mixed_golden.py).  float64 images have one flow,
-  which is the reference's, bit for bit;
+  default), each the reference's own arithmetic under one NumPy generation, each reproduced BIT FOR BIT.
+  ``"numpy2"`` -- THE DEFAULT wherever it exists (the ``Jacobi`` solver, anisotropic; DESIGN.md
+  section 3 lists the rest) -- is the reference under NumPy >= 2: the Jacobi iterate is float64
+  (jacobi.py:101-114), ``d``, ``b`` and the right-hand side float32, a float64 weight map the
+  threshold (``PipeNp2`` in dxh_np2_pipe.h, ``k_fused_np2``; 0.285 ms per iteration at 4000 x 8000 x 3).
+  ``"native"`` keeps every quantity float32 (0.15 ms): the reference under NumPy < 2 (value-based
+  casting), pinned on vectors made under NumPy 1.26 (tests/test_np1_golden_gpu.py).  The two are 2e-7
+  apart while the shrinkage is inactive (``mu / ell`` above the image's gradients: ``mu = 0.1``,
+  ``ell = 2 mu`` on a [0, 1] image, the benchmark's setting) and 1e-4 absolute = 10 - 80 x rtol 1e-4 once
+  it is active (``mu = 1``, or ``ell >= 0.3`` at ``mu = 0.1``: a near-threshold element that shrinks
+  in one flow and not in the other).  float64 images have one flow, which is the reference's, bit for bit;
 * the isotropic variant also accepts float32 and colour images (the reference's
   numba kernel is float64 / 2-D only);
 * float images only (integer images silently break the reference, quirk Q5).
