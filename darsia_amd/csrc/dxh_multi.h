@@ -26,6 +26,12 @@ void launch_multi_kernel_c24(int C, bool coupled, bool iso, bool want_inc, bool 
 #ifndef DXH_NP2_WAVES
 #define DXH_NP2_WAVES 3
 #endif
+#ifndef DXH_F64P_WAVES      // the same pipeline for float64 images (16.6 KB of LDS per wave: two blocks per CU)
+#define DXH_F64P_WAVES 2
+#endif
+#ifndef DXH_F64P_PFD
+#define DXH_F64P_PFD 1
+#endif
 #ifndef DXH_NP2_WAVES_KQV   // threshold-plane variant: K more threshold rows in registers (168 VGPRs spill 24 - 108 bytes per lane)
 #define DXH_NP2_WAVES_KQV 2
 #endif
@@ -37,6 +43,8 @@ constexpr int kNp2K = 4;
 void launch_multi_kernel_np2_scalar(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
 // ... C in {2, 4}, scalar threshold (object np2_s24)
 void launch_multi_kernel_np2_scalar_c24(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
+// the same K-stage pipeline with every quantity float64: float64 IMAGES, anisotropic, scalar coefficients, C in {1, 3} (object f64p)
+void launch_multi_kernel_f64p(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
 void launch_multi_kernel_np2_kqv(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
 
 }  // namespace dxh

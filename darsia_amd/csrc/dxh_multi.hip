@@ -24,7 +24,11 @@
 // mu) -- one object each (build.sh: np2_s, np2_q)
 #include "dxh_np2_pipe.h"
 namespace dxh {
-#if DXH_MULTI_NP2 == 2
+#if DXH_MULTI_NP2 == 3
+#define DXH_NP2_KQV false
+#define DXH_NP2_F double
+void launch_multi_kernel_f64p(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream) {
+#elif DXH_MULTI_NP2 == 2
 #define DXH_NP2_KQV true
 void launch_multi_kernel_np2_kqv(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream) {
 #elif DXH_MULTI_CSET == 1
@@ -35,10 +39,13 @@ void launch_multi_kernel_np2_scalar_c24(int C, bool coupled, bool want_inc, cons
 void launch_multi_kernel_np2_scalar(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream) {
 #endif
     constexpr int K = kNp2K;
+#ifndef DXH_NP2_F
+#define DXH_NP2_F float
+#endif
 #define DXH_NP2_K(C_, CP_)                                                                                                          \
     do {                                                                                                                            \
-        if (want_inc) hipLaunchKernelGGL((k_fused_multi_np2<C_, CP_, K, true, DXH_NP2_KQV>), dim3(grid), dim3(256), 0, stream, a);  \
-        else hipLaunchKernelGGL((k_fused_multi_np2<C_, CP_, K, false, DXH_NP2_KQV>), dim3(grid), dim3(256), 0, stream, a);          \
+        if (want_inc) hipLaunchKernelGGL((k_fused_multi_np2<C_, CP_, K, true, DXH_NP2_KQV, true, DXH_NP2_F>), dim3(grid), dim3(256), 0, stream, a);  \
+        else hipLaunchKernelGGL((k_fused_multi_np2<C_, CP_, K, false, DXH_NP2_KQV, true, DXH_NP2_F>), dim3(grid), dim3(256), 0, stream, a);          \
     } while (0)
 #if DXH_MULTI_CSET == 1
     if (C == 2) { if (coupled) DXH_NP2_K(2, true); else DXH_NP2_K(2, false); }

@@ -32,16 +32,19 @@
 
 namespace dxh {
 
-template <int K>
+// F: the type of the quantities that are float32 in the reference's mixed flow (d, b, t, omega*img, the right-hand side) --
+// float for a numpy2 context; double for a float64 IMAGE, whose flow is float64 throughout: the same pipeline then serves
+// the native float64 contexts (no conversions at all; both divisions through the reciprocal with two corrections).
+template <int K, typename F>
 struct Np2State {
     static constexpr int N = 2;
     double U[K + 1][4][N];   // rows of level l, slot = (row - rs) & 3 (level K: parity)
-    float t0[K][2][N];       // ell (b_0 - d_0) of each stage's current / previous row
-    float b0[K][2][N];
+    F t0[K][2][N];           // ell (b_0 - d_0) of each stage's current / previous row
+    F b0[K][2][N];
     double q0l[2][N], q1l[2][N];  // loaded level-0 q rows (current / prefetched)
-    float of0[N];            // omega*img of stage 0's row
+    F of0[N];                // omega*img of stage 0's row
     double pf[2][4][N];      // prefetch distance 2: rows in flight two steps ahead (u, -, q0, q1)
-    float pff[2][N];         // ... and omega*img
+    F pff[2][N];             // ... and omega*img
     double kqv[K][N];        // KQV: the float64 threshold mu / ell of each stage's current row
     double kqn[N];
     bool kbad[K];            // KQV, wave-uniform: that row holds a threshold that is negative or NaN somewhere in the wave (the
@@ -60,7 +63,7 @@ struct Np2State {
 //              conflict cycles per launch).  slot = (level - 1) * 2 + parity of the step it is READ in
 //   b_1 rows   2 (K - 1) slots of 64 lanes x 8 B   float32 b_1 of the same rows (the consumer forms q_1 = D_1 u + b_1 itself)
 //   omega*img  4 slots of 64 lanes x 8 B          rows r .. r - 3 as float32, written by stage 0
-template <int K>
+template <int K, typename F>
 struct Np2Lds {
     static constexpr int PAD = 16;
     static constexpr int UHALF = PAD + kWave * 8;           // one parity of a row: pad + 64 x 8 B (the next half's pad follows)
@@ -68,7 +71,7 @@ struct Np2Lds {
     static constexpr int NU = 2 * (K - 1);
     static constexpr int U_BYTES = NU * USLOT + PAD;
     static constexpr int B1_OFF = U_BYTES;
-    static constexpr int FSLOT = kWave * 8;
+    static constexpr int FSLOT = kWave * 2 * (int)sizeof(F);   // (float64 images: 16 B per lane, 16.6 KB per wave, 2 blocks per CU)
     static constexpr int OF_OFF = B1_OFF + NU * FSLOT;
     static constexpr int BYTES = OF_OFF + 4 * FSLOT;        // K = 4: 6352 + 3072 + 2048 = 11472 per wave
     // byte offset, within U slot 0, of element e of the wave's window (e = 2 lane + j; e in [-4, 132) stays inside the pads)
@@ -80,8 +83,8 @@ struct Np2Lds {
     static_assert(PAD >= 16, "C <= 4: a lane looks at most 4 elements (2 lanes x 8 B per half) past the wave's ends");
 };
 
-template <int DELTA>
-__device__ __forceinline__ void shifted2f(const float (&v)[2], float (&w)[2]) {
+template <int DELTA, typename F>
+__device__ __forceinline__ void shifted2f(const F (&v)[2], F (&w)[2]) {
     w[0] = shifted_elem<DELTA, 0, true>(v);
     w[1] = shifted_elem<DELTA, 1, true>(v);
 }
@@ -110,13 +113,24 @@ __device__ __forceinline__ void np2_split_fast(double q, double negk, double k, 
     d = (float)(q - np2_clamp(q, negk, k));
     b = (float)(q - (double)d);
 }
+// float64 image: d = q - clamp(q, -k, k), b = q - d (split_vars<double, 2, false, true>)
+__device__ __forceinline__ void np2_split_fast(double q, double negk, double k, double& d, double& b) {
+    d = q - np2_clamp(q, negk, k);
+    b = q - d;
+}
+template <typename F> struct Np2Vec2;
+template <> struct Np2Vec2<float> { using type = float2; };
+template <> struct Np2Vec2<double> { using type = double2; };
 
-template <int C, bool COUPLED, int K, bool NTS, bool EDGE, bool NORM, bool KQV>
+template <int C, bool COUPLED, int K, bool NTS, bool EDGE, bool NORM, bool KQV, typename F = float>
 struct PipeNp2 {
     static constexpr int N = 2;
-    static constexpr int PFD = KQV ? 1 : DXH_NP2_PFD;   // the per-element threshold is prefetched at distance 1
-    using L = Np2Lds<K>;
-    const float* of_p;   // omega * img, float32 plane (FusedArgs::of32)
+    static constexpr bool F32 = std::is_same<F, float>::value;
+    static_assert(F32 || !KQV, "float64 images: scalar threshold only (the threshold plane keeps the generic pipeline)");
+    static constexpr int PFD = KQV ? 1 : (F32 ? DXH_NP2_PFD : DXH_F64P_PFD);   // the per-element threshold is prefetched at distance 1
+    using L = Np2Lds<K, F>;
+    using F2 = typename Np2Vec2<F>::type;
+    const F* of_p;       // omega * img: the float32 plane of a numpy2 context (FusedArgs::of32) / the float64 plane of a float64 image
     const double* u_in;
     const double* q0_in;
     const double* q1_in;
@@ -127,7 +141,7 @@ struct PipeNp2 {
     int64_t P, nrow, R0, R1;
     int nrow32, R0_32, R1_32;
     double dsc, rdsc, kq, negkq;
-    float ell_f, diag_f, rdiag_f;
+    F ell_f, diag_f, rdiag_f;
     bool div3f;         // rhs / diag: one residual correction is exact for every numerator (k_div3_check on this diag)
     bool np2_first;
     bool store_lane;
@@ -139,8 +153,8 @@ struct PipeNp2 {
     char* aR[N];        // (the element itself where the reference replicates: image border, first / last channel)
     char* aCL[N];
     char* aCR[N];
-    float* lb1;         // this lane's pair in b_1 slot 0
-    float* lof;         // this lane's pair in omega*img slot 0
+    F* lb1;             // this lane's pair in b_1 slot 0
+    F* lof;             // this lane's pair in omega*img slot 0
     double* linc;       // eps instantiation: running sums of squared increments, [stage][lane] in LDS
 
     __device__ __forceinline__ void u_put(int slot, const double (&v)[N]) const {
@@ -150,11 +164,14 @@ struct PipeNp2 {
     __device__ __forceinline__ double u_get(const char* a, int slot) const {
         return *reinterpret_cast<const double*>(a + slot * L::USLOT);
     }
-    __device__ __forceinline__ void f_put(float* base, int slot, const float (&v)[N]) const {
-        *reinterpret_cast<float2*>(base + slot * (kWave * N)) = make_float2(v[0], v[1]);
+    __device__ __forceinline__ void f_put(F* base, int slot, const F (&v)[N]) const {
+        F2 t;
+        t.x = v[0];
+        t.y = v[1];
+        *reinterpret_cast<F2*>(base + slot * (kWave * N)) = t;
     }
-    __device__ __forceinline__ void f_get(const float* base, int slot, float (&v)[N]) const {
-        const float2 t = *reinterpret_cast<const float2*>(base + slot * (kWave * N));
+    __device__ __forceinline__ void f_get(const F* base, int slot, F (&v)[N]) const {
+        const F2 t = *reinterpret_cast<const F2*>(base + slot * (kWave * N));
         v[0] = t.x;
         v[1] = t.y;
     }
@@ -165,23 +182,23 @@ struct PipeNp2 {
     __device__ __forceinline__ double* at(double* plane, int64_t row) const {
         return reinterpret_cast<double*>(reinterpret_cast<char*>(plane + row * P) + voff);
     }
-    // the lane's two float32 values of a row of the omega * img plane (same pitch in elements, half the bytes)
-    __device__ __forceinline__ void load_of(int64_t row, float (&v)[N]) const {
-        const float2 t = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(of_p + row * P) + (voff >> 1));
+    // the lane's two values of a row of the omega * img plane (same pitch in elements; float32: half the bytes)
+    __device__ __forceinline__ void load_of(int64_t row, F (&v)[N]) const {
+        const F2 t = *reinterpret_cast<const F2*>(reinterpret_cast<const char*>(of_p + row * P) + (F32 ? (voff >> 1) : voff));
         v[0] = t.x;
         v[1] = t.y;
     }
-    __device__ __forceinline__ void split(double q, double kqj, float& d, float& b) const {
+    __device__ __forceinline__ void split(double q, double kqj, F& d, F& b) const {
         if constexpr (KQV) np2_split_fast(q, -kqj, kqj, d, b);
         else np2_split_fast(q, negkq, kq, d, b);
     }
 
     // un = float64( float32(rhs) / float32(diag) ) + N(u) / diag_scaled        (jacobi.py:107,110-114)
-    __device__ __forceinline__ void divide(const float (&rhs)[N], const double (&acc)[N], double (&un)[N]) const {
-        float rs[N];
+    __device__ __forceinline__ void divide(const F (&rhs)[N], const double (&acc)[N], double (&un)[N]) const {
+        F rs[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) rs[j] = div_by_const3(rhs[j], diag_f, rdiag_f);
-        if (!div3f) {
+        if (!F32 || !div3f) {   // (float64: no exhaustive check exists -- always both corrections)
             DXH_UNIFORM_BRANCH();
 #pragma unroll
             for (int j = 0; j < N; ++j) rs[j] = div_refine(rs[j], rhs[j], diag_f, rdiag_f);
@@ -190,9 +207,9 @@ struct PipeNp2 {
         for (int j = 0; j < N; ++j) un[j] = (double)rs[j] + div_by_const<double>(acc[j], dsc, rdsc);
         // numerators outside the reciprocal chains' proven range (non-zero and tiny): the IEEE divisions.  One cheap
         // screen per lane first (exact zeros trip it and are sorted out by the precise test)
-        const float lo_f = np2_absmin(rhs[0], rhs[1]);
+        const F lo_f = np2_absmin(rhs[0], rhs[1]);
         const double lo_d = np2_absmin(acc[0], acc[1]);
-        if (__builtin_expect(__any(lo_f < DivSafe<float>::tiny || lo_d < DivSafe<double>::tiny), 0)) {
+        if (__builtin_expect(__any(lo_f < DivSafe<F>::tiny || lo_d < DivSafe<double>::tiny), 0)) {
             bool unsafe = false;
 #pragma unroll
             for (int j = 0; j < N; ++j) unsafe = unsafe || div_unsafe(rhs[j]) || div_unsafe(acc[j]);
@@ -205,8 +222,8 @@ struct PipeNp2 {
 
     // ACT: stages 0 .. ACT - 1 run (the first steps of a chunk, fused_np2_body)
     template <int PH, int ACT = K>
-    __device__ __forceinline__ void step(Np2State<K>& st, const int64_t r) const {
-        float frn[N];
+    __device__ __forceinline__ void step(Np2State<K, F>& st, const int64_t r) const {
+        F frn[N];
         if constexpr (PFD == 1) {
             const int64_t rn = clampr(r + 1);
             load_vec(at(u_in, clampr(r + 2)), st.U[0][(PH + 2) & 3]);
@@ -234,16 +251,16 @@ struct PipeNp2 {
             double(&um)[N] = st.U[s][cm];
             double(&uc)[N] = st.U[s][c];
             double(&up)[N] = st.U[s][cp];
-            float(&t0m)[N] = st.t0[s][prv];
-            float(&t0c)[N] = st.t0[s][cur];
-            float(&b0m)[N] = st.b0[s][prv];
-            float(&b0c)[N] = st.b0[s][cur];
+            F(&t0m)[N] = st.t0[s][prv];
+            F(&t0c)[N] = st.t0[s][cur];
+            F(&b0m)[N] = st.b0[s][prv];
+            F(&b0c)[N] = st.b0[s][cur];
             double(&un)[N] = last ? st.U[K][cur] : st.U[s + 1][c];
             const double(&unm)[N] = last ? st.U[K][prv] : st.U[s + 1][cm];
 
             // neighbours of this stage's row: nl / nr (column -+C), cl / cr (channel -+1), replicate rules applied
             double nl[N], nr[N], cl[N], cr[N], q1c[N];
-            float ofv[N];
+            F ofv[N];
             if constexpr (s == 0) {
                 // level 0 comes from HBM into registers: lane shifts by DPP, selects for the replicate rules
                 double ul[N], ur[N], ucl[N], ucr[N];
@@ -267,7 +284,7 @@ struct PipeNp2 {
             } else {
                 // levels >= 1: out of the row stage s - 1 put into LDS one step ago; q_1 = D_1 u + b_1 is formed here
                 constexpr int slot = (s - 1) * 2 + cur;
-                float b1p[N];
+                F b1p[N];
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
                     nl[j] = u_get(aL[j], slot);
@@ -284,11 +301,11 @@ struct PipeNp2 {
             }
 
             // d_j = float32(shrink(q_j)), b_j = float32(q_j - d_j), t_j = ell (b_j - d_j) in float32   (:84-89,143-146)
-            float b1c[N], t1c[N];
+            F b1c[N], t1c[N];
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 const double kqj = KQV ? st.kqv[s][j] : kq;
-                float d0f, b0f, d1f, b1f;
+                F d0f, b0f, d1f, b1f;
                 split((s == 0) ? st.q0l[cur][j] : q0h[j], kqj, d0f, b0f);
                 split(q1c[j], kqj, d1f, b1f);
                 t0c[j] = ell_f * (b0f - d0f);
@@ -319,21 +336,21 @@ struct PipeNp2 {
                     t0m[j] = t0c[j];
                 }
             }
-            float rhs[N];
+            F rhs[N];
             double acc[N];
             if constexpr (EDGE) {
-                float t1l[N];
+                F t1l[N];
                 shifted2f<-C>(t1c, t1l);
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
-                    const float rf = ofv[j] + (t0c[j] - t0m[j]);
+                    const F rf = ofv[j] + (t0c[j] - t0m[j]);
                     rhs[j] = rf + (t1c[j] - sel_bits(edgeL[j], t1c[j], t1l[j]));
                 }
             } else {
                 // interior strips: the lane shift rides on the subtraction where the neighbour is one lane away
                 static_for<0, N>([&](auto jc) {
                     constexpr int j = decltype(jc)::value;
-                    const float rf = ofv[j] + (t0c[j] - t0m[j]);
+                    const F rf = ofv[j] + (t0c[j] - t0m[j]);
                     rhs[j] = rf + add_shifted_elem<-C, j, true>(t1c[j], t1c);
                 });
             }
@@ -348,7 +365,7 @@ struct PipeNp2 {
                 }
                 acc[j] = a;
             }
-            if constexpr (s == 0) {
+            if constexpr (s == 0 && F32) {
                 if (np2_first) {  // u is the float32 image: the reference's accumulator is float32 too (wave-uniform)
                     DXH_UNIFORM_BRANCH();
 #pragma unroll
@@ -446,13 +463,14 @@ struct PipeNp2 {
     }
 };
 
-template <int C, bool COUPLED, int K, bool NTS, bool EDGE, bool NORM, bool KQV>
+template <int C, bool COUPLED, int K, bool NTS, bool EDGE, bool NORM, bool KQV, typename F>
 __device__ __forceinline__ void fused_np2_body(const FusedArgs<double>& a, const int strip, const int chunk, const int lane,
                                                char* lds_wave, double* linc_lane) {
     constexpr int N = 2;
+    constexpr bool F32 = std::is_same<F, float>::value;
     using SG = StripGeomK<double, C, K>;
-    using PipeT = PipeNp2<C, COUPLED, K, NTS, EDGE, NORM, KQV>;
-    using L = Np2Lds<K>;
+    using PipeT = PipeNp2<C, COUPLED, K, NTS, EDGE, NORM, KQV, F>;
+    using L = Np2Lds<K, F>;
     PipeT pp;
     pp.linc = linc_lane;
     chunk_rows(a, chunk, pp.R0, pp.R1);
@@ -462,8 +480,8 @@ __device__ __forceinline__ void fused_np2_body(const FusedArgs<double>& a, const
     if (xl < 0) xl = 0;
     if (xl > a.pitch - N) xl = a.pitch - N;
     pp.store_lane = lane >= SG::LH && lane < SG::LH + SG::VALID && x0 < a.L;
-    pp.lb1 = reinterpret_cast<float*>(lds_wave + L::B1_OFF) + lane * N;
-    pp.lof = reinterpret_cast<float*>(lds_wave + L::OF_OFF) + lane * N;
+    pp.lb1 = reinterpret_cast<F*>(lds_wave + L::B1_OFF) + lane * N;
+    pp.lof = reinterpret_cast<F*>(lds_wave + L::OF_OFF) + lane * N;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         const int64_t x = x0 + j;
@@ -483,7 +501,8 @@ __device__ __forceinline__ void fused_np2_body(const FusedArgs<double>& a, const
         pp.aCL[j] = lds_wave + L::elem_off(cc == 0 ? e : e - 1);
         pp.aCR[j] = lds_wave + L::elem_off(cc == C - 1 ? e : e + 1);
     }
-    pp.of_p = a.of32;
+    if constexpr (F32) pp.of_p = a.of32;
+    else pp.of_p = a.of;
     pp.u_in = a.u_in;
     pp.q0_in = a.q0_in;
     pp.q1_in = a.q1_in;
@@ -501,13 +520,13 @@ __device__ __forceinline__ void fused_np2_body(const FusedArgs<double>& a, const
     pp.rdsc = a.c.rdsc;
     pp.kq = a.c.kq;
     pp.negkq = -a.c.kq;
-    pp.ell_f = (float)a.c.ell;
-    pp.diag_f = (float)a.c.diag;
-    pp.rdiag_f = 1.0f / pp.diag_f;     // RN(1 / diag): IEEE division, once per wave
-    pp.div3f = a.np2_div3 != 0;
-    pp.np2_first = a.np2_first != 0;
+    pp.ell_f = (F)a.c.ell;
+    pp.diag_f = (F)a.c.diag;
+    pp.rdiag_f = F(1) / pp.diag_f;     // RN(1 / diag): IEEE division, once per wave
+    pp.div3f = F32 && a.np2_div3 != 0;
+    pp.np2_first = F32 && a.np2_first != 0;
 
-    Np2State<K> st;
+    Np2State<K, F> st;
 #pragma unroll
     for (int l = 0; l <= K; ++l)
 #pragma unroll
@@ -519,7 +538,7 @@ __device__ __forceinline__ void fused_np2_body(const FusedArgs<double>& a, const
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < N; ++j) st.t0[l][i][j] = st.b0[l][i][j] = 0.0f;
+            for (int j = 0; j < N; ++j) st.t0[l][i][j] = st.b0[l][i][j] = F(0);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -532,7 +551,7 @@ __device__ __forceinline__ void fused_np2_body(const FusedArgs<double>& a, const
     for (int l = 0; l < K; ++l) st.kbad[l] = false;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-        st.of0[j] = 0.0f;
+        st.of0[j] = F(0);
         st.kqn[j] = 0.0;
     }
     {
@@ -568,7 +587,7 @@ __device__ __forceinline__ void fused_np2_body(const FusedArgs<double>& a, const
         if constexpr (KQV) st.kbad[0] = __any(!(st.kqv[0][0] >= 0.0) || !(st.kqv[0][1] >= 0.0)) != 0;
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-            float df, bf;
+            F df, bf;
             if constexpr (KQV) np2_split<false>(q0v[j], kqm[j], df, bf);   // (once per chunk: the general expression)
             else pp.split(q0v[j], pp.kq, df, bf);
             st.t0[0][1][j] = pp.ell_f * (bf - df);   // parity "prv" of phase 0
@@ -615,11 +634,12 @@ __device__ __forceinline__ void fused_np2_body(const FusedArgs<double>& a, const
     }
 }
 
-template <int C, bool COUPLED, int K, bool NORM, bool KQV, bool NTS = true>
-__global__ void __launch_bounds__(256, (KQV ? DXH_NP2_WAVES_KQV : DXH_NP2_WAVES)) k_fused_multi_np2(FusedArgs<double> a) {
+template <int C, bool COUPLED, int K, bool NORM, bool KQV, bool NTS = true, typename F = float>
+__global__ void __launch_bounds__(256, (std::is_same<F, double>::value ? DXH_F64P_WAVES : (KQV ? DXH_NP2_WAVES_KQV : DXH_NP2_WAVES)))
+k_fused_multi_np2(FusedArgs<double> a) {
     constexpr int N = 2;
     using SG = StripGeomK<double, C, K>;
-    using L = Np2Lds<K>;
+    using L = Np2Lds<K, F>;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
     constexpr int WPB = 4;
@@ -635,9 +655,9 @@ __global__ void __launch_bounds__(256, (KQV ? DXH_NP2_WAVES_KQV : DXH_NP2_WAVES)
     char* lds_wave = lds_all + (size_t)wave * L::BYTES;
     double* linc_lane = NORM ? lds_inc + (size_t)wave * (K * kWave) + lane : lds_inc;
     if (edge)
-        fused_np2_body<C, COUPLED, K, NTS, true, NORM, KQV>(a, strip, chunk, lane, lds_wave, linc_lane);
+        fused_np2_body<C, COUPLED, K, NTS, true, NORM, KQV, F>(a, strip, chunk, lane, lds_wave, linc_lane);
     else
-        fused_np2_body<C, COUPLED, K, NTS, false, NORM, KQV>(a, strip, chunk, lane, lds_wave, linc_lane);
+        fused_np2_body<C, COUPLED, K, NTS, false, NORM, KQV, F>(a, strip, chunk, lane, lds_wave, linc_lane);
     signal_chunk_done(a, chunk, lane);
 }
 

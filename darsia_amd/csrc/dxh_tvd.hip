@@ -636,6 +636,14 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
         c->no_kernel = true;   // never a silent no-op: the callers turn this into DXH_ESTATE (launched_or_fail)
         return;
     }
+    // float64 images, anisotropic, scalar coefficients: the numpy2 pipeline's structure with every quantity float64
+    // (dxh_np2_pipe.h, F = double; DXH_FUSED_TUNE bit 4194304: the generic Pipe<double>, A/B)
+    if constexpr (std::is_same<T, double>::value && !ISO && (C == 1 || C == 3) && K == kNp2K) {
+        if (!c->het && !(c->tune & 4194304)) {
+            launch_multi_kernel_f64p(C, COUPLED, want_inc, a, grid, c->stream);
+            return;
+        }
+    }
     // the kernels are instantiated in dxh_multi.hip (one object per element type and K, built in parallel)
     if constexpr (C == 1 || C == 3) launch_multi_kernel<T, K>(C, COUPLED, ISO, want_inc, pair, a, grid, c->stream);
     else launch_multi_kernel_c24<T, K>(C, COUPLED, ISO, want_inc, pair, a, grid, c->stream);

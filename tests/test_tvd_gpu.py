@@ -435,13 +435,14 @@ def test_isotropic_relaxations_verified_per_threshold_change_no_bit(monkeypatch)
     rng = np.random.default_rng(77)
     img = rng.random((96, 300, 3)).astype(np.float32)
     img[10:20, 30:60] = 0.0
-    img[40, 100:120] *= 1e20
-    img[50, 10:40] *= 1e-25
+    img[40, 100:120] *= 1e12     # squares beyond 2^60: the IEEE branch (no overflow: the results stay finite and comparable)
+    img[50, 10:40] *= 1e-25      # squares below 2^-60: the IEEE branch
     for mu, ell in ((0.1, None), (0.37, 0.11), (0.05, 2.0), (1.0, 0.7)):
         lean, _ = run_device(img, mu=mu, ell=ell, n_iter=8, isotropic=True)
         monkeypatch.setenv("DXH_FUSED_TUNE", "2097152")
         screened, _ = run_device(img, mu=mu, ell=ell, n_iter=8, isotropic=True)
         monkeypatch.delenv("DXH_FUSED_TUNE")
+        assert np.isfinite(lean).all()
         assert_bits(lean, screened)
         assert_bits(lean, O.split_bregman_tvd(img, mu=mu, ell=ell, max_num_iter=8, isotropic=True, promotion="strict"))
 

@@ -24,7 +24,7 @@ for n in (8, 4, 2):
     line = {"ranks": n, "rows": rows}
     for mode in ("overlap", "serial"):
         plan = make_plan(rows, 1, 0, K_HALO, periodic=True)
-        s = SlabTVD(plan, periodic_slab(img, plan), mu=0.1, halo_iters=K_HALO, comm=comm,
+        s = SlabTVD(plan, periodic_slab(img, plan), mu=0.1, halo_iters=K_HALO, comm=comm, promotion=os.environ.get('DXH_BENCH_FLOW', 'native'),
                     flags=_lib.FLAG_NO_OVERLAP if mode == "serial" else 0)
         s.run(ITERS, more_to_come=True, asynchronous=True)
         s.synchronize()

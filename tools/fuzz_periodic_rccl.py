@@ -28,16 +28,17 @@ def main():
             k = int(rng.integers(1, left + 1)) if rng.random() < 0.5 else left
             parts.append(k); left -= k
         plan = make_plan(h, 1, 0, halo, periodic=True)
-        s = SlabTVD(plan, periodic_slab(img, plan), mu=0.1, halo_iters=halo, comm=comm, flags=flags)
+        flow = "numpy2" if rng.random() < 0.5 else "native"      # both dtype flows of float32 images
+        s = SlabTVD(plan, periodic_slab(img, plan), mu=0.1, halo_iters=halo, comm=comm, flags=flags, promotion=flow)
         done = 0
         for p in parts:
             done += s.run(p, more_to_come=done + p < n, asynchronous=bool(rng.random() < 0.7))
         got = s.owned_result(); s.close()
         tiled = np.ascontiguousarray(np.concatenate([img, img, img], axis=0))
-        with da.DeviceTVD(tiled.shape, tiled.dtype, dim=2) as st:
+        with da.DeviceTVD(tiled.shape, tiled.dtype, dim=2, promotion=flow) as st:
             st.set_coeffs(0.1, 1.0, None, tiled); st.upload(tiled); st.run(n); ref = st.download()[h:2 * h]
         ok = np.array_equal(got, ref)
-        print(("ok      " if ok else "MISMATCH"), shape, f"halo={halo} n={n} parts={parts} no_overlap={bool(flags)} wait={os.environ.get('DXH_SLAB_WAIT', '-')}", flush=True)
+        print(("ok      " if ok else "MISMATCH"), shape, f"{flow} halo={halo} n={n} parts={parts} no_overlap={bool(flags)} wait={os.environ.get('DXH_SLAB_WAIT', '-')}", flush=True)
         bad += int(not ok)
     comm.close()
     print(f"{n_cases} cases, {bad} mismatches")

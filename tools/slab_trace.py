@@ -12,7 +12,7 @@ os.environ.setdefault("MASTER_PORT", "29613")
 comm = Comm.rccl(0, 1, device=0)
 img = synthetic_image(8000 // n, 16000, 3)
 plan = make_plan(img.shape[0], 1, 0, k, periodic=True)
-s = SlabTVD(plan, periodic_slab(img, plan), mu=0.1, halo_iters=k, comm=comm,
+s = SlabTVD(plan, periodic_slab(img, plan), mu=0.1, halo_iters=k, comm=comm, promotion='native',
             flags=_lib.FLAG_NO_OVERLAP if mode == "serial" else 0)
 s.run(100, more_to_come=True, asynchronous=True)
 s.synchronize()
