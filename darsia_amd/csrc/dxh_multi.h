@@ -29,8 +29,14 @@ void launch_multi_kernel_c24(int C, bool coupled, bool iso, bool want_inc, bool 
 #ifndef DXH_F64P_WAVES      // the same pipeline for float64 images (16.6 KB of LDS per wave: two blocks per CU)
 #define DXH_F64P_WAVES 2
 #endif
-#ifndef DXH_F64P_PFD
-#define DXH_F64P_PFD 1
+#ifndef DXH_F64P_PFD        // prefetch distance of the two-waves-per-SIMD variants: two row steps (-2 % against one, measured)
+#define DXH_F64P_PFD 2
+#endif
+#ifndef DXH_NP2_WAVES_K6    // six iterations per pass (single-channel images): 15.7 KB of LDS per wave, two blocks per CU
+#define DXH_NP2_WAVES_K6 2
+#endif
+#ifndef DXH_NP2_PFD_K6
+#define DXH_NP2_PFD_K6 2
 #endif
 #ifndef DXH_NP2_WAVES_KQV   // threshold-plane variant: K more threshold rows in registers (168 VGPRs spill 24 - 108 bytes per lane)
 #define DXH_NP2_WAVES_KQV 2
@@ -43,6 +49,10 @@ constexpr int kNp2K = 4;
 void launch_multi_kernel_np2_scalar(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
 // ... C in {2, 4}, scalar threshold (object np2_s24)
 void launch_multi_kernel_np2_scalar_c24(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
+// single-channel float32 images, scalar threshold: kNp2GrayK iterations per pass (HBM-bound at K = 4: 52 B per element and
+// launch; object np2_g6)
+constexpr int kNp2GrayK = 6;
+void launch_multi_kernel_np2_gray6(bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
 // the same K-stage pipeline with every quantity float64: float64 IMAGES, anisotropic, scalar coefficients, C in {1, 3} (object f64p)
 void launch_multi_kernel_f64p(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
 void launch_multi_kernel_np2_kqv(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);

@@ -24,6 +24,19 @@
 // mu) -- one object each (build.sh: np2_s, np2_q)
 #include "dxh_np2_pipe.h"
 namespace dxh {
+#if DXH_MULTI_NP2 == 4
+void launch_multi_kernel_np2_gray6(bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream) {
+    constexpr int K = kNp2GrayK;
+#define DXH_G6(CP_)                                                                                                         \
+    do {                                                                                                                    \
+        if (want_inc) hipLaunchKernelGGL((k_fused_multi_np2<1, CP_, K, true, false>), dim3(grid), dim3(256), 0, stream, a);  \
+        else hipLaunchKernelGGL((k_fused_multi_np2<1, CP_, K, false, false>), dim3(grid), dim3(256), 0, stream, a);          \
+    } while (0)
+    if (coupled) DXH_G6(true); else DXH_G6(false);
+#undef DXH_G6
+}
+}  // namespace dxh
+#else
 #if DXH_MULTI_NP2 == 3
 #define DXH_NP2_KQV false
 #define DXH_NP2_F double
@@ -57,6 +70,7 @@ void launch_multi_kernel_np2_scalar(int C, bool coupled, bool want_inc, const Fu
 #undef DXH_NP2_K
 }
 }  // namespace dxh
+#endif  // DXH_MULTI_NP2 == 4
 #else
 
 namespace dxh {

@@ -61,8 +61,11 @@ struct Np2State {
 //              bound_ctrl DPP gives them).  De-interleaved so that a wave's 8-byte reads at consecutive lanes are consecutive
 //              in LDS: conflict-free (a 16-byte lane stride is a 2-way bank conflict for ds_read_b64: measured, 5.4e7
 //              conflict cycles per launch).  slot = (level - 1) * 2 + parity of the step it is READ in
-//   b_1 rows   2 (K - 1) slots of 64 lanes x 8 B   float32 b_1 of the same rows (the consumer forms q_1 = D_1 u + b_1 itself)
-//   omega*img  4 slots of 64 lanes x 8 B          rows r .. r - 3 as float32, written by stage 0
+//   b_1 rows   2 (K - 1) slots of 64 lanes x 2 F   float32 (F) b_1 of the same rows (the consumer forms q_1 = D_1 u + b_1 itself)
+//   omega*img  4 slots of 64 lanes x 2 F          rows r .. r - 3, written by stage 0
+// K > 4 (Np2Lds::FWD; the row loop is unrolled by four, so a ring of K rows has no compile-time slot): omega*img travels down
+// the stages WITH b_1 -- one row of 64 lanes x 4 F per level -- and there is ONE slot per level: every stage's row of the
+// previous step is fetched at the start of the step, before any stage writes (4 (K - 1) registers held through the step)
 template <int K, typename F>
 struct Np2Lds {
     static constexpr int PAD = 16;
@@ -71,9 +74,11 @@ struct Np2Lds {
     static constexpr int NU = 2 * (K - 1);
     static constexpr int U_BYTES = NU * USLOT + PAD;
     static constexpr int B1_OFF = U_BYTES;
-    static constexpr int FSLOT = kWave * 2 * (int)sizeof(F);   // (float64 images: 16 B per lane, 16.6 KB per wave, 2 blocks per CU)
-    static constexpr int OF_OFF = B1_OFF + NU * FSLOT;
-    static constexpr int BYTES = OF_OFF + 4 * FSLOT;        // K = 4: 6352 + 3072 + 2048 = 11472 per wave
+    static constexpr bool FWD = K > 4;
+    static constexpr int FSLOT = kWave * (FWD ? 4 : 2) * (int)sizeof(F);   // (float64 images: 16 B per lane, 16.6 KB per wave, 2 blocks per CU)
+    static constexpr int OF_OFF = B1_OFF + (FWD ? (K - 1) : NU) * FSLOT;
+    // per wave: K = 4 float 6352 + 3072 + 2048 = 11472; K = 6 float (FWD) 10576 + 5120 = 15696 (two blocks of four waves per CU)
+    static constexpr int BYTES = OF_OFF + (FWD ? 0 : 4 * FSLOT);
     // byte offset, within U slot 0, of element e of the wave's window (e = 2 lane + j; e in [-4, 132) stays inside the pads)
     static __device__ __forceinline__ int elem_off(int e) {
         const int par = e & 1;
@@ -127,7 +132,7 @@ struct PipeNp2 {
     static constexpr int N = 2;
     static constexpr bool F32 = std::is_same<F, float>::value;
     static_assert(F32 || !KQV, "float64 images: scalar threshold only (the threshold plane keeps the generic pipeline)");
-    static constexpr int PFD = KQV ? 1 : (F32 ? DXH_NP2_PFD : DXH_F64P_PFD);   // the per-element threshold is prefetched at distance 1
+    static constexpr int PFD = KQV ? 1 : (F32 ? (K > 4 ? DXH_NP2_PFD_K6 : DXH_NP2_PFD) : DXH_F64P_PFD);   // the per-element threshold is prefetched at distance 1
     using L = Np2Lds<K, F>;
     using F2 = typename Np2Vec2<F>::type;
     const F* of_p;       // omega * img: the float32 plane of a numpy2 context (FusedArgs::of32) / the float64 plane of a float64 image
@@ -174,6 +179,25 @@ struct PipeNp2 {
         const F2 t = *reinterpret_cast<const F2*>(base + slot * (kWave * N));
         v[0] = t.x;
         v[1] = t.y;
+    }
+    // FWD rows: (b_1 pair, omega*img pair) of one level, 4 F per lane
+    __device__ __forceinline__ void fw_put(int slot, const F (&b1)[N], const F (&of)[N]) const {
+        F2* p = reinterpret_cast<F2*>(lb1 + slot * (kWave * 4));
+        F2 t, o;
+        t.x = b1[0];
+        t.y = b1[1];
+        o.x = of[0];
+        o.y = of[1];
+        p[0] = t;
+        p[1] = o;
+    }
+    __device__ __forceinline__ void fw_get(int slot, F (&b1)[N], F (&of)[N]) const {
+        const F2* p = reinterpret_cast<const F2*>(lb1 + slot * (kWave * 4));
+        const F2 t = p[0], o = p[1];
+        b1[0] = t.x;
+        b1[1] = t.y;
+        of[0] = o.x;
+        of[1] = o.y;
     }
     __device__ __forceinline__ int64_t clampr(int64_t r) const { return r < 0 ? 0 : (r > nrow - 1 ? nrow - 1 : r); }
     __device__ __forceinline__ const double* at(const double* plane, int64_t row) const {
@@ -238,7 +262,16 @@ struct PipeNp2 {
             load_vec(at(q0_in, rn), st.pf[PH & 1][2]);
             load_vec(at(q1_in, rn), st.pf[PH & 1][3]);
         }
-        if constexpr (K > 1) f_put(lof, PH & 3, st.of0);   // omega*img of row r for the later stages
+        F hb1[L::FWD ? K : 1][N], hof[L::FWD ? K : 1][N];
+        if constexpr (L::FWD) {
+            // every stage's (b_1, omega*img) row of the previous step comes out of LDS before any stage of this step writes
+            static_for<1, ACT>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                fw_get(s - 1, hb1[s], hof[s]);
+            });
+        } else if constexpr (K > 1) {
+            f_put(lof, PH & 3, st.of0);   // omega*img of row r for the later stages
+        }
         double q0h[N];   // Q0 of the next level at the next stage's row, handed from stage to stage
         static_for<0, ACT>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
@@ -294,8 +327,16 @@ struct PipeNp2 {
                         cr[j] = u_get(aCR[j], slot);
                     }
                 }
-                f_get(lb1, slot, b1p);
-                f_get(lof, c, ofv);
+                if constexpr (L::FWD) {
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {
+                        b1p[j] = hb1[s][j];
+                        ofv[j] = hof[s][j];
+                    }
+                } else {
+                    f_get(lb1, slot, b1p);
+                    f_get(lof, c, ofv);
+                }
 #pragma unroll
                 for (int j = 0; j < N; ++j) q1c[j] = (nr[j] - uc[j]) + (double)b1p[j];
             }
@@ -433,7 +474,8 @@ struct PipeNp2 {
             } else {
                 // the new row and its b_1 for stage s + 1, which reads them at the next step (its parity "cur")
                 u_put(s * 2 + prv, un);
-                f_put(lb1, s * 2 + prv, b1c);
+                if constexpr (L::FWD) fw_put(s, b1c, ofv);
+                else f_put(lb1, s * 2 + prv, b1c);
 #pragma unroll
                 for (int j = 0; j < N; ++j) q0h[j] = q0o[j];
             }
@@ -480,7 +522,7 @@ __device__ __forceinline__ void fused_np2_body(const FusedArgs<double>& a, const
     if (xl < 0) xl = 0;
     if (xl > a.pitch - N) xl = a.pitch - N;
     pp.store_lane = lane >= SG::LH && lane < SG::LH + SG::VALID && x0 < a.L;
-    pp.lb1 = reinterpret_cast<F*>(lds_wave + L::B1_OFF) + lane * N;
+    pp.lb1 = reinterpret_cast<F*>(lds_wave + L::B1_OFF) + lane * (L::FWD ? 4 : N);
     pp.lof = reinterpret_cast<F*>(lds_wave + L::OF_OFF) + lane * N;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
@@ -635,7 +677,7 @@ __device__ __forceinline__ void fused_np2_body(const FusedArgs<double>& a, const
 }
 
 template <int C, bool COUPLED, int K, bool NORM, bool KQV, bool NTS = true, typename F = float>
-__global__ void __launch_bounds__(256, (std::is_same<F, double>::value ? DXH_F64P_WAVES : (KQV ? DXH_NP2_WAVES_KQV : DXH_NP2_WAVES)))
+__global__ void __launch_bounds__(256, (std::is_same<F, double>::value ? DXH_F64P_WAVES : (KQV ? DXH_NP2_WAVES_KQV : (K > 4 ? DXH_NP2_WAVES_K6 : DXH_NP2_WAVES))))
 k_fused_multi_np2(FusedArgs<double> a) {
     constexpr int N = 2;
     using SG = StripGeomK<double, C, K>;

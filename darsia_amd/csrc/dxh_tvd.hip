@@ -547,7 +547,7 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
             nchunks = std::max<int64_t>(1, target_blocks / nbx);
         } else {
             // blocks resident per CU (one wave of each per SIMD); the numpy2 pipelines have their own register budget
-            const int W = c->np2 ? (kqv_pipe ? DXH_NP2_WAVES_KQV : DXH_NP2_WAVES) : pipe_waves<T, K, false>();
+            const int W = c->np2 ? (kqv_pipe ? DXH_NP2_WAVES_KQV : (K > 4 ? DXH_NP2_WAVES_K6 : DXH_NP2_WAVES)) : pipe_waves<T, K <= 4 ? K : 4, false>();
             // issue cost of one VALU instruction per SIMD with 1 / 2 / 3 / 4 waves taking turns (tools/valubench.hip)
             static const double cpi[5] = {0.0, 6.6, 3.7, 3.5, 3.2};  // 3: fitted to chunk sweeps of this kernel (a third wave adds ~8 %)
             const int64_t cu_per_xcd = std::max(1, c->num_cu / 8);
@@ -633,6 +633,12 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
                 return;
             }
         }
+        if constexpr (std::is_same<T, double>::value && !ISO && C == 1 && K == kNp2GrayK) {
+            if (!c->het) {   // single channel, scalar threshold: six iterations per pass (the K = 4 launch is HBM-bound)
+                launch_multi_kernel_np2_gray6(COUPLED, want_inc, a, grid, c->stream);
+                return;
+            }
+        }
         c->no_kernel = true;   // never a silent no-op: the callers turn this into DXH_ESTATE (launched_or_fail)
         return;
     }
@@ -645,7 +651,8 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
         }
     }
     // the kernels are instantiated in dxh_multi.hip (one object per element type and K, built in parallel)
-    if constexpr (C == 1 || C == 3) launch_multi_kernel<T, K>(C, COUPLED, ISO, want_inc, pair, a, grid, c->stream);
+    if constexpr (K > 4) c->no_kernel = true;   // (six iterations per pass exist in the numpy2 flow only)
+    else if constexpr (C == 1 || C == 3) launch_multi_kernel<T, K>(C, COUPLED, ISO, want_inc, pair, a, grid, c->stream);
     else launch_multi_kernel_c24<T, K>(C, COUPLED, ISO, want_inc, pair, a, grid, c->stream);
 }
 
@@ -666,6 +673,11 @@ static int pick_k(const Ctx* c, int left) {
         // the reference's float32 dtype flow: K = kNp2K pipelines -- scalar threshold for 1 - 4 channels, threshold plane for 1
         // and 3 --, remainders one iteration per launch (k_fused_np2)
         if (!(c->g.n2 == 1 || c->g.n2 == 3) && c->het) return 1;
+        // single channel, scalar threshold: six iterations per pass where that leaves no worse a remainder than fours do
+        // (DXH_FUSED_TUNE bit 8388608: fours only, A/B)
+        if (c->g.n2 == 1 && !c->het && c->fuse_k >= kNp2K && !(c->tune & 8388608) &&
+            (left == kNp2GrayK || left == kNp2GrayK + 1 || left >= kNp2GrayK + 4))
+            return kNp2GrayK;
         return (c->fuse_k >= kNp2K && left >= kNp2K) ? kNp2K : 1;
     }
     if (c->het) return (c->fuse_k >= kHetFuseK && left >= kHetFuseK) ? kHetFuseK : 1;
@@ -679,6 +691,11 @@ static void launch_fused_multi_c(Ctx* c, int in, int out, bool iso, int K, bool 
     switch (K) {                                                                      \
         case 2: launch_fused_multi_t<T, C, CP_, ISO_, 2>(c, in, out, want_inc); break;          \
         case 3: launch_fused_multi_t<T, C, CP_, ISO_, 3>(c, in, out, want_inc); break;          \
+        case kNp2GrayK:                                                                         \
+            if constexpr (C == 1 && !ISO_ && std::is_same<T, double>::value)                    \
+                launch_fused_multi_t<T, C, CP_, ISO_, kNp2GrayK>(c, in, out, want_inc);         \
+            else c->no_kernel = true;                                                           \
+            break;                                                                              \
         default: launch_fused_multi_t<T, C, CP_, ISO_, 4>(c, in, out, want_inc); break;         \
     }
     if (coupled) { if (iso) { DXH_M(true, true) } else { DXH_M(true, false) } }
@@ -1831,7 +1848,7 @@ static int run_slab_t(Ctx* c, int n_iter, int m, double eps, uint32_t flags, dxh
             K = use_eps ? 1 : std::min(pick_k(c, left), cap);
             if (K >= 2 && !(dpp && multi_supported(c))) K = 1;
             if (K >= 2 && c->het && !c->np2 && K != kHetFuseK) K = 1;
-            if (K >= 2 && c->np2 && K != kNp2K) K = 1;   // numpy2 flow: the pipelines exist for K = kNp2K only
+            if (K >= 2 && c->np2 && K != kNp2K && K != kNp2GrayK) K = K > kNp2K ? kNp2K : 1;   // numpy2 flow: the K its pipelines exist for
             const int in = c->cur, out = c->cur ^ 1;
             const bool xchg_after = dist && (c->halo_valid - (int64_t)K * m < m) &&
                                     (done + K < n_iter || (flags & DXH_FLAG_CONTINUE)) && !use_eps;
