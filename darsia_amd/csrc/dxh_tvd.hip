@@ -605,7 +605,7 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
     a.of32 = nullptr;
     a.iso_lean = a.iso_div3 = 0;
     if constexpr (ISO && std::is_same<T, float>::value) {
-        if (!c->het && !(c->tune & 2097152)) {   // (DXH_FUSED_TUNE bit 2097152: the screened five-operation form, A/B)
+        if (!c->het && !(c->tune & 16777216)) {   // (DXH_FUSED_TUNE bit 16777216: the screened five-operation form, A/B)
             const unsigned r = iso_relaxations_verified(c, (float)c->c_kq);
             a.iso_lean = (r & 1u) ? 1 : 0;
             a.iso_div3 = (r & 2u) ? 1 : 0;

@@ -430,7 +430,7 @@ def test_multi_sweep_jacobi_on_volumes(shape, dtype, maxiter):
 def test_isotropic_relaxations_verified_per_threshold_change_no_bit(monkeypatch):
     """The K-stage isotropic float pipelines drop the per-element significand screen and stop the quotient after one residual
     correction when an exhaustive device check of every float x in [2^-60, 2^60) says so for the call's threshold
-    (iso_split_vec / k_isolean_check): same bits as the screened five-operation form (DXH_FUSED_TUNE bit 2097152) and as the
+    (iso_split_vec / k_isolean_check): same bits as the screened five-operation form (DXH_FUSED_TUNE bit 16777216) and as the
     oracle, for thresholds of several magnitudes, incl. values that take the IEEE branch (zeros, huge, tiny)."""
     rng = np.random.default_rng(77)
     img = rng.random((96, 300, 3)).astype(np.float32)
@@ -439,7 +439,7 @@ def test_isotropic_relaxations_verified_per_threshold_change_no_bit(monkeypatch)
     img[50, 10:40] *= 1e-25      # squares below 2^-60: the IEEE branch
     for mu, ell in ((0.1, None), (0.37, 0.11), (0.05, 2.0), (1.0, 0.7)):
         lean, _ = run_device(img, mu=mu, ell=ell, n_iter=8, isotropic=True)
-        monkeypatch.setenv("DXH_FUSED_TUNE", "2097152")
+        monkeypatch.setenv("DXH_FUSED_TUNE", "16777216")
         screened, _ = run_device(img, mu=mu, ell=ell, n_iter=8, isotropic=True)
         monkeypatch.delenv("DXH_FUSED_TUNE")
         assert np.isfinite(lean).all()
