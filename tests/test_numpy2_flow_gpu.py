@@ -382,6 +382,43 @@ def test_full_size_config2_default_call_windows_against_the_oracle(monkeypatch):
     bits(out3, O.split_bregman_tvd(img, mu=0.1, max_num_iter=3))
 
 
+def test_full_size_gray_and_float64_images_windows_against_the_oracle():
+    """The two other instantiations of the LDS-row pipeline at BASELINE's width: (a) a 4000 x 8000 single-channel float32
+    image in the default flow, 100 iterations = 16 launches of six + one of four (kNp2GrayK; the hand-off rows forwarded
+    and single-buffered); (b) a 1500 x 8000 x 3 float64 image, 40 iterations (every quantity float64, `F = double`).  Oracle
+    windows as in the RGB test above; launch counts show which pipeline served."""
+    from darsia_amd.synthetic import synthetic_image
+
+    H, W, n, S = 4000, 8000, 100, 384
+    img = synthetic_image(H, W, 1)
+    with da.DeviceTVD(img.shape, img.dtype, promotion="numpy2") as st:
+        st.set_coeffs(0.1, 1.0, None, img)
+        st.upload(img)
+        res = st.run(n)
+        out = st.download()
+    assert res.launches == 17 and np.isfinite(out).all()
+    m = n + 2
+    for (r0, c0) in ((0, 0), ((H - S) // 2, (W - S) // 2), (H - S, W - S)):
+        crop = np.ascontiguousarray(img[r0:r0 + S, c0:c0 + S])
+        ra, rb = (0 if r0 == 0 else m), (S if r0 + S == H else S - m)
+        ca, cb = (0 if c0 == 0 else m), (S if c0 + S == W else S - m)
+        bits(out[r0 + ra:r0 + rb, c0 + ca:c0 + cb], O.split_bregman_tvd(crop, mu=0.1, max_num_iter=n)[ra:rb, ca:cb])
+    H, n, S = 1500, 40, 256
+    img64 = synthetic_image(H, W, 3).astype(np.float64)
+    with da.DeviceTVD(img64.shape, img64.dtype) as st:
+        st.set_coeffs(0.1, 1.0, None, img64)
+        st.upload(img64)
+        res = st.run(n)
+        out = st.download()
+    assert res.launches == 10
+    m = n + 2
+    for (r0, c0) in ((0, 0), ((H - S) // 2, (W - S) // 2), (H - S, W - S), (H - S, 0)):
+        crop = np.ascontiguousarray(img64[r0:r0 + S, c0:c0 + S])
+        ra, rb = (0 if r0 == 0 else m), (S if r0 + S == H else S - m)
+        ca, cb = (0 if c0 == 0 else m), (S if c0 + S == W else S - m)
+        bits(out[r0 + ra:r0 + rb, c0 + ca:c0 + cb], O.split_bregman_tvd(crop, mu=0.1, max_num_iter=n)[ra:rb, ca:cb])
+
+
 def test_large_host_image_with_array_valued_omega_or_ell():
     """>= 32 MB float32 host image, scalar mu next to a float64 ARRAY omega (or ell): not a row-band case (the bands take
     scalar coefficients) -- the kept-context path serves it, same bits as the explicit device run.  (Regression: the band
