@@ -2614,11 +2614,11 @@ static int solve_banded_impl(const dxh_tvd_desc* desc, const void* img, void* ou
     std::vector<int64_t> cuts;
     if (S == 0) {
         // rates measured on MI355X + PCIe 5 from pageable memory: 50 GB/s each way; per value
-        // and iteration 1.6 ps (float) / 3.6 ps (double) in one piece, isotropic and array-valued coefficients ~1.5x;
+        // and iteration 1.6 ps (float) / 3.3 ps (double) / 3.0 ps (numpy2) in one piece, isotropic and array-valued coefficients ~1.5x;
         // bands iterate ~20 % slower than their share of the whole image (fewer row chunks, the copies alongside)
         const double sec_copy = (double)L * esz / 50e9;
-        double per = desc->dtype == DXH_F32 ? 1.6e-12 : 3.6e-12;
-        if (np2) per = 3.9e-12;
+        double per = desc->dtype == DXH_F32 ? 1.6e-12 : 3.3e-12;
+        if (np2) per = 3.0e-12;   // 0.285 ms per iteration at 96 M elements (round 3: 3.9e-12)
         if ((flags & DXH_FLAG_ISOTROPIC) || mu_arr || omega_arr || ell_arr) per *= 1.5;
         const double sec_comp = (double)L * per * n_iter * jacobi_maxiter;
         band_cuts(H, 1, 1.0, &cuts);
