@@ -128,3 +128,42 @@ def test_rendezvous_file_per_communicator(monkeypatch):
     monkeypatch.setenv("DXH_RENDEZVOUS_FILE", "/tmp/x.id")
     monkeypatch.setattr(parallel, "_rccl_seq", 0)
     assert parallel._rendezvous_path() == "/tmp/x.id" and parallel._rendezvous_path() == "/tmp/x.id.1"
+
+
+def test_slab_runs_follow_the_same_policy(monkeypatch):
+    """SlabTVD (and bench.py's N > 1 path through it) resolves the dtype flow like split_bregman_tvd: explicit, then
+    DXH_PROMOTION, then the reference's own flow wherever the slab path has it."""
+    from darsia_amd.parallel import slab_promotion
+
+    monkeypatch.delenv("DXH_PROMOTION", raising=False)
+    assert slab_promotion(None, np.float32, 0.1, 1.0, None, 2, 1, False) == "numpy2"
+    assert slab_promotion(None, np.float32, np.ones((4, 4)), 1.0, 1.0, 2, 1, False) == "numpy2"      # float64 mu array
+    assert slab_promotion(None, np.float64, 0.1, 1.0, None, 2, 1, False) == "native"
+    assert slab_promotion(None, np.float32, 0.1, 1.0, None, 2, 3, False) == "native"                  # several sweeps
+    assert slab_promotion(None, np.float32, 0.1, 1.0, None, 2, 1, True) == "native"                   # isotropic
+    assert slab_promotion(None, np.float32, 0.1, np.ones((4, 4)), 1.0, 2, 1, False) == "native"       # array omega
+    assert slab_promotion("native", np.float32, 0.1, 1.0, None, 2, 1, False) == "native"
+    with pytest.raises(NotImplementedError):
+        slab_promotion("numpy2", np.float32, 0.1, 1.0, None, 2, 1, True)
+    monkeypatch.setenv("DXH_PROMOTION", "native")
+    assert slab_promotion(None, np.float32, 0.1, 1.0, None, 2, 1, False) == "native"
+
+
+def test_tvd_operator_copies_and_refresh():
+    """ADVICE (round 3): a deep copy of a TVD operator owns its coefficient arrays (an in-place edit of the original's weight
+    map must not reach the copy), device contexts and the lock are not shared, the operator survives pickling, and
+    refresh() exists for the documented no-in-place-edit contract."""
+    import copy
+    import pickle
+
+    w = np.full((6, 7), 0.25)
+    op = da.TVD(method="heterogeneous bregman", weight=w, omega=np.ones((6, 7)), max_num_iter=3, eps=None)
+    cp = copy.deepcopy(op)
+    assert cp.weight is not op.weight and np.array_equal(cp.weight, w) and cp.omega is not op.omega
+    w[2, 3] = 9.0
+    assert cp.weight[2, 3] == 0.25 and op.weight[2, 3] == 9.0
+    assert cp._contexts == {} and cp._lock is not op._lock
+    back = pickle.loads(pickle.dumps(op))
+    assert back.method == op.method and np.array_equal(back.weight, op.weight) and back._contexts == {}
+    op.refresh()        # nothing held: a no-op that must not raise
+    assert op._contexts == {}

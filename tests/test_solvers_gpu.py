@@ -205,3 +205,22 @@ def test_device_resident_chaining_through_jacobi_mg_cg_and_h1():
         assert np.array_equal(out.img.get(), da.H1_regularization(x0, mu=0.4, omega=1.3, solver=da.Jacobi(maxiter=3)))
     with pytest.raises(NotImplementedError):
         da.H1_regularization(da.DeviceArray.from_host(col), mu=0.4, omega=1.3, solver=da.Jacobi(maxiter=9, tol=1e-3))
+
+
+def test_jacobi_takes_array_likes_and_numpy_scalar_coefficients():
+    """ADVICE (round 3): ``Jacobi.__call__`` coerces lists like the reference's NumPy expressions do; NumPy-scalar
+    coefficients (strongly typed under NEP 50, unlike Python floats) stay with the native flow instead of being erased."""
+    rng = np.random.default_rng(3)
+    x0 = rng.random((12, 17)).astype(np.float32)
+    rhs = (1.3 * x0).astype(np.float32)
+    s = da.Jacobi(maxiter=3)
+    s.update_params(mass_coeff=1.3, diffusion_coeff=0.4, dim=2)
+    a = s(x0, rhs)
+    b = s(x0.tolist(), rhs.tolist())           # lists: float64 arrays after np.asarray -> the float64 (native) solve
+    assert a.dtype == np.float64 and b.dtype == np.float64
+    assert np.array_equal(b, tv.jacobi(np.asarray(x0.tolist()), np.asarray(rhs.tolist()), 1.3, 0.4, dim=2, maxiter=3))
+    assert np.array_equal(a, tv.jacobi(x0, rhs, 1.3, 0.4, dim=2, maxiter=3))          # the reference's NumPy-2 flow
+    s32 = da.Jacobi(maxiter=3)
+    s32.update_params(mass_coeff=np.float32(1.3), diffusion_coeff=np.float32(0.4), dim=2)
+    c = s32(x0, rhs)
+    assert c.dtype == np.float32                # float32 scalars keep a float32 array float32 in NumPy as well
