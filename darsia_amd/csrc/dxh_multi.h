@@ -38,6 +38,9 @@ void launch_multi_kernel_c24(int C, bool coupled, bool iso, bool want_inc, bool 
 #ifndef DXH_NP2_PFD_K6
 #define DXH_NP2_PFD_K6 2
 #endif
+#ifndef DXH_NP2_PREFETCH     // dxh_np2_pipe.h: stage s fetches stage s + 1's LDS operands before its own tail
+#define DXH_NP2_PREFETCH 1
+#endif
 #ifndef DXH_NP2_WAVES_KQV   // threshold-plane variant: K more threshold rows in registers (168 VGPRs spill 24 - 108 bytes per lane)
 #define DXH_NP2_WAVES_KQV 2
 #endif

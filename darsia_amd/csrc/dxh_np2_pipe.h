@@ -273,6 +273,28 @@ struct PipeNp2 {
             f_put(lof, PH & 3, st.of0);   // omega*img of row r for the later stages
         }
         double q0h[N];   // Q0 of the next level at the next stage's row, handed from stage to stage
+        // DXH_NP2_PREFETCH: stage s issues the LDS reads of stage s + 1 (rows written in the PREVIOUS step, so they may be
+        // fetched at any time) before its own tail -- the divisions' consumers, the q updates, the stores -- instead of
+        // stage s + 1 waiting for them at its head
+        double pnl[N], pnr[N], pcl[N], pcr[N];
+        F pb1[N], pof[N];
+        auto fetch = [&](auto sn) {
+            constexpr int s1 = decltype(sn)::value;           // the stage whose operands are fetched
+            constexpr int slot1 = (s1 - 1) * 2 + (PH & 1);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                pnl[j] = u_get(aL[j], slot1);
+                pnr[j] = u_get(aR[j], slot1);
+                if constexpr (COUPLED) {
+                    pcl[j] = u_get(aCL[j], slot1);
+                    pcr[j] = u_get(aCR[j], slot1);
+                }
+            }
+            if constexpr (!L::FWD) {
+                f_get(lb1, slot1, pb1);
+                f_get(lof, (PH - s1) & 3, pof);
+            }
+        };
         static_for<0, ACT>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             constexpr int c = (PH - s) & 3;
@@ -318,13 +340,25 @@ struct PipeNp2 {
                 // levels >= 1: out of the row stage s - 1 put into LDS one step ago; q_1 = D_1 u + b_1 is formed here
                 constexpr int slot = (s - 1) * 2 + cur;
                 F b1p[N];
+                if constexpr (DXH_NP2_PREFETCH) {
 #pragma unroll
-                for (int j = 0; j < N; ++j) {
-                    nl[j] = u_get(aL[j], slot);
-                    nr[j] = u_get(aR[j], slot);
-                    if constexpr (COUPLED) {
-                        cl[j] = u_get(aCL[j], slot);
-                        cr[j] = u_get(aCR[j], slot);
+                    for (int j = 0; j < N; ++j) {
+                        nl[j] = pnl[j];
+                        nr[j] = pnr[j];
+                        if constexpr (COUPLED) {
+                            cl[j] = pcl[j];
+                            cr[j] = pcr[j];
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {
+                        nl[j] = u_get(aL[j], slot);
+                        nr[j] = u_get(aR[j], slot);
+                        if constexpr (COUPLED) {
+                            cl[j] = u_get(aCL[j], slot);
+                            cr[j] = u_get(aCR[j], slot);
+                        }
                     }
                 }
                 if constexpr (L::FWD) {
@@ -332,6 +366,12 @@ struct PipeNp2 {
                     for (int j = 0; j < N; ++j) {
                         b1p[j] = hb1[s][j];
                         ofv[j] = hof[s][j];
+                    }
+                } else if constexpr (DXH_NP2_PREFETCH) {
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {
+                        b1p[j] = pb1[j];
+                        ofv[j] = pof[j];
                     }
                 } else {
                     f_get(lb1, slot, b1p);
@@ -423,6 +463,7 @@ struct PipeNp2 {
                 }
             }
             divide(rhs, acc, un);
+            if constexpr (DXH_NP2_PREFETCH && s + 1 < ACT) fetch(IC<s + 1>{});
             if (p32 >= nrow32) {  // below the image: replicate the new iterate
                 DXH_UNIFORM_BRANCH();
 #pragma unroll
