@@ -49,6 +49,8 @@ run np2_s dxh_multi.hip -DDXH_MULTI_T=double -DDXH_MULTI_K=4 -DDXH_MULTI_NP2=1
 run np2_q dxh_multi.hip -DDXH_MULTI_T=double -DDXH_MULTI_K=4 -DDXH_MULTI_NP2=2
 run f64p dxh_multi.hip -DDXH_MULTI_T=double -DDXH_MULTI_K=4 -DDXH_MULTI_NP2=3
 run np2_g6 dxh_multi.hip -DDXH_MULTI_T=double -DDXH_MULTI_K=6 -DDXH_MULTI_NP2=4
+run np2_s2 dxh_multi.hip -DDXH_MULTI_T=double -DDXH_MULTI_K=2 -DDXH_MULTI_NP2=5
+run np2_s3 dxh_multi.hip -DDXH_MULTI_T=double -DDXH_MULTI_K=3 -DDXH_MULTI_NP2=5
 run np2_s24 dxh_multi.hip -DDXH_MULTI_T=double -DDXH_MULTI_K=4 -DDXH_MULTI_NP2=1 -DDXH_MULTI_CSET=1
 run tvd dxh_tvd.hip
 run chambolle dxh_chambolle.hip

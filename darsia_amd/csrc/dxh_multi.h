@@ -50,6 +50,9 @@ void launch_multi_kernel_c24(int C, bool coupled, bool iso, bool want_inc, bool 
 // (build.sh: np2_s, np2_q, np2_s24).
 constexpr int kNp2K = 4;
 void launch_multi_kernel_np2_scalar(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
+// ... two / three iterations per pass (the remainders of an iteration count; objects np2_s2, np2_s3)
+void launch_multi_kernel_np2_scalar_k2(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
+void launch_multi_kernel_np2_scalar_k3(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
 // ... C in {2, 4}, scalar threshold (object np2_s24)
 void launch_multi_kernel_np2_scalar_c24(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
 // single-channel float32 images, scalar threshold: kNp2GrayK iterations per pass (HBM-bound at K = 4: 52 B per element and

@@ -24,7 +24,26 @@
 // mu) -- one object each (build.sh: np2_s, np2_q)
 #include "dxh_np2_pipe.h"
 namespace dxh {
-#if DXH_MULTI_NP2 == 4
+#if DXH_MULTI_NP2 == 5
+// two / three iterations per pass, scalar threshold, C in {1, 3}: the remainders of an iteration count (objects np2_s2, np2_s3)
+#if DXH_MULTI_K == 2
+void launch_multi_kernel_np2_scalar_k2(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream) {
+#else
+void launch_multi_kernel_np2_scalar_k3(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream) {
+#endif
+    constexpr int K = DXH_MULTI_K;
+    static_assert(K == 2 || K == 3, "remainder pipelines");
+#define DXH_R(C_, CP_)                                                                                                       \
+    do {                                                                                                                     \
+        if (want_inc) hipLaunchKernelGGL((k_fused_multi_np2<C_, CP_, K, true, false>), dim3(grid), dim3(256), 0, stream, a);  \
+        else hipLaunchKernelGGL((k_fused_multi_np2<C_, CP_, K, false, false>), dim3(grid), dim3(256), 0, stream, a);          \
+    } while (0)
+    if (C == 1) { if (coupled) DXH_R(1, true); else DXH_R(1, false); }
+    else        { if (coupled) DXH_R(3, true); else DXH_R(3, false); }
+#undef DXH_R
+}
+}  // namespace dxh
+#elif DXH_MULTI_NP2 == 4
 void launch_multi_kernel_np2_gray6(bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream) {
     constexpr int K = kNp2GrayK;
 #define DXH_G6(CP_)                                                                                                         \

@@ -633,6 +633,13 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
                 return;
             }
         }
+        if constexpr (std::is_same<T, double>::value && !ISO && (C == 1 || C == 3) && (K == 2 || K == 3)) {
+            if (!c->het) {   // the remainders of an iteration count: two / three iterations per pass
+                if constexpr (K == 2) launch_multi_kernel_np2_scalar_k2(C, COUPLED, want_inc, a, grid, c->stream);
+                else launch_multi_kernel_np2_scalar_k3(C, COUPLED, want_inc, a, grid, c->stream);
+                return;
+            }
+        }
         if constexpr (std::is_same<T, double>::value && !ISO && C == 1 && K == kNp2GrayK) {
             if (!c->het) {   // single channel, scalar threshold: six iterations per pass (the K = 4 launch is HBM-bound)
                 launch_multi_kernel_np2_gray6(COUPLED, want_inc, a, grid, c->stream);
@@ -678,7 +685,10 @@ static int pick_k(const Ctx* c, int left) {
         if (c->g.n2 == 1 && !c->het && c->fuse_k >= kNp2K && !(c->tune & 8388608) &&
             (left == kNp2GrayK || left == kNp2GrayK + 1 || left >= kNp2GrayK + 4))
             return kNp2GrayK;
-        return (c->fuse_k >= kNp2K && left >= kNp2K) ? kNp2K : 1;
+        if (c->fuse_k >= kNp2K && left >= kNp2K) return kNp2K;
+        // remainders: two / three iterations per pass exist for the scalar threshold on 1 and 3 channels
+        if (!c->het && (c->g.n2 == 1 || c->g.n2 == 3) && left >= 2) return std::min(std::min(c->fuse_k, left), 3);
+        return 1;
     }
     if (c->het) return (c->fuse_k >= kHetFuseK && left >= kHetFuseK) ? kHetFuseK : 1;
     return std::max(1, std::min(c->fuse_k, left));
@@ -1848,7 +1858,10 @@ static int run_slab_t(Ctx* c, int n_iter, int m, double eps, uint32_t flags, dxh
             K = use_eps ? 1 : std::min(pick_k(c, left), cap);
             if (K >= 2 && !(dpp && multi_supported(c))) K = 1;
             if (K >= 2 && c->het && !c->np2 && K != kHetFuseK) K = 1;
-            if (K >= 2 && c->np2 && K != kNp2K && K != kNp2GrayK) K = K > kNp2K ? kNp2K : 1;   // numpy2 flow: the K its pipelines exist for
+            if (K >= 2 && c->np2 && K != kNp2K && K != kNp2GrayK) {   // numpy2 flow: the K its pipelines exist for
+                const bool small_k = !c->het && (c->g.n2 == 1 || c->g.n2 == 3);   // two / three iterations per pass
+                K = K > kNp2K ? kNp2K : (small_k ? K : 1);
+            }
             const int in = c->cur, out = c->cur ^ 1;
             const bool xchg_after = dist && (c->halo_valid - (int64_t)K * m < m) &&
                                     (done + K < n_iter || (flags & DXH_FLAG_CONTINUE)) && !use_eps;

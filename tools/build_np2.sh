@@ -13,7 +13,13 @@ p3=$!
 p4=$!
 /opt/rocm/bin/hipcc "${F[@]}" -DDXH_MULTI_T=double -DDXH_MULTI_K=6 -DDXH_MULTI_NP2=4 -c "${HERE}/dxh_multi.hip" -o "${HERE}/_build/np2_g6.o" &
 p5=$!
+/opt/rocm/bin/hipcc "${F[@]}" -DDXH_MULTI_T=double -DDXH_MULTI_K=2 -DDXH_MULTI_NP2=5 -c "${HERE}/dxh_multi.hip" -o "${HERE}/_build/np2_s2.o" &
+p6=$!
+/opt/rocm/bin/hipcc "${F[@]}" -DDXH_MULTI_T=double -DDXH_MULTI_K=3 -DDXH_MULTI_NP2=5 -c "${HERE}/dxh_multi.hip" -o "${HERE}/_build/np2_s3.o" &
+p7=$!
 wait $p5
+wait $p6
+wait $p7
 wait $p1
 wait $p2
 wait $p3
