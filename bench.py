@@ -345,8 +345,12 @@ def main():
         img = synthetic_image(H, W, C)
         res = time_single(main_flow, img, a, local_rank, mu)
         if other_flow:
-            # Outside the timed region of `value`, with the same rigour: the same workload in the other dtype flow
-            other = time_single(other_flow, img, a, local_rank, mu)
+            # Outside the timed region of `value`, with the same rigour: the same workload in the other dtype flow (a failure
+            # there is reported in the line, it does not take `value` with it)
+            try:
+                other = time_single(other_flow, img, a, local_rank, mu)
+            except (Exception, SystemExit) as e:  # noqa: BLE001 -- incl. a failed self-check of the OTHER flow
+                other = {"error": f"{type(e).__name__}: {e}"}
         total_rows, rows_per_rank = H, H
     else:
         from darsia_amd.parallel import init_from_env
@@ -412,7 +416,9 @@ def main():
             out["roofline"] = roofline_block(main_flow, elems, C, res["kernel_ms"], res["launches"], a.iters * a.steps, traffic)
             if self_check:
                 out["self_check"] = self_check
-            if other:
+            if other and "error" in other:
+                out["other_flow"] = {"promotion": other_flow, "value": None, "error": other["error"]}
+            elif other:
                 oe = other["elapsed"]
                 out["other_flow"] = {
                     "promotion": other_flow, "what": flow_words(other_flow),
