@@ -121,6 +121,9 @@ int dxh_tvd_set_coeffs(dxh_tvd_t ctx, double mu, const void* mu_arr, double omeg
  * The same with coefficient arrays of either float type (DXH_F32 / DXH_F64 per array): an array whose type is not the
  * image's is converted on the device (round to nearest, like ndarray.astype) -- a float64 porosity map as the weight of a
  * float32 image (presets/workflows/restoration.py:118-140) costs a 2x larger upload instead of a pass over it on the host.
+ * Arrays may be host or device pointers.  In a numpy2 context (dxh_tvd_set_promotion) a FLOAT32 mu array next to scalar omega
+ * and ell becomes the threshold NumPy forms for it -- the float32 quotient mu / float32(ell) (split_bregman_tvd.py:144 with a
+ * float32 array and a Python float), widened -- on the device; a float64 mu array is divided in float64.
  */
 int dxh_tvd_set_coeffs_typed(dxh_tvd_t ctx, double mu, const void* mu_arr, int mu_dtype, double omega, const void* omega_arr,
                              int omega_dtype, int has_ell, double ell, const void* ell_arr, int ell_dtype);
@@ -308,7 +311,8 @@ int dxh_tvd_download_typed(dxh_tvd_t ctx, void* u, int out_dtype);
 
 /*
  * Warm start x0 = (img0, d0, b0) of a numpy2 context (split_bregman_tvd.py:92-96 with float32 arrays): img float32; u0
- * float32 or float64 (u0_dtype), or NULL for img itself; d0, b0 float32 arrays of shape (*img.shape, dim).  Host pointers.
+ * float32 or float64 (u0_dtype), or NULL for img itself; d0, b0 float32 arrays of shape (*img.shape, dim).  Host or device
+ * pointers (a chain of warm-started calls can keep its state in device memory).
  * dxh_tvd_download_split_np2 hands d and b back as the reference leaves them in the caller's arrays (float32; either
  * pointer may be NULL).  Scalar omega and ell.
  */
