@@ -10,7 +10,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import _lib
-from .device import DeviceArray
+from .device import DeviceArray, host_empty
 
 _IN_CODES = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.uint8): 2, np.dtype(np.uint16): 3}
 
@@ -36,7 +36,7 @@ def apply_affine_balance(img: np.ndarray, scaling: np.ndarray, translation=None,
         out = DeviceArray(src.shape, np.float32, device)
     else:
         src, device = np.ascontiguousarray(img), _lib.default_device()
-        out = np.empty(src.shape, np.float32)
+        out = host_empty(src.shape, np.float32)
     _lib.check(_lib.load().dxh_affine_color(device, _IN_CODES[src.dtype], src.size // 3, _lib.ptr(src),
                                              _lib.ptr(a), _lib.ptr(b), int(bool(clip)), _lib.ptr(out)))
     return out

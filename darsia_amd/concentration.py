@@ -35,7 +35,7 @@ import logging
 import numpy as np
 
 from . import _lib
-from .device import DeviceArray
+from .device import DeviceArray, host_empty
 from .image import ScalarImage
 from .restoration.split_bregman_tvd import DeviceTVD
 from .restoration.tvd import TVD
@@ -466,7 +466,7 @@ class ConcentrationAnalysis:
         """The model stage and the way back of the frame whose restoration ``_start_frame`` started."""
         ops = plan[2]
         post = ops if self.first_restoration_then_model else []
-        out = DeviceArray(st.shape, st.dtype, st.device) if on_device else np.empty(st.shape, st.dtype)
+        out = DeviceArray(st.shape, st.dtype, st.device) if on_device else host_empty(st.shape, st.dtype)
         _lib.check(st.lib.dxh_tvd_download_model(st._h, _lib.ptr(out), C.cast(_ops_array(post), C.c_void_p), len(post)))
         return out
 

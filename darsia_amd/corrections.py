@@ -24,7 +24,7 @@ import numpy as np
 from . import _lib
 from .geometry import VoxelArray
 from .image import Image  # noqa: F401
-from .device import DeviceArray
+from .device import DeviceArray, host_empty
 from .registration import _opencv_block_width, get_perspective_transform, warp_patches
 
 _MC_DTYPES = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.uint8): 2, np.dtype(np.uint16): 3}
@@ -60,7 +60,7 @@ def map_coordinates(img, grid, order: int = 1, cval: float = 0.0):
     chans = 1 if src.ndim == 2 else src.shape[2]
     n = int(rows.size)
     out_shape = (n,) if src.ndim == 2 else (n, chans)
-    out = DeviceArray(out_shape, src.dtype, src.device) if on_device else np.empty(out_shape, src.dtype)
+    out = DeviceArray(out_shape, src.dtype, src.device) if on_device else host_empty(out_shape, src.dtype)
     _lib.check(_lib.load().dxh_map_coordinates(
         src.device if on_device else _lib.default_device(), _MC_DTYPES[np.dtype(src.dtype)], src.shape[0], src.shape[1], chans,
         _lib.ptr(src), 0 if coord_dtype == np.float32 else 1, _lib.ptr(rows), _lib.ptr(cols), n, int(order), float(cval),

@@ -18,6 +18,8 @@ from typing import Optional
 
 import numpy as np
 
+from .hostpool import empty as host_empty
+
 from . import _lib
 
 
@@ -57,7 +59,7 @@ class DeviceArray:
     def get(self, out: Optional[np.ndarray] = None) -> np.ndarray:
         """Copy to the host (into ``out`` if given: same shape and dtype, C-contiguous)."""
         if out is None:
-            out = np.empty(self.shape, self.dtype)
+            out = host_empty(self.shape, self.dtype)
         assert out.shape == self.shape and out.dtype == self.dtype and out.flags.c_contiguous
         if self.nbytes:
             _lib.check(self.lib.dxh_mem_copy(self.device, _lib.ptr(out), self.ptr, self.nbytes))

@@ -19,7 +19,7 @@ from typing import Optional
 import numpy as np
 
 from . import _lib
-from .device import DeviceArray
+from .device import DeviceArray, host_empty
 
 INTER_NEAREST, INTER_LINEAR, INTER_AREA = 0, 1, 3  # cv2's flag values
 _DTYPES = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.uint8): 2}
@@ -126,7 +126,7 @@ def cv_resize(img: np.ndarray, dsize=None, fx=None, fy=None, interpolation: Opti
     src = img if on_device else np.ascontiguousarray(img)
     chans = 1 if src.ndim == 2 else src.shape[2]
     out_shape = (dh, dw) if src.ndim == 2 else (dh, dw, chans)
-    out = DeviceArray(out_shape, src.dtype, src.device) if on_device else np.empty(out_shape, src.dtype)
+    out = DeviceArray(out_shape, src.dtype, src.device) if on_device else host_empty(out_shape, src.dtype)
     _lib.check(_lib.load().dxh_resize(src.device if on_device else _lib.default_device(), _DTYPES[src.dtype], h, w, chans,
                                        _lib.ptr(src), dh, dw, C.byref(plan), _lib.ptr(out)))
     return out

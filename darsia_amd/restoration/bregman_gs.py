@@ -17,7 +17,7 @@ from typing import Optional
 import numpy as np
 
 from .. import _lib
-from ..device import DeviceArray
+from ..device import DeviceArray, host_empty
 
 
 def _img_as_float(image: np.ndarray) -> np.ndarray:
@@ -60,7 +60,7 @@ def denoise_tv_bregman(image: np.ndarray, weight: float = 5.0, max_num_iter: int
         return (res, [o[1] for o in outs]) if return_iters else res
     _lib.require_gpu()
     src = np.ascontiguousarray(image)
-    out = np.empty(src.shape, src.dtype)
+    out = host_empty(src.shape, src.dtype)
     dims = src.shape[2] if src.ndim == 3 else 1
     done = C.c_int(0)
     rmse = C.c_double(0.0)

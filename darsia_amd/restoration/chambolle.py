@@ -13,7 +13,7 @@ import ctypes as C
 import numpy as np
 
 from .. import _lib
-from ..device import DeviceArray
+from ..device import DeviceArray, host_empty
 
 
 def denoise_tv_chambolle(image: np.ndarray, weight: float = 0.1, eps: float = 2e-4, max_num_iter: int = 200,
@@ -44,7 +44,7 @@ def denoise_tv_chambolle(image: np.ndarray, weight: float = 0.1, eps: float = 2e
         raise ValueError("arrays with 2 or 3 axes are supported")
     _lib.require_gpu()
     src = np.ascontiguousarray(image)
-    out = np.empty(src.shape, src.dtype)
+    out = host_empty(src.shape, src.dtype)
     n2 = src.shape[2] if src.ndim == 3 else 1
     done = C.c_int(0)
     _lib.check(_lib.load().dxh_chambolle(_lib.default_device(), _lib.dtype_code(src.dtype), src.ndim, src.shape[0],

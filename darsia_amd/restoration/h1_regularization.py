@@ -10,7 +10,7 @@ from typing import Optional
 import numpy as np
 
 from .. import _lib
-from ..device import DeviceArray
+from ..device import DeviceArray, host_empty
 from ..image import with_array
 from ..utils.linear_solvers.jacobi import Jacobi, float32_flow
 from ..utils.linear_solvers.solver import Solver
@@ -95,7 +95,7 @@ def _h1_array(img: np.ndarray, mu: float, omega: float, dim: int, solver: Solver
     # omega * img: on the device when omega is a Python number (NumPy rounds it to the image dtype and multiplies there:
     # the kernel does the same); any other scalar type goes through NumPy's own promotion on the host
     rhs = None if type(omega) in (float, int) else np.ascontiguousarray(omega * src, dtype=img.dtype)
-    out = np.empty(src.shape, src.dtype)
+    out = host_empty(src.shape, src.dtype)
     done = C.c_int(0)
     _lib.check(_lib.load().dxh_jacobi_solve(
         _lib.default_device(), code, ndim, dim, nsum, n0, n1, n2, _lib.ptr(src), _lib.ptr(rhs), _lib.ptr(out),

@@ -37,7 +37,7 @@ from typing import Optional, Union
 import numpy as np
 
 from .. import _lib
-from ..device import DeviceArray
+from ..device import DeviceArray, host_empty
 from ..utils.linear_solvers.cg import CG
 from ..utils.linear_solvers.jacobi import Jacobi
 from ..utils.linear_solvers.mg import MG
@@ -239,7 +239,7 @@ class DeviceTVD:
         """The iterate (and the split variables) as host arrays, or into ``out`` (ndarray or DeviceArray); numpy2 contexts
         write the split variables into ``split_out = (d, b)`` when given (float32 ``(..., dim)`` DeviceArrays or contiguous
         ndarrays)."""
-        u = np.empty(self.shape, self.dtype) if out is None else out
+        u = host_empty(self.shape, self.dtype) if out is None else out
         assert tuple(u.shape) == self.shape and u.dtype == self.dtype
         assert isinstance(u, DeviceArray) or u.flags.c_contiguous
         if self.numpy2:
@@ -253,15 +253,15 @@ class DeviceTVD:
                     assert tuple(a.shape) == self.shape + (self.dim,) and a.dtype == np.float32
                     assert isinstance(a, DeviceArray) or a.flags.c_contiguous
             else:
-                d = np.empty(self.shape + (self.dim,), np.float32)   # the reference's float32 d, b
-                b = np.empty(self.shape + (self.dim,), np.float32)
+                d = host_empty(self.shape + (self.dim,), np.float32)   # the reference's float32 d, b
+                b = host_empty(self.shape + (self.dim,), np.float32)
             _lib.check(self.lib.dxh_tvd_download_split_np2(self._h, _lib.ptr(d), _lib.ptr(b)))
             return u, d, b
         if not want_split:
             _lib.check(self.lib.dxh_tvd_download(self._h, _lib.ptr(u), None, None))
             return u
-        d = np.empty(self.shape + (self.dim,), self.dtype)
-        b = np.empty(self.shape + (self.dim,), self.dtype)
+        d = host_empty(self.shape + (self.dim,), self.dtype)
+        b = host_empty(self.shape + (self.dim,), self.dtype)
         _lib.check(self.lib.dxh_tvd_download(self._h, _lib.ptr(u), _lib.ptr(d), _lib.ptr(b)))
         return u, d, b
 
@@ -284,7 +284,7 @@ def solve_banded(img: np.ndarray, mu, omega, ell, n_iter: int, jacobi_maxiter: i
     d.ndim, d.dim, d.nsum = ndim, 2, _lib.NSUM_ALL_AXES
     d.n0, d.n1, d.n2 = n0, n1, n2
     d.top_is_boundary = d.bottom_is_boundary = 1
-    out = np.empty(src.shape, src.dtype)
+    out = host_empty(src.shape, src.dtype)
     used = C.c_int(0)
     _lib.check(lib.dxh_tvd_solve_banded(C.byref(d), _lib.ptr(src), _lib.ptr(out), mu_s, _lib.ptr(mu_a), om_s, _lib.ptr(om_a),
                                         has_ell, ell_s, _lib.ptr(ell_a), int(n_iter), int(jacobi_maxiter),
@@ -307,7 +307,7 @@ def solve_banded_numpy2(img: np.ndarray, mu: float, omega: float, ell: Optional[
     d.ndim, d.dim, d.nsum = ndim, 2, _lib.NSUM_ALL_AXES
     d.n0, d.n1, d.n2 = n0, n1, n2
     d.top_is_boundary = d.bottom_is_boundary = 1
-    out = np.empty(src.shape, np.float32)
+    out = host_empty(src.shape, np.float32)
     used = C.c_int(0)
     has_ell, ell_s = (0, 0.0) if ell is None else (1, float(ell))
     _lib.check(lib.dxh_tvd_solve_banded_typed(C.byref(d), _lib.ptr(src), _lib.ptr(out), _lib.dtype_code(np.dtype(np.float32)),
@@ -530,7 +530,7 @@ def split_bregman_tvd(
             else:
                 # the result array's pages are mapped on this thread WHILE the device iterates (the blocking C call runs
                 # on a helper thread and holds no GIL): a fresh 384 MB array costs ~14 ms of page faults otherwise
-                out = np.empty(img.shape, img.dtype)
+                out = host_empty(img.shape, img.dtype)
                 box = {}
 
                 def work():
@@ -602,7 +602,7 @@ def split_bregman_tvd(
                 st.run(max_num_iter, solver.maxiter, solver.tol, eps=eps, isotropic=isotropic)
                 if x0 is None:
                     return st.download(out=DeviceArray(img.shape, img.dtype, img.device))
-            out = np.empty(img.shape, img.dtype) if (x0 is None and not on_device) else None
+            out = host_empty(img.shape, img.dtype) if (x0 is None and not on_device) else None
             box = {}
 
             def work():

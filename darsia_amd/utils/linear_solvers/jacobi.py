@@ -20,7 +20,7 @@ import ctypes as C
 import numpy as np
 
 from ... import _lib
-from ...device import DeviceArray
+from ...device import DeviceArray, host_empty
 from .solver import Solver
 
 
@@ -77,7 +77,7 @@ class Jacobi(Solver):
         m_s, m_a = _coef(self.mass_coeff, np.broadcast_to(like, x0.shape) if on_device else x0)
         k_s, k_a = _coef(self.diffusion_coeff, np.broadcast_to(like, x0.shape) if on_device else x0)
         src = x0 if on_device else np.ascontiguousarray(x0)
-        out = DeviceArray(src.shape, src.dtype, src.device) if on_device else np.empty(src.shape, src.dtype)
+        out = DeviceArray(src.shape, src.dtype, src.device) if on_device else host_empty(src.shape, src.dtype)
         done = C.c_int(0)
         tol = -1.0 if self.tol is None else float(self.tol)
         _lib.check(_lib.load().dxh_jacobi_solve(
@@ -100,7 +100,7 @@ class Jacobi(Solver):
         ndim, n0, n1, n2 = _lib.shape3(src.shape, min(self.dim, src.ndim))
         _lib.require_gpu()
         out_dtype = np.dtype(out_dtype)
-        out = DeviceArray(src.shape, out_dtype, src.device) if on_device else np.empty(src.shape, out_dtype)
+        out = DeviceArray(src.shape, out_dtype, src.device) if on_device else host_empty(src.shape, out_dtype)
         done = C.c_int(0)
         _lib.check(_lib.load().dxh_jacobi_solve_np2(
             src.device if on_device else _lib.default_device(), ndim, self.dim, nsum, n0, n1, n2, _lib.ptr(src), _lib.ptr(rhs),

@@ -20,7 +20,7 @@ from typing import Optional, Union
 import numpy as np
 
 from ... import _lib
-from ...device import DeviceArray
+from ...device import DeviceArray, host_empty
 from .solver import Solver
 
 
@@ -80,14 +80,14 @@ class _DeviceSolverHandle:
             x0 = np.ascontiguousarray(x0, dtype=self.dtype)
         if not isinstance(rhs, DeviceArray):
             rhs = np.ascontiguousarray(rhs, dtype=self.dtype)
-        out = DeviceArray(x0.shape, x0.dtype, x0.device) if on_device else np.empty(x0.shape, x0.dtype)
+        out = DeviceArray(x0.shape, x0.dtype, x0.device) if on_device else host_empty(x0.shape, x0.dtype)
         n = C.c_int32(0)
         _lib.check(self.lib.dxh_solver_solve(self._h, _lib.ptr(x0), _lib.ptr(rhs), _lib.ptr(out), C.byref(n)))
         return out, n.value
 
     def get_params(self, want_mass, want_diffusion):
-        m = np.empty(self.shape, self.dtype) if want_mass else None
-        k = np.empty(self.shape, self.dtype) if want_diffusion else None
+        m = host_empty(self.shape, self.dtype) if want_mass else None
+        k = host_empty(self.shape, self.dtype) if want_diffusion else None
         _lib.check(self.lib.dxh_solver_get_params(self._h, _lib.ptr(m), _lib.ptr(k)))
         return m, k
 

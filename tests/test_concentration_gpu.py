@@ -162,6 +162,34 @@ def test_series_map_equals_frame_by_frame(n_frames):
         assert isinstance(g, da.ScalarImage) and g.img.dtype == w_.dtype and np.array_equal(g.img, w_)
 
 
+def test_series_results_are_recycled_only_when_dead():
+    """Large host results come out of the pool of recycled result arrays (darsia_amd/hostpool.py): a streaming caller gets the
+    pages of the result it dropped, a caller who keeps results never sees one change."""
+    import gc
+
+    from darsia_amd import hostpool
+
+    hostpool.trim()
+    h, w = 1536, 1600   # 9.8 MB of float32 per result: above the pool's threshold
+    base, _ = _frames(h, w, 40)
+    frames = [_frames(h, w, 41 + i)[1] for i in range(4)]
+    ca = da.ConcentrationAnalysis(base, da.MonochromaticReduction(color="red"), None,
+                                  da.TVD(method="heterogeneous bregman", weight=0.1, max_num_iter=5, eps=None), None)
+    kept = [r.img for r in ca.map(frames)]
+    copies = [k.copy() for k in kept]
+    assert len({k.ctypes.data for k in kept}) == 4
+    seen = set()
+    for i, r in enumerate(ca.map(frames)):          # streaming: each result dropped before the next is fetched
+        assert np.array_equal(r.img, copies[i])
+        seen.add(r.img.ctypes.data)
+        del r
+        gc.collect()
+    assert len(seen) < 4                            # pages were re-used ...
+    assert not seen & {k.ctypes.data for k in kept}
+    assert all(np.array_equal(k, c) for k, c in zip(kept, copies))   # ... but never those of a live result
+    hostpool.trim()
+
+
 def test_series_map_mixed_frames_and_early_exit():
     base, _ = _frames(48, 64, 30)
     a, b = _frames(48, 64, 31)[1], _frames(48, 64, 32)[1]

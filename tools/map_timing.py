@@ -59,3 +59,14 @@ print("map: %.2f ms/frame (8 frames)  %.2f ms/frame (16 frames)" % (series(8), s
 t0 = time.perf_counter()
 res = [ca(probe_img) for _ in range(8)]
 print("frame by frame: %.2f ms/frame" % ((time.perf_counter() - t0) * 1e3 / 8))
+
+def streaming(n):
+    """Each result dropped before the next one is fetched, as a caller reducing every frame to a number would."""
+    t0 = time.perf_counter()
+    acc = 0.0
+    for r in ca.map([probe_img] * n):
+        acc += float(r.img[17, 17])
+        del r
+    return (time.perf_counter() - t0) * 1e3 / n
+streaming(4)
+print("map, results dropped as they come: %.2f ms/frame (8 frames)  %.2f ms/frame (16 frames)" % (streaming(8), streaming(16)))
