@@ -119,6 +119,7 @@ struct Ctx {
     bool np2_mu_is_kq = false;   // the given mu array already is the threshold mu / ell (float32 quotient, widened)
     bool np2_mu_auto = false;    // ... because dxh_tvd_set_coeffs_typed formed that quotient itself from a float32 mu array
     bool ell_is_arr = false, om_is_arr = false;   // set_coeffs: ell (given, or 2 mu) / omega is an array
+    int np2_sweeps = 0;          // > 0 while run_t launches the S-sweeps-per-iteration pipeline (dxh_np2_sweeps.h): S
     bool np2_q32 = false;        // the stored q was formed in float32 (the solver handed the float32 iterate back): Np2Coef::q32
     bool np2_adapted = false;    // dxh_tvd_adapt_ell on a numpy2 context: cp_ell / cp_kq hold the adapted float32 ell and threshold
 
@@ -547,7 +548,8 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
             nchunks = std::max<int64_t>(1, target_blocks / nbx);
         } else {
             // blocks resident per CU (one wave of each per SIMD); the numpy2 pipelines have their own register budget
-            const int W = c->np2 ? (kqv_pipe ? DXH_NP2_WAVES_KQV : (K > 4 ? DXH_NP2_WAVES_K6 : DXH_NP2_WAVES)) : pipe_waves<T, K <= 4 ? K : 4, false>();
+            const int W = c->np2_sweeps ? np2_sweep_waves(K)
+                                          : c->np2 ? (kqv_pipe ? DXH_NP2_WAVES_KQV : (K > 4 ? DXH_NP2_WAVES_K6 : DXH_NP2_WAVES)) : pipe_waves<T, K <= 4 ? K : 4, false>();
             // issue cost of one VALU instruction per SIMD with 1 / 2 / 3 / 4 waves taking turns (tools/valubench.hip)
             static const double cpi[5] = {0.0, 6.6, 3.7, 3.5, 3.2};  // 3: fitted to chunk sweeps of this kernel (a third wave adds ~8 %)
             const int64_t cu_per_xcd = std::max(1, c->num_cu / 8);
@@ -620,6 +622,16 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
         const float fd = (float)c->c_diag;
         if (std::isfinite(fd) && std::fabs(fd) >= 0x1p-20f && std::fabs(fd) <= 0x1p+20f && !(c->tune & 128))
             a.np2_div3 = div3_verified(c, fd, fd);
+        if (c->np2_sweeps) {   // ONE iteration of K Jacobi sweeps per pass (dxh_np2_sweeps.h; objects np2_sw2 .. np2_sw6)
+            if constexpr (std::is_same<T, double>::value && !ISO && (C == 1 || C == 3) && K >= kNp2SweepsMin && K <= kNp2SweepsMax) {
+                if ((!c->het || a.kqv) && c->np2_sweeps == K && !want_inc) {
+                    launch_np2_sweeps<K>(C, COUPLED, a.kqv != 0, a, grid, c->stream);
+                    return;
+                }
+            }
+            c->no_kernel = true;
+            return;
+        }
         // the reference's float32 dtype flow: PipeNp2 (dxh_np2_pipe.h; dxh_multi.hip objects np2_s / np2_q); pick_k only asks for
         // the combinations that exist
         if constexpr (std::is_same<T, double>::value && !ISO && (C == 1 || C == 3) && K == kNp2K) {
@@ -701,8 +713,13 @@ static void launch_fused_multi_c(Ctx* c, int in, int out, bool iso, int K, bool 
     switch (K) {                                                                      \
         case 2: launch_fused_multi_t<T, C, CP_, ISO_, 2>(c, in, out, want_inc); break;          \
         case 3: launch_fused_multi_t<T, C, CP_, ISO_, 3>(c, in, out, want_inc); break;          \
+        case 5:                                                                                 \
+            if constexpr ((C == 1 || C == 3) && !ISO_ && std::is_same<T, double>::value)        \
+                launch_fused_multi_t<T, C, CP_, ISO_, 5>(c, in, out, want_inc);                 \
+            else c->no_kernel = true;                                                           \
+            break;                                                                              \
         case kNp2GrayK:                                                                         \
-            if constexpr (C == 1 && !ISO_ && std::is_same<T, double>::value)                    \
+            if constexpr ((C == 1 || C == 3) && !ISO_ && std::is_same<T, double>::value)        \
                 launch_fused_multi_t<T, C, CP_, ISO_, kNp2GrayK>(c, in, out, want_inc);         \
             else c->no_kernel = true;                                                           \
             break;                                                                              \
@@ -1432,7 +1449,14 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
     const bool explicit_mode = (flags & DXH_FLAG_EXPLICIT) || c->explicit_db;
     const bool fused3d_ok = fused3d_supported(c) && jacobi_maxiter == 1 && !use_tol && !(flags & DXH_FLAG_NO_FUSED) &&
                             !c->solver && !explicit_mode && !c->np2;
-    const bool need_generic = (!fused_ok && !fused3d_ok) || c->from_db || c->np2_q32;
+    // numpy2, Jacobi(maxiter = 2 .. 6) without a tolerance, scalar omega / ell, 1 / 3 channels: one pass per iteration with
+    // the sweeps as its stages (dxh_np2_sweeps.h; DXH_FUSED_TUNE bit 33554432: the three-launch flow instead, A/B)
+    const bool sweeps_ok = c->np2 && std::is_same<T, double>::value && dim == 2 && (c->g.n2 == 1 || c->g.n2 == 3) &&
+                           (!c->het || (c->het_cdiag && c->cp_kq && make_coef<T>(c).const_diag && !(c->tune & 65536))) &&
+                           jacobi_maxiter >= kNp2SweepsMin && jacobi_maxiter <= kNp2SweepsMax && !use_tol && dpp &&
+                           !(flags & DXH_FLAG_NO_FUSED) && !explicit_mode && fused_supported(c) && multi_supported(c) &&
+                           c->of32_valid && !(c->tune & 33554432);
+    const bool need_generic = (!fused_ok && !fused3d_ok && !sweeps_ok) || c->from_db || c->np2_q32;
     if (need_generic) {
         int rc = alloc_plane(c, &c->rs);
         if (rc) return rc;
@@ -1540,6 +1564,14 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
             it += K - 1;
             ++launches;
             c->cur = out;
+        } else if (sweeps_ok && !c->from_db && !c->np2_q32) {
+            c->np2_sweeps = jacobi_maxiter;
+            launch_fused_multi<T>(c, in, out, false, jacobi_maxiter);
+            c->np2_sweeps = 0;
+            if (int rc = launched_or_fail(c, jacobi_maxiter)) return rc;
+            c->np2_first = false;
+            ++launches;
+            c->cur = out;
         } else if (fused3d_ok && !c->from_db) {
             launch_fused3d<T>(c, in, out, iso);
             ++launches;
@@ -1570,7 +1602,7 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
         } else if (c->np2) {   // np2_generic, or the first iteration of a warm start
             // (with an eps test the previous iterate must survive the iteration: its plane is where the fused pass would put
             // the next first sweep)
-            const bool more = it + 1 < n_iter && !use_eps;
+            const bool more = it + 1 < n_iter && !use_eps && !sweeps_ok;   // (the sweeps pipeline starts from the plain state)
             int rc = dim == 2 ? np2_generic_iteration<2>(c, jacobi_maxiter, jacobi_tol, tmp, &launches, more)
                               : np2_generic_iteration<3>(c, jacobi_maxiter, jacobi_tol, tmp, &launches, more);
             if (rc) return rc;

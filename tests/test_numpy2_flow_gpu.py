@@ -648,3 +648,49 @@ def test_a_tolerance_met_by_the_first_sweep_hands_the_float32_iterate_back():
     x0 = img[..., 0].copy()
     out = sol(x0, x0)
     assert out.dtype == np.float32 and np.array_equal(out, x0)
+
+
+# ---- Jacobi(maxiter = 2 .. 6) on 1 / 3 channels with scalar coefficients: ONE pass per iteration (dxh_np2_sweeps.h) ----
+@pytest.mark.parametrize("sweeps", [2, 3, 4, 5, 6])
+@pytest.mark.parametrize("shape", [(41, 700, 3), (300, 517), (23, 60, 3), (2, 2), (9, 131, 1)])
+@pytest.mark.parametrize("mu_kind", ["scalar", "array", "array with negative entries"])
+def test_several_sweeps_run_as_one_pass_per_iteration_bit_for_bit_against_the_oracle(sweeps, shape, mu_kind, monkeypatch):
+    """Strips of both kinds (image-border and interior waves), chunk starts inside the image (DXH_NCHUNKS), the first
+    iteration on the float32 image and later calls on the float64 iterate, the reference's replicate rules at every border --
+    against the oracle's reference flow (jacobi.py:107-114 inside split_bregman_tvd.py:129-146); the launch count shows the
+    pipeline served the call, and the three-launch flow it replaces (DXH_FUSED_TUNE bit 33554432) gives the same bits."""
+    rng = np.random.default_rng(sweeps * 100 + shape[1])
+    img = rng.random(shape, dtype=np.float32)
+    kw = dict(mu=0.13, omega=0.9, ell=0.35)
+    if mu_kind != "scalar":   # a float64 weight map next to scalar omega / ell: the threshold mu / ell is a plane
+        kw["mu"] = 0.13 * (0.2 + 0.8 * rng.random(shape))
+        if mu_kind.endswith("negative entries"):
+            kw["mu"][rng.random(shape) < 0.02] *= -1.0
+            kw["mu"].flat[0] = -0.0
+    n = 4
+    ref, dl, bl, _ = O.split_bregman_tvd(img, max_num_iter=n, jacobi_maxiter=sweeps, promotion="numpy2", return_state=True, **kw)
+    ref2 = O.split_bregman_tvd(img, max_num_iter=n + 3, jacobi_maxiter=sweeps, promotion="numpy2", **kw)
+    for chunks, tune in ((None, None), ("2", None), (None, "33554432")):
+        if chunks and shape[0] < 200:
+            continue
+        monkeypatch.delenv("DXH_NCHUNKS", raising=False)
+        monkeypatch.delenv("DXH_FUSED_TUNE", raising=False)
+        if chunks:
+            monkeypatch.setenv("DXH_NCHUNKS", chunks)
+        if tune:
+            monkeypatch.setenv("DXH_FUSED_TUNE", tune)
+        with da.DeviceTVD(img.shape, img.dtype, promotion="numpy2") as st:
+            st.set_coeffs(kw["mu"], kw["omega"], kw["ell"], img)
+            st.upload(img)
+            r = st.run(n, jacobi_maxiter=sweeps)
+            pipelined = shape[-1] in (1, 3) or len(shape) == 2
+            assert (r.launches == n) == (tune is None and pipelined), (r.launches, chunks, tune)
+            u, d, b = st.download(want_split=True)
+            bits(u, ref)
+            bits(d, np.stack(dl, axis=-1))
+            bits(b, np.stack(bl, axis=-1))
+            r = st.run(3, jacobi_maxiter=sweeps)     # the context goes on from its float64 iterate: n + 3 iterations in all
+            bits(st.download(), ref2)
+    monkeypatch.delenv("DXH_NCHUNKS", raising=False)
+    monkeypatch.delenv("DXH_FUSED_TUNE", raising=False)
+    bits(da.split_bregman_tvd(img, max_num_iter=n, solver=da.Jacobi(maxiter=sweeps), **kw), ref)

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Developer: rebuild only the objects of dxh_np2_sweeps.h (np2_sw2 .. np2_sw6) and dxh_tvd.hip, relink libdarsia_hip.so.
+# Extra args -> hipcc; DXH_OUT = another output library (A/B variants).
+set -euo pipefail
+HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")/../darsia_amd/csrc" && pwd)"
+F=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function "$@")
+pids=()
+for k in 6 5 4 3 2; do
+    /opt/rocm/bin/hipcc "${F[@]}" -DDXH_SWEEPS_K=${k} -c "${HERE}/dxh_np2_sweeps.hip" -o "${HERE}/_build/np2_sw${k}.o" &
+    pids+=($!)
+done
+/opt/rocm/bin/hipcc "${F[@]}" -c "${HERE}/dxh_tvd.hip" -o "${HERE}/_build/tvd.o" &
+pids+=($!)
+for p in "${pids[@]}"; do wait "$p"; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC "${HERE}"/_build/*.o -o "${DXH_OUT:-${HERE}/../libdarsia_hip.so}"
+echo "relinked ${DXH_OUT:-${HERE}/../libdarsia_hip.so}"
