@@ -27,10 +27,10 @@ from __future__ import annotations
 
 import copy
 import ctypes as C
+import logging
+import os
 from typing import Optional
 from warnings import warn
-
-import logging
 
 import numpy as np
 
@@ -240,9 +240,11 @@ class ConcentrationAnalysis:
         self._diff_option = kwargs.get("diff option", "absolute")
         self.first_restoration_then_model = kwargs.get("restoration -> model", False)
         self.verbosity = kwargs.get("verbosity", 0)
-        self._ctxs = [None, None]      # device contexts: [0] on this thread's stream, [1] on the uploader thread's (map)
-        self._ctx_keys = [None, None]
+        # device contexts: [0] on this thread's stream, [1] on the uploader thread's, [2] on a helper thread's (map)
+        self._ctxs = [None, None, None]
+        self._ctx_keys = [None, None, None]
         self._uploader = None
+        self._slot2_thread = None
         self.find_cleaning_filter()
         self.mask = None if self.base is None else np.ones(self.base.img.shape[:2], dtype=bool)
 
@@ -284,12 +286,12 @@ class ConcentrationAnalysis:
             for img in baseline_images:
                 mono = self._reduce_signal(self._subtract_background(img.copy()))
                 self.threshold_cleaning_filter = np.maximum(self.threshold_cleaning_filter, mono)
-        self._ctx_keys = [None, None]  # device copies are stale
+        self._ctx_keys = [None, None, None]  # device copies are stale
 
     def update(self, base=None, mask=None) -> None:
         if base is not None:
             self.base = base.copy()
-            self._ctx_keys = [None, None]
+            self._ctx_keys = [None, None, None]
         if mask is not None:
             self.mask = mask
 
@@ -373,8 +375,9 @@ class ConcentrationAnalysis:
         return np.dtype(dt)
 
     def _ctx_for(self, slot: int, key, channels: int) -> DeviceTVD:
-        """Scalar TV context of slot 0 / 1 with the baseline and the cleaning filter resident.  A context takes the
-        stream of the thread that creates it: slot 0 belongs to the caller's thread, slot 1 to the uploader's (map)."""
+        """Scalar TV context of a slot with the baseline and the cleaning filter resident.  A context takes the stream of
+        the thread that creates it: slot 0 belongs to the caller's thread, slot 1 to the uploader's, slot 2 to a helper
+        thread that does nothing else (map)."""
         if self._ctxs[slot] is None or self._ctx_keys[slot] != key:
             if self._ctxs[slot] is not None:
                 self._ctxs[slot].close()
@@ -398,16 +401,17 @@ class ConcentrationAnalysis:
         """Drop every device-side copy (baseline, cleaning filter, coefficient planes): the next frame uploads them
         again.  Needed after an IN-PLACE edit of the baseline image or of a coefficient array of the restoration (new
         objects are noticed by themselves, ``_fingerprint``)."""
-        self._ctx_keys = [None, None]
+        self._ctx_keys = [None, None, None]
         for st in getattr(self, "_ctxs", []):
             if st is not None:
                 st._coef_mark = None
 
     def close(self) -> None:
         """Release the device contexts and the uploader thread (both come back on demand)."""
-        if getattr(self, "_uploader", None) is not None:
-            self._uploader.shutdown(wait=True)
-            self._uploader = None
+        for name in ("_uploader", "_slot2_thread"):
+            if getattr(self, name, None) is not None:
+                getattr(self, name).shutdown(wait=True)
+                setattr(self, name, None)
         for i, st in enumerate(getattr(self, "_ctxs", [])):
             if st is not None:
                 st.close()
@@ -527,37 +531,49 @@ class ConcentrationAnalysis:
             self._upload_frame(self._ctx_for(slot, key, channels), img.img, plan)
 
         fut = submit(0, cur)
+        fut_next = None
         try:
             # Two slots, two schedules (measured on 4000 x 8000 frames, 100 TV iterations; three slots with everything side
             # by side were slower than either):
             #  * upload-bound (float32 / float64 colour frames in the native flow: 7 - 15 ms of PCIe per frame): frame k + 1
             #    goes up while frame k iterates, runs its model stage and comes back;
             #  * compute-bound (the reference's float32 flow, whose TV stage is 2.3 x longer; frames of few bytes per
-            #    pixel): frame k iterates (enqueued) while frame k - 1 comes back, then frame k + 1 goes up into the slot that
-            #    became free -- results are yielded one frame behind the iterations.
+            #    pixel): frame k iterates (enqueued) while frame k - 1 comes back AND frame k + 1 goes up into a THIRD slot
+            #    (three contexts on three streams: the copy up, the iterations and the copy down all overlap) -- results are
+            #    yielded one frame behind the iterations.  DXH_MAP_SLOTS=2: frame k + 1 goes up only after frame k - 1 has
+            #    come back, into its slot (round 3's schedule, A/B).
             bytes_per_pixel = cur.img.dtype.itemsize * (1 if cur.img.ndim == 2 else cur.img.shape[2])
             late_upload = plan[5] == "hb2" or bytes_per_pixel <= 6
+            ns = 3 if (late_upload and os.environ.get("DXH_MAP_SLOTS", "3") != "2") else 2
+            if ns == 3:
+                if self._slot2_thread is None:
+                    self._slot2_thread = ThreadPoolExecutor(max_workers=1, thread_name_prefix="dxh-slot2")
+                self._slot2_thread.submit(self._ctx_for, 2, key, channels).result()
             k = 0
             pending = None   # (slot, image) of the frame whose iterations have been started but whose result is still on the device
             while cur is not None:
-                fut.result()                                      # frame k is on the device (slot k % 2)
-                fut = None
                 nxt = next(it, None)
                 same = nxt is not None and nxt.img.shape == shape and fusable(nxt) == plan and \
                     self._signal_dtype(nxt.img, plan[0]) == dt
+                if same and ns == 3:
+                    # into the slot of frame k - 2, fetched one turn ago; queued behind the upload of frame k on the uploader
+                    # thread, so that the copies up follow each other without a gap
+                    fut_next = submit((k + 1) % ns, nxt)
+                fut.result()                                      # frame k is on the device (slot k % ns)
+                fut, fut_next = fut_next, None
                 if same and not late_upload:
-                    fut = submit((k + 1) % 2, nxt)   # overlaps the work on frame k below
-                self._start_frame(self._ctxs[k % 2], plan)
+                    fut = submit((k + 1) % ns, nxt)   # overlaps the work on frame k below
+                self._start_frame(self._ctxs[k % ns], plan)
                 if pending is not None:
                     out = self._fetch_frame(self._ctxs[pending[0]], plan, isinstance(pending[1].img, DeviceArray))
                     yield self._wrap(pending[1], out)
                     pending = None
                 if late_upload:
-                    if same:
-                        fut = submit((k + 1) % 2, nxt)   # into the slot just fetched; overlaps the iterations of frame k
-                    pending = (k % 2, cur)
+                    if same and ns == 2:
+                        fut = submit((k + 1) % ns, nxt)   # into the slot just fetched; overlaps the iterations of frame k
+                    pending = (k % ns, cur)
                 else:
-                    out = self._fetch_frame(self._ctxs[k % 2], plan, isinstance(cur.img, DeviceArray))
+                    out = self._fetch_frame(self._ctxs[k % ns], plan, isinstance(cur.img, DeviceArray))
                     yield self._wrap(cur, out)
                 if nxt is not None and not same:
                     # a frame of another kind ends the pipelined stretch
@@ -575,11 +591,12 @@ class ConcentrationAnalysis:
                 out = self._fetch_frame(self._ctxs[pending[0]], plan, isinstance(pending[1].img, DeviceArray))
                 yield self._wrap(pending[1], out)
         finally:
-            if fut is not None:   # generator abandoned or failed: join the upload in flight
-                try:
-                    fut.result()
-                except Exception:
-                    pass
+            for f in (fut, fut_next):   # generator abandoned or failed: join the uploads in flight
+                if f is not None:
+                    try:
+                        f.result()
+                    except Exception:
+                        pass
 
     def __call__(self, img):
         """Extract the concentration from a probing image (concentrationanalysis.py:230-310)."""

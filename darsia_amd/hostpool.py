@@ -1,7 +1,8 @@
 """Recycled host result arrays.
 
 A fresh ``np.empty`` of a 4000 x 8000 float32 result costs ~8 ms of first-touch page faults when the device-to-host copy
-lands in it (10.5 ms against 2.3 ms into pages that are mapped already -- the same 2.3 ms a page-locked buffer gets, measured),
+lands in it (10.5 ms against 2.3 ms into pages that are mapped already -- the same 2.3 ms a page-locked buffer gets, measured;
+page-locking the recycled buffers, hipHostRegister at 6 ms per 128 MB, was tried and changed nothing in a frame series),
 and NumPy hands arrays of that size back to the OS the moment they die.  Frame series (``ConcentrationAnalysis.map``) and
 repeated whole-image calls therefore take their result arrays from here: a buffer goes back to the pool when the array the
 caller was given -- and every view of it -- has been garbage-collected, and the next result of the same size re-uses its
