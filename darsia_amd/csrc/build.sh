@@ -54,6 +54,7 @@ run np2_s3 dxh_multi.hip -DDXH_MULTI_T=double -DDXH_MULTI_K=3 -DDXH_MULTI_NP2=5
 run np2_s24 dxh_multi.hip -DDXH_MULTI_T=double -DDXH_MULTI_K=4 -DDXH_MULTI_NP2=1 -DDXH_MULTI_CSET=1
 for k in 6 5 4 3 2; do run "np2_sw${k}" dxh_np2_sweeps.hip -DDXH_SWEEPS_K=${k}; done   # S Jacobi sweeps per iteration, one pass each
 run tvd dxh_tvd.hip
+run vol_multi dxh_vol_multi.hip
 run chambolle dxh_chambolle.hip
 run dense dxh_dense.hip
 run solvers dxh_solvers.hip

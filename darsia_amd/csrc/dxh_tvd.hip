@@ -21,6 +21,7 @@
 #include "dxh_comm.h"
 #include "dxh_kernels.h"
 #include "dxh_multi.h"
+#include "dxh_vol_multi.h"
 #include "dxh_solvers.h"
 
 namespace dxh {
@@ -1053,9 +1054,44 @@ static void launch_jacobi(Ctx* c, const void* xin, void* xout) {
                        make_coef<T>(c), make_planes_min<T>(c), (T*)xout);
 }
 
-static bool jacobi_multi_supported(const Ctx* c) {
-    // (an array-valued mu alone leaves the sweep's only coefficient, diag_scaled, the scalar of make_coef: het_cdiag)
-    return c->desc.dim == 2 && (!c->het || c->het_cdiag) && (c->g.n2 == 1 || c->g.n2 == 3) && !(c->tune & 64);
+
+// volumes (dim = 3, all three axes in the sum): two or three sweeps per pass in tiles of the (axis 1, axis 2) plane
+// (dxh_vol_multi.h; DXH_FUSED_TUNE bit 67108864: sweep by sweep, A/B)
+static bool jacobi_vol_multi_supported(const Ctx* c) {
+    return c->desc.dim == 3 && c->g.ndim == 3 && c->g.nsum_axes == 3 && (!c->het || c->het_cdiag) && c->g.n1 >= 16 && c->g.n2 >= 32 &&
+           c->g.n1 * c->g.n2 < (int64_t)INT32_MAX && !(c->tune & (64 | 67108864));
+}
+
+// sweeps of the next pass when `left` sweeps remain (0: no multi-sweep pass for this context).  2-D: fours, 5 = 3 + 2;
+// volumes: threes, 4 = 2 + 2.  A last single sweep goes through the one-sweep kernels
+static int jacobi_group(const Ctx* c, int left) {
+    if (left < 2) return 0;
+    if (c->desc.dim == 2) return (c->g.n2 == 1 || c->g.n2 == 3) && (!c->het || c->het_cdiag) && !(c->tune & 64) ? (left == 5 ? 3 : std::min(4, left)) : 0;
+    return jacobi_vol_multi_supported(c) ? (left == 4 ? 2 : std::min(3, left)) : 0;
+}
+
+template <typename T>
+static void launch_jacobi_vol_multi_t(Ctx* c, const void* xin, void* xout, int K) {
+    VolMultiArgs<T> a{};
+    a.rs = (const T*)c->rs;
+    a.x_in = (const T*)xin;
+    a.x_out = (T*)xout;
+    a.n0 = c->g.n0; a.n1 = c->g.n1; a.n2 = c->g.n2; a.pitch = c->g.pitch;
+    const int vy = 32 - 2 * K, vx = 64 - 2 * K;
+    a.tiles_y = (int)((c->g.n1 + vy - 1) / vy);
+    a.tiles_x = (int)((c->g.n2 + vx - 1) / vx);
+    // two blocks per CU are resident: about one round of them, chunks of at least 8 K planes
+    const int64_t tiles = (int64_t)a.tiles_y * a.tiles_x;
+    int64_t nchunks = std::max<int64_t>(1, ((int64_t)c->num_cu * 2 + tiles / 2) / tiles);
+    const int64_t ppc = std::max<int64_t>(8 * K, (c->g.n0 + nchunks - 1) / nchunks);
+    nchunks = (c->g.n0 + ppc - 1) / ppc;
+    a.planes_per_chunk = ppc;
+    a.nchunks = (int)nchunks;
+    a.dsc = (T)c->c_dsc;
+    a.rdsc = T(0);
+    if (std::isfinite((double)a.dsc) && std::fabs((double)a.dsc) >= 0x1p-20 && std::fabs((double)a.dsc) <= 0x1p+20) a.rdsc = T(1) / a.dsc;
+    const int64_t total = tiles * nchunks;
+    launch_jacobi_vol_multi<T>(K, a, (unsigned)(((total + 7) / 8) * 8), c->stream);
 }
 
 template <typename T, int C, bool COUPLED, int K>
@@ -1087,6 +1123,7 @@ static void launch_jacobi_multi_k(Ctx* c, const void* xin, void* xout) {
 
 template <typename T>
 static void launch_jacobi_multi(Ctx* c, const void* xin, void* xout, int K) {
+    if (c->desc.dim == 3) { launch_jacobi_vol_multi_t<T>(c, xin, xout, K); return; }
     const bool coupled = c->g.ndim == 3 && c->g.nsum_axes == 3;
 #define DXH_JM(C_, CP_)                                                        \
     switch (K) {                                                               \
@@ -1139,8 +1176,7 @@ static int jacobi_sweeps(Ctx* c, int maxiter, double tol, void* tmp, int64_t* la
         // (no plane copy at the end; with a tolerance the stop is not known in advance)
         int left = maxiter, passes = 0;
         if (first_f32 && left >= 1) { ++passes; --left; }
-        if (left >= 2 && jacobi_multi_supported(c))
-            while (left >= 2) { left -= (left == 5 ? 3 : std::min(4, left)); ++passes; }
+        for (int k = jacobi_group(c, left); k > 0; k = jacobi_group(c, left)) { left -= k; ++passes; }
         passes += left;
         if (passes >= 2 && passes % 2 == 0) w = 1;
     }
@@ -1171,11 +1207,10 @@ static int jacobi_sweeps(Ctx* c, int maxiter, double tol, void* tmp, int64_t* la
         if (rc) return rc;
         --maxiter;
     }
-    if (!stop && !use_tol && maxiter >= 2 && jacobi_multi_supported(c)) {
+    if (!stop && !use_tol && jacobi_group(c, maxiter) > 0) {
         // several sweeps per pass; a remainder of one sweep goes through the single-sweep kernel below
         int left = maxiter;
-        while (left >= 2) {
-            const int k = left == 5 ? 3 : std::min(4, left);
+        for (int k = jacobi_group(c, left); k > 0; k = jacobi_group(c, left)) {
             void* xn = bufs[w];
             launch_jacobi_multi<T>(c, x, xn, k);
             ++*launches;
@@ -1198,8 +1233,7 @@ static int jacobi_sweeps(Ctx* c, int maxiter, double tol, void* tmp, int64_t* la
 static int jacobi_passes(const Ctx* c, int sweeps, bool first_f32) {
     int left = sweeps, passes = 0;
     if (first_f32 && left >= 1) { ++passes; --left; }
-    if (left >= 2 && jacobi_multi_supported(c))
-        while (left >= 2) { left -= (left == 5 ? 3 : std::min(4, left)); ++passes; }
+    for (int k = jacobi_group(c, left); k > 0; k = jacobi_group(c, left)) { left -= k; ++passes; }
     return passes + left;
 }
 

@@ -694,3 +694,38 @@ def test_several_sweeps_run_as_one_pass_per_iteration_bit_for_bit_against_the_or
     monkeypatch.delenv("DXH_NCHUNKS", raising=False)
     monkeypatch.delenv("DXH_FUSED_TUNE", raising=False)
     bits(da.split_bregman_tvd(img, max_num_iter=n, solver=da.Jacobi(maxiter=sweeps), **kw), ref)
+
+
+# ---- volumes with several Jacobi sweeps: two or three sweeps per pass in plane tiles (dxh_vol_multi.h) ----
+@pytest.mark.parametrize("sweeps", [2, 3, 4, 5, 7, 20])
+@pytest.mark.parametrize("shape", [(9, 40, 70), (30, 16, 32), (5, 61, 129)])
+@pytest.mark.parametrize("kind", ["float32 numpy2", "float32 native", "float64"])
+def test_volume_sweeps_in_plane_tiles_bit_for_bit_against_the_oracle(sweeps, shape, kind, monkeypatch):
+    """The reference's own volume workloads run Jacobi(maxiter=20) inside the TV loop (examples/regularization.py:8-31,
+    examples/paper/pet_simulations_comparison_block_b.py:700-713).  Tiles that touch every face of the volume and interior
+    ones, plane chunks that start inside the volume, every grouping of a sweep count into passes of three and two (+ a
+    single) -- against the oracle (jacobi.py:107-114 with replicate ghosts along all three axes), and against the one-sweep
+    kernels (DXH_FUSED_TUNE bit 67108864), whose launch count shows that the passes replaced them."""
+    rng = np.random.default_rng(sweeps * 31 + shape[2])
+    dtype = np.float64 if kind == "float64" else np.float32
+    vol = rng.random(shape).astype(dtype)
+    promotion = "native" if kind.endswith("native") else ("numpy2" if dtype == np.float32 else None)
+    kw = dict(mu=0.2, omega=0.8, ell=0.4)
+    n = 3
+    ref = O.split_bregman_tvd(vol, dim=3, max_num_iter=n, jacobi_maxiter=sweeps,
+                              promotion={"native": "strict", "numpy2": "numpy2", None: "strict"}[promotion], **kw)
+    launches = {}
+    for tune in (None, "67108864"):
+        monkeypatch.delenv("DXH_FUSED_TUNE", raising=False)
+        if tune:
+            monkeypatch.setenv("DXH_FUSED_TUNE", tune)
+        pk = {} if promotion is None else dict(promotion=promotion)
+        with da.DeviceTVD(vol.shape, vol.dtype, dim=3, **pk) as st:
+            st.set_coeffs(kw["mu"], kw["omega"], kw["ell"], vol)
+            st.upload(vol)
+            launches[tune] = st.run(n, jacobi_maxiter=sweeps).launches
+            bits(st.download(), ref)
+    # (numpy2: the first sweep of an iteration belongs to the fused shrinkage / right-hand-side pass or sums in float32)
+    if sweeps - (1 if promotion == "numpy2" else 0) >= 2:
+        assert launches[None] < launches["67108864"], launches
+    monkeypatch.delenv("DXH_FUSED_TUNE", raising=False)
