@@ -1058,7 +1058,7 @@ static void launch_jacobi(Ctx* c, const void* xin, void* xout) {
 // volumes (dim = 3, all three axes in the sum): two or three sweeps per pass in tiles of the (axis 1, axis 2) plane
 // (dxh_vol_multi.h; DXH_FUSED_TUNE bit 67108864: sweep by sweep, A/B)
 static bool jacobi_vol_multi_supported(const Ctx* c) {
-    return c->desc.dim == 3 && c->g.ndim == 3 && c->g.nsum_axes == 3 && (!c->het || c->het_cdiag) && c->g.n1 >= 16 && c->g.n2 >= 32 &&
+    return c->desc.dim == 3 && c->g.ndim == 3 && c->g.nsum_axes == 3 && (!c->het || c->het_cdiag || c->cp_dsc) && c->g.n1 >= 16 && c->g.n2 >= 32 &&
            c->g.n1 * c->g.n2 < (int64_t)INT32_MAX && !(c->tune & (64 | 67108864));
 }
 
@@ -1067,7 +1067,9 @@ static bool jacobi_vol_multi_supported(const Ctx* c) {
 static int jacobi_group(const Ctx* c, int left) {
     if (left < 2) return 0;
     if (c->desc.dim == 2) return (c->g.n2 == 1 || c->g.n2 == 3) && (!c->het || c->het_cdiag) && !(c->tune & 64) ? (left == 5 ? 3 : std::min(4, left)) : 0;
-    return jacobi_vol_multi_supported(c) ? (left == 4 ? 2 : std::min(3, left)) : 0;
+    if (!jacobi_vol_multi_supported(c)) return 0;
+    if (c->het && !c->het_cdiag) return 2;   // a divisor plane: pairs
+    return left == 4 ? 2 : std::min(3, left);
 }
 
 template <typename T>
@@ -1090,6 +1092,7 @@ static void launch_jacobi_vol_multi_t(Ctx* c, const void* xin, void* xout, int K
     a.dsc = (T)c->c_dsc;
     a.rdsc = T(0);
     if (std::isfinite((double)a.dsc) && std::fabs((double)a.dsc) >= 0x1p-20 && std::fabs((double)a.dsc) <= 0x1p+20) a.rdsc = T(1) / a.dsc;
+    a.dsc_plane = make_planes_min<T>(c).dsc;
     const int64_t total = tiles * nchunks;
     launch_jacobi_vol_multi<T>(K, a, (unsigned)(((total + 7) / 8) * 8), c->stream);
 }

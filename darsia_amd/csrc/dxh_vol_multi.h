@@ -15,7 +15,8 @@
 //     offset of zero.
 // Bytes per element and PASS of K sweeps: (x in + rs in + x out) / 0.74 = 33 B in float64 instead of 72 B for three sweeps.
 // Same expressions in the same order as k_jacobi_vol_x (the quotient through the host-rounded reciprocal with two residual
-// corrections, IEEE division for numerators outside its proven range): same bits.  Scalar diag_scaled, no tolerance.
+// corrections, IEEE division for numerators outside its proven range): same bits.  No tolerance; diag_scaled a scalar or (HET)
+// a plane read once per stage (array-valued omega / ell: the IEEE division per element, as k_jacobi_vol_x does it).
 #pragma once
 
 #include "dxh_kernels.h"
@@ -31,6 +32,7 @@ struct VolMultiArgs {
     int tiles_y, tiles_x, nchunks;
     int64_t planes_per_chunk;
     T dsc, rdsc;                 // rdsc = RN(1 / dsc), 0: divide the IEEE way
+    const T* dsc_plane;          // HET: diag_scaled per element (array-valued omega / ell), IEEE division
 };
 
 template <typename T, int K>
@@ -41,7 +43,7 @@ struct VolMultiGeom {
     static_assert(TY * TX == 256 * E, "one cell per (thread, slot)");
 };
 
-template <typename T, int K>
+template <typename T, int K, bool HET>
 __global__ void __launch_bounds__(256, 2) k_jacobi_vol_multi(VolMultiArgs<T> a) {
     using G = VolMultiGeom<T, K>;
     constexpr int TY = G::TY, TX = G::TX, E = G::E;
@@ -126,7 +128,14 @@ __global__ void __launch_bounds__(256, 2) k_jacobi_vol_multi(VolMultiArgs<T> a) 
                 acc[i] = v;
             }
             bool ieee = !recip;
-            if (!ieee) {
+            if constexpr (HET) {
+                T dv[E];
+#pragma unroll
+                for (int i = 0; i < E; ++i) dv[i] = a.dsc_plane[pc * a.pitch + goff[i]];
+#pragma unroll
+                for (int i = 0; i < E; ++i) xn[i] = r[i] + acc[i] / dv[i];
+                ieee = false;
+            } else if (!ieee) {
                 T lo = t_abs(acc[0]);
 #pragma unroll
                 for (int i = 0; i < E; ++i) {

@@ -5,8 +5,12 @@ namespace dxh {
 
 template <typename T>
 void launch_jacobi_vol_multi(int K, const VolMultiArgs<T>& a, unsigned grid, hipStream_t stream) {
-    if (K == 2) hipLaunchKernelGGL((k_jacobi_vol_multi<T, 2>), dim3(grid), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((k_jacobi_vol_multi<T, 3>), dim3(grid), dim3(256), 0, stream, a);
+    if (a.dsc_plane) {   // per-element divisor: two sweeps per pass (registers)
+        hipLaunchKernelGGL((k_jacobi_vol_multi<T, 2, true>), dim3(grid), dim3(256), 0, stream, a);
+        return;
+    }
+    if (K == 2) hipLaunchKernelGGL((k_jacobi_vol_multi<T, 2, false>), dim3(grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((k_jacobi_vol_multi<T, 3, false>), dim3(grid), dim3(256), 0, stream, a);
 }
 template void launch_jacobi_vol_multi<float>(int, const VolMultiArgs<float>&, unsigned, hipStream_t);
 template void launch_jacobi_vol_multi<double>(int, const VolMultiArgs<double>&, unsigned, hipStream_t);
