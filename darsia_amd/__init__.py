@@ -8,6 +8,7 @@ gfx950); there is no CPU fallback.
 """
 from ._lib import HipError, device_count  # noqa: F401
 from .device import DeviceArray, trim_device_cache  # noqa: F401
+from .hostpool import trim as trim_host_pool  # noqa: F401  (recycled host result arrays: darsia_amd/hostpool.py)
 from .image import ExtensiveImage, Image, OpticalImage, ScalarImage  # noqa: F401
 from .geometry import (Coordinate, CoordinateArray, CoordinateSystem, Voxel, VoxelArray, full_like,  # noqa: F401
                        interpret_indexing, make_coordinate, make_voxel, ones_like, roi_to_mask,
