@@ -3,9 +3,9 @@
 // 700-713 run split Bregman on DICOM volumes with Jacobi(maxiter=20)):
 //     x_{s+1} = rs + N(x_s) / dsc        rs = rhs / diag the same for every sweep, N = the six-neighbour sum with replicate ghosts
 // One sweep per launch (k_jacobi_vol_x) streams x in, rs in, x out: 24 B per element and sweep in float64, and a 256^3 float64
-// volume (3 x 134 MB) does not fit the Infinity Cache.  Here a block of 256 threads owns a TY x TX tile of the (axis 1, axis 2)
+// volume (3 x 134 MB) does not fit the Infinity Cache.  Here a block of 512 threads owns a TY x TX tile of the (axis 1, axis 2)
 // plane and marches down axis 0 with a K-stage pipeline (3.5-D blocking): stage s applies sweep s to plane z - s.
-//   * along axis 0 a thread keeps the two planes above of every level in registers (8 elements per thread: rows ty, ty + 4, ...
+//   * along axis 0 a thread keeps the two planes above of every level in registers (4 cells per thread: rows ty, ty + 8, ...
 //     of one column) and takes the plane below from the stage before it, in the same step;
 //   * in-plane neighbours come out of ONE LDS tile per level (the level's current plane, written at the end of the step
 //     before): every stage reads its four neighbours, a barrier, then every level's tile is overwritten with its next plane,
@@ -35,17 +35,22 @@ struct VolMultiArgs {
     const T* dsc_plane;          // HET: diag_scaled per element (array-valued omega / ell), IEEE division
 };
 
-template <typename T, int K>
+// 512 threads x 4 cells per tile (16 waves per CU at <= 128 registers: 256 x 8 needs 251 in float64, K = 3 -- 8 waves per CU;
+// measured 256^3 float64 1.32 -> 1.27 ms per Jacobi(20) iteration, float32 0.76 -> 0.68); the float64 divisor-plane variant
+// needs 130 registers at 4 cells and keeps 256 x 8 (1.93 against 2.07 ms)
+template <typename T, int K, bool HET>
 struct VolMultiGeom {
-    static constexpr int TY = 32, TX = 64, E = 8;           // 256 threads x 8 cells
+    static constexpr bool WIDE = !(HET && sizeof(T) == 8);
+    static constexpr int TY = 32, TX = 64, E = WIDE ? 4 : 8, NT = WIDE ? 512 : 256;
     static constexpr int VY = TY - 2 * K, VX = TX - 2 * K;  // cells a tile stores
     static constexpr int TILE_BYTES = TY * TX * (int)sizeof(T);
-    static_assert(TY * TX == 256 * E, "one cell per (thread, slot)");
+    static constexpr int RS = NT / TX;                       // rows between a thread's cells
+    static_assert(TY * TX == NT * E, "one cell per (thread, slot)");
 };
 
 template <typename T, int K, bool HET>
-__global__ void __launch_bounds__(256, 2) k_jacobi_vol_multi(VolMultiArgs<T> a) {
-    using G = VolMultiGeom<T, K>;
+__global__ void __launch_bounds__((VolMultiGeom<T, K, HET>::NT), 2) k_jacobi_vol_multi(VolMultiArgs<T> a) {
+    using G = VolMultiGeom<T, K, HET>;
     constexpr int TY = G::TY, TX = G::TX, E = G::E;
     __shared__ __attribute__((aligned(16))) char tiles[K * G::TILE_BYTES];
     // XCD x (= blockIdx % 8) works a contiguous run of (chunk, tile row, tile) blocks: neighbouring tiles share their halo in L2
@@ -57,7 +62,7 @@ __global__ void __launch_bounds__(256, 2) k_jacobi_vol_multi(VolMultiArgs<T> a) 
     const int64_t Z0 = (int64_t)chunk * a.planes_per_chunk;
     if (Z0 >= a.n0) return;  // block-uniform
     const int64_t Z1 = (Z0 + a.planes_per_chunk < a.n0) ? Z0 + a.planes_per_chunk : a.n0;
-    const int tx = (int)threadIdx.x & (TX - 1), ty0 = (int)threadIdx.x / TX;   // rows ty0, ty0 + 4, ...
+    const int tx = (int)threadIdx.x & (TX - 1), ty0 = (int)threadIdx.x / TX;   // rows ty0, ty0 + RS, ...
     const int64_t gx = (int64_t)txi * G::VX - K + tx;
     const int64_t cx = gx < 0 ? 0 : (gx > a.n2 - 1 ? a.n2 - 1 : gx);
     const bool x_in_vol = gx >= 0 && gx < a.n2, x_stored = tx >= K && tx < TX - K && x_in_vol;
@@ -69,7 +74,7 @@ __global__ void __launch_bounds__(256, 2) k_jacobi_vol_multi(VolMultiArgs<T> a) 
     bool stored[E];
 #pragma unroll
     for (int i = 0; i < E; ++i) {
-        const int y = ty0 + 4 * i;
+        const int y = ty0 + G::RS * i;
         const int64_t gy = (int64_t)tyi * G::VY - K + y;
         const int64_t cy = gy < 0 ? 0 : (gy > a.n1 - 1 ? a.n1 - 1 : gy);
         own[i] = (y * TX + tx) * (int)sizeof(T);
