@@ -1823,9 +1823,10 @@ struct Np2Het {
     float ell_f, diag_f;
     int rhs64;
 };
-template <int DIM>
-__global__ void __launch_bounds__(256) k_rhs_np2_het(Geom g, const double* __restrict__ of, QPlanes<double, DIM> q, Np2Het k,
-                                                      double* __restrict__ rs) {
+// FROM_DB: the first iteration of a warm start -- d, b are the caller's float32 arrays, held as explicit planes
+template <int DIM, bool FROM_DB = false>
+__global__ void __launch_bounds__(256) k_rhs_np2_het(Geom g, const double* __restrict__ of, QPlanes<double, DIM> q, DBPlanes<double> db,
+                                                      Np2Het k, double* __restrict__ rs) {
     ElemIdx e;
     if (!elem_index(g, e)) return;
     const double kq_c = k.kq_p ? k.kq_p[e.off] : k.kq;
@@ -1833,11 +1834,17 @@ __global__ void __launch_bounds__(256) k_rhs_np2_het(Geom g, const double* __res
 #pragma unroll
     for (int j = 0; j < DIM; ++j) {
         float d, b;
-        np2_split(q.in[j][e.off], kq_c, d, b);
-        const float bd_c = b - d;
         const int64_t o = nb_off(g, e, j, -1);
-        np2_split(q.in[j][o], k.kq_p ? k.kq_p[o] : k.kq, d, b);
-        const float bd_n = b - d;
+        float bd_c, bd_n;
+        if constexpr (FROM_DB) {
+            bd_c = (float)db.b[j][e.off] - (float)db.d[j][e.off];
+            bd_n = (float)db.b[j][o] - (float)db.d[j][o];
+        } else {
+            np2_split(q.in[j][e.off], kq_c, d, b);
+            bd_c = b - d;
+            np2_split(q.in[j][o], k.kq_p ? k.kq_p[o] : k.kq, d, b);
+            bd_n = b - d;
+        }
         if (k.ell_p) {
             const double fd = k.ell_p[e.off] * (double)bd_c - k.ell_p[o] * (double)bd_n;
             r = k.rhs64 ? r + fd : (double)(float)(r + fd);

@@ -1319,7 +1319,6 @@ static int np2_generic_iteration(Ctx* c, int maxiter, double tol, void* tmp, int
     auto q = make_q<double, DIM>(c, in, in);
     const bool fdb = c->from_db;   // first iteration of a warm start: d, b are explicit planes (float32 values)
     auto db = make_db<double>(c);
-    if (fdb) DXH_REQUIRE(!c->het || c->het_cdiag, "numpy2 promotion: a warm start needs scalar omega and ell");
     int swept = 0;
     if (c->np2_pre) {
         // rs and the first sweep of this iteration came out of the previous iteration's fused pass
@@ -1337,7 +1336,8 @@ static int np2_generic_iteration(Ctx* c, int maxiter, double tol, void* tmp, int
         hk.ell_f = (float)c->ell_s;
         hk.diag_f = (float)c->c_diag;
         hk.rhs64 = c->om_is_arr ? 1 : 0;
-        hipLaunchKernelGGL((k_rhs_np2_het<DIM>), grid, blk, 0, c->stream, c->g, (const double*)c->of, q, hk, (double*)c->rs);
+        if (fdb) hipLaunchKernelGGL((k_rhs_np2_het<DIM, true>), grid, blk, 0, c->stream, c->g, (const double*)c->of, q, db, hk, (double*)c->rs);
+        else hipLaunchKernelGGL((k_rhs_np2_het<DIM, false>), grid, blk, 0, c->stream, c->g, (const double*)c->of, q, db, hk, (double*)c->rs);
     }
     else if (fdb) {
         if (k.kq_plane) hipLaunchKernelGGL((k_rhs_np2<DIM, true, true>), grid, blk, 0, c->stream, c->g, (const double*)c->of, q, db, k, (double*)c->rs);
@@ -3302,7 +3302,7 @@ int dxh_tvd_download_split_np2(dxh_tvd_t h, void* d, void* b) {
     DXH_REQUIRE(c, "null context");
     DXH_REQUIRE(c->np2, "the context is not in numpy2 promotion");
     if (!c->uploaded) { set_error("nothing to download"); return DXH_ESTATE; }
-    DXH_REQUIRE(!c->het || c->het_cdiag || c->np2_adapted, "numpy2 promotion: split variables are available with scalar omega and ell only");
+    DXH_REQUIRE(!c->het || c->cp_kq, "numpy2 promotion: the threshold plane is missing");   // (array-valued omega / ell: the threshold mu / ell is cp_kq, as in k_rhs_np2_het)
     int rc = set_device(c);
     if (rc) return rc;
     const int dim = c->desc.dim;

@@ -343,14 +343,12 @@ def numpy2_unsupported(img, mu, omega, ell, dim, x0, isotropic, solver, adaptive
             return "the adaptive schedule needs mu as a scalar or a float64 array"
     if x0 is not None:
         # a warm start in the reference's flow: float32 d0 / b0 (what the function itself leaves in them for a float32
-        # image), u0 float32 or float64, on the host or on the device, scalar omega and ell
+        # image), u0 float32 or float64, on the host or on the device
         u0, d0, b0 = x0
         if any(not isinstance(a, (np.ndarray, DeviceArray)) for a in (u0, d0, b0)):
             return "a warm start needs arrays (ndarray or DeviceArray)"
         if d0.dtype != np.float32 or b0.dtype != np.float32 or u0.dtype not in (np.float32, np.float64):
             return "a warm start needs float32 d0 / b0 and a float32 or float64 u0"
-        if arr_ell:
-            return "a warm start needs scalar omega and ell"
     if isotropic:
         return "anisotropic only (the reference's isotropic branch is float64-only)"
     if not isinstance(solver, Jacobi) or solver.maxiter < 1:

@@ -173,6 +173,12 @@ def main():
     adapt("d3_vol_m2", vol, {1, 2}, maxiter=2, mu=0.2, omega=0.7, ell=0.4, dim=3, max_num_iter=4)
     adapt("d4_gray_late", gray, {4}, mu=1.0, ell=0.45, max_num_iter=6)
 
+    # warm starts next to array-valued omega / ell (float64 arrays: parts of the right-hand side become float64, k_rhs_np2_het);
+    # added in round 4, after everything else so that the shared generator of `arr` leaves the older vectors as they were
+    warm("w5_gray_omega_ell_arr_m2", gray, 3, 4, maxiter=2, mu=0.1, omega=arr(gray.shape, 0.5, 1.5), ell=arr(gray.shape, 0.15, 0.6))
+    warm("w6_vol_ellarr", vol, 2, 3, mu=0.2, omega=0.7, ell=arr(vol.shape, 0.3, 0.8), dim=3)
+    warm("w7_rgb_munone_u0_f64", rgb, 2, 3, u0_as=np.float64, mu=arr(rgb.shape, 0.03, 0.2))
+
     for k, v in meta.items():
         out["meta/" + k] = np.array(v)
     path = os.path.join(HERE, "tvd_np2_generic_golden.npz")

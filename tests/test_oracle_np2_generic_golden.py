@@ -137,13 +137,18 @@ WARM_CASES = {
     "w2_rgb_muarr_m2": dict(ell=0.5),
     "w3_vol_u0_f64": dict(mu=0.2, omega=0.7, ell=0.4, dim=3),
     "w4_gray_one": dict(mu=1.0, ell=0.45),
+    # next to array-valued omega / ell (round 4)
+    "w5_gray_omega_ell_arr_m2": dict(mu=0.1),
+    "w6_vol_ellarr": dict(mu=0.2, omega=0.7, dim=3),
+    "w7_rgb_munone_u0_f64": dict(),
 }
 
 
 def warm_inputs(generic, name):
     kw = dict(WARM_CASES[name])
-    if f"{name}/mu" in generic.files:
-        kw["mu"] = generic[f"{name}/mu"]
+    for c in ("mu", "omega", "ell"):
+        if f"{name}/{c}" in generic.files:
+            kw[c] = generic[f"{name}/{c}"]
     return kw, int(generic[name + "/maxiter"]), int(generic[name + "/iters"])
 
 
