@@ -61,7 +61,8 @@ constexpr int kNp2GrayK = 6;
 void launch_multi_kernel_np2_gray6(bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
 // the same K-stage pipeline with every quantity float64: float64 IMAGES, anisotropic, scalar coefficients, C in {1, 3} (object f64p)
 void launch_multi_kernel_f64p(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
-// one outer iteration with K Jacobi sweeps per pass, numpy2 flow, scalar omega / ell (mu: scalar or array), C in {1, 3} (dxh_np2_sweeps.h;
+// one outer iteration with K Jacobi sweeps per pass: numpy2 flow, scalar omega / ell (mu: scalar or array), or a float64 image
+// with scalar coefficients; C in {1, 3} (dxh_np2_sweeps.h;
 // specialised in dxh_np2_sweeps.hip for K = kNp2SweepsMin .. kNp2SweepsMax, one object each)
 constexpr int kNp2SweepsMin = 2, kNp2SweepsMax = 6;
 // waves per SIMD the K-sweep pipeline is compiled for (registers: 128 / 168 / 256; LDS: 21 / 25 - 50 / 54 KB per block)
@@ -70,8 +71,8 @@ constexpr int kNp2SweepsMin = 2, kNp2SweepsMax = 6;
 #endif
 constexpr int np2_sweep_waves(int K) { return K <= DXH_SWEEPS_4W ? 4 : (K <= 5 ? 3 : 2); }
 template <int K>
-void launch_np2_sweeps(int C, bool coupled, bool kqv, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
-#define DXH_SW_DECL(K_) template <> void launch_np2_sweeps<K_>(int C, bool coupled, bool kqv, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
+void launch_np2_sweeps(int C, bool coupled, bool kqv, bool f64, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
+#define DXH_SW_DECL(K_) template <> void launch_np2_sweeps<K_>(int C, bool coupled, bool kqv, bool f64, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
 DXH_SW_DECL(2) DXH_SW_DECL(3) DXH_SW_DECL(4) DXH_SW_DECL(5) DXH_SW_DECL(6)
 #undef DXH_SW_DECL
 void launch_multi_kernel_np2_kqv(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);

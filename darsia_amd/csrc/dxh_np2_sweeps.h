@@ -20,14 +20,18 @@
 // Scalar omega and ell; mu scalar or a float64 array (KQV: the threshold mu / ell read per element by stage 0 -- 8 B more per
 // element; rows with a negative or NaN threshold take the shrinkage as written); no solver tolerance: everything else keeps
 // the three-launch flow.
+// F = double: float64 IMAGES (every quantity float64, the native flow of such images; scalar coefficients).  The tail then
+// re-reads the stored q_0, q_1 of its rows (L2: stage 0 read them K - 1 steps ago) and repeats the head's shrinkage instead of
+// holding b_0, b_1 in LDS -- a ring of float64 rows would leave one block per CU.
 #pragma once
 
 #include "dxh_np2_pipe.h"
 
 namespace dxh {
 
-template <int K>
+template <int K, typename F = float>
 struct Np2SweepLds {
+    static constexpr bool FIFO = std::is_same<F, float>::value;   // b_0, b_1 wait in LDS (float) / are recomputed by the tail (double)
     static constexpr int PAD = 16;
     static constexpr int UHALF = PAD + kWave * 8;
     static constexpr int USLOT = 2 * UHALF;
@@ -39,7 +43,7 @@ struct Np2SweepLds {
     static constexpr int FHALF = kWave * 2 * (int)sizeof(float);   // a row's b_0 pairs, then its b_1 pairs: 8 B per lane each
     static constexpr int FSLOT = 2 * FHALF;                        // (consecutive lanes 8 B apart: conflict-free ds_read_b64)
     static constexpr int NF = K + 1 <= 4 ? 4 : 8;                  // rows between stage 0 and the last stage, a power of two
-    static constexpr int BYTES = FIFO_OFF + NF * FSLOT;            // K = 5: 4240 + 8192 = 12432 per wave (three blocks per CU)
+    static constexpr int BYTES = FIFO ? FIFO_OFF + NF * FSLOT : U_BYTES;            // K = 5: 4240 + 8192 = 12432 per wave (three blocks per CU)
     static __device__ __forceinline__ int elem_off(int e) {
         const int par = e & 1;
         return PAD + par * UHALF + ((e - par) >> 1) * 8;
@@ -48,22 +52,25 @@ struct Np2SweepLds {
     static_assert(U_BYTES % 16 == 0 && USLOT % 16 == 0, "16-byte rows");
 };
 
-template <int K>
+template <int K, typename F = float>
 struct Np2SweepState {
     static constexpr int N = 2;
     double U[K + 1][4][N];        // rows of level l, slot = (row - rs) & 3 (level K: parity)
-    float t0[2][N];               // stage 0: ell (b_0 - d_0) of the current / previous row
+    F t0[2][N];                   // stage 0: ell (b_0 - d_0) of the current / previous row
     double q0l[2][N], q1l[2][N];  // loaded q rows (current / prefetched)
-    float of0[N];                 // omega*img of stage 0's row
+    F of0[N];                     // omega*img of stage 0's row
     double kql[2][N];             // KQV: the threshold of stage 0's row (current / prefetched)
-    float rs[K][2][N];            // rs[s][parity of the step it is read in]: rhs / diag of stage s's row (s >= 1)
+    F rs[K][2][N];                // rs[s][parity of the step it is read in]: rhs / diag of stage s's row (s >= 1)
 };
 
-template <int C, bool COUPLED, int K, bool NTS, bool EDGE, bool KQV>
+template <int C, bool COUPLED, int K, bool NTS, bool EDGE, bool KQV, typename F = float>
 struct PipeNp2Sweeps {
     static constexpr int N = 2;
-    using L = Np2SweepLds<K>;
-    const float* of_p;
+    static constexpr bool F32 = std::is_same<F, float>::value;
+    static_assert(F32 || !KQV, "float64 images: scalar threshold");
+    using L = Np2SweepLds<K, F>;
+    using F2 = typename Np2Vec2<F>::type;
+    const F* of_p;
     const double* u_in;
     const double* q0_in;
     const double* q1_in;
@@ -74,7 +81,7 @@ struct PipeNp2Sweeps {
     int64_t P, nrow, R0, R1;
     int nrow32, R0_32, R1_32;
     double dsc, rdsc, kq, negkq;
-    float ell_f, diag_f, rdiag_f;
+    F ell_f, diag_f, rdiag_f;
     bool div3f, np2_first, store_lane;
     uint32_t edgeL[N], edgeR[N], ch0[N], chLast[N];
     uint32_t voff;
@@ -99,27 +106,27 @@ struct PipeNp2Sweeps {
     __device__ __forceinline__ double* at(double* plane, int64_t row) const {
         return reinterpret_cast<double*>(reinterpret_cast<char*>(plane + row * P) + voff);
     }
-    __device__ __forceinline__ void load_of(int64_t row, float (&v)[N]) const {
-        const float2 t = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(of_p + row * P) + (voff >> 1));
+    __device__ __forceinline__ void load_of(int64_t row, F (&v)[N]) const {
+        const F2 t = *reinterpret_cast<const F2*>(reinterpret_cast<const char*>(of_p + row * P) + (F32 ? (voff >> 1) : voff));
         v[0] = t.x;
         v[1] = t.y;
     }
-    __device__ __forceinline__ void split(double q, double kqj, float& d, float& b) const {
+    __device__ __forceinline__ void split(double q, double kqj, F& d, F& b) const {
         if constexpr (KQV) np2_split_fast(q, -kqj, kqj, d, b);
         else np2_split_fast(q, negkq, kq, d, b);
     }
 
     // rs = float32(rhs) / float32(diag) through the host-rounded reciprocal (three operations where the exhaustive check of
     // this divisor allows, five otherwise); non-zero tiny numerators: the IEEE division
-    __device__ __forceinline__ void div_rhs(const float (&rhs)[N], float (&rs)[N]) const {
+    __device__ __forceinline__ void div_rhs(const F (&rhs)[N], F (&rs)[N]) const {
 #pragma unroll
         for (int j = 0; j < N; ++j) rs[j] = div_by_const3(rhs[j], diag_f, rdiag_f);
-        if (!div3f) {
+        if (!F32 || !div3f) {   // (float64: no exhaustive check exists -- always both corrections)
             DXH_UNIFORM_BRANCH();
 #pragma unroll
             for (int j = 0; j < N; ++j) rs[j] = div_refine(rs[j], rhs[j], diag_f, rdiag_f);
         }
-        if (__builtin_expect(__any(np2_absmin(rhs[0], rhs[1]) < DivSafe<float>::tiny), 0)) {
+        if (__builtin_expect(__any(np2_absmin(rhs[0], rhs[1]) < DivSafe<F>::tiny), 0)) {
             if (__any(div_unsafe(rhs[0]) || div_unsafe(rhs[1]))) {
 #pragma unroll
                 for (int j = 0; j < N; ++j) rs[j] = rhs[j] / diag_f;
@@ -140,9 +147,9 @@ struct PipeNp2Sweeps {
 
     // PH = step number mod 8; ACT: stages 0 .. ACT - 1 run (the first steps of a chunk)
     template <int PH, int ACT = K>
-    __device__ __forceinline__ void step(Np2SweepState<K>& st, const int64_t r) const {
+    __device__ __forceinline__ void step(Np2SweepState<K, F>& st, const int64_t r) const {
         constexpr int cur = PH & 1, prv = cur ^ 1;
-        float frn[N];
+        F frn[N];
         {
             const int64_t rn = clampr(r + 1);
             load_vec(at(u_in, clampr(r + 2)), st.U[0][(PH + 2) & 3]);
@@ -152,8 +159,14 @@ struct PipeNp2Sweeps {
             if constexpr (KQV) load_vec(at(kq_p, rn), st.kql[prv]);
         }
         // the last stage's b_1 of its row (written K - 1 steps ago) and b_0 of the row above it (K steps ago)
-        float tb0m[N], tb1c[N];
-        if constexpr (ACT == K) {
+        F tb0m[N], tb1c[N];
+        double tq0[N], tq1[N];
+        if constexpr (ACT == K && !L::FIFO) {
+            // float64: the stored q_1 of the tail's row and q_0 of the row above it (read by stage 0 K - 1 / K steps ago: L2)
+            load_vec(at(q1_in, clampr(r - (K - 1))), tq1);
+            load_vec(at(q0_in, clampr(r - K)), tq0);
+        }
+        if constexpr (ACT == K && L::FIFO) {
             const float2 vb1 = *reinterpret_cast<const float2*>(lfifo + ((PH - (K - 1)) & (L::NF - 1)) * L::FSLOT + L::FHALF);
             const float2 vb0 = *reinterpret_cast<const float2*>(lfifo + ((PH - K) & (L::NF - 1)) * L::FSLOT);
             tb1c[0] = vb1.x;
@@ -234,15 +247,15 @@ struct PipeNp2Sweeps {
                 }
                 acc[j] = a;
             }
-            float rsv[N];
+            F rsv[N];
             if constexpr (s == 0) {
                 // d_j = float32(shrink(q_j)), b_j = float32(q_j - d_j), t_j = ell (b_j - d_j) in float32   (:84-89,143-146)
-                float(&t0m)[N] = st.t0[prv];
-                float(&t0c)[N] = st.t0[cur];
-                float b0c[N], b1c[N], t1c[N];
+                F(&t0m)[N] = st.t0[prv];
+                F(&t0c)[N] = st.t0[cur];
+                F b0c[N], b1c[N], t1c[N];
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
-                    float d0f, b0f, d1f, b1f;
+                    F d0f, b0f, d1f, b1f;
                     split(st.q0l[cur][j], st.kql[cur][j], d0f, b0f);
                     split(st.q1l[cur][j], st.kql[cur][j], d1f, b1f);
                     t0c[j] = ell_f * (b0f - d0f);
@@ -271,23 +284,23 @@ struct PipeNp2Sweeps {
 #pragma unroll
                     for (int j = 0; j < N; ++j) t0m[j] = t0c[j];
                 }
-                float rhs[N];
+                F rhs[N];
                 if constexpr (EDGE) {
-                    float t1l[N];
+                    F t1l[N];
                     shifted2f<-C>(t1c, t1l);
 #pragma unroll
                     for (int j = 0; j < N; ++j) {
-                        const float rf = st.of0[j] + (t0c[j] - t0m[j]);
+                        const F rf = st.of0[j] + (t0c[j] - t0m[j]);
                         rhs[j] = rf + (t1c[j] - sel_bits(edgeL[j], t1c[j], t1l[j]));
                     }
                 } else {
                     static_for<0, N>([&](auto jc) {
                         constexpr int j = decltype(jc)::value;
-                        const float rf = st.of0[j] + (t0c[j] - t0m[j]);
+                        const F rf = st.of0[j] + (t0c[j] - t0m[j]);
                         rhs[j] = rf + add_shifted_elem<-C, j, true>(t1c[j], t1c);
                     });
                 }
-                if (np2_first) {  // u is the float32 image: the reference's accumulator is float32 too (wave-uniform)
+                if (F32 && np2_first) {  // u is the float32 image: the reference's accumulator is float32 too (wave-uniform)
                     DXH_UNIFORM_BRANCH();
 #pragma unroll
                     for (int j = 0; j < N; ++j) {
@@ -302,13 +315,15 @@ struct PipeNp2Sweeps {
                     }
                 }
                 div_rhs(rhs, rsv);
-                float2 fb0, fb1;
-                fb0.x = b0c[0];
-                fb0.y = b0c[1];
-                fb1.x = b1c[0];
-                fb1.y = b1c[1];
-                *reinterpret_cast<float2*>(lfifo + (PH & (L::NF - 1)) * L::FSLOT) = fb0;
-                *reinterpret_cast<float2*>(lfifo + (PH & (L::NF - 1)) * L::FSLOT + L::FHALF) = fb1;
+                if constexpr (L::FIFO) {
+                    float2 fb0, fb1;
+                    fb0.x = b0c[0];
+                    fb0.y = b0c[1];
+                    fb1.x = b1c[0];
+                    fb1.y = b1c[1];
+                    *reinterpret_cast<float2*>(lfifo + (PH & (L::NF - 1)) * L::FSLOT) = fb0;
+                    *reinterpret_cast<float2*>(lfifo + (PH & (L::NF - 1)) * L::FSLOT + L::FHALF) = fb1;
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < N; ++j) rsv[j] = st.rs[s][cur][j];
@@ -328,6 +343,14 @@ struct PipeNp2Sweeps {
                 for (int j = 0; j < N; ++j) un[j] = unm[j];
             }
             if constexpr (last) {
+                if constexpr (!L::FIFO) {   // the head's shrinkage of these rows once more: b = q - d (np2_split_fast, float64)
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {
+                        F dd;
+                        split(tq0[j], 0.0, dd, tb0m[j]);
+                        split(tq1[j], 0.0, dd, tb1c[j]);
+                    }
+                }
                 double unr[N], q0o[N], q1o[N];
                 shifted<+C, true>(un, unr);
 #pragma unroll
@@ -364,13 +387,14 @@ struct PipeNp2Sweeps {
     }
 };
 
-template <int C, bool COUPLED, int K, bool NTS, bool EDGE, bool KQV>
+template <int C, bool COUPLED, int K, bool NTS, bool EDGE, bool KQV, typename F>
 __device__ __forceinline__ void np2_sweeps_body(const FusedArgs<double>& a, const int strip, const int chunk, const int lane,
                                                 char* lds_wave) {
     constexpr int N = 2;
     using SG = StripGeomK<double, C, K>;
-    using PipeT = PipeNp2Sweeps<C, COUPLED, K, NTS, EDGE, KQV>;
-    using L = Np2SweepLds<K>;
+    using PipeT = PipeNp2Sweeps<C, COUPLED, K, NTS, EDGE, KQV, F>;
+    using L = Np2SweepLds<K, F>;
+    constexpr bool F32 = std::is_same<F, float>::value;
     PipeT pp;
     chunk_rows(a, chunk, pp.R0, pp.R1);
     if (pp.R0 >= a.n0) return;
@@ -396,7 +420,8 @@ __device__ __forceinline__ void np2_sweeps_body(const FusedArgs<double>& a, cons
         pp.aCL[j] = lds_wave + L::elem_off(cc == 0 ? e : e - 1);
         pp.aCR[j] = lds_wave + L::elem_off(cc == C - 1 ? e : e + 1);
     }
-    pp.of_p = a.of32;
+    if constexpr (F32) pp.of_p = a.of32;
+    else pp.of_p = a.of;
     pp.u_in = a.u_in;
     pp.q0_in = a.q0_in;
     pp.q1_in = a.q1_in;
@@ -414,13 +439,13 @@ __device__ __forceinline__ void np2_sweeps_body(const FusedArgs<double>& a, cons
     pp.rdsc = a.c.rdsc;
     pp.kq = a.c.kq;
     pp.negkq = -a.c.kq;
-    pp.ell_f = (float)a.c.ell;
-    pp.diag_f = (float)a.c.diag;
-    pp.rdiag_f = 1.0f / pp.diag_f;
-    pp.div3f = a.np2_div3 != 0;
-    pp.np2_first = a.np2_first != 0;
+    pp.ell_f = (F)a.c.ell;
+    pp.diag_f = (F)a.c.diag;
+    pp.rdiag_f = F(1) / pp.diag_f;
+    pp.div3f = F32 && a.np2_div3 != 0;
+    pp.np2_first = F32 && a.np2_first != 0;
 
-    Np2SweepState<K> st;
+    Np2SweepState<K, F> st;
 #pragma unroll
     for (int l = 0; l <= K; ++l)
 #pragma unroll
@@ -431,7 +456,7 @@ __device__ __forceinline__ void np2_sweeps_body(const FusedArgs<double>& a, cons
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-            st.t0[i][j] = 0.0f;
+            st.t0[i][j] = F(0);
             st.q0l[i][j] = st.q1l[i][j] = st.kql[i][j] = 0.0;
         }
 #pragma unroll
@@ -439,9 +464,9 @@ __device__ __forceinline__ void np2_sweeps_body(const FusedArgs<double>& a, cons
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < N; ++j) st.rs[l][i][j] = 0.0f;
+            for (int j = 0; j < N; ++j) st.rs[l][i][j] = F(0);
 #pragma unroll
-    for (int j = 0; j < N; ++j) st.of0[j] = 0.0f;
+    for (int j = 0; j < N; ++j) st.of0[j] = F(0);
     {
         static_assert(L::BYTES % 16 == 0, "whole 16-byte words");
         for (int off = lane * 16; off < L::BYTES; off += kWave * 16)
@@ -465,9 +490,12 @@ __device__ __forceinline__ void np2_sweeps_body(const FusedArgs<double>& a, cons
         }
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-            float df, bf;
-            if constexpr (KQV) np2_split<false>(q0v[j], kqm[j], df, bf);   // (once per chunk: the general expression)
-            else pp.split(q0v[j], 0.0, df, bf);
+            F df, bf;
+            if constexpr (KQV) {
+                if constexpr (F32) np2_split<false>(q0v[j], kqm[j], df, bf);   // (once per chunk: the general expression)
+            } else {
+                pp.split(q0v[j], 0.0, df, bf);
+            }
             st.t0[1][j] = pp.ell_f * (bf - df);   // parity "prv" of phase 0
         }
     }
@@ -509,11 +537,11 @@ __device__ __forceinline__ void np2_sweeps_body(const FusedArgs<double>& a, cons
     }
 }
 
-template <int C, bool COUPLED, int K, bool KQV, bool NTS = true>
-__global__ void __launch_bounds__(256, np2_sweep_waves(K)) k_sweeps_np2(FusedArgs<double> a) {
+template <int C, bool COUPLED, int K, bool KQV, typename F = float, bool NTS = true>
+__global__ void __launch_bounds__(256, (std::is_same<F, float>::value ? np2_sweep_waves(K) : 2)) k_sweeps_np2(FusedArgs<double> a) {
     constexpr int N = 2;
     using SG = StripGeomK<double, C, K>;
-    using L = Np2SweepLds<K>;
+    using L = Np2SweepLds<K, F>;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
     constexpr int WPB = 4;
@@ -527,9 +555,9 @@ __global__ void __launch_bounds__(256, np2_sweep_waves(K)) k_sweeps_np2(FusedArg
     __shared__ __attribute__((aligned(16))) char lds_all[WPB * L::BYTES];
     char* lds_wave = lds_all + (size_t)wave * L::BYTES;
     if (edge)
-        np2_sweeps_body<C, COUPLED, K, NTS, true, KQV>(a, strip, chunk, lane, lds_wave);
+        np2_sweeps_body<C, COUPLED, K, NTS, true, KQV, F>(a, strip, chunk, lane, lds_wave);
     else
-        np2_sweeps_body<C, COUPLED, K, NTS, false, KQV>(a, strip, chunk, lane, lds_wave);
+        np2_sweeps_body<C, COUPLED, K, NTS, false, KQV, F>(a, strip, chunk, lane, lds_wave);
     signal_chunk_done(a, chunk, lane);
 }
 

@@ -1,5 +1,5 @@
 // One object per sweep count (build.sh: np2_sw2 .. np2_sw6, -DDXH_SWEEPS_K=S): the numpy2 pipeline of ONE outer iteration
-// with S Jacobi sweeps (dxh_np2_sweeps.h), C in {1, 3}, scalar threshold or threshold plane (array-valued mu).
+// with S Jacobi sweeps (dxh_np2_sweeps.h), C in {1, 3}, scalar threshold or threshold plane (array-valued mu); float64 images: scalar threshold.
 #include "dxh_multi.h"
 #include "dxh_np2_sweeps.h"
 
@@ -10,11 +10,12 @@
 namespace dxh {
 
 template <>
-void launch_np2_sweeps<DXH_SWEEPS_K>(int C, bool coupled, bool kqv, const FusedArgs<double>& a, unsigned grid, hipStream_t stream) {
+void launch_np2_sweeps<DXH_SWEEPS_K>(int C, bool coupled, bool kqv, bool f64, const FusedArgs<double>& a, unsigned grid, hipStream_t stream) {
     constexpr int K = DXH_SWEEPS_K;
 #define DXH_SW(C_, CP_)                                                                                       \
     do {                                                                                                      \
-        if (kqv) hipLaunchKernelGGL((k_sweeps_np2<C_, CP_, K, true>), dim3(grid), dim3(256), 0, stream, a);    \
+        if (f64) hipLaunchKernelGGL((k_sweeps_np2<C_, CP_, K, false, double>), dim3(grid), dim3(256), 0, stream, a);   \
+        else if (kqv) hipLaunchKernelGGL((k_sweeps_np2<C_, CP_, K, true>), dim3(grid), dim3(256), 0, stream, a);    \
         else hipLaunchKernelGGL((k_sweeps_np2<C_, CP_, K, false>), dim3(grid), dim3(256), 0, stream, a);       \
     } while (0)
     if (C == 1) { if (coupled) DXH_SW(1, true); else DXH_SW(1, false); }

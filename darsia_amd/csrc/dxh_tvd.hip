@@ -549,7 +549,7 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
             nchunks = std::max<int64_t>(1, target_blocks / nbx);
         } else {
             // blocks resident per CU (one wave of each per SIMD); the numpy2 pipelines have their own register budget
-            const int W = c->np2_sweeps ? np2_sweep_waves(K)
+            const int W = c->np2_sweeps ? (c->np2 ? np2_sweep_waves(K) : 2)
                                           : c->np2 ? (kqv_pipe ? DXH_NP2_WAVES_KQV : (K > 4 ? DXH_NP2_WAVES_K6 : DXH_NP2_WAVES)) : pipe_waves<T, K <= 4 ? K : 4, false>();
             // issue cost of one VALU instruction per SIMD with 1 / 2 / 3 / 4 waves taking turns (tools/valubench.hip)
             static const double cpi[5] = {0.0, 6.6, 3.7, 3.5, 3.2};  // 3: fitted to chunk sweeps of this kernel (a third wave adds ~8 %)
@@ -615,6 +615,21 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
             if (c->tune & 512) fprintf(stderr, "[dxh] isotropic shrink factor, k = %g: lean %d, three-operation quotient %d\n", c->c_kq, a.iso_lean, a.iso_div3);
         }
     }
+    if (c->np2_sweeps) {   // ONE iteration of K Jacobi sweeps per pass (dxh_np2_sweeps.h; objects np2_sw2 .. np2_sw6)
+        if constexpr (std::is_same<T, double>::value && !ISO && (C == 1 || C == 3) && K >= kNp2SweepsMin && K <= kNp2SweepsMax) {
+            if (c->np2_sweeps == K && !want_inc && (c->np2 ? (c->of32_valid && (!c->het || a.kqv)) : !c->het)) {
+                if (c->np2) {
+                    a.of32 = (const float*)c->of32;
+                    const float fd = (float)c->c_diag;
+                    if (std::isfinite(fd) && std::fabs(fd) >= 0x1p-20f && std::fabs(fd) <= 0x1p+20f && !(c->tune & 128)) a.np2_div3 = div3_verified(c, fd, fd);
+                }
+                launch_np2_sweeps<K>(C, COUPLED, a.kqv != 0, !c->np2, a, grid, c->stream);
+                return;
+            }
+        }
+        c->no_kernel = true;
+        return;
+    }
     if (c->np2) {
         if (!c->of32_valid) { c->no_kernel = true; return; }   // (cannot happen: every upload of a scalar-omega numpy2 context fills it)
         a.of32 = (const float*)c->of32;
@@ -623,16 +638,6 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
         const float fd = (float)c->c_diag;
         if (std::isfinite(fd) && std::fabs(fd) >= 0x1p-20f && std::fabs(fd) <= 0x1p+20f && !(c->tune & 128))
             a.np2_div3 = div3_verified(c, fd, fd);
-        if (c->np2_sweeps) {   // ONE iteration of K Jacobi sweeps per pass (dxh_np2_sweeps.h; objects np2_sw2 .. np2_sw6)
-            if constexpr (std::is_same<T, double>::value && !ISO && (C == 1 || C == 3) && K >= kNp2SweepsMin && K <= kNp2SweepsMax) {
-                if ((!c->het || a.kqv) && c->np2_sweeps == K && !want_inc) {
-                    launch_np2_sweeps<K>(C, COUPLED, a.kqv != 0, a, grid, c->stream);
-                    return;
-                }
-            }
-            c->no_kernel = true;
-            return;
-        }
         // the reference's float32 dtype flow: PipeNp2 (dxh_np2_pipe.h; dxh_multi.hip objects np2_s / np2_q); pick_k only asks for
         // the combinations that exist
         if constexpr (std::is_same<T, double>::value && !ISO && (C == 1 || C == 3) && K == kNp2K) {
@@ -1488,11 +1493,13 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
                             !c->solver && !explicit_mode && !c->np2;
     // numpy2, Jacobi(maxiter = 2 .. 6) without a tolerance, scalar omega / ell, 1 / 3 channels: one pass per iteration with
     // the sweeps as its stages (dxh_np2_sweeps.h; DXH_FUSED_TUNE bit 33554432: the three-launch flow instead, A/B)
-    const bool sweeps_ok = c->np2 && std::is_same<T, double>::value && dim == 2 && (c->g.n2 == 1 || c->g.n2 == 3) &&
-                           (!c->het || (c->het_cdiag && c->cp_kq && make_coef<T>(c).const_diag && !(c->tune & 65536))) &&
+    // (float64 images, anisotropic, scalar coefficients: the same pipeline with every quantity float64)
+    const bool sweeps_ok = std::is_same<T, double>::value && dim == 2 && (c->g.n2 == 1 || c->g.n2 == 3) &&
+                           (c->np2 ? (c->of32_valid && (!c->het || (c->het_cdiag && c->cp_kq && make_coef<T>(c).const_diag && !(c->tune & 65536))))
+                                   : (!c->het && !iso && !c->solver)) &&
                            jacobi_maxiter >= kNp2SweepsMin && jacobi_maxiter <= kNp2SweepsMax && !use_tol && dpp &&
                            !(flags & DXH_FLAG_NO_FUSED) && !explicit_mode && fused_supported(c) && multi_supported(c) &&
-                           c->of32_valid && !(c->tune & 33554432);
+                           !(c->tune & 33554432);
     const bool need_generic = (!fused_ok && !fused3d_ok && !sweeps_ok) || c->from_db || c->np2_q32;
     if (need_generic) {
         int rc = alloc_plane(c, &c->rs);

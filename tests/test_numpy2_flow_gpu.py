@@ -732,3 +732,44 @@ def test_volume_sweeps_in_plane_tiles_bit_for_bit_against_the_oracle(sweeps, sha
     if sweeps - (1 if promotion == "numpy2" and omega_kind == "scalar omega" else 0) >= 2:
         assert launches[None] < launches["67108864"], launches
     monkeypatch.delenv("DXH_FUSED_TUNE", raising=False)
+
+
+@pytest.mark.parametrize("sweeps", [2, 3, 4, 5, 6])
+@pytest.mark.parametrize("shape", [(41, 700, 3), (300, 517), (23, 60, 3), (2, 2)])
+def test_float64_images_with_several_sweeps_run_as_one_pass_per_iteration(sweeps, shape, monkeypatch):
+    """float64 images (what scikit-image's img_as_float hands the reference's pipelines) with Jacobi(maxiter = 2 .. 6): the
+    sweeps pipeline with every quantity float64 (dxh_np2_sweeps.h, F = double; the tail repeats the head's shrinkage of the
+    stored q instead of holding b in LDS) -- against the oracle, with the launch count, and against the three launches per
+    iteration it replaces (DXH_FUSED_TUNE bit 33554432)."""
+    rng = np.random.default_rng(sweeps * 7 + shape[1])
+    img = rng.random(shape)
+    kw = dict(mu=0.13, omega=0.9, ell=0.35)
+    n = 4
+    ref, dl, bl, _ = O.split_bregman_tvd(img, max_num_iter=n, jacobi_maxiter=sweeps, return_state=True, **kw)
+    ref2 = O.split_bregman_tvd(img, max_num_iter=n + 3, jacobi_maxiter=sweeps, **kw)
+    for chunks, tune in ((None, None), ("2", None), (None, "33554432")):
+        if chunks and shape[0] < 200:
+            continue
+        monkeypatch.delenv("DXH_NCHUNKS", raising=False)
+        monkeypatch.delenv("DXH_FUSED_TUNE", raising=False)
+        if chunks:
+            monkeypatch.setenv("DXH_NCHUNKS", chunks)
+        if tune:
+            monkeypatch.setenv("DXH_FUSED_TUNE", tune)
+        with da.DeviceTVD(img.shape, img.dtype) as st:
+            st.set_coeffs(kw["mu"], kw["omega"], kw["ell"], img)
+            st.upload(img)
+            r = st.run(n, jacobi_maxiter=sweeps)
+            assert (r.launches == n) == (tune is None), (r.launches, chunks, tune)
+            u, d, b = st.download(want_split=True)
+            bits(u, ref)
+            bits(d, np.stack(dl, axis=-1))
+            bits(b, np.stack(bl, axis=-1))
+            st.run(3, jacobi_maxiter=sweeps)
+            bits(st.download(), ref2)
+    monkeypatch.delenv("DXH_NCHUNKS", raising=False)
+    monkeypatch.delenv("DXH_FUSED_TUNE", raising=False)
+    bits(da.split_bregman_tvd(img, max_num_iter=n, solver=da.Jacobi(maxiter=sweeps), **kw), ref)
+    # with the stopping criterion the same pipeline serves every iteration (the increment is reduced after each pass)
+    bits(da.split_bregman_tvd(img, max_num_iter=30, eps=1e-3, solver=da.Jacobi(maxiter=sweeps), **kw),
+         O.split_bregman_tvd(img, max_num_iter=30, eps=1e-3, jacobi_maxiter=sweeps, **kw))
