@@ -26,6 +26,10 @@
 #include "dxh_kernels.h"
 
 // DXH_NP2_WAVES (dxh_multi.h): waves per SIMD the pipeline is compiled for (register cap 168 / 256)
+#ifndef DXH_NP2_INC_REGS
+#define DXH_NP2_INC_REGS 0   // eps instantiation: the running sums of squared increments in registers (measured: the allocator spills them to
+                             // scratch at 168 registers -- a load / add / store chain per stage) or (0) in LDS through ds_add_f64, which returns nothing
+#endif
 #ifndef DXH_NP2_PFD
 #define DXH_NP2_PFD 1     // prefetch distance in row steps (2: staging registers, needs DXH_NP2_WAVES = 2)
 #endif
@@ -47,6 +51,7 @@ struct Np2State {
     F pff[2][N];             // ... and omega*img
     double kqv[K][N];        // KQV: the float64 threshold mu / ell of each stage's current row
     double kqn[N];
+    double inc[K];           // eps instantiation (DXH_NP2_INC_REGS): this lane's running sum of squared increments per stage
     bool kbad[K];            // KQV, wave-uniform: that row holds a threshold that is negative or NaN somewhere in the wave (the
                              // clamp form of the shrinkage needs k >= 0; such rows take the general expression)
 };
@@ -56,12 +61,14 @@ struct Np2State {
 // per-lane addresses -- no v_mov_b32_dpp pairs per double and, because the image-border / channel-border replicate rules are
 // folded into the (loop-invariant) addresses, no v_bfi selects either: 14 of the 71 VALU instructions per element and stage of
 // the first version.  A wave's LDS operations execute in order, so no barrier is involved.
-//   U rows     2 (K - 1) slots, each the row's EVEN elements (element 0 of every lane: 64 x 8 B) followed by its ODD elements,
+//   U rows     K - 1 slots (one per level; two without DXH_NP2_PREFETCH), each the row's EVEN elements (element 0 of every lane: 64 x 8 B) followed by its ODD elements,
 //              16 B of zeros in front of each half and behind the last (lanes that look past the wave's ends read zeros, as
 //              bound_ctrl DPP gives them).  De-interleaved so that a wave's 8-byte reads at consecutive lanes are consecutive
 //              in LDS: conflict-free (a 16-byte lane stride is a 2-way bank conflict for ds_read_b64: measured, 5.4e7
-//              conflict cycles per launch).  slot = (level - 1) * 2 + parity of the step it is READ in
-//   b_1 rows   2 (K - 1) slots of 64 lanes x 2 F   float32 (F) b_1 of the same rows (the consumer forms q_1 = D_1 u + b_1 itself)
+//              conflict cycles per launch).  Single-buffered: stage s issues stage s + 1's reads of the row before it writes the
+//              next one (round 4 started with two slots per level; the eps instantiation's 8 KB of running sums then left two
+//              blocks per CU instead of three: +25 % per launch)
+//   b_1 rows   K - 1 slots of 64 lanes x 2 F       float32 (F) b_1 of the same rows (the consumer forms q_1 = D_1 u + b_1 itself)
 //   omega*img  4 slots of 64 lanes x 2 F          rows r .. r - 3, written by stage 0
 // K > 4 (Np2Lds::FWD; the row loop is unrolled by four, so a ring of K rows has no compile-time slot): omega*img travels down
 // the stages WITH b_1 -- one row of 64 lanes x 4 F per level -- and there is ONE slot per level: every stage's row of the
@@ -71,7 +78,10 @@ struct Np2Lds {
     static constexpr int PAD = 16;
     static constexpr int UHALF = PAD + kWave * 8;           // one parity of a row: pad + 64 x 8 B (the next half's pad follows)
     static constexpr int USLOT = 2 * UHALF;
-    static constexpr int NU = 2 * (K - 1);
+    // DXH_NP2_PREFETCH: ONE slot per level -- stage s fetches stage s + 1's operands (the row it wrote one step ago) before it
+    // writes the new row, and a wave's LDS operations execute in order; without the prefetch two (parity of the reading step)
+    static constexpr int SLOTS_PER_LEVEL = DXH_NP2_PREFETCH ? 1 : 2;
+    static constexpr int NU = SLOTS_PER_LEVEL * (K - 1);
     static constexpr int U_BYTES = NU * USLOT + PAD;
     static constexpr int B1_OFF = U_BYTES;
     static constexpr bool FWD = K > 4;
@@ -87,6 +97,13 @@ struct Np2Lds {
     static_assert(U_BYTES % 16 == 0 && USLOT % 16 == 0, "16-byte rows");
     static_assert(PAD >= 16, "C <= 4: a lane looks at most 4 elements (2 lanes x 8 B per half) past the wave's ends");
 };
+
+__device__ __forceinline__ void lds_add_f64(double* p, double v) {
+    const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)p;
+    // (no memory clobber: the zeroing stores and the final reads of these slots are volatile accesses, which keep their order
+    // relative to a volatile asm; everything else may move across it)
+    asm volatile("ds_add_f64 %0, %1" : : "v"(addr), "v"(v));
+}
 
 template <int DELTA, typename F>
 __device__ __forceinline__ void shifted2f(const F (&v)[2], F (&w)[2]) {
@@ -280,7 +297,7 @@ struct PipeNp2 {
         F pb1[N], pof[N];
         auto fetch = [&](auto sn) {
             constexpr int s1 = decltype(sn)::value;           // the stage whose operands are fetched
-            constexpr int slot1 = (s1 - 1) * 2 + (PH & 1);
+            constexpr int slot1 = (s1 - 1) * L::SLOTS_PER_LEVEL + (L::SLOTS_PER_LEVEL == 2 ? (PH & 1) : 0);
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 pnl[j] = u_get(aL[j], slot1);
@@ -338,7 +355,7 @@ struct PipeNp2 {
                 }
             } else {
                 // levels >= 1: out of the row stage s - 1 put into LDS one step ago; q_1 = D_1 u + b_1 is formed here
-                constexpr int slot = (s - 1) * 2 + cur;
+                constexpr int slot = (s - 1) * L::SLOTS_PER_LEVEL + (L::SLOTS_PER_LEVEL == 2 ? cur : 0);
                 F b1p[N];
                 if constexpr (DXH_NP2_PREFETCH) {
 #pragma unroll
@@ -469,18 +486,24 @@ struct PipeNp2 {
 #pragma unroll
                 for (int j = 0; j < N; ++j) un[j] = unm[j];
             }
-            if (NORM && p32 >= R0_32 && p32 < R1_32) {  // wave-uniform; rows of this chunk only (each element once)
-                // one running sum per lane and stage, kept in LDS through volatile accesses; the lane mask (strip halo) is
-                // applied when the sums are read back (fused_np2_body)
+            if constexpr (NORM) {
+                const bool in_chunk = p32 >= R0_32 && p32 < R1_32;  // wave-uniform; rows of this chunk only (each element once)
+                // one running sum per lane and stage in LDS; the lane mask (strip halo) is applied when the sums are read back
+                // (fused_np2_body)
                 double t = 0.0;
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
                     const double dlt = un[j] - uc[j];
-                    const double sq = inL[j] ? dlt * dlt : 0.0;
+                    const double sq = (in_chunk && inL[j]) ? dlt * dlt : 0.0;   // (a select, not a branch: the stages stay one block)
                     t = j == 0 ? sq : t + sq;
                 }
-                volatile double* slot = linc + s * kWave;
-                *slot = *slot + t;
+                if constexpr (DXH_NP2_INC_REGS) {
+                    st.inc[s] = st.inc[s] + t;
+                } else {
+                    // fire and forget: no result comes back, so nothing waits on the LDS round trip (a volatile read-modify-write here
+                    // cost 0.6 ms per K = 4 launch); a lane's adds reach its slot in program order
+                    lds_add_f64(linc + s * kWave, t);
+                }
             }
             double q0o[N];
 #pragma unroll
@@ -514,9 +537,9 @@ struct PipeNp2 {
                 }
             } else {
                 // the new row and its b_1 for stage s + 1, which reads them at the next step (its parity "cur")
-                u_put(s * 2 + prv, un);
+                u_put(s * L::SLOTS_PER_LEVEL + (L::SLOTS_PER_LEVEL == 2 ? prv : 0), un);
                 if constexpr (L::FWD) fw_put(s, b1c, ofv);
-                else f_put(lb1, s * 2 + prv, b1c);
+                else f_put(lb1, s * L::SLOTS_PER_LEVEL + (L::SLOTS_PER_LEVEL == 2 ? prv : 0), b1c);
 #pragma unroll
                 for (int j = 0; j < N; ++j) q0h[j] = q0o[j];
             }
@@ -678,7 +701,9 @@ __device__ __forceinline__ void fused_np2_body(const FusedArgs<double>& a, const
         }
     }
     const int64_t r_end = pp.R1 + (K - 1);
-    if constexpr (NORM) {
+#pragma unroll
+    for (int i = 0; i < K; ++i) st.inc[i] = 0.0;
+    if constexpr (NORM && !DXH_NP2_INC_REGS) {
 #pragma unroll
         for (int i = 0; i < K; ++i) *(volatile double*)(linc_lane + i * kWave) = 0.0;
     }
@@ -709,7 +734,7 @@ __device__ __forceinline__ void fused_np2_body(const FusedArgs<double>& a, const
         double inc[K][N];
 #pragma unroll
         for (int s = 0; s < K; ++s) {
-            const double v = *(volatile double*)(linc_lane + s * kWave);
+            const double v = DXH_NP2_INC_REGS ? st.inc[s] : *(volatile double*)(linc_lane + s * kWave);
             inc[s][0] = pp.store_lane ? v : 0.0;
             inc[s][1] = 0.0;
         }
@@ -734,9 +759,9 @@ k_fused_multi_np2(FusedArgs<double> a) {
     const int64_t w0 = (int64_t)strip * SG::STRIDE - SG::LH * N;  // first element of the wave's window
     const bool edge = (w0 < C) || (w0 + kWave * N > a.L - C);     // wave-uniform
     __shared__ __attribute__((aligned(16))) char lds_all[WPB * L::BYTES];
-    __shared__ double lds_inc[NORM ? WPB * K * kWave : 1];
+    __shared__ double lds_inc[(NORM && !DXH_NP2_INC_REGS) ? WPB * K * kWave : 1];
     char* lds_wave = lds_all + (size_t)wave * L::BYTES;
-    double* linc_lane = NORM ? lds_inc + (size_t)wave * (K * kWave) + lane : lds_inc;
+    double* linc_lane = (NORM && !DXH_NP2_INC_REGS) ? lds_inc + (size_t)wave * (K * kWave) + lane : lds_inc;
     if (edge)
         fused_np2_body<C, COUPLED, K, NTS, true, NORM, KQV, F>(a, strip, chunk, lane, lds_wave, linc_lane);
     else

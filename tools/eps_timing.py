@@ -17,3 +17,11 @@ with da.DeviceTVD(img.shape, img.dtype) as st:
     print(f"  device loop: {r.iters_done} iterations, converged={bool(r.converged)}, {r.loop_ms:.2f} ms = {r.loop_ms / max(1, r.iters_done):.4f} ms/iteration, {r.launches} launches")
     st.upload(img); r = st.run(r.iters_done)
     print(f"  same count without the criterion: {r.loop_ms:.2f} ms")
+for C in (3, 1):
+    im = img if C == 3 else np.ascontiguousarray(img[..., 0])
+    with da.DeviceTVD(im.shape, im.dtype, promotion="numpy2") as st:
+        st.set_coeffs(0.1, 1.0, 0.2, im); st.upload(im)
+        r = st.run(200, eps=2e-4)
+        print(f"  default flow (numpy2) C={C}: {r.iters_done} iterations, converged={bool(r.converged)}, {r.loop_ms:.2f} ms = {r.loop_ms / max(1, r.iters_done):.4f} ms/iteration, {r.launches} launches")
+        st.upload(im); r = st.run(r.iters_done)
+        print(f"  same count without the criterion: {r.loop_ms:.2f} ms = {r.loop_ms / max(1, r.iters_done):.4f} ms/iteration")
