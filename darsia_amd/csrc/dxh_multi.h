@@ -41,9 +41,11 @@ void launch_multi_kernel_c24(int C, bool coupled, bool iso, bool want_inc, bool 
 #ifndef DXH_NP2_PREFETCH     // dxh_np2_pipe.h: stage s fetches stage s + 1's LDS operands before its own tail
 #define DXH_NP2_PREFETCH 1
 #endif
-#ifndef DXH_NP2_WAVES_KQV   // threshold-plane variant: K more threshold rows in registers (168 VGPRs spill 24 - 108 bytes per lane)
-#define DXH_NP2_WAVES_KQV 2
+#ifndef DXH_NP2_WAVES_KQV   // threshold-plane variant: three since the thresholds travel down the stages through LDS rows (152 - 167 registers;
+#define DXH_NP2_WAVES_KQV 3   // with a register delay line of K x 4 registers it spilled 24 - 108 B at three and ran at two)
 #endif
+// ... single-channel images stay at two (HBM-bound at 60 B per element: 0.102 against 0.105 ms per iteration at three)
+constexpr int np2_kqv_waves(int C) { return C == 1 ? 2 : DXH_NP2_WAVES_KQV; }
 
 // the reference's float32 dtype flow (numpy2 pipelines, dxh_np2_pipe.h; double planes): K = kNp2K for both the scalar-threshold
 // and the threshold-plane (kqv: array-valued mu) variant, C in {1, 3}; scalar threshold also for C in {2, 4}.  Three objects

@@ -49,11 +49,9 @@ struct Np2State {
     F of0[N];                // omega*img of stage 0's row
     double pf[2][4][N];      // prefetch distance 2: rows in flight two steps ahead (u, -, q0, q1)
     F pff[2][N];             // ... and omega*img
-    double kqv[K][N];        // KQV: the float64 threshold mu / ell of each stage's current row
+    double kqv[1][N];        // KQV: the float64 threshold mu / ell of stage 0's current row (the later stages: LDS rows)
     double kqn[N];
     double inc[K];           // eps instantiation (DXH_NP2_INC_REGS): this lane's running sum of squared increments per stage
-    bool kbad[K];            // KQV, wave-uniform: that row holds a threshold that is negative or NaN somewhere in the wave (the
-                             // clamp form of the shrinkage needs k >= 0; such rows take the general expression)
 };
 
 // LDS of one wave.  Rows of the levels 1 .. K - 1 go from their producer (stage l - 1) to their consumer (stage l, one step
@@ -73,7 +71,7 @@ struct Np2State {
 // K > 4 (Np2Lds::FWD; the row loop is unrolled by four, so a ring of K rows has no compile-time slot): omega*img travels down
 // the stages WITH b_1 -- one row of 64 lanes x 4 F per level -- and there is ONE slot per level: every stage's row of the
 // previous step is fetched at the start of the step, before any stage writes (4 (K - 1) registers held through the step)
-template <int K, typename F>
+template <int K, typename F, bool KQV = false>
 struct Np2Lds {
     static constexpr int PAD = 16;
     static constexpr int UHALF = PAD + kWave * 8;           // one parity of a row: pad + 64 x 8 B (the next half's pad follows)
@@ -88,7 +86,11 @@ struct Np2Lds {
     static constexpr int FSLOT = kWave * (FWD ? 4 : 2) * (int)sizeof(F);   // (float64 images: 16 B per lane, 16.6 KB per wave, 2 blocks per CU)
     static constexpr int OF_OFF = B1_OFF + (FWD ? (K - 1) : NU) * FSLOT;
     // per wave: K = 4 float 6352 + 3072 + 2048 = 11472; K = 6 float (FWD) 10576 + 5120 = 15696 (two blocks of four waves per CU)
-    static constexpr int BYTES = OF_OFF + (FWD ? 0 : 4 * FSLOT);
+    // KQV: the threshold pair of a row travels down the stages through one more row per level (64 lanes x 16 B) instead of a
+    // register delay line of K x 4 registers (three waves per SIMD without spills)
+    static constexpr int KQ_OFF = OF_OFF + (FWD ? 0 : 4 * FSLOT);
+    static constexpr int KQSLOT = kWave * 16;
+    static constexpr int BYTES = KQ_OFF + (KQV ? (K - 1) * KQSLOT : 0);
     // byte offset, within U slot 0, of element e of the wave's window (e = 2 lane + j; e in [-4, 132) stays inside the pads)
     static __device__ __forceinline__ int elem_off(int e) {
         const int par = e & 1;
@@ -150,7 +152,7 @@ struct PipeNp2 {
     static constexpr bool F32 = std::is_same<F, float>::value;
     static_assert(F32 || !KQV, "float64 images: scalar threshold only (the threshold plane keeps the generic pipeline)");
     static constexpr int PFD = KQV ? 1 : (F32 ? (K > 4 ? DXH_NP2_PFD_K6 : DXH_NP2_PFD) : DXH_F64P_PFD);   // the per-element threshold is prefetched at distance 1
-    using L = Np2Lds<K, F>;
+    using L = Np2Lds<K, F, KQV>;
     using F2 = typename Np2Vec2<F>::type;
     const F* of_p;       // omega * img: the float32 plane of a numpy2 context (FusedArgs::of32) / the float64 plane of a float64 image
     const double* u_in;
@@ -177,6 +179,7 @@ struct PipeNp2 {
     char* aCR[N];
     F* lb1;             // this lane's pair in b_1 slot 0
     F* lof;             // this lane's pair in omega*img slot 0
+    char* lkq;          // KQV: this lane's 16 B in threshold-row slot 0
     double* linc;       // eps instantiation: running sums of squared increments, [stage][lane] in LDS
 
     __device__ __forceinline__ void u_put(int slot, const double (&v)[N]) const {
@@ -295,6 +298,8 @@ struct PipeNp2 {
         // stage s + 1 waiting for them at its head
         double pnl[N], pnr[N], pcl[N], pcr[N];
         F pb1[N], pof[N];
+        double pkq[N];
+        static_assert(!KQV || DXH_NP2_PREFETCH, "the threshold rows are single-buffered: the prefetch order is what makes that safe");
         auto fetch = [&](auto sn) {
             constexpr int s1 = decltype(sn)::value;           // the stage whose operands are fetched
             constexpr int slot1 = (s1 - 1) * L::SLOTS_PER_LEVEL + (L::SLOTS_PER_LEVEL == 2 ? (PH & 1) : 0);
@@ -311,6 +316,11 @@ struct PipeNp2 {
                 f_get(lb1, slot1, pb1);
                 f_get(lof, (PH - s1) & 3, pof);
             }
+            if constexpr (KQV) {
+                const double2 t = *reinterpret_cast<const double2*>(lkq + (s1 - 1) * L::KQSLOT);
+                pkq[0] = t.x;
+                pkq[1] = t.y;
+            }
         };
         static_for<0, ACT>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
@@ -323,6 +333,12 @@ struct PipeNp2 {
             double(&um)[N] = st.U[s][cm];
             double(&uc)[N] = st.U[s][c];
             double(&up)[N] = st.U[s][cp];
+            // KQV: this stage's thresholds -- stage 0's row came from HBM, the later stages' out of the row the stage before wrote
+            double kqs[N];
+            if constexpr (KQV) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) kqs[j] = (s == 0) ? st.kqv[0][j] : pkq[j];
+            }
             F(&t0m)[N] = st.t0[s][prv];
             F(&t0c)[N] = st.t0[s][cur];
             F(&b0m)[N] = st.b0[s][prv];
@@ -402,7 +418,7 @@ struct PipeNp2 {
             F b1c[N], t1c[N];
 #pragma unroll
             for (int j = 0; j < N; ++j) {
-                const double kqj = KQV ? st.kqv[s][j] : kq;
+                const double kqj = KQV ? kqs[j] : kq;
                 F d0f, b0f, d1f, b1f;
                 split((s == 0) ? st.q0l[cur][j] : q0h[j], kqj, d0f, b0f);
                 split(q1c[j], kqj, d1f, b1f);
@@ -412,13 +428,14 @@ struct PipeNp2 {
                 b1c[j] = b1f;
             }
             if constexpr (KQV) {
-                if (st.kbad[s]) {  // a negative or NaN threshold in this row: np.maximum(|x| - k, 0) * np.sign(x) as written
+                // wave-uniform: a negative or NaN threshold in this row: np.maximum(|x| - k, 0) * np.sign(x) as written
+                if (__any(!(kqs[0] >= 0.0) || !(kqs[1] >= 0.0))) {
                     DXH_UNIFORM_BRANCH();
 #pragma unroll
                     for (int j = 0; j < N; ++j) {
                         float d0f, b0f, d1f, b1f;
-                        np2_split<false>((s == 0) ? st.q0l[cur][j] : q0h[j], st.kqv[s][j], d0f, b0f);
-                        np2_split<false>(q1c[j], st.kqv[s][j], d1f, b1f);
+                        np2_split<false>((s == 0) ? st.q0l[cur][j] : q0h[j], kqs[j], d0f, b0f);
+                        np2_split<false>(q1c[j], kqs[j], d1f, b1f);
                         t0c[j] = ell_f * (b0f - d0f);
                         t1c[j] = ell_f * (b1f - d1f);
                         b0c[j] = b0f;
@@ -540,20 +557,19 @@ struct PipeNp2 {
                 u_put(s * L::SLOTS_PER_LEVEL + (L::SLOTS_PER_LEVEL == 2 ? prv : 0), un);
                 if constexpr (L::FWD) fw_put(s, b1c, ofv);
                 else f_put(lb1, s * L::SLOTS_PER_LEVEL + (L::SLOTS_PER_LEVEL == 2 ? prv : 0), b1c);
+                if constexpr (KQV) {
+                    double2 t;
+                    t.x = kqs[0];
+                    t.y = kqs[1];
+                    *reinterpret_cast<double2*>(lkq + s * L::KQSLOT) = t;   // (stage s + 1's read of this slot was issued above)
+                }
 #pragma unroll
                 for (int j = 0; j < N; ++j) q0h[j] = q0o[j];
             }
         });
         if constexpr (KQV) {
 #pragma unroll
-            for (int s2 = K - 1; s2 >= 1; --s2)
-#pragma unroll
-                for (int j = 0; j < N; ++j) st.kqv[s2][j] = st.kqv[s2 - 1][j];
-#pragma unroll
             for (int j = 0; j < N; ++j) st.kqv[0][j] = st.kqn[j];
-#pragma unroll
-            for (int s2 = K - 1; s2 >= 1; --s2) st.kbad[s2] = st.kbad[s2 - 1];
-            st.kbad[0] = __any(!(st.kqn[0] >= 0.0) || !(st.kqn[1] >= 0.0)) != 0;
         }
         if constexpr (PFD == 2) {
 #pragma unroll
@@ -576,7 +592,7 @@ __device__ __forceinline__ void fused_np2_body(const FusedArgs<double>& a, const
     constexpr bool F32 = std::is_same<F, float>::value;
     using SG = StripGeomK<double, C, K>;
     using PipeT = PipeNp2<C, COUPLED, K, NTS, EDGE, NORM, KQV, F>;
-    using L = Np2Lds<K, F>;
+    using L = Np2Lds<K, F, KQV>;
     PipeT pp;
     pp.linc = linc_lane;
     chunk_rows(a, chunk, pp.R0, pp.R1);
@@ -588,6 +604,7 @@ __device__ __forceinline__ void fused_np2_body(const FusedArgs<double>& a, const
     pp.store_lane = lane >= SG::LH && lane < SG::LH + SG::VALID && x0 < a.L;
     pp.lb1 = reinterpret_cast<F*>(lds_wave + L::B1_OFF) + lane * (L::FWD ? 4 : N);
     pp.lof = reinterpret_cast<F*>(lds_wave + L::OF_OFF) + lane * N;
+    pp.lkq = lds_wave + L::KQ_OFF + lane * 16;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         const int64_t x = x0 + j;
@@ -650,11 +667,7 @@ __device__ __forceinline__ void fused_np2_body(const FusedArgs<double>& a, const
 #pragma unroll
         for (int j = 0; j < N; ++j) st.q0l[i][j] = st.q1l[i][j] = 0.0;
 #pragma unroll
-    for (int l = 0; l < K; ++l)
-#pragma unroll
-        for (int j = 0; j < N; ++j) st.kqv[l][j] = 0.0;   // thresholds of the not yet started stages: shrink by nothing
-#pragma unroll
-    for (int l = 0; l < K; ++l) st.kbad[l] = false;
+    for (int j = 0; j < N; ++j) st.kqv[0][j] = 0.0;   // (the not yet started stages read zeroed LDS rows: shrink by nothing)
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         st.of0[j] = F(0);
@@ -690,7 +703,6 @@ __device__ __forceinline__ void fused_np2_body(const FusedArgs<double>& a, const
             load_vec(pp.at(pp.kq_p, rm), kqm);
             load_vec(pp.at(pp.kq_p, pp.clampr(rs)), st.kqv[0]);
         }
-        if constexpr (KQV) st.kbad[0] = __any(!(st.kqv[0][0] >= 0.0) || !(st.kqv[0][1] >= 0.0)) != 0;
 #pragma unroll
         for (int j = 0; j < N; ++j) {
             F df, bf;
@@ -743,11 +755,11 @@ __device__ __forceinline__ void fused_np2_body(const FusedArgs<double>& a, const
 }
 
 template <int C, bool COUPLED, int K, bool NORM, bool KQV, bool NTS = true, typename F = float>
-__global__ void __launch_bounds__(256, (std::is_same<F, double>::value ? DXH_F64P_WAVES : (KQV ? DXH_NP2_WAVES_KQV : (K > 4 ? DXH_NP2_WAVES_K6 : DXH_NP2_WAVES))))
+__global__ void __launch_bounds__(256, (std::is_same<F, double>::value ? DXH_F64P_WAVES : (KQV ? np2_kqv_waves(C) : (K > 4 ? DXH_NP2_WAVES_K6 : DXH_NP2_WAVES))))
 k_fused_multi_np2(FusedArgs<double> a) {
     constexpr int N = 2;
     using SG = StripGeomK<double, C, K>;
-    using L = Np2Lds<K, F>;
+    using L = Np2Lds<K, F, KQV>;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
     constexpr int WPB = 4;

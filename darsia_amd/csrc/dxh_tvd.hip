@@ -551,7 +551,7 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
         } else {
             // blocks resident per CU (one wave of each per SIMD); the numpy2 pipelines have their own register budget
             const int W = c->np2_sweeps ? (c->np2 ? np2_sweep_waves(K) : 2)
-                                          : c->np2 ? (kqv_pipe ? DXH_NP2_WAVES_KQV : (K > 4 ? DXH_NP2_WAVES_K6 : DXH_NP2_WAVES)) : pipe_waves<T, K <= 4 ? K : 4, false>();
+                                          : c->np2 ? (kqv_pipe ? np2_kqv_waves(C) : (K > 4 ? DXH_NP2_WAVES_K6 : DXH_NP2_WAVES)) : pipe_waves<T, K <= 4 ? K : 4, false>();
             // issue cost of one VALU instruction per SIMD with 1 / 2 / 3 / 4 waves taking turns (tools/valubench.hip)
             static const double cpi[5] = {0.0, 6.6, 3.7, 3.5, 3.2};  // 3: fitted to chunk sweeps of this kernel (a third wave adds ~8 %)
             const int64_t cu_per_xcd = std::max(1, c->num_cu / 8);
