@@ -43,7 +43,8 @@ struct Np2SweepLds {
     static constexpr int FHALF = kWave * 2 * (int)sizeof(float);   // a row's b_0 pairs, then its b_1 pairs: 8 B per lane each
     static constexpr int FSLOT = 2 * FHALF;                        // (consecutive lanes 8 B apart: conflict-free ds_read_b64)
     static constexpr int NF = K + 1 <= 4 ? 4 : 8;                  // rows between stage 0 and the last stage, a power of two
-    static constexpr int BYTES = FIFO ? FIFO_OFF + NF * FSLOT : U_BYTES;            // K = 5: 4240 + 8192 = 12432 per wave (three blocks per CU)
+    static constexpr int INC_OFF = FIFO ? FIFO_OFF + NF * FSLOT : U_BYTES;   // eps: this lane's running sum of squared increments
+    static constexpr int BYTES = INC_OFF + kWave * 8;            // K = 5: 4240 + 8192 = 12432 per wave (three blocks per CU)
     static __device__ __forceinline__ int elem_off(int e) {
         const int par = e & 1;
         return PAD + par * UHALF + ((e - par) >> 1) * 8;
@@ -91,6 +92,9 @@ struct PipeNp2Sweeps {
     char* aCL[N];
     char* aCR[N];
     char* lfifo;   // this lane's b_0 pair in slot 0 of the (b_0, b_1) ring (its b_1 pair: FHALF further)
+    double* linc;  // eps (norm): this lane's running sum of squared increments of the iteration, in LDS (ds_add_f64)
+    bool norm;     // wave-uniform: the launch also reduces || u_new - u_old ||^2 (FusedArgs::inc_partial set)
+    bool inL[N];
 
     __device__ __forceinline__ void u_put(int slot, const double (&v)[N]) const {
 #pragma unroll
@@ -160,7 +164,13 @@ struct PipeNp2Sweeps {
         }
         // the last stage's b_1 of its row (written K - 1 steps ago) and b_0 of the row above it (K steps ago)
         F tb0m[N], tb1c[N];
-        double tq0[N], tq1[N];
+        double tq0[N], tq1[N], tu0[N];
+        if constexpr (ACT == K) {
+            if (norm) {   // the iterate this iteration started from, at the tail's row (read by stage 0 K - 1 steps ago: L2)
+                DXH_UNIFORM_BRANCH();
+                load_vec(at(u_in, clampr(r - (K - 1))), tu0);
+            }
+        }
         if constexpr (ACT == K && !L::FIFO) {
             // float64: the stored q_1 of the tail's row and q_0 of the row above it (read by stage 0 K - 1 / K steps ago: L2)
             load_vec(at(q1_in, clampr(r - (K - 1))), tq1);
@@ -343,6 +353,18 @@ struct PipeNp2Sweeps {
                 for (int j = 0; j < N; ++j) un[j] = unm[j];
             }
             if constexpr (last) {
+                if (norm) {
+                    DXH_UNIFORM_BRANCH();
+                    const bool in_chunk = p32 >= R0_32 && p32 < R1_32;   // rows of this chunk only (each element once)
+                    double t = 0.0;
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {
+                        const double dlt = un[j] - tu0[j];
+                        const double sq = (in_chunk && inL[j]) ? dlt * dlt : 0.0;
+                        t = j == 0 ? sq : t + sq;
+                    }
+                    lds_add_f64(linc, t);
+                }
                 if constexpr (!L::FIFO) {   // the head's shrinkage of these rows once more: b = q - d (np2_split_fast, float64)
 #pragma unroll
                     for (int j = 0; j < N; ++j) {
@@ -404,6 +426,8 @@ __device__ __forceinline__ void np2_sweeps_body(const FusedArgs<double>& a, cons
     if (xl > a.pitch - N) xl = a.pitch - N;
     pp.store_lane = lane >= SG::LH && lane < SG::LH + SG::VALID && x0 < a.L;
     pp.lfifo = lds_wave + L::FIFO_OFF + lane * 8;
+    pp.linc = reinterpret_cast<double*>(lds_wave + L::INC_OFF) + lane;
+    pp.norm = a.inc_partial != nullptr;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         const int64_t x = x0 + j;
@@ -413,6 +437,7 @@ __device__ __forceinline__ void np2_sweeps_body(const FusedArgs<double>& a, cons
         pp.edgeR[j] = lane_mask_bits(eR);
         pp.ch0[j] = lane_mask_bits(cc == 0);
         pp.chLast[j] = lane_mask_bits(cc == C - 1);
+        pp.inL[j] = x >= 0 && x < a.L;
         const int e = 2 * lane + j;
         pp.lw[j] = lds_wave + L::elem_off(e);
         pp.aL[j] = lds_wave + L::elem_off(eL ? e : e - C);
@@ -534,6 +559,14 @@ __device__ __forceinline__ void np2_sweeps_body(const FusedArgs<double>& a, cons
         pp.template step<1>(st, r + 1);
         pp.template step<2>(st, r + 2);
         pp.template step<3>(st, r + 3);
+    }
+    if (pp.norm) {
+        // a wave's LDS operations complete in order: the sum is final here.  Lanes outside the strip's stored part drop out
+        double inc[1][N];
+        const double v = *(volatile double*)pp.linc;
+        inc[0][0] = pp.store_lane ? v : 0.0;
+        inc[0][1] = 0.0;
+        pipe_write_partials<1, 0>(a, inc, chunk * a.nstrips + strip, lane);
     }
 }
 

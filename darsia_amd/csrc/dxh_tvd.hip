@@ -618,7 +618,7 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
     }
     if (c->np2_sweeps) {   // ONE iteration of K Jacobi sweeps per pass (dxh_np2_sweeps.h; objects np2_sw2 .. np2_sw6)
         if constexpr (std::is_same<T, double>::value && !ISO && (C == 1 || C == 3) && K >= kNp2SweepsMin && K <= kNp2SweepsMax) {
-            if (c->np2_sweeps == K && !want_inc && (c->np2 ? (c->of32_valid && (!c->het || a.kqv)) : !c->het)) {
+            if (c->np2_sweeps == K && (c->np2 ? (c->of32_valid && (!c->het || a.kqv)) : !c->het)) {
                 if (c->np2) {
                     a.of32 = (const float*)c->of32;
                     const float fd = (float)c->c_diag;
@@ -1612,12 +1612,21 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
             c->cur = out;
         } else if (sweeps_ok && !c->from_db && !c->np2_q32) {
             c->np2_sweeps = jacobi_maxiter;
-            launch_fused_multi<T>(c, in, out, false, jacobi_maxiter);
+            launch_fused_multi<T>(c, in, out, false, jacobi_maxiter, use_eps);   // (with eps: the pass also reduces the increment)
             c->np2_sweeps = 0;
             if (int rc = launched_or_fail(c, jacobi_maxiter)) return rc;
             c->np2_first = false;
             ++launches;
             c->cur = out;
+            if (use_eps) {
+                if (!c->inc_partial) { set_error("out of device memory for the increment partials"); return DXH_ENOMEM; }
+                hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->inc_partial, c->inc_nwaves, c->red_out + 8);
+                DXH_HIP(hipStreamSynchronize(c->stream));
+                rel = std::sqrt(reinterpret_cast<volatile double*>(c->red_out)[8]) / nrm_img;
+                done = it + 1;
+                if (rel < eps) { converged = 1; break; }
+                continue;
+            }
         } else if (fused3d_ok && !c->from_db) {
             launch_fused3d<T>(c, in, out, iso);
             ++launches;
