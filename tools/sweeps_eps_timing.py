@@ -1,3 +1,5 @@
+"""Developer timing: Jacobi(maxiter=3) with the stopping criterion, float32 (default flow) and float64 images: the sweeps pass that
+reduces the increment itself against three launches + a reduction per iteration (DXH_FUSED_TUNE bit 33554432)."""
 import sys; sys.path.insert(0, ".")
 import os
 import numpy as np, darsia_amd as da
