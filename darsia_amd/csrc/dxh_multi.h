@@ -72,9 +72,15 @@ constexpr int kNp2SweepsMin = 2, kNp2SweepsMax = 6;
 #define DXH_SWEEPS_4W 2   // sweep counts up to this run four waves per SIMD (three sweeps: 32 - 56 B of scratch then, 0.97 vs 0.88 ms)
 #endif
 constexpr int np2_sweep_waves(int K) { return K <= DXH_SWEEPS_4W ? 4 : (K <= 5 ? 3 : 2); }
+// ... of the plain-sweeps instantiation (float64 contexts, PLAIN): registers 128 / 168 / 256
+constexpr int np2_plain_waves(int K) { return K <= 4 ? 4 : 3; }   // (K = 4: 101 - 111 registers)
 template <int K>
 void launch_np2_sweeps(int C, bool coupled, bool kqv, bool f64, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
-#define DXH_SW_DECL(K_) template <> void launch_np2_sweeps<K_>(int C, bool coupled, bool kqv, bool f64, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
+// K plain Jacobi sweeps per pass on a float64 context (a.q0_in = the rs plane, a.u_in / a.u_out the iterate in / out)
+template <int K>
+void launch_np2_plain_sweeps(int C, bool coupled, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
+#define DXH_SW_DECL(K_) template <> void launch_np2_sweeps<K_>(int C, bool coupled, bool kqv, bool f64, const FusedArgs<double>& a, unsigned grid, hipStream_t stream); \
+    template <> void launch_np2_plain_sweeps<K_>(int C, bool coupled, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
 DXH_SW_DECL(2) DXH_SW_DECL(3) DXH_SW_DECL(4) DXH_SW_DECL(5) DXH_SW_DECL(6)
 #undef DXH_SW_DECL
 void launch_multi_kernel_np2_kqv(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);

@@ -23,6 +23,10 @@
 // F = double: float64 IMAGES (every quantity float64, the native flow of such images; scalar coefficients).  The tail then
 // re-reads the stored q_0, q_1 of its rows (L2: stage 0 read them K - 1 steps ago) and repeats the head's shrinkage instead of
 // holding b_0, b_1 in LDS -- a ring of float64 rows would leave one block per CU.
+// PLAIN (F = double): K Jacobi sweeps and nothing else -- every stage a plain sweep, rs = rhs / diag read from its plane by
+// stage 0, only the new iterate stored: the multi-sweep passes of a Jacobi solve on a float64 context (H1_regularization, the
+// `Jacobi` operator, TV loops with more than six sweeps), bit for bit k_jacobi_multi<double> (dxh_kernels.h), which shifts
+// every level by DPP pairs and selects the replicate cases per element (1.03 ms per four sweeps at 4000 x 8000 x 3).
 #pragma once
 
 #include "dxh_np2_pipe.h"
@@ -64,11 +68,12 @@ struct Np2SweepState {
     F rs[K][2][N];                // rs[s][parity of the step it is read in]: rhs / diag of stage s's row (s >= 1)
 };
 
-template <int C, bool COUPLED, int K, bool NTS, bool EDGE, bool KQV, typename F = float>
+template <int C, bool COUPLED, int K, bool NTS, bool EDGE, bool KQV, typename F = float, bool PLAIN = false>
 struct PipeNp2Sweeps {
     static constexpr int N = 2;
     static constexpr bool F32 = std::is_same<F, float>::value;
     static_assert(F32 || !KQV, "float64 images: scalar threshold");
+    static_assert(!PLAIN || !F32, "plain sweeps: float64 contexts");
     using L = Np2SweepLds<K, F>;
     using F2 = typename Np2Vec2<F>::type;
     const F* of_p;
@@ -157,26 +162,28 @@ struct PipeNp2Sweeps {
         {
             const int64_t rn = clampr(r + 1);
             load_vec(at(u_in, clampr(r + 2)), st.U[0][(PH + 2) & 3]);
-            load_of(rn, frn);
-            load_vec(at(q0_in, rn), st.q0l[prv]);
-            load_vec(at(q1_in, rn), st.q1l[prv]);
-            if constexpr (KQV) load_vec(at(kq_p, rn), st.kql[prv]);
+            load_vec(at(q0_in, rn), st.q0l[prv]);   // (PLAIN: q0_in is the rs plane)
+            if constexpr (!PLAIN) {
+                load_of(rn, frn);
+                load_vec(at(q1_in, rn), st.q1l[prv]);
+                if constexpr (KQV) load_vec(at(kq_p, rn), st.kql[prv]);
+            }
         }
         // the last stage's b_1 of its row (written K - 1 steps ago) and b_0 of the row above it (K steps ago)
         F tb0m[N], tb1c[N];
         double tq0[N], tq1[N], tu0[N];
-        if constexpr (ACT == K) {
+        if constexpr (ACT == K && !PLAIN) {
             if (norm) {   // the iterate this iteration started from, at the tail's row (read by stage 0 K - 1 steps ago: L2)
                 DXH_UNIFORM_BRANCH();
                 load_vec(at(u_in, clampr(r - (K - 1))), tu0);
             }
         }
-        if constexpr (ACT == K && !L::FIFO) {
+        if constexpr (ACT == K && !L::FIFO && !PLAIN) {
             // float64: the stored q_1 of the tail's row and q_0 of the row above it (read by stage 0 K - 1 / K steps ago: L2)
             load_vec(at(q1_in, clampr(r - (K - 1))), tq1);
             load_vec(at(q0_in, clampr(r - K)), tq0);
         }
-        if constexpr (ACT == K && L::FIFO) {
+        if constexpr (ACT == K && L::FIFO && !PLAIN) {
             const float2 vb1 = *reinterpret_cast<const float2*>(lfifo + ((PH - (K - 1)) & (L::NF - 1)) * L::FSLOT + L::FHALF);
             const float2 vb0 = *reinterpret_cast<const float2*>(lfifo + ((PH - K) & (L::NF - 1)) * L::FSLOT);
             tb1c[0] = vb1.x;
@@ -258,7 +265,10 @@ struct PipeNp2Sweeps {
                 acc[j] = a;
             }
             F rsv[N];
-            if constexpr (s == 0) {
+            if constexpr (s == 0 && PLAIN) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) rsv[j] = (F)st.q0l[cur][j];
+            } else if constexpr (s == 0) {
                 // d_j = float32(shrink(q_j)), b_j = float32(q_j - d_j), t_j = ell (b_j - d_j) in float32   (:84-89,143-146)
                 F(&t0m)[N] = st.t0[prv];
                 F(&t0c)[N] = st.t0[cur];
@@ -352,7 +362,12 @@ struct PipeNp2Sweeps {
 #pragma unroll
                 for (int j = 0; j < N; ++j) un[j] = unm[j];
             }
-            if constexpr (last) {
+            if constexpr (last && PLAIN) {
+                if (store_lane && p32 >= R0_32 && p32 < R1_32) {
+                    if constexpr (NTS) store_vec_nt(at(u_out, p), un);
+                    else store_vec(at(u_out, p), un);
+                }
+            } else if constexpr (last) {
                 if (norm) {
                     DXH_UNIFORM_BRANCH();
                     const bool in_chunk = p32 >= R0_32 && p32 < R1_32;   // rows of this chunk only (each element once)
@@ -404,17 +419,19 @@ struct PipeNp2Sweeps {
                 u_put(s, un);   // the new row for stage s + 1, which meets it at the next step
             }
         });
+        if constexpr (!PLAIN) {
 #pragma unroll
-        for (int j = 0; j < N; ++j) st.of0[j] = frn[j];
+            for (int j = 0; j < N; ++j) st.of0[j] = frn[j];
+        }
     }
 };
 
-template <int C, bool COUPLED, int K, bool NTS, bool EDGE, bool KQV, typename F>
+template <int C, bool COUPLED, int K, bool NTS, bool EDGE, bool KQV, typename F, bool PLAIN>
 __device__ __forceinline__ void np2_sweeps_body(const FusedArgs<double>& a, const int strip, const int chunk, const int lane,
                                                 char* lds_wave) {
     constexpr int N = 2;
     using SG = StripGeomK<double, C, K>;
-    using PipeT = PipeNp2Sweeps<C, COUPLED, K, NTS, EDGE, KQV, F>;
+    using PipeT = PipeNp2Sweeps<C, COUPLED, K, NTS, EDGE, KQV, F, PLAIN>;
     using L = Np2SweepLds<K, F>;
     constexpr bool F32 = std::is_same<F, float>::value;
     PipeT pp;
@@ -427,7 +444,7 @@ __device__ __forceinline__ void np2_sweeps_body(const FusedArgs<double>& a, cons
     pp.store_lane = lane >= SG::LH && lane < SG::LH + SG::VALID && x0 < a.L;
     pp.lfifo = lds_wave + L::FIFO_OFF + lane * 8;
     pp.linc = reinterpret_cast<double*>(lds_wave + L::INC_OFF) + lane;
-    pp.norm = a.inc_partial != nullptr;
+    pp.norm = !PLAIN && a.inc_partial != nullptr;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         const int64_t x = x0 + j;
@@ -504,8 +521,10 @@ __device__ __forceinline__ void np2_sweeps_body(const FusedArgs<double>& a, cons
         load_vec(pp.at(pp.u_in, pp.clampr(rs - 1)), st.U[0][3]);
         load_vec(pp.at(pp.u_in, pp.clampr(rs)), st.U[0][0]);
         load_vec(pp.at(pp.u_in, pp.clampr(rs + 1)), st.U[0][1]);
+        load_vec(pp.at(pp.q0_in, pp.clampr(rs)), st.q0l[0]);   // (PLAIN: rs of row rs)
+    }
+    if constexpr (!PLAIN) {
         pp.load_of(pp.clampr(rs), st.of0);
-        load_vec(pp.at(pp.q0_in, pp.clampr(rs)), st.q0l[0]);
         load_vec(pp.at(pp.q1_in, pp.clampr(rs)), st.q1l[0]);
         double q0v[N], kqm[N] = {0.0, 0.0};
         load_vec(pp.at(pp.q0_in, pp.clampr(rs - 1)), q0v);
@@ -560,7 +579,7 @@ __device__ __forceinline__ void np2_sweeps_body(const FusedArgs<double>& a, cons
         pp.template step<2>(st, r + 2);
         pp.template step<3>(st, r + 3);
     }
-    if (pp.norm) {
+    if constexpr (!PLAIN) if (pp.norm) {
         // a wave's LDS operations complete in order: the sum is final here.  Lanes outside the strip's stored part drop out
         double inc[1][N];
         const double v = *(volatile double*)pp.linc;
@@ -570,8 +589,8 @@ __device__ __forceinline__ void np2_sweeps_body(const FusedArgs<double>& a, cons
     }
 }
 
-template <int C, bool COUPLED, int K, bool KQV, typename F = float, bool NTS = true>
-__global__ void __launch_bounds__(256, (std::is_same<F, float>::value ? np2_sweep_waves(K) : 2)) k_sweeps_np2(FusedArgs<double> a) {
+template <int C, bool COUPLED, int K, bool KQV, typename F = float, bool PLAIN = false, bool NTS = true>
+__global__ void __launch_bounds__(256, (std::is_same<F, float>::value ? np2_sweep_waves(K) : (PLAIN ? np2_plain_waves(K) : 2))) k_sweeps_np2(FusedArgs<double> a) {
     constexpr int N = 2;
     using SG = StripGeomK<double, C, K>;
     using L = Np2SweepLds<K, F>;
@@ -588,9 +607,9 @@ __global__ void __launch_bounds__(256, (std::is_same<F, float>::value ? np2_swee
     __shared__ __attribute__((aligned(16))) char lds_all[WPB * L::BYTES];
     char* lds_wave = lds_all + (size_t)wave * L::BYTES;
     if (edge)
-        np2_sweeps_body<C, COUPLED, K, NTS, true, KQV, F>(a, strip, chunk, lane, lds_wave);
+        np2_sweeps_body<C, COUPLED, K, NTS, true, KQV, F, PLAIN>(a, strip, chunk, lane, lds_wave);
     else
-        np2_sweeps_body<C, COUPLED, K, NTS, false, KQV, F>(a, strip, chunk, lane, lds_wave);
+        np2_sweeps_body<C, COUPLED, K, NTS, false, KQV, F, PLAIN>(a, strip, chunk, lane, lds_wave);
     signal_chunk_done(a, chunk, lane);
 }
 

@@ -23,4 +23,13 @@ void launch_np2_sweeps<DXH_SWEEPS_K>(int C, bool coupled, bool kqv, bool f64, co
 #undef DXH_SW
 }
 
+template <>
+void launch_np2_plain_sweeps<DXH_SWEEPS_K>(int C, bool coupled, const FusedArgs<double>& a, unsigned grid, hipStream_t stream) {
+    constexpr int K = DXH_SWEEPS_K;
+#define DXH_PL(C_, CP_) hipLaunchKernelGGL((k_sweeps_np2<C_, CP_, K, false, double, true>), dim3(grid), dim3(256), 0, stream, a)
+    if (C == 1) { if (coupled) DXH_PL(1, true); else DXH_PL(1, false); }
+    else        { if (coupled) DXH_PL(3, true); else DXH_PL(3, false); }
+#undef DXH_PL
+}
+
 }  // namespace dxh

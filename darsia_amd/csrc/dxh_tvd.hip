@@ -122,6 +122,9 @@ struct Ctx {
     bool np2_mu_auto = false;    // ... because dxh_tvd_set_coeffs_typed formed that quotient itself from a float32 mu array
     bool ell_is_arr = false, om_is_arr = false;   // set_coeffs: ell (given, or 2 mu) / omega is an array
     int np2_sweeps = 0;          // > 0 while run_t launches the S-sweeps-per-iteration pipeline (dxh_np2_sweeps.h): S
+    bool jm_plain = false;       // ... in its PLAIN form: K Jacobi sweeps from jm_in to jm_out (rs in c->rs), nothing else
+    const void* jm_in = nullptr;
+    void* jm_out = nullptr;
     bool np2_q32 = false;        // the stored q was formed in float32 (the solver handed the float32 iterate back): Np2Coef::q32
     bool np2_adapted = false;    // dxh_tvd_adapt_ell on a numpy2 context: cp_ell / cp_kq hold the adapted float32 ell and threshold
 
@@ -550,7 +553,7 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
             nchunks = std::max<int64_t>(1, target_blocks / nbx);
         } else {
             // blocks resident per CU (one wave of each per SIMD); the numpy2 pipelines have their own register budget
-            const int W = c->np2_sweeps ? (c->np2 ? np2_sweep_waves(K) : 2)
+            const int W = c->np2_sweeps ? (c->jm_plain ? np2_plain_waves(K) : c->np2 ? np2_sweep_waves(K) : 2)
                                           : c->np2 ? (kqv_pipe ? np2_kqv_waves(C) : (K > 4 ? DXH_NP2_WAVES_K6 : DXH_NP2_WAVES)) : pipe_waves<T, K <= 4 ? K : 4, false>();
             // issue cost of one VALU instruction per SIMD with 1 / 2 / 3 / 4 waves taking turns (tools/valubench.hip)
             static const double cpi[5] = {0.0, 6.6, 3.7, 3.5, 3.2};  // 3: fitted to chunk sweeps of this kernel (a third wave adds ~8 %)
@@ -618,6 +621,14 @@ static void launch_fused_multi_t(Ctx* c, int in, int out, bool want_inc) {
     }
     if (c->np2_sweeps) {   // ONE iteration of K Jacobi sweeps per pass (dxh_np2_sweeps.h; objects np2_sw2 .. np2_sw6)
         if constexpr (std::is_same<T, double>::value && !ISO && (C == 1 || C == 3) && K >= kNp2SweepsMin && K <= kNp2SweepsMax) {
+            if (c->jm_plain && c->np2_sweeps == K) {   // K plain sweeps of a Jacobi solve: x in, rs, x out
+                a.u_in = (const T*)c->jm_in;
+                a.u_out = (T*)c->jm_out;
+                a.q0_in = (const T*)c->rs;
+                a.inc_partial = nullptr;
+                launch_np2_plain_sweeps<K>(C, COUPLED, a, grid, c->stream);
+                return;
+            }
             if (c->np2_sweeps == K && (c->np2 ? (c->of32_valid && (!c->het || a.kqv)) : !c->het)) {
                 if (c->np2) {
                     a.of32 = (const float*)c->of32;
@@ -1068,11 +1079,26 @@ static bool jacobi_vol_multi_supported(const Ctx* c) {
            c->g.n1 * c->g.n2 < (int64_t)INT32_MAX && !(c->tune & (64 | 67108864));
 }
 
+// float64 contexts, 2-D, 1 / 3 channels, scalar diag_scaled in the reciprocal's range: the LDS-row sweeps pipeline in its PLAIN
+// form (dxh_np2_sweeps.h; DXH_FUSED_TUNE bit 134217728: k_jacobi_multi<double>, A/B)
+static bool jacobi_plain_supported(const Ctx* c) {
+    auto ok = [](double d) { return std::isfinite(d) && std::fabs(d) >= 0x1p-20 && std::fabs(d) <= 0x1p+20; };
+    return c->desc.dtype == DXH_F64 && c->desc.dim == 2 && (c->g.n2 == 1 || c->g.n2 == 3) && (!c->het || c->het_cdiag) &&
+           c->g.n0 <= (int64_t)INT32_MAX - 64 && ok(c->c_dsc) && !(c->tune & (8 | 134217728));
+}
+
 // sweeps of the next pass when `left` sweeps remain (0: no multi-sweep pass for this context).  2-D: fours, 5 = 3 + 2;
 // volumes: threes, 4 = 2 + 2.  A last single sweep goes through the one-sweep kernels
 static int jacobi_group(const Ctx* c, int left) {
     if (left < 2) return 0;
-    if (c->desc.dim == 2) return (c->g.n2 == 1 || c->g.n2 == 3) && (!c->het || c->het_cdiag) && !(c->tune & 64) ? (left == 5 ? 3 : std::min(4, left)) : 0;
+    if (c->desc.dim == 2) {
+        if (!((c->g.n2 == 1 || c->g.n2 == 3) && (!c->het || c->het_cdiag) && !(c->tune & 64))) return 0;
+        if (jacobi_plain_supported(c)) {   // float64 contexts: up to five sweeps per pass, never a single sweep left over
+            const int k = std::min(5, left);
+            return left - k == 1 ? k - 1 : k;
+        }
+        return left == 5 ? 3 : std::min(4, left);
+    }
     if (!jacobi_vol_multi_supported(c)) return 0;
     if (c->het && !c->het_cdiag) return 2;   // a divisor plane: pairs
     return left == 4 ? 2 : std::min(3, left);
@@ -1133,6 +1159,19 @@ static void launch_jacobi_multi_k(Ctx* c, const void* xin, void* xout) {
 template <typename T>
 static void launch_jacobi_multi(Ctx* c, const void* xin, void* xout, int K) {
     if (c->desc.dim == 3) { launch_jacobi_vol_multi_t<T>(c, xin, xout, K); return; }
+    if constexpr (std::is_same<T, double>::value) {
+        if (jacobi_plain_supported(c)) {
+            c->np2_sweeps = K;
+            c->jm_plain = true;
+            c->jm_in = xin;
+            c->jm_out = xout;
+            launch_fused_multi<double>(c, c->cur, c->cur ^ 1, false, K);
+            c->np2_sweeps = 0;
+            c->jm_plain = false;
+            if (!c->no_kernel) return;
+            c->no_kernel = false;   // (cannot happen for K = 2 .. 5; fall through to the generic pass)
+        }
+    }
     const bool coupled = c->g.ndim == 3 && c->g.nsum_axes == 3;
 #define DXH_JM(C_, CP_)                                                        \
     switch (K) {                                                               \

@@ -224,3 +224,29 @@ def test_jacobi_takes_array_likes_and_numpy_scalar_coefficients():
     s32.update_params(mass_coeff=np.float32(1.3), diffusion_coeff=np.float32(0.4), dim=2)
     c = s32(x0, rhs)
     assert c.dtype == np.float32                # float32 scalars keep a float32 array float32 in NumPy as well
+
+
+@pytest.mark.parametrize("shape", [(61, 300), (40, 517, 3), (300, 96, 3), (30, 40, 1), (2, 2)])
+@pytest.mark.parametrize("maxiter", [2, 3, 4, 5, 6, 7, 9, 20])
+def test_float64_multi_sweep_passes_in_the_lds_row_pipeline(shape, maxiter, monkeypatch):
+    """Jacobi(maxiter > 1) on float64 operands (2-D, 1 / 3 channels): up to five sweeps per pass in the sweeps pipeline's PLAIN
+    form (dxh_np2_sweeps.h) -- against the oracle's sweeps (jacobi.py:107-114) and against k_jacobi_multi<double>
+    (DXH_FUSED_TUNE bit 134217728); H1_regularization (h1_regularization.py:73-78) on the same path."""
+    rng = np.random.default_rng(maxiter * 13 + shape[1])
+    x0, rhs = rng.random(shape), rng.random(shape)
+    want = tv.jacobi(x0, rhs, 0.7, 0.3, dim=2, maxiter=maxiter, promotion="strict")
+    for tune in (None, "134217728"):
+        monkeypatch.delenv("DXH_FUSED_TUNE", raising=False)
+        if tune:
+            monkeypatch.setenv("DXH_FUSED_TUNE", tune)
+        got = da.Jacobi(maxiter=maxiter, mass_coeff=0.7, diffusion_coeff=0.3)(x0, rhs)
+        assert got.dtype == want.dtype and np.array_equal(got, want), (tune, np.abs(got - want).max())
+    monkeypatch.delenv("DXH_FUSED_TUNE", raising=False)
+    if maxiter in (3, 9):
+        out = da.H1_regularization(x0, mu=0.4, omega=1.3, solver=da.Jacobi(maxiter=maxiter))
+        monkeypatch.setenv("DXH_FUSED_TUNE", "134217728")
+        assert np.array_equal(out, da.H1_regularization(x0, mu=0.4, omega=1.3, solver=da.Jacobi(maxiter=maxiter)))
+        monkeypatch.delenv("DXH_FUSED_TUNE", raising=False)
+        # ... and inside the TV loop (more sweeps than the one-pass-per-iteration pipeline takes: maxiter = 9)
+        ref = tv.split_bregman_tvd(x0, mu=0.1, ell=0.3, max_num_iter=3, jacobi_maxiter=maxiter)
+        assert np.array_equal(da.split_bregman_tvd(x0, mu=0.1, ell=0.3, max_num_iter=3, solver=da.Jacobi(maxiter=maxiter)), ref)
