@@ -71,6 +71,8 @@ constexpr int kNp2SweepsMin = 2, kNp2SweepsMax = 6;
 #ifndef DXH_SWEEPS_4W
 #define DXH_SWEEPS_4W 2   // sweep counts up to this run four waves per SIMD (three sweeps: 32 - 56 B of scratch then, 0.97 vs 0.88 ms)
 #endif
+// the sweeps pass reduces the stopping criterion's increment itself (all but five sweeps in the numpy2 flow: Np2SweepLds::HAS_NORM)
+constexpr bool np2_sweeps_fold_norm(int K, bool np2) { return !(np2 && K == 5); }
 constexpr int np2_sweep_waves(int K) { return K <= DXH_SWEEPS_4W ? 4 : (K <= 5 ? 3 : 2); }
 // ... of the plain-sweeps instantiation (float64 contexts, PLAIN): registers 128 / 168 / 256
 constexpr int np2_plain_waves(int K) { return K <= 4 ? 4 : 3; }   // (K = 4: 101 - 111 registers)

@@ -47,8 +47,12 @@ struct Np2SweepLds {
     static constexpr int FHALF = kWave * 2 * (int)sizeof(float);   // a row's b_0 pairs, then its b_1 pairs: 8 B per lane each
     static constexpr int FSLOT = 2 * FHALF;                        // (consecutive lanes 8 B apart: conflict-free ds_read_b64)
     static constexpr int NF = K + 1 <= 4 ? 4 : 8;                  // rows between stage 0 and the last stage, a power of two
-    static constexpr int INC_OFF = FIFO ? FIFO_OFF + NF * FSLOT : U_BYTES;   // eps: this lane's running sum of squared increments
-    static constexpr int BYTES = INC_OFF + kWave * 8;            // K = 5: 4240 + 8192 = 12432 per wave (three blocks per CU)
+    // eps: this lane's running sum of squared increments.  Not at K = 5 in float: its 168 registers and 49.7 KB of LDS per block
+    // have no room for it (36 - 80 B of scratch and 51.8 KB: +9 % per pass without the criterion) -- the host reduces the
+    // increment with a kernel of its own there (np2_sweeps_fold_norm)
+    static constexpr bool HAS_NORM = !(FIFO && K == 5);
+    static constexpr int INC_OFF = FIFO ? FIFO_OFF + NF * FSLOT : U_BYTES;
+    static constexpr int BYTES = INC_OFF + (HAS_NORM ? kWave * 8 : 0);            // K = 5: 4240 + 8192 = 12432 per wave (three blocks per CU)
     static __device__ __forceinline__ int elem_off(int e) {
         const int par = e & 1;
         return PAD + par * UHALF + ((e - par) >> 1) * 8;
@@ -172,7 +176,7 @@ struct PipeNp2Sweeps {
         // the last stage's b_1 of its row (written K - 1 steps ago) and b_0 of the row above it (K steps ago)
         F tb0m[N], tb1c[N];
         double tq0[N], tq1[N], tu0[N];
-        if constexpr (ACT == K && !PLAIN) {
+        if constexpr (ACT == K && !PLAIN && L::HAS_NORM) {
             if (norm) {   // the iterate this iteration started from, at the tail's row (read by stage 0 K - 1 steps ago: L2)
                 DXH_UNIFORM_BRANCH();
                 load_vec(at(u_in, clampr(r - (K - 1))), tu0);
@@ -368,7 +372,7 @@ struct PipeNp2Sweeps {
                     else store_vec(at(u_out, p), un);
                 }
             } else if constexpr (last) {
-                if (norm) {
+                if (L::HAS_NORM && norm) {
                     DXH_UNIFORM_BRANCH();
                     const bool in_chunk = p32 >= R0_32 && p32 < R1_32;   // rows of this chunk only (each element once)
                     double t = 0.0;
@@ -444,7 +448,7 @@ __device__ __forceinline__ void np2_sweeps_body(const FusedArgs<double>& a, cons
     pp.store_lane = lane >= SG::LH && lane < SG::LH + SG::VALID && x0 < a.L;
     pp.lfifo = lds_wave + L::FIFO_OFF + lane * 8;
     pp.linc = reinterpret_cast<double*>(lds_wave + L::INC_OFF) + lane;
-    pp.norm = !PLAIN && a.inc_partial != nullptr;
+    pp.norm = !PLAIN && L::HAS_NORM && a.inc_partial != nullptr;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         const int64_t x = x0 + j;
@@ -579,7 +583,7 @@ __device__ __forceinline__ void np2_sweeps_body(const FusedArgs<double>& a, cons
         pp.template step<2>(st, r + 2);
         pp.template step<3>(st, r + 3);
     }
-    if constexpr (!PLAIN) if (pp.norm) {
+    if constexpr (!PLAIN && L::HAS_NORM) if (pp.norm) {
         // a wave's LDS operations complete in order: the sum is final here.  Lanes outside the strip's stored part drop out
         double inc[1][N];
         const double v = *(volatile double*)pp.linc;

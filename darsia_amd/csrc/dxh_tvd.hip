@@ -1651,13 +1651,14 @@ static int run_t(Ctx* c, int n_iter, int jacobi_maxiter, double jacobi_tol, doub
             c->cur = out;
         } else if (sweeps_ok && !c->from_db && !c->np2_q32) {
             c->np2_sweeps = jacobi_maxiter;
-            launch_fused_multi<T>(c, in, out, false, jacobi_maxiter, use_eps);   // (with eps: the pass also reduces the increment)
+            const bool fold = use_eps && np2_sweeps_fold_norm(jacobi_maxiter, c->np2);   // (with eps: the pass also reduces the increment)
+            launch_fused_multi<T>(c, in, out, false, jacobi_maxiter, fold);
             c->np2_sweeps = 0;
             if (int rc = launched_or_fail(c, jacobi_maxiter)) return rc;
             c->np2_first = false;
             ++launches;
             c->cur = out;
-            if (use_eps) {
+            if (fold) {
                 if (!c->inc_partial) { set_error("out of device memory for the increment partials"); return DXH_ENOMEM; }
                 hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, c->stream, c->inc_partial, c->inc_nwaves, c->red_out + 8);
                 DXH_HIP(hipStreamSynchronize(c->stream));
