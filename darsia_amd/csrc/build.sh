@@ -39,6 +39,7 @@ run() {  # run NAME SRC [extra flags]
     names+=("${name}")
 }
 # heaviest first
+for k in 6 5 4 3 2; do for part in 0 1; do run "np2_sw${k}_${part}" dxh_np2_sweeps.hip -DDXH_SWEEPS_K=${k} -DDXH_SWEEPS_PART=${part}; done; done   # S Jacobi sweeps per iteration, one pass each
 for k in 3 4 2; do
     for cs in 0 1; do   # channel sets: {1, 3} and {2, 4}
         run "multi_f32_k${k}_c${cs}" dxh_multi.hip -DDXH_MULTI_T=float -DDXH_MULTI_K=${k} -DDXH_MULTI_CSET=${cs}
@@ -52,7 +53,6 @@ run np2_g6 dxh_multi.hip -DDXH_MULTI_T=double -DDXH_MULTI_K=6 -DDXH_MULTI_NP2=4
 run np2_s2 dxh_multi.hip -DDXH_MULTI_T=double -DDXH_MULTI_K=2 -DDXH_MULTI_NP2=5
 run np2_s3 dxh_multi.hip -DDXH_MULTI_T=double -DDXH_MULTI_K=3 -DDXH_MULTI_NP2=5
 run np2_s24 dxh_multi.hip -DDXH_MULTI_T=double -DDXH_MULTI_K=4 -DDXH_MULTI_NP2=1 -DDXH_MULTI_CSET=1
-for k in 6 5 4 3 2; do run "np2_sw${k}" dxh_np2_sweeps.hip -DDXH_SWEEPS_K=${k}; done   # S Jacobi sweeps per iteration, one pass each
 run tvd dxh_tvd.hip
 run vol_multi dxh_vol_multi.hip
 run chambolle dxh_chambolle.hip

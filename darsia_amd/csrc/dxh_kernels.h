@@ -1078,6 +1078,8 @@ struct CoefIn {
     T h2;                    // T(h^2)
     T two_dim;               // unused helper
     T diag_s, dsc_s;         // omega AND ell scalar (only mu is an array): the reference's diagonal is a Python float
+    T kq_s;                  // mu AND ell scalar (only omega is an array): the threshold mu / ell is a Python float, rounded ONCE
+                             // (float(0.1) / float(0.3) is one ulp off float(0.1 / 0.3): found by tests/fuzz/fuzz_r4.py)
     int dim;
     int has_ell;
 };
@@ -1111,7 +1113,7 @@ __device__ __forceinline__ void derive_coefs(const CoefIn<T>& in, T mu_v, T omeg
         diag = omega + lap;
         dsc = diag / ell_h2;
     }
-    kq = mu / ell;
+    kq = (!in.mu && !ell_is_arr) ? in.kq_s : mu / ell;
 }
 
 template <typename T>

@@ -77,14 +77,23 @@ constexpr int np2_sweep_waves(int K) { return K <= DXH_SWEEPS_4W ? 4 : (K <= 5 ?
 // ... of the plain-sweeps instantiation (float64 contexts, PLAIN): registers 128 / 168 / 256
 constexpr int np2_plain_waves(int K) { return K <= 4 ? 4 : 3; }   // (K = 4: 101 - 111 registers)
 template <int K>
-void launch_np2_sweeps(int C, bool coupled, bool kqv, bool f64, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
-// K plain Jacobi sweeps per pass on a float64 context (a.q0_in = the rs plane, a.u_in / a.u_out the iterate in / out)
+void launch_np2_sweeps_f32(int C, bool coupled, bool kqv, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
+template <int K>
+void launch_np2_sweeps_f64(int C, bool coupled, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
+// K plain Jacobi sweeps per pass on a float64 context (a.q0_in = the rs plane, a.u_in / a.u_out the iterate in / out; K <= 5)
 template <int K>
 void launch_np2_plain_sweeps(int C, bool coupled, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
-#define DXH_SW_DECL(K_) template <> void launch_np2_sweeps<K_>(int C, bool coupled, bool kqv, bool f64, const FusedArgs<double>& a, unsigned grid, hipStream_t stream); \
+#define DXH_SW_DECL(K_)                                                                                                                         \
+    template <> void launch_np2_sweeps_f32<K_>(int C, bool coupled, bool kqv, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);  \
+    template <> void launch_np2_sweeps_f64<K_>(int C, bool coupled, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);            \
     template <> void launch_np2_plain_sweeps<K_>(int C, bool coupled, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
 DXH_SW_DECL(2) DXH_SW_DECL(3) DXH_SW_DECL(4) DXH_SW_DECL(5) DXH_SW_DECL(6)
 #undef DXH_SW_DECL
+template <int K>
+inline void launch_np2_sweeps(int C, bool coupled, bool kqv, bool f64, const FusedArgs<double>& a, unsigned grid, hipStream_t stream) {
+    if (f64) launch_np2_sweeps_f64<K>(C, coupled, a, grid, stream);
+    else launch_np2_sweeps_f32<K>(C, coupled, kqv, a, grid, stream);
+}
 void launch_multi_kernel_np2_kqv(int C, bool coupled, bool want_inc, const FusedArgs<double>& a, unsigned grid, hipStream_t stream);
 
 }  // namespace dxh

@@ -292,6 +292,7 @@ struct MGSolver final : DeviceSolver {
         in.ell_over_h2_s = (T)(diff_s / h2);
         in.diag_s = (T)(mass_s + diff_s * 2 * L.g.dim / h2);
         in.dsc_s = (T)((mass_s + diff_s * 2 * L.g.dim / h2) / (diff_s / h2));
+        in.kq_s = T(0);   // (no threshold in a linear solve)
         in.h2 = (T)h2;
         in.two_dim = (T)(2 * L.g.dim);
         in.dim = L.g.dim;

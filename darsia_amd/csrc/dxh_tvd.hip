@@ -426,6 +426,7 @@ static CoefIn<T> make_coefin(const Ctx* c) {
         in.diag_s = (T)diag_d;
         in.dsc_s = (T)(diag_d / (c->ell_s / h2));
     }
+    in.kq_s = (T)(c->mu_s / c->ell_s);
     in.h2 = (T)h2;
     in.two_dim = (T)(2 * dim);
     in.dim = dim;
@@ -2129,6 +2130,7 @@ static int set_coeffs_t(Ctx* c, double mu, const void* mu_arr, double omega, con
         in.diag_s = (T)diag_d;
         in.dsc_s = (T)(diag_d / (ell_d / h2));
     }
+    in.kq_s = (T)(mu / ell_d);
     in.h2 = (T)h2;
     in.two_dim = (T)(2 * dim);
     in.dim = dim;

@@ -978,3 +978,24 @@ def test_array_mu_with_scalar_omega_ell_runs_the_per_element_threshold_pipeline(
     general, res_g = run_device(img, n_iter=60, eps=3e-3, isotropic=iso, **kw)
     assert res.iters_done == res_g.iters_done and 1 < res.iters_done < 60
     assert_bits(out_eps, general)
+
+
+@pytest.mark.parametrize("shape,dim", [((60, 103), 2), ((44, 103, 3), 2), ((17, 44, 103), 3)])
+@pytest.mark.parametrize("mu,ell", [(0.1, 0.3), (0.7, 0.9), (0.05, None)])
+def test_scalar_threshold_next_to_an_array_omega_is_rounded_once(shape, dim, mu, ell):
+    """float32 image, float32 array omega, scalar mu and ell: the threshold mu / ell is a Python float in the reference
+    (split_bregman_tvd.py:80-81,143), rounded to float32 ONCE where it meets the float32 array -- float32(0.1) / float32(0.3) is
+    one ulp off float32(0.1 / 0.3).  Found by tests/fuzz/fuzz_r4.py (the derived-coefficient path divided the rounded scalars);
+    both the native flow and the default call (which takes the native flow for float32 coefficient arrays) against the oracle."""
+    rng = np.random.default_rng(5)
+    img = rng.random(shape).astype(np.float32)
+    om = (0.5 + rng.random(shape)).astype(np.float32)
+    kw = dict(mu=mu, omega=om, dim=dim, max_num_iter=4)
+    if ell is not None:
+        kw["ell"] = ell
+    ref = O.split_bregman_tvd(img, promotion="strict", **kw)
+    assert np.array_equal(O.split_bregman_tvd(img, promotion="numpy2", **kw), ref)   # float32 arrays only: one flow
+    assert_bits(da.split_bregman_tvd(img, promotion="native", **kw), ref)
+    assert_bits(da.split_bregman_tvd(img, **kw), ref)
+    assert_bits(da.split_bregman_tvd(img, solver=da.Jacobi(maxiter=3), **kw),
+                O.split_bregman_tvd(img, jacobi_maxiter=3, promotion="strict", **kw))
