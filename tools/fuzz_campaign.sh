@@ -12,6 +12,7 @@ run tests/fuzz/fuzz_others.py $((S+4)) 400
 run tests/fuzz/fuzz3.py $((S+5)) 400
 run tests/fuzz/fuzz_special.py $((S+6)) 300
 run tests/fuzz/fuzz_r4.py $((S+7)) 1500
+run tests/fuzz/combos_r4.py
 run tools/fuzz_slabs.py
 run tools/fuzz_periodic_rccl.py
 run tools/fuzz_banded.py
