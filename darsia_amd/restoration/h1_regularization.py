@@ -55,11 +55,16 @@ def _h1_array(img: np.ndarray, mu: float, omega: float, dim: int, solver: Solver
     if img.dtype.kind != "f":
         raise TypeError("H1_regularization needs a float32/float64 image")
     solver.update_params(mass_coeff=omega, diffusion_coeff=mu, dim=dim)
+    arrays = any(isinstance(c, DeviceArray) or np.ndim(c) != 0 for c in (mu, omega))
     if isinstance(img, DeviceArray):
+        if arrays:
+            raise NotImplementedError("device-resident H1_regularization: scalar mu and omega (array-valued coefficients: pass a "
+                                      "host image, or call the solver on device arrays yourself)")
         return _h1_device(img, mu, omega, dim, solver, promotion)
-    if not isinstance(solver, Jacobi):
-        # MG / CG objects (device solvers themselves): the reference's generic flow, channel by channel
-        # (h1_regularization.py:54-70)
+    if not isinstance(solver, Jacobi) or arrays:
+        # MG / CG objects (device solvers themselves), and Jacobi with array-valued mu / omega (the reference's own volume
+        # workload: examples/paper/pet_simulations_comparison_block_b.py:680-686 passes omega per voxel): the reference's
+        # generic flow, channel by channel (h1_regularization.py:48-76) -- the solver object does the work on the device
         if not callable(solver):
             raise TypeError("solver must be a darsia_amd Solver object")
         if img.ndim != dim:
@@ -69,7 +74,9 @@ def _h1_array(img: np.ndarray, mu: float, omega: float, dim: int, solver: Solver
                 plane = np.ascontiguousarray(moved[idx])
                 res[idx] = solver(plane, omega * plane)
             return np.ascontiguousarray(np.moveaxis(res, np.arange(-dim, 0).tolist(), np.arange(dim).tolist()))
-        return solver(img, omega * img)
+        out = solver(img, omega * img)
+        # convert_dtype(out_img, img_dtype) (h1_regularization.py:76): Jacobi hands a float64 array back for float32 operands
+        return out if out.dtype == img.dtype else out.astype(img.dtype)
     code = _lib.dtype_code(img.dtype)
     _lib.require_gpu()
     src = np.ascontiguousarray(img)

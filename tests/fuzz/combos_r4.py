@@ -39,4 +39,33 @@ for shape, dim in (((37, 70), 2), ((23, 41, 3), 2), ((9, 21, 40), 3)):
                 print("MISMATCH", shape, "dim", dim, np.dtype(img_dt).name, "arrays", np.dtype(arr_dt).name, promo, "mu", mk, "omega", ok, "ell", ek, "S", S,
                       out.dtype, ref.dtype, "n", int(np.count_nonzero(out != ref)), "max", float(np.abs(out.astype(np.float64) - ref).max()), flush=True)
 print(f"{n} combinations, {bad} mismatches")
-sys.exit(1 if bad else 0)
+
+# ---- the Jacobi operator and H1_regularization: scalar / array mass and diffusion coefficients, both float types, dim 2 / 3 ----
+bad2 = n2 = 0
+for shape, dim in (((37, 70), 2), ((9, 21, 40), 3)):
+    base, r0 = rng.random(shape), rng.random(shape)
+    arrs = {k: 0.2 + 0.8 * rng.random(shape) for k in ("m", "d")}
+    for dt in (np.float32, np.float64):
+        x0, rhs = base.astype(dt), r0.astype(dt)
+        for mk, dk, m in itertools.product(("s", "a"), ("s", "a"), (1, 3, 7)):
+            mass = 0.7 if mk == "s" else (0.7 * arrs["m"]).astype(dt)
+            diff = 0.3 if dk == "s" else (0.3 * arrs["d"]).astype(dt)
+            for promo in (("strict", "numpy2") if dt == np.float32 else ("strict",)):
+                want = O.jacobi(x0, rhs, mass, diff, dim=dim, maxiter=m, promotion=promo)
+                if dt == np.float32 and promo == "strict":
+                    continue   # the operator follows the NumPy of the process (the reference's own behaviour): numpy2 here
+                got = da.Jacobi(maxiter=m, dim=dim, mass_coeff=mass, diffusion_coeff=diff)(x0, rhs)
+                n2 += 1
+                if got.dtype != want.dtype or not np.array_equal(got, want):
+                    bad2 += 1
+                    print("MISMATCH Jacobi", shape, dim, np.dtype(dt).name, "mass", mk, "diffusion", dk, "m", m, got.dtype, want.dtype,
+                          int(np.count_nonzero(got != want)), flush=True)
+            if mk == "s":   # H1_regularization takes a scalar or array mu (diffusion) and omega (mass)
+                want = O.h1_regularization(x0, diff, mass, dim=dim, jacobi_maxiter=m, promotion="numpy2" if dt == np.float32 else "strict")
+                got = da.H1_regularization(x0, mu=diff, omega=mass, dim=dim, solver=da.Jacobi(maxiter=m))
+                n2 += 1
+                if got.dtype != want.dtype or not np.array_equal(got, want):
+                    bad2 += 1
+                    print("MISMATCH H1", shape, dim, np.dtype(dt).name, "mu", dk, "m", m, got.dtype, want.dtype, int(np.count_nonzero(got != want)), flush=True)
+print(f"{n2} solver combinations, {bad2} mismatches")
+sys.exit(1 if (bad or bad2) else 0)

@@ -250,3 +250,22 @@ def test_float64_multi_sweep_passes_in_the_lds_row_pipeline(shape, maxiter, monk
         # ... and inside the TV loop (more sweeps than the one-pass-per-iteration pipeline takes: maxiter = 9)
         ref = tv.split_bregman_tvd(x0, mu=0.1, ell=0.3, max_num_iter=3, jacobi_maxiter=maxiter)
         assert np.array_equal(da.split_bregman_tvd(x0, mu=0.1, ell=0.3, max_num_iter=3, solver=da.Jacobi(maxiter=maxiter)), ref)
+
+
+@pytest.mark.parametrize("shape,dim", [((37, 70), 2), ((9, 21, 40), 3)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("which", ["omega", "mu", "both"])
+def test_h1_regularization_with_array_valued_coefficients(shape, dim, dtype, which):
+    """The reference's volume workload passes omega per voxel (examples/paper/pet_simulations_comparison_block_b.py:680-686);
+    h1_regularization.py:48-76 hands the arrays to the solver as they are.  Until round 4 the Jacobi branch here took
+    float(omega) / float(mu) (TypeError for arrays) -- found by tests/fuzz/combos_r4.py."""
+    rng = np.random.default_rng(21)
+    img = rng.random(shape).astype(dtype)
+    om = (0.7 * (0.2 + 0.8 * rng.random(shape))).astype(dtype) if which in ("omega", "both") else 0.7
+    mu = (0.3 * (0.2 + 0.8 * rng.random(shape))).astype(dtype) if which in ("mu", "both") else 0.3
+    for m in (1, 4):
+        want = tv.h1_regularization(img, mu, om, dim=dim, jacobi_maxiter=m, promotion="numpy2" if dtype == np.float32 else "strict")
+        got = da.H1_regularization(img, mu=mu, omega=om, dim=dim, solver=da.Jacobi(maxiter=m))
+        assert got.dtype == want.dtype and np.array_equal(got, want)
+    with pytest.raises(NotImplementedError):
+        da.H1_regularization(da.DeviceArray.from_host(img), mu=mu, omega=om, dim=dim)
