@@ -108,8 +108,9 @@ def _h1_array(img: np.ndarray, mu: float, omega: float, dim: int, solver: Solver
         _lib.default_device(), code, ndim, dim, nsum, n0, n1, n2, _lib.ptr(src), _lib.ptr(rhs), _lib.ptr(out),
         float(omega), None, float(mu), None, 1.0, int(solver.maxiter), -1.0 if solver.tol is None else float(solver.tol),
         C.byref(done)))
-    if getattr(solver, "verbose", False):   # (what Jacobi.__call__ prints; the reference prints one line per sweep, jacobi.py:115,128)
-        print(f"Jacobi: {done.value} of {solver.maxiter} sweeps completed.")
+    if getattr(solver, "verbose", False):   # (what Jacobi.__call__ prints: the reference's line per sweep, jacobi.py:115,128)
+        from ..utils.linear_solvers.jacobi import _verbose_lines
+        _verbose_lines(done.value, solver.maxiter, solver.tol)
     return out
 
 

@@ -46,6 +46,17 @@ def float32_flow(promotion, *coefficients) -> str:
     return promotion
 
 
+
+def _verbose_lines(done: int, maxiter: int, tol) -> None:
+    """What the reference prints (jacobi.py:115,127-131): one line per sweep.  Without a tolerance the lines carry no numbers and
+    are reproduced as they are; with one the reference also prints each sweep's increment, which stays on the device here -- a
+    summary line instead."""
+    if tol is None:
+        for i in range(done):
+            print(f"Jacobi iteration {i} of {maxiter} completed.")
+    else:
+        print(f"Jacobi: {done} of {maxiter} sweeps completed.")
+
 class Jacobi(Solver):
     def __call__(self, x0: np.ndarray, rhs: np.ndarray, h: float = 1.0, promotion=None) -> np.ndarray:
         if self.mass_coeff is None or self.diffusion_coeff is None:
@@ -85,7 +96,7 @@ class Jacobi(Solver):
             _lib.ptr(src), _lib.ptr(rhs), _lib.ptr(out), m_s, _lib.ptr(m_a), k_s, _lib.ptr(k_a), float(h),
             int(self.maxiter), tol, C.byref(done)))
         if self.verbose:
-            print(f"Jacobi: {done.value} of {self.maxiter} sweeps completed.")
+            _verbose_lines(done.value, self.maxiter, self.tol)
         return out
 
     def _call_numpy2(self, x0, rhs, h: float, out_dtype=np.float64, nsum=_lib.NSUM_ALL_AXES):
@@ -107,7 +118,7 @@ class Jacobi(Solver):
             _lib.ptr(out), _lib.dtype_code(out_dtype), float(self.mass_coeff), float(self.diffusion_coeff), float(h),
             int(self.maxiter), -1.0 if self.tol is None else float(self.tol), C.byref(done)))
         if self.verbose:
-            print(f"Jacobi: {done.value} of {self.maxiter} sweeps completed.")
+            _verbose_lines(done.value, self.maxiter, self.tol)
         if done.value == 0 and out_dtype != np.float32:
             # no sweep was accepted (a tolerance met by the very first one, jacobi.py:123-126): the reference returns x0
             # itself, a float32 array
